@@ -1,0 +1,224 @@
+/*
+ * syldet.h -- C ABI of libsyldet, the MI355X (gfx950) batched syllable-detection engine.
+ *
+ * This is the drop-in boundary for ONE path of gardner-lab/syllable-detector-swift:
+ *   CircularShortTimeFourierTransform.extractPower  -> band slice -> sliding timeRange window
+ *   -> NeuralNet.apply -> threshold,   as driven by SyllableDetector.processNewValue.
+ *
+ * The reference has no FFI for this path (the arithmetic is inline Swift calling Apple
+ * Accelerate); its only C boundary is Common/Common-Bridging-Header.h:5, which exposes
+ * TPCircularBuffer.h to Swift.  libsyldet is bound the same way (one more #include in
+ * that bridging header), and every entry point below names the
+ * reference interface (file:line, relative to the reference root) it stands in for.
+ *
+ * Conventions
+ *   - plain C types only; the library copies every configuration array at create time;
+ *     callers own all input/output buffers; the library owns its device memory;
+ *   - return value: SYLDET_OK (0) or a negative syldet_status_t.  Where the reference
+ *     calls fatalError (ring overflow, shape mismatch, bad FFT size) or throws
+ *     ParseError, this ABI returns a status instead of aborting the host; data
+ *     availability is reported as 1/0 like processNewValue's Bool;
+ *   - `*_device` entry points take device pointers and a hipStream_t (passed as void*)
+ *     and are asynchronous on that stream; the others take host pointers and block;
+ *   - channels are independent detectors (Processor.swift:57-59: one SyllableDetector
+ *     per channel; main.swift:86-89: one per track); batch layouts are channel-major;
+ *   - threading: one producer (append) + one consumer (process/read) per channel, as
+ *     TPCircularBuffer.h:14 guarantees in the reference; run* is not re-entrant on one
+ *     handle; distinct handles are independent.
+ *   - there is NO CPU fallback: without a gfx950 device create fails with
+ *     SYLDET_ERR_NO_DEVICE.
+ */
+#ifndef SYLDET_H
+#define SYLDET_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SYLDET_ABI_VERSION 1
+
+typedef enum {
+    SYLDET_OK = 0,
+    SYLDET_ERR_INVALID_ARGUMENT   = -1,  /* NULL pointer, negative size, bad enum                        */
+    SYLDET_ERR_FFT_SIZE           = -2,  /* CircularShortTimeFourierTransform.swift:82-88 fatalError     */
+    SYLDET_ERR_OVERLAP            = -3,  /* CircularShortTimeFourierTransform.swift:76-78 fatalError     */
+    SYLDET_ERR_FREQ_RANGE         = -4,  /* SyllableDetector.swift:46-48 fatalError                      */
+    SYLDET_ERR_INPUT_MISMATCH     = -5,  /* SyllableDetector.swift:52-55 fatalError                      */
+    SYLDET_ERR_THRESHOLD_MISMATCH = -6,  /* SyllableDetector.swift:58-60 fatalError                      */
+    SYLDET_ERR_LAYER_SHAPE        = -7,  /* NeuralNet.swift:244-254, :341-349 fatalError                 */
+    SYLDET_ERR_BUFFER_FULL        = -8,  /* CircularShortTimeFourierTransform.swift:199 "Insufficient space on buffer." */
+    SYLDET_ERR_NO_DEVICE          = -9,  /* no gfx950 device / HIP runtime failure at create             */
+    SYLDET_ERR_DEVICE             = -10, /* HIP error during a call (message via syldet_last_error)      */
+    SYLDET_ERR_OUT_OF_MEMORY      = -11,
+    SYLDET_ERR_PARSE_OPEN         = -20, /* ParseError.unableToOpenPath, SyllableDetectorConfig.swift:51 */
+    SYLDET_ERR_PARSE_MISSING      = -21, /* ParseError.missingValue     :52                              */
+    SYLDET_ERR_PARSE_INVALID      = -22, /* ParseError.invalidValue     :53                              */
+    SYLDET_ERR_PARSE_LENGTH       = -23, /* ParseError.mismatchedLength :54                              */
+    SYLDET_ERR_UNSUPPORTED        = -30
+} syldet_status_t;
+
+/* WindowType, CircularShortTimeFourierTransform.swift:12-29.  SyllableDetector always
+ * selects hamming (SyllableDetector.swift:43); the others are the STFT class's options. */
+typedef enum { SYLDET_WINDOW_NONE = 0, SYLDET_WINDOW_HAMMING = 1, SYLDET_WINDOW_HANNING = 2,
+               SYLDET_WINDOW_BLACKMAN = 3 } syldet_window_t;
+/* SyllableDetectorConfig.Scaling, SyllableDetectorConfig.swift:13-30 */
+typedef enum { SYLDET_SCALING_LINEAR = 0, SYLDET_SCALING_LOG = 1, SYLDET_SCALING_DB = 2 } syldet_scaling_t;
+/* extractPower (|X|, what the detector uses) vs extractMagnitude (|X|^2),
+ * CircularShortTimeFourierTransform.swift:280 / :221 (the names are as in the reference) */
+typedef enum { SYLDET_SPECTRUM_POWER = 0, SYLDET_SPECTRUM_MAGNITUDE = 1 } syldet_spectrum_t;
+/* processing functions accepted by SyllableDetectorConfig.swift:133-151 (inputs) and
+ * :158-167 (outputs: mapminmax, mapstd only)                                            */
+typedef enum { SYLDET_FN_L2NORMALIZE = 0, SYLDET_FN_NORMALIZE = 1, SYLDET_FN_NORMALIZESTD = 2,
+               SYLDET_FN_MAPMINMAX = 3, SYLDET_FN_MAPSTD = 4 } syldet_fn_kind_t;
+/* transfer functions, SyllableDetectorConfig.swift:250-256 / NeuralNet.swift:185-228 */
+typedef enum { SYLDET_TF_TANSIG = 0, SYLDET_TF_LOGSIG = 1, SYLDET_TF_PURELIN = 2,
+               SYLDET_TF_SATLIN = 3 } syldet_transfer_t;
+/* which outputs raise the detection flag: output 0 (SyllableDetector.lastDetected,
+ * SyllableDetector.swift:27-31) or any output (CLI, TrackDetector.swift:72-77)          */
+typedef enum { SYLDET_RULE_FIRST = 0, SYLDET_RULE_ANY = 1 } syldet_rule_t;
+
+/* MapMinMax / MapStd parameters, NeuralNet.swift:111-182 (count = vector length; unused
+ * and 0 for the parameter-free functions)                                               */
+typedef struct {
+    int32_t kind;            /* syldet_fn_kind_t */
+    int32_t count;
+    const float *x_offsets;
+    const float *gains;
+    float y;                 /* yMin (mapminmax) / yMean (mapstd) */
+} syldet_fn_t;
+
+/* NeuralNetLayer, NeuralNet.swift:329-378.  weights row-major [outputs][inputs]
+ * (vDSP_mmul M=outputs, P=inputs at :368; convert_to_text.m:202).                        */
+typedef struct {
+    int32_t inputs, outputs;
+    int32_t transfer;        /* syldet_transfer_t */
+    const float *weights;
+    const float *biases;
+} syldet_layer_t;
+
+/* SyllableDetectorConfig, SyllableDetectorConfig.swift:11-45 (+ the STFT options the
+ * detector fixes).  All arrays are copied by syldet_create.                              */
+typedef struct {
+    double sampling_rate;            /* samplingRate  */
+    int32_t fourier_length;          /* fourierLength */
+    int32_t window_length;           /* windowLength  */
+    int32_t window_overlap;          /* windowOverlap; negative = gap between windows */
+    double freq_lo, freq_hi;         /* freqRange     */
+    int32_t time_range;              /* timeRange     */
+    int32_t scaling;                 /* syldet_scaling_t  */
+    int32_t window;                  /* syldet_window_t; the detector uses SYLDET_WINDOW_HAMMING */
+    int32_t spectrum;                /* syldet_spectrum_t; the detector uses SYLDET_SPECTRUM_POWER */
+    int32_t rule;                    /* syldet_rule_t     */
+    int32_t n_input_fns;
+    const syldet_fn_t *input_fns;    /* net.inputProcessing, applied in order */
+    int32_t n_layers;
+    const syldet_layer_t *layers;    /* net.layers */
+    int32_t n_output_fns;
+    const syldet_fn_t *output_fns;   /* net.outputProcessing, applied in order as reverse maps */
+    int32_t n_thresholds;
+    const double *thresholds;        /* thresholds (Double) */
+} syldet_config_t;
+
+/* Derived geometry (what SyllableDetector.init computes, SyllableDetector.swift:42-60). */
+typedef struct {
+    int32_t gap, overlap, hop;       /* CircularShortTimeFourierTransform.swift:66-73; hop = gap + W - overlap */
+    int32_t f0, f1;                  /* frequencyIndexRange, :166-191 */
+    int32_t bins;                    /* F = f1 - f0 */
+    int32_t inputs;                  /* F * timeRange == net.inputs */
+    int32_t outputs;                 /* net.outputs */
+    int32_t first_index;             /* sample number of evaluation 0, TrackDetector.swift:39-42 */
+    int32_t engine;                  /* which kernel family create selected (syldet_engine_t) */
+} syldet_geometry_t;
+
+typedef enum { SYLDET_ENGINE_AUTO = 0, SYLDET_ENGINE_GENERIC = 1, SYLDET_ENGINE_FUSED = 2 } syldet_engine_t;
+
+typedef struct syldet syldet_t;
+
+/* ---- library ---- */
+int         syldet_abi_version(void);
+const char *syldet_strerror(int status);
+/* message of the last failing call on this thread (HIP error text, parse key, ...) */
+const char *syldet_last_error(void);
+
+/* ---- configuration file ----
+ * SyllableDetectorConfig.init(fromTextFile:), SyllableDetectorConfig.swift:170-277.
+ * On success *out owns every array it points to; free with syldet_config_free.
+ * window/spectrum/rule are set to the detector's fixed choices (hamming, power, first). */
+int  syldet_config_load_text(const char *path, syldet_config_t **out);
+void syldet_config_free(syldet_config_t *cfg);
+/* the same validation SyllableDetector.init performs, without touching a device */
+int  syldet_config_geometry(const syldet_config_t *cfg, syldet_geometry_t *out);
+/* CircularShortTimeFourierTransform.frequencyIndexRange, :166-191 (1 = range found, 0 = nil) */
+int  syldet_frequency_index_range(int32_t fourier_length, double sampling_rate, double lo, double hi,
+                                  int32_t *f0, int32_t *f1);
+/* WindowType.createWindow, :19-28 */
+int  syldet_make_window(int32_t window, int32_t length, float *out);
+
+/* ---- detector bank ----
+ * SyllableDetector.init(config:), SyllableDetector.swift:37-74, for n_channels
+ * independent channels on HIP device `device`.  engine: SYLDET_ENGINE_AUTO unless a
+ * test wants a specific kernel family.                                                  */
+int syldet_create(const syldet_config_t *cfg, int32_t n_channels, int32_t device, int32_t engine,
+                  syldet_t **out);
+int syldet_destroy(syldet_t *h);
+int syldet_get_geometry(const syldet_t *h, syldet_geometry_t *out);
+int32_t syldet_channels(const syldet_t *h);
+
+/* frames J = floor((S - gap - W)/hop) + 1 and evaluations E = J - T + 1 that S samples
+ * per channel yield (extractPower's availability rule :286-288 + consume :299-302;
+ * processNewValue's :164-178)                                                            */
+int64_t syldet_count_frames(const syldet_t *h, int64_t n_samples);
+int64_t syldet_count_evals(const syldet_t *h, int64_t n_samples);
+
+/* ---- batch: the whole of `while detector.processNewValue() {...}` for every channel ----
+ * (TrackDetector.swift:62-77 / Processor.swift:136-141).
+ * samples  [C][channel_stride] fp32, the first n_samples of each row are used;
+ * outputs  [C][E][outputs]    fp32  = lastOutputs after each evaluation;
+ * flags    [C][E]             u8    = Double(out) >= threshold under cfg.rule;
+ * Either output pointer may be NULL.                                                     */
+int syldet_run_device(syldet_t *h, const float *d_samples, int64_t n_samples, int64_t channel_stride,
+                      float *d_outputs, uint8_t *d_flags, void *hip_stream);
+int syldet_run(syldet_t *h, const float *samples, int64_t n_samples, int64_t channel_stride,
+               float *outputs, uint8_t *flags);
+
+/* the spectrogram columns the detector feeds its network, [C][J][bins] fp32
+ * (processFourierData, SyllableDetector.swift:134-151; linear values, before scaling)    */
+int syldet_spectrogram_device(syldet_t *h, const float *d_samples, int64_t n_samples, int64_t channel_stride,
+                              float *d_columns, void *hip_stream);
+int syldet_spectrogram(syldet_t *h, const float *samples, int64_t n_samples, int64_t channel_stride,
+                       float *columns);
+
+/* detection sample numbers with debounce, TrackDetector.swift:39-43,:65-100:
+ * idx_e = first_index + e*hop; emit iff flag && debounce_until < idx_e, then
+ * debounce_until = idx_e + Int(debounce_seconds * samplingRate).
+ * indices [C][capacity] int64 (first counts[c] valid), counts [C] int64 (may exceed
+ * capacity: the number that would have been written).                                    */
+int syldet_detections_device(syldet_t *h, const uint8_t *d_flags, int64_t n_evals, double debounce_seconds,
+                             int64_t *d_indices, int64_t capacity, int64_t *d_counts, void *hip_stream);
+int syldet_detections(syldet_t *h, const uint8_t *flags, int64_t n_evals, double debounce_seconds,
+                      int64_t *indices, int64_t capacity, int64_t *counts);
+
+/* ---- streaming: the reference's per-detector API, one call per channel ----
+ * appendAudioData(_:withSamples:), SyllableDetector.swift:129-132                         */
+int syldet_append(syldet_t *h, int32_t channel, const float *data, int64_t n_samples);
+/* appendInterleavedData(_:withSamples:fromChannel:ofTotalChannels:),
+ * CircularShortTimeFourierTransform.swift:203-217: de-interleaves frame-major audio into
+ * every channel of the bank (total_channels == syldet_channels(h))                       */
+int syldet_append_interleaved(syldet_t *h, const float *data, int64_t n_frames, int32_t total_channels);
+/* processNewValue() -> Bool, SyllableDetector.swift:153-217: 1 = a new evaluation is in
+ * last_outputs, 0 = not enough data yet                                                  */
+int syldet_process_new_value(syldet_t *h, int32_t channel);
+/* lastOutputs, :26 (zeros before the first evaluation, :70)                              */
+int syldet_last_outputs(const syldet_t *h, int32_t channel, float *out);
+/* lastDetected, :27-31                                                                   */
+int syldet_last_detected(const syldet_t *h, int32_t channel);
+/* seenSyllable(), :220-230: drains every pending evaluation, 1 if any was detected       */
+int syldet_seen_syllable(syldet_t *h, int32_t channel);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SYLDET_H */

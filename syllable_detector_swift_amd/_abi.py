@@ -1,0 +1,137 @@
+"""ctypes declaration of the C ABI in include/syldet.h.
+
+The product path is libsyldet.so (hand-written HIP for gfx950).  There is no Python or
+CPU fallback: if the library is missing this module raises at import time.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsyldet.so")
+
+ABI_VERSION = 1
+
+# status codes (syldet_status_t)
+OK = 0
+ERR_INVALID_ARGUMENT = -1
+ERR_FFT_SIZE = -2
+ERR_OVERLAP = -3
+ERR_FREQ_RANGE = -4
+ERR_INPUT_MISMATCH = -5
+ERR_THRESHOLD_MISMATCH = -6
+ERR_LAYER_SHAPE = -7
+ERR_BUFFER_FULL = -8
+ERR_NO_DEVICE = -9
+ERR_DEVICE = -10
+ERR_OUT_OF_MEMORY = -11
+ERR_PARSE_OPEN = -20
+ERR_PARSE_MISSING = -21
+ERR_PARSE_INVALID = -22
+ERR_PARSE_LENGTH = -23
+ERR_UNSUPPORTED = -30
+
+WINDOW_NONE, WINDOW_HAMMING, WINDOW_HANNING, WINDOW_BLACKMAN = 0, 1, 2, 3
+SCALING_LINEAR, SCALING_LOG, SCALING_DB = 0, 1, 2
+SPECTRUM_POWER, SPECTRUM_MAGNITUDE = 0, 1
+FN_L2NORMALIZE, FN_NORMALIZE, FN_NORMALIZESTD, FN_MAPMINMAX, FN_MAPSTD = 0, 1, 2, 3, 4
+TF_TANSIG, TF_LOGSIG, TF_PURELIN, TF_SATLIN = 0, 1, 2, 3
+RULE_FIRST, RULE_ANY = 0, 1
+ENGINE_AUTO, ENGINE_GENERIC, ENGINE_FUSED = 0, 1, 2
+
+c_float_p = C.POINTER(C.c_float)
+c_double_p = C.POINTER(C.c_double)
+c_uint8_p = C.POINTER(C.c_uint8)
+c_int64_p = C.POINTER(C.c_int64)
+c_int32_p = C.POINTER(C.c_int32)
+
+
+class Fn(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("count", C.c_int32), ("x_offsets", c_float_p),
+                ("gains", c_float_p), ("y", C.c_float)]
+
+
+class Layer(C.Structure):
+    _fields_ = [("inputs", C.c_int32), ("outputs", C.c_int32), ("transfer", C.c_int32),
+                ("weights", c_float_p), ("biases", c_float_p)]
+
+
+class Config(C.Structure):
+    _fields_ = [("sampling_rate", C.c_double),
+                ("fourier_length", C.c_int32), ("window_length", C.c_int32), ("window_overlap", C.c_int32),
+                ("freq_lo", C.c_double), ("freq_hi", C.c_double),
+                ("time_range", C.c_int32), ("scaling", C.c_int32), ("window", C.c_int32),
+                ("spectrum", C.c_int32), ("rule", C.c_int32),
+                ("n_input_fns", C.c_int32), ("input_fns", C.POINTER(Fn)),
+                ("n_layers", C.c_int32), ("layers", C.POINTER(Layer)),
+                ("n_output_fns", C.c_int32), ("output_fns", C.POINTER(Fn)),
+                ("n_thresholds", C.c_int32), ("thresholds", c_double_p)]
+
+
+class Geometry(C.Structure):
+    _fields_ = [("gap", C.c_int32), ("overlap", C.c_int32), ("hop", C.c_int32),
+                ("f0", C.c_int32), ("f1", C.c_int32), ("bins", C.c_int32),
+                ("inputs", C.c_int32), ("outputs", C.c_int32), ("first_index", C.c_int32),
+                ("engine", C.c_int32)]
+
+
+Handle = C.c_void_p
+Config_p = C.POINTER(Config)
+
+# every symbol include/syldet.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "syldet_abi_version": (C.c_int, []),
+    "syldet_strerror": (C.c_char_p, [C.c_int]),
+    "syldet_last_error": (C.c_char_p, []),
+    "syldet_config_load_text": (C.c_int, [C.c_char_p, C.POINTER(Config_p)]),
+    "syldet_config_free": (None, [Config_p]),
+    "syldet_config_geometry": (C.c_int, [Config_p, C.POINTER(Geometry)]),
+    "syldet_frequency_index_range": (C.c_int, [C.c_int32, C.c_double, C.c_double, C.c_double, c_int32_p, c_int32_p]),
+    "syldet_make_window": (C.c_int, [C.c_int32, C.c_int32, c_float_p]),
+    "syldet_create": (C.c_int, [Config_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Handle)]),
+    "syldet_destroy": (C.c_int, [Handle]),
+    "syldet_get_geometry": (C.c_int, [Handle, C.POINTER(Geometry)]),
+    "syldet_channels": (C.c_int32, [Handle]),
+    "syldet_count_frames": (C.c_int64, [Handle, C.c_int64]),
+    "syldet_count_evals": (C.c_int64, [Handle, C.c_int64]),
+    "syldet_run_device": (C.c_int, [Handle, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "syldet_run": (C.c_int, [Handle, c_float_p, C.c_int64, C.c_int64, c_float_p, c_uint8_p]),
+    "syldet_spectrogram_device": (C.c_int, [Handle, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
+    "syldet_spectrogram": (C.c_int, [Handle, c_float_p, C.c_int64, C.c_int64, c_float_p]),
+    "syldet_detections_device": (C.c_int, [Handle, C.c_void_p, C.c_int64, C.c_double, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "syldet_detections": (C.c_int, [Handle, c_uint8_p, C.c_int64, C.c_double, c_int64_p, C.c_int64, c_int64_p]),
+    "syldet_append": (C.c_int, [Handle, C.c_int32, c_float_p, C.c_int64]),
+    "syldet_append_interleaved": (C.c_int, [Handle, c_float_p, C.c_int64, C.c_int32]),
+    "syldet_process_new_value": (C.c_int, [Handle, C.c_int32]),
+    "syldet_last_outputs": (C.c_int, [Handle, C.c_int32, c_float_p]),
+    "syldet_last_detected": (C.c_int, [Handle, C.c_int32]),
+    "syldet_seen_syllable": (C.c_int, [Handle, C.c_int32]),
+}
+
+
+def load(path: str = LIB_PATH) -> C.CDLL:
+    if not os.path.exists(path):
+        raise ImportError(
+            f"{path} not found: libsyldet (the HIP/gfx950 engine) has not been built. "
+            "Run `python -c 'import __graft_entry__ as g; g.build()'` at the repository root. "
+            "There is no CPU fallback.")
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.syldet_abi_version() != ABI_VERSION:
+        raise ImportError(f"libsyldet ABI {lib.syldet_abi_version()} != expected {ABI_VERSION}")
+    return lib
+
+
+lib = load()
+
+
+def last_error() -> str:
+    return (lib.syldet_last_error() or b"").decode("utf-8", "replace")
+
+
+def strerror(status: int) -> str:
+    return (lib.syldet_strerror(status) or b"").decode("utf-8", "replace")

@@ -1,0 +1,339 @@
+// kernels_generic.hip -- the always-applicable engine: any power-of-two FFT size, any
+// window/gap/overlap, any input/output processing chain, any layer sizes.
+//
+// It materialises the sliced spectrogram [C][J][F] in HBM and evaluates the network per
+// sliding window with no algebraic folding, i.e. it is the direct data-parallel restatement
+// of   extractPower (CircularShortTimeFourierTransform.swift:280-337)
+//   -> processFourierData (SyllableDetector.swift:134-151)
+//   -> processNewValue / NeuralNet.apply (SyllableDetector.swift:153-217, NeuralNet.swift:294-326).
+// The fused engine (kernels_fused.hip) is the fast path; this one is its fallback and the
+// producer of syldet_spectrogram_device.
+//
+// gfx950 only: wave = 64 lanes, 256-thread workgroups.
+
+#include "kernels.hpp"
+
+namespace sd {
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kWave = 64;
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b)
+{
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
+    return v;
+}
+__device__ __forceinline__ float wave_min(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, kWave));
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, kWave));
+    return v;
+}
+
+// ------------------------------------------------------------------------------------
+// STFT: one frame per group of TPF = min(256, M/2) threads, G = 256/TPF frames per pass.
+// Packed real FFT: z[m] = xw[2m] + i xw[2m+1] (the vDSP_ctoz step :314-316), M-point
+// complex Stockham radix-2 through two LDS buffers, then the real split restricted to the
+// band:  2X[k] = (Z[k] + conj Z[M-k]) - i e^{-2 pi i k/N} (Z[k] - conj Z[M-k]).
+// ------------------------------------------------------------------------------------
+constexpr int kStftPasses = 8;   // frames per block = G * kStftPasses
+
+__global__ void __launch_bounds__(kBlock)
+stft_generic_kernel(StftDesc d, const float *__restrict__ samples, int64_t stride, int64_t J,
+                    float *__restrict__ columns)
+{
+    extern __shared__ float2 lds[];
+    const int M = d.M;
+    const int half = M >> 1;
+    const int TPF = half < kBlock ? (half < 1 ? 1 : half) : kBlock;
+    const int G = kBlock / TPF;
+    const int g = threadIdx.x / TPF;
+    const int t = threadIdx.x - g * TPF;
+    const int c = blockIdx.y;
+    float2 *bufA = lds + (size_t)g * 2 * M;
+    float2 *bufB = bufA + M;
+    const float *chan = samples + (int64_t)c * stride;
+    float *cols = columns + (int64_t)c * J * d.F;
+
+    for (int pass = 0; pass < kStftPasses; pass++) {
+        const int64_t j = ((int64_t)blockIdx.x * kStftPasses + pass) * G + g;
+        const bool valid = j < J;
+        const float *x = chan + j * d.hop + d.gap;
+
+        // window multiply (vDSP_vmul :311) + zero pad (:110) + even/odd packing
+        for (int m = t; m < M; m += TPF) {
+            const int n0 = 2 * m;
+            float a = 0.0f, b = 0.0f;
+            if (valid) {
+                if (n0 < d.W) a = x[n0] * d.window[n0];
+                if (n0 + 1 < d.W) b = x[n0 + 1] * d.window[n0 + 1];
+            }
+            bufA[m] = make_float2(a, b);
+        }
+        __syncthreads();
+
+        float2 *in = bufA, *out = bufB;
+        for (int Ns = 1; Ns < M; Ns <<= 1) {
+            const int tw_stride = half / Ns;          // twiddle e^{-2 pi i k / (2 Ns)} = tw[k * M/(2Ns)]
+            for (int jj = t; jj < half; jj += TPF) {
+                const int k = jj & (Ns - 1);
+                const float2 w = d.tw[k * tw_stride];
+                const float2 v0 = in[jj];
+                const float2 v1 = cmul(in[jj + half], w);
+                const int j0 = ((jj - k) << 1) + k;
+                out[j0] = make_float2(v0.x + v1.x, v0.y + v1.y);
+                out[j0 + Ns] = make_float2(v0.x - v1.x, v0.y - v1.y);
+            }
+            __syncthreads();
+            float2 *tmp = in; in = out; out = tmp;
+        }
+
+        // real split + magnitude for the band only; Nyquist is dropped (:323)
+        for (int f = t; f < d.F; f += TPF) {
+            const int k = d.f0 + f;
+            float re2, im2;
+            if (k == 0) {
+                const float2 z0 = in[0];
+                re2 = 2.0f * (z0.x + z0.y);
+                im2 = 0.0f;
+            } else {
+                const float2 zk = in[k], zm = in[M - k];
+                const float2 w = d.sw[k];
+                const float ar = zk.x + zm.x, ai = zk.y - zm.y;
+                const float br = zk.x - zm.x, bi = zk.y + zm.y;
+                const float tr = br * w.x - bi * w.y, ti = br * w.y + bi * w.x;
+                re2 = ar + ti;
+                im2 = ai - tr;
+            }
+            const float p = re2 * re2 + im2 * im2;
+            const float v = d.power_mode ? p * 0.25f : sqrtf(p) * 0.5f;   // zvmags/4 :270-274, zvabs/2 :329-333
+            if (valid) cols[j * d.F + f] = v;
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Network: one wave per evaluation, 4 evaluations per block pass.  Evaluation e reads
+// the I = T*F contiguous floats columns[e*F .. e*F + I) (T columns, oldest first,
+// SyllableDetector.swift:180-181), applies scaling (:184-212), the input functions in
+// order (NeuralNet.swift:300-307), the layers (:310-313, :366-377), the output reverse
+// maps (:316-323) and the threshold rule (SyllableDetector.swift:27-31 /
+// TrackDetector.swift:72-77).
+// ------------------------------------------------------------------------------------
+constexpr int kMlpPasses = 8;    // evaluations per wave
+
+__device__ __forceinline__ float transfer(int tf, float x)
+{
+    switch (tf) {
+    case 0: return tanhf(x);                         // TanSig  NeuralNet.swift:189-194
+    case 1: return 1.0f / (expf(-x) + 1.0f);         // LogSig  :196-215
+    case 3: return fminf(fmaxf(x, 0.0f), 1.0f);      // SatLin  :223-228
+    default: return x;                               // PureLin :217-221
+    }
+}
+
+__global__ void __launch_bounds__(kBlock)
+mlp_generic_kernel(NetDesc n, int F, const float *__restrict__ columns, int64_t J, int64_t E,
+                   float *__restrict__ outputs, uint8_t *__restrict__ flags)
+{
+    extern __shared__ float smem[];
+    const int wave = threadIdx.x / kWave;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int c = blockIdx.y;
+    float *bufA = smem + (size_t)wave * 2 * n.max_width;
+    float *bufB = bufA + n.max_width;
+    const float *cols = columns + (int64_t)c * J * F;
+    const float *P = n.params;
+
+    for (int pass = 0; pass < kMlpPasses; pass++) {
+        const int64_t e = ((int64_t)blockIdx.x * kMlpPasses + pass) * (kBlock / kWave) + wave;
+        const bool valid = e < E;
+        const float *src = cols + e * F;
+
+        for (int i = lane; i < n.I; i += kWave) {
+            float v = valid ? src[i] : 1.0f;
+            if (n.scaling == 1) v = logf(v);                    // vvlogf, SyllableDetector.swift:207
+            else if (n.scaling == 2) v = 20.0f * log10f(v);     // vDSP_vdbcon ref 1, amplitude flag :195
+            bufA[i] = v;
+        }
+        __syncthreads();
+
+        for (int k = 0; k < n.n_in_fns; k++) {
+            const DevFn fn = n.in_fns[k];
+            if (fn.kind == 0) {                                  // L2Normalize :47-59
+                float s = 0.0f;
+                for (int i = lane; i < n.I; i += kWave) s += bufA[i] * bufA[i];
+                s = sqrtf(wave_sum(s));
+                for (int i = lane; i < n.I; i += kWave) bufA[i] = bufA[i] / s;
+            } else if (fn.kind == 1) {                           // Normalize :69-96
+                float mn = INFINITY, mx = -INFINITY;
+                for (int i = lane; i < n.I; i += kWave) { mn = fminf(mn, bufA[i]); mx = fmaxf(mx, bufA[i]); }
+                mn = wave_min(mn);
+                mx = wave_max(mx);
+                const float range = mx - mn;
+                if (range == 0.0f) {
+                    for (int i = lane; i < n.I; i += kWave) bufA[i] = -1.0f;
+                } else {
+                    const float slope = 2.0f / range, intercept = (0.0f - mn - mx) / range;
+                    for (int i = lane; i < n.I; i += kWave) bufA[i] = bufA[i] * slope + intercept;
+                }
+            } else if (fn.kind == 2) {                           // NormalizeStd :105-108 (population sigma)
+                float s = 0.0f;
+                for (int i = lane; i < n.I; i += kWave) s += bufA[i];
+                const float mean = wave_sum(s) / (float)n.I;
+                float q = 0.0f;
+                for (int i = lane; i < n.I; i += kWave) { const float dlt = bufA[i] - mean; q += dlt * dlt; }
+                const float sd = sqrtf(wave_sum(q) / (float)n.I);
+                for (int i = lane; i < n.I; i += kWave) bufA[i] = (bufA[i] - mean) / sd;
+            } else if (fn.kind == 3) {                           // MapMinMax.apply :127-131
+                for (int i = lane; i < n.I; i += kWave)
+                    bufA[i] = (bufA[i] - P[fn.xoff + i]) * P[fn.gain + i] + fn.y;
+            } else {                                             // MapStd.apply :162-169
+                for (int i = lane; i < n.I; i += kWave)
+                    bufA[i] = (bufA[i] - P[fn.xoff + i]) * P[fn.gain + i] + fn.y;
+            }
+            __syncthreads();
+        }
+
+        float *cur = bufA, *nxt = bufB;
+        for (int l = 0; l < n.n_layers; l++) {
+            const DevLayer L = n.layers[l];
+            const float *W = P + L.w;
+            if (L.out < kWave) {
+                // few outputs: the whole wave reduces one dot product at a time
+                for (int o = 0; o < L.out; o++) {
+                    float acc = 0.0f;
+                    const float *wrow = W + (size_t)o * L.in;
+                    for (int i = lane; i < L.in; i += kWave) acc = fmaf(wrow[i], cur[i], acc);
+                    acc = wave_sum(acc);
+                    if (lane == 0) nxt[o] = transfer(L.tf, acc + P[L.b + o]);
+                }
+            } else {
+                // many outputs: each lane owns whole rows
+                for (int o = lane; o < L.out; o += kWave) {
+                    float acc = 0.0f;
+                    const float *wrow = W + (size_t)o * L.in;
+                    for (int i = 0; i < L.in; i++) acc = fmaf(wrow[i], cur[i], acc);
+                    nxt[o] = transfer(L.tf, acc + P[L.b + o]);
+                }
+            }
+            __syncthreads();
+            float *tmp = cur; cur = nxt; nxt = tmp;
+        }
+
+        // reverse maps, (y - yOff)/gain + xOffset, NeuralNet.swift:137-142 / :175-180
+        for (int o = lane; o < n.n_out; o += kWave) {
+            float v = cur[o];
+            for (int k = 0; k < n.n_out_fns; k++) {
+                const DevFn fn = n.out_fns[k];
+                v = (v - fn.y) / P[fn.gain + o] + P[fn.xoff + o];
+            }
+            cur[o] = v;
+            if (valid && outputs) outputs[(((int64_t)c * E) + e) * n.n_out + o] = v;
+        }
+        __syncthreads();
+        if (lane == 0 && valid && flags) {
+            uint8_t hit = 0;
+            const int lim = n.rule == 0 ? 1 : n.n_out;
+            for (int o = 0; o < lim; o++) hit |= ((double)cur[o] >= n.thresholds[o]) ? 1 : 0;
+            flags[(int64_t)c * E + e] = hit;
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Detection sample numbers with debounce (TrackDetector.swift:39-43, :65-100): a greedy
+// scan along time, one wave per channel, 64 flags per step; the wave skips ahead with
+// ballots so quiet stretches cost one load per 64 evaluations.
+// ------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kWave)
+detections_kernel(const uint8_t *__restrict__ flags, int64_t E, int64_t first_index, int64_t hop,
+                  int64_t debounce_frames, int64_t *__restrict__ indices, int64_t capacity,
+                  int64_t *__restrict__ counts)
+{
+    const int c = blockIdx.x;
+    const int lane = threadIdx.x;
+    const uint8_t *fl = flags + (int64_t)c * E;
+    int64_t *out = indices ? indices + (int64_t)c * capacity : nullptr;
+    int64_t until = -1;      // debounceUntil :30
+    int64_t n = 0;
+    for (int64_t e0 = 0; e0 < E; e0 += kWave) {
+        const int64_t e = e0 + lane;
+        const bool set = e < E && fl[e] != 0;
+        const int64_t idx = first_index + e * hop;               // curOutput :67-68
+        unsigned long long mask = __ballot(set && until < idx);  // hasDetection && debounceUntil < curOutput :80
+        while (mask) {
+            const int l = __ffsll((long long)mask) - 1;
+            const int64_t hit = first_index + (e0 + l) * hop;
+            if (lane == 0 && out && n < capacity) out[n] = hit;
+            n++;
+            until = hit + debounce_frames;                       // :99
+            const unsigned long long later = (l == 63) ? 0ull : (~0ull << (l + 1));
+            mask = __ballot(set && until < idx) & later;
+        }
+    }
+    if (lane == 0 && counts) counts[c] = n;
+}
+
+}  // namespace
+
+hipError_t launch_stft_generic(const StftDesc &d, const float *samples, int64_t stride, int C, int64_t J,
+                               float *columns, hipStream_t stream)
+{
+    if (J <= 0 || C <= 0) return hipSuccess;
+    const int half = d.M / 2;
+    const int TPF = half < kBlock ? (half < 1 ? 1 : half) : kBlock;
+    const int G = kBlock / TPF;
+    const size_t lds = (size_t)G * 2 * d.M * sizeof(float2);
+    const int64_t per_block = (int64_t)G * kStftPasses;
+    dim3 grid((unsigned)((J + per_block - 1) / per_block), (unsigned)C);
+    if (lds > 64 * 1024) {
+        hipError_t st = hipFuncSetAttribute((const void *)stft_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (st != hipSuccess) return st;
+    }
+    hipLaunchKernelGGL(stft_generic_kernel, grid, dim3(kBlock), lds, stream, d, samples, stride, J, columns);
+    return hipGetLastError();
+}
+
+hipError_t launch_mlp_generic(const NetDesc &n, int F, const float *columns, int C, int64_t J, int64_t E,
+                              float *outputs, uint8_t *flags, hipStream_t stream)
+{
+    if (E <= 0 || C <= 0) return hipSuccess;
+    const size_t lds = (size_t)(kBlock / kWave) * 2 * n.max_width * sizeof(float);
+    const int64_t per_block = (int64_t)(kBlock / kWave) * kMlpPasses;
+    dim3 grid((unsigned)((E + per_block - 1) / per_block), (unsigned)C);
+    if (lds > 64 * 1024) {
+        hipError_t st = hipFuncSetAttribute((const void *)mlp_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (st != hipSuccess) return st;
+    }
+    hipLaunchKernelGGL(mlp_generic_kernel, grid, dim3(kBlock), lds, stream, n, F, columns, J, E, outputs, flags);
+    return hipGetLastError();
+}
+
+hipError_t launch_detections(const uint8_t *flags, int C, int64_t E, int64_t first_index, int64_t hop,
+                             int64_t debounce_frames, int64_t *indices, int64_t capacity, int64_t *counts,
+                             hipStream_t stream)
+{
+    if (C <= 0) return hipSuccess;
+    hipLaunchKernelGGL(detections_kernel, dim3((unsigned)C), dim3(kWave), 0, stream, flags, E, first_index, hop,
+                       debounce_frames, indices, capacity, counts);
+    return hipGetLastError();
+}
+
+}  // namespace sd

@@ -1,0 +1,503 @@
+// syldet_api.cpp -- the device-facing half of the C ABI: handle life-cycle, table upload,
+// kernel dispatch (batch), the streaming front-end, host-buffer conveniences.
+//
+// There is no CPU execution path in this library: every entry point that computes runs
+// HIP kernels on a gfx950 device, and create fails without one.
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+#include "syldet_internal.hpp"
+
+using namespace sd;
+
+namespace {
+
+#define SYLDET_HIP(expr)                                                                         \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess)                                                                    \
+            return fail(SYLDET_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e));  \
+    } while (0)
+
+struct DeviceBuffer {
+    void *ptr = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes)
+    {
+        if (bytes <= cap) return SYLDET_OK;
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+        hipError_t e = hipMalloc(&ptr, bytes);
+        if (e != hipSuccess) {
+            ptr = nullptr;
+            return fail(e == hipErrorOutOfMemory ? SYLDET_ERR_OUT_OF_MEMORY : SYLDET_ERR_DEVICE,
+                        std::string("hipMalloc: ") + hipGetErrorString(e));
+        }
+        cap = bytes;
+        return SYLDET_OK;
+    }
+    void release()
+    {
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+    }
+};
+
+// Per-channel streaming state: the reference's two rings restated as "samples not yet
+// fully consumed" + a queue of evaluations already computed on the device.
+struct ChannelStream {
+    std::vector<float> pending;       // samples from the first frame of the next evaluation onward
+    int64_t appended = 0;             // total samples ever appended
+    int64_t frames_done = 0;          // STFT frames the reference would have extracted so far
+    std::deque<std::vector<float>> ready;   // evaluated outputs not yet handed out
+    std::vector<float> last;          // lastOutputs
+    std::mutex mu;                    // producer (append) vs consumer (process)
+};
+
+}  // namespace
+
+struct syldet {
+    OwnedConfig cfg;
+    syldet_geometry_t geom{};
+    int channels = 0;
+    int device = 0;
+    int engine = SYLDET_ENGINE_GENERIC;
+
+    // device tables
+    DeviceBuffer d_window, d_tw, d_sw, d_params, d_thr;
+    StftDesc stft{};
+    NetDesc net{};
+
+    // scratch
+    DeviceBuffer d_columns;           // generic engine: [C][J][F]
+    DeviceBuffer d_stage_in, d_stage_out, d_stage_flags, d_stage_idx, d_stage_cnt;
+    hipStream_t stream = nullptr;     // used by the host-pointer entry points
+
+    std::vector<std::unique_ptr<ChannelStream>> streams;
+};
+
+namespace {
+
+int build_tables(syldet *h)
+{
+    const syldet_config_t &c = h->cfg.view;
+    const syldet_geometry_t &g = h->geom;
+    const int N = c.fourier_length, W = c.window_length, M = N / 2;
+    int logM = 0;
+    while ((1 << logM) < M) logM++;
+
+    std::vector<float> win((size_t)W);
+    make_window(c.window, W, win.data());
+    std::vector<float2> tw((size_t)std::max(1, M / 2)), sw((size_t)M);
+    const double two_pi = 6.283185307179586476925286766559;
+    for (int t = 0; t < M / 2; t++) {
+        const double a = -two_pi * (double)t / (double)M;
+        tw[(size_t)t] = make_float2((float)std::cos(a), (float)std::sin(a));
+    }
+    for (int k = 0; k < M; k++) {
+        const double a = -two_pi * (double)k / (double)N;
+        sw[(size_t)k] = make_float2((float)std::cos(a), (float)std::sin(a));
+    }
+    if (int st = h->d_window.reserve(win.size() * sizeof(float))) return st;
+    if (int st = h->d_tw.reserve(tw.size() * sizeof(float2))) return st;
+    if (int st = h->d_sw.reserve(sw.size() * sizeof(float2))) return st;
+    SYLDET_HIP(hipMemcpy(h->d_window.ptr, win.data(), win.size() * sizeof(float), hipMemcpyHostToDevice));
+    SYLDET_HIP(hipMemcpy(h->d_tw.ptr, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice));
+    SYLDET_HIP(hipMemcpy(h->d_sw.ptr, sw.data(), sw.size() * sizeof(float2), hipMemcpyHostToDevice));
+
+    StftDesc &s = h->stft;
+    s.N = N; s.W = W; s.M = M; s.logM = logM;
+    s.hop = g.hop; s.gap = g.gap; s.f0 = g.f0; s.F = g.bins;
+    s.power_mode = c.spectrum == SYLDET_SPECTRUM_MAGNITUDE ? 1 : 0;
+    s.window = (const float *)h->d_window.ptr;
+    s.tw = (const float2 *)h->d_tw.ptr;
+    s.sw = (const float2 *)h->d_sw.ptr;
+
+    // parameter blob for the unfolded network
+    NetDesc &n = h->net;
+    std::memset(&n, 0, sizeof(n));
+    if (c.n_input_fns > kMaxFns || c.n_output_fns > kMaxFns || c.n_layers > kMaxLayers)
+        return fail(SYLDET_ERR_UNSUPPORTED, "more than 8 processing functions or 8 layers");
+    std::vector<float> blob;
+    auto push = [&blob](const float *p, size_t cnt) {
+        const int off = (int)blob.size();
+        blob.insert(blob.end(), p, p + cnt);
+        return off;
+    };
+    n.n_in_fns = c.n_input_fns;
+    for (int i = 0; i < c.n_input_fns; i++) {
+        const syldet_fn_t &f = c.input_fns[i];
+        n.in_fns[i].kind = f.kind;
+        n.in_fns[i].y = f.y;
+        if (f.count > 0) {
+            n.in_fns[i].xoff = push(f.x_offsets, (size_t)f.count);
+            n.in_fns[i].gain = push(f.gains, (size_t)f.count);
+        }
+    }
+    n.n_layers = c.n_layers;
+    int max_width = g.inputs;
+    for (int l = 0; l < c.n_layers; l++) {
+        const syldet_layer_t &L = c.layers[l];
+        n.layers[l].in = L.inputs;
+        n.layers[l].out = L.outputs;
+        n.layers[l].tf = L.transfer;
+        n.layers[l].w = push(L.weights, (size_t)L.inputs * (size_t)L.outputs);
+        n.layers[l].b = push(L.biases, (size_t)L.outputs);
+        max_width = std::max(max_width, L.outputs);
+    }
+    n.n_out_fns = c.n_output_fns;
+    for (int i = 0; i < c.n_output_fns; i++) {
+        const syldet_fn_t &f = c.output_fns[i];
+        n.out_fns[i].kind = f.kind;
+        n.out_fns[i].y = f.y;
+        n.out_fns[i].xoff = push(f.x_offsets, (size_t)f.count);
+        n.out_fns[i].gain = push(f.gains, (size_t)f.count);
+    }
+    n.I = g.inputs;
+    n.n_out = g.outputs;
+    n.max_width = max_width;
+    n.scaling = c.scaling;
+    n.rule = c.rule;
+    if ((size_t)max_width * 2 * 4 * sizeof(float) > 160 * 1024)
+        return fail(SYLDET_ERR_UNSUPPORTED, "layer wider than the generic engine's LDS budget");
+    if (int st = h->d_params.reserve(std::max<size_t>(blob.size(), 1) * sizeof(float))) return st;
+    if (!blob.empty())
+        SYLDET_HIP(hipMemcpy(h->d_params.ptr, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (int st = h->d_thr.reserve((size_t)c.n_thresholds * sizeof(double))) return st;
+    SYLDET_HIP(hipMemcpy(h->d_thr.ptr, c.thresholds, (size_t)c.n_thresholds * sizeof(double), hipMemcpyHostToDevice));
+    n.params = (const float *)h->d_params.ptr;
+    n.thresholds = (const double *)h->d_thr.ptr;
+    return SYLDET_OK;
+}
+
+int64_t count_frames(const syldet *h, int64_t S)
+{
+    const int64_t need = (int64_t)h->geom.gap + h->cfg.view.window_length;   // :286-288
+    if (S < need) return 0;
+    return (S - need) / h->geom.hop + 1;                                     // consume hop per frame :299-302
+}
+int64_t count_evals(const syldet *h, int64_t S)
+{
+    const int64_t J = count_frames(h, S);
+    const int T = h->cfg.view.time_range;
+    return J >= T ? J - T + 1 : 0;                                           // SyllableDetector.swift:164-178
+}
+
+int run_on_stream(syldet *h, const float *d_samples, int64_t S, int64_t stride, int C, float *d_outputs,
+                  uint8_t *d_flags, hipStream_t stream)
+{
+    const int64_t J = count_frames(h, S), E = count_evals(h, S);
+    if (E <= 0) return SYLDET_OK;
+    SYLDET_HIP(hipSetDevice(h->device));
+    if (int st = h->d_columns.reserve((size_t)C * (size_t)J * (size_t)h->geom.bins * sizeof(float))) return st;
+    SYLDET_HIP(launch_stft_generic(h->stft, d_samples, stride, C, J, (float *)h->d_columns.ptr, stream));
+    SYLDET_HIP(launch_mlp_generic(h->net, h->geom.bins, (const float *)h->d_columns.ptr, C, J, E, d_outputs,
+                                  d_flags, stream));
+    return SYLDET_OK;
+}
+
+int check_batch_args(const syldet *h, const void *samples, int64_t S, int64_t stride)
+{
+    if (!h || !samples) return fail(SYLDET_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (S < 0 || stride < S) return fail(SYLDET_ERR_INVALID_ARGUMENT, "channel_stride must be >= n_samples >= 0");
+    return SYLDET_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int syldet_create(const syldet_config_t *cfg, int32_t n_channels, int32_t device, int32_t engine, syldet_t **out)
+{
+    if (!cfg || !out) return fail(SYLDET_ERR_INVALID_ARGUMENT, "NULL argument");
+    *out = nullptr;
+    if (n_channels <= 0 || n_channels > 65535)
+        return fail(SYLDET_ERR_INVALID_ARGUMENT, "n_channels must be in [1, 65535]");
+    if (engine != SYLDET_ENGINE_AUTO && engine != SYLDET_ENGINE_GENERIC && engine != SYLDET_ENGINE_FUSED)
+        return fail(SYLDET_ERR_INVALID_ARGUMENT, "unknown engine");
+    std::unique_ptr<syldet> h(new (std::nothrow) syldet());
+    if (!h) return fail(SYLDET_ERR_OUT_OF_MEMORY, "out of memory");
+    if (int st = h->cfg.assign(*cfg)) return st;
+    if (int st = compute_geometry(h->cfg.view, &h->geom)) return st;
+
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess || n_dev <= 0)
+        return fail(SYLDET_ERR_NO_DEVICE, std::string("no HIP device: ") + (e != hipSuccess ? hipGetErrorString(e) : "count is 0"));
+    if (device < 0 || device >= n_dev) return fail(SYLDET_ERR_NO_DEVICE, "device index out of range");
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return fail(SYLDET_ERR_NO_DEVICE, "hipGetDeviceProperties failed");
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(SYLDET_ERR_NO_DEVICE, std::string("libsyldet is built for gfx950 only, found ") + prop.gcnArchName);
+    SYLDET_HIP(hipSetDevice(device));
+    h->device = device;
+    h->channels = n_channels;
+    h->engine = SYLDET_ENGINE_GENERIC;
+    if (engine == SYLDET_ENGINE_FUSED) return fail(SYLDET_ERR_UNSUPPORTED, "fused engine not available for this configuration");
+    h->geom.engine = h->engine;
+    SYLDET_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    if (int st = build_tables(h.get())) {
+        syldet_destroy(h.release());
+        return st;
+    }
+    h->streams.resize((size_t)n_channels);
+    for (auto &s : h->streams) {
+        s.reset(new ChannelStream());
+        s->last.assign((size_t)h->geom.outputs, 0.0f);   // lastOutputs zeros, SyllableDetector.swift:70
+    }
+    *out = h.release();
+    return SYLDET_OK;
+}
+
+int syldet_destroy(syldet_t *h)
+{
+    if (!h) return SYLDET_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) {
+        (void)hipStreamSynchronize(h->stream);
+        (void)hipStreamDestroy(h->stream);
+    }
+    for (DeviceBuffer *b : {&h->d_window, &h->d_tw, &h->d_sw, &h->d_params, &h->d_thr, &h->d_columns, &h->d_stage_in,
+                            &h->d_stage_out, &h->d_stage_flags, &h->d_stage_idx, &h->d_stage_cnt})
+        b->release();
+    delete h;
+    return SYLDET_OK;
+}
+
+int syldet_get_geometry(const syldet_t *h, syldet_geometry_t *out)
+{
+    if (!h || !out) return fail(SYLDET_ERR_INVALID_ARGUMENT, "NULL argument");
+    *out = h->geom;
+    return SYLDET_OK;
+}
+
+int32_t syldet_channels(const syldet_t *h) { return h ? h->channels : 0; }
+
+int64_t syldet_count_frames(const syldet_t *h, int64_t n_samples) { return h ? count_frames(h, n_samples) : -1; }
+int64_t syldet_count_evals(const syldet_t *h, int64_t n_samples) { return h ? count_evals(h, n_samples) : -1; }
+
+int syldet_run_device(syldet_t *h, const float *d_samples, int64_t n_samples, int64_t channel_stride, float *d_outputs,
+                      uint8_t *d_flags, void *hip_stream)
+{
+    if (int st = check_batch_args(h, d_samples, n_samples, channel_stride)) return st;
+    return run_on_stream(h, d_samples, n_samples, channel_stride, h->channels, d_outputs, d_flags, (hipStream_t)hip_stream);
+}
+
+int syldet_spectrogram_device(syldet_t *h, const float *d_samples, int64_t n_samples, int64_t channel_stride,
+                              float *d_columns, void *hip_stream)
+{
+    if (int st = check_batch_args(h, d_samples, n_samples, channel_stride)) return st;
+    if (!d_columns) return fail(SYLDET_ERR_INVALID_ARGUMENT, "NULL argument");
+    SYLDET_HIP(hipSetDevice(h->device));
+    const int64_t J = count_frames(h, n_samples);
+    SYLDET_HIP(launch_stft_generic(h->stft, d_samples, channel_stride, h->channels, J, d_columns, (hipStream_t)hip_stream));
+    return SYLDET_OK;
+}
+
+int syldet_detections_device(syldet_t *h, const uint8_t *d_flags, int64_t n_evals, double debounce_seconds,
+                             int64_t *d_indices, int64_t capacity, int64_t *d_counts, void *hip_stream)
+{
+    if (!h || !d_flags || n_evals < 0 || capacity < 0 || (capacity > 0 && !d_indices))
+        return fail(SYLDET_ERR_INVALID_ARGUMENT, "bad argument");
+    SYLDET_HIP(hipSetDevice(h->device));
+    const int64_t debounce_frames = (int64_t)(debounce_seconds * h->cfg.view.sampling_rate);   // TrackDetector.swift:19-26
+    SYLDET_HIP(launch_detections(d_flags, h->channels, n_evals, h->geom.first_index, h->geom.hop, debounce_frames,
+                                 d_indices, capacity, d_counts, (hipStream_t)hip_stream));
+    return SYLDET_OK;
+}
+
+// ---- host-pointer conveniences: stage, run, copy back, block ----
+
+int syldet_run(syldet_t *h, const float *samples, int64_t n_samples, int64_t channel_stride, float *outputs, uint8_t *flags)
+{
+    if (int st = check_batch_args(h, samples, n_samples, channel_stride)) return st;
+    SYLDET_HIP(hipSetDevice(h->device));
+    const int C = h->channels;
+    const int64_t E = count_evals(h, n_samples);
+    const size_t in_bytes = (size_t)C * (size_t)n_samples * sizeof(float);
+    const size_t out_bytes = (size_t)C * (size_t)E * (size_t)h->geom.outputs * sizeof(float);
+    const size_t fl_bytes = (size_t)C * (size_t)E;
+    if (E <= 0) return SYLDET_OK;
+    if (int st = h->d_stage_in.reserve(in_bytes)) return st;
+    if (int st = h->d_stage_out.reserve(out_bytes)) return st;
+    if (int st = h->d_stage_flags.reserve(fl_bytes)) return st;
+    SYLDET_HIP(hipMemcpy2DAsync(h->d_stage_in.ptr, (size_t)n_samples * sizeof(float), samples,
+                                (size_t)channel_stride * sizeof(float), (size_t)n_samples * sizeof(float), (size_t)C,
+                                hipMemcpyHostToDevice, h->stream));
+    if (int st = run_on_stream(h, (const float *)h->d_stage_in.ptr, n_samples, n_samples, C, (float *)h->d_stage_out.ptr,
+                               (uint8_t *)h->d_stage_flags.ptr, h->stream))
+        return st;
+    if (outputs) SYLDET_HIP(hipMemcpyAsync(outputs, h->d_stage_out.ptr, out_bytes, hipMemcpyDeviceToHost, h->stream));
+    if (flags) SYLDET_HIP(hipMemcpyAsync(flags, h->d_stage_flags.ptr, fl_bytes, hipMemcpyDeviceToHost, h->stream));
+    SYLDET_HIP(hipStreamSynchronize(h->stream));
+    return SYLDET_OK;
+}
+
+int syldet_spectrogram(syldet_t *h, const float *samples, int64_t n_samples, int64_t channel_stride, float *columns)
+{
+    if (int st = check_batch_args(h, samples, n_samples, channel_stride)) return st;
+    if (!columns) return fail(SYLDET_ERR_INVALID_ARGUMENT, "NULL argument");
+    SYLDET_HIP(hipSetDevice(h->device));
+    const int C = h->channels;
+    const int64_t J = count_frames(h, n_samples);
+    if (J <= 0) return SYLDET_OK;
+    const size_t in_bytes = (size_t)C * (size_t)n_samples * sizeof(float);
+    const size_t col_bytes = (size_t)C * (size_t)J * (size_t)h->geom.bins * sizeof(float);
+    if (int st = h->d_stage_in.reserve(in_bytes)) return st;
+    if (int st = h->d_columns.reserve(col_bytes)) return st;
+    SYLDET_HIP(hipMemcpy2DAsync(h->d_stage_in.ptr, (size_t)n_samples * sizeof(float), samples,
+                                (size_t)channel_stride * sizeof(float), (size_t)n_samples * sizeof(float), (size_t)C,
+                                hipMemcpyHostToDevice, h->stream));
+    SYLDET_HIP(launch_stft_generic(h->stft, (const float *)h->d_stage_in.ptr, n_samples, C, J, (float *)h->d_columns.ptr, h->stream));
+    SYLDET_HIP(hipMemcpyAsync(columns, h->d_columns.ptr, col_bytes, hipMemcpyDeviceToHost, h->stream));
+    SYLDET_HIP(hipStreamSynchronize(h->stream));
+    return SYLDET_OK;
+}
+
+int syldet_detections(syldet_t *h, const uint8_t *flags, int64_t n_evals, double debounce_seconds, int64_t *indices,
+                      int64_t capacity, int64_t *counts)
+{
+    if (!h || !flags || !counts || n_evals < 0 || capacity < 0 || (capacity > 0 && !indices))
+        return fail(SYLDET_ERR_INVALID_ARGUMENT, "bad argument");
+    SYLDET_HIP(hipSetDevice(h->device));
+    const int C = h->channels;
+    const size_t fl_bytes = std::max<size_t>((size_t)C * (size_t)n_evals, 1);
+    const size_t idx_bytes = std::max<size_t>((size_t)C * (size_t)capacity * sizeof(int64_t), 8);
+    if (int st = h->d_stage_flags.reserve(fl_bytes)) return st;
+    if (int st = h->d_stage_idx.reserve(idx_bytes)) return st;
+    if (int st = h->d_stage_cnt.reserve((size_t)C * sizeof(int64_t))) return st;
+    if (n_evals > 0)
+        SYLDET_HIP(hipMemcpyAsync(h->d_stage_flags.ptr, flags, (size_t)C * (size_t)n_evals, hipMemcpyHostToDevice, h->stream));
+    if (int st = syldet_detections_device(h, (const uint8_t *)h->d_stage_flags.ptr, n_evals, debounce_seconds,
+                                          capacity > 0 ? (int64_t *)h->d_stage_idx.ptr : nullptr, capacity,
+                                          (int64_t *)h->d_stage_cnt.ptr, h->stream))
+        return st;
+    if (capacity > 0)
+        SYLDET_HIP(hipMemcpyAsync(indices, h->d_stage_idx.ptr, (size_t)C * (size_t)capacity * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+    SYLDET_HIP(hipMemcpyAsync(counts, h->d_stage_cnt.ptr, (size_t)C * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+    SYLDET_HIP(hipStreamSynchronize(h->stream));
+    return SYLDET_OK;
+}
+
+// ---- streaming front-end -------------------------------------------------------------
+// The reference keeps, per detector, a 409600-byte sample ring drained one frame at a
+// time and a feature ring of F-float columns drained one column per evaluation.  Here a
+// channel keeps the raw samples from the first frame of its next evaluation onward; when
+// the consumer asks for a value and none is queued, every evaluation those samples allow
+// is computed in one device pass and queued.  Results are the batch engine's.
+
+static const int64_t kSampleRingBytes = 409600;   // CircularShortTimeFourierTransform.init(buffer:) default :61
+
+static int stream_append(syldet *h, ChannelStream &cs, const float *data, int64_t n, int64_t step)
+{
+    std::lock_guard<std::mutex> lock(cs.mu);
+    // TPCircularBufferProduceBytes fails when fewer than n*4 bytes are free (TPCircularBuffer.h:177-185);
+    // the bytes in the reference's ring are the samples no extracted frame has consumed yet.
+    const int64_t unconsumed = cs.appended - cs.frames_done * h->geom.hop;
+    if ((unconsumed + n) * 4 > kSampleRingBytes) return fail(SYLDET_ERR_BUFFER_FULL, "Insufficient space on buffer.");
+    const size_t old = cs.pending.size();
+    cs.pending.resize(old + (size_t)n);
+    for (int64_t i = 0; i < n; i++) cs.pending[old + (size_t)i] = data[i * step];
+    cs.appended += n;
+    return SYLDET_OK;
+}
+
+int syldet_append(syldet_t *h, int32_t channel, const float *data, int64_t n_samples)
+{
+    if (!h || channel < 0 || channel >= h->channels || n_samples < 0 || (n_samples > 0 && !data))
+        return fail(SYLDET_ERR_INVALID_ARGUMENT, "bad argument");
+    return stream_append(h, *h->streams[(size_t)channel], data, n_samples, 1);
+}
+
+int syldet_append_interleaved(syldet_t *h, const float *data, int64_t n_frames, int32_t total_channels)
+{
+    if (!h || n_frames < 0 || (n_frames > 0 && !data) || total_channels != h->channels)
+        return fail(SYLDET_ERR_INVALID_ARGUMENT, "bad argument");
+    for (int c = 0; c < h->channels; c++)
+        if (int st = stream_append(h, *h->streams[(size_t)c], data + c, n_frames, total_channels)) return st;
+    return SYLDET_OK;
+}
+
+int syldet_process_new_value(syldet_t *h, int32_t channel)
+{
+    if (!h || channel < 0 || channel >= h->channels) return fail(SYLDET_ERR_INVALID_ARGUMENT, "bad argument");
+    ChannelStream &cs = *h->streams[(size_t)channel];
+    std::vector<float> chunk;
+    int64_t E = 0;
+    {
+        std::lock_guard<std::mutex> lock(cs.mu);
+        // `while processFourierData() {}` (SyllableDetector.swift:155): every whole frame is extracted now
+        cs.frames_done = count_frames(h, cs.appended);
+        if (cs.ready.empty()) {
+            E = count_evals(h, (int64_t)cs.pending.size());
+            if (E > 0) chunk = cs.pending;   // snapshot; the producer may keep appending
+        }
+    }
+    if (E > 0) {
+        const int n_out = h->geom.outputs;
+        const int64_t S = (int64_t)chunk.size();
+        SYLDET_HIP(hipSetDevice(h->device));
+        if (int st = h->d_stage_in.reserve((size_t)S * sizeof(float))) return st;
+        if (int st = h->d_stage_out.reserve((size_t)E * (size_t)n_out * sizeof(float))) return st;
+        SYLDET_HIP(hipMemcpyAsync(h->d_stage_in.ptr, chunk.data(), (size_t)S * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        if (int st = run_on_stream(h, (const float *)h->d_stage_in.ptr, S, S, 1, (float *)h->d_stage_out.ptr, nullptr, h->stream))
+            return st;
+        std::vector<float> outs((size_t)E * (size_t)n_out);
+        SYLDET_HIP(hipMemcpyAsync(outs.data(), h->d_stage_out.ptr, outs.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        SYLDET_HIP(hipStreamSynchronize(h->stream));
+        std::lock_guard<std::mutex> lock(cs.mu);
+        for (int64_t e = 0; e < E; e++)
+            cs.ready.emplace_back(outs.begin() + (size_t)e * (size_t)n_out, outs.begin() + (size_t)(e + 1) * (size_t)n_out);
+        // each evaluation consumes one column = hop samples (:175-178)
+        cs.pending.erase(cs.pending.begin(), cs.pending.begin() + (size_t)(E * h->geom.hop));
+    }
+    std::lock_guard<std::mutex> lock(cs.mu);
+    if (cs.ready.empty()) return 0;
+    cs.last = std::move(cs.ready.front());
+    cs.ready.pop_front();
+    return 1;
+}
+
+int syldet_last_outputs(const syldet_t *h, int32_t channel, float *out)
+{
+    if (!h || !out || channel < 0 || channel >= h->channels) return fail(SYLDET_ERR_INVALID_ARGUMENT, "bad argument");
+    ChannelStream &cs = *h->streams[(size_t)channel];
+    std::lock_guard<std::mutex> lock(cs.mu);
+    std::copy(cs.last.begin(), cs.last.end(), out);
+    return SYLDET_OK;
+}
+
+int syldet_last_detected(const syldet_t *h, int32_t channel)
+{
+    if (!h || channel < 0 || channel >= h->channels) return fail(SYLDET_ERR_INVALID_ARGUMENT, "bad argument");
+    ChannelStream &cs = *h->streams[(size_t)channel];
+    std::lock_guard<std::mutex> lock(cs.mu);
+    return (double)cs.last[0] >= h->cfg.view.thresholds[0] ? 1 : 0;   // SyllableDetector.swift:27-31
+}
+
+int syldet_seen_syllable(syldet_t *h, int32_t channel)
+{
+    int ret = 0;                                                       // SyllableDetector.swift:220-230
+    for (;;) {
+        const int r = syldet_process_new_value(h, channel);
+        if (r < 0) return r;
+        if (r == 0) break;
+        if (syldet_last_detected(h, channel) == 1) ret = 1;
+    }
+    return ret;
+}
+
+}  // extern "C"

@@ -1,0 +1,173 @@
+"""Host-side mirror of SyllableDetector over the C ABI.
+
+Keeps the reference's surface (Common/SyllableDetector.swift): init(config:) :37,
+appendAudioData :129, processNewValue :153, lastOutputs :26, lastDetected :27,
+seenSyllable :220 -- per channel of a bank -- and adds the batch entry points the MI355X
+engine is built around (whole recordings of many channels in one pass).  All arithmetic
+happens in libsyldet's HIP kernels; torch is used only for device memory and streams.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+from . import _abi
+from .config import SyllableDetectorConfig, SyllableDetectorError, check
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class SyllableDetector:
+    def __init__(self, config: SyllableDetectorConfig, channels: int = 1, device: int = 0,
+                 engine: int = _abi.ENGINE_AUTO):
+        self.config = config
+        self.channels = int(channels)
+        self.device = int(device)
+        self._h = _abi.Handle()
+        c, keep = config.to_abi()
+        check(_abi.lib.syldet_create(C.byref(c), self.channels, self.device, int(engine), C.byref(self._h)))
+        del keep                      # the library copied every array
+        g = _abi.Geometry()
+        check(_abi.lib.syldet_get_geometry(self._h, C.byref(g)))
+        self.geometry = g
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _abi.lib.syldet_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # ---- geometry -----------------------------------------------------------------
+    def countFrames(self, n_samples: int) -> int:
+        return int(_abi.lib.syldet_count_frames(self._h, int(n_samples)))
+
+    def countEvaluations(self, n_samples: int) -> int:
+        return int(_abi.lib.syldet_count_evals(self._h, int(n_samples)))
+
+    # ---- the reference's streaming API, one detector per channel -------------------
+    def appendAudioData(self, data, channel: int = 0) -> None:
+        a = np.ascontiguousarray(data, dtype=np.float32)
+        check(_abi.lib.syldet_append(self._h, channel, a.ctypes.data_as(_abi.c_float_p), a.size))
+
+    def appendInterleavedData(self, data) -> None:
+        a = np.ascontiguousarray(data, dtype=np.float32).reshape(-1, self.channels)
+        check(_abi.lib.syldet_append_interleaved(self._h, a.ctypes.data_as(_abi.c_float_p), a.shape[0], self.channels))
+
+    def processNewValue(self, channel: int = 0) -> bool:
+        return check(_abi.lib.syldet_process_new_value(self._h, channel)) == 1
+
+    def lastOutputsFor(self, channel: int) -> List[float]:
+        out = np.zeros(self.geometry.outputs, np.float32)
+        check(_abi.lib.syldet_last_outputs(self._h, channel, out.ctypes.data_as(_abi.c_float_p)))
+        return out.tolist()
+
+    @property
+    def lastOutputs(self) -> List[float]:
+        return self.lastOutputsFor(0)
+
+    def lastDetectedFor(self, channel: int) -> bool:
+        return check(_abi.lib.syldet_last_detected(self._h, channel)) == 1
+
+    @property
+    def lastDetected(self) -> bool:
+        return self.lastDetectedFor(0)
+
+    def seenSyllable(self, channel: int = 0) -> bool:
+        return check(_abi.lib.syldet_seen_syllable(self._h, channel)) == 1
+
+    # ---- batch, device tensors ----------------------------------------------------
+    def _stream_ptr(self, stream) -> int:
+        torch = _torch()
+        s = stream if stream is not None else torch.cuda.current_stream(self.device)
+        return int(s.cuda_stream)
+
+    def _check_samples(self, samples):
+        torch = _torch()
+        if not (samples.is_cuda and samples.dtype == torch.float32 and samples.dim() == 2):
+            raise ValueError("samples must be a 2-D float32 CUDA tensor [channels, n_samples]")
+        if samples.shape[0] != self.channels or samples.stride(1) != 1:
+            raise ValueError("samples must have one contiguous row per channel")
+        if samples.device.index != self.device:
+            raise ValueError("samples live on a different device than the detector")
+
+    def run(self, samples, outputs=None, flags=None, stream=None):
+        """samples [C, S] -> (outputs [C, E, n_out] f32, flags [C, E] u8), asynchronous on `stream`."""
+        torch = _torch()
+        self._check_samples(samples)
+        S = int(samples.shape[1])
+        E = self.countEvaluations(S)
+        if outputs is None:
+            outputs = torch.empty((self.channels, E, self.geometry.outputs), dtype=torch.float32, device=samples.device)
+        if flags is None:
+            flags = torch.empty((self.channels, E), dtype=torch.uint8, device=samples.device)
+        check(_abi.lib.syldet_run_device(self._h, samples.data_ptr(), S, int(samples.stride(0)),
+                                         outputs.data_ptr(), flags.data_ptr(), self._stream_ptr(stream)))
+        return outputs, flags
+
+    def spectrogram(self, samples, stream=None):
+        """samples [C, S] -> columns [C, J, bins] f32 (what processFourierData appends)."""
+        torch = _torch()
+        self._check_samples(samples)
+        S = int(samples.shape[1])
+        J = self.countFrames(S)
+        cols = torch.empty((self.channels, J, self.geometry.bins), dtype=torch.float32, device=samples.device)
+        check(_abi.lib.syldet_spectrogram_device(self._h, samples.data_ptr(), S, int(samples.stride(0)),
+                                                 cols.data_ptr(), self._stream_ptr(stream)))
+        return cols
+
+    def detections(self, flags, debounce: float = 0.0, capacity: Optional[int] = None, stream=None):
+        """flags [C, E] u8 -> (indices [C, capacity] i64, counts [C] i64); TrackDetector.swift:65-100."""
+        torch = _torch()
+        E = int(flags.shape[1])
+        cap = E if capacity is None else int(capacity)
+        idx = torch.empty((self.channels, max(cap, 1)), dtype=torch.int64, device=flags.device)
+        cnt = torch.empty((self.channels,), dtype=torch.int64, device=flags.device)
+        check(_abi.lib.syldet_detections_device(self._h, flags.data_ptr(), E, float(debounce), idx.data_ptr(), cap,
+                                                cnt.data_ptr(), self._stream_ptr(stream)))
+        return idx, cnt
+
+    # ---- batch, host arrays -------------------------------------------------------
+    def runHost(self, samples: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+        a = np.ascontiguousarray(samples, dtype=np.float32).reshape(self.channels, -1)
+        S = a.shape[1]
+        E = self.countEvaluations(S)
+        out = np.zeros((self.channels, E, self.geometry.outputs), np.float32)
+        fl = np.zeros((self.channels, E), np.uint8)
+        check(_abi.lib.syldet_run(self._h, a.ctypes.data_as(_abi.c_float_p), S, S,
+                                  out.ctypes.data_as(_abi.c_float_p), fl.ctypes.data_as(_abi.c_uint8_p)))
+        return out, fl
+
+    def spectrogramHost(self, samples: np.ndarray) -> np.ndarray:
+        a = np.ascontiguousarray(samples, dtype=np.float32).reshape(self.channels, -1)
+        S = a.shape[1]
+        J = self.countFrames(S)
+        cols = np.zeros((self.channels, J, self.geometry.bins), np.float32)
+        check(_abi.lib.syldet_spectrogram(self._h, a.ctypes.data_as(_abi.c_float_p), S, S,
+                                          cols.ctypes.data_as(_abi.c_float_p)))
+        return cols
+
+    def detectionsHost(self, flags: np.ndarray, debounce: float = 0.0, capacity: Optional[int] = None):
+        f = np.ascontiguousarray(flags, dtype=np.uint8).reshape(self.channels, -1)
+        E = f.shape[1]
+        cap = E if capacity is None else int(capacity)
+        idx = np.zeros((self.channels, max(cap, 1)), np.int64)
+        cnt = np.zeros((self.channels,), np.int64)
+        check(_abi.lib.syldet_detections(self._h, f.ctypes.data_as(_abi.c_uint8_p), E, float(debounce),
+                                         idx.ctypes.data_as(_abi.c_int64_p), cap, cnt.ctypes.data_as(_abi.c_int64_p)))
+        return idx, cnt

@@ -1,0 +1,106 @@
+"""Shared helpers of the test-suite: golden cases, input regeneration, tolerances."""
+import hashlib
+import os
+
+import numpy as np
+
+import pyoracle as po
+from syllable_detector_swift_amd import nets, synth
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+# Floating-point tolerance of the north star ("spectrogram/NN activations within 1e-5 fp32"):
+# absolute 1e-5 at unit scale, relative 1e-5 against the largest value of the same spectrogram
+# column / output vector (rounding error of an FFT bin scales with the column, not the bin).
+TOL = 1e-5
+
+
+def sample_net():
+    return nets.from_npz(os.path.join(GOLD, "sample_net.npz"))
+
+
+def template():
+    return np.load(os.path.join(GOLD, "syllable_template.npy"))
+
+
+def case_names():
+    return sorted(f[:-4] for f in os.listdir(GOLD) if f.startswith("case_") and f.endswith(".npz"))
+
+
+def regenerate(kind: str, seed: int, n: int) -> np.ndarray:
+    if kind == "channel":
+        return synth.channel(n, seed)
+    if kind == "channel_fs16000":
+        return synth.channel(n, seed, fs=16000.0)
+    if kind == "syllable_channel":
+        return synth.syllable_channel(n, template(), seed=seed)
+    if kind == "syllable_channel_hop128":
+        return synth.syllable_channel(n, template(), seed=seed, hop=128)
+    raise KeyError(kind)
+
+
+def load_case(name: str):
+    """-> (cfg, samples, golden dict).  Inputs not stored explicitly are regenerated from their
+    seed and checked against the stored sha256."""
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    tmp = {k[4:]: z[k] for k in z.files if k.startswith("cfg_")}
+    path = os.path.join(GOLD, "_tmp_%s_%d.npz" % (name, os.getpid()))
+    np.savez(path, **tmp)
+    try:
+        cfg = nets.from_npz(path)
+    finally:
+        os.remove(path)
+    cfg.window = int(z["window"][0])
+    cfg.spectrum = int(z["spectrum"][0])
+    cfg.rule = int(z["rule"][0])
+    n = int(z["n_samples"][0])
+    if "samples" in z.files:
+        x = z["samples"]
+    else:
+        x = regenerate(str(z["desc_kind"]), int(z["desc_seed"]), n)
+    digest = hashlib.sha256(np.ascontiguousarray(x).tobytes()).hexdigest()
+    assert digest == str(z["sha256"]), "regenerated input of %s differs from the one the golden was made from" % name
+    gold = {k: z[k] for k in z.files if not k.startswith("cfg_") and k != "samples"}
+    gold["flags"] = np.unpackbits(z["flags"])[: int(z["n_evals"][0])]
+    return cfg, x, gold
+
+
+def oracle_for(cfg) -> po.Oracle:
+    return po.Oracle(po.from_config(cfg))
+
+
+def column_scale(cols: np.ndarray) -> np.ndarray:
+    """Per-column tolerance scale: max(1, max |column|)."""
+    return np.maximum(1.0, np.abs(cols).max(axis=-1, keepdims=True))
+
+
+def assert_columns_close(got, want, tol=TOL):
+    got = np.asarray(got, np.float64)
+    want = np.asarray(want, np.float64)
+    assert got.shape == want.shape
+    err = np.abs(got - want) / column_scale(want)
+    assert err.max() <= tol, "spectrogram error %.3g (scaled) > %.1g" % (err.max(), tol)
+
+
+def assert_outputs_close(got, want, tol=TOL):
+    got = np.asarray(got, np.float64)
+    want = np.asarray(want, np.float64)
+    assert got.shape == want.shape
+    err = np.abs(got - want) / np.maximum(1.0, np.abs(want))
+    assert err.max() <= tol, "output error %.3g > %.1g" % (err.max(), tol)
+
+
+def assert_flags_exact(got_flags, want_out64, thresholds, rule, tol=TOL):
+    """Flags must be bit-identical wherever the anchor's output is farther than the float
+    tolerance from its threshold; the committed goldens keep every evaluation farther."""
+    thr = np.asarray(thresholds, np.float64)[None, :]
+    o = np.asarray(want_out64, np.float64)
+    hit = o >= thr
+    want = hit[:, 0] if rule == 0 else hit.any(axis=1)
+    cols = slice(0, 1) if rule == 0 else slice(None)
+    safe = (np.abs(o - thr)[:, cols] > 2 * tol * np.maximum(1.0, np.abs(o[:, cols]))).all(axis=1)
+    got = np.asarray(got_flags).astype(bool)
+    assert got.shape == want.shape
+    bad = np.nonzero((got != want) & safe)[0]
+    assert bad.size == 0, "flag mismatch at evaluations %s" % bad[:8]
+    return safe
