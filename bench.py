@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""Headline benchmark: audio frames/sec of the STFT + network hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step is one pass of the hot path (samples in HBM -> network outputs + detection flags in HBM)
+over one batch of synthetic audio.  At N=1 the workload is BASELINE.json configs[1]: the sample.txt
+network (N=W=256, overlap 124 => hop 132, Hamming, bins [12,41), T=10, 290 -> 4 TanSig -> 1 PureLin),
+64 synthetic channels x 2^24 samples (4 GiB, far past the 256 MiB Infinity Cache), fp32.  For N>1
+(launched by torch.distributed.run, one rank per GPU) every rank holds its own 64 channels (weak
+scaling; channels are independent detectors, so no data-path collective) and the timed step ends
+with ONE RCCL all-gather of the per-channel detection flags (BASELINE config 4's exchange).
+
+Rank 0 prints one JSON line.  `roofline` is computed from HIP-event timings of the dominant
+kernel taken inside the timed region on the launch stream; `cpu_baseline` is the oracle's fp32
+port of the reference's per-frame call sequence, single-threaded like the reference, on a bounded
+sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(cfg, samples_host, budget_s=12.0):
+    """Oracle fp32 port (kind "port"), one thread, repeated over channel slices for ~budget_s."""
+    import numpy as np
+    import pyoracle as po
+    po.build()
+    o = po.Oracle(po.from_config(cfg))
+    frames = 0
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        for c in range(samples_host.shape[0]):
+            o.run(samples_host[c], po.F32)
+            frames += o.count_frames(samples_host.shape[1])
+        reps += 1
+        if time.perf_counter() - t0 >= budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": frames / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "%d channel(s) x %d samples of the benchmark input, %d pass(es), %.1f s, "
+                      "oracle fp32 port (one frame at a time, radix-2 packed real FFT, unfolded network)"
+                      % (samples_host.shape[0], samples_host.shape[1], reps, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--channels", type=int, default=64, help="channels per GPU")
+    ap.add_argument("--log2-samples", type=int, default=24, help="samples per channel = 2^k")
+    ap.add_argument("--overlap", type=int, default=None, help="override windowOverlap (128 => the hop-128 variant)")
+    ap.add_argument("--workload", default="sample", choices=["sample", "config3"])
+    ap.add_argument("--engine", type=int, default=0, help="0 auto, 1 generic, 2 fused")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import syllable_detector_swift_amd as sd
+    from syllable_detector_swift_amd import nets, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    if args.workload == "config3":
+        cfg = nets.config3()
+        C, S = (512 if args.channels == 64 else args.channels), 1 << (21 if args.log2_samples == 24 else args.log2_samples)
+        name = "BASELINE configs[2]: 1024-pt FFT hop 256, synthetic 1160-4-1 network"
+    else:
+        cfg = nets.from_npz()
+        C, S = args.channels, 1 << args.log2_samples
+        name = "BASELINE configs[1]: sample.txt network, 256-pt FFT, Hamming"
+    if args.overlap is not None:
+        cfg = nets.variant(cfg, windowOverlap=args.overlap)
+
+    det = sd.SyllableDetector(cfg, channels=C, device=local_rank, engine=args.engine)
+    g = det.geometry
+    J, E = det.countFrames(S), det.countEvaluations(S)
+    x = synth.channels_on_device(C, S, dev, first=rank * C, fs=cfg.samplingRate)
+    outputs = torch.empty((C, E, g.outputs), dtype=torch.float32, device=dev)
+    flags = torch.empty((C, E), dtype=torch.uint8, device=dev)
+    gathered = torch.empty((world * C, E), dtype=torch.uint8, device=dev) if world > 1 else None
+    det.profile(True)
+
+    def step():
+        det.run(x, outputs, flags)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, flags)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    kernel_ms = {}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        # event queries only (no host sync beyond the events of the step just enqueued)
+        for nm, ms in det.lastTimings():
+            kernel_ms.setdefault(nm, []).append(ms)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    frames_per_step = world * C * J
+    value = frames_per_step * args.steps / elapsed
+
+    if rank == 0:
+        # algorithmic bytes per frame: unique input bytes + fp32 outputs + 1 flag byte
+        b_frame = 4 * g.hop + 4 * g.outputs + 1
+        means = {k: sum(v) / len(v) for k, v in kernel_ms.items()}
+        dom = max(means, key=means.get)
+        # the dominant kernel's launch covers C*J frames of this rank; when the path is split over
+        # several kernels each is charged the whole frame's algorithmic bytes (none moves fewer)
+        achieved = C * J * b_frame / (means[dom] * 1e-3) / 1e9
+        line = {
+            "metric": "audio frames/sec (256-pt STFT + 2-layer MLP), whole job" if args.workload == "sample"
+                      else "audio frames/sec (1024-pt STFT + 2-layer MLP), whole job",
+            "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "per_gpu": value / world,
+            "config": {"workload": name, "channels_per_gpu": C, "samples_per_channel": S, "frames_per_channel": J,
+                       "evaluations_per_channel": E, "fourier_length": cfg.fourierLength, "hop": g.hop,
+                       "bins": [g.f0, g.f1], "time_range": cfg.timeRange, "engine": {1: "generic", 2: "fused"}.get(g.engine, str(g.engine)),
+                       "sharding": "channels, %d per GPU; one all-gather of flags per step" % C if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_frame": b_frame, "kernel_ms": means},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            n_cpu = min(S, 1 << 22)
+            line["cpu_baseline"] = cpu_baseline(cfg, x[:1, :n_cpu].cpu().numpy())
+            line["cpu_baseline"]["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
+        print(json.dumps(line), flush=True)
+    det.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -201,6 +201,14 @@ int syldet_detections_device(syldet_t *h, const uint8_t *d_flags, int64_t n_eval
 int syldet_detections(syldet_t *h, const uint8_t *flags, int64_t n_evals, double debounce_seconds,
                       int64_t *indices, int64_t capacity, int64_t *counts);
 
+/* ---- measurement (replaces the reference's Time stopwatch, SyllableDetector/Time.swift:36-100,
+ * which wraps processNewValue in ViewControllerSimulator.swift:309-319) ----
+ * With profiling enabled every kernel of a batch call is bracketed by HIP events on the stream it
+ * is launched on.  syldet_last_timings blocks until the last call's events have completed and
+ * returns up to `capacity` kernel durations in milliseconds, in launch order, with their names.   */
+int syldet_profile(syldet_t *h, int enable);
+int syldet_last_timings(syldet_t *h, double *milliseconds, const char **names, int32_t capacity, int32_t *count);
+
 /* ---- streaming: the reference's per-detector API, one call per channel ----
  * appendAudioData(_:withSamples:), SyllableDetector.swift:129-132                         */
 int syldet_append(syldet_t *h, int32_t channel, const float *data, int64_t n_samples);

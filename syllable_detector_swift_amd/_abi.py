@@ -101,6 +101,8 @@ SIGNATURES = {
     "syldet_spectrogram": (C.c_int, [Handle, c_float_p, C.c_int64, C.c_int64, c_float_p]),
     "syldet_detections_device": (C.c_int, [Handle, C.c_void_p, C.c_int64, C.c_double, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "syldet_detections": (C.c_int, [Handle, c_uint8_p, C.c_int64, C.c_double, c_int64_p, C.c_int64, c_int64_p]),
+    "syldet_profile": (C.c_int, [Handle, C.c_int]),
+    "syldet_last_timings": (C.c_int, [Handle, c_double_p, C.POINTER(C.c_char_p), C.c_int32, c_int32_p]),
     "syldet_append": (C.c_int, [Handle, C.c_int32, c_float_p, C.c_int64]),
     "syldet_append_interleaved": (C.c_int, [Handle, c_float_p, C.c_int64, C.c_int32]),
     "syldet_process_new_value": (C.c_int, [Handle, C.c_int32]),
@@ -110,7 +112,28 @@ SIGNATURES = {
 }
 
 
+def _share_hip_runtime_with_torch() -> None:
+    """The torch wheel carries its own libamdhip64.so (SONAME libamdhip64.so.7) and asks for it by
+    file name.  If libsyldet pulled /opt/rocm's copy in first, a later `import torch` would load a
+    second HIP runtime into the process and one of the two would see no device.  Loading torch's
+    copy by path first makes both sides resolve to the same runtime, whatever the import order."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    rt = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(rt):
+        C.CDLL(rt, mode=C.RTLD_GLOBAL)
+
+
 def load(path: str = LIB_PATH) -> C.CDLL:
+    _share_hip_runtime_with_torch()
     if not os.path.exists(path):
         raise ImportError(
             f"{path} not found: libsyldet (the HIP/gfx950 engine) has not been built. "

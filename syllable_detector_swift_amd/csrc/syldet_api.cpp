@@ -87,6 +87,12 @@ struct syldet {
     hipStream_t stream = nullptr;     // used by the host-pointer entry points
 
     std::vector<std::unique_ptr<ChannelStream>> streams;
+
+    // optional per-kernel timing (syldet_profile)
+    bool profiling = false;
+    std::vector<hipEvent_t> events;          // 2 per kernel slot
+    std::vector<const char *> event_names;
+    int timed_kernels = 0;
 };
 
 namespace {
@@ -196,23 +202,57 @@ int64_t count_evals(const syldet *h, int64_t S)
     return J >= T ? J - T + 1 : 0;                                           // SyllableDetector.swift:164-178
 }
 
+// Brackets one kernel launch with events on its own stream when profiling is on.
+struct KernelTimer {
+    syldet *h;
+    hipStream_t stream;
+    int slot = -1;
+    KernelTimer(syldet *h_, hipStream_t s, const char *name) : h(h_), stream(s)
+    {
+        if (!h->profiling) return;
+        slot = h->timed_kernels++;
+        while ((int)h->events.size() < 2 * (slot + 1)) {
+            hipEvent_t e = nullptr;
+            (void)hipEventCreate(&e);
+            h->events.push_back(e);
+        }
+        if ((int)h->event_names.size() <= slot) h->event_names.resize((size_t)slot + 1);
+        h->event_names[(size_t)slot] = name;
+        (void)hipEventRecord(h->events[(size_t)(2 * slot)], stream);
+    }
+    ~KernelTimer()
+    {
+        if (slot >= 0) (void)hipEventRecord(h->events[(size_t)(2 * slot + 1)], stream);
+    }
+};
+
 int run_on_stream(syldet *h, const float *d_samples, int64_t S, int64_t stride, int C, float *d_outputs,
                   uint8_t *d_flags, hipStream_t stream)
 {
     const int64_t J = count_frames(h, S), E = count_evals(h, S);
     if (E <= 0) return SYLDET_OK;
     SYLDET_HIP(hipSetDevice(h->device));
+    h->timed_kernels = 0;
     if (int st = h->d_columns.reserve((size_t)C * (size_t)J * (size_t)h->geom.bins * sizeof(float))) return st;
-    SYLDET_HIP(launch_stft_generic(h->stft, d_samples, stride, C, J, (float *)h->d_columns.ptr, stream));
-    SYLDET_HIP(launch_mlp_generic(h->net, h->geom.bins, (const float *)h->d_columns.ptr, C, J, E, d_outputs,
-                                  d_flags, stream));
+    {
+        KernelTimer t(h, stream, "stft_generic_kernel");
+        SYLDET_HIP(launch_stft_generic(h->stft, d_samples, stride, C, J, (float *)h->d_columns.ptr, stream));
+    }
+    {
+        KernelTimer t(h, stream, "mlp_generic_kernel");
+        SYLDET_HIP(launch_mlp_generic(h->net, h->geom.bins, (const float *)h->d_columns.ptr, C, J, E, d_outputs,
+                                      d_flags, stream));
+    }
     return SYLDET_OK;
 }
 
 int check_batch_args(const syldet *h, const void *samples, int64_t S, int64_t stride)
 {
-    if (!h || !samples) return fail(SYLDET_ERR_INVALID_ARGUMENT, "NULL argument");
-    if (S < 0 || stride < S) return fail(SYLDET_ERR_INVALID_ARGUMENT, "channel_stride must be >= n_samples >= 0");
+    if (!h) return fail(SYLDET_ERR_INVALID_ARGUMENT, "NULL handle");
+    if (S < 0) return fail(SYLDET_ERR_INVALID_ARGUMENT, "n_samples must be >= 0");
+    if (!samples && S > 0) return fail(SYLDET_ERR_INVALID_ARGUMENT, "NULL samples");
+    // the stride only matters between rows; a single channel may pass anything
+    if (h->channels > 1 && stride < S) return fail(SYLDET_ERR_INVALID_ARGUMENT, "channel_stride must be >= n_samples");
     return SYLDET_OK;
 }
 
@@ -270,6 +310,7 @@ int syldet_destroy(syldet_t *h)
         (void)hipStreamSynchronize(h->stream);
         (void)hipStreamDestroy(h->stream);
     }
+    for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
     for (DeviceBuffer *b : {&h->d_window, &h->d_tw, &h->d_sw, &h->d_params, &h->d_thr, &h->d_columns, &h->d_stage_in,
                             &h->d_stage_out, &h->d_stage_flags, &h->d_stage_idx, &h->d_stage_cnt})
         b->release();
@@ -285,6 +326,29 @@ int syldet_get_geometry(const syldet_t *h, syldet_geometry_t *out)
 }
 
 int32_t syldet_channels(const syldet_t *h) { return h ? h->channels : 0; }
+
+int syldet_profile(syldet_t *h, int enable)
+{
+    if (!h) return fail(SYLDET_ERR_INVALID_ARGUMENT, "NULL argument");
+    h->profiling = enable != 0;
+    h->timed_kernels = 0;
+    return SYLDET_OK;
+}
+
+int syldet_last_timings(syldet_t *h, double *milliseconds, const char **names, int32_t capacity, int32_t *count)
+{
+    if (!h || !count || capacity < 0 || (capacity > 0 && !milliseconds))
+        return fail(SYLDET_ERR_INVALID_ARGUMENT, "bad argument");
+    *count = h->timed_kernels;
+    for (int i = 0; i < h->timed_kernels && i < capacity; i++) {
+        SYLDET_HIP(hipEventSynchronize(h->events[(size_t)(2 * i + 1)]));
+        float ms = 0.0f;
+        SYLDET_HIP(hipEventElapsedTime(&ms, h->events[(size_t)(2 * i)], h->events[(size_t)(2 * i + 1)]));
+        milliseconds[i] = (double)ms;
+        if (names) names[i] = h->event_names[(size_t)i];
+    }
+    return SYLDET_OK;
+}
 
 int64_t syldet_count_frames(const syldet_t *h, int64_t n_samples) { return h ? count_frames(h, n_samples) : -1; }
 int64_t syldet_count_evals(const syldet_t *h, int64_t n_samples) { return h ? count_evals(h, n_samples) : -1; }

@@ -142,6 +142,18 @@ class SyllableDetector:
                                                 cnt.data_ptr(), self._stream_ptr(stream)))
         return idx, cnt
 
+    # ---- measurement ------------------------------------------------------------------
+    def profile(self, enable: bool = True) -> None:
+        check(_abi.lib.syldet_profile(self._h, 1 if enable else 0))
+
+    def lastTimings(self):
+        """[(kernel name, milliseconds)] of the last batch call (HIP events on its stream)."""
+        ms = (C.c_double * 8)()
+        names = (C.c_char_p * 8)()
+        n = C.c_int32()
+        check(_abi.lib.syldet_last_timings(self._h, ms, names, 8, C.byref(n)))
+        return [(names[i].decode(), float(ms[i])) for i in range(min(n.value, 8))]
+
     # ---- batch, host arrays -------------------------------------------------------
     def runHost(self, samples: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
         a = np.ascontiguousarray(samples, dtype=np.float32).reshape(self.channels, -1)

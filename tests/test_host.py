@@ -1,0 +1,162 @@
+"""Host logic of the product on CPU: the C-ABI library loads and exports every declared symbol,
+the text-format parser (N1) agrees with an independent reader and reports the reference's error
+kinds, SyllableDetector.init's validation, and the loud failure without a GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import pyoracle as po
+import util
+import syllable_detector_swift_amd as sd
+from syllable_detector_swift_amd import _abi, nets
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "syldet.h")).read()
+    declared = set(re.findall(r"\b(syldet_[a-z_0-9]+)\s*\(", header))
+    declared -= {"syldet_create_from"}                      # (none; guard against stale names)
+    lib = C.CDLL(_abi.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), "libsyldet.so does not export %s" % name
+    assert declared == set(_abi.SIGNATURES), "ctypes table and header disagree: %s" % (declared ^ set(_abi.SIGNATURES))
+    assert lib.syldet_abi_version() == 1
+
+
+def test_strerror_covers_every_status():
+    for st in (0, -1, -2, -3, -4, -5, -6, -7, -8, -9, -10, -11, -20, -21, -22, -23, -30):
+        assert _abi.strerror(st) not in ("", "unknown status")
+    assert _abi.strerror(-999) == "unknown status"
+
+
+def _same_net(a, b):
+    assert len(a["layers"]) == len(b["layers"]) and len(a["inputs"]) == len(b["inputs"]) and len(a["outputs"]) == len(b["outputs"])
+    for k in ("samplingRate", "fourierLength", "windowLength", "windowOverlap", "freqRange", "timeRange", "scaling"):
+        assert a[k] == b[k], k
+    assert np.array_equal(a["thresholds"], b["thresholds"])
+    for x, y in zip(a["layers"], b["layers"]):
+        assert (x["inputs"], x["outputs"], x["transferFunction"]) == (y["inputs"], y["outputs"], y["transferFunction"])
+        assert np.array_equal(x["weights"], y["weights"]) and np.array_equal(x["biases"], y["biases"])
+    for x, y in zip(a["inputs"] + a["outputs"], b["inputs"] + b["outputs"]):
+        assert x["function"] == y["function"]
+        if "xOffsets" in x:
+            assert np.array_equal(x["xOffsets"], y["xOffsets"]) and np.array_equal(x["gains"], y["gains"]) and x["y"] == y["y"]
+
+
+@pytest.mark.parametrize("name", ["sample"] + util.case_names())
+def test_text_format_round_trip_against_independent_reader(tmp_path, name):
+    cfg = util.sample_net() if name == "sample" else util.load_case(name)[0]
+    text = cfg.toText()
+    p = tmp_path / "net.txt"
+    p.write_text(text)
+    parsed = sd.SyllableDetectorConfig.fromTextFile(str(p))
+    _same_net(po.from_config(parsed), po.parse_text(text))
+    # %.15g round-trips every float32 exactly
+    _same_net(po.from_config(parsed), po.from_config(nets.variant(cfg, window=1, spectrum=0, rule=0)))
+    assert (parsed.window, parsed.spectrum, parsed.rule) == (_abi.WINDOW_HAMMING, _abi.SPECTRUM_POWER, _abi.RULE_FIRST)
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/sample.txt"), reason="reference tree not present")
+def test_reference_sample_file_parses_to_the_committed_fixture():
+    parsed = sd.SyllableDetectorConfig.fromTextFile("/root/reference/sample.txt")
+    _same_net(po.from_config(parsed), po.from_config(util.sample_net()))
+    g = parsed.geometry()
+    assert (g.hop, g.gap, g.f0, g.f1, g.bins, g.inputs, g.outputs, g.first_index) == (132, 0, 12, 41, 29, 290, 1, 1444)
+
+
+def _write(tmp_path, text):
+    p = tmp_path / "cfg.txt"
+    p.write_text(text)
+    return str(p)
+
+
+def test_parser_line_rules(tmp_path):
+    """Lines without exactly one '=' are skipped (comments, blanks, 'a=b=c'); later keys win; the
+    legacy singular `threshold` is accepted; windowLength defaults to fourierLength; CRLF is trimmed."""
+    cfg = nets.variant(util.sample_net())
+    text = cfg.toText().replace("thresholds = ", "threshold = ")
+    text = text.replace("windowLength = 256\n", "")
+    text = "junk line\n\n# c = d = e\nsamplingRate = 1.0\n" + text.replace("\n", "\r\n") + "ignored=\n=ignored\n"
+    parsed = sd.SyllableDetectorConfig.fromTextFile(_write(tmp_path, text))
+    assert parsed.samplingRate == 44100.0 and parsed.windowLength == 256 and parsed.thresholds == [0.442442442442442]
+
+
+def test_parser_error_kinds(tmp_path):
+    good = util.sample_net().toText()
+    with pytest.raises(sd.UnableToOpenPath):
+        sd.SyllableDetectorConfig.fromTextFile(str(tmp_path / "missing.txt"))
+    cases = [
+        (lambda t: t.replace("samplingRate = 44100.0\n", ""), sd.MissingValue, "samplingRate"),
+        (lambda t: t.replace("fourierLength = 256", "fourierLength = 255"), sd.InvalidValue, "fourierLength"),
+        (lambda t: t.replace("fourierLength = 256", "fourierLength = 256.0"), sd.InvalidValue, "fourierLength"),
+        (lambda t: t.replace("freqRange = 2000.0, 7000.0", "freqRange = 2000.0"), sd.MismatchedLength, "freqRange"),
+        (lambda t: t.replace("thresholds = ", "thresholdz = "), sd.MissingValue, "threshold"),
+        (lambda t: t.replace("scaling = linear", "scaling = cubic"), sd.InvalidValue, "scaling"),
+        (lambda t: t.replace("layer0.transferFunction = TanSig", "layer0.transferFunction = ReLU"), sd.InvalidValue, "layer0.transferFunction"),
+        (lambda t: t.replace("layer1.biases = ", "layer1.biases = 1.0, "), sd.MismatchedLength, "layer1.biases"),
+        (lambda t: t.replace("layer1.weights = ", "layer1.weights = x, "), sd.InvalidValue, "layer1.weights"),
+        (lambda t: t.replace("processInputs0.function = l2normalize", "processInputs0.function = whiten"), sd.InvalidValue, "processInputs0.function"),
+        (lambda t: t.replace("processOutputs0.function = mapminmax", "processOutputs0.function = l2normalize"), sd.InvalidValue, "processOutputs0.function"),
+        (lambda t: t.replace("processInputs1.yMin = -1\n", ""), sd.MissingValue, "processInputs1.yMin"),
+        (lambda t: t.replace("timeRange = 10", "timeRange = ten"), sd.InvalidValue, "timeRange"),
+    ]
+    for edit, exc, key in cases:
+        bad = edit(good)
+        assert bad != good, key
+        with pytest.raises(exc) as ei:
+            sd.SyllableDetectorConfig.fromTextFile(_write(tmp_path, bad))
+        assert key in str(ei.value)
+
+
+def test_detector_init_validation():
+    """The checks SyllableDetector.init / CircularShortTimeFourierTransform.init make with
+    fatalError come back as statuses."""
+    base = util.sample_net()
+    bad = [(dict(windowOverlap=256), _abi.ERR_OVERLAP), (dict(fourierLength=128), _abi.ERR_FFT_SIZE),
+           (dict(fourierLength=300), _abi.ERR_FFT_SIZE), (dict(freqRange=(7000.0, 2000.0)), _abi.ERR_FREQ_RANGE),
+           (dict(freqRange=(23000.0, 24000.0)), _abi.ERR_FREQ_RANGE), (dict(timeRange=9), _abi.ERR_INPUT_MISMATCH),
+           (dict(thresholds=[0.1, 0.2]), _abi.ERR_THRESHOLD_MISMATCH)]
+    for change, status in bad:
+        with pytest.raises(sd.SyllableDetectorError) as ei:
+            nets.variant(base, **change).geometry()
+        assert ei.value.status == status, change
+    broken = nets.variant(base)
+    broken.net.layers[1].inputs = 5
+    with pytest.raises(sd.SyllableDetectorError) as ei:
+        broken.geometry()
+    assert ei.value.status == _abi.ERR_LAYER_SHAPE
+
+
+def test_frequency_index_range_and_windows_match_the_oracle(oracle_lib):
+    assert sd.frequencyIndexRange(256, 44100.0, 2000.0, 7000.0) == (12, 41)
+    assert sd.frequencyIndexRange(1024, 44100.0, 2000.0, 7000.0) == (47, 163)
+    assert sd.frequencyIndexRange(256, 44100.0, 0.0, 1e9) == (0, 128)
+    assert sd.frequencyIndexRange(256, 44100.0, 23000.0, 24000.0) is None
+    for w in range(4):
+        for n in (96, 256, 1024):
+            want = np.zeros(n, np.float32)
+            oracle_lib.orc_window(w, n, want.ctypes.data_as(C.POINTER(C.c_float)))
+            assert np.array_equal(sd.createWindow(w, n), want)
+
+
+def test_no_cpu_fallback():
+    """Without a gfx950 device the product refuses to construct a detector."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(sd.SyllableDetectorError) as ei:
+        sd.SyllableDetector(util.sample_net())
+    assert ei.value.status == _abi.ERR_NO_DEVICE
+
+
+def test_product_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "syllable_detector_swift_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "pyoracle" not in text and "syldet_oracle" not in text and "orc_" not in text, f

@@ -1,0 +1,248 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle and the committed goldens.
+
+Bar (north star): spectrogram and network outputs within 1e-5 (scaled as tests/util.py states),
+detection flags and sample indices bit-identical.  Everything here runs libsyldet kernels on
+cuda:0; nothing falls back to the CPU."""
+import numpy as np
+import pytest
+
+import pyoracle as po
+import util
+import syllable_detector_swift_amd as sd
+from syllable_detector_swift_amd import _abi, nets, synth
+
+pytestmark = pytest.mark.gpu
+
+ENGINES = [_abi.ENGINE_GENERIC, _abi.ENGINE_AUTO]
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _run_gpu(cfg, x2d, engine=_abi.ENGINE_AUTO):
+    torch = _torch()
+    with sd.SyllableDetector(cfg, channels=x2d.shape[0], engine=engine) as det:
+        xs = torch.from_numpy(np.ascontiguousarray(x2d)).cuda()
+        out, fl = det.run(xs)
+        cols = det.spectrogram(xs)
+        torch.cuda.synchronize()
+        return out.cpu().numpy(), fl.cpu().numpy(), cols.cpu().numpy(), det.geometry.engine
+
+
+@pytest.mark.parametrize("engine", ENGINES)
+@pytest.mark.parametrize("name", util.case_names())
+def test_golden_cases(oracle_lib, name, engine):
+    cfg, x, gold = util.load_case(name)
+    o = util.oracle_for(cfg)
+    out, fl, cols, _ = _run_gpu(cfg, x[None, :], engine)
+    want_cols = o.spectrogram(x, po.F64)
+    _, want_fl, want64 = o.run(x, po.F64, cfg.rule)
+    # committed vectors
+    util.assert_columns_close(cols[0, :4], gold["columns_head"])
+    util.assert_outputs_close(out[0, :4096], gold["outputs64"])
+    assert np.array_equal(fl[0], gold["flags"])
+    # live oracle, every frame and evaluation
+    util.assert_columns_close(cols[0], want_cols)
+    util.assert_outputs_close(out[0], want64)
+    safe = util.assert_flags_exact(fl[0], want64, cfg.thresholds, cfg.rule)
+    assert safe.all() and np.array_equal(fl[0], want_fl)
+
+
+@pytest.mark.parametrize("engine", ENGINES)
+def test_many_channels_and_strided_rows(oracle_lib, engine):
+    """Channels are independent detectors; rows may be padded (channel_stride > n_samples)."""
+    torch = _torch()
+    cfg = util.sample_net()
+    o = util.oracle_for(cfg)
+    C, S = 7, 30011
+    tpl = util.template()
+    x = np.stack([synth.syllable_channel(S, tpl, seed=100 + c) if c % 2 else synth.channel(S, c) for c in range(C)])
+    with sd.SyllableDetector(cfg, channels=C, engine=engine) as det:
+        padded = torch.zeros((C, S + 13), dtype=torch.float32, device="cuda")
+        padded[:, :S] = torch.from_numpy(x)
+        out, fl = det.run(padded[:, :S])
+        torch.cuda.synchronize()
+        out, fl = out.cpu().numpy(), fl.cpu().numpy()
+    for c in range(C):
+        _, wfl, w64 = o.run(x[c], po.F64)
+        util.assert_outputs_close(out[c], w64)
+        util.assert_flags_exact(fl[c], w64, cfg.thresholds, cfg.rule)
+
+
+@pytest.mark.parametrize("engine", ENGINES)
+@pytest.mark.parametrize("n", [0, 255, 256, 256 + 131, 256 + 132, 256 + 9 * 132 - 1, 256 + 9 * 132, 256 + 10 * 132 + 5, 5000])
+def test_ragged_lengths(oracle_lib, engine, n):
+    """Empty and too-short inputs give zero evaluations; every length boundary is respected."""
+    torch = _torch()
+    cfg = util.sample_net()
+    o = util.oracle_for(cfg)
+    x = synth.channel(max(n, 1), 4)[:n]
+    with sd.SyllableDetector(cfg, channels=1, engine=engine) as det:
+        assert det.countFrames(n) == o.count_frames(n) and det.countEvaluations(n) == o.count_evals(n)
+        xs = torch.zeros((1, max(n, 1)), dtype=torch.float32, device="cuda")
+        if n:
+            xs[0, :n] = torch.from_numpy(x)
+        out, fl = det.run(xs[:, :n])
+        torch.cuda.synchronize()
+        assert out.shape == (1, o.count_evals(n), 1) and fl.shape == (1, o.count_evals(n))
+        if o.count_evals(n):
+            _, _, w64 = o.run(x, po.F64)
+            util.assert_outputs_close(out.cpu().numpy()[0], w64)
+
+
+@pytest.mark.parametrize("window", [0, 1, 2, 3])
+@pytest.mark.parametrize("spectrum", [0, 1])
+def test_window_types_and_power_mode(oracle_lib, window, spectrum):
+    torch = _torch()
+    cfg = nets.variant(util.sample_net(), window=window, spectrum=spectrum)
+    o = util.oracle_for(cfg)
+    x = synth.channel(20000, 5)
+    with sd.SyllableDetector(cfg, channels=1) as det:
+        cols = det.spectrogram(torch.from_numpy(x[None]).cuda()).cpu().numpy()[0]
+    util.assert_columns_close(cols, o.spectrogram(x, po.F64))
+
+
+@pytest.mark.parametrize("N", [4, 8, 16, 32, 64, 128, 512, 1024, 2048, 4096])
+def test_every_fft_size(oracle_lib, N):
+    """Any power of two: the band [f0,f1) is derived from the frequency range as the reference does."""
+    torch = _torch()
+    rng = np.random.default_rng(N)
+    W = max(2, N - N // 4)
+    probe = sd.SyllableDetectorConfig(8000.0, N, W, W // 3, (0.0, 3000.0), 2, "linear", [0.0],
+                                      nets.random_net(rng, 2, (3,), 1, in_fns=("l2normalize",), out_fns=()))
+    f0, f1 = sd.frequencyIndexRange(N, 8000.0, 0.0, 3000.0)
+    probe.net = nets.random_net(rng, (f1 - f0) * 2, (3,), 1, in_fns=("l2normalize",), out_fns=())
+    o = util.oracle_for(probe)
+    x = synth.channel(6 * N + 1000, 6, fs=8000.0)
+    with sd.SyllableDetector(probe, channels=1) as det:
+        xs = torch.from_numpy(x[None]).cuda()
+        cols = det.spectrogram(xs).cpu().numpy()[0]
+        out, _ = det.run(xs)
+        out = out.cpu().numpy()[0]
+    util.assert_columns_close(cols, o.spectrogram(x, po.F64))
+    util.assert_outputs_close(out, o.run(x, po.F64)[2])
+
+
+def test_detection_indices_and_debounce(oracle_lib):
+    torch = _torch()
+    cfg, x, gold = util.load_case("case_sample_syllables")
+    o = util.oracle_for(cfg)
+    C = 3
+    rng = np.random.default_rng(3)
+    flags = (rng.random((C, 5000)) < np.array([[0.001], [0.05], [0.9]])).astype(np.uint8)
+    flags[0, [0, 1, 2, 63, 64, 65, 4999]] = 1
+    with sd.SyllableDetector(cfg, channels=C) as det:
+        for debounce in (0.0, 0.0031, 0.05, 10.0):
+            idx, cnt = det.detections(torch.from_numpy(flags).cuda(), debounce=debounce)
+            idx, cnt = idx.cpu().numpy(), cnt.cpu().numpy()
+            for c in range(C):
+                want = o.detections(flags[c], debounce)
+                assert cnt[c] == len(want) and np.array_equal(idx[c, :cnt[c]], want)
+            hidx, hcnt = det.detectionsHost(flags, debounce=debounce, capacity=4)
+            for c in range(C):
+                want = o.detections(flags[c], debounce)
+                assert hcnt[c] == len(want) and np.array_equal(hidx[c, :min(4, len(want))], want[:4])
+    # end to end on the golden case
+    with sd.SyllableDetector(cfg, channels=1) as det:
+        _, fl = det.run(torch.from_numpy(x[None]).cuda())
+        for debounce, key in ((0.0, "det_0"), (0.05, "det_50ms")):
+            idx, cnt = det.detections(fl, debounce=debounce)
+            assert np.array_equal(idx.cpu().numpy()[0, :int(cnt[0])], gold[key])
+
+
+@pytest.mark.parametrize("name", ["case_sample_syllables", "case_chain_normstd_log"])
+def test_streaming_api_equals_batch(oracle_lib, name):
+    """appendAudioData / processNewValue / lastOutputs / lastDetected / seenSyllable, ragged appends."""
+    cfg, x, _ = util.load_case(name)
+    x = x[:30000]
+    o = util.oracle_for(cfg)
+    _, _, w64 = o.run(x, po.F64)
+    rng = np.random.default_rng(2)
+    with sd.SyllableDetector(cfg, channels=2) as det:
+        assert det.lastOutputs == [0.0] * o.n_out and not det.processNewValue()
+        got, pos = [], 0
+        while pos < x.size:
+            n = int(rng.integers(1, 900))
+            det.appendAudioData(x[pos:pos + n], channel=1)
+            pos += n
+            while det.processNewValue(1):
+                got.append(det.lastOutputsFor(1))
+                assert det.lastDetectedFor(1) == (float(np.float32(got[-1][0])) >= cfg.thresholds[0])
+        assert not det.processNewValue(0)                       # channel 0 saw no audio
+        got = np.array(got).reshape(-1, o.n_out)
+        util.assert_outputs_close(got, w64)
+        batch, _ = det.runHost(np.stack([x, x]))
+        assert np.array_equal(batch[1], got)                    # streaming results are the batch engine's
+
+
+def test_streaming_seen_syllable_and_overflow(oracle_lib):
+    cfg, x, gold = util.load_case("case_sample_syllables")
+    with sd.SyllableDetector(cfg, channels=1) as det:
+        det.appendAudioData(np.zeros(102400, np.float32))
+        with pytest.raises(sd.SyllableDetectorError) as ei:
+            det.appendAudioData(np.zeros(1, np.float32))        # "Insufficient space on buffer."
+        assert ei.value.status == _abi.ERR_BUFFER_FULL
+        assert not det.seenSyllable()                           # silence: drains, nothing detected
+        det.appendAudioData(np.zeros(1000, np.float32))
+    with sd.SyllableDetector(cfg, channels=1) as det:
+        seen = []
+        for pos in range(0, x.size, 4410):
+            det.appendAudioData(x[pos:pos + 4410])
+            seen.append(det.seenSyllable())
+        assert any(seen) and not all(seen) and gold["flags"].sum() > 0
+
+
+def test_interleaved_append(oracle_lib):
+    cfg = util.sample_net()
+    o = util.oracle_for(cfg)
+    C, S = 3, 6000
+    x = np.stack([synth.channel(S, 20 + c) for c in range(C)])
+    with sd.SyllableDetector(cfg, channels=C) as det:
+        det.appendInterleavedData(x.T.copy())
+        for c in range(C):
+            outs = []
+            while det.processNewValue(c):
+                outs.append(det.lastOutputsFor(c))
+            util.assert_outputs_close(np.array(outs).reshape(-1, 1), o.run(x[c], po.F64)[2])
+
+
+def test_host_pointer_entry_points(oracle_lib):
+    cfg, x, gold = util.load_case("case_sample_syllables")
+    o = util.oracle_for(cfg)
+    with sd.SyllableDetector(cfg, channels=2) as det:
+        xs = np.stack([x, x[::-1].copy()])
+        out, fl = det.runHost(xs)
+        cols = det.spectrogramHost(xs)
+    for c in range(2):
+        util.assert_columns_close(cols[c], o.spectrogram(xs[c], po.F64))
+        util.assert_outputs_close(out[c], o.run(xs[c], po.F64)[2])
+    assert np.array_equal(fl[0], gold["flags"])
+
+
+def test_full_size_properties():
+    """BASELINE config-2 shape at reduced channel count (size-independent properties): scaling the
+    input leaves the l2-normalised detector's outputs unchanged; shifting the input by k*hop
+    shifts the outputs by k evaluations; channels do not interact."""
+    torch = _torch()
+    cfg = util.sample_net()
+    C, S = 8, 1 << 22
+    x = synth.channels_on_device(C, S, "cuda")
+    with sd.SyllableDetector(cfg, channels=C) as det:
+        out, fl = det.run(x)
+        out2, _ = det.run(x * 0.5)
+        k = 37
+        shifted = torch.zeros_like(x)
+        shifted[:, : S - k * 132] = x[:, k * 132:]
+        out3, _ = det.run(shifted)
+        perm = torch.arange(C - 1, -1, -1, device="cuda")
+        out4, _ = det.run(x[perm].contiguous())
+        torch.cuda.synchronize()
+        E = out.shape[1]
+        assert E == det.countEvaluations(S)
+        assert torch.isfinite(out).all()
+        assert (out - out2).abs().max().item() < 2e-6
+        n = det.countEvaluations(S - k * 132)
+        assert torch.equal(out3[:, :n], out[:, k:k + n])
+        assert torch.equal(out4, out[perm])
