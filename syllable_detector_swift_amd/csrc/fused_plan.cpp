@@ -1,0 +1,255 @@
+// fused_plan.cpp -- decides whether a configuration fits the fused engine and, if so, builds its
+// constant tables on the host in fp64: the split-f16 DFT basis fragments, the first layer folded with
+// the affine input maps, and the LDS layout.
+//
+// Folding (reference: NeuralNet.apply, Common/NeuralNet.swift:294-326):
+//   input chain  = [one of l2normalize | normalize | normalizestd]?  then  (mapminmax | mapstd)*
+//   the affine tail composes to  x = a o v' + b  (per position);  the head is  v' = alpha*v + beta*1
+//   with per-window scalars (alpha, beta) = (1/||v||, 0) | (2/(mx-mn), (-mn-mx)/(mx-mn)) | (1/sigma, -mu/sigma);
+//   layer 0:  W0.x + b0 = alpha * (W0 o a).v + beta * (W0 o a).1 + (b0 + W0.b)
+//   and (W0 o a).v splits over the T columns of the window, so each frame contributes T*H partial dot
+//   products that are summed along a diagonal in (frame, t).
+// Anything else (a normaliser after an affine map, three or more layers, wide layers, long windows)
+// runs on the generic engine.
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "fused_plan.hpp"
+
+namespace sd {
+
+namespace {
+
+// float -> IEEE binary16, round to nearest even
+uint16_t to_half(float f)
+{
+    uint32_t x;
+    std::memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    const int32_t exp = (int32_t)((x >> 23) & 0xff) - 127 + 15;
+    uint32_t man = x & 0x7fffffu;
+    if (((x >> 23) & 0xff) == 0xff) return (uint16_t)(sign | 0x7c00u | (man ? 0x200u : 0));
+    if (exp >= 31) return (uint16_t)(sign | 0x7c00u);
+    if (exp <= 0) {
+        if (exp < -10) return (uint16_t)sign;
+        man |= 0x800000u;
+        const int shift = 14 - exp;
+        uint32_t h = man >> shift;
+        const uint32_t rem = man & ((1u << shift) - 1), halfway = 1u << (shift - 1);
+        if (rem > halfway || (rem == halfway && (h & 1))) h++;
+        return (uint16_t)(sign | h);
+    }
+    uint32_t h = ((uint32_t)exp << 10) | (man >> 13);
+    const uint32_t rem = man & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1))) h++;
+    return (uint16_t)(sign | h);
+}
+
+float from_half(uint16_t h)
+{
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    const uint32_t exp = (h >> 10) & 0x1f, man = h & 0x3ffu;
+    uint32_t x;
+    if (exp == 0) {
+        if (man == 0) x = sign;
+        else {
+            int e = -1;
+            uint32_t m = man;
+            do { e++; m <<= 1; } while (!(m & 0x400u));
+            x = sign | ((uint32_t)(127 - 15 - e) << 23) | ((m & 0x3ffu) << 13);
+        }
+    } else if (exp == 31) x = sign | 0x7f800000u | (man << 13);
+    else x = sign | ((exp - 15 + 127) << 23) | (man << 13);
+    float f;
+    std::memcpy(&f, &x, 4);
+    return f;
+}
+
+void split_half(double v, uint16_t &hi, uint16_t &lo)
+{
+    hi = to_half((float)v);
+    lo = to_half((float)(v - (double)from_half(hi)));
+}
+
+}  // namespace
+
+bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, FusedPlan &p)
+{
+    p = FusedPlan();
+    auto no = [&p](const char *why) { p.reason = why; return false; };
+    const int N = c.fourier_length, W = c.window_length, F = g.bins, T = c.time_range;
+    if (g.hop % 4 != 0) return no("hop is not a multiple of 4");
+    if (W > 256) return no("window longer than 256 samples");
+    if (F > 32) return no("more than 32 bins");
+    if (T > 32) return no("timeRange above 32");
+    if (c.n_layers < 1 || c.n_layers > 2) return no("more than two layers");
+    const syldet_layer_t &L0 = c.layers[0];
+    const int H = L0.outputs;
+    if (H > 16) return no("first layer wider than 16");
+    const int TH = T * H;
+    if (TH > 128) return no("timeRange x first-layer width above 128");
+    const int n_out = g.outputs;
+    if (c.n_layers == 2 && n_out > 4) return no("more than 4 outputs");
+    if (c.n_output_fns > kMaxFns) return no("too many output functions");
+    const int KS = W <= 128 ? 8 : 16;
+    const int MT = TH <= 32 ? 1 : (TH <= 64 ? 2 : 4);
+    if (!fused_supported(KS, MT)) return no("no kernel instantiation");
+
+    // ---- input chain pattern
+    const int I = g.inputs;
+    int norm = 0, first_affine = 0;
+    if (c.n_input_fns > 0) {
+        const int k0 = c.input_fns[0].kind;
+        if (k0 == SYLDET_FN_L2NORMALIZE) { norm = 1; first_affine = 1; }
+        else if (k0 == SYLDET_FN_NORMALIZE) { norm = 2; first_affine = 1; }
+        else if (k0 == SYLDET_FN_NORMALIZESTD) { norm = 3; first_affine = 1; }
+    }
+    std::vector<double> a((size_t)I, 1.0), b((size_t)I, 0.0);
+    for (int k = first_affine; k < c.n_input_fns; k++) {
+        const syldet_fn_t &f = c.input_fns[k];
+        if (f.kind != SYLDET_FN_MAPMINMAX && f.kind != SYLDET_FN_MAPSTD) return no("a normaliser follows another input function");
+        for (int i = 0; i < I; i++) {          // x <- (x - xoff) * gain + y   (MapMinMax.apply :127-131, MapStd.apply :162-169)
+            a[(size_t)i] = a[(size_t)i] * (double)f.gains[i];
+            b[(size_t)i] = (b[(size_t)i] - (double)f.x_offsets[i]) * (double)f.gains[i] + (double)f.y;
+        }
+    }
+
+    // ---- geometry of a pass
+    const int hop = g.hop;
+    const int nsmp = (kFusedTileFrames - 1) * hop + KS * 16;
+    const int nload = (nsmp / 4 + 255) / 256;
+    if (nload > kFusedMaxLoads) return no("hop too large for the staging registers");
+    // LDS bank spreading: consecutive frames are hop/2 dwords apart; if that stride maps 32 lanes onto
+    // few banks (e.g. hop = 128 -> stride 64 dwords = 0 mod 64) skew every hop by 2 dwords.
+    int skew = 0;
+    {
+        const int stride_dw = (hop / 2) % 64;
+        bool seen[64] = {false};
+        int distinct = 0;
+        for (int r = 0; r < 32; r++) {
+            const int bank = (stride_dw * r) % 64 & ~1;
+            if (!seen[bank]) { seen[bank] = true; distinct++; }
+        }
+        if (distinct < 32 && hop % 8 == 0) skew = 4;
+    }
+    auto skewed = [&](int i) { return i + skew * (i / hop); };
+    const int nsmp_p = (skewed(nsmp + 16) + 15) / 8 * 8;
+    const int PS = kFusedTileFrames + T - 1;
+
+    p.desc.W = W; p.desc.KS = KS; p.desc.hop = hop; p.desc.gap = g.gap; p.desc.F = F; p.desc.T = T;
+    p.desc.H = H; p.desc.TH = TH; p.desc.MT = MT; p.desc.norm = norm;
+    p.desc.scaling = c.scaling; p.desc.power_mode = c.spectrum == SYLDET_SPECTRUM_MAGNITUDE ? 1 : 0;
+    p.desc.n_layers = c.n_layers; p.desc.n_out = n_out; p.desc.tf0 = L0.transfer;
+    p.desc.tf1 = c.n_layers == 2 ? c.layers[1].transfer : SYLDET_TF_PURELIN;
+    p.desc.rule = c.rule; p.desc.n_out_fns = c.n_output_fns; p.desc.I = I;
+    p.desc.nsmp = nsmp; p.desc.nload = nload; p.desc.skew = skew;
+    p.desc.hop_magic = (unsigned)((0x100000000ull + (unsigned)hop - 1) / (unsigned)hop);
+    p.desc.ps = PS;
+    int off = 0;
+    auto take = [&off](int bytes) { const int o = off; off += (bytes + 15) / 16 * 16; return o; };
+    p.desc.lds_dfrag = take(KS * 4 * 1024);
+    p.desc.lds_hi = take(nsmp_p * 2);
+    p.desc.lds_lo = take(nsmp_p * 2);
+    p.desc.lds_pbuf = take((TH + 2) * PS * 4);
+    p.desc.lds_stat = p.desc.lds_pbuf + TH * PS * 4;
+    p.desc.lds_red = take(64);
+    p.desc.lds_total = off;
+    if (off > 160 * 1024) return no("LDS budget exceeded");
+
+    // ---- DFT basis fragments: A operand of v_mfma_f32_32x32x16_f16, lane l holds row l&31,
+    // k = 8*(l>>5) + j.  Basis row r < F: re = w[n] cos(2 pi (f0+r) n / N), im = -w[n] sin(...), scaled by 2^13.
+    std::vector<float> win((size_t)W);
+    make_window(c.window, W, win.data());
+    const double two_pi = 6.283185307179586476925286766559;
+    p.dfrag.assign((size_t)KS * 4 * 64 * 8, 0);
+    for (int ks = 0; ks < KS; ks++)
+        for (int tile = 0; tile < 2; tile++)
+            for (int l = 0; l < 64; l++)
+                for (int j = 0; j < 8; j++) {
+                    const int r = l & 31, n = 16 * ks + 8 * (l >> 5) + j;
+                    double v = 0.0;
+                    if (r < F && n < W) {
+                        const int kn = (int)(((int64_t)(g.f0 + r) * n) % N);      // exact angle reduction
+                        const double ang = two_pi * (double)kn / (double)N;
+                        v = (double)win[(size_t)n] * (tile == 0 ? std::cos(ang) : -std::sin(ang)) * 8192.0;
+                        if (tile == 1 && g.f0 + r == 0) v = 0.0;                  // DC is real (:323 drops the packed Nyquist)
+                    }
+                    uint16_t hi, lo;
+                    split_half(v, hi, lo);
+                    p.dfrag[((((size_t)ks * 2 + tile) * 2 + 0) * 64 + l) * 8 + j] = hi;
+                    p.dfrag[((((size_t)ks * 2 + tile) * 2 + 1) * 64 + l) * 8 + j] = lo;
+                }
+
+    // ---- folded first layer: W'[(t,h)][f] = W0[h][t*F+f] * a[t*F+f]
+    double wmax = 0.0;
+    for (int h = 0; h < H; h++)
+        for (int i = 0; i < I; i++) wmax = std::max(wmax, std::fabs((double)L0.weights[(size_t)h * I + i] * a[(size_t)i]));
+    int wexp = 0;
+    if (wmax > 0.0) wexp = 13 - (int)std::ceil(std::log2(wmax));
+    wexp = std::max(-100, std::min(100, wexp));
+    const double wscale = std::ldexp(1.0, wexp);
+    p.desc.w_unscale = (float)std::ldexp(1.0, -wexp);
+    p.wfrag.assign((size_t)MT * 4 * 64 * 8, 0);
+    for (int m = 0; m < MT; m++)
+        for (int s = 0; s < 2; s++)
+            for (int l = 0; l < 64; l++)
+                for (int j = 0; j < 8; j++) {
+                    const int prow = 32 * m + (l & 31);                           // = t*H + h
+                    const int bin = 16 * s + 8 * (j >> 2) + 4 * (l >> 5) + (j & 3);   // accumulator register 8s+j of lane half l>>5
+                    double v = 0.0;
+                    if (prow < TH && bin < F) {
+                        const int t = prow / H, h = prow % H, i = t * F + bin;
+                        v = (double)L0.weights[(size_t)h * I + i] * a[(size_t)i] * wscale;
+                    }
+                    uint16_t hi, lo;
+                    split_half(v, hi, lo);
+                    p.wfrag[((((size_t)m * 2 + s) * 2 + 0) * 64 + l) * 8 + j] = hi;
+                    p.wfrag[((((size_t)m * 2 + s) * 2 + 1) * 64 + l) * 8 + j] = lo;
+                }
+    p.bias0.resize((size_t)H);
+    p.rvec.resize((size_t)H);
+    for (int h = 0; h < H; h++) {
+        double sb = (double)L0.biases[h], sr = 0.0;
+        for (int i = 0; i < I; i++) {
+            const double w = (double)L0.weights[(size_t)h * I + i];
+            sb += w * b[(size_t)i];
+            sr += w * a[(size_t)i];
+        }
+        p.bias0[(size_t)h] = (float)sb;
+        p.rvec[(size_t)h] = (float)sr;
+    }
+    if (c.n_layers == 2) {
+        const syldet_layer_t &L1 = c.layers[1];
+        p.w1.assign(L1.weights, L1.weights + (size_t)L1.inputs * (size_t)L1.outputs);
+        p.b1.assign(L1.biases, L1.biases + L1.outputs);
+    }
+    for (int k = 0; k < c.n_output_fns; k++) {
+        const syldet_fn_t &f = c.output_fns[k];
+        p.out_params.push_back(f.y);
+        p.out_params.insert(p.out_params.end(), f.gains, f.gains + n_out);
+        p.out_params.insert(p.out_params.end(), f.x_offsets, f.x_offsets + n_out);
+    }
+    p.koff.resize((size_t)KS * 2);
+    for (int ks = 0; ks < KS; ks++)
+        for (int h = 0; h < 2; h++) {
+            const int o = 16 * ks + 8 * h;
+            p.koff[(size_t)ks * 2 + h] = o + skew * (o / hop);
+        }
+    p.ok = true;
+    return true;
+}
+
+void fused_segmentation(FusedDesc &d, int64_t E, int C)
+{
+    // a workgroup segment = `runs` passes of 128 frames, emitting 128*runs - (T-1) evaluations; aim for
+    // >= ~2048 segments in flight-worthy grids, at most 16 passes each
+    const int64_t frames = E + d.T - 1;
+    int64_t runs = (frames * (int64_t)C) / ((int64_t)kFusedTileFrames * 2048);
+    runs = std::max<int64_t>(1, std::min<int64_t>(16, runs));
+    d.runs = (int)runs;
+    d.seg_evals = (int)(runs * kFusedTileFrames - (d.T - 1));
+}
+
+}  // namespace sd

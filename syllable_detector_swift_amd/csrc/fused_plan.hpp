@@ -1,0 +1,27 @@
+// fused_plan.hpp -- host-side tables of the fused engine (see fused_plan.cpp).
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+#include "syldet_internal.hpp"
+
+namespace sd {
+
+struct FusedPlan {
+    bool ok = false;
+    std::string reason;              // why the configuration does not fit, when !ok
+    FusedDesc desc{};                // device pointers are filled in by the owner after upload
+    std::vector<uint16_t> dfrag;     // f16 bit patterns
+    std::vector<uint16_t> wfrag;
+    std::vector<int> koff;
+    std::vector<float> bias0, rvec, w1, b1, out_params;
+};
+
+bool make_fused_plan(const syldet_config_t &cfg, const syldet_geometry_t &geom, FusedPlan &plan);
+// choose passes per workgroup for a batch of E evaluations x C channels
+void fused_segmentation(FusedDesc &d, int64_t E, int C);
+
+}  // namespace sd

@@ -56,4 +56,42 @@ hipError_t launch_detections(const uint8_t *flags, int C, int64_t E, int64_t fir
                              int64_t debounce_frames, int64_t *indices, int64_t capacity, int64_t *counts,
                              hipStream_t stream);
 
+// ---- fused engine (kernels_fused.hip) ----------------------------------------------------
+// One kernel: samples -> outputs + flags.  The band-limited windowed DFT of 32 frames at a
+// time is a GEMM on the matrix cores (f16 hi/lo split operands, fp32 accumulate), the first
+// network layer is folded into a second MFMA on the accumulator tile, the sliding window is a
+// diagonal sum over an LDS ring.  Built by make_fused_plan() when the configuration fits.
+constexpr int kFusedTileFrames = 128;   // frames per workgroup pass (4 waves x 32)
+constexpr int kFusedMaxLoads = 20;      // float4 loads per thread per pass
+
+struct FusedDesc {
+    int W, KS;                  // window length, k-steps of 16 samples (KS*16 >= W)
+    int hop, gap, F, T;         // frame advance, leading gap, bins, timeRange
+    int H, TH, MT;              // first-layer outputs, T*H, M-tiles of 32 rows (MT*32 >= TH)
+    int norm;                   // 0 none, 1 l2normalize, 2 normalize, 3 normalizestd (first input fn)
+    int scaling, power_mode;
+    int n_layers, n_out, tf0, tf1, rule, n_out_fns;
+    int I;                      // F*T
+    int nsmp, nload;            // samples staged per pass, float4 loads per thread
+    int skew;                   // f16 elements inserted after every `hop` staged samples (bank spreading)
+    unsigned hop_magic;         // ceil(2^32 / hop): i / hop == umulhi(i, hop_magic) for i < 2^16
+    int runs, seg_evals;        // passes per workgroup, evaluations per workgroup segment
+    int ps;                     // slot stride of the partial-product ring (frames per pass + T - 1)
+    float w_unscale;            // 1 / (power-of-two scale of the folded first-layer weights)
+    int lds_dfrag, lds_hi, lds_lo, lds_pbuf, lds_stat, lds_red, lds_total;   // byte offsets
+    const uint4 *dfrag;         // [KS][re,im][hi,lo][64 lanes] A-operand fragments of the DFT basis
+    const uint4 *wfrag;         // [MT][2 k-steps][hi,lo][64 lanes] A-operand fragments of the folded layer 0
+    const int *koff;            // [KS][2] staged-sample offset of k-step ks for lane half h (skew applied)
+    const float *bias0;         // [H]  b0 + W0 . (constant part of the input maps)
+    const float *rvec;          // [H]  (W0 o a) . 1
+    const float *w1, *b1;       // layer 1, row-major [n_out][H] (2-layer nets)
+    const float *out_params;    // per output fn: y, gain[n_out], xoff[n_out]
+    const double *thresholds;   // [n_out]
+};
+
+hipError_t launch_fused(const FusedDesc &d, const float *samples, int64_t stride, int C, int64_t S, int64_t J,
+                        int64_t E, float *outputs, uint8_t *flags, hipStream_t stream);
+// 0 when this build has an instantiation for (KS, MT)
+int fused_supported(int KS, int MT);
+
 }  // namespace sd

@@ -16,6 +16,7 @@
 #include <string>
 #include <vector>
 
+#include "fused_plan.hpp"
 #include "kernels.hpp"
 #include "syldet_internal.hpp"
 
@@ -83,6 +84,10 @@ struct syldet {
 
     // scratch
     DeviceBuffer d_columns;           // generic engine: [C][J][F]
+
+    // fused engine tables
+    FusedPlan fused;
+    DeviceBuffer d_fused;             // one blob: dfrag | wfrag | koff | bias0 | rvec | w1 | b1 | out_params
     DeviceBuffer d_stage_in, d_stage_out, d_stage_flags, d_stage_idx, d_stage_cnt;
     hipStream_t stream = nullptr;     // used by the host-pointer entry points
 
@@ -189,6 +194,36 @@ int build_tables(syldet *h)
     return SYLDET_OK;
 }
 
+int upload_fused(syldet *h)
+{
+    FusedPlan &p = h->fused;
+    std::vector<unsigned char> blob;
+    auto put = [&blob](const void *src, size_t bytes) {
+        const size_t off = (blob.size() + 255) / 256 * 256;
+        blob.resize(off + std::max<size_t>(bytes, 16));
+        if (bytes) std::memcpy(blob.data() + off, src, bytes);
+        return off;
+    };
+    const size_t o_d = put(p.dfrag.data(), p.dfrag.size() * 2), o_w = put(p.wfrag.data(), p.wfrag.size() * 2);
+    const size_t o_k = put(p.koff.data(), p.koff.size() * 4), o_b = put(p.bias0.data(), p.bias0.size() * 4);
+    const size_t o_r = put(p.rvec.data(), p.rvec.size() * 4), o_w1 = put(p.w1.data(), p.w1.size() * 4);
+    const size_t o_b1 = put(p.b1.data(), p.b1.size() * 4), o_op = put(p.out_params.data(), p.out_params.size() * 4);
+    if (int st = h->d_fused.reserve(blob.size())) return st;
+    SYLDET_HIP(hipMemcpy(h->d_fused.ptr, blob.data(), blob.size(), hipMemcpyHostToDevice));
+    unsigned char *base = (unsigned char *)h->d_fused.ptr;
+    FusedDesc &d = p.desc;
+    d.dfrag = (const uint4 *)(base + o_d);
+    d.wfrag = (const uint4 *)(base + o_w);
+    d.koff = (const int *)(base + o_k);
+    d.bias0 = (const float *)(base + o_b);
+    d.rvec = (const float *)(base + o_r);
+    d.w1 = (const float *)(base + o_w1);
+    d.b1 = (const float *)(base + o_b1);
+    d.out_params = (const float *)(base + o_op);
+    d.thresholds = (const double *)h->d_thr.ptr;
+    return SYLDET_OK;
+}
+
 int64_t count_frames(const syldet *h, int64_t S)
 {
     const int64_t need = (int64_t)h->geom.gap + h->cfg.view.window_length;   // :286-288
@@ -233,6 +268,13 @@ int run_on_stream(syldet *h, const float *d_samples, int64_t S, int64_t stride, 
     if (E <= 0) return SYLDET_OK;
     SYLDET_HIP(hipSetDevice(h->device));
     h->timed_kernels = 0;
+    if (h->engine == SYLDET_ENGINE_FUSED) {
+        FusedDesc d = h->fused.desc;
+        fused_segmentation(d, E, C);
+        KernelTimer t(h, stream, "fused_kernel");
+        SYLDET_HIP(launch_fused(d, d_samples, stride, C, S, J, E, d_outputs, d_flags, stream));
+        return SYLDET_OK;
+    }
     if (int st = h->d_columns.reserve((size_t)C * (size_t)J * (size_t)h->geom.bins * sizeof(float))) return st;
     {
         KernelTimer t(h, stream, "stft_generic_kernel");
@@ -286,12 +328,22 @@ int syldet_create(const syldet_config_t *cfg, int32_t n_channels, int32_t device
     h->device = device;
     h->channels = n_channels;
     h->engine = SYLDET_ENGINE_GENERIC;
-    if (engine == SYLDET_ENGINE_FUSED) return fail(SYLDET_ERR_UNSUPPORTED, "fused engine not available for this configuration");
+    if (engine != SYLDET_ENGINE_GENERIC) {
+        if (make_fused_plan(h->cfg.view, h->geom, h->fused)) h->engine = SYLDET_ENGINE_FUSED;
+        else if (engine == SYLDET_ENGINE_FUSED)
+            return fail(SYLDET_ERR_UNSUPPORTED, "fused engine not available for this configuration: " + h->fused.reason);
+    }
     h->geom.engine = h->engine;
     SYLDET_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     if (int st = build_tables(h.get())) {
         syldet_destroy(h.release());
         return st;
+    }
+    if (h->engine == SYLDET_ENGINE_FUSED) {
+        if (int st = upload_fused(h.get())) {
+            syldet_destroy(h.release());
+            return st;
+        }
     }
     h->streams.resize((size_t)n_channels);
     for (auto &s : h->streams) {
@@ -311,7 +363,7 @@ int syldet_destroy(syldet_t *h)
         (void)hipStreamDestroy(h->stream);
     }
     for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
-    for (DeviceBuffer *b : {&h->d_window, &h->d_tw, &h->d_sw, &h->d_params, &h->d_thr, &h->d_columns, &h->d_stage_in,
+    for (DeviceBuffer *b : {&h->d_window, &h->d_tw, &h->d_sw, &h->d_params, &h->d_thr, &h->d_columns, &h->d_fused, &h->d_stage_in,
                             &h->d_stage_out, &h->d_stage_flags, &h->d_stage_idx, &h->d_stage_cnt})
         b->release();
     delete h;
