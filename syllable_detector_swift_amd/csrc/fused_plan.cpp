@@ -82,14 +82,19 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
     const int N = c.fourier_length, W = c.window_length, F = g.bins, T = c.time_range;
     if (g.hop % 4 != 0) return no("hop is not a multiple of 4");
     if (W > 256) return no("window longer than 256 samples");
+    if (W % 4 != 0) return no("window length is not a multiple of 4");
     if (F > 32) return no("more than 32 bins");
     if (T > 32) return no("timeRange above 32");
     if (c.n_layers < 1 || c.n_layers > 2) return no("more than two layers");
     const syldet_layer_t &L0 = c.layers[0];
     const int H = L0.outputs;
     if (H > 16) return no("first layer wider than 16");
-    const int TH = T * H;
-    if (TH > 128) return no("timeRange x first-layer width above 128");
+    // partial-product rows are ordered h * TP + t with TP the power of two >= max(T, 2)
+    int tp_log2 = 1;
+    while ((1 << tp_log2) < T) tp_log2++;
+    const int TP = 1 << tp_log2, TL = (T + 1) & ~1;
+    const int TH = H * TP;
+    if (TH > 128) return no("first-layer width x padded timeRange above 128 rows");
     const int n_out = g.outputs;
     if (c.n_layers == 2 && n_out > 4) return no("more than 4 outputs");
     if (c.n_output_fns > kMaxFns) return no("too many output functions");
@@ -121,21 +126,14 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
     const int nsmp = (kFusedTileFrames - 1) * hop + KS * 16;
     const int nload = (nsmp / 4 + 255) / 256;
     if (nload > kFusedMaxLoads) return no("hop too large for the staging registers");
-    // LDS bank spreading: consecutive frames are hop/2 dwords apart; if that stride maps 32 lanes onto
-    // few banks (e.g. hop = 128 -> stride 64 dwords = 0 mod 64) skew every hop by 2 dwords.
-    int skew = 0;
-    {
-        const int stride_dw = (hop / 2) % 64;
-        bool seen[64] = {false};
-        int distinct = 0;
-        for (int r = 0; r < 32; r++) {
-            const int bank = (stride_dw * r) % 64 & ~1;
-            if (!seen[bank]) { seen[bank] = true; distinct++; }
-        }
-        if (distinct < 32 && hop % 8 == 0) skew = 4;
-    }
+    // LDS bank spreading: a lane reads 8 consecutive fp32 samples of its frame with two ds_read_b128;
+    // those are conflict-free when consecutive frames start an odd number of 16-byte slots apart
+    // (hop = 132: 33 slots).  For hop = 0 mod 8 (e.g. 128: 32 slots, every lane on one slot) one slot of
+    // padding is inserted after every hop staged samples; 8-sample groups never straddle the padding
+    // because they start at multiples of 8 inside a frame and hop is then a multiple of 8.
+    const int skew = ((hop / 4) % 2 == 0) ? 4 : 0;
     auto skewed = [&](int i) { return i + skew * (i / hop); };
-    const int nsmp_p = (skewed(nsmp + 16) + 15) / 8 * 8;
+    const int nsmp_p = (skewed(nload * 1024 + 16) + 15) / 8 * 8;   // every thread writes all its quads
     const int PS = kFusedTileFrames + T - 1;
 
     p.desc.W = W; p.desc.KS = KS; p.desc.hop = hop; p.desc.gap = g.gap; p.desc.F = F; p.desc.T = T;
@@ -150,10 +148,11 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
     int off = 0;
     auto take = [&off](int bytes) { const int o = off; off += (bytes + 15) / 16 * 16; return o; };
     p.desc.lds_dfrag = take(KS * 4 * 1024);
-    p.desc.lds_hi = take(nsmp_p * 2);
-    p.desc.lds_lo = take(nsmp_p * 2);
-    p.desc.lds_pbuf = take((TH + 2) * PS * 4);
-    p.desc.lds_stat = p.desc.lds_pbuf + TH * PS * 4;
+    p.desc.lds_hi = take(nsmp_p * 4);      // staged samples, scaled fp32
+    p.desc.lds_lo = p.desc.lds_hi;
+    p.desc.tl = TL; p.desc.tp_log2 = tp_log2; p.desc.ring_spare = H * PS * TL;
+    p.desc.lds_pbuf = take((H * PS * TL + 256) * 4);   // ring [H][PS][TL] + 256 spare words
+    p.desc.lds_stat = take(2 * PS * 4);
     p.desc.lds_red = take(64);
     p.desc.lds_total = off;
     if (off > 160 * 1024) return no("LDS budget exceeded");
@@ -199,8 +198,9 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
                     const int prow = 32 * m + (l & 31);                           // = t*H + h
                     const int bin = 16 * s + 8 * (j >> 2) + 4 * (l >> 5) + (j & 3);   // accumulator register 8s+j of lane half l>>5
                     double v = 0.0;
-                    if (prow < TH && bin < F) {
-                        const int t = prow / H, h = prow % H, i = t * F + bin;
+                    const int t = prow & (TP - 1), h = prow >> tp_log2;
+                    if (t < T && h < H && bin < F) {
+                        const int i = t * F + bin;
                         v = (double)L0.weights[(size_t)h * I + i] * a[(size_t)i] * wscale;
                     }
                     uint16_t hi, lo;

@@ -76,7 +76,9 @@ struct FusedDesc {
     int skew;                   // f16 elements inserted after every `hop` staged samples (bank spreading)
     unsigned hop_magic;         // ceil(2^32 / hop): i / hop == umulhi(i, hop_magic) for i < 2^16
     int runs, seg_evals;        // passes per workgroup, evaluations per workgroup segment
-    int ps;                     // slot stride of the partial-product ring (frames per pass + T - 1)
+    int ps;                     // slots of the partial-product ring (frames per pass + T - 1)
+    int tl, tp_log2;            // ring row length (T rounded up to even); partial rows are h * 2^tp_log2 + t
+    int ring_spare;             // float index of 256 spare words behind the ring (padding rows land there)
     float w_unscale;            // 1 / (power-of-two scale of the folded first-layer weights)
     int lds_dfrag, lds_hi, lds_lo, lds_pbuf, lds_stat, lds_red, lds_total;   // byte offsets
     const uint4 *dfrag;         // [KS][re,im][hi,lo][64 lanes] A-operand fragments of the DFT basis
@@ -87,6 +89,7 @@ struct FusedDesc {
     const float *w1, *b1;       // layer 1, row-major [n_out][H] (2-layer nets)
     const float *out_params;    // per output fn: y, gain[n_out], xoff[n_out]
     const double *thresholds;   // [n_out]
+    const float *zeros;         // 16 zero bytes (source of out-of-range quads)
 };
 
 hipError_t launch_fused(const FusedDesc &d, const float *samples, int64_t stride, int C, int64_t S, int64_t J,

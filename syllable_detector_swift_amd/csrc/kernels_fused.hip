@@ -15,16 +15,27 @@
 //     is just the address j*hop: no per-frame copy, no ring).  It runs on the matrix cores as
 //     v_mfma_f32_32x32x16_f16 with every operand split into f16 hi + lo (block floating point,
 //     power-of-two scales): hi*hi + hi*lo + lo*hi reproduces an fp32 product to ~2^-21, and the
-//     fp32 accumulate keeps the sum; measured error vs the fp64 anchor is below an fp32 FFT's;
+//     fp32 accumulate keeps the sum; measured error vs the fp64 anchor is below an fp32 FFT's.
+//     The split of the samples happens on the fragment a lane has just read from LDS, in the
+//     issue slots the matrix pipe leaves free (4 VALU per MFMA), so it costs no time of its own;
 //   * the result tile has frames on lanes and bins in registers, which is exactly the B-operand
 //     layout of the next MFMA, so the first layer -- folded with the affine input maps into
 //     W' = W0 o gain, split per time slot into T*H partial dot products per frame -- runs on the
 //     matrix cores too with no data movement;
-//   * evaluation e is the diagonal sum  sum_t P[(t,h)][e+t]  over an LDS ring of partials plus a
+//   * evaluation e is the sum over t of partial (t,h) of frame e+t.  Each partial is stored at
+//     ring[h][e][t], so an evaluation reads T contiguous floats per hidden unit, plus a
 //     per-window statistic (l2 norm / min-max / mean-std) -- every frame is transformed once,
 //     instead of T times as in the reference's sliding re-read.
 //
-// gfx950 only.  wave = 64; 256-thread workgroups, one per CU (LDS-limited).
+// Workgroup = 4 waves x 32 frames = 128 frames per pass; a workgroup walks `runs` consecutive
+// passes of one channel, carrying the incomplete evaluations' partials in LDS.  HBM traffic =
+// every sample once (+ (T-1) frames of overlap per segment) + 5 bytes per evaluation.
+//
+// The kernel is instruction-issue bound (one wave per SIMD: LDS holds 64 KB of basis fragments,
+// 68 KB of samples and the ring), so the code below is written to keep the per-pass instruction
+// count low: hardware-bounds-checked buffer loads, precomputed LDS offsets, no divergent guards.
+//
+// gfx950 only.  wave = 64.
 
 #include "kernels.hpp"
 
@@ -33,14 +44,13 @@ namespace sd {
 namespace {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef unsigned int uint32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kBlock = 256;
 constexpr int kTile = kFusedTileFrames;
-
-struct __attribute__((packed, aligned(4))) float4_u { float x, y, z, w; };   // 4-byte aligned 16-byte load
 
 __device__ __forceinline__ half8 as_half8(uint32x4 v)
 {
@@ -48,9 +58,16 @@ __device__ __forceinline__ half8 as_half8(uint32x4 v)
     c.u = v;
     return c.h;
 }
+__device__ __forceinline__ floatx4 as_floatx4(uint32x4 v)
+{
+    union { uint32x4 u; floatx4 f; } c;
+    c.u = v;
+    return c.f;
+}
 
-// f32 -> f16 hi + f16 lo with hi = the top 11 significand bits (so the conversion is exact) and
-// lo = the exact remainder rounded toward zero: hi + lo == x to 2^-21 relative.
+// f32 pair -> packed f16 hi pair + packed f16 lo pair, hi = the top 11 significand bits (the
+// conversion is then exact in any rounding mode), lo = the exact remainder rounded toward zero:
+// hi + lo == x to 2^-21 relative.  6 VALU instructions per pair.
 __device__ __forceinline__ void split_pair(float a, float b, unsigned &hi, unsigned &lo)
 {
     const float ah = __uint_as_float(__float_as_uint(a) & 0xFFFFE000u);
@@ -62,19 +79,47 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned &hi, unsig
     lo = cl.u;
 }
 
+__device__ __forceinline__ void split8(floatx4 lo4, floatx4 hi4, half8 &h, half8 &l)
+{
+    uint32x4 uh, ul;
+    unsigned a, b;
+    split_pair(lo4[0], lo4[1], a, b); uh[0] = a; ul[0] = b;
+    split_pair(lo4[2], lo4[3], a, b); uh[1] = a; ul[1] = b;
+    split_pair(hi4[0], hi4[1], a, b); uh[2] = a; ul[2] = b;
+    split_pair(hi4[2], hi4[3], a, b); uh[3] = a; ul[3] = b;
+    h = as_half8(uh);
+    l = as_half8(ul);
+}
+
 __device__ __forceinline__ float pow2f(int e)   // 2^e for e in [-126, 127]
 {
     return __uint_as_float((unsigned)(e + 127) << 23);
 }
 
+// max(m, |x|, |y|) in one instruction (fmaxf's NaN canonicalisation costs an extra op per value)
+__device__ __forceinline__ float absmax3(float m, float x, float y)
+{
+    float r;
+    asm("v_max3_f32 %0, |%1|, |%2|, %3" : "=v"(r) : "v"(x), "v"(y), "v"(m));
+    return r;
+}
+
+// Transfer functions (NeuralNet.swift:185-228).  tanh/logistic through the hardware exp2/rcp:
+// absolute error below 4e-7, far inside the 1e-5 bar, at a tenth of the library call's cost.
+// NaN in, NaN out (silence gives 0/0 in l2normalize; the reference then never detects).
 __device__ __forceinline__ float transfer_fn(int tf, float x)
 {
-    switch (tf) {
-    case 0: return tanhf(x);                         // TanSig  NeuralNet.swift:189-194
-    case 1: return 1.0f / (expf(-x) + 1.0f);         // LogSig  :196-215
-    case 3: return fminf(fmaxf(x, 0.0f), 1.0f);      // SatLin  :223-228
-    default: return x;                               // PureLin :217-221
+    if (tf == 0) {                                   // TanSig
+        const float t = __builtin_amdgcn_exp2f(fminf(fabsf(x), 20.0f) * 2.885390081777927f);   // e^{2|x|}
+        const float r = 1.0f - 2.0f * __builtin_amdgcn_rcpf(t + 1.0f);
+        return x != x ? x : copysignf(r, x);
     }
+    if (tf == 1) {                                   // LogSig
+        const float t = __builtin_amdgcn_exp2f(fminf(fmaxf(-x, -80.0f), 80.0f) * 1.4426950408889634f);
+        return x != x ? x : __builtin_amdgcn_rcpf(t + 1.0f);
+    }
+    if (tf == 3) return x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x);   // SatLin
+    return x;                                        // PureLin
 }
 
 __device__ __forceinline__ floatx16 mfma16(half8 a, half8 b, floatx16 c)
@@ -82,34 +127,49 @@ __device__ __forceinline__ floatx16 mfma16(half8 a, half8 b, floatx16 c)
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 
+// This thread's quads of the pass whose first sample is `first` (row-relative).  The buffer
+// descriptor ends one past the last sample any existing frame reads, so quads beyond it come back
+// as zeros from the hardware bounds check: no per-lane guards.
+template <int NL>
+__device__ __forceinline__ void load_tile(const float *row, int64_t first, int64_t s_eff, int nsmp, int nload, int tid,
+                                          uint32x4 (&v)[NL])
+{
+    int64_t left = s_eff - first;
+    left = left < 0 ? 0 : (left > nsmp ? nsmp : left);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(row + first), 0, (int)left * 4, 0x00020000);
+#pragma unroll
+    for (int k = 0; k < NL; k++)
+        if (k < nload) v[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * tid + 4096 * k, 0, 0);
+}
+
 template <int KS, int MT>
 __global__ void __launch_bounds__(kBlock, 1)
-fused_kernel(FusedDesc d, const float *__restrict__ samples, int64_t stride, int64_t S, int64_t E,
+fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t stride, int64_t s_eff, int64_t E,
              float *__restrict__ outputs, uint8_t *__restrict__ flags)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32x4 *lds_dfrag = reinterpret_cast<uint32x4 *>(smem + d.lds_dfrag);
-    _Float16 *smp_hi = reinterpret_cast<_Float16 *>(smem + d.lds_hi);
-    _Float16 *smp_lo = reinterpret_cast<_Float16 *>(smem + d.lds_lo);
-    float *pbuf = reinterpret_cast<float *>(smem + d.lds_pbuf);     // rows [0,TH): partials; rows TH, TH+1: window statistics
+    float *smp = reinterpret_cast<float *>(smem + d.lds_hi);       // staged samples (scaled fp32)
+    float *ring = reinterpret_cast<float *>(smem + d.lds_pbuf);    // [H][PS evaluations][TL]: partial (t,h) of frame e+t
+    float *stat = reinterpret_cast<float *>(smem + d.lds_stat);    // [2][PS frames]: per-frame statistics
     float *red = reinterpret_cast<float *>(smem + d.lds_red);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31;          // frame column inside the wave's 32-frame tile
-    const int hh = lane >> 5;         // lane half: selects k rows 8h..8h+7 of an operand, rows +4 of a result
+    const int hh = lane >> 5;         // lane half: k rows 8h..8h+7 of an operand, rows +4 of a result
     const int c = blockIdx.y;
     const int64_t e_b = (int64_t)blockIdx.x * d.seg_evals;
     if (e_b >= E) return;
     const int64_t e_e = (e_b + d.seg_evals < E) ? e_b + d.seg_evals : E;
     const float *row = samples + (int64_t)c * stride;
-    const int PS = d.ps;
-    const int T = d.T, F = d.F, H = d.H, TH = d.TH;
+    const int PS = d.ps, T = d.T, TL = d.tl, H = d.H;
+    const int fl = 32 * wave + r;     // this lane's frame inside the pass
 
     // DFT basis fragments -> LDS (64 KB for W = 256), once per workgroup
     for (int i = tid; i < KS * 4 * 64; i += kBlock) lds_dfrag[i] = reinterpret_cast<const uint32x4 *>(d.dfrag)[i];
-    // folded first-layer fragments and per-k-step sample offsets -> registers
+    // folded first-layer fragments -> registers
     half8 wfr[MT][2][2];
 #pragma unroll
     for (int m = 0; m < MT; m++)
@@ -118,143 +178,187 @@ fused_kernel(FusedDesc d, const float *__restrict__ samples, int64_t stride, int
 #pragma unroll
             for (int p = 0; p < 2; p++)
                 wfr[m][s][p] = as_half8(reinterpret_cast<const uint32x4 *>(d.wfrag)[((m * 2 + s) * 2 + p) * 64 + lane]);
+    // where partial row (m, g) of this lane's frame goes in the ring: row = h*TP + t (TP = 2^tp_log2 >= T),
+    // it belongs to evaluation slot fl - t + (T-1) at position t; padding rows go to a spare word.
+    int poff[MT][16];
+#pragma unroll
+    for (int m = 0; m < MT; m++)
+#pragma unroll
+        for (int g = 0; g < 16; g++) {
+            const int prow = 32 * m + (g & 3) + 8 * (g >> 2) + 4 * hh;
+            const int t = prow & ((1 << d.tp_log2) - 1), h = prow >> d.tp_log2;
+            poff[m][g] = (t < TL && h < H) ? ((h * PS + fl - t + (T - 1)) * TL + t) : d.ring_spare + tid;
+        }
+    // this lane's frame in the staged stream, and where k-step ks of lane half hh starts inside it
+    const float *fptr = smp + fl * (d.hop + d.skew);
     int ko[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ks++) ko[ks] = d.koff[ks * 2 + hh];
-    const int fbase = (32 * wave + r) * (d.hop + d.skew);
+    const int wr0 = d.skew == 0 ? 4 * tid : 0;
+
+    uint32x4 v[kFusedMaxLoads];
+    load_tile(row, e_b * d.hop + d.gap, s_eff, d.nsmp, d.nload, tid, v);
 
     for (int pass = 0; pass < d.runs; pass++) {
         const int64_t jp = e_b + (int64_t)kTile * pass;       // first frame of this pass
         if (jp - (T - 1) >= e_e) break;
 
-        // ---------------- stage: HBM -> registers -> (block max, scale, hi/lo split) -> LDS
-        const int64_t g0 = jp * d.hop + d.gap;                 // frame j covers [j*hop + gap, j*hop + gap + W)
-        float4 v[kFusedMaxLoads];
+        // ---------------- block floating point: scale the tile so its largest sample is in [2^13, 2^14)
         float amax = 0.0f;
 #pragma unroll
-        for (int k = 0; k < kFusedMaxLoads; k++) {
-            v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < kFusedMaxLoads; k++)
             if (k < d.nload) {
-                const int i = 4 * (tid + kBlock * k);
-                const int64_t gi = g0 + i;
-                if (i < d.nsmp) {
-                    if (gi + 3 < S) {
-                        const float4_u t = *reinterpret_cast<const float4_u *>(row + gi);
-                        v[k] = make_float4(t.x, t.y, t.z, t.w);
-                    } else {
-                        if (gi < S) v[k].x = row[gi];
-                        if (gi + 1 < S) v[k].y = row[gi + 1];
-                        if (gi + 2 < S) v[k].z = row[gi + 2];
-                    }
-                }
-                amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[k].x), fabsf(v[k].y))), fmaxf(fabsf(v[k].z), fabsf(v[k].w)));
+                const floatx4 f = as_floatx4(v[k]);
+                amax = absmax3(absmax3(amax, f[0], f[1]), f[2], f[3]);
             }
-        }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
         if (lane == 0) red[wave] = amax;
-        __syncthreads();
+        __syncthreads();                                      // (A) previous pass fully consumed
         amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-        // block floating point: scale the tile so its largest sample lands in [2^13, 2^14)
         int se = 13 - (int)((__float_as_uint(amax) >> 23) & 0xffu) + 127;   // exponent of the scale
         se = amax > 0.0f ? (se < -100 ? -100 : (se > 100 ? 100 : se)) : 0;
+        se = __builtin_amdgcn_readfirstlane(se);
         const float sx = pow2f(se);
+        if (d.skew == 0) {
 #pragma unroll
-        for (int k = 0; k < kFusedMaxLoads; k++) {
-            if (k < d.nload) {
-                const int i = 4 * (tid + kBlock * k);
-                if (i < d.nsmp) {
-                    unsigned h0, l0, h1, l1;
-                    split_pair(v[k].x * sx, v[k].y * sx, h0, l0);
-                    split_pair(v[k].z * sx, v[k].w * sx, h1, l1);
-                    const int p = i + d.skew * (int)__umulhi((unsigned)i, d.hop_magic);
-                    *reinterpret_cast<uint2 *>(smp_hi + p) = make_uint2(h0, h1);
-                    *reinterpret_cast<uint2 *>(smp_lo + p) = make_uint2(l0, l1);
+            for (int k = 0; k < kFusedMaxLoads; k++)
+                if (k < d.nload) {
+                    const floatx4 f = as_floatx4(v[k]);
+                    *reinterpret_cast<floatx4 *>(smp + wr0 + 1024 * k) = f * sx;
                 }
+        } else {
+#pragma unroll
+            for (int k = 0; k < kFusedMaxLoads; k++)
+                if (k < d.nload) {
+                    const int i = 4 * (tid + kBlock * k);     // quads past nsmp hold zeros and land in the buffer's slack
+                    const floatx4 f = as_floatx4(v[k]);
+                    *reinterpret_cast<floatx4 *>(smp + i + d.skew * (int)__umulhi((unsigned)i, d.hop_magic)) = f * sx;
+                }
+        }
+        // evaluations the previous pass left incomplete move to the front of the ring (with their
+        // frames' statistics); everything behind them starts this pass empty
+        if (pass > 0) {
+            const int n_carry = (T - 1) * TL;
+            for (int idx = tid; idx < H * n_carry; idx += kBlock) {
+                const int h = idx / n_carry, rem = idx - h * n_carry;
+                ring[h * PS * TL + rem] = ring[h * PS * TL + kTile * TL + rem];
+            }
+            if (tid < 2 * (T - 1)) {
+                const int k = tid / (T - 1), t = tid - k * (T - 1);
+                stat[k * PS + t] = stat[k * PS + kTile + t];
             }
         }
-        __syncthreads();
+        __syncthreads();                                      // (B) samples staged
 
-        // ---------------- band-limited DFT of this wave's 32 frames on the matrix cores
+        // next pass's samples: issued now, consumed after this pass's matrix work
+        if (pass + 1 < d.runs) load_tile(row, (jp + kTile) * d.hop + d.gap, s_eff, d.nsmp, d.nload, tid, v);
+
+        // ---------------- band-limited DFT of this wave's 32 frames on the matrix cores.
+        // Software pipeline: while the six MFMAs of k-step ks execute, the lane's next 8 samples
+        // (already in registers) are split into f16 hi/lo and the fragments after that are fetched.
         floatx16 acc_re = {0}, acc_im = {0};
+        floatx4 s0 = *reinterpret_cast<const floatx4 *>(fptr + ko[0]);
+        floatx4 s1 = *reinterpret_cast<const floatx4 *>(fptr + ko[0] + 4);
+        half8 bh, bl;
+        split8(s0, s1, bh, bl);
+        if (KS > 1) {
+            s0 = *reinterpret_cast<const floatx4 *>(fptr + ko[1]);
+            s1 = *reinterpret_cast<const floatx4 *>(fptr + ko[1] + 4);
+        }
+        uint32x4 a0 = lds_dfrag[0 * 64 + lane], a1 = lds_dfrag[1 * 64 + lane];
+        uint32x4 a2 = lds_dfrag[2 * 64 + lane], a3 = lds_dfrag[3 * 64 + lane];
 #pragma unroll
         for (int ks = 0; ks < KS; ks++) {
-            const _Float16 *ph = smp_hi + fbase + ko[ks];
-            const _Float16 *pl = smp_lo + fbase + ko[ks];
-            const half4 bh0 = *reinterpret_cast<const half4 *>(ph), bh1 = *reinterpret_cast<const half4 *>(ph + 4);
-            const half4 bl0 = *reinterpret_cast<const half4 *>(pl), bl1 = *reinterpret_cast<const half4 *>(pl + 4);
-            const half8 bh = __builtin_shufflevector(bh0, bh1, 0, 1, 2, 3, 4, 5, 6, 7);
-            const half8 bl = __builtin_shufflevector(bl0, bl1, 0, 1, 2, 3, 4, 5, 6, 7);
-            const half8 a_re_h = as_half8(lds_dfrag[((ks * 2 + 0) * 2 + 0) * 64 + lane]);
-            const half8 a_re_l = as_half8(lds_dfrag[((ks * 2 + 0) * 2 + 1) * 64 + lane]);
-            const half8 a_im_h = as_half8(lds_dfrag[((ks * 2 + 1) * 2 + 0) * 64 + lane]);
-            const half8 a_im_l = as_half8(lds_dfrag[((ks * 2 + 1) * 2 + 1) * 64 + lane]);
-            acc_re = mfma16(a_re_h, bh, acc_re);
-            acc_im = mfma16(a_im_h, bh, acc_im);
-            acc_re = mfma16(a_re_h, bl, acc_re);
-            acc_im = mfma16(a_im_h, bl, acc_im);
-            acc_re = mfma16(a_re_l, bh, acc_re);
-            acc_im = mfma16(a_im_l, bh, acc_im);
+            const half8 a_re_h = as_half8(a0), a_re_l = as_half8(a1), a_im_h = as_half8(a2), a_im_l = as_half8(a3);
+            const half8 cbh = bh, cbl = bl;
+            const floatx4 n0 = s0, n1 = s1;
+            if (ks + 1 < KS) {                                // fragments of the next k-step
+                a0 = lds_dfrag[((ks + 1) * 4 + 0) * 64 + lane];
+                a1 = lds_dfrag[((ks + 1) * 4 + 1) * 64 + lane];
+                a2 = lds_dfrag[((ks + 1) * 4 + 2) * 64 + lane];
+                a3 = lds_dfrag[((ks + 1) * 4 + 3) * 64 + lane];
+            }
+            if (ks + 2 < KS) {                                // raw samples two k-steps ahead
+                s0 = *reinterpret_cast<const floatx4 *>(fptr + ko[ks + 2]);
+                s1 = *reinterpret_cast<const floatx4 *>(fptr + ko[ks + 2] + 4);
+            }
+            acc_re = mfma16(a_re_h, cbh, acc_re);
+            acc_im = mfma16(a_im_h, cbh, acc_im);
+            acc_re = mfma16(a_re_h, cbl, acc_re);
+            acc_im = mfma16(a_im_h, cbl, acc_im);
+            acc_re = mfma16(a_re_l, cbh, acc_re);
+            acc_im = mfma16(a_im_l, cbh, acc_im);
+            if (ks + 1 < KS) split8(n0, n1, bh, bl);          // 24 VALU, scheduled into the MFMA shadows below
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   // 4 VALU
+            }
         }
 
         // ---------------- magnitude (zvabs/2 :329-333 or zvmags/4 :270-274), scaling
         // (SyllableDetector.swift:184-212), per-frame statistic, f16 split for the next MFMA.
         // Result layout: column = frame r, register g of lane half hh = bin row (g&3) + 8(g>>2) + 4hh.
         const float inv = pow2f(-se - 13);                   // accumulators hold X * sx * 2^13
-        // scale that keeps the column inside f16 range for the layer-0 MFMA (exact power of two)
-        float cs = 1.0f;
+        float cs = 1.0f;                                     // keeps the column inside f16 range (power of two)
         if (d.scaling == 0) cs = d.power_mode ? pow2f(2 * (se < 40 ? (se > -40 ? se : -40) : 40) - 30) : pow2f(se - 8);
+        const int fh = d.F - 4 * hh;                          // register g holds a band row iff (g&3) + 8(g>>2) < fh
         float cval[16];
-        float st0 = 0.0f, st1 = 0.0f;
-        if (d.norm == 2) { st0 = INFINITY; st1 = -INFINITY; }
 #pragma unroll
         for (int g = 0; g < 16; g++) {
             const float re = acc_re[g] * inv, im = acc_im[g] * inv;
-            const float pw = re * re + im * im;
-            float x = d.power_mode ? pw : sqrtf(pw);
-            if (d.scaling == 1) x = logf(x);
-            else if (d.scaling == 2) x = 20.0f * log10f(x);
-            const bool valid = ((g & 3) + 8 * (g >> 2) + 4 * hh) < F;
-            x = valid ? x : 0.0f;
-            cval[g] = x;
-            if (d.norm == 1) st0 = fmaf(x, x, st0);
-            else if (d.norm == 2) { st0 = valid ? fminf(st0, x) : st0; st1 = valid ? fmaxf(st1, x) : st1; }
-            else if (d.norm == 3) st0 += x;
+            const float pw = fmaf(re, re, im * im);
+            cval[g] = d.power_mode ? pw : __builtin_amdgcn_sqrtf(pw);
         }
+        if (d.scaling != 0) {
+            const float k = d.scaling == 1 ? 0.6931471805599453f : 6.020599913279624f;   // ln 2, 20 log10 2
+#pragma unroll
+            for (int g = 0; g < 16; g++) cval[g] = k * __builtin_amdgcn_logf(cval[g]);   // v_log_f32 = log2
+        }
+        if (d.F < 32 || d.scaling != 0) {
+#pragma unroll
+            for (int g = 0; g < 16; g++) cval[g] = ((g & 3) + 8 * (g >> 2)) < fh ? cval[g] : 0.0f;
+        }
+        const int slot = (T - 1) + fl;
         if (d.norm == 1) {
+            float st0 = 0.0f;
+#pragma unroll
+            for (int g = 0; g < 16; g++) st0 = fmaf(cval[g], cval[g], st0);
             st0 += __shfl_xor(st0, 32, 64);
+            if (hh == 0) stat[slot] = st0;
         } else if (d.norm == 2) {
-            st0 = fminf(st0, __shfl_xor(st0, 32, 64));
-            st1 = fmaxf(st1, __shfl_xor(st1, 32, 64));
-        } else if (d.norm == 3) {
-            st0 += __shfl_xor(st0, 32, 64);
-            st0 = st0 / (float)F;                            // mean of this frame's column
+            float st0 = INFINITY, st1 = -INFINITY;
 #pragma unroll
             for (int g = 0; g < 16; g++) {
-                const bool valid = ((g & 3) + 8 * (g >> 2) + 4 * hh) < F;
+                const bool valid = ((g & 3) + 8 * (g >> 2)) < fh;
+                st0 = valid ? fminf(st0, cval[g]) : st0;
+                st1 = valid ? fmaxf(st1, cval[g]) : st1;
+            }
+            st0 = fminf(st0, __shfl_xor(st0, 32, 64));
+            st1 = fmaxf(st1, __shfl_xor(st1, 32, 64));
+            if (hh == 0) { stat[slot] = st0; stat[PS + slot] = st1; }
+        } else if (d.norm == 3) {
+            float st0 = 0.0f, st1 = 0.0f;
+#pragma unroll
+            for (int g = 0; g < 16; g++) st0 += cval[g];
+            st0 += __shfl_xor(st0, 32, 64);
+            st0 = st0 / (float)d.F;                           // mean of this frame's column
+#pragma unroll
+            for (int g = 0; g < 16; g++) {
                 const float dlt = cval[g] - st0;
-                st1 = valid ? fmaf(dlt, dlt, st1) : st1;     // M2 of this frame's column
+                st1 = ((g & 3) + 8 * (g >> 2)) < fh ? fmaf(dlt, dlt, st1) : st1;   // M2 of this frame's column
             }
             st1 += __shfl_xor(st1, 32, 64);
-        }
-        const int slot = (T - 1) + 32 * wave + r;
-        if (hh == 0 && d.norm != 0) {
-            pbuf[TH * PS + slot] = st0;
-            pbuf[(TH + 1) * PS + slot] = st1;
+            if (hh == 0) { stat[slot] = st0; stat[PS + slot] = st1; }
         }
         half8 bh2[2], bl2[2];
 #pragma unroll
         for (int s = 0; s < 2; s++) {
-            uint32x4 uh, ul;
+            floatx4 lo4, hi4;
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                unsigned a, b;
-                split_pair(cval[8 * s + 2 * j] * cs, cval[8 * s + 2 * j + 1] * cs, a, b);
-                uh[j] = a;
-                ul[j] = b;
-            }
-            bh2[s] = as_half8(uh);
-            bl2[s] = as_half8(ul);
+            for (int j = 0; j < 4; j++) { lo4[j] = cval[8 * s + j] * cs; hi4[j] = cval[8 * s + 4 + j] * cs; }
+            split8(lo4, hi4, bh2[s], bl2[s]);
         }
 
         // ---------------- first layer, folded and split per time slot: P[(t,h)][frame] on the matrix cores
@@ -269,108 +373,84 @@ fused_kernel(FusedDesc d, const float *__restrict__ samples, int64_t stride, int
                 pacc = mfma16(wfr[m][s][1], bh2[s], pacc);
             }
 #pragma unroll
-            for (int g = 0; g < 16; g++) {
-                const int prow = 32 * m + (g & 3) + 8 * (g >> 2) + 4 * hh;
-                if (prow < TH) pbuf[prow * PS + slot] = pacc[g] * unscale;
-            }
+            for (int g = 0; g < 16; g++) ring[poff[m][g]] = pacc[g] * unscale;
         }
-        __syncthreads();
+        __syncthreads();                                      // (C) partials of all 128 frames visible
 
-        // ---------------- evaluations completed by this pass: e = jp - (T-1) + q uses slots q..q+T-1
+        // ---------------- evaluations completed by this pass: slot q = e - (jp - (T-1)); lane half hh
+        // owns hidden units hh, hh+2, ...; both halves hold the same evaluation
         {
-            const int q = 32 * wave + r;
+            const int q = fl;
             const int64_t e = jp - (T - 1) + q;
             const bool valid = e >= e_b && e < e_e;
             float alpha = 1.0f, beta = 0.0f;
-            const float *s0 = pbuf + TH * PS + q, *s1 = pbuf + (TH + 1) * PS + q;
             if (d.norm == 1) {                                // L2Normalize, NeuralNet.swift:47-59
                 float ssw = 0.0f;
-                for (int t = 0; t < T; t++) ssw += s0[t];
-                alpha = 1.0f / sqrtf(ssw);
+                for (int t = 0; t < T; t++) ssw += stat[q + t];
+                alpha = __builtin_amdgcn_rsqf(ssw);
             } else if (d.norm == 2) {                         // Normalize, :69-96
                 float mn = INFINITY, mx = -INFINITY;
-                for (int t = 0; t < T; t++) { mn = fminf(mn, s0[t]); mx = fmaxf(mx, s1[t]); }
+                for (int t = 0; t < T; t++) { mn = fminf(mn, stat[q + t]); mx = fmaxf(mx, stat[PS + q + t]); }
                 const float range = mx - mn;
                 if (range == 0.0f) { alpha = 0.0f; beta = -1.0f; }
                 else { alpha = 2.0f / range; beta = (0.0f - mn - mx) / range; }
             } else if (d.norm == 3) {                         // NormalizeStd, :105-108 (population sigma)
                 float n = 0.0f, mean = 0.0f, m2 = 0.0f;
                 for (int t = 0; t < T; t++) {                 // pairwise-stable combination of per-frame (mean, M2)
-                    const float nb = (float)F, tot = n + nb, dlt = s0[t] - mean;
+                    const float nb = (float)d.F, tot = n + nb, dlt = stat[q + t] - mean;
                     mean += dlt * nb / tot;
-                    m2 += s1[t] + dlt * dlt * n * nb / tot;
+                    m2 += stat[PS + q + t] + dlt * dlt * n * nb / tot;
                     n = tot;
                 }
                 const float sd = sqrtf(m2 / (float)d.I);
                 alpha = 1.0f / sd;
                 beta = -mean / sd;
             }
-            // hidden unit h of lane half hh: h = 2*i + hh
-            float act[8];
+            const int64_t obase = ((int64_t)c * E + e) * d.n_out;
+            float y[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            bool hit = false;
+            for (int h = hh; h < H; h += 2) {
+                const floatx2 *pp = reinterpret_cast<const floatx2 *>(ring + (h * PS + q) * TL);
+                float z0 = 0.0f, z1 = 0.0f;
+                for (int t = 0; t < TL / 2; t++) { const floatx2 p2 = pp[t]; z0 += p2[0]; z1 += p2[1]; }
+                float a = transfer_fn(d.tf0, fmaf(alpha, z0 + z1, fmaf(beta, d.rvec[h], d.bias0[h])));
+                if (d.n_layers == 2) {
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const int h = 2 * i + hh;
-                act[i] = 0.0f;
-                if (h < H) {
-                    float z = 0.0f;
-                    for (int t = 0; t < T; t++) z += pbuf[(t * H + h) * PS + q + t];
-                    act[i] = transfer_fn(d.tf0, fmaf(alpha, z, fmaf(beta, d.rvec[h], d.bias0[h])));
+                    for (int o = 0; o < 4; o++)
+                        if (o < d.n_out) y[o] = fmaf(d.w1[o * H + h], a, y[o]);
+                } else {
+                    for (int k = 0; k < d.n_out_fns; k++) {                    // reverse maps, NeuralNet.swift:137-142 / :175-180
+                        const float *op = d.out_params + k * (1 + 2 * d.n_out);
+                        a = (a - op[0]) / op[1 + h] + op[1 + d.n_out + h];
+                    }
+                    if (valid && outputs) outputs[obase + h] = a;
+                    if (h == 0 || d.rule == 1) hit = hit || ((double)a >= d.thresholds[h]);
                 }
             }
-            const int64_t obase = ((int64_t)c * E + e) * d.n_out;
             if (d.n_layers == 2) {
-                bool hit = false;
 #pragma unroll
                 for (int o = 0; o < 4; o++) {
                     if (o < d.n_out) {
-                        float y = 0.0f;
-#pragma unroll
-                        for (int i = 0; i < 8; i++) {
-                            const int h = 2 * i + hh;
-                            if (h < H) y = fmaf(d.w1[o * H + h], act[i], y);
-                        }
-                        y += __shfl_xor(y, 32, 64);
-                        y = transfer_fn(d.tf1, y + d.b1[o]);
-                        for (int k = 0; k < d.n_out_fns; k++) {       // reverse maps, NeuralNet.swift:137-142 / :175-180
-                            const float *op = d.out_params + k * (1 + 2 * d.n_out);
-                            y = (y - op[0]) / op[1 + o] + op[1 + d.n_out + o];
-                        }
-                        if (valid && hh == 0 && outputs) outputs[obase + o] = y;
-                        if (o == 0 || d.rule == 1) hit = hit || ((double)y >= d.thresholds[o]);
-                    }
-                }
-                if (valid && hh == 0 && flags) flags[(int64_t)c * E + e] = hit ? 1 : 0;
-            } else {
-                bool hit = false;
-#pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    const int h = 2 * i + hh;
-                    if (h < H) {
-                        float y = act[i];
+                        float yo = y[o] + __shfl_xor(y[o], 32, 64);
+                        yo = transfer_fn(d.tf1, yo + d.b1[o]);
                         for (int k = 0; k < d.n_out_fns; k++) {
                             const float *op = d.out_params + k * (1 + 2 * d.n_out);
-                            y = (y - op[0]) / op[1 + h] + op[1 + d.n_out + h];
+                            yo = (yo - op[0]) / op[1 + o] + op[1 + d.n_out + o];
                         }
-                        if (valid && outputs) outputs[obase + h] = y;
-                        if (h == 0 || d.rule == 1) hit = hit || ((double)y >= d.thresholds[h]);
+                        if (valid && hh == 0 && outputs) outputs[obase + o] = yo;
+                        if (o == 0 || d.rule == 1) hit = hit || ((double)yo >= d.thresholds[o]);
                     }
                 }
-                const bool other = __shfl_xor((int)hit, 32, 64) != 0;
-                if (valid && hh == 0 && flags) flags[(int64_t)c * E + e] = (hit || other) ? 1 : 0;
+            } else {
+                hit = hit || (__shfl_xor((int)hit, 32, 64) != 0);
             }
+            if (valid && hh == 0 && flags) flags[(int64_t)c * E + e] = hit ? 1 : 0;
         }
-        __syncthreads();
-        // ---------------- keep the last T-1 frames' partials and statistics for the next pass
-        for (int idx = tid; idx < (TH + 2) * (T - 1); idx += kBlock) {
-            const int prow = idx / (T - 1), t = idx - prow * (T - 1);
-            pbuf[prow * PS + t] = pbuf[prow * PS + kTile + t];
-        }
-        __syncthreads();
     }
 }
 
 template <int KS, int MT>
-hipError_t launch_one(const FusedDesc &d, const float *samples, int64_t stride, int C, int64_t S, int64_t E,
+hipError_t launch_one(const FusedDesc &d, const float *samples, int64_t stride, int C, int64_t s_eff, int64_t E,
                       float *outputs, uint8_t *flags, hipStream_t stream)
 {
     auto kern = fused_kernel<KS, MT>;
@@ -378,7 +458,7 @@ hipError_t launch_one(const FusedDesc &d, const float *samples, int64_t stride, 
     if (st != hipSuccess) return st;
     const int64_t segs = (E + d.seg_evals - 1) / d.seg_evals;
     dim3 grid((unsigned)segs, (unsigned)C);
-    hipLaunchKernelGGL(kern, grid, dim3(kBlock), (size_t)d.lds_total, stream, d, samples, stride, S, E, outputs, flags);
+    hipLaunchKernelGGL(kern, grid, dim3(kBlock), (size_t)d.lds_total, stream, d, samples, stride, s_eff, E, outputs, flags);
     return hipGetLastError();
 }
 
@@ -392,10 +472,12 @@ int fused_supported(int KS, int MT)
 hipError_t launch_fused(const FusedDesc &d, const float *samples, int64_t stride, int C, int64_t S, int64_t J,
                         int64_t E, float *outputs, uint8_t *flags, hipStream_t stream)
 {
-    (void)J;
+    (void)S;
     if (E <= 0 || C <= 0) return hipSuccess;
+    // one past the last sample an existing frame reads: frame J-1 covers [(J-1)*hop + gap, ... + W)
+    const int64_t s_eff = (J - 1) * (int64_t)d.hop + d.gap + d.W;
 #define SD_CASE(K, M) \
-    if (d.KS == K && d.MT == M) return launch_one<K, M>(d, samples, stride, C, S, E, outputs, flags, stream)
+    if (d.KS == K && d.MT == M) return launch_one<K, M>(d, samples, stride, C, s_eff, E, outputs, flags, stream)
     SD_CASE(16, 1);
     SD_CASE(16, 2);
     SD_CASE(16, 4);

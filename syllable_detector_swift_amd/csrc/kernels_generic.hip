@@ -142,7 +142,7 @@ __device__ __forceinline__ float transfer(int tf, float x)
     switch (tf) {
     case 0: return tanhf(x);                         // TanSig  NeuralNet.swift:189-194
     case 1: return 1.0f / (expf(-x) + 1.0f);         // LogSig  :196-215
-    case 3: return fminf(fmaxf(x, 0.0f), 1.0f);      // SatLin  :223-228
+    case 3: return x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x);   // SatLin  :223-228 (NaN stays NaN)
     default: return x;                               // PureLin :217-221
     }
 }

@@ -208,6 +208,8 @@ int upload_fused(syldet *h)
     const size_t o_k = put(p.koff.data(), p.koff.size() * 4), o_b = put(p.bias0.data(), p.bias0.size() * 4);
     const size_t o_r = put(p.rvec.data(), p.rvec.size() * 4), o_w1 = put(p.w1.data(), p.w1.size() * 4);
     const size_t o_b1 = put(p.b1.data(), p.b1.size() * 4), o_op = put(p.out_params.data(), p.out_params.size() * 4);
+    const float zero4[4] = {0.f, 0.f, 0.f, 0.f};
+    const size_t o_z = put(zero4, sizeof(zero4));
     if (int st = h->d_fused.reserve(blob.size())) return st;
     SYLDET_HIP(hipMemcpy(h->d_fused.ptr, blob.data(), blob.size(), hipMemcpyHostToDevice));
     unsigned char *base = (unsigned char *)h->d_fused.ptr;
@@ -221,6 +223,7 @@ int upload_fused(syldet *h)
     d.b1 = (const float *)(base + o_b1);
     d.out_params = (const float *)(base + o_op);
     d.thresholds = (const double *)h->d_thr.ptr;
+    d.zeros = (const float *)(base + o_z);
     return SYLDET_OK;
 }
 
