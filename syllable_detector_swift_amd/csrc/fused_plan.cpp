@@ -97,6 +97,7 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
     if (TH > 128) return no("first-layer width x padded timeRange above 128 rows");
     const int n_out = g.outputs;
     if (c.n_layers == 2 && n_out > 4) return no("more than 4 outputs");
+    if (n_out > 16) return no("more than 16 outputs");
     if (c.n_output_fns > kMaxFns) return no("too many output functions");
     const int KS = W <= 128 ? 8 : 16;
     const int MT = TH <= 32 ? 1 : (TH <= 64 ? 2 : 4);
@@ -154,6 +155,7 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
     p.desc.lds_pbuf = take((H * PS * TL + 256) * 4);   // ring [H][PS][TL] + 256 spare words
     p.desc.lds_stat = take(2 * PS * 4);
     p.desc.lds_red = take(64);
+    p.desc.lds_cst = take((132 + kMaxFns * 33) * 4);   // evaluation constants (see kCst* in kernels_fused.hip)
     p.desc.lds_total = off;
     if (off > 160 * 1024) return no("LDS budget exceeded");
 

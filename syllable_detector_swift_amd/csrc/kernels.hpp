@@ -80,7 +80,7 @@ struct FusedDesc {
     int tl, tp_log2;            // ring row length (T rounded up to even); partial rows are h * 2^tp_log2 + t
     int ring_spare;             // float index of 256 spare words behind the ring (padding rows land there)
     float w_unscale;            // 1 / (power-of-two scale of the folded first-layer weights)
-    int lds_dfrag, lds_hi, lds_lo, lds_pbuf, lds_stat, lds_red, lds_total;   // byte offsets
+    int lds_dfrag, lds_hi, lds_lo, lds_pbuf, lds_stat, lds_red, lds_cst, lds_total;   // byte offsets
     const uint4 *dfrag;         // [KS][re,im][hi,lo][64 lanes] A-operand fragments of the DFT basis
     const uint4 *wfrag;         // [MT][2 k-steps][hi,lo][64 lanes] A-operand fragments of the folded layer 0
     const int *koff;            // [KS][2] staged-sample offset of k-step ks for lane half h (skew applied)
@@ -89,7 +89,8 @@ struct FusedDesc {
     const float *w1, *b1;       // layer 1, row-major [n_out][H] (2-layer nets)
     const float *out_params;    // per output fn: y, gain[n_out], xoff[n_out]
     const double *thresholds;   // [n_out]
-    const float *zeros;         // 16 zero bytes (source of out-of-range quads)
+    const float *zeros;         // 16 zero bytes
+    unsigned long long *stamps; // diagnostic build only: [workgroups][8] phase cycle sums, else null
 };
 
 hipError_t launch_fused(const FusedDesc &d, const float *samples, int64_t stride, int C, int64_t S, int64_t J,

@@ -51,6 +51,8 @@ typedef unsigned int uint32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kBlock = 256;
 constexpr int kTile = kFusedTileFrames;
+// layout of the constant block in LDS (floats)
+constexpr int kCstBias0 = 0, kCstRvec = 16, kCstW1 = 32, kCstB1 = 96, kCstThr = 100 /* 16 doubles */, kCstOut = 132;
 
 __device__ __forceinline__ half8 as_half8(uint32x4 v)
 {
@@ -130,19 +132,35 @@ __device__ __forceinline__ floatx16 mfma16(half8 a, half8 b, floatx16 c)
 // This thread's quads of the pass whose first sample is `first` (row-relative).  The buffer
 // descriptor ends one past the last sample any existing frame reads, so quads beyond it come back
 // as zeros from the hardware bounds check: no per-lane guards.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const float *row, int64_t first, int64_t s_eff, int nsmp)
+{
+    int64_t left = s_eff - first;
+    left = left < 0 ? 0 : (left > nsmp ? nsmp : left);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(row + first), 0, (int)left * 4, 0x00020000);
+}
 template <int NL>
 __device__ __forceinline__ void load_tile(const float *row, int64_t first, int64_t s_eff, int nsmp, int nload, int tid,
                                           uint32x4 (&v)[NL])
 {
-    int64_t left = s_eff - first;
-    left = left < 0 ? 0 : (left > nsmp ? nsmp : left);
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(row + first), 0, (int)left * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs = tile_rsrc(row, first, s_eff, nsmp);
 #pragma unroll
     for (int k = 0; k < NL; k++)
         if (k < nload) v[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * tid + 4096 * k, 0, 0);
 }
 
-template <int KS, int MT>
+// Diagnostic stamps (STAMP instantiation only; never the shipped path): s_memtime at phase
+// boundaries, summed per workgroup by wave 0 and stored to d.stamps[workgroup][phase].
+#define SD_STAMP(slot)                                                                     \
+    if (STAMP) {                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+        const unsigned long long now = __builtin_amdgcn_s_memtime();                       \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+        tsum[slot] += now - tprev;                                                         \
+        tprev = now;                                                                       \
+    }
+
+template <int KS, int MT, bool STAMP>
 __global__ void __launch_bounds__(kBlock, 1)
 fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t stride, int64_t s_eff, int64_t E,
              float *__restrict__ outputs, uint8_t *__restrict__ flags)
@@ -153,6 +171,8 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
     float *ring = reinterpret_cast<float *>(smem + d.lds_pbuf);    // [H][PS evaluations][TL]: partial (t,h) of frame e+t
     float *stat = reinterpret_cast<float *>(smem + d.lds_stat);    // [2][PS frames]: per-frame statistics
     float *red = reinterpret_cast<float *>(smem + d.lds_red);
+    // evaluation-phase constants (kCst* offsets): read back with LDS latency, not a global round trip
+    float *cst = reinterpret_cast<float *>(smem + d.lds_cst);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -169,6 +189,14 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
 
     // DFT basis fragments -> LDS (64 KB for W = 256), once per workgroup
     for (int i = tid; i < KS * 4 * 64; i += kBlock) lds_dfrag[i] = reinterpret_cast<const uint32x4 *>(d.dfrag)[i];
+    if (tid < 16) {
+        cst[kCstBias0 + tid] = tid < H ? d.bias0[tid] : 0.0f;
+        cst[kCstRvec + tid] = tid < H ? d.rvec[tid] : 0.0f;
+        reinterpret_cast<double *>(cst + kCstThr)[tid] = tid < d.n_out ? d.thresholds[tid] : 0.0;
+    }
+    if (tid < 64) cst[kCstW1 + tid] = (d.n_layers == 2 && (tid >> 4) < d.n_out && (tid & 15) < H) ? d.w1[(tid >> 4) * H + (tid & 15)] : 0.0f;
+    if (tid < 4) cst[kCstB1 + tid] = (d.n_layers == 2 && tid < d.n_out) ? d.b1[tid] : 0.0f;
+    for (int i = tid; i < d.n_out_fns * (1 + 2 * d.n_out); i += kBlock) cst[kCstOut + i] = d.out_params[i];
     // folded first-layer fragments -> registers
     half8 wfr[MT][2][2];
 #pragma unroll
@@ -198,11 +226,19 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
 
     uint32x4 v[kFusedMaxLoads];
     load_tile(row, e_b * d.hop + d.gap, s_eff, d.nsmp, d.nload, tid, v);
+    // results of the previous pass, stored at the start of the next one: the prefetch wait (vmcnt) then
+    // never sits behind a store that was issued moments ago
+    float pend_y[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    int64_t pend_e = -1;
+    bool pend_hit = false;
+    unsigned long long tsum[16] = {0}, tprev = 0;
+    if (STAMP) tprev = __builtin_amdgcn_s_memtime();
 
     for (int pass = 0; pass < d.runs; pass++) {
         const int64_t jp = e_b + (int64_t)kTile * pass;       // first frame of this pass
         if (jp - (T - 1) >= e_e) break;
 
+        SD_STAMP(8)                                           // loop back-edge
         // ---------------- block floating point: scale the tile so its largest sample is in [2^13, 2^14)
         float amax = 0.0f;
 #pragma unroll
@@ -211,10 +247,13 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
                 const floatx4 f = as_floatx4(v[k]);
                 amax = absmax3(absmax3(amax, f[0], f[1]), f[2], f[3]);
             }
+        SD_STAMP(9)                                           // max over the prefetched registers (vmcnt wait)
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
         if (lane == 0) red[wave] = amax;
+        SD_STAMP(0)                                           // amax (+ wait for the prefetched samples)
         __syncthreads();                                      // (A) previous pass fully consumed
+        SD_STAMP(1)
         amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
         int se = 13 - (int)((__float_as_uint(amax) >> 23) & 0xffu) + 127;   // exponent of the scale
         se = amax > 0.0f ? (se < -100 ? -100 : (se > 100 ? 100 : se)) : 0;
@@ -239,20 +278,38 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
         // evaluations the previous pass left incomplete move to the front of the ring (with their
         // frames' statistics); everything behind them starts this pass empty
         if (pass > 0) {
-            const int n_carry = (T - 1) * TL;
-            for (int idx = tid; idx < H * n_carry; idx += kBlock) {
-                const int h = idx / n_carry, rem = idx - h * n_carry;
-                ring[h * PS * TL + rem] = ring[h * PS * TL + kTile * TL + rem];
-            }
-            if (tid < 2 * (T - 1)) {
-                const int k = tid / (T - 1), t = tid - k * (T - 1);
-                stat[k * PS + t] = stat[k * PS + kTile + t];
+            // (T-1) incomplete evaluations x H rows of TL floats, copied as float2 pairs
+            const int pairs = (T - 1) * (TL / 2);             // per hidden unit, contiguous in the ring
+            for (int h = 0; h < H; h++)
+                for (int i = tid; i < pairs; i += kBlock) {
+                    floatx2 *base = reinterpret_cast<floatx2 *>(ring + h * PS * TL);
+                    base[i] = base[kTile * (TL / 2) + i];
+                }
+            if (tid < T - 1) {
+                stat[tid] = stat[kTile + tid];
+                stat[PS + tid] = stat[PS + kTile + tid];
             }
         }
+        SD_STAMP(2)                                           // scale + LDS stage writes + carry
         __syncthreads();                                      // (B) samples staged
+        SD_STAMP(3)
 
-        // next pass's samples: issued now, consumed after this pass's matrix work
-        if (pass + 1 < d.runs) load_tile(row, (jp + kTile) * d.hop + d.gap, s_eff, d.nsmp, d.nload, tid, v);
+        SD_STAMP(10)
+        // previous pass's results out (2-layer networks; see the evaluation phase)
+        if (pend_e >= 0) {
+            if (outputs) {
+#pragma unroll
+                for (int o = 0; o < 4; o++)
+                    if (o < d.n_out) outputs[((int64_t)c * E + pend_e) * d.n_out + o] = pend_y[o];
+            }
+            if (flags) flags[(int64_t)c * E + pend_e] = pend_hit ? 1 : 0;
+            pend_e = -1;
+        }
+        // next pass's samples: fetched during this pass's matrix work, a load or two per k-step, so the
+        // memory queue never backs up into the wave (a burst of 17 KB-sized loads stalls issue for ~3k cycles)
+        const __amdgpu_buffer_rsrc_t nrs = tile_rsrc(row, (jp + kTile) * d.hop + d.gap, pass + 1 < d.runs ? s_eff : 0, d.nsmp);
+        constexpr int kLoadsPerStep = (kFusedMaxLoads + KS - 1) / KS;
+        SD_STAMP(11)                                          // deferred stores + prefetch issue
 
         // ---------------- band-limited DFT of this wave's 32 frames on the matrix cores.
         // Software pipeline: while the six MFMAs of k-step ks execute, the lane's next 8 samples
@@ -268,6 +325,7 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
         }
         uint32x4 a0 = lds_dfrag[0 * 64 + lane], a1 = lds_dfrag[1 * 64 + lane];
         uint32x4 a2 = lds_dfrag[2 * 64 + lane], a3 = lds_dfrag[3 * 64 + lane];
+        __builtin_amdgcn_sched_barrier(0);                    // the prologue's fetches stay out of the loop's groups
 #pragma unroll
         for (int ks = 0; ks < KS; ks++) {
             const half8 a_re_h = as_half8(a0), a_re_l = as_half8(a1), a_im_h = as_half8(a2), a_im_l = as_half8(a3);
@@ -283,6 +341,11 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
                 s0 = *reinterpret_cast<const floatx4 *>(fptr + ko[ks + 2]);
                 s1 = *reinterpret_cast<const floatx4 *>(fptr + ko[ks + 2] + 4);
             }
+#pragma unroll
+            for (int j = 0; j < kLoadsPerStep; j++) {         // next pass's quads ks*kLoadsPerStep + j
+                const int k = ks * kLoadsPerStep + j;
+                if (k < kFusedMaxLoads && k < d.nload) v[k] = __builtin_amdgcn_raw_buffer_load_b128(nrs, 16 * tid + 4096 * k, 0, 0);
+            }
             acc_re = mfma16(a_re_h, cbh, acc_re);
             acc_im = mfma16(a_im_h, cbh, acc_im);
             acc_re = mfma16(a_re_h, cbl, acc_re);
@@ -290,6 +353,9 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
             acc_re = mfma16(a_re_l, cbh, acc_re);
             acc_im = mfma16(a_im_l, cbh, acc_im);
             if (ks + 1 < KS) split8(n0, n1, bh, bl);          // 24 VALU, scheduled into the MFMA shadows below
+            // schedule: this k-step's 6 LDS fetches first (their data is used one and two k-steps later),
+            // then each MFMA followed by 4 of the split's VALU instructions
+            __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);       // 6 DS reads
 #pragma unroll
             for (int i = 0; i < 6; i++) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
@@ -297,6 +363,7 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
             }
         }
 
+        SD_STAMP(4)                                           // DFT MFMA loop
         // ---------------- magnitude (zvabs/2 :329-333 or zvmags/4 :270-274), scaling
         // (SyllableDetector.swift:184-212), per-frame statistic, f16 split for the next MFMA.
         // Result layout: column = frame r, register g of lane half hh = bin row (g&3) + 8(g>>2) + 4hh.
@@ -375,7 +442,9 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
 #pragma unroll
             for (int g = 0; g < 16; g++) ring[poff[m][g]] = pacc[g] * unscale;
         }
+        SD_STAMP(5)                                           // magnitude, statistic, layer-0 MFMA, ring writes
         __syncthreads();                                      // (C) partials of all 128 frames visible
+        SD_STAMP(6)
 
         // ---------------- evaluations completed by this pass: slot q = e - (jp - (T-1)); lane half hh
         // owns hidden units hh, hh+2, ...; both halves hold the same evaluation
@@ -386,6 +455,7 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
             float alpha = 1.0f, beta = 0.0f;
             if (d.norm == 1) {                                // L2Normalize, NeuralNet.swift:47-59
                 float ssw = 0.0f;
+#pragma unroll 4
                 for (int t = 0; t < T; t++) ssw += stat[q + t];
                 alpha = __builtin_amdgcn_rsqf(ssw);
             } else if (d.norm == 2) {                         // Normalize, :69-96
@@ -407,24 +477,26 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
                 beta = -mean / sd;
             }
             const int64_t obase = ((int64_t)c * E + e) * d.n_out;
+            const double *thr = reinterpret_cast<const double *>(cst + kCstThr);
             float y[4] = {0.0f, 0.0f, 0.0f, 0.0f};
             bool hit = false;
             for (int h = hh; h < H; h += 2) {
                 const floatx2 *pp = reinterpret_cast<const floatx2 *>(ring + (h * PS + q) * TL);
+                const float b0 = cst[kCstBias0 + h], rv = cst[kCstRvec + h];
+                const float w10 = cst[kCstW1 + h], w11 = cst[kCstW1 + 16 + h], w12 = cst[kCstW1 + 32 + h], w13 = cst[kCstW1 + 48 + h];
                 float z0 = 0.0f, z1 = 0.0f;
+#pragma unroll 8
                 for (int t = 0; t < TL / 2; t++) { const floatx2 p2 = pp[t]; z0 += p2[0]; z1 += p2[1]; }
-                float a = transfer_fn(d.tf0, fmaf(alpha, z0 + z1, fmaf(beta, d.rvec[h], d.bias0[h])));
+                float a = transfer_fn(d.tf0, fmaf(alpha, z0 + z1, fmaf(beta, rv, b0)));
                 if (d.n_layers == 2) {
-#pragma unroll
-                    for (int o = 0; o < 4; o++)
-                        if (o < d.n_out) y[o] = fmaf(d.w1[o * H + h], a, y[o]);
+                    y[0] = fmaf(w10, a, y[0]); y[1] = fmaf(w11, a, y[1]); y[2] = fmaf(w12, a, y[2]); y[3] = fmaf(w13, a, y[3]);
                 } else {
                     for (int k = 0; k < d.n_out_fns; k++) {                    // reverse maps, NeuralNet.swift:137-142 / :175-180
-                        const float *op = d.out_params + k * (1 + 2 * d.n_out);
+                        const float *op = cst + kCstOut + k * (1 + 2 * d.n_out);
                         a = (a - op[0]) / op[1 + h] + op[1 + d.n_out + h];
                     }
                     if (valid && outputs) outputs[obase + h] = a;
-                    if (h == 0 || d.rule == 1) hit = hit || ((double)a >= d.thresholds[h]);
+                    if (h == 0 || d.rule == 1) hit = hit || ((double)a >= thr[h]);
                 }
             }
             if (d.n_layers == 2) {
@@ -432,28 +504,41 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
                 for (int o = 0; o < 4; o++) {
                     if (o < d.n_out) {
                         float yo = y[o] + __shfl_xor(y[o], 32, 64);
-                        yo = transfer_fn(d.tf1, yo + d.b1[o]);
+                        yo = transfer_fn(d.tf1, yo + cst[kCstB1 + o]);
                         for (int k = 0; k < d.n_out_fns; k++) {
-                            const float *op = d.out_params + k * (1 + 2 * d.n_out);
+                            const float *op = cst + kCstOut + k * (1 + 2 * d.n_out);
                             yo = (yo - op[0]) / op[1 + o] + op[1 + d.n_out + o];
                         }
-                        if (valid && hh == 0 && outputs) outputs[obase + o] = yo;
-                        if (o == 0 || d.rule == 1) hit = hit || ((double)yo >= d.thresholds[o]);
+                        pend_y[o] = yo;
+                        if (o == 0 || d.rule == 1) hit = hit || ((double)yo >= thr[o]);
                     }
                 }
+                pend_hit = hit;
+                pend_e = (valid && hh == 0) ? e : -1;
             } else {
                 hit = hit || (__shfl_xor((int)hit, 32, 64) != 0);
+                if (valid && hh == 0 && flags) flags[(int64_t)c * E + e] = hit ? 1 : 0;
             }
-            if (valid && hh == 0 && flags) flags[(int64_t)c * E + e] = hit ? 1 : 0;
         }
+        SD_STAMP(7)                                           // evaluations
     }
+    if (pend_e >= 0) {
+        if (outputs) {
+#pragma unroll
+            for (int o = 0; o < 4; o++)
+                if (o < d.n_out) outputs[((int64_t)c * E + pend_e) * d.n_out + o] = pend_y[o];
+        }
+        if (flags) flags[(int64_t)c * E + pend_e] = pend_hit ? 1 : 0;
+    }
+    if (STAMP && tid == 0 && d.stamps)
+        for (int i = 0; i < 16; i++) d.stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + i] = tsum[i];
 }
 
-template <int KS, int MT>
+template <int KS, int MT, bool STAMP = false>
 hipError_t launch_one(const FusedDesc &d, const float *samples, int64_t stride, int C, int64_t s_eff, int64_t E,
                       float *outputs, uint8_t *flags, hipStream_t stream)
 {
-    auto kern = fused_kernel<KS, MT>;
+    auto kern = fused_kernel<KS, MT, STAMP>;
     hipError_t st = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, d.lds_total);
     if (st != hipSuccess) return st;
     const int64_t segs = (E + d.seg_evals - 1) / d.seg_evals;
@@ -476,6 +561,7 @@ hipError_t launch_fused(const FusedDesc &d, const float *samples, int64_t stride
     if (E <= 0 || C <= 0) return hipSuccess;
     // one past the last sample an existing frame reads: frame J-1 covers [(J-1)*hop + gap, ... + W)
     const int64_t s_eff = (J - 1) * (int64_t)d.hop + d.gap + d.W;
+    if (d.stamps && d.KS == 16 && d.MT == 2) return launch_one<16, 2, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
 #define SD_CASE(K, M) \
     if (d.KS == K && d.MT == M) return launch_one<K, M>(d, samples, stride, C, s_eff, E, outputs, flags, stream)
     SD_CASE(16, 1);

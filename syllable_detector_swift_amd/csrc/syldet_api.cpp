@@ -8,6 +8,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <memory>
@@ -87,6 +89,7 @@ struct syldet {
 
     // fused engine tables
     FusedPlan fused;
+    DeviceBuffer d_stamps;            // diagnostic stamps (SYLDET_FUSED_STAMPS)
     DeviceBuffer d_fused;             // one blob: dfrag | wfrag | koff | bias0 | rvec | w1 | b1 | out_params
     DeviceBuffer d_stage_in, d_stage_out, d_stage_flags, d_stage_idx, d_stage_cnt;
     hipStream_t stream = nullptr;     // used by the host-pointer entry points
@@ -274,6 +277,31 @@ int run_on_stream(syldet *h, const float *d_samples, int64_t S, int64_t stride, 
     if (h->engine == SYLDET_ENGINE_FUSED) {
         FusedDesc d = h->fused.desc;
         fused_segmentation(d, E, C);
+        d.stamps = nullptr;
+        // diagnostic only: SYLDET_FUSED_STAMPS=1 runs the stamped instantiation and prints where a
+        // workgroup pass spends its cycles (never set in tests or the benchmark)
+        static const bool want_stamps = std::getenv("SYLDET_FUSED_STAMPS") != nullptr;
+        if (want_stamps) {
+            const size_t n = (size_t)((E + d.seg_evals - 1) / d.seg_evals) * (size_t)C * 16;
+            if (int st = h->d_stamps.reserve(n * sizeof(unsigned long long))) return st;
+            SYLDET_HIP(hipMemsetAsync(h->d_stamps.ptr, 0, n * sizeof(unsigned long long), stream));
+            d.stamps = (unsigned long long *)h->d_stamps.ptr;
+            SYLDET_HIP(launch_fused(d, d_samples, stride, C, S, J, E, d_outputs, d_flags, stream));
+            std::vector<unsigned long long> host(n);
+            SYLDET_HIP(hipMemcpyAsync(host.data(), h->d_stamps.ptr, n * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+            SYLDET_HIP(hipStreamSynchronize(stream));
+            double sum[16] = {0};
+            for (size_t i = 0; i < n; i++) sum[i % 16] += (double)host[i];
+            double tot = 0;
+            for (double v : sum) tot += v;
+            static const char *names[16] = {"shuffle-reduce+red", "barrier A", "scale+stage+carry", "barrier B", "DFT MFMA loop",
+                                            "mag+stat+layer0+ring", "barrier C", "evaluations", "loop back-edge", "max over prefetch (vmcnt)",
+                                            "-", "deferred stores+prefetch issue", "-", "-", "-", "-"};
+            std::fprintf(stderr, "[syldet stamps] runs=%d workgroups=%zu cycles/pass=%.0f\n", d.runs, n / 16, tot / ((double)(n / 16) * d.runs));
+            for (int i = 0; i < 16; i++)
+                if (sum[i] > 0) std::fprintf(stderr, "   %-32s %6.0f cycles/pass  %5.1f %%\n", names[i], sum[i] / ((double)(n / 16) * d.runs), 100.0 * sum[i] / tot);
+            return SYLDET_OK;
+        }
         KernelTimer t(h, stream, "fused_kernel");
         SYLDET_HIP(launch_fused(d, d_samples, stride, C, S, J, E, d_outputs, d_flags, stream));
         return SYLDET_OK;
@@ -366,7 +394,7 @@ int syldet_destroy(syldet_t *h)
         (void)hipStreamDestroy(h->stream);
     }
     for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
-    for (DeviceBuffer *b : {&h->d_window, &h->d_tw, &h->d_sw, &h->d_params, &h->d_thr, &h->d_columns, &h->d_fused, &h->d_stage_in,
+    for (DeviceBuffer *b : {&h->d_window, &h->d_tw, &h->d_sw, &h->d_params, &h->d_thr, &h->d_columns, &h->d_fused, &h->d_stamps, &h->d_stage_in,
                             &h->d_stage_out, &h->d_stage_flags, &h->d_stage_idx, &h->d_stage_cnt})
         b->release();
     delete h;
