@@ -7,8 +7,8 @@
 //   the affine tail composes to  x = a o v' + b  (per position);  the head is  v' = alpha*v + beta*1
 //   with per-window scalars (alpha, beta) = (1/||v||, 0) | (2/(mx-mn), (-mn-mx)/(mx-mn)) | (1/sigma, -mu/sigma);
 //   layer 0:  W0.x + b0 = alpha * (W0 o a).v + beta * (W0 o a).1 + (b0 + W0.b)
-//   and (W0 o a).v splits over the T columns of the window, so each frame contributes T*H partial dot
-//   products that are summed along a diagonal in (frame, t).
+//   and (W0 o a).v = sum_t (W0 o a)_t . column(e + t) is a GEMM over the T taps of the window whose B
+//   operand is the column buffer at row offset e + t (kernels_fused.hip).
 // Anything else (a normaliser after an affine map, three or more layers, wide layers, long windows)
 // runs on the generic engine.
 
@@ -83,25 +83,14 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
     if (g.hop % 4 != 0) return no("hop is not a multiple of 4");
     if (W > 256) return no("window longer than 256 samples");
     if (W % 4 != 0) return no("window length is not a multiple of 4");
-    if (F > 32) return no("more than 32 bins");
-    if (T > 32) return no("timeRange above 32");
     if (c.n_layers < 1 || c.n_layers > 2) return no("more than two layers");
     const syldet_layer_t &L0 = c.layers[0];
     const int H = L0.outputs;
-    if (H > 16) return no("first layer wider than 16");
-    // partial-product rows are ordered h * TP + t with TP the power of two >= max(T, 2)
-    int tp_log2 = 1;
-    while ((1 << tp_log2) < T) tp_log2++;
-    const int TP = 1 << tp_log2, TL = (T + 1) & ~1;
-    const int TH = H * TP;
-    if (TH > 128) return no("first-layer width x padded timeRange above 128 rows");
     const int n_out = g.outputs;
     if (c.n_layers == 2 && n_out > 4) return no("more than 4 outputs");
-    if (n_out > 16) return no("more than 16 outputs");
     if (c.n_output_fns > kMaxFns) return no("too many output functions");
     const int KS = W <= 128 ? 8 : 16;
-    const int MT = TH <= 32 ? 1 : (TH <= 64 ? 2 : 4);
-    if (!fused_supported(KS, MT)) return no("no kernel instantiation");
+    if (fused_taps_max(T) == 0) return no("timeRange above 12");
 
     // ---- input chain pattern
     const int I = g.inputs;
@@ -112,6 +101,9 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
         else if (k0 == SYLDET_FN_NORMALIZE) { norm = 2; first_affine = 1; }
         else if (k0 == SYLDET_FN_NORMALIZESTD) { norm = 3; first_affine = 1; }
     }
+    // l2normalize: the sum of squares takes two spare bins (F, F+1) and one spare result row (index H)
+    if (F > (norm == 1 ? 30 : 32)) return no("too many bins");
+    if (H > (norm == 1 ? 15 : 16)) return no("first layer too wide");
     std::vector<double> a((size_t)I, 1.0), b((size_t)I, 0.0);
     for (int k = first_affine; k < c.n_input_fns; k++) {
         const syldet_fn_t &f = c.input_fns[k];
@@ -137,26 +129,32 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
     const int nsmp_p = (skewed(nload * 1024 + 16) + 15) / 8 * 8;   // every thread writes all its quads
     const int PS = kFusedTileFrames + T - 1;
 
-    p.desc.W = W; p.desc.KS = KS; p.desc.hop = hop; p.desc.gap = g.gap; p.desc.F = F; p.desc.T = T;
-    p.desc.H = H; p.desc.TH = TH; p.desc.MT = MT; p.desc.norm = norm;
-    p.desc.scaling = c.scaling; p.desc.power_mode = c.spectrum == SYLDET_SPECTRUM_MAGNITUDE ? 1 : 0;
-    p.desc.n_layers = c.n_layers; p.desc.n_out = n_out; p.desc.tf0 = L0.transfer;
-    p.desc.tf1 = c.n_layers == 2 ? c.layers[1].transfer : SYLDET_TF_PURELIN;
-    p.desc.rule = c.rule; p.desc.n_out_fns = c.n_output_fns; p.desc.I = I;
-    p.desc.nsmp = nsmp; p.desc.nload = nload; p.desc.skew = skew;
-    p.desc.hop_magic = (unsigned)((0x100000000ull + (unsigned)hop - 1) / (unsigned)hop);
-    p.desc.ps = PS;
+    FusedDesc &d = p.desc;
+    d.W = W; d.KS = KS; d.hop = hop; d.gap = g.gap; d.F = F; d.T = T; d.H = H; d.norm = norm;
+    d.scaling = c.scaling; d.power_mode = c.spectrum == SYLDET_SPECTRUM_MAGNITUDE ? 1 : 0;
+    d.n_layers = c.n_layers; d.n_out = n_out; d.tf0 = L0.transfer;
+    d.tf1 = c.n_layers == 2 ? c.layers[1].transfer : SYLDET_TF_PURELIN;
+    d.rule = c.rule; d.n_out_fns = c.n_output_fns; d.I = I;
+    d.nsmp = nsmp; d.nload = nload; d.skew = skew;
+    d.hop_magic = (unsigned)((0x100000000ull + (unsigned)hop - 1) / (unsigned)hop);
+    d.ps = PS;
+    // a result register g of lane half hh holds bin (g&3) + 8(g>>2) + 4hh
+    d.stat_bin = norm == 1 ? F : -1;
+    d.stat_hh = (F >> 2) & 1;
+    d.stat_g = (F & 3) + 4 * (F >> 3);
+    d.stat_hh2 = ((F + 1) >> 2) & 1;
+    d.stat_g2 = ((F + 1) & 3) + 4 * ((F + 1) >> 3);
+    d.stat_row = H;
     int off = 0;
     auto take = [&off](int bytes) { const int o = off; off += (bytes + 15) / 16 * 16; return o; };
-    p.desc.lds_dfrag = take(KS * 4 * 1024);
-    p.desc.lds_hi = take(nsmp_p * 4);      // staged samples, scaled fp32
-    p.desc.lds_lo = p.desc.lds_hi;
-    p.desc.tl = TL; p.desc.tp_log2 = tp_log2; p.desc.ring_spare = H * PS * TL;
-    p.desc.lds_pbuf = take((H * PS * TL + 256) * 4);   // ring [H][PS][TL] + 256 spare words
-    p.desc.lds_stat = take(2 * PS * 4);
-    p.desc.lds_red = take(64);
-    p.desc.lds_cst = take((132 + kMaxFns * 33) * 4);   // evaluation constants (see kCst* in kernels_fused.hip)
-    p.desc.lds_total = off;
+    d.lds_dfrag = take(KS * 4 * 1024);
+    d.lds_smp = take(nsmp_p * 4);                    // staged samples, scaled fp32
+    d.lds_colh = take(PS * kFusedColStride * 2);     // |X| columns, f16 hi
+    d.lds_coll = take(PS * kFusedColStride * 2);     //              f16 lo
+    d.lds_stat = take(2 * PS * 4);
+    d.lds_red = take(64);
+    d.lds_cst = take((32 + kMaxFns * 33) * 4);       // thresholds + output maps (kCst* in kernels_fused.hip)
+    d.lds_total = off;
     if (off > 160 * 1024) return no("LDS budget exceeded");
 
     // ---- DFT basis fragments: A operand of v_mfma_f32_32x32x16_f16, lane l holds row l&31,
@@ -183,7 +181,26 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
                     p.dfrag[((((size_t)ks * 2 + tile) * 2 + 1) * 64 + l) * 8 + j] = lo;
                 }
 
-    // ---- folded first layer: W'[(t,h)][f] = W0[h][t*F+f] * a[t*F+f]
+    // |X[k]| <= (sum_n |D[k][n]|) * max|x|: with samples scaled below 2^14 the column shift keeps |X| * 2^(cse-shift) < 2^13
+    {
+        double rowsum_max = 1.0;
+        for (int r = 0; r < F; r++) {
+            double sr = 0.0, si = 0.0;
+            for (int n = 0; n < W; n++) {
+                const int kn = (int)(((int64_t)(g.f0 + r) * n) % N);
+                const double ang = two_pi * (double)kn / (double)N;
+                sr += std::fabs((double)win[(size_t)n] * std::cos(ang));
+                si += std::fabs((double)win[(size_t)n] * std::sin(ang));
+            }
+            rowsum_max = std::max(rowsum_max, std::sqrt(sr * sr + si * si));
+        }
+        d.col_shift = (int)std::ceil(std::log2(rowsum_max)) + 1;   // 2^14 * rowsum * 2^-shift <= 2^13
+        if (d.power_mode) d.col_shift += 7;                         // squares: 2^(2 * 13) * 2^-(2*7) = 2^12 ... stays < 2^13
+    }
+
+    // ---- folded first layer, one fragment pair per tap: A operand of v_mfma_f32_16x16x32_f16, lane l holds
+    // row l&15 (hidden unit), k = 8*(l>>4) + j (bin):  W'_t[h][f] = W0[h][t*F+f] * a[t*F+f], scaled by 2^wexp.
+    // l2normalize adds row H with a unit weight on bin F (where the kernel puts the column's sum of squares).
     double wmax = 0.0;
     for (int h = 0; h < H; h++)
         for (int i = 0; i < I; i++) wmax = std::max(wmax, std::fabs((double)L0.weights[(size_t)h * I + i] * a[(size_t)i]));
@@ -191,25 +208,21 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
     if (wmax > 0.0) wexp = 13 - (int)std::ceil(std::log2(wmax));
     wexp = std::max(-100, std::min(100, wexp));
     const double wscale = std::ldexp(1.0, wexp);
-    p.desc.w_unscale = (float)std::ldexp(1.0, -wexp);
-    p.wfrag.assign((size_t)MT * 4 * 64 * 8, 0);
-    for (int m = 0; m < MT; m++)
-        for (int s = 0; s < 2; s++)
-            for (int l = 0; l < 64; l++)
-                for (int j = 0; j < 8; j++) {
-                    const int prow = 32 * m + (l & 31);                           // = t*H + h
-                    const int bin = 16 * s + 8 * (j >> 2) + 4 * (l >> 5) + (j & 3);   // accumulator register 8s+j of lane half l>>5
-                    double v = 0.0;
-                    const int t = prow & (TP - 1), h = prow >> tp_log2;
-                    if (t < T && h < H && bin < F) {
-                        const int i = t * F + bin;
-                        v = (double)L0.weights[(size_t)h * I + i] * a[(size_t)i] * wscale;
-                    }
-                    uint16_t hi, lo;
-                    split_half(v, hi, lo);
-                    p.wfrag[((((size_t)m * 2 + s) * 2 + 0) * 64 + l) * 8 + j] = hi;
-                    p.wfrag[((((size_t)m * 2 + s) * 2 + 1) * 64 + l) * 8 + j] = lo;
-                }
+    d.w_unscale = (float)std::ldexp(1.0, -wexp);
+    p.afrag.assign((size_t)T * 2 * 64 * 8, 0);
+    for (int t = 0; t < T; t++)
+        for (int l = 0; l < 64; l++)
+            for (int j = 0; j < 8; j++) {
+                const int h = l & 15, bin = 8 * (l >> 4) + j;
+                double v = 0.0;
+                if (h < H && bin < F) v = (double)L0.weights[(size_t)h * I + t * F + bin] * a[(size_t)(t * F + bin)] * wscale;
+                else if (norm == 1 && h == H && bin == F) v = 1.0;
+                else if (norm == 1 && h == H && bin == F + 1) v = 1.0 / 2048.0;
+                uint16_t hi, lo;
+                split_half(v, hi, lo);
+                p.afrag[(((size_t)t * 2 + 0) * 64 + l) * 8 + j] = hi;
+                p.afrag[(((size_t)t * 2 + 1) * 64 + l) * 8 + j] = lo;
+            }
     p.bias0.resize((size_t)H);
     p.rvec.resize((size_t)H);
     for (int h = 0; h < H; h++) {

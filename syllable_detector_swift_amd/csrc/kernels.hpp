@@ -63,39 +63,40 @@ hipError_t launch_detections(const uint8_t *flags, int C, int64_t E, int64_t fir
 // diagonal sum over an LDS ring.  Built by make_fused_plan() when the configuration fits.
 constexpr int kFusedTileFrames = 128;   // frames per workgroup pass (4 waves x 32)
 constexpr int kFusedMaxLoads = 20;      // float4 loads per thread per pass
+constexpr int kFusedColStride = 40;     // halves per column row in LDS: 32 bins + 8 of padding (80 B rows: 16-byte
+                                        // aligned, and 16 consecutive rows cover all 64 banks once for ds_read_b128)
 
 struct FusedDesc {
     int W, KS;                  // window length, k-steps of 16 samples (KS*16 >= W)
     int hop, gap, F, T;         // frame advance, leading gap, bins, timeRange
-    int H, TH, MT;              // first-layer outputs, T*H, M-tiles of 32 rows (MT*32 >= TH)
+    int H;                      // first-layer outputs
     int norm;                   // 0 none, 1 l2normalize, 2 normalize, 3 normalizestd (first input fn)
     int scaling, power_mode;
     int n_layers, n_out, tf0, tf1, rule, n_out_fns;
     int I;                      // F*T
     int nsmp, nload;            // samples staged per pass, float4 loads per thread
-    int skew;                   // f16 elements inserted after every `hop` staged samples (bank spreading)
+    int skew;                   // floats of padding after every `hop` staged samples (bank spreading)
     unsigned hop_magic;         // ceil(2^32 / hop): i / hop == umulhi(i, hop_magic) for i < 2^16
     int runs, seg_evals;        // passes per workgroup, evaluations per workgroup segment
-    int ps;                     // slots of the partial-product ring (frames per pass + T - 1)
-    int tl, tp_log2;            // ring row length (T rounded up to even); partial rows are h * 2^tp_log2 + t
-    int ring_spare;             // float index of 256 spare words behind the ring (padding rows land there)
+    int ps;                     // column slots in LDS (frames per pass + T - 1)
+    int stat_bin, stat_hh, stat_g, stat_hh2, stat_g2, stat_row;   // l2normalize: the sum of squares rides in bins F, F+1; row H
+    int col_shift;              // |X| columns are stored as |X| * 2^(cse - col_shift) (2x for |X|^2)
     float w_unscale;            // 1 / (power-of-two scale of the folded first-layer weights)
-    int lds_dfrag, lds_hi, lds_lo, lds_pbuf, lds_stat, lds_red, lds_cst, lds_total;   // byte offsets
-    const uint4 *dfrag;         // [KS][re,im][hi,lo][64 lanes] A-operand fragments of the DFT basis
-    const uint4 *wfrag;         // [MT][2 k-steps][hi,lo][64 lanes] A-operand fragments of the folded layer 0
+    int lds_dfrag, lds_smp, lds_colh, lds_coll, lds_stat, lds_red, lds_cst, lds_total;   // byte offsets
+    const uint4 *dfrag;         // [KS][re,im][hi,lo][64 lanes] A-operand fragments of the DFT basis (32x32x16)
+    const uint4 *afrag;         // [T][hi,lo][64 lanes] A-operand fragments of the folded first layer (16x16x32)
     const int *koff;            // [KS][2] staged-sample offset of k-step ks for lane half h (skew applied)
     const float *bias0;         // [H]  b0 + W0 . (constant part of the input maps)
     const float *rvec;          // [H]  (W0 o a) . 1
     const float *w1, *b1;       // layer 1, row-major [n_out][H] (2-layer nets)
     const float *out_params;    // per output fn: y, gain[n_out], xoff[n_out]
     const double *thresholds;   // [n_out]
-    const float *zeros;         // 16 zero bytes
-    unsigned long long *stamps; // diagnostic build only: [workgroups][8] phase cycle sums, else null
+    unsigned long long *stamps; // diagnostic build only: [workgroups][16] phase cycle sums, else null
 };
 
 hipError_t launch_fused(const FusedDesc &d, const float *samples, int64_t stride, int C, int64_t S, int64_t J,
                         int64_t E, float *outputs, uint8_t *flags, hipStream_t stream);
-// 0 when this build has an instantiation for (KS, MT)
-int fused_supported(int KS, int MT);
+// taps the register-resident first-layer fragments are instantiated for (0: timeRange too long)
+int fused_taps_max(int T);
 
 }  // namespace sd

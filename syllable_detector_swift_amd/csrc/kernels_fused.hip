@@ -8,32 +8,32 @@
 //   NeuralNet.apply       Common/NeuralNet.swift:294-326, :366-377
 //   lastDetected          Common/SyllableDetector.swift:27-31
 //
-// MI355X formulation (not a translation of the vDSP call sequence):
-//   * the detector only needs F (<= 32) bins of each N-point spectrum, so the windowed DFT of a
-//     tile of 32 frames is the GEMM  Xt[2 x 32 rows, 32 frames] = Dt[rows, W] . S[W, 32 frames]
-//     with Dt = window o {cos, -sin} and S read straight from the staged sample stream (frame j
-//     is just the address j*hop: no per-frame copy, no ring).  It runs on the matrix cores as
-//     v_mfma_f32_32x32x16_f16 with every operand split into f16 hi + lo (block floating point,
-//     power-of-two scales): hi*hi + hi*lo + lo*hi reproduces an fp32 product to ~2^-21, and the
-//     fp32 accumulate keeps the sum; measured error vs the fp64 anchor is below an fp32 FFT's.
-//     The split of the samples happens on the fragment a lane has just read from LDS, in the
-//     issue slots the matrix pipe leaves free (4 VALU per MFMA), so it costs no time of its own;
-//   * the result tile has frames on lanes and bins in registers, which is exactly the B-operand
-//     layout of the next MFMA, so the first layer -- folded with the affine input maps into
-//     W' = W0 o gain, split per time slot into T*H partial dot products per frame -- runs on the
-//     matrix cores too with no data movement;
-//   * evaluation e is the sum over t of partial (t,h) of frame e+t.  Each partial is stored at
-//     ring[h][e][t], so an evaluation reads T contiguous floats per hidden unit, plus a
-//     per-window statistic (l2 norm / min-max / mean-std) -- every frame is transformed once,
-//     instead of T times as in the reference's sliding re-read.
+// MI355X formulation (not a translation of the vDSP call sequence): two chained GEMMs on the matrix
+// cores whose B operands are *addresses*, not copies.
+//   1. The detector needs F (<= 32) bins of each N-point spectrum, so the windowed DFT of a tile of
+//      32 frames is  Xt[2 x 32 rows, 32 frames] = Dt[rows, W] . S[W, 32 frames]  with
+//      Dt = window o {cos, -sin}; column j of S is simply the staged sample stream at offset j*hop
+//      (no per-frame copy, no ring).  v_mfma_f32_32x32x16_f16 with every operand split into f16
+//      hi + lo (block floating point, power-of-two scales): hi*hi + hi*lo + lo*hi reproduces an fp32
+//      product to ~2^-21 and the fp32 accumulate keeps the sum; measured error against the fp64
+//      anchor is below an fp32 FFT's.  The split of the samples is done on the fragment a lane has
+//      just read from LDS, in the issue slots the matrix pipe leaves free (4 VALU per MFMA).
+//   2. |X| columns (f16 hi/lo) go to a small LDS buffer [frame][bin].  The first network layer,
+//      folded with the affine input maps into W' = W0 o gain, is  Z[h, e] = sum_t W'_t[h, :] . C[:, e+t]:
+//      again a GEMM (v_mfma_f32_16x16x32_f16, K = 32 bins per tap) whose B operand for tap t is the
+//      column buffer at row offset e + t.  For l2normalize the per-frame sum of squares rides along
+//      as one more bin with a unit weight in one more row, so the window's norm falls out of the
+//      same MFMAs.  An evaluation then finishes in registers: scale, transfer function, second
+//      layer, reverse map, threshold.
+// Every frame is transformed once (the reference re-reads each column T times).
 //
-// Workgroup = 4 waves x 32 frames = 128 frames per pass; a workgroup walks `runs` consecutive
-// passes of one channel, carrying the incomplete evaluations' partials in LDS.  HBM traffic =
-// every sample once (+ (T-1) frames of overlap per segment) + 5 bytes per evaluation.
+// Workgroup = 4 waves x 32 frames = 128 frames per pass; a workgroup walks `runs` consecutive passes of
+// one channel, carrying the last T-1 columns in LDS.  HBM traffic = every sample once (+ (T-1) frames
+// of overlap per segment) + 5 bytes per evaluation.
 //
-// The kernel is instruction-issue bound (one wave per SIMD: LDS holds 64 KB of basis fragments,
-// 68 KB of samples and the ring), so the code below is written to keep the per-pass instruction
-// count low: hardware-bounds-checked buffer loads, precomputed LDS offsets, no divergent guards.
+// The kernel is instruction-issue bound (LDS holds 64 KB of basis fragments + 68 KB of samples, so
+// one wave per SIMD): buffer loads with hardware bounds instead of guards, next-pass loads trickled
+// through the MFMA loop, results stored one pass late so no wait sits behind a fresh store.
 //
 // gfx950 only.  wave = 64.
 
@@ -44,15 +44,16 @@ namespace sd {
 namespace {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef float floatx2 __attribute__((ext_vector_type(2)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef unsigned int uint32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int uint32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kBlock = 256;
 constexpr int kTile = kFusedTileFrames;
+constexpr int kColStride = kFusedColStride;
 // layout of the constant block in LDS (floats)
-constexpr int kCstBias0 = 0, kCstRvec = 16, kCstW1 = 32, kCstB1 = 96, kCstThr = 100 /* 16 doubles */, kCstOut = 132;
+constexpr int kCstThr = 0 /* 16 doubles */, kCstOut = 32;
 
 __device__ __forceinline__ half8 as_half8(uint32x4 v)
 {
@@ -124,32 +125,17 @@ __device__ __forceinline__ float transfer_fn(int tf, float x)
     return x;                                        // PureLin
 }
 
-__device__ __forceinline__ floatx16 mfma16(half8 a, half8 b, floatx16 c)
-{
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-}
-
-// This thread's quads of the pass whose first sample is `first` (row-relative).  The buffer
-// descriptor ends one past the last sample any existing frame reads, so quads beyond it come back
-// as zeros from the hardware bounds check: no per-lane guards.
+// The buffer descriptor of one pass's samples ends one past the last sample any existing frame
+// reads, so quads beyond it come back as zeros from the hardware bounds check: no per-lane guards.
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const float *row, int64_t first, int64_t s_eff, int nsmp)
 {
     int64_t left = s_eff - first;
     left = left < 0 ? 0 : (left > nsmp ? nsmp : left);
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(row + first), 0, (int)left * 4, 0x00020000);
 }
-template <int NL>
-__device__ __forceinline__ void load_tile(const float *row, int64_t first, int64_t s_eff, int nsmp, int nload, int tid,
-                                          uint32x4 (&v)[NL])
-{
-    const __amdgpu_buffer_rsrc_t rs = tile_rsrc(row, first, s_eff, nsmp);
-#pragma unroll
-    for (int k = 0; k < NL; k++)
-        if (k < nload) v[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * tid + 4096 * k, 0, 0);
-}
 
 // Diagnostic stamps (STAMP instantiation only; never the shipped path): s_memtime at phase
-// boundaries, summed per workgroup by wave 0 and stored to d.stamps[workgroup][phase].
+// boundaries, summed per workgroup by thread 0 and stored to d.stamps[workgroup][phase].
 #define SD_STAMP(slot)                                                                     \
     if (STAMP) {                                                                           \
         __builtin_amdgcn_sched_barrier(0);                                                 \
@@ -160,18 +146,24 @@ __device__ __forceinline__ void load_tile(const float *row, int64_t first, int64
         tprev = now;                                                                       \
     }
 
-template <int KS, int MT, bool STAMP>
+// KS: k-steps; TMAX / NL: array sizes for taps and staging quads; EXACT: timeRange == TMAX and
+// nload == NL are compile-time facts (no guards); SKEW: staged samples carry bank-spreading padding;
+// LEAN: the configuration class of the reference's example detector is a compile-time fact --
+// l2normalize first, linear |X| columns, two layers, TanSig hidden units (at most 4), one output --
+// so that instantiation carries only the code it runs (the generic one is ~8k instructions and
+// stalls on instruction fetch).
+template <int KS, int TMAX, int NL, bool EXACT, bool SKEW, bool LEAN, bool STAMP>
 __global__ void __launch_bounds__(kBlock, 1)
 fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t stride, int64_t s_eff, int64_t E,
              float *__restrict__ outputs, uint8_t *__restrict__ flags)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32x4 *lds_dfrag = reinterpret_cast<uint32x4 *>(smem + d.lds_dfrag);
-    float *smp = reinterpret_cast<float *>(smem + d.lds_hi);       // staged samples (scaled fp32)
-    float *ring = reinterpret_cast<float *>(smem + d.lds_pbuf);    // [H][PS evaluations][TL]: partial (t,h) of frame e+t
-    float *stat = reinterpret_cast<float *>(smem + d.lds_stat);    // [2][PS frames]: per-frame statistics
+    float *smp = reinterpret_cast<float *>(smem + d.lds_smp);        // staged samples (scaled fp32)
+    _Float16 *colh = reinterpret_cast<_Float16 *>(smem + d.lds_colh); // [PS frames][kColStride]: column hi parts
+    _Float16 *coll = reinterpret_cast<_Float16 *>(smem + d.lds_coll); //                           lo parts
+    float *stat = reinterpret_cast<float *>(smem + d.lds_stat);      // [2][PS frames]: per-frame min/max or mean/M2
     float *red = reinterpret_cast<float *>(smem + d.lds_red);
-    // evaluation-phase constants (kCst* offsets): read back with LDS latency, not a global round trip
     float *cst = reinterpret_cast<float *>(smem + d.lds_cst);
 
     const int tid = threadIdx.x;
@@ -184,132 +176,153 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
     if (e_b >= E) return;
     const int64_t e_e = (e_b + d.seg_evals < E) ? e_b + d.seg_evals : E;
     const float *row = samples + (int64_t)c * stride;
-    const int PS = d.ps, T = d.T, TL = d.tl, H = d.H;
+    const int PS = d.ps, T = EXACT ? TMAX : d.T, H = d.H;
+    const int nload = EXACT ? NL : d.nload;
+    const int norm = LEAN ? 1 : d.norm, scaling = LEAN ? 0 : d.scaling, power_mode = LEAN ? 0 : d.power_mode;
+    const int n_layers = LEAN ? 2 : d.n_layers, n_out = LEAN ? 1 : d.n_out, tf0 = LEAN ? 0 : d.tf0;
     const int fl = 32 * wave + r;     // this lane's frame inside the pass
 
-    // DFT basis fragments -> LDS (64 KB for W = 256), once per workgroup
+    // ---- once per workgroup: constants
     for (int i = tid; i < KS * 4 * 64; i += kBlock) lds_dfrag[i] = reinterpret_cast<const uint32x4 *>(d.dfrag)[i];
-    if (tid < 16) {
-        cst[kCstBias0 + tid] = tid < H ? d.bias0[tid] : 0.0f;
-        cst[kCstRvec + tid] = tid < H ? d.rvec[tid] : 0.0f;
-        reinterpret_cast<double *>(cst + kCstThr)[tid] = tid < d.n_out ? d.thresholds[tid] : 0.0;
+    if (tid < 16) reinterpret_cast<double *>(cst + kCstThr)[tid] = tid < n_out ? d.thresholds[tid] : 0.0;
+    for (int i = tid; i < d.n_out_fns * (1 + 2 * n_out); i += kBlock) cst[kCstOut + i] = d.out_params[i];
+    // first-layer fragments, one (hi, lo) pair per tap: A operand of v_mfma_f32_16x16x32_f16, lane l holds
+    // row l&15 (hidden unit, or the statistic row), k = 8*(l>>4) + j (bin)
+    half8 afr[TMAX][2];
+#pragma unroll
+    for (int t = 0; t < TMAX; t++)
+#pragma unroll
+        for (int p = 0; p < 2; p++)
+            afr[t][p] = as_half8(reinterpret_cast<const uint32x4 *>(d.afrag)[((t < T ? t : 0) * 2 + p) * 64 + lane]);
+    // evaluation-phase constants of the 4 hidden units this lane group owns (rows 4*(l>>4) + j of a 16x16 result)
+    const int g4 = lane >> 4;
+    float c_b0[4], c_rv[4], c_w1[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int h = 4 * g4 + j;
+        c_b0[j] = h < H ? d.bias0[h] : 0.0f;
+        c_rv[j] = h < H ? d.rvec[h] : 0.0f;
+#pragma unroll
+        for (int o = 0; o < 4; o++) c_w1[o][j] = (n_layers == 2 && h < H && o < n_out) ? d.w1[o * H + h] : 0.0f;
     }
-    if (tid < 64) cst[kCstW1 + tid] = (d.n_layers == 2 && (tid >> 4) < d.n_out && (tid & 15) < H) ? d.w1[(tid >> 4) * H + (tid & 15)] : 0.0f;
-    if (tid < 4) cst[kCstB1 + tid] = (d.n_layers == 2 && tid < d.n_out) ? d.b1[tid] : 0.0f;
-    for (int i = tid; i < d.n_out_fns * (1 + 2 * d.n_out); i += kBlock) cst[kCstOut + i] = d.out_params[i];
-    // folded first-layer fragments -> registers
-    half8 wfr[MT][2][2];
+    float c_b1[4];
 #pragma unroll
-    for (int m = 0; m < MT; m++)
-#pragma unroll
-        for (int s = 0; s < 2; s++)
-#pragma unroll
-            for (int p = 0; p < 2; p++)
-                wfr[m][s][p] = as_half8(reinterpret_cast<const uint32x4 *>(d.wfrag)[((m * 2 + s) * 2 + p) * 64 + lane]);
-    // where partial row (m, g) of this lane's frame goes in the ring: row = h*TP + t (TP = 2^tp_log2 >= T),
-    // it belongs to evaluation slot fl - t + (T-1) at position t; padding rows go to a spare word.
-    int poff[MT][16];
-#pragma unroll
-    for (int m = 0; m < MT; m++)
-#pragma unroll
-        for (int g = 0; g < 16; g++) {
-            const int prow = 32 * m + (g & 3) + 8 * (g >> 2) + 4 * hh;
-            const int t = prow & ((1 << d.tp_log2) - 1), h = prow >> d.tp_log2;
-            poff[m][g] = (t < TL && h < H) ? ((h * PS + fl - t + (T - 1)) * TL + t) : d.ring_spare + tid;
-        }
+    for (int o = 0; o < 4; o++) c_b1[o] = (n_layers == 2 && o < n_out) ? d.b1[o] : 0.0f;
+
     // this lane's frame in the staged stream, and where k-step ks of lane half hh starts inside it
-    const float *fptr = smp + fl * (d.hop + d.skew);
+    const float *fptr = smp + fl * (d.hop + (SKEW ? d.skew : 0)) + (SKEW ? 0 : 8 * hh);
     int ko[KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ks++) ko[ks] = d.koff[ks * 2 + hh];
-    const int wr0 = d.skew == 0 ? 4 * tid : 0;
+    for (int ks = 0; ks < KS; ks++) ko[ks] = SKEW ? d.koff[ks * 2 + hh] : 16 * ks;   // immediates without skew
+    const int wr0 = 4 * tid;
 
-    uint32x4 v[kFusedMaxLoads];
-    load_tile(row, e_b * d.hop + d.gap, s_eff, d.nsmp, d.nload, tid, v);
-    // results of the previous pass, stored at the start of the next one: the prefetch wait (vmcnt) then
-    // never sits behind a store that was issued moments ago
-    float pend_y[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    int64_t pend_e = -1;
-    bool pend_hit = false;
+    uint32x4 v[NL];
+    {
+        const __amdgpu_buffer_rsrc_t rs = tile_rsrc(row, e_b * d.hop + d.gap, s_eff, d.nsmp);
+#pragma unroll
+        for (int k = 0; k < NL; k++)
+            if (k < nload) v[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * tid + 4096 * k, 0, 0);
+    }
+    // results of the previous pass are stored at the start of the next one, so the wait for the
+    // prefetched samples never sits behind a store that was issued moments ago
+    float pend_y[2][4];
+    int64_t pend_e[2] = {-1, -1};
+    bool pend_hit[2] = {false, false};
+    int cse_prev = 0;                 // column scale exponent of the previous pass
     unsigned long long tsum[16] = {0}, tprev = 0;
     if (STAMP) tprev = __builtin_amdgcn_s_memtime();
 
     for (int pass = 0; pass < d.runs; pass++) {
         const int64_t jp = e_b + (int64_t)kTile * pass;       // first frame of this pass
         if (jp - (T - 1) >= e_e) break;
+        SD_STAMP(8)
 
-        SD_STAMP(8)                                           // loop back-edge
         // ---------------- block floating point: scale the tile so its largest sample is in [2^13, 2^14)
         float amax = 0.0f;
 #pragma unroll
-        for (int k = 0; k < kFusedMaxLoads; k++)
-            if (k < d.nload) {
+        for (int k = 0; k < NL; k++)
+            if (k < nload) {
                 const floatx4 f = as_floatx4(v[k]);
                 amax = absmax3(absmax3(amax, f[0], f[1]), f[2], f[3]);
             }
-        SD_STAMP(9)                                           // max over the prefetched registers (vmcnt wait)
+        SD_STAMP(9)
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
         if (lane == 0) red[wave] = amax;
-        SD_STAMP(0)                                           // amax (+ wait for the prefetched samples)
+        SD_STAMP(0)
         __syncthreads();                                      // (A) previous pass fully consumed
         SD_STAMP(1)
         amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-        int se = 13 - (int)((__float_as_uint(amax) >> 23) & 0xffu) + 127;   // exponent of the scale
-        se = amax > 0.0f ? (se < -100 ? -100 : (se > 100 ? 100 : se)) : 0;
+        int se = 13 - (int)((__float_as_uint(amax) >> 23) & 0xffu) + 127;   // exponent of the sample scale
+        const int lim = power_mode ? 40 : 100;
+        se = amax > 0.0f ? (se < -lim ? -lim : (se > lim ? lim : se)) : 0;
         se = __builtin_amdgcn_readfirstlane(se);
         const float sx = pow2f(se);
-        if (d.skew == 0) {
+        // columns of this pass and the T-1 carried ones share one scale: the smaller of the two tiles'
+        const int cse = scaling != 0 ? 0 : ((pass > 0 && cse_prev < se) ? cse_prev : se);
+        if (!SKEW) {
 #pragma unroll
-            for (int k = 0; k < kFusedMaxLoads; k++)
-                if (k < d.nload) {
+            for (int k = 0; k < NL; k++)
+                if (k < nload) {
                     const floatx4 f = as_floatx4(v[k]);
                     *reinterpret_cast<floatx4 *>(smp + wr0 + 1024 * k) = f * sx;
                 }
         } else {
 #pragma unroll
-            for (int k = 0; k < kFusedMaxLoads; k++)
-                if (k < d.nload) {
+            for (int k = 0; k < NL; k++)
+                if (k < nload) {
                     const int i = 4 * (tid + kBlock * k);     // quads past nsmp hold zeros and land in the buffer's slack
                     const floatx4 f = as_floatx4(v[k]);
                     *reinterpret_cast<floatx4 *>(smp + i + d.skew * (int)__umulhi((unsigned)i, d.hop_magic)) = f * sx;
                 }
         }
-        // evaluations the previous pass left incomplete move to the front of the ring (with their
-        // frames' statistics); everything behind them starts this pass empty
+        // the last T-1 columns of the previous pass move to the front (rescaled if the column scale changed)
         if (pass > 0) {
-            // (T-1) incomplete evaluations x H rows of TL floats, copied as float2 pairs
-            const int pairs = (T - 1) * (TL / 2);             // per hidden unit, contiguous in the ring
-            for (int h = 0; h < H; h++)
-                for (int i = tid; i < pairs; i += kBlock) {
-                    floatx2 *base = reinterpret_cast<floatx2 *>(ring + h * PS * TL);
-                    base[i] = base[kTile * (TL / 2) + i];
+            const int dexp = (cse - cse_prev) * (power_mode ? 2 : 1);
+            const int words = (T - 1) * (kColStride / 2);      // 32-bit words per array
+            for (int i = tid; i < 2 * words; i += kBlock) {
+                unsigned *arr = reinterpret_cast<unsigned *>(i < words ? colh : coll);
+                const int w = i < words ? i : i - words;
+                unsigned u = arr[kTile * (kColStride / 2) + w];
+                if (dexp != 0) {
+                    const int bin = 2 * (w % (kColStride / 2));
+                    union { unsigned u; _Float16 h[2]; } x;
+                    x.u = u;
+                    const float f0 = (float)x.h[0] * pow2f((bin == d.stat_bin || bin == d.stat_bin + 1) ? 2 * dexp : dexp);
+                    const float f1 = (float)x.h[1] * pow2f((bin + 1 == d.stat_bin || bin == d.stat_bin) ? 2 * dexp : dexp);
+                    union { decltype(__builtin_amdgcn_cvt_pkrtz(0.f, 0.f)) h; unsigned u; } y;
+                    y.h = __builtin_amdgcn_cvt_pkrtz(f0, f1);
+                    u = y.u;
                 }
-            if (tid < T - 1) {
+                arr[w] = u;
+            }
+            if (norm >= 2 && tid < T - 1) {
                 stat[tid] = stat[kTile + tid];
                 stat[PS + tid] = stat[PS + kTile + tid];
             }
         }
-        SD_STAMP(2)                                           // scale + LDS stage writes + carry
+        cse_prev = cse;
+        SD_STAMP(2)
         __syncthreads();                                      // (B) samples staged
         SD_STAMP(3)
 
-        SD_STAMP(10)
-        // previous pass's results out (2-layer networks; see the evaluation phase)
-        if (pend_e >= 0) {
-            if (outputs) {
+        // previous pass's results out
 #pragma unroll
-                for (int o = 0; o < 4; o++)
-                    if (o < d.n_out) outputs[((int64_t)c * E + pend_e) * d.n_out + o] = pend_y[o];
+        for (int n = 0; n < 2; n++)
+            if (pend_e[n] >= 0) {
+                if (outputs) {
+#pragma unroll
+                    for (int o = 0; o < 4; o++)
+                        if (o < n_out) outputs[((int64_t)c * E + pend_e[n]) * n_out + o] = pend_y[n][o];
+                }
+                if (flags) flags[(int64_t)c * E + pend_e[n]] = pend_hit[n] ? 1 : 0;
+                pend_e[n] = -1;
             }
-            if (flags) flags[(int64_t)c * E + pend_e] = pend_hit ? 1 : 0;
-            pend_e = -1;
-        }
         // next pass's samples: fetched during this pass's matrix work, a load or two per k-step, so the
         // memory queue never backs up into the wave (a burst of 17 KB-sized loads stalls issue for ~3k cycles)
         const __amdgpu_buffer_rsrc_t nrs = tile_rsrc(row, (jp + kTile) * d.hop + d.gap, pass + 1 < d.runs ? s_eff : 0, d.nsmp);
-        constexpr int kLoadsPerStep = (kFusedMaxLoads + KS - 1) / KS;
-        SD_STAMP(11)                                          // deferred stores + prefetch issue
+        constexpr int kLoadsPerStep = (NL + KS - 1) / KS;
+        SD_STAMP(11)
 
         // ---------------- band-limited DFT of this wave's 32 frames on the matrix cores.
         // Software pipeline: while the six MFMAs of k-step ks execute, the lane's next 8 samples
@@ -344,14 +357,14 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
 #pragma unroll
             for (int j = 0; j < kLoadsPerStep; j++) {         // next pass's quads ks*kLoadsPerStep + j
                 const int k = ks * kLoadsPerStep + j;
-                if (k < kFusedMaxLoads && k < d.nload) v[k] = __builtin_amdgcn_raw_buffer_load_b128(nrs, 16 * tid + 4096 * k, 0, 0);
+                if (k < NL && k < nload) v[k] = __builtin_amdgcn_raw_buffer_load_b128(nrs, 16 * tid + 4096 * k, 0, 0);
             }
-            acc_re = mfma16(a_re_h, cbh, acc_re);
-            acc_im = mfma16(a_im_h, cbh, acc_im);
-            acc_re = mfma16(a_re_h, cbl, acc_re);
-            acc_im = mfma16(a_im_h, cbl, acc_im);
-            acc_re = mfma16(a_re_l, cbh, acc_re);
-            acc_im = mfma16(a_im_l, cbh, acc_im);
+            acc_re = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_re_h, cbh, acc_re, 0, 0, 0);
+            acc_im = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_im_h, cbh, acc_im, 0, 0, 0);
+            acc_re = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_re_h, cbl, acc_re, 0, 0, 0);
+            acc_im = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_im_h, cbl, acc_im, 0, 0, 0);
+            acc_re = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_re_l, cbh, acc_re, 0, 0, 0);
+            acc_im = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_im_l, cbh, acc_im, 0, 0, 0);
             if (ks + 1 < KS) split8(n0, n1, bh, bl);          // 24 VALU, scheduled into the MFMA shadows below
             // schedule: this k-step's 6 LDS fetches first (their data is used one and two k-steps later),
             // then each MFMA followed by 4 of the split's VALU instructions
@@ -362,39 +375,34 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
                 __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   // 4 VALU
             }
         }
+        SD_STAMP(4)
 
-        SD_STAMP(4)                                           // DFT MFMA loop
         // ---------------- magnitude (zvabs/2 :329-333 or zvmags/4 :270-274), scaling
-        // (SyllableDetector.swift:184-212), per-frame statistic, f16 split for the next MFMA.
-        // Result layout: column = frame r, register g of lane half hh = bin row (g&3) + 8(g>>2) + 4hh.
+        // (SyllableDetector.swift:184-212), statistic, f16 split, column -> LDS.
+        // Result layout: column = frame r, register g of lane half hh = bin (g&3) + 8(g>>2) + 4hh.
         const float inv = pow2f(-se - 13);                   // accumulators hold X * sx * 2^13
-        float cs = 1.0f;                                     // keeps the column inside f16 range (power of two)
-        if (d.scaling == 0) cs = d.power_mode ? pow2f(2 * (se < 40 ? (se > -40 ? se : -40) : 40) - 30) : pow2f(se - 8);
-        const int fh = d.F - 4 * hh;                          // register g holds a band row iff (g&3) + 8(g>>2) < fh
+        // column scale (power of two; col_shift from the basis' largest row sum): |X| * 2^(cse - shift) < 2^13,
+        // |X|^2 * 2^(2 (cse - shift)) < 2^13 with its own shift; log/dB columns are stored unscaled
+        const float cs = scaling != 0 ? 1.0f : (power_mode ? pow2f(2 * (cse - d.col_shift)) : pow2f(cse - d.col_shift));
+        const int fh = d.F - 4 * hh;                          // register g holds a band bin iff (g&3) + 8(g>>2) < fh
         float cval[16];
 #pragma unroll
         for (int g = 0; g < 16; g++) {
             const float re = acc_re[g] * inv, im = acc_im[g] * inv;
             const float pw = fmaf(re, re, im * im);
-            cval[g] = d.power_mode ? pw : __builtin_amdgcn_sqrtf(pw);
+            cval[g] = power_mode ? pw : __builtin_amdgcn_sqrtf(pw);
         }
-        if (d.scaling != 0) {
-            const float k = d.scaling == 1 ? 0.6931471805599453f : 6.020599913279624f;   // ln 2, 20 log10 2
+        if (scaling != 0) {
+            const float k = scaling == 1 ? 0.6931471805599453f : 6.020599913279624f;   // ln 2, 20 log10 2
 #pragma unroll
             for (int g = 0; g < 16; g++) cval[g] = k * __builtin_amdgcn_logf(cval[g]);   // v_log_f32 = log2
         }
-        if (d.F < 32 || d.scaling != 0) {
+        if (d.F < 32 || scaling != 0) {
 #pragma unroll
             for (int g = 0; g < 16; g++) cval[g] = ((g & 3) + 8 * (g >> 2)) < fh ? cval[g] : 0.0f;
         }
         const int slot = (T - 1) + fl;
-        if (d.norm == 1) {
-            float st0 = 0.0f;
-#pragma unroll
-            for (int g = 0; g < 16; g++) st0 = fmaf(cval[g], cval[g], st0);
-            st0 += __shfl_xor(st0, 32, 64);
-            if (hh == 0) stat[slot] = st0;
-        } else if (d.norm == 2) {
+        if (norm == 2) {
             float st0 = INFINITY, st1 = -INFINITY;
 #pragma unroll
             for (int g = 0; g < 16; g++) {
@@ -405,7 +413,7 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
             st0 = fminf(st0, __shfl_xor(st0, 32, 64));
             st1 = fmaxf(st1, __shfl_xor(st1, 32, 64));
             if (hh == 0) { stat[slot] = st0; stat[PS + slot] = st1; }
-        } else if (d.norm == 3) {
+        } else if (norm == 3) {
             float st0 = 0.0f, st1 = 0.0f;
 #pragma unroll
             for (int g = 0; g < 16; g++) st0 += cval[g];
@@ -419,126 +427,183 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
             st1 += __shfl_xor(st1, 32, 64);
             if (hh == 0) { stat[slot] = st0; stat[PS + slot] = st1; }
         }
-        half8 bh2[2], bl2[2];
 #pragma unroll
-        for (int s = 0; s < 2; s++) {
-            floatx4 lo4, hi4;
+        for (int g = 0; g < 16; g++) cval[g] *= cs;
+        if (norm == 1) {
+            // sum of squares of the (scaled) column rides in two spare bins: its top 11 bits in bin F and the
+            // remainder, scaled by 2^11 so that it stays a normal f16, in bin F+1 (weights 1 and 2^-11 in row H
+            // of the first-layer fragments) -- together exact to fp32, whatever the column's level
+            float ss = 0.0f;
 #pragma unroll
-            for (int j = 0; j < 4; j++) { lo4[j] = cval[8 * s + j] * cs; hi4[j] = cval[8 * s + 4 + j] * cs; }
-            split8(lo4, hi4, bh2[s], bl2[s]);
-        }
-
-        // ---------------- first layer, folded and split per time slot: P[(t,h)][frame] on the matrix cores
-        const float unscale = d.w_unscale / cs;
+            for (int g = 0; g < 16; g++) ss = fmaf(cval[g], cval[g], ss);
+            ss += __shfl_xor(ss, 32, 64);
+            ss *= scaling != 0 ? 0.015625f : 9.5367431640625e-07f;   // 2^-6 (log/dB values) or 2^-20
+            const float ss_hi = __uint_as_float(__float_as_uint(ss) & 0xFFFFE000u);
+            const float ss_lo = (ss - ss_hi) * 2048.0f;
 #pragma unroll
-        for (int m = 0; m < MT; m++) {
-            floatx16 pacc = {0};
-#pragma unroll
-            for (int s = 0; s < 2; s++) {
-                pacc = mfma16(wfr[m][s][0], bh2[s], pacc);
-                pacc = mfma16(wfr[m][s][0], bl2[s], pacc);
-                pacc = mfma16(wfr[m][s][1], bh2[s], pacc);
+            for (int g = 0; g < 16; g++) {
+                cval[g] = (hh == d.stat_hh && g == d.stat_g) ? ss_hi : cval[g];
+                cval[g] = (hh == d.stat_hh2 && g == d.stat_g2) ? ss_lo : cval[g];
             }
-#pragma unroll
-            for (int g = 0; g < 16; g++) ring[poff[m][g]] = pacc[g] * unscale;
         }
-        SD_STAMP(5)                                           // magnitude, statistic, layer-0 MFMA, ring writes
-        __syncthreads();                                      // (C) partials of all 128 frames visible
+        {
+            _Float16 *ph = colh + slot * kColStride + 4 * hh, *pl = coll + slot * kColStride + 4 * hh;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {                     // bins 8q + 4hh .. +3: four consecutive halves
+                unsigned h0, l0, h1, l1;
+                split_pair(cval[4 * q], cval[4 * q + 1], h0, l0);
+                split_pair(cval[4 * q + 2], cval[4 * q + 3], h1, l1);
+                uint32x2 uh = {h0, h1}, ul = {l0, l1};
+                *reinterpret_cast<uint32x2 *>(ph + 8 * q) = uh;
+                *reinterpret_cast<uint32x2 *>(pl + 8 * q) = ul;
+            }
+        }
+        SD_STAMP(5)
+        __syncthreads();                                      // (C) columns of all 128 frames visible
         SD_STAMP(6)
 
-        // ---------------- evaluations completed by this pass: slot q = e - (jp - (T-1)); lane half hh
-        // owns hidden units hh, hh+2, ...; both halves hold the same evaluation
+        // ---------------- first layer as a shifted GEMM + the rest of the network in registers.
+        // Wave `wave` finishes evaluation slots 32*wave .. +31 (slot q: e = jp - (T-1) + q, columns q .. q+T-1),
+        // 16 per MFMA tile: result column = l&15, rows 4*(l>>4) + j = hidden unit (row H = window sum of squares).
+        const float zs = d.w_unscale / cs;                    // first-layer sums back to true units
+        floatx4 zz[2] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};
         {
-            const int q = fl;
-            const int64_t e = jp - (T - 1) + q;
+            const int qa = 32 * wave + (lane & 15);
+            const _Float16 *bph = colh + qa * kColStride + 8 * g4, *bpl = coll + qa * kColStride + 8 * g4;
+            constexpr int kTileOff = 16 * kColStride;         // second tile: 16 evaluation slots further
+            uint32x4 fh0[2], fl0[2], fh1[2], fl1[2];          // [tile], two taps in flight
+            fh0[0] = *reinterpret_cast<const uint32x4 *>(bph);
+            fl0[0] = *reinterpret_cast<const uint32x4 *>(bpl);
+            fh0[1] = *reinterpret_cast<const uint32x4 *>(bph + kTileOff);
+            fl0[1] = *reinterpret_cast<const uint32x4 *>(bpl + kTileOff);
+            if (T > 1) {
+                fh1[0] = *reinterpret_cast<const uint32x4 *>(bph + kColStride);
+                fl1[0] = *reinterpret_cast<const uint32x4 *>(bpl + kColStride);
+                fh1[1] = *reinterpret_cast<const uint32x4 *>(bph + kColStride + kTileOff);
+                fl1[1] = *reinterpret_cast<const uint32x4 *>(bpl + kColStride + kTileOff);
+            }
+#pragma unroll
+            for (int t = 0; t < TMAX; t++) {
+                if (t < T) {
+                    const half8 h0 = as_half8(fh0[0]), l0 = as_half8(fl0[0]), h1 = as_half8(fh0[1]), l1 = as_half8(fl0[1]);
+                    fh0[0] = fh1[0]; fl0[0] = fl1[0]; fh0[1] = fh1[1]; fl0[1] = fl1[1];
+                    if (t + 2 < T) {
+                        fh1[0] = *reinterpret_cast<const uint32x4 *>(bph + (t + 2) * kColStride);
+                        fl1[0] = *reinterpret_cast<const uint32x4 *>(bpl + (t + 2) * kColStride);
+                        fh1[1] = *reinterpret_cast<const uint32x4 *>(bph + (t + 2) * kColStride + kTileOff);
+                        fl1[1] = *reinterpret_cast<const uint32x4 *>(bpl + (t + 2) * kColStride + kTileOff);
+                    }
+                    zz[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[t][0], h0, zz[0], 0, 0, 0);
+                    zz[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[t][0], h1, zz[1], 0, 0, 0);
+                    zz[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[t][0], l0, zz[0], 0, 0, 0);
+                    zz[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[t][0], l1, zz[1], 0, 0, 0);
+                    zz[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[t][1], h0, zz[0], 0, 0, 0);
+                    zz[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[t][1], h1, zz[1], 0, 0, 0);
+                }
+            }
+        }
+        SD_STAMP(12)                                          // first-layer GEMM
+#pragma unroll
+        for (int n = 0; n < 2; n++) {
+            const floatx4 z = zz[n];
+            const int q0 = 32 * wave + 16 * n + (lane & 15);
+            const int64_t e = jp - (T - 1) + q0;
             const bool valid = e >= e_b && e < e_e;
-            float alpha = 1.0f, beta = 0.0f;
-            if (d.norm == 1) {                                // L2Normalize, NeuralNet.swift:47-59
-                float ssw = 0.0f;
-#pragma unroll 4
-                for (int t = 0; t < T; t++) ssw += stat[q + t];
-                alpha = __builtin_amdgcn_rsqf(ssw);
-            } else if (d.norm == 2) {                         // Normalize, :69-96
+            float alpha = zs, beta = 0.0f;                    // layer-0 input = alpha * z + beta * rvec + bias0
+            if (norm == 1) {                                // L2Normalize, NeuralNet.swift:47-59
+                const float zst = d.stat_row & 2 ? (d.stat_row & 1 ? z[3] : z[2]) : (d.stat_row & 1 ? z[1] : z[0]);
+                const float ssw = __shfl(zst, (d.stat_row >> 2) * 16 + (lane & 15), 64);
+                alpha = d.w_unscale * (scaling != 0 ? 0.125f : 0.0009765625f) * __builtin_amdgcn_rsqf(ssw);   // 2^-3 | 2^-10
+            } else if (norm == 2) {                         // Normalize, :69-96
                 float mn = INFINITY, mx = -INFINITY;
-                for (int t = 0; t < T; t++) { mn = fminf(mn, stat[q + t]); mx = fmaxf(mx, stat[PS + q + t]); }
+                for (int t = 0; t < T; t++) { mn = fminf(mn, stat[q0 + t]); mx = fmaxf(mx, stat[PS + q0 + t]); }
                 const float range = mx - mn;
                 if (range == 0.0f) { alpha = 0.0f; beta = -1.0f; }
-                else { alpha = 2.0f / range; beta = (0.0f - mn - mx) / range; }
-            } else if (d.norm == 3) {                         // NormalizeStd, :105-108 (population sigma)
-                float n = 0.0f, mean = 0.0f, m2 = 0.0f;
+                else { alpha = zs * 2.0f / range; beta = (0.0f - mn - mx) / range; }
+            } else if (norm == 3) {                         // NormalizeStd, :105-108 (population sigma)
+                float nn = 0.0f, mean = 0.0f, m2 = 0.0f;
                 for (int t = 0; t < T; t++) {                 // pairwise-stable combination of per-frame (mean, M2)
-                    const float nb = (float)d.F, tot = n + nb, dlt = stat[q + t] - mean;
+                    const float nb = (float)d.F, tot = nn + nb, dlt = stat[q0 + t] - mean;
                     mean += dlt * nb / tot;
-                    m2 += stat[PS + q + t] + dlt * dlt * n * nb / tot;
-                    n = tot;
+                    m2 += stat[PS + q0 + t] + dlt * dlt * nn * nb / tot;
+                    nn = tot;
                 }
                 const float sd = sqrtf(m2 / (float)d.I);
-                alpha = 1.0f / sd;
+                alpha = zs / sd;
                 beta = -mean / sd;
             }
-            const int64_t obase = ((int64_t)c * E + e) * d.n_out;
+            SD_STAMP(13)                                      // window statistic -> alpha, beta
+            float a[4];                                       // rows past H (padding, statistic) contribute nothing
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                a[j] = (4 * g4 + j) < H ? transfer_fn(tf0, fmaf(alpha, z[j], fmaf(beta, c_rv[j], c_b0[j]))) : 0.0f;
+            SD_STAMP(14)                                      // transfer function of layer 0
             const double *thr = reinterpret_cast<const double *>(cst + kCstThr);
-            float y[4] = {0.0f, 0.0f, 0.0f, 0.0f};
             bool hit = false;
-            for (int h = hh; h < H; h += 2) {
-                const floatx2 *pp = reinterpret_cast<const floatx2 *>(ring + (h * PS + q) * TL);
-                const float b0 = cst[kCstBias0 + h], rv = cst[kCstRvec + h];
-                const float w10 = cst[kCstW1 + h], w11 = cst[kCstW1 + 16 + h], w12 = cst[kCstW1 + 32 + h], w13 = cst[kCstW1 + 48 + h];
-                float z0 = 0.0f, z1 = 0.0f;
-#pragma unroll 8
-                for (int t = 0; t < TL / 2; t++) { const floatx2 p2 = pp[t]; z0 += p2[0]; z1 += p2[1]; }
-                float a = transfer_fn(d.tf0, fmaf(alpha, z0 + z1, fmaf(beta, rv, b0)));
-                if (d.n_layers == 2) {
-                    y[0] = fmaf(w10, a, y[0]); y[1] = fmaf(w11, a, y[1]); y[2] = fmaf(w12, a, y[2]); y[3] = fmaf(w13, a, y[3]);
-                } else {
-                    for (int k = 0; k < d.n_out_fns; k++) {                    // reverse maps, NeuralNet.swift:137-142 / :175-180
-                        const float *op = cst + kCstOut + k * (1 + 2 * d.n_out);
-                        a = (a - op[0]) / op[1 + h] + op[1 + d.n_out + h];
-                    }
-                    if (valid && outputs) outputs[obase + h] = a;
-                    if (h == 0 || d.rule == 1) hit = hit || ((double)a >= thr[h]);
-                }
-            }
-            if (d.n_layers == 2) {
+            if (n_layers == 2) {
 #pragma unroll
                 for (int o = 0; o < 4; o++) {
-                    if (o < d.n_out) {
-                        float yo = y[o] + __shfl_xor(y[o], 32, 64);
-                        yo = transfer_fn(d.tf1, yo + cst[kCstB1 + o]);
-                        for (int k = 0; k < d.n_out_fns; k++) {
-                            const float *op = cst + kCstOut + k * (1 + 2 * d.n_out);
-                            yo = (yo - op[0]) / op[1 + o] + op[1 + d.n_out + o];
+                    if (o < n_out) {
+                        float y = c_w1[o][0] * a[0];          // padding rows carry zero weights
+                        y = fmaf(c_w1[o][1], a[1], y);
+                        y = fmaf(c_w1[o][2], a[2], y);
+                        y = fmaf(c_w1[o][3], a[3], y);
+                        if (!LEAN && H > 4) {
+                            y += __shfl_xor(y, 16, 64);
+                            y += __shfl_xor(y, 32, 64);
                         }
-                        pend_y[o] = yo;
-                        if (o == 0 || d.rule == 1) hit = hit || ((double)yo >= thr[o]);
+                        y = transfer_fn(d.tf1, y + c_b1[o]);
+                        for (int k = 0; k < d.n_out_fns; k++) {       // reverse maps, NeuralNet.swift:137-142 / :175-180
+                            const float *op = cst + kCstOut + k * (1 + 2 * n_out);
+                            y = (y - op[0]) / op[1 + o] + op[1 + n_out + o];
+                        }
+                        pend_y[n][o] = y;
+                        if (o == 0 || d.rule == 1) hit = hit || ((double)y >= thr[o]);
                     }
                 }
-                pend_hit = hit;
-                pend_e = (valid && hh == 0) ? e : -1;
+                pend_hit[n] = hit;
+                pend_e[n] = (valid && g4 == 0) ? e : -1;
             } else {
-                hit = hit || (__shfl_xor((int)hit, 32, 64) != 0);
-                if (valid && hh == 0 && flags) flags[(int64_t)c * E + e] = hit ? 1 : 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int h = 4 * g4 + j;
+                    if (h < H) {
+                        float y = a[j];
+                        for (int k = 0; k < d.n_out_fns; k++) {
+                            const float *op = cst + kCstOut + k * (1 + 2 * n_out);
+                            y = (y - op[0]) / op[1 + h] + op[1 + n_out + h];
+                        }
+                        if (valid && outputs) outputs[((int64_t)c * E + e) * n_out + h] = y;
+                        if (h == 0 || d.rule == 1) hit = hit || ((double)y >= thr[h]);
+                    }
+                }
+                int anyhit = hit ? 1 : 0;
+                anyhit |= __shfl_xor(anyhit, 16, 64);
+                anyhit |= __shfl_xor(anyhit, 32, 64);
+                if (valid && g4 == 0 && flags) flags[(int64_t)c * E + e] = anyhit ? 1 : 0;
             }
         }
-        SD_STAMP(7)                                           // evaluations
+        SD_STAMP(7)
     }
-    if (pend_e >= 0) {
-        if (outputs) {
 #pragma unroll
-            for (int o = 0; o < 4; o++)
-                if (o < d.n_out) outputs[((int64_t)c * E + pend_e) * d.n_out + o] = pend_y[o];
+    for (int n = 0; n < 2; n++)
+        if (pend_e[n] >= 0) {
+            if (outputs) {
+#pragma unroll
+                for (int o = 0; o < 4; o++)
+                    if (o < n_out) outputs[((int64_t)c * E + pend_e[n]) * n_out + o] = pend_y[n][o];
+            }
+            if (flags) flags[(int64_t)c * E + pend_e[n]] = pend_hit[n] ? 1 : 0;
         }
-        if (flags) flags[(int64_t)c * E + pend_e] = pend_hit ? 1 : 0;
-    }
     if (STAMP && tid == 0 && d.stamps)
         for (int i = 0; i < 16; i++) d.stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + i] = tsum[i];
 }
 
-template <int KS, int MT, bool STAMP = false>
+template <int KS, int TMAX, int NL, bool EXACT, bool SKEW, bool LEAN = false, bool STAMP = false>
 hipError_t launch_one(const FusedDesc &d, const float *samples, int64_t stride, int C, int64_t s_eff, int64_t E,
                       float *outputs, uint8_t *flags, hipStream_t stream)
 {
-    auto kern = fused_kernel<KS, MT, STAMP>;
+    auto kern = fused_kernel<KS, TMAX, NL, EXACT, SKEW, LEAN, STAMP>;
     hipError_t st = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, d.lds_total);
     if (st != hipSuccess) return st;
     const int64_t segs = (E + d.seg_evals - 1) / d.seg_evals;
@@ -549,10 +614,7 @@ hipError_t launch_one(const FusedDesc &d, const float *samples, int64_t stride, 
 
 }  // namespace
 
-int fused_supported(int KS, int MT)
-{
-    return (KS == 16 || KS == 8) && (MT == 1 || MT == 2 || MT == 4) ? 1 : 0;
-}
+int fused_taps_max(int T) { return T <= 12 ? 12 : 0; }
 
 hipError_t launch_fused(const FusedDesc &d, const float *samples, int64_t stride, int C, int64_t S, int64_t J,
                         int64_t E, float *outputs, uint8_t *flags, hipStream_t stream)
@@ -561,16 +623,18 @@ hipError_t launch_fused(const FusedDesc &d, const float *samples, int64_t stride
     if (E <= 0 || C <= 0) return hipSuccess;
     // one past the last sample an existing frame reads: frame J-1 covers [(J-1)*hop + gap, ... + W)
     const int64_t s_eff = (J - 1) * (int64_t)d.hop + d.gap + d.W;
-    if (d.stamps && d.KS == 16 && d.MT == 2) return launch_one<16, 2, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
-#define SD_CASE(K, M) \
-    if (d.KS == K && d.MT == M) return launch_one<K, M>(d, samples, stride, C, s_eff, E, outputs, flags, stream)
-    SD_CASE(16, 1);
-    SD_CASE(16, 2);
-    SD_CASE(16, 4);
-    SD_CASE(8, 1);
-    SD_CASE(8, 2);
-    SD_CASE(8, 4);
-#undef SD_CASE
+    const bool skew = d.skew != 0;
+    // the reference's example shape (W = 256, hop 132, timeRange 10) gets an instantiation with exact sizes
+    if (d.KS == 16 && d.T == 10 && d.nload == 17 && !skew) {
+        const bool lean = d.norm == 1 && d.scaling == 0 && d.power_mode == 0 && d.n_layers == 2 && d.tf0 == 0 && d.n_out == 1 && d.H <= 4;
+        if (lean && d.stamps) return launch_one<16, 10, 17, true, false, true, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
+        if (lean) return launch_one<16, 10, 17, true, false, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
+        return launch_one<16, 10, 17, true, false>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
+    }
+    if (d.KS == 16) return skew ? launch_one<16, 12, kFusedMaxLoads, false, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream)
+                                : launch_one<16, 12, kFusedMaxLoads, false, false>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
+    if (d.KS == 8) return skew ? launch_one<8, 12, kFusedMaxLoads, false, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream)
+                               : launch_one<8, 12, kFusedMaxLoads, false, false>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
     return hipErrorInvalidValue;
 }
 

@@ -207,18 +207,16 @@ int upload_fused(syldet *h)
         if (bytes) std::memcpy(blob.data() + off, src, bytes);
         return off;
     };
-    const size_t o_d = put(p.dfrag.data(), p.dfrag.size() * 2), o_w = put(p.wfrag.data(), p.wfrag.size() * 2);
+    const size_t o_d = put(p.dfrag.data(), p.dfrag.size() * 2), o_w = put(p.afrag.data(), p.afrag.size() * 2);
     const size_t o_k = put(p.koff.data(), p.koff.size() * 4), o_b = put(p.bias0.data(), p.bias0.size() * 4);
     const size_t o_r = put(p.rvec.data(), p.rvec.size() * 4), o_w1 = put(p.w1.data(), p.w1.size() * 4);
     const size_t o_b1 = put(p.b1.data(), p.b1.size() * 4), o_op = put(p.out_params.data(), p.out_params.size() * 4);
-    const float zero4[4] = {0.f, 0.f, 0.f, 0.f};
-    const size_t o_z = put(zero4, sizeof(zero4));
     if (int st = h->d_fused.reserve(blob.size())) return st;
     SYLDET_HIP(hipMemcpy(h->d_fused.ptr, blob.data(), blob.size(), hipMemcpyHostToDevice));
     unsigned char *base = (unsigned char *)h->d_fused.ptr;
     FusedDesc &d = p.desc;
     d.dfrag = (const uint4 *)(base + o_d);
-    d.wfrag = (const uint4 *)(base + o_w);
+    d.afrag = (const uint4 *)(base + o_w);
     d.koff = (const int *)(base + o_k);
     d.bias0 = (const float *)(base + o_b);
     d.rvec = (const float *)(base + o_r);
@@ -226,7 +224,6 @@ int upload_fused(syldet *h)
     d.b1 = (const float *)(base + o_b1);
     d.out_params = (const float *)(base + o_op);
     d.thresholds = (const double *)h->d_thr.ptr;
-    d.zeros = (const float *)(base + o_z);
     return SYLDET_OK;
 }
 
@@ -295,8 +292,8 @@ int run_on_stream(syldet *h, const float *d_samples, int64_t S, int64_t stride, 
             double tot = 0;
             for (double v : sum) tot += v;
             static const char *names[16] = {"shuffle-reduce+red", "barrier A", "scale+stage+carry", "barrier B", "DFT MFMA loop",
-                                            "mag+stat+layer0+ring", "barrier C", "evaluations", "loop back-edge", "max over prefetch (vmcnt)",
-                                            "-", "deferred stores+prefetch issue", "-", "-", "-", "-"};
+                                            "mag+stat+columns", "barrier C", "layer1+out+compare", "loop back-edge", "max over prefetch (vmcnt)",
+                                            "-", "deferred stores+prefetch issue", "layer-0 GEMM", "alpha/beta", "transfer fn", "-"};
             std::fprintf(stderr, "[syldet stamps] runs=%d workgroups=%zu cycles/pass=%.0f\n", d.runs, n / 16, tot / ((double)(n / 16) * d.runs));
             for (int i = 0; i < 16; i++)
                 if (sum[i] > 0) std::fprintf(stderr, "   %-32s %6.0f cycles/pass  %5.1f %%\n", names[i], sum[i] / ((double)(n / 16) * d.runs), 100.0 * sum[i] / tot);
