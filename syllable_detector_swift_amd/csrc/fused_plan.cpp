@@ -89,7 +89,7 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
     const int n_out = g.outputs;
     if (c.n_layers == 2 && n_out > 4) return no("more than 4 outputs");
     if (c.n_output_fns > kMaxFns) return no("too many output functions");
-    const int KS = W <= 128 ? 8 : 16;
+    const int KS = W <= 128 ? 4 : 8;              // k-steps of 32 samples
     if (fused_taps_max(T) == 0) return no("timeRange above 12");
 
     // ---- input chain pattern
@@ -116,8 +116,8 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
 
     // ---- geometry of a pass
     const int hop = g.hop;
-    const int nsmp = (kFusedTileFrames - 1) * hop + KS * 16;
-    const int nload = (nsmp / 4 + 255) / 256;
+    const int nsmp = (kFusedTileFrames - 1) * hop + KS * 32;
+    const int nload = (nsmp / 4 + kFusedBlock - 1) / kFusedBlock;
     if (nload > kFusedMaxLoads) return no("hop too large for the staging registers");
     // LDS bank spreading: a lane reads 8 consecutive fp32 samples of its frame with two ds_read_b128;
     // those are conflict-free when consecutive frames start an odd number of 16-byte slots apart
@@ -126,7 +126,7 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
     // because they start at multiples of 8 inside a frame and hop is then a multiple of 8.
     const int skew = ((hop / 4) % 2 == 0) ? 4 : 0;
     auto skewed = [&](int i) { return i + skew * (i / hop); };
-    const int nsmp_p = (skewed(nload * 1024 + 16) + 15) / 8 * 8;   // every thread writes all its quads
+    const int nsmp_p = (skewed(nload * kFusedBlock * 4 + 16) + 15) / 8 * 8;   // every thread writes all its quads
     const int PS = kFusedTileFrames + T - 1;
 
     FusedDesc &d = p.desc;
@@ -138,16 +138,16 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
     d.nsmp = nsmp; d.nload = nload; d.skew = skew;
     d.hop_magic = (unsigned)((0x100000000ull + (unsigned)hop - 1) / (unsigned)hop);
     d.ps = PS;
-    // a result register g of lane half hh holds bin (g&3) + 8(g>>2) + 4hh
+    // a lane of group g4 holds bins 4*g4 + j (value index j) and 16 + 4*g4 + j (value index 4 + j)
     d.stat_bin = norm == 1 ? F : -1;
-    d.stat_hh = (F >> 2) & 1;
-    d.stat_g = (F & 3) + 4 * (F >> 3);
-    d.stat_hh2 = ((F + 1) >> 2) & 1;
-    d.stat_g2 = ((F + 1) & 3) + 4 * ((F + 1) >> 3);
+    d.stat_g4 = (F & 15) >> 2;
+    d.stat_i = 4 * (F >> 4) + (F & 3);
+    d.stat_g4b = ((F + 1) & 15) >> 2;
+    d.stat_ib = 4 * ((F + 1) >> 4) + ((F + 1) & 3);
     d.stat_row = H;
     int off = 0;
     auto take = [&off](int bytes) { const int o = off; off += (bytes + 15) / 16 * 16; return o; };
-    d.lds_dfrag = take(KS * 4 * 1024);
+    d.lds_dfrag = take(KS * 8 * 1024);
     d.lds_smp = take(nsmp_p * 4);                    // staged samples, scaled fp32
     d.lds_colh = take(PS * kFusedColStride * 2);     // |X| columns, f16 hi
     d.lds_coll = take(PS * kFusedColStride * 2);     //              f16 lo
@@ -157,28 +157,30 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
     d.lds_total = off;
     if (off > 160 * 1024) return no("LDS budget exceeded");
 
-    // ---- DFT basis fragments: A operand of v_mfma_f32_32x32x16_f16, lane l holds row l&31,
-    // k = 8*(l>>5) + j.  Basis row r < F: re = w[n] cos(2 pi (f0+r) n / N), im = -w[n] sin(...), scaled by 2^13.
+    // ---- DFT basis fragments: A operand of v_mfma_f32_16x16x32_f16, lane l holds row l&15 of its tile,
+    // k = 8*(l>>4) + j.  Tiles: re bins 0-15, re 16-31, im 0-15, im 16-31.  Basis row r < F:
+    // re = w[n] cos(2 pi (f0+r) n / N), im = -w[n] sin(...), scaled by 2^13.
     std::vector<float> win((size_t)W);
     make_window(c.window, W, win.data());
     const double two_pi = 6.283185307179586476925286766559;
-    p.dfrag.assign((size_t)KS * 4 * 64 * 8, 0);
+    p.dfrag.assign((size_t)KS * 8 * 64 * 8, 0);
     for (int ks = 0; ks < KS; ks++)
-        for (int tile = 0; tile < 2; tile++)
+        for (int m = 0; m < 4; m++)
             for (int l = 0; l < 64; l++)
                 for (int j = 0; j < 8; j++) {
-                    const int r = l & 31, n = 16 * ks + 8 * (l >> 5) + j;
+                    const int r = 16 * (m & 1) + (l & 15), n = 32 * ks + 8 * (l >> 4) + j;
+                    const bool imag = m >= 2;
                     double v = 0.0;
                     if (r < F && n < W) {
                         const int kn = (int)(((int64_t)(g.f0 + r) * n) % N);      // exact angle reduction
                         const double ang = two_pi * (double)kn / (double)N;
-                        v = (double)win[(size_t)n] * (tile == 0 ? std::cos(ang) : -std::sin(ang)) * 8192.0;
-                        if (tile == 1 && g.f0 + r == 0) v = 0.0;                  // DC is real (:323 drops the packed Nyquist)
+                        v = (double)win[(size_t)n] * (imag ? -std::sin(ang) : std::cos(ang)) * 8192.0;
+                        if (imag && g.f0 + r == 0) v = 0.0;                       // DC is real (:323 drops the packed Nyquist)
                     }
                     uint16_t hi, lo;
                     split_half(v, hi, lo);
-                    p.dfrag[((((size_t)ks * 2 + tile) * 2 + 0) * 64 + l) * 8 + j] = hi;
-                    p.dfrag[((((size_t)ks * 2 + tile) * 2 + 1) * 64 + l) * 8 + j] = lo;
+                    p.dfrag[((((size_t)ks * 4 + m) * 2 + 0) * 64 + l) * 8 + j] = hi;
+                    p.dfrag[((((size_t)ks * 4 + m) * 2 + 1) * 64 + l) * 8 + j] = lo;
                 }
 
     // |X[k]| <= (sum_n |D[k][n]|) * max|x|: with samples scaled below 2^14 the column shift keeps |X| * 2^(cse-shift) < 2^13
@@ -246,11 +248,11 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
         p.out_params.insert(p.out_params.end(), f.gains, f.gains + n_out);
         p.out_params.insert(p.out_params.end(), f.x_offsets, f.x_offsets + n_out);
     }
-    p.koff.resize((size_t)KS * 2);
+    p.koff.resize((size_t)KS * 4);
     for (int ks = 0; ks < KS; ks++)
-        for (int h = 0; h < 2; h++) {
-            const int o = 16 * ks + 8 * h;
-            p.koff[(size_t)ks * 2 + h] = o + skew * (o / hop);
+        for (int h = 0; h < 4; h++) {
+            const int o = 32 * ks + 8 * h;
+            p.koff[(size_t)ks * 4 + h] = o + skew * (o / hop);
         }
     p.ok = true;
     return true;

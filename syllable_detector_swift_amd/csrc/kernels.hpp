@@ -61,13 +61,14 @@ hipError_t launch_detections(const uint8_t *flags, int C, int64_t E, int64_t fir
 // time is a GEMM on the matrix cores (f16 hi/lo split operands, fp32 accumulate), the first
 // network layer is folded into a second MFMA on the accumulator tile, the sliding window is a
 // diagonal sum over an LDS ring.  Built by make_fused_plan() when the configuration fits.
-constexpr int kFusedTileFrames = 128;   // frames per workgroup pass (4 waves x 32)
-constexpr int kFusedMaxLoads = 20;      // float4 loads per thread per pass
+constexpr int kFusedBlock = 512;        // 8 waves
+constexpr int kFusedTileFrames = 128;   // frames per workgroup pass (8 waves x 16)
+constexpr int kFusedMaxLoads = 10;      // float4 loads per thread per pass
 constexpr int kFusedColStride = 40;     // halves per column row in LDS: 32 bins + 8 of padding (80 B rows: 16-byte
                                         // aligned, and 16 consecutive rows cover all 64 banks once for ds_read_b128)
 
 struct FusedDesc {
-    int W, KS;                  // window length, k-steps of 16 samples (KS*16 >= W)
+    int W, KS;                  // window length, k-steps of 32 samples (KS*32 >= W)
     int hop, gap, F, T;         // frame advance, leading gap, bins, timeRange
     int H;                      // first-layer outputs
     int norm;                   // 0 none, 1 l2normalize, 2 normalize, 3 normalizestd (first input fn)
@@ -79,13 +80,14 @@ struct FusedDesc {
     unsigned hop_magic;         // ceil(2^32 / hop): i / hop == umulhi(i, hop_magic) for i < 2^16
     int runs, seg_evals;        // passes per workgroup, evaluations per workgroup segment
     int ps;                     // column slots in LDS (frames per pass + T - 1)
-    int stat_bin, stat_hh, stat_g, stat_hh2, stat_g2, stat_row;   // l2normalize: the sum of squares rides in bins F, F+1; row H
+    int stat_bin, stat_g4, stat_i, stat_g4b, stat_ib, stat_row;   // l2normalize: the sum of squares rides in bins F, F+1
+                                // (lane group, value index inside the lane); row H of the first-layer result
     int col_shift;              // |X| columns are stored as |X| * 2^(cse - col_shift) (2x for |X|^2)
     float w_unscale;            // 1 / (power-of-two scale of the folded first-layer weights)
     int lds_dfrag, lds_smp, lds_colh, lds_coll, lds_stat, lds_red, lds_cst, lds_total;   // byte offsets
-    const uint4 *dfrag;         // [KS][re,im][hi,lo][64 lanes] A-operand fragments of the DFT basis (32x32x16)
+    const uint4 *dfrag;         // [KS][re 0-15, re 16-31, im 0-15, im 16-31][hi,lo][64 lanes] A-operand fragments of the DFT basis
     const uint4 *afrag;         // [T][hi,lo][64 lanes] A-operand fragments of the folded first layer (16x16x32)
-    const int *koff;            // [KS][2] staged-sample offset of k-step ks for lane half h (skew applied)
+    const int *koff;            // [KS][4] staged-sample offset of k-step ks for lane group g4 (skew applied)
     const float *bias0;         // [H]  b0 + W0 . (constant part of the input maps)
     const float *rvec;          // [H]  (W0 o a) . 1
     const float *w1, *b1;       // layer 1, row-major [n_out][H] (2-layer nets)

@@ -9,31 +9,30 @@
 //   lastDetected          Common/SyllableDetector.swift:27-31
 //
 // MI355X formulation (not a translation of the vDSP call sequence): two chained GEMMs on the matrix
-// cores whose B operands are *addresses*, not copies.
+// cores (v_mfma_f32_16x16x32_f16) whose B operands are *addresses*, not copies.
 //   1. The detector needs F (<= 32) bins of each N-point spectrum, so the windowed DFT of a tile of
-//      32 frames is  Xt[2 x 32 rows, 32 frames] = Dt[rows, W] . S[W, 32 frames]  with
-//      Dt = window o {cos, -sin}; column j of S is simply the staged sample stream at offset j*hop
-//      (no per-frame copy, no ring).  v_mfma_f32_32x32x16_f16 with every operand split into f16
+//      16 frames is  Xt[64 rows, 16 frames] = Dt[rows, W] . S[W, 16 frames]  with
+//      Dt = window o {cos, -sin} (32 real + 32 imaginary rows); column j of S is simply the staged
+//      sample stream at offset j*hop (no per-frame copy, no ring).  Every operand is split into f16
 //      hi + lo (block floating point, power-of-two scales): hi*hi + hi*lo + lo*hi reproduces an fp32
 //      product to ~2^-21 and the fp32 accumulate keeps the sum; measured error against the fp64
 //      anchor is below an fp32 FFT's.  The split of the samples is done on the fragment a lane has
-//      just read from LDS, in the issue slots the matrix pipe leaves free (4 VALU per MFMA).
+//      just read from LDS, in the issue slots the matrix pipe leaves free.
 //   2. |X| columns (f16 hi/lo) go to a small LDS buffer [frame][bin].  The first network layer,
 //      folded with the affine input maps into W' = W0 o gain, is  Z[h, e] = sum_t W'_t[h, :] . C[:, e+t]:
-//      again a GEMM (v_mfma_f32_16x16x32_f16, K = 32 bins per tap) whose B operand for tap t is the
-//      column buffer at row offset e + t.  For l2normalize the per-frame sum of squares rides along
-//      as one more bin with a unit weight in one more row, so the window's norm falls out of the
-//      same MFMAs.  An evaluation then finishes in registers: scale, transfer function, second
-//      layer, reverse map, threshold.
+//      again a GEMM (K = 32 bins per tap) whose B operand for tap t is the column buffer at row
+//      offset e + t.  For l2normalize the per-frame sum of squares rides along in two spare bins with
+//      weights in one more row, so the window's norm falls out of the same MFMAs.  An evaluation
+//      then finishes in registers: scale, transfer function, second layer, reverse map, threshold.
 // Every frame is transformed once (the reference re-reads each column T times).
 //
-// Workgroup = 4 waves x 32 frames = 128 frames per pass; a workgroup walks `runs` consecutive passes of
-// one channel, carrying the last T-1 columns in LDS.  HBM traffic = every sample once (+ (T-1) frames
-// of overlap per segment) + 5 bytes per evaluation.
-//
-// The kernel is instruction-issue bound (LDS holds 64 KB of basis fragments + 68 KB of samples, so
-// one wave per SIMD): buffer loads with hardware bounds instead of guards, next-pass loads trickled
-// through the MFMA loop, results stored one pass late so no wait sits behind a fresh store.
+// Workgroup = 8 waves x 16 frames = 128 frames per pass, two waves per SIMD so that one wave's waits
+// and VALU work overlap the other's matrix work (LDS -- 64 KB of basis fragments + 68 KB of samples --
+// allows one workgroup per CU).  A workgroup walks `runs` consecutive passes of one channel, carrying
+// the last T-1 columns in LDS.  HBM traffic = every sample once (+ (T-1) frames of overlap per
+// segment) + 5 bytes per evaluation.  Buffer loads with hardware bounds instead of guards, next-pass
+// loads trickled through the MFMA loop, results stored one pass late so no wait sits behind a fresh
+// store.
 //
 // gfx950 only.  wave = 64.
 
@@ -45,12 +44,12 @@ namespace {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
-typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef unsigned int uint32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int uint32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kBlock = 256;
-constexpr int kTile = kFusedTileFrames;
+constexpr int kBlock = kFusedBlock;            // 512 threads = 8 waves
+constexpr int kWaves = kBlock / 64;
+constexpr int kTile = kFusedTileFrames;        // 128 frames per pass = 16 per wave
 constexpr int kColStride = kFusedColStride;
 // layout of the constant block in LDS (floats)
 constexpr int kCstThr = 0 /* 16 doubles */, kCstOut = 32;
@@ -134,6 +133,11 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const float *row, in
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(row + first), 0, (int)left * 4, 0x00020000);
 }
 
+__device__ __forceinline__ floatx4 mfma(half8 a, half8 b, floatx4 c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
 // Diagnostic stamps (STAMP instantiation only; never the shipped path): s_memtime at phase
 // boundaries, summed per workgroup by thread 0 and stored to d.stamps[workgroup][phase].
 #define SD_STAMP(slot)                                                                     \
@@ -146,14 +150,13 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const float *row, in
         tprev = now;                                                                       \
     }
 
-// KS: k-steps; TMAX / NL: array sizes for taps and staging quads; EXACT: timeRange == TMAX and
-// nload == NL are compile-time facts (no guards); SKEW: staged samples carry bank-spreading padding;
+// KS: k-steps of 32 samples; TMAX / NL: array sizes for taps and staging quads; EXACT: timeRange == TMAX
+// and nload == NL are compile-time facts (no guards); SKEW: staged samples carry bank-spreading padding;
 // LEAN: the configuration class of the reference's example detector is a compile-time fact --
 // l2normalize first, linear |X| columns, two layers, TanSig hidden units (at most 4), one output --
-// so that instantiation carries only the code it runs (the generic one is ~8k instructions and
-// stalls on instruction fetch).
+// so that instantiation carries only the code it runs.
 template <int KS, int TMAX, int NL, bool EXACT, bool SKEW, bool LEAN, bool STAMP>
-__global__ void __launch_bounds__(kBlock, 1)
+__global__ void __launch_bounds__(kBlock, 2)
 fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t stride, int64_t s_eff, int64_t E,
              float *__restrict__ outputs, uint8_t *__restrict__ flags)
 {
@@ -169,8 +172,8 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 31;          // frame column inside the wave's 32-frame tile
-    const int hh = lane >> 5;         // lane half: k rows 8h..8h+7 of an operand, rows +4 of a result
+    const int f = lane & 15;          // frame (DFT) / evaluation (first layer) column inside the wave's tile
+    const int g4 = lane >> 4;         // k block 8*g4..8*g4+7 of an operand; rows 4*g4..4*g4+3 of a result
     const int c = blockIdx.y;
     const int64_t e_b = (int64_t)blockIdx.x * d.seg_evals;
     if (e_b >= E) return;
@@ -180,22 +183,21 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
     const int nload = EXACT ? NL : d.nload;
     const int norm = LEAN ? 1 : d.norm, scaling = LEAN ? 0 : d.scaling, power_mode = LEAN ? 0 : d.power_mode;
     const int n_layers = LEAN ? 2 : d.n_layers, n_out = LEAN ? 1 : d.n_out, tf0 = LEAN ? 0 : d.tf0;
-    const int fl = 32 * wave + r;     // this lane's frame inside the pass
+    const int fl = 16 * wave + f;     // this lane's frame / evaluation slot inside the pass
 
     // ---- once per workgroup: constants
-    for (int i = tid; i < KS * 4 * 64; i += kBlock) lds_dfrag[i] = reinterpret_cast<const uint32x4 *>(d.dfrag)[i];
+    for (int i = tid; i < KS * 8 * 64; i += kBlock) lds_dfrag[i] = reinterpret_cast<const uint32x4 *>(d.dfrag)[i];
     if (tid < 16) reinterpret_cast<double *>(cst + kCstThr)[tid] = tid < n_out ? d.thresholds[tid] : 0.0;
     for (int i = tid; i < d.n_out_fns * (1 + 2 * n_out); i += kBlock) cst[kCstOut + i] = d.out_params[i];
-    // first-layer fragments, one (hi, lo) pair per tap: A operand of v_mfma_f32_16x16x32_f16, lane l holds
-    // row l&15 (hidden unit, or the statistic row), k = 8*(l>>4) + j (bin)
+    // first-layer fragments, one (hi, lo) pair per tap: A operand, lane l holds row l&15 (hidden unit, or the
+    // statistic row), k = 8*(l>>4) + j (bin)
     half8 afr[TMAX][2];
 #pragma unroll
     for (int t = 0; t < TMAX; t++)
 #pragma unroll
         for (int p = 0; p < 2; p++)
             afr[t][p] = as_half8(reinterpret_cast<const uint32x4 *>(d.afrag)[((t < T ? t : 0) * 2 + p) * 64 + lane]);
-    // evaluation-phase constants of the 4 hidden units this lane group owns (rows 4*(l>>4) + j of a 16x16 result)
-    const int g4 = lane >> 4;
+    // evaluation-phase constants of the 4 hidden units this lane group owns (rows 4*g4 + j of a result)
     float c_b0[4], c_rv[4], c_w1[4][4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -209,25 +211,24 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
 #pragma unroll
     for (int o = 0; o < 4; o++) c_b1[o] = (n_layers == 2 && o < n_out) ? d.b1[o] : 0.0f;
 
-    // this lane's frame in the staged stream, and where k-step ks of lane half hh starts inside it
-    const float *fptr = smp + fl * (d.hop + (SKEW ? d.skew : 0)) + (SKEW ? 0 : 8 * hh);
+    // this lane's frame in the staged stream, and where k-step ks of lane group g4 starts inside it
+    const float *fptr = smp + fl * (d.hop + (SKEW ? d.skew : 0)) + (SKEW ? 0 : 8 * g4);
     int ko[KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ks++) ko[ks] = SKEW ? d.koff[ks * 2 + hh] : 16 * ks;   // immediates without skew
-    const int wr0 = 4 * tid;
+    for (int ks = 0; ks < KS; ks++) ko[ks] = SKEW ? d.koff[ks * 4 + g4] : 32 * ks;   // immediates without skew
 
     uint32x4 v[NL];
     {
         const __amdgpu_buffer_rsrc_t rs = tile_rsrc(row, e_b * d.hop + d.gap, s_eff, d.nsmp);
 #pragma unroll
         for (int k = 0; k < NL; k++)
-            if (k < nload) v[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * tid + 4096 * k, 0, 0);
+            if (k < nload) v[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * tid + 16 * kBlock * k, 0, 0);
     }
     // results of the previous pass are stored at the start of the next one, so the wait for the
     // prefetched samples never sits behind a store that was issued moments ago
-    float pend_y[2][4];
-    int64_t pend_e[2] = {-1, -1};
-    bool pend_hit[2] = {false, false};
+    float pend_y[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    int64_t pend_e = -1;
+    bool pend_hit = false;
     int cse_prev = 0;                 // column scale exponent of the previous pass
     unsigned long long tsum[16] = {0}, tprev = 0;
     if (STAMP) tprev = __builtin_amdgcn_s_memtime();
@@ -242,8 +243,8 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
 #pragma unroll
         for (int k = 0; k < NL; k++)
             if (k < nload) {
-                const floatx4 f = as_floatx4(v[k]);
-                amax = absmax3(absmax3(amax, f[0], f[1]), f[2], f[3]);
+                const floatx4 q = as_floatx4(v[k]);
+                amax = absmax3(absmax3(amax, q[0], q[1]), q[2], q[3]);
             }
         SD_STAMP(9)
 #pragma unroll
@@ -252,7 +253,7 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
         SD_STAMP(0)
         __syncthreads();                                      // (A) previous pass fully consumed
         SD_STAMP(1)
-        amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        amax = fmaxf(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])), fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7])));
         int se = 13 - (int)((__float_as_uint(amax) >> 23) & 0xffu) + 127;   // exponent of the sample scale
         const int lim = power_mode ? 40 : 100;
         se = amax > 0.0f ? (se < -lim ? -lim : (se > lim ? lim : se)) : 0;
@@ -260,22 +261,13 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
         const float sx = pow2f(se);
         // columns of this pass and the T-1 carried ones share one scale: the smaller of the two tiles'
         const int cse = scaling != 0 ? 0 : ((pass > 0 && cse_prev < se) ? cse_prev : se);
-        if (!SKEW) {
 #pragma unroll
-            for (int k = 0; k < NL; k++)
-                if (k < nload) {
-                    const floatx4 f = as_floatx4(v[k]);
-                    *reinterpret_cast<floatx4 *>(smp + wr0 + 1024 * k) = f * sx;
-                }
-        } else {
-#pragma unroll
-            for (int k = 0; k < NL; k++)
-                if (k < nload) {
-                    const int i = 4 * (tid + kBlock * k);     // quads past nsmp hold zeros and land in the buffer's slack
-                    const floatx4 f = as_floatx4(v[k]);
-                    *reinterpret_cast<floatx4 *>(smp + i + d.skew * (int)__umulhi((unsigned)i, d.hop_magic)) = f * sx;
-                }
-        }
+        for (int k = 0; k < NL; k++)
+            if (k < nload) {
+                const int i = 4 * (tid + kBlock * k);         // quads past nsmp hold zeros and land in the buffer's slack
+                const floatx4 q = as_floatx4(v[k]);
+                *reinterpret_cast<floatx4 *>(smp + i + (SKEW ? d.skew * (int)__umulhi((unsigned)i, d.hop_magic) : 0)) = q * sx;
+            }
         // the last T-1 columns of the previous pass move to the front (rescaled if the column scale changed)
         if (pass > 0) {
             const int dexp = (cse - cse_prev) * (power_mode ? 2 : 1);
@@ -307,27 +299,26 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
         SD_STAMP(3)
 
         // previous pass's results out
+        if (pend_e >= 0) {
+            if (outputs) {
 #pragma unroll
-        for (int n = 0; n < 2; n++)
-            if (pend_e[n] >= 0) {
-                if (outputs) {
-#pragma unroll
-                    for (int o = 0; o < 4; o++)
-                        if (o < n_out) outputs[((int64_t)c * E + pend_e[n]) * n_out + o] = pend_y[n][o];
-                }
-                if (flags) flags[(int64_t)c * E + pend_e[n]] = pend_hit[n] ? 1 : 0;
-                pend_e[n] = -1;
+                for (int o = 0; o < 4; o++)
+                    if (o < n_out) outputs[((int64_t)c * E + pend_e) * n_out + o] = pend_y[o];
             }
+            if (flags) flags[(int64_t)c * E + pend_e] = pend_hit ? 1 : 0;
+            pend_e = -1;
+        }
         // next pass's samples: fetched during this pass's matrix work, a load or two per k-step, so the
-        // memory queue never backs up into the wave (a burst of 17 KB-sized loads stalls issue for ~3k cycles)
+        // memory queue never backs up into the wave
         const __amdgpu_buffer_rsrc_t nrs = tile_rsrc(row, (jp + kTile) * d.hop + d.gap, pass + 1 < d.runs ? s_eff : 0, d.nsmp);
         constexpr int kLoadsPerStep = (NL + KS - 1) / KS;
         SD_STAMP(11)
 
-        // ---------------- band-limited DFT of this wave's 32 frames on the matrix cores.
-        // Software pipeline: while the six MFMAs of k-step ks execute, the lane's next 8 samples
-        // (already in registers) are split into f16 hi/lo and the fragments after that are fetched.
-        floatx16 acc_re = {0}, acc_im = {0};
+        // ---------------- band-limited DFT of this wave's 16 frames on the matrix cores: four 16-row tiles
+        // (re bins 0-15, re 16-31, im 0-15, im 16-31), 12 MFMAs per k-step of 32 samples.
+        // Software pipeline: while the MFMAs of k-step ks execute, the lane's next 8 samples (already in
+        // registers) are split into f16 hi/lo and the fragments after that are fetched.
+        floatx4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         floatx4 s0 = *reinterpret_cast<const floatx4 *>(fptr + ko[0]);
         floatx4 s1 = *reinterpret_cast<const floatx4 *>(fptr + ko[0] + 4);
         half8 bh, bl;
@@ -336,19 +327,20 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
             s0 = *reinterpret_cast<const floatx4 *>(fptr + ko[1]);
             s1 = *reinterpret_cast<const floatx4 *>(fptr + ko[1] + 4);
         }
-        uint32x4 a0 = lds_dfrag[0 * 64 + lane], a1 = lds_dfrag[1 * 64 + lane];
-        uint32x4 a2 = lds_dfrag[2 * 64 + lane], a3 = lds_dfrag[3 * 64 + lane];
+        uint32x4 a[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) a[i] = lds_dfrag[i * 64 + lane];
         __builtin_amdgcn_sched_barrier(0);                    // the prologue's fetches stay out of the loop's groups
 #pragma unroll
         for (int ks = 0; ks < KS; ks++) {
-            const half8 a_re_h = as_half8(a0), a_re_l = as_half8(a1), a_im_h = as_half8(a2), a_im_l = as_half8(a3);
+            half8 ah[4], al[4];
+#pragma unroll
+            for (int m = 0; m < 4; m++) { ah[m] = as_half8(a[2 * m]); al[m] = as_half8(a[2 * m + 1]); }
             const half8 cbh = bh, cbl = bl;
             const floatx4 n0 = s0, n1 = s1;
             if (ks + 1 < KS) {                                // fragments of the next k-step
-                a0 = lds_dfrag[((ks + 1) * 4 + 0) * 64 + lane];
-                a1 = lds_dfrag[((ks + 1) * 4 + 1) * 64 + lane];
-                a2 = lds_dfrag[((ks + 1) * 4 + 2) * 64 + lane];
-                a3 = lds_dfrag[((ks + 1) * 4 + 3) * 64 + lane];
+#pragma unroll
+                for (int i = 0; i < 8; i++) a[i] = lds_dfrag[((ks + 1) * 8 + i) * 64 + lane];
             }
             if (ks + 2 < KS) {                                // raw samples two k-steps ahead
                 s0 = *reinterpret_cast<const floatx4 *>(fptr + ko[ks + 2]);
@@ -357,105 +349,107 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
 #pragma unroll
             for (int j = 0; j < kLoadsPerStep; j++) {         // next pass's quads ks*kLoadsPerStep + j
                 const int k = ks * kLoadsPerStep + j;
-                if (k < NL && k < nload) v[k] = __builtin_amdgcn_raw_buffer_load_b128(nrs, 16 * tid + 4096 * k, 0, 0);
+                if (k < NL && k < nload) v[k] = __builtin_amdgcn_raw_buffer_load_b128(nrs, 16 * tid + 16 * kBlock * k, 0, 0);
             }
-            acc_re = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_re_h, cbh, acc_re, 0, 0, 0);
-            acc_im = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_im_h, cbh, acc_im, 0, 0, 0);
-            acc_re = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_re_h, cbl, acc_re, 0, 0, 0);
-            acc_im = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_im_h, cbl, acc_im, 0, 0, 0);
-            acc_re = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_re_l, cbh, acc_re, 0, 0, 0);
-            acc_im = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_im_l, cbh, acc_im, 0, 0, 0);
-            if (ks + 1 < KS) split8(n0, n1, bh, bl);          // 24 VALU, scheduled into the MFMA shadows below
-            // schedule: this k-step's 6 LDS fetches first (their data is used one and two k-steps later),
-            // then each MFMA followed by 4 of the split's VALU instructions
-            __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);       // 6 DS reads
 #pragma unroll
-            for (int i = 0; i < 6; i++) {
+            for (int m = 0; m < 4; m++) acc[m] = mfma(ah[m], cbh, acc[m]);
+#pragma unroll
+            for (int m = 0; m < 4; m++) acc[m] = mfma(ah[m], cbl, acc[m]);
+#pragma unroll
+            for (int m = 0; m < 4; m++) acc[m] = mfma(al[m], cbh, acc[m]);
+            if (ks + 1 < KS) split8(n0, n1, bh, bl);          // 24 VALU, scheduled between the MFMAs below
+            // schedule: this k-step's 10 LDS fetches first (their data is used one and two k-steps later),
+            // then each MFMA followed by 2 of the split's VALU instructions
+            __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);      // 10 DS reads
+#pragma unroll
+            for (int i = 0; i < 12; i++) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
-                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   // 4 VALU
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // 2 VALU
             }
         }
         SD_STAMP(4)
 
         // ---------------- magnitude (zvabs/2 :329-333 or zvmags/4 :270-274), scaling
         // (SyllableDetector.swift:184-212), statistic, f16 split, column -> LDS.
-        // Result layout: column = frame r, register g of lane half hh = bin (g&3) + 8(g>>2) + 4hh.
+        // Result layout: column = frame f, register j of lane group g4 in tile m = basis row 16m + 4*g4 + j;
+        // this lane therefore holds bins 4*g4 + j (i = j) and 16 + 4*g4 + j (i = 4 + j).
         const float inv = pow2f(-se - 13);                   // accumulators hold X * sx * 2^13
         // column scale (power of two; col_shift from the basis' largest row sum): |X| * 2^(cse - shift) < 2^13,
         // |X|^2 * 2^(2 (cse - shift)) < 2^13 with its own shift; log/dB columns are stored unscaled
         const float cs = scaling != 0 ? 1.0f : (power_mode ? pow2f(2 * (cse - d.col_shift)) : pow2f(cse - d.col_shift));
-        const int fh = d.F - 4 * hh;                          // register g holds a band bin iff (g&3) + 8(g>>2) < fh
-        float cval[16];
+        const int fh = d.F - 4 * g4;                          // cval[i] is a band bin iff (i&3) + 16(i>>2) < fh
+        float cval[8];
 #pragma unroll
-        for (int g = 0; g < 16; g++) {
-            const float re = acc_re[g] * inv, im = acc_im[g] * inv;
+        for (int i = 0; i < 8; i++) {
+            const float re = acc[i >> 2][i & 3] * inv, im = acc[2 + (i >> 2)][i & 3] * inv;
             const float pw = fmaf(re, re, im * im);
-            cval[g] = power_mode ? pw : __builtin_amdgcn_sqrtf(pw);
+            cval[i] = power_mode ? pw : __builtin_amdgcn_sqrtf(pw);
         }
         if (scaling != 0) {
             const float k = scaling == 1 ? 0.6931471805599453f : 6.020599913279624f;   // ln 2, 20 log10 2
 #pragma unroll
-            for (int g = 0; g < 16; g++) cval[g] = k * __builtin_amdgcn_logf(cval[g]);   // v_log_f32 = log2
+            for (int i = 0; i < 8; i++) cval[i] = k * __builtin_amdgcn_logf(cval[i]);  // v_log_f32 = log2
         }
         if (d.F < 32 || scaling != 0) {
 #pragma unroll
-            for (int g = 0; g < 16; g++) cval[g] = ((g & 3) + 8 * (g >> 2)) < fh ? cval[g] : 0.0f;
+            for (int i = 0; i < 8; i++) cval[i] = ((i & 3) + 16 * (i >> 2)) < fh ? cval[i] : 0.0f;
         }
         const int slot = (T - 1) + fl;
         if (norm == 2) {
             float st0 = INFINITY, st1 = -INFINITY;
 #pragma unroll
-            for (int g = 0; g < 16; g++) {
-                const bool valid = ((g & 3) + 8 * (g >> 2)) < fh;
-                st0 = valid ? fminf(st0, cval[g]) : st0;
-                st1 = valid ? fmaxf(st1, cval[g]) : st1;
+            for (int i = 0; i < 8; i++) {
+                const bool valid = ((i & 3) + 16 * (i >> 2)) < fh;
+                st0 = valid ? fminf(st0, cval[i]) : st0;
+                st1 = valid ? fmaxf(st1, cval[i]) : st1;
             }
-            st0 = fminf(st0, __shfl_xor(st0, 32, 64));
-            st1 = fmaxf(st1, __shfl_xor(st1, 32, 64));
-            if (hh == 0) { stat[slot] = st0; stat[PS + slot] = st1; }
+            st0 = fminf(st0, __shfl_xor(st0, 16, 64)); st0 = fminf(st0, __shfl_xor(st0, 32, 64));
+            st1 = fmaxf(st1, __shfl_xor(st1, 16, 64)); st1 = fmaxf(st1, __shfl_xor(st1, 32, 64));
+            if (g4 == 0) { stat[slot] = st0; stat[PS + slot] = st1; }
         } else if (norm == 3) {
             float st0 = 0.0f, st1 = 0.0f;
 #pragma unroll
-            for (int g = 0; g < 16; g++) st0 += cval[g];
-            st0 += __shfl_xor(st0, 32, 64);
+            for (int i = 0; i < 8; i++) st0 += cval[i];
+            st0 += __shfl_xor(st0, 16, 64); st0 += __shfl_xor(st0, 32, 64);
             st0 = st0 / (float)d.F;                           // mean of this frame's column
 #pragma unroll
-            for (int g = 0; g < 16; g++) {
-                const float dlt = cval[g] - st0;
-                st1 = ((g & 3) + 8 * (g >> 2)) < fh ? fmaf(dlt, dlt, st1) : st1;   // M2 of this frame's column
+            for (int i = 0; i < 8; i++) {
+                const float dlt = cval[i] - st0;
+                st1 = ((i & 3) + 16 * (i >> 2)) < fh ? fmaf(dlt, dlt, st1) : st1;   // M2 of this frame's column
             }
-            st1 += __shfl_xor(st1, 32, 64);
-            if (hh == 0) { stat[slot] = st0; stat[PS + slot] = st1; }
+            st1 += __shfl_xor(st1, 16, 64); st1 += __shfl_xor(st1, 32, 64);
+            if (g4 == 0) { stat[slot] = st0; stat[PS + slot] = st1; }
         }
 #pragma unroll
-        for (int g = 0; g < 16; g++) cval[g] *= cs;
+        for (int i = 0; i < 8; i++) cval[i] *= cs;
         if (norm == 1) {
             // sum of squares of the (scaled) column rides in two spare bins: its top 11 bits in bin F and the
             // remainder, scaled by 2^11 so that it stays a normal f16, in bin F+1 (weights 1 and 2^-11 in row H
             // of the first-layer fragments) -- together exact to fp32, whatever the column's level
             float ss = 0.0f;
 #pragma unroll
-            for (int g = 0; g < 16; g++) ss = fmaf(cval[g], cval[g], ss);
+            for (int i = 0; i < 8; i++) ss = fmaf(cval[i], cval[i], ss);
+            ss += __shfl_xor(ss, 16, 64);
             ss += __shfl_xor(ss, 32, 64);
             ss *= scaling != 0 ? 0.015625f : 9.5367431640625e-07f;   // 2^-6 (log/dB values) or 2^-20
             const float ss_hi = __uint_as_float(__float_as_uint(ss) & 0xFFFFE000u);
             const float ss_lo = (ss - ss_hi) * 2048.0f;
 #pragma unroll
-            for (int g = 0; g < 16; g++) {
-                cval[g] = (hh == d.stat_hh && g == d.stat_g) ? ss_hi : cval[g];
-                cval[g] = (hh == d.stat_hh2 && g == d.stat_g2) ? ss_lo : cval[g];
+            for (int i = 0; i < 8; i++) {
+                cval[i] = (g4 == d.stat_g4 && i == d.stat_i) ? ss_hi : cval[i];
+                cval[i] = (g4 == d.stat_g4b && i == d.stat_ib) ? ss_lo : cval[i];
             }
         }
         {
-            _Float16 *ph = colh + slot * kColStride + 4 * hh, *pl = coll + slot * kColStride + 4 * hh;
+            _Float16 *ph = colh + slot * kColStride + 4 * g4, *pl = coll + slot * kColStride + 4 * g4;
 #pragma unroll
-            for (int q = 0; q < 4; q++) {                     // bins 8q + 4hh .. +3: four consecutive halves
+            for (int m = 0; m < 2; m++) {                     // bins 16m + 4*g4 .. +3: four consecutive halves
                 unsigned h0, l0, h1, l1;
-                split_pair(cval[4 * q], cval[4 * q + 1], h0, l0);
-                split_pair(cval[4 * q + 2], cval[4 * q + 3], h1, l1);
+                split_pair(cval[4 * m], cval[4 * m + 1], h0, l0);
+                split_pair(cval[4 * m + 2], cval[4 * m + 3], h1, l1);
                 uint32x2 uh = {h0, h1}, ul = {l0, l1};
-                *reinterpret_cast<uint32x2 *>(ph + 8 * q) = uh;
-                *reinterpret_cast<uint32x2 *>(pl + 8 * q) = ul;
+                *reinterpret_cast<uint32x2 *>(ph + 16 * m) = uh;
+                *reinterpret_cast<uint32x2 *>(pl + 16 * m) = ul;
             }
         }
         SD_STAMP(5)
@@ -463,91 +457,77 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
         SD_STAMP(6)
 
         // ---------------- first layer as a shifted GEMM + the rest of the network in registers.
-        // Wave `wave` finishes evaluation slots 32*wave .. +31 (slot q: e = jp - (T-1) + q, columns q .. q+T-1),
-        // 16 per MFMA tile: result column = l&15, rows 4*(l>>4) + j = hidden unit (row H = window sum of squares).
+        // This wave finishes evaluation slots 16*wave .. +15 (slot q: e = jp - (T-1) + q, columns q .. q+T-1):
+        // result column = f, rows 4*g4 + j = hidden unit (row H = window sum of squares).
         const float zs = d.w_unscale / cs;                    // first-layer sums back to true units
-        floatx4 zz[2] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};
+        floatx4 z = {0.0f, 0.0f, 0.0f, 0.0f}, z2 = {0.0f, 0.0f, 0.0f, 0.0f};
         {
-            const int qa = 32 * wave + (lane & 15);
-            const _Float16 *bph = colh + qa * kColStride + 8 * g4, *bpl = coll + qa * kColStride + 8 * g4;
-            constexpr int kTileOff = 16 * kColStride;         // second tile: 16 evaluation slots further
-            uint32x4 fh0[2], fl0[2], fh1[2], fl1[2];          // [tile], two taps in flight
-            fh0[0] = *reinterpret_cast<const uint32x4 *>(bph);
-            fl0[0] = *reinterpret_cast<const uint32x4 *>(bpl);
-            fh0[1] = *reinterpret_cast<const uint32x4 *>(bph + kTileOff);
-            fl0[1] = *reinterpret_cast<const uint32x4 *>(bpl + kTileOff);
+            const _Float16 *bph = colh + fl * kColStride + 8 * g4, *bpl = coll + fl * kColStride + 8 * g4;
+            uint32x4 fh0 = *reinterpret_cast<const uint32x4 *>(bph), fl0 = *reinterpret_cast<const uint32x4 *>(bpl);
+            uint32x4 fh1 = fh0, fl1 = fl0;
             if (T > 1) {
-                fh1[0] = *reinterpret_cast<const uint32x4 *>(bph + kColStride);
-                fl1[0] = *reinterpret_cast<const uint32x4 *>(bpl + kColStride);
-                fh1[1] = *reinterpret_cast<const uint32x4 *>(bph + kColStride + kTileOff);
-                fl1[1] = *reinterpret_cast<const uint32x4 *>(bpl + kColStride + kTileOff);
+                fh1 = *reinterpret_cast<const uint32x4 *>(bph + kColStride);
+                fl1 = *reinterpret_cast<const uint32x4 *>(bpl + kColStride);
             }
 #pragma unroll
             for (int t = 0; t < TMAX; t++) {
                 if (t < T) {
-                    const half8 h0 = as_half8(fh0[0]), l0 = as_half8(fl0[0]), h1 = as_half8(fh0[1]), l1 = as_half8(fl0[1]);
-                    fh0[0] = fh1[0]; fl0[0] = fl1[0]; fh0[1] = fh1[1]; fl0[1] = fl1[1];
+                    const half8 h0 = as_half8(fh0), l0 = as_half8(fl0);
+                    fh0 = fh1; fl0 = fl1;
                     if (t + 2 < T) {
-                        fh1[0] = *reinterpret_cast<const uint32x4 *>(bph + (t + 2) * kColStride);
-                        fl1[0] = *reinterpret_cast<const uint32x4 *>(bpl + (t + 2) * kColStride);
-                        fh1[1] = *reinterpret_cast<const uint32x4 *>(bph + (t + 2) * kColStride + kTileOff);
-                        fl1[1] = *reinterpret_cast<const uint32x4 *>(bpl + (t + 2) * kColStride + kTileOff);
+                        fh1 = *reinterpret_cast<const uint32x4 *>(bph + (t + 2) * kColStride);
+                        fl1 = *reinterpret_cast<const uint32x4 *>(bpl + (t + 2) * kColStride);
                     }
-                    zz[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[t][0], h0, zz[0], 0, 0, 0);
-                    zz[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[t][0], h1, zz[1], 0, 0, 0);
-                    zz[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[t][0], l0, zz[0], 0, 0, 0);
-                    zz[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[t][0], l1, zz[1], 0, 0, 0);
-                    zz[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[t][1], h0, zz[0], 0, 0, 0);
-                    zz[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afr[t][1], h1, zz[1], 0, 0, 0);
+                    z = mfma(afr[t][0], h0, z);               // two accumulation chains: hi*hi on one,
+                    z2 = mfma(afr[t][0], l0, z2);             // the cross terms on the other
+                    z2 = mfma(afr[t][1], h0, z2);
                 }
             }
+            z += z2;
         }
-        SD_STAMP(12)                                          // first-layer GEMM
-#pragma unroll
-        for (int n = 0; n < 2; n++) {
-            const floatx4 z = zz[n];
-            const int q0 = 32 * wave + 16 * n + (lane & 15);
-            const int64_t e = jp - (T - 1) + q0;
+        SD_STAMP(12)
+        {
+            const int64_t e = jp - (T - 1) + fl;
             const bool valid = e >= e_b && e < e_e;
             float alpha = zs, beta = 0.0f;                    // layer-0 input = alpha * z + beta * rvec + bias0
-            if (norm == 1) {                                // L2Normalize, NeuralNet.swift:47-59
+            if (norm == 1) {                                  // L2Normalize, NeuralNet.swift:47-59
                 const float zst = d.stat_row & 2 ? (d.stat_row & 1 ? z[3] : z[2]) : (d.stat_row & 1 ? z[1] : z[0]);
-                const float ssw = __shfl(zst, (d.stat_row >> 2) * 16 + (lane & 15), 64);
+                const float ssw = __shfl(zst, (d.stat_row >> 2) * 16 + f, 64);
                 alpha = d.w_unscale * (scaling != 0 ? 0.125f : 0.0009765625f) * __builtin_amdgcn_rsqf(ssw);   // 2^-3 | 2^-10
-            } else if (norm == 2) {                         // Normalize, :69-96
+            } else if (norm == 2) {                           // Normalize, :69-96
                 float mn = INFINITY, mx = -INFINITY;
-                for (int t = 0; t < T; t++) { mn = fminf(mn, stat[q0 + t]); mx = fmaxf(mx, stat[PS + q0 + t]); }
+                for (int t = 0; t < T; t++) { mn = fminf(mn, stat[fl + t]); mx = fmaxf(mx, stat[PS + fl + t]); }
                 const float range = mx - mn;
                 if (range == 0.0f) { alpha = 0.0f; beta = -1.0f; }
                 else { alpha = zs * 2.0f / range; beta = (0.0f - mn - mx) / range; }
-            } else if (norm == 3) {                         // NormalizeStd, :105-108 (population sigma)
+            } else if (norm == 3) {                           // NormalizeStd, :105-108 (population sigma)
                 float nn = 0.0f, mean = 0.0f, m2 = 0.0f;
                 for (int t = 0; t < T; t++) {                 // pairwise-stable combination of per-frame (mean, M2)
-                    const float nb = (float)d.F, tot = nn + nb, dlt = stat[q0 + t] - mean;
+                    const float nb = (float)d.F, tot = nn + nb, dlt = stat[fl + t] - mean;
                     mean += dlt * nb / tot;
-                    m2 += stat[PS + q0 + t] + dlt * dlt * nn * nb / tot;
+                    m2 += stat[PS + fl + t] + dlt * dlt * nn * nb / tot;
                     nn = tot;
                 }
                 const float sd = sqrtf(m2 / (float)d.I);
                 alpha = zs / sd;
                 beta = -mean / sd;
             }
-            SD_STAMP(13)                                      // window statistic -> alpha, beta
-            float a[4];                                       // rows past H (padding, statistic) contribute nothing
+            SD_STAMP(13)
+            float act[4];                                     // rows past H (padding, statistic) contribute nothing
 #pragma unroll
             for (int j = 0; j < 4; j++)
-                a[j] = (4 * g4 + j) < H ? transfer_fn(tf0, fmaf(alpha, z[j], fmaf(beta, c_rv[j], c_b0[j]))) : 0.0f;
-            SD_STAMP(14)                                      // transfer function of layer 0
+                act[j] = (4 * g4 + j) < H ? transfer_fn(tf0, fmaf(alpha, z[j], fmaf(beta, c_rv[j], c_b0[j]))) : 0.0f;
+            SD_STAMP(14)
             const double *thr = reinterpret_cast<const double *>(cst + kCstThr);
             bool hit = false;
             if (n_layers == 2) {
 #pragma unroll
                 for (int o = 0; o < 4; o++) {
                     if (o < n_out) {
-                        float y = c_w1[o][0] * a[0];          // padding rows carry zero weights
-                        y = fmaf(c_w1[o][1], a[1], y);
-                        y = fmaf(c_w1[o][2], a[2], y);
-                        y = fmaf(c_w1[o][3], a[3], y);
+                        float y = c_w1[o][0] * act[0];        // padding rows carry zero weights
+                        y = fmaf(c_w1[o][1], act[1], y);
+                        y = fmaf(c_w1[o][2], act[2], y);
+                        y = fmaf(c_w1[o][3], act[3], y);
                         if (!LEAN && H > 4) {
                             y += __shfl_xor(y, 16, 64);
                             y += __shfl_xor(y, 32, 64);
@@ -557,18 +537,18 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
                             const float *op = cst + kCstOut + k * (1 + 2 * n_out);
                             y = (y - op[0]) / op[1 + o] + op[1 + n_out + o];
                         }
-                        pend_y[n][o] = y;
+                        pend_y[o] = y;
                         if (o == 0 || d.rule == 1) hit = hit || ((double)y >= thr[o]);
                     }
                 }
-                pend_hit[n] = hit;
-                pend_e[n] = (valid && g4 == 0) ? e : -1;
+                pend_hit = hit;
+                pend_e = (valid && g4 == 0) ? e : -1;
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const int h = 4 * g4 + j;
                     if (h < H) {
-                        float y = a[j];
+                        float y = act[j];
                         for (int k = 0; k < d.n_out_fns; k++) {
                             const float *op = cst + kCstOut + k * (1 + 2 * n_out);
                             y = (y - op[0]) / op[1 + h] + op[1 + n_out + h];
@@ -585,16 +565,14 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
         }
         SD_STAMP(7)
     }
+    if (pend_e >= 0) {
+        if (outputs) {
 #pragma unroll
-    for (int n = 0; n < 2; n++)
-        if (pend_e[n] >= 0) {
-            if (outputs) {
-#pragma unroll
-                for (int o = 0; o < 4; o++)
-                    if (o < n_out) outputs[((int64_t)c * E + pend_e[n]) * n_out + o] = pend_y[n][o];
-            }
-            if (flags) flags[(int64_t)c * E + pend_e[n]] = pend_hit[n] ? 1 : 0;
+            for (int o = 0; o < 4; o++)
+                if (o < n_out) outputs[((int64_t)c * E + pend_e) * n_out + o] = pend_y[o];
         }
+        if (flags) flags[(int64_t)c * E + pend_e] = pend_hit ? 1 : 0;
+    }
     if (STAMP && tid == 0 && d.stamps)
         for (int i = 0; i < 16; i++) d.stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + i] = tsum[i];
 }
@@ -625,16 +603,16 @@ hipError_t launch_fused(const FusedDesc &d, const float *samples, int64_t stride
     const int64_t s_eff = (J - 1) * (int64_t)d.hop + d.gap + d.W;
     const bool skew = d.skew != 0;
     // the reference's example shape (W = 256, hop 132, timeRange 10) gets an instantiation with exact sizes
-    if (d.KS == 16 && d.T == 10 && d.nload == 17 && !skew) {
+    if (d.KS == 8 && d.T == 10 && d.nload == 9 && !skew) {
         const bool lean = d.norm == 1 && d.scaling == 0 && d.power_mode == 0 && d.n_layers == 2 && d.tf0 == 0 && d.n_out == 1 && d.H <= 4;
-        if (lean && d.stamps) return launch_one<16, 10, 17, true, false, true, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
-        if (lean) return launch_one<16, 10, 17, true, false, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
-        return launch_one<16, 10, 17, true, false>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
+        if (lean && d.stamps) return launch_one<8, 10, 9, true, false, true, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
+        if (lean) return launch_one<8, 10, 9, true, false, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
+        return launch_one<8, 10, 9, true, false>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
     }
-    if (d.KS == 16) return skew ? launch_one<16, 12, kFusedMaxLoads, false, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream)
-                                : launch_one<16, 12, kFusedMaxLoads, false, false>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
     if (d.KS == 8) return skew ? launch_one<8, 12, kFusedMaxLoads, false, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream)
                                : launch_one<8, 12, kFusedMaxLoads, false, false>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
+    if (d.KS == 4) return skew ? launch_one<4, 12, kFusedMaxLoads, false, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream)
+                               : launch_one<4, 12, kFusedMaxLoads, false, false>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
     return hipErrorInvalidValue;
 }
 
