@@ -53,6 +53,20 @@ def cpu_baseline(cfg, samples_host, budget_s=12.0):
                       % (samples_host.shape[0], samples_host.shape[1], reps, dt)}
 
 
+def measured_traffic(C, S, hop, engine):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r01_traffic.json:
+    FETCH_SIZE and WRITE_SIZE collected separately, gfx950 FETCH_SIZE x2 correction), if they were taken on
+    exactly this workload; else None."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+        w = t["workload"]
+        if (w["channels_per_gpu"], w["samples_per_channel"], w["hop"], w["engine"]) == (C, S, hop, engine):
+            return t["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -93,19 +107,19 @@ def main():
     if args.overlap is not None:
         cfg = nets.variant(cfg, windowOverlap=args.overlap)
 
+    from syllable_detector_swift_amd.dist import gather_flags
     det = sd.SyllableDetector(cfg, channels=C, device=local_rank, engine=args.engine)
     g = det.geometry
     J, E = det.countFrames(S), det.countEvaluations(S)
     x = synth.channels_on_device(C, S, dev, first=rank * C, fs=cfg.samplingRate)
     outputs = torch.empty((C, E, g.outputs), dtype=torch.float32, device=dev)
     flags = torch.empty((C, E), dtype=torch.uint8, device=dev)
-    gathered = torch.empty((world * C, E), dtype=torch.uint8, device=dev) if world > 1 else None
     det.profile(True)
 
     def step():
         det.run(x, outputs, flags)
         if world > 1:
-            dist.all_gather_into_tensor(gathered, flags)
+            gather_flags(flags, world * C)       # ONE collective per batch: [world*C, E] u8 flags on every rank
 
     for _ in range(args.warmup):
         step()
@@ -117,7 +131,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        # event queries only (no host sync beyond the events of the step just enqueued)
+        # waits for this step's two events (the step's own kernel); negligible next to a >1 ms step
         for nm, ms in det.lastTimings():
             kernel_ms.setdefault(nm, []).append(ms)
     torch.cuda.synchronize()
@@ -153,7 +167,9 @@ def main():
                        "bins": [g.f0, g.f1], "time_range": cfg.timeRange, "engine": {1: "generic", 2: "fused"}.get(g.engine, str(g.engine)),
                        "sharding": "channels, %d per GPU; one all-gather of flags per step" % C if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": measured_traffic(C, S, g.hop, {1: "generic", 2: "fused"}.get(g.engine, "")),
+                         "algorithmic_bytes_per_launch": C * J * b_frame,
                          "algorithmic_bytes_per_frame": b_frame, "kernel_ms": means},
         }
         if world == 1 and not args.no_cpu_baseline:

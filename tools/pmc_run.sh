@@ -7,7 +7,7 @@ ctrs=$1; shift
 out=$GRAFT_REPO_ROOT/gpurun_out/$name
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $out -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > $out/bench.log 2>&1 || true
+timeout 240 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $out -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > $out/bench.log 2>&1 || true
 cd $GRAFT_REPO_ROOT
 python3 - "$out" <<'PY'
 import csv, glob, sys, collections
