@@ -1,0 +1,141 @@
+// syldet.hpp -- C++ mirror of the reference's Swift interface for this path, over the C ABI in
+// syldet.h.  Header-only; links against libsyldet.so.
+//
+// The reference is compiled Swift (no Swift toolchain in the build image), so the host side above
+// the C ABI is written in C++ with the reference's names, argument meaning and error behaviour:
+//   SyllableDetectorConfig(fromTextFile:)  throws ParseError     Common/SyllableDetectorConfig.swift:170-277
+//   SyllableDetector(config:)              fatalError on mismatch Common/SyllableDetector.swift:37-74
+//   appendAudioData(_:withSamples:)                               :129-132
+//   processNewValue() -> Bool                                     :153-217
+//   lastOutputs / lastDetected / seenSyllable()                   :26-31, :220-230
+// Swift's fatalError becomes syldetxx::FatalError (a std::runtime_error carrying the status);
+// ParseError keeps its four kinds.  A detector here is one channel of a bank; `SyllableDetectorBank`
+// is the batched form the MI355X engine is built around.
+#pragma once
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "syldet.h"
+
+namespace syldetxx {
+
+struct FatalError : std::runtime_error {
+    int status;
+    FatalError(int st, const std::string &msg) : std::runtime_error(msg), status(st) {}
+};
+
+// SyllableDetectorConfig.ParseError, SyllableDetectorConfig.swift:50-55
+struct ParseError : std::runtime_error {
+    enum Kind { unableToOpenPath, missingValue, invalidValue, mismatchedLength } kind;
+    ParseError(Kind k, const std::string &msg) : std::runtime_error(msg), kind(k) {}
+};
+
+inline void check(int status)
+{
+    if (status >= 0) return;
+    const std::string msg = std::string(syldet_strerror(status)) + ": " + syldet_last_error();
+    switch (status) {
+    case SYLDET_ERR_PARSE_OPEN: throw ParseError(ParseError::unableToOpenPath, msg);
+    case SYLDET_ERR_PARSE_MISSING: throw ParseError(ParseError::missingValue, msg);
+    case SYLDET_ERR_PARSE_INVALID: throw ParseError(ParseError::invalidValue, msg);
+    case SYLDET_ERR_PARSE_LENGTH: throw ParseError(ParseError::mismatchedLength, msg);
+    default: throw FatalError(status, msg);
+    }
+}
+
+// SyllableDetectorConfig (struct, SyllableDetectorConfig.swift:11-45): same stored fields.
+class SyllableDetectorConfig {
+public:
+    explicit SyllableDetectorConfig(const std::string &fromTextFile) { check(syldet_config_load_text(fromTextFile.c_str(), &cfg_)); }
+    ~SyllableDetectorConfig() { syldet_config_free(cfg_); }
+    SyllableDetectorConfig(const SyllableDetectorConfig &) = delete;
+    SyllableDetectorConfig &operator=(const SyllableDetectorConfig &) = delete;
+
+    double samplingRate() const { return cfg_->sampling_rate; }
+    int fourierLength() const { return cfg_->fourier_length; }
+    int windowLength() const { return cfg_->window_length; }
+    int windowOverlap() const { return cfg_->window_overlap; }
+    std::pair<double, double> freqRange() const { return {cfg_->freq_lo, cfg_->freq_hi}; }
+    int timeRange() const { return cfg_->time_range; }
+    int spectrogramScaling() const { return cfg_->scaling; }
+    std::vector<double> thresholds() const { return std::vector<double>(cfg_->thresholds, cfg_->thresholds + cfg_->n_thresholds); }
+    int netInputs() const { return cfg_->layers[0].inputs; }
+    int netOutputs() const { return cfg_->layers[cfg_->n_layers - 1].outputs; }
+    const syldet_config_t *raw() const { return cfg_; }
+    syldet_config_t *raw() { return cfg_; }
+
+private:
+    syldet_config_t *cfg_ = nullptr;
+};
+
+// A bank of independent detectors on one GPU (Processor.swift:57-59 keeps one SyllableDetector
+// per channel; here they share one engine so that a batch of channels is one kernel launch).
+class SyllableDetectorBank {
+public:
+    SyllableDetectorBank(const SyllableDetectorConfig &config, int channels, int device = 0, int engine = SYLDET_ENGINE_AUTO)
+    {
+        check(syldet_create(config.raw(), channels, device, engine, &h_));
+        check(syldet_get_geometry(h_, &geometry_));
+    }
+    ~SyllableDetectorBank() { syldet_destroy(h_); }
+    SyllableDetectorBank(const SyllableDetectorBank &) = delete;
+    SyllableDetectorBank &operator=(const SyllableDetectorBank &) = delete;
+
+    const syldet_geometry_t &geometry() const { return geometry_; }
+    int channels() const { return syldet_channels(h_); }
+    int64_t countEvaluations(int64_t samples) const { return syldet_count_evals(h_, samples); }
+
+    // whole recordings, host buffers: samples [channels][n], outputs [channels][E][outputs], flags [channels][E]
+    void run(const float *samples, int64_t n, std::vector<float> &outputs, std::vector<uint8_t> &flags)
+    {
+        const int64_t E = countEvaluations(n);
+        outputs.assign((size_t)channels() * (size_t)E * (size_t)geometry_.outputs, 0.0f);
+        flags.assign((size_t)channels() * (size_t)E, 0);
+        check(syldet_run(h_, samples, n, n, outputs.data(), flags.data()));
+    }
+    // device buffers, asynchronous on `hipStream`
+    void runDevice(const float *d_samples, int64_t n, int64_t stride, float *d_outputs, uint8_t *d_flags, void *hipStream)
+    {
+        check(syldet_run_device(h_, d_samples, n, stride, d_outputs, d_flags, hipStream));
+    }
+    // TrackDetector's sample numbering and debounce (TrackDetector.swift:39-43, :65-100)
+    std::vector<int64_t> detections(const uint8_t *flags, int64_t nEvals, double debounceSeconds, int channel)
+    {
+        std::vector<int64_t> idx((size_t)channels() * (size_t)nEvals), counts((size_t)channels());
+        check(syldet_detections(h_, flags, nEvals, debounceSeconds, idx.data(), nEvals, counts.data()));
+        return std::vector<int64_t>(idx.begin() + (size_t)channel * (size_t)nEvals,
+                                    idx.begin() + (size_t)channel * (size_t)nEvals + (size_t)counts[(size_t)channel]);
+    }
+    syldet_t *raw() { return h_; }
+
+private:
+    syldet_t *h_ = nullptr;
+    syldet_geometry_t geometry_{};
+};
+
+// One channel of a bank with the reference's per-detector surface.
+class SyllableDetector {
+public:
+    SyllableDetector(SyllableDetectorBank &bank, int channel) : bank_(bank), channel_(channel) {}
+
+    void appendAudioData(const float *data, int64_t withSamples) { check(syldet_append(bank_.raw(), channel_, data, withSamples)); }
+    bool processNewValue() { const int r = syldet_process_new_value(bank_.raw(), channel_); check(r); return r == 1; }
+    std::vector<float> lastOutputs() const
+    {
+        std::vector<float> out((size_t)bank_.geometry().outputs);
+        check(syldet_last_outputs(bank_.raw(), channel_, out.data()));
+        return out;
+    }
+    bool lastDetected() const { const int r = syldet_last_detected(bank_.raw(), channel_); check(r); return r == 1; }
+    bool seenSyllable() { const int r = syldet_seen_syllable(bank_.raw(), channel_); check(r); return r == 1; }
+
+private:
+    SyllableDetectorBank &bank_;
+    int channel_;
+};
+
+}  // namespace syldetxx

@@ -1,0 +1,73 @@
+//  SyllableDetector.swift (libsyldet shim)
+//
+//  Drop-in for Common/SyllableDetector.swift of gardner-lab/syllable-detector-swift: same class
+//  name and the members its callers use (Processor.swift:58,120,124,136-141; TrackDetector.swift:33,62,
+//  65-77; ViewControllerSimulator.swift:172,292,311,322), with the arithmetic done by libsyldet on an
+//  MI355X through the C ABI in include/syldet.h.  The header is imported the way the reference imports
+//  TPCircularBuffer.h: one more line in Common/Common-Bridging-Header.h (#include "syldet.h").
+//
+//  Not compiled in this repository (no Swift toolchain in the build image); INTEGRATION.md shows where
+//  it goes.  One SyllableDetector here owns a one-channel bank; Processor-style callers that hold many
+//  channels should create one bank for all of them (see SyllableDetectorBank below) so that a batch of
+//  channels is a single kernel launch.
+
+import Foundation
+
+final class SyllableDetectorBank {
+    let handle: OpaquePointer
+    let config: SyllableDetectorConfig
+    let geometry: syldet_geometry_t
+
+    init(config: SyllableDetectorConfig, channels: Int, device: Int32 = 0) {
+        self.config = config
+        var h: OpaquePointer? = nil
+        let st = config.withCStruct { syldet_create($0, Int32(channels), device, Int32(SYLDET_ENGINE_AUTO.rawValue), &h) }
+        guard st == 0, let hh = h else {
+            // the reference calls fatalError for the same conditions (SyllableDetector.swift:47,54,59)
+            fatalError(String(cString: syldet_strerror(st)) + ": " + String(cString: syldet_last_error()))
+        }
+        handle = hh
+        var g = syldet_geometry_t()
+        syldet_get_geometry(hh, &g)
+        geometry = g
+    }
+
+    deinit { syldet_destroy(handle) }
+}
+
+class SyllableDetector: NSObject {
+    let config: SyllableDetectorConfig
+    private let bank: SyllableDetectorBank
+    private let channel: Int32
+
+    var lastOutputs: [Float] {
+        var out = [Float](repeating: 0.0, count: Int(bank.geometry.outputs))
+        syldet_last_outputs(bank.handle, channel, &out)
+        return out
+    }
+    var lastDetected: Bool { return syldet_last_detected(bank.handle, channel) == 1 }
+
+    init(config: SyllableDetectorConfig) {
+        self.config = config
+        bank = SyllableDetectorBank(config: config, channels: 1)
+        channel = 0
+        super.init()
+    }
+
+    init(bank: SyllableDetectorBank, channel: Int) {
+        config = bank.config
+        self.bank = bank
+        self.channel = Int32(channel)
+        super.init()
+    }
+
+    func appendAudioData(_ data: UnsafeMutablePointer<Float>, withSamples numSamples: Int) {
+        if syldet_append(bank.handle, channel, data, Int64(numSamples)) != 0 {
+            fatalError("Insufficient space on buffer.")      // CircularShortTimeFourierTransform.swift:199
+        }
+    }
+
+    func processNewValue() -> Bool { return syldet_process_new_value(bank.handle, channel) == 1 }
+
+    func seenSyllable() -> Bool { return syldet_seen_syllable(bank.handle, channel) == 1 }
+}

@@ -259,3 +259,30 @@ def test_full_size_properties():
         n = det.countEvaluations(S - k * 132)
         assert torch.equal(out3[:, :n], out[:, k:k + n])
         assert torch.equal(out4, out[perm])
+
+
+def test_cpp_mirror_of_the_swift_surface(oracle_lib, tmp_path):
+    """include/syldet.hpp (SyllableDetectorConfig(fromTextFile:), SyllableDetector.appendAudioData /
+    processNewValue / lastOutputs / lastDetected, bank.run, detections) driven from a C++ program."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(_abi.LIB_PATH), "host_mirror_test")
+    if not os.path.exists(exe):
+        pytest.skip("host_mirror_test not built (run __graft_entry__.build())")
+    cfg, x, gold = util.load_case("case_sample_syllables")
+    x = x[:40000]
+    net = tmp_path / "net.txt"
+    net.write_text(cfg.toText())
+    (tmp_path / "x.f32").write_bytes(np.ascontiguousarray(x, np.float32).tobytes())
+    r = subprocess.run([exe, str(net), str(tmp_path / "x.f32"), str(tmp_path / "out.f32")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    n_stream, n_batch, detected, n_idx, first_idx = [int(v) for v in r.stdout.split()]
+    o = util.oracle_for(cfg)
+    _, wfl, w64 = o.run(x, po.F64)
+    assert n_stream == n_batch == len(w64)
+    got = np.fromfile(str(tmp_path / "out.f32"), np.float32)
+    util.assert_outputs_close(got[:n_stream].reshape(-1, 1), w64)
+    util.assert_outputs_close(got[n_stream:].reshape(-1, 1), w64)
+    assert detected == int(wfl.sum())
+    want_idx = o.detections(wfl, 0.0)
+    assert n_idx == len(want_idx) and (n_idx == 0 or first_idx == int(want_idx[0]))
