@@ -116,8 +116,9 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
 
     // ---- geometry of a pass
     const int hop = g.hop;
-    const int nsmp = (kFusedTileFrames - 1) * hop + KS * 32;
-    const int nload = (nsmp / 4 + kFusedBlock - 1) / kFusedBlock;
+    const int team = kFusedBlock / 2;             // threads per team
+    const int nsmp = (kFusedChunkFrames - 1) * hop + KS * 32;   // samples one chunk's frames read
+    const int nload = (nsmp / 4 + team - 1) / team;
     if (nload > kFusedMaxLoads) return no("hop too large for the staging registers");
     // LDS bank spreading: a lane reads 8 consecutive fp32 samples of its frame with two ds_read_b128;
     // those are conflict-free when consecutive frames start an odd number of 16-byte slots apart
@@ -126,8 +127,8 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
     // because they start at multiples of 8 inside a frame and hop is then a multiple of 8.
     const int skew = ((hop / 4) % 2 == 0) ? 4 : 0;
     auto skewed = [&](int i) { return i + skew * (i / hop); };
-    const int nsmp_p = (skewed(nload * kFusedBlock * 4 + 16) + 15) / 8 * 8;   // every thread writes all its quads
-    const int PS = kFusedTileFrames + T - 1;
+    const int nsmp_p = (skewed(nsmp + 16) + 15) / 8 * 8;
+    const int PS = kFusedChunkFrames + T - 1;
 
     FusedDesc &d = p.desc;
     d.W = W; d.KS = KS; d.hop = hop; d.gap = g.gap; d.F = F; d.T = T; d.H = H; d.norm = norm;
@@ -137,7 +138,7 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
     d.rule = c.rule; d.n_out_fns = c.n_output_fns; d.I = I;
     d.nsmp = nsmp; d.nload = nload; d.skew = skew;
     d.hop_magic = (unsigned)((0x100000000ull + (unsigned)hop - 1) / (unsigned)hop);
-    d.ps = PS;
+    d.ps = PS; d.smp_stride = nsmp_p;
     // a lane of group g4 holds bins 4*g4 + j (value index j) and 16 + 4*g4 + j (value index 4 + j)
     d.stat_bin = norm == 1 ? F : -1;
     d.stat_g4 = (F & 15) >> 2;
@@ -148,10 +149,10 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
     int off = 0;
     auto take = [&off](int bytes) { const int o = off; off += (bytes + 15) / 16 * 16; return o; };
     d.lds_dfrag = take(KS * 8 * 1024);
-    d.lds_smp = take(nsmp_p * 4);                    // staged samples, scaled fp32
-    d.lds_colh = take(PS * kFusedColStride * 2);     // |X| columns, f16 hi
-    d.lds_coll = take(PS * kFusedColStride * 2);     //              f16 lo
-    d.lds_stat = take(2 * PS * 4);
+    d.lds_smp = take(2 * nsmp_p * 4);                // staged samples (raw fp32), one region per team
+    d.lds_colh = take(2 * PS * kFusedColStride * 2); // |X| columns, f16 hi, one buffer per team
+    d.lds_coll = take(2 * PS * kFusedColStride * 2); //              f16 lo
+    d.lds_stat = take(2 * 2 * PS * 4);
     d.lds_red = take(64);
     d.lds_cst = take((32 + kMaxFns * 33) * 4);       // thresholds + output maps (kCst* in kernels_fused.hip)
     d.lds_total = off;

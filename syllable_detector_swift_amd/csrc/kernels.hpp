@@ -62,7 +62,8 @@ hipError_t launch_detections(const uint8_t *flags, int C, int64_t E, int64_t fir
 // network layer is folded into a second MFMA on the accumulator tile, the sliding window is a
 // diagonal sum over an LDS ring.  Built by make_fused_plan() when the configuration fits.
 constexpr int kFusedBlock = 512;        // 8 waves
-constexpr int kFusedTileFrames = 128;   // frames per workgroup pass (8 waves x 16)
+constexpr int kFusedChunkFrames = 64;   // frames per team chunk (4 waves x 16); a workgroup = 2 teams
+constexpr int kFusedTileFrames = 128;   // frames per workgroup period (two chunks)
 constexpr int kFusedMaxLoads = 10;      // float4 loads per thread per pass
 constexpr int kFusedColStride = 40;     // halves per column row in LDS: 32 bins + 8 of padding (80 B rows: 16-byte
                                         // aligned, and 16 consecutive rows cover all 64 banks once for ds_read_b128)
@@ -79,7 +80,8 @@ struct FusedDesc {
     int skew;                   // floats of padding after every `hop` staged samples (bank spreading)
     unsigned hop_magic;         // ceil(2^32 / hop): i / hop == umulhi(i, hop_magic) for i < 2^16
     int runs, seg_evals;        // passes per workgroup, evaluations per workgroup segment
-    int ps;                     // column slots in LDS (frames per pass + T - 1)
+    int ps;                     // column slots per team buffer (chunk frames + T - 1)
+    int smp_stride;             // floats between the two teams' sample regions
     int stat_bin, stat_g4, stat_i, stat_g4b, stat_ib, stat_row;   // l2normalize: the sum of squares rides in bins F, F+1
                                 // (lane group, value index inside the lane); row H of the first-layer result
     int col_shift;              // |X| columns are stored as |X| * 2^(cse - col_shift) (2x for |X|^2)

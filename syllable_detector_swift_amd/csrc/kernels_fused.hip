@@ -26,13 +26,13 @@
 //      then finishes in registers: scale, transfer function, second layer, reverse map, threshold.
 // Every frame is transformed once (the reference re-reads each column T times).
 //
-// Workgroup = 8 waves x 16 frames = 128 frames per pass, two waves per SIMD so that one wave's waits
-// and VALU work overlap the other's matrix work (LDS -- 64 KB of basis fragments + 68 KB of samples --
-// allows one workgroup per CU).  A workgroup walks `runs` consecutive passes of one channel, carrying
-// the last T-1 columns in LDS.  HBM traffic = every sample once (+ (T-1) frames of overlap per
-// segment) + 5 bytes per evaluation.  Buffer loads with hardware bounds instead of guards, next-pass
-// loads trickled through the MFMA loop, results stored one pass late so no wait sits behind a fresh
-// store.
+// Workgroup = 8 waves = two teams of 4 (one wave of each team per SIMD); a team owns alternate 64-frame
+// chunks (16 frames per wave) of the workgroup's segment of one channel, and the teams run half a period
+// apart so that one team's matrix work overlaps the other's staging / evaluation work (see fused_kernel).
+// LDS -- 64 KB of basis fragments + 2 x 34 KB of samples + 2 x 12 KB of columns -- allows one workgroup
+// per CU.  HBM traffic = every sample once (+ W - hop samples of overlap per chunk, L2 hits) + 5 bytes per
+// evaluation.  Buffer loads with hardware bounds instead of guards; a chunk's samples are fetched two
+// half-steps ahead, a load or two per k-step inside the MFMA loop.
 //
 // gfx950 only.  wave = 64.
 
@@ -49,7 +49,8 @@ typedef unsigned int uint32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kBlock = kFusedBlock;            // 512 threads = 8 waves
 constexpr int kWaves = kBlock / 64;
-constexpr int kTile = kFusedTileFrames;        // 128 frames per pass = 16 per wave
+constexpr int kTeam = kBlock / 2;              // 256 threads = 4 waves per team
+constexpr int kChunk = kFusedChunkFrames;      // 64 frames per team chunk = 16 per wave
 constexpr int kColStride = kFusedColStride;
 // layout of the constant block in LDS (floats)
 constexpr int kCstThr = 0 /* 16 doubles */, kCstOut = 32;
@@ -155,6 +156,16 @@ __device__ __forceinline__ floatx4 mfma(half8 a, half8 b, floatx4 c)
 // LEAN: the configuration class of the reference's example detector is a compile-time fact --
 // l2normalize first, linear |X| columns, two layers, TanSig hidden units (at most 4), one output --
 // so that instantiation carries only the code it runs.
+//
+// Two-team pipeline.  Waves 0-3 (team 0) and 4-7 (team 1) own alternate 64-frame chunks of the
+// workgroup's segment and run half a period apart; each SIMD hosts one wave of each team.  In one
+// half-step (one workgroup barrier) a team is either in its FRONT phase on chunk k
+//     scale <- block max of the staged samples; carry the neighbour chunk's last T-1 columns over;
+//     DFT of its 4 x 16 frames on the matrix cores; magnitudes -> column buffer (LDS)
+// or in its BACK phase on the chunk it fronted one half-step earlier
+//     next chunk's prefetched samples -> block max partials + LDS; first layer as a shifted GEMM over its
+//     column buffer; rest of the network in registers; results -> HBM
+// so matrix-heavy and VALU/latency-heavy work of different waves overlap on every SIMD.
 template <int KS, int TMAX, int NL, bool EXACT, bool SKEW, bool LEAN, bool STAMP>
 __global__ void __launch_bounds__(kBlock, 2)
 fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t stride, int64_t s_eff, int64_t E,
@@ -162,16 +173,15 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32x4 *lds_dfrag = reinterpret_cast<uint32x4 *>(smem + d.lds_dfrag);
-    float *smp = reinterpret_cast<float *>(smem + d.lds_smp);        // staged samples (scaled fp32)
-    _Float16 *colh = reinterpret_cast<_Float16 *>(smem + d.lds_colh); // [PS frames][kColStride]: column hi parts
-    _Float16 *coll = reinterpret_cast<_Float16 *>(smem + d.lds_coll); //                           lo parts
-    float *stat = reinterpret_cast<float *>(smem + d.lds_stat);      // [2][PS frames]: per-frame min/max or mean/M2
-    float *red = reinterpret_cast<float *>(smem + d.lds_red);
+    float *red = reinterpret_cast<float *>(smem + d.lds_red);        // [2 teams][4 waves] block-max partials, then [2] column scale exponents
+    int *cse_shared = reinterpret_cast<int *>(red + 8);
     float *cst = reinterpret_cast<float *>(smem + d.lds_cst);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int team = wave >> 2, tw = wave & 3;      // team, wave inside the team
+    const int ttid = tid & (kTeam - 1);             // thread inside the team
     const int f = lane & 15;          // frame (DFT) / evaluation (first layer) column inside the wave's tile
     const int g4 = lane >> 4;         // k block 8*g4..8*g4+7 of an operand; rows 4*g4..4*g4+3 of a result
     const int c = blockIdx.y;
@@ -179,11 +189,20 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
     if (e_b >= E) return;
     const int64_t e_e = (e_b + d.seg_evals < E) ? e_b + d.seg_evals : E;
     const float *row = samples + (int64_t)c * stride;
-    const int PS = d.ps, T = EXACT ? TMAX : d.T, H = d.H;
+    const int CS = d.ps, T = EXACT ? TMAX : d.T, H = d.H;      // CS: column slots per team buffer = 64 + T - 1
     const int nload = EXACT ? NL : d.nload;
     const int norm = LEAN ? 1 : d.norm, scaling = LEAN ? 0 : d.scaling, power_mode = LEAN ? 0 : d.power_mode;
     const int n_layers = LEAN ? 2 : d.n_layers, n_out = LEAN ? 1 : d.n_out, tf0 = LEAN ? 0 : d.tf0;
-    const int fl = 16 * wave + f;     // this lane's frame / evaluation slot inside the pass
+    const int fl = 16 * tw + f;       // this lane's frame / evaluation slot inside the team's chunk
+    const int nchunks = 2 * d.runs;
+
+    float *smp = reinterpret_cast<float *>(smem + d.lds_smp) + team * d.smp_stride;          // this team's staged samples (raw fp32)
+    _Float16 *colh = reinterpret_cast<_Float16 *>(smem + d.lds_colh) + team * CS * kColStride; // this team's columns, hi parts
+    _Float16 *coll = reinterpret_cast<_Float16 *>(smem + d.lds_coll) + team * CS * kColStride; //                       lo parts
+    const _Float16 *ocolh = reinterpret_cast<const _Float16 *>(smem + d.lds_colh) + (1 - team) * CS * kColStride;
+    const _Float16 *ocoll = reinterpret_cast<const _Float16 *>(smem + d.lds_coll) + (1 - team) * CS * kColStride;
+    float *stat = reinterpret_cast<float *>(smem + d.lds_stat) + team * 2 * CS;               // [2][CS] per-frame min/max or mean/M2
+    const float *ostat = reinterpret_cast<const float *>(smem + d.lds_stat) + (1 - team) * 2 * CS;
 
     // ---- once per workgroup: constants
     for (int i = tid; i < KS * 8 * 64; i += kBlock) lds_dfrag[i] = reinterpret_cast<const uint32x4 *>(d.dfrag)[i];
@@ -211,283 +230,274 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
 #pragma unroll
     for (int o = 0; o < 4; o++) c_b1[o] = (n_layers == 2 && o < n_out) ? d.b1[o] : 0.0f;
 
-    // this lane's frame in the staged stream, and where k-step ks of lane group g4 starts inside it
+    // this lane's frame in the team's staged stream, and where k-step ks of lane group g4 starts inside it
     const float *fptr = smp + fl * (d.hop + (SKEW ? d.skew : 0)) + (SKEW ? 0 : 8 * g4);
     int ko[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ks++) ko[ks] = SKEW ? d.koff[ks * 4 + g4] : 32 * ks;   // immediates without skew
 
+    // raw samples of one chunk: quads 4*(ttid + 256 k), k < nload, through a bounds-checked descriptor
     uint32x4 v[NL];
-    {
-        const __amdgpu_buffer_rsrc_t rs = tile_rsrc(row, e_b * d.hop + d.gap, s_eff, d.nsmp);
-#pragma unroll
-        for (int k = 0; k < NL; k++)
-            if (k < nload) v[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * tid + 16 * kBlock * k, 0, 0);
-    }
-    // results of the previous pass are stored at the start of the next one, so the wait for the
-    // prefetched samples never sits behind a store that was issued moments ago
-    float pend_y[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    int64_t pend_e = -1;
-    bool pend_hit = false;
-    int cse_prev = 0;                 // column scale exponent of the previous pass
-    unsigned long long tsum[16] = {0}, tprev = 0;
-    if (STAMP) tprev = __builtin_amdgcn_s_memtime();
-
-    for (int pass = 0; pass < d.runs; pass++) {
-        const int64_t jp = e_b + (int64_t)kTile * pass;       // first frame of this pass
-        if (jp - (T - 1) >= e_e) break;
-        SD_STAMP(8)
-
-        // ---------------- block floating point: scale the tile so its largest sample is in [2^13, 2^14)
+    auto chunk_rsrc = [&](int k) {
+        return tile_rsrc(row, (e_b + (int64_t)kChunk * k) * d.hop + d.gap, k < nchunks ? s_eff : 0, d.nsmp);
+    };
+    // block-max partial of the quads in v[] -> red, quads -> this team's sample region
+    auto stage_chunk = [&]() {
         float amax = 0.0f;
 #pragma unroll
         for (int k = 0; k < NL; k++)
             if (k < nload) {
                 const floatx4 q = as_floatx4(v[k]);
                 amax = absmax3(absmax3(amax, q[0], q[1]), q[2], q[3]);
+                const int i = 4 * (ttid + kTeam * k);
+                if (i < d.nsmp)
+                    *reinterpret_cast<floatx4 *>(smp + i + (SKEW ? d.skew * (int)__umulhi((unsigned)i, d.hop_magic) : 0)) = q;
             }
-        SD_STAMP(9)
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
         if (lane == 0) red[wave] = amax;
-        SD_STAMP(0)
-        __syncthreads();                                      // (A) previous pass fully consumed
-        SD_STAMP(1)
-        amax = fmaxf(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])), fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7])));
-        int se = 13 - (int)((__float_as_uint(amax) >> 23) & 0xffu) + 127;   // exponent of the sample scale
-        const int lim = power_mode ? 40 : 100;
-        se = amax > 0.0f ? (se < -lim ? -lim : (se > lim ? lim : se)) : 0;
-        se = __builtin_amdgcn_readfirstlane(se);
-        const float sx = pow2f(se);
-        // columns of this pass and the T-1 carried ones share one scale: the smaller of the two tiles'
-        const int cse = scaling != 0 ? 0 : ((pass > 0 && cse_prev < se) ? cse_prev : se);
+    };
+    {
+        const __amdgpu_buffer_rsrc_t rs = chunk_rsrc(team);
 #pragma unroll
         for (int k = 0; k < NL; k++)
-            if (k < nload) {
-                const int i = 4 * (tid + kBlock * k);         // quads past nsmp hold zeros and land in the buffer's slack
-                const floatx4 q = as_floatx4(v[k]);
-                *reinterpret_cast<floatx4 *>(smp + i + (SKEW ? d.skew * (int)__umulhi((unsigned)i, d.hop_magic) : 0)) = q * sx;
-            }
-        // the last T-1 columns of the previous pass move to the front (rescaled if the column scale changed)
-        if (pass > 0) {
-            const int dexp = (cse - cse_prev) * (power_mode ? 2 : 1);
-            const int words = (T - 1) * (kColStride / 2);      // 32-bit words per array
-            for (int i = tid; i < 2 * words; i += kBlock) {
-                unsigned *arr = reinterpret_cast<unsigned *>(i < words ? colh : coll);
-                const int w = i < words ? i : i - words;
-                unsigned u = arr[kTile * (kColStride / 2) + w];
-                if (dexp != 0) {
-                    const int bin = 2 * (w % (kColStride / 2));
-                    union { unsigned u; _Float16 h[2]; } x;
-                    x.u = u;
-                    const float f0 = (float)x.h[0] * pow2f((bin == d.stat_bin || bin == d.stat_bin + 1) ? 2 * dexp : dexp);
-                    const float f1 = (float)x.h[1] * pow2f((bin + 1 == d.stat_bin || bin == d.stat_bin) ? 2 * dexp : dexp);
-                    union { decltype(__builtin_amdgcn_cvt_pkrtz(0.f, 0.f)) h; unsigned u; } y;
-                    y.h = __builtin_amdgcn_cvt_pkrtz(f0, f1);
-                    u = y.u;
-                }
-                arr[w] = u;
-            }
-            if (norm >= 2 && tid < T - 1) {
-                stat[tid] = stat[kTile + tid];
-                stat[PS + tid] = stat[PS + kTile + tid];
-            }
-        }
-        cse_prev = cse;
-        SD_STAMP(2)
-        __syncthreads();                                      // (B) samples staged
-        SD_STAMP(3)
+            if (k < nload) v[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * ttid + 16 * kTeam * k, 0, 0);
+        stage_chunk();                                         // chunk `team` staged before the first half-step
+    }
+    int se = 0, cse = 0;              // sample / column scale exponents of the chunk this team is working on
+    unsigned long long tsum[16] = {0}, tprev = 0;
+    if (STAMP) tprev = __builtin_amdgcn_s_memtime();
+    __syncthreads();
 
-        // previous pass's results out
-        if (pend_e >= 0) {
-            if (outputs) {
-#pragma unroll
-                for (int o = 0; o < 4; o++)
-                    if (o < n_out) outputs[((int64_t)c * E + pend_e) * n_out + o] = pend_y[o];
-            }
-            if (flags) flags[(int64_t)c * E + pend_e] = pend_hit ? 1 : 0;
-            pend_e = -1;
-        }
-        // next pass's samples: fetched during this pass's matrix work, a load or two per k-step, so the
-        // memory queue never backs up into the wave
-        const __amdgpu_buffer_rsrc_t nrs = tile_rsrc(row, (jp + kTile) * d.hop + d.gap, pass + 1 < d.runs ? s_eff : 0, d.nsmp);
-        constexpr int kLoadsPerStep = (NL + KS - 1) / KS;
-        SD_STAMP(11)
-
-        // ---------------- band-limited DFT of this wave's 16 frames on the matrix cores: four 16-row tiles
-        // (re bins 0-15, re 16-31, im 0-15, im 16-31), 12 MFMAs per k-step of 32 samples.
-        // Software pipeline: while the MFMAs of k-step ks execute, the lane's next 8 samples (already in
-        // registers) are split into f16 hi/lo and the fragments after that are fetched.
-        floatx4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-        floatx4 s0 = *reinterpret_cast<const floatx4 *>(fptr + ko[0]);
-        floatx4 s1 = *reinterpret_cast<const floatx4 *>(fptr + ko[0] + 4);
-        half8 bh, bl;
-        split8(s0, s1, bh, bl);
-        if (KS > 1) {
-            s0 = *reinterpret_cast<const floatx4 *>(fptr + ko[1]);
-            s1 = *reinterpret_cast<const floatx4 *>(fptr + ko[1] + 4);
-        }
-        uint32x4 a[8];
-#pragma unroll
-        for (int i = 0; i < 8; i++) a[i] = lds_dfrag[i * 64 + lane];
-        __builtin_amdgcn_sched_barrier(0);                    // the prologue's fetches stay out of the loop's groups
-#pragma unroll
-        for (int ks = 0; ks < KS; ks++) {
-            half8 ah[4], al[4];
-#pragma unroll
-            for (int m = 0; m < 4; m++) { ah[m] = as_half8(a[2 * m]); al[m] = as_half8(a[2 * m + 1]); }
-            const half8 cbh = bh, cbl = bl;
-            const floatx4 n0 = s0, n1 = s1;
-            if (ks + 1 < KS) {                                // fragments of the next k-step
-#pragma unroll
-                for (int i = 0; i < 8; i++) a[i] = lds_dfrag[((ks + 1) * 8 + i) * 64 + lane];
-            }
-            if (ks + 2 < KS) {                                // raw samples two k-steps ahead
-                s0 = *reinterpret_cast<const floatx4 *>(fptr + ko[ks + 2]);
-                s1 = *reinterpret_cast<const floatx4 *>(fptr + ko[ks + 2] + 4);
-            }
-#pragma unroll
-            for (int j = 0; j < kLoadsPerStep; j++) {         // next pass's quads ks*kLoadsPerStep + j
-                const int k = ks * kLoadsPerStep + j;
-                if (k < NL && k < nload) v[k] = __builtin_amdgcn_raw_buffer_load_b128(nrs, 16 * tid + 16 * kBlock * k, 0, 0);
-            }
-#pragma unroll
-            for (int m = 0; m < 4; m++) acc[m] = mfma(ah[m], cbh, acc[m]);
-#pragma unroll
-            for (int m = 0; m < 4; m++) acc[m] = mfma(ah[m], cbl, acc[m]);
-#pragma unroll
-            for (int m = 0; m < 4; m++) acc[m] = mfma(al[m], cbh, acc[m]);
-            if (ks + 1 < KS) split8(n0, n1, bh, bl);          // 24 VALU, scheduled between the MFMAs below
-            // schedule: this k-step's 10 LDS fetches first (their data is used one and two k-steps later),
-            // then each MFMA followed by 2 of the split's VALU instructions
-            __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);      // 10 DS reads
-#pragma unroll
-            for (int i = 0; i < 12; i++) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
-                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // 2 VALU
-            }
-        }
-        SD_STAMP(4)
-
-        // ---------------- magnitude (zvabs/2 :329-333 or zvmags/4 :270-274), scaling
-        // (SyllableDetector.swift:184-212), statistic, f16 split, column -> LDS.
-        // Result layout: column = frame f, register j of lane group g4 in tile m = basis row 16m + 4*g4 + j;
-        // this lane therefore holds bins 4*g4 + j (i = j) and 16 + 4*g4 + j (i = 4 + j).
-        const float inv = pow2f(-se - 13);                   // accumulators hold X * sx * 2^13
-        // column scale (power of two; col_shift from the basis' largest row sum): |X| * 2^(cse - shift) < 2^13,
-        // |X|^2 * 2^(2 (cse - shift)) < 2^13 with its own shift; log/dB columns are stored unscaled
-        const float cs = scaling != 0 ? 1.0f : (power_mode ? pow2f(2 * (cse - d.col_shift)) : pow2f(cse - d.col_shift));
-        const int fh = d.F - 4 * g4;                          // cval[i] is a band bin iff (i&3) + 16(i>>2) < fh
-        float cval[8];
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const float re = acc[i >> 2][i & 3] * inv, im = acc[2 + (i >> 2)][i & 3] * inv;
-            const float pw = fmaf(re, re, im * im);
-            cval[i] = power_mode ? pw : __builtin_amdgcn_sqrtf(pw);
-        }
-        if (scaling != 0) {
-            const float k = scaling == 1 ? 0.6931471805599453f : 6.020599913279624f;   // ln 2, 20 log10 2
-#pragma unroll
-            for (int i = 0; i < 8; i++) cval[i] = k * __builtin_amdgcn_logf(cval[i]);  // v_log_f32 = log2
-        }
-        if (d.F < 32 || scaling != 0) {
-#pragma unroll
-            for (int i = 0; i < 8; i++) cval[i] = ((i & 3) + 16 * (i >> 2)) < fh ? cval[i] : 0.0f;
-        }
-        const int slot = (T - 1) + fl;
-        if (norm == 2) {
-            float st0 = INFINITY, st1 = -INFINITY;
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const bool valid = ((i & 3) + 16 * (i >> 2)) < fh;
-                st0 = valid ? fminf(st0, cval[i]) : st0;
-                st1 = valid ? fmaxf(st1, cval[i]) : st1;
-            }
-            st0 = fminf(st0, __shfl_xor(st0, 16, 64)); st0 = fminf(st0, __shfl_xor(st0, 32, 64));
-            st1 = fmaxf(st1, __shfl_xor(st1, 16, 64)); st1 = fmaxf(st1, __shfl_xor(st1, 32, 64));
-            if (g4 == 0) { stat[slot] = st0; stat[PS + slot] = st1; }
-        } else if (norm == 3) {
-            float st0 = 0.0f, st1 = 0.0f;
-#pragma unroll
-            for (int i = 0; i < 8; i++) st0 += cval[i];
-            st0 += __shfl_xor(st0, 16, 64); st0 += __shfl_xor(st0, 32, 64);
-            st0 = st0 / (float)d.F;                           // mean of this frame's column
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const float dlt = cval[i] - st0;
-                st1 = ((i & 3) + 16 * (i >> 2)) < fh ? fmaf(dlt, dlt, st1) : st1;   // M2 of this frame's column
-            }
-            st1 += __shfl_xor(st1, 16, 64); st1 += __shfl_xor(st1, 32, 64);
-            if (g4 == 0) { stat[slot] = st0; stat[PS + slot] = st1; }
-        }
-#pragma unroll
-        for (int i = 0; i < 8; i++) cval[i] *= cs;
-        if (norm == 1) {
-            // sum of squares of the (scaled) column rides in two spare bins: its top 11 bits in bin F and the
-            // remainder, scaled by 2^11 so that it stays a normal f16, in bin F+1 (weights 1 and 2^-11 in row H
-            // of the first-layer fragments) -- together exact to fp32, whatever the column's level
-            float ss = 0.0f;
-#pragma unroll
-            for (int i = 0; i < 8; i++) ss = fmaf(cval[i], cval[i], ss);
-            ss += __shfl_xor(ss, 16, 64);
-            ss += __shfl_xor(ss, 32, 64);
-            ss *= scaling != 0 ? 0.015625f : 9.5367431640625e-07f;   // 2^-6 (log/dB values) or 2^-20
-            const float ss_hi = __uint_as_float(__float_as_uint(ss) & 0xFFFFE000u);
-            const float ss_lo = (ss - ss_hi) * 2048.0f;
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                cval[i] = (g4 == d.stat_g4 && i == d.stat_i) ? ss_hi : cval[i];
-                cval[i] = (g4 == d.stat_g4b && i == d.stat_ib) ? ss_lo : cval[i];
-            }
-        }
-        {
-            _Float16 *ph = colh + slot * kColStride + 4 * g4, *pl = coll + slot * kColStride + 4 * g4;
-#pragma unroll
-            for (int m = 0; m < 2; m++) {                     // bins 16m + 4*g4 .. +3: four consecutive halves
-                unsigned h0, l0, h1, l1;
-                split_pair(cval[4 * m], cval[4 * m + 1], h0, l0);
-                split_pair(cval[4 * m + 2], cval[4 * m + 3], h1, l1);
-                uint32x2 uh = {h0, h1}, ul = {l0, l1};
-                *reinterpret_cast<uint32x2 *>(ph + 16 * m) = uh;
-                *reinterpret_cast<uint32x2 *>(pl + 16 * m) = ul;
-            }
-        }
-        SD_STAMP(5)
-        __syncthreads();                                      // (C) columns of all 128 frames visible
-        SD_STAMP(6)
-
-        // ---------------- first layer as a shifted GEMM + the rest of the network in registers.
-        // This wave finishes evaluation slots 16*wave .. +15 (slot q: e = jp - (T-1) + q, columns q .. q+T-1):
-        // result column = f, rows 4*g4 + j = hidden unit (row H = window sum of squares).
-        const float zs = d.w_unscale / cs;                    // first-layer sums back to true units
-        floatx4 z = {0.0f, 0.0f, 0.0f, 0.0f}, z2 = {0.0f, 0.0f, 0.0f, 0.0f};
-        {
-            const _Float16 *bph = colh + fl * kColStride + 8 * g4, *bpl = coll + fl * kColStride + 8 * g4;
-            uint32x4 fh0 = *reinterpret_cast<const uint32x4 *>(bph), fl0 = *reinterpret_cast<const uint32x4 *>(bpl);
-            uint32x4 fh1 = fh0, fl1 = fl0;
-            if (T > 1) {
-                fh1 = *reinterpret_cast<const uint32x4 *>(bph + kColStride);
-                fl1 = *reinterpret_cast<const uint32x4 *>(bpl + kColStride);
-            }
-#pragma unroll
-            for (int t = 0; t < TMAX; t++) {
-                if (t < T) {
-                    const half8 h0 = as_half8(fh0), l0 = as_half8(fl0);
-                    fh0 = fh1; fl0 = fl1;
-                    if (t + 2 < T) {
-                        fh1 = *reinterpret_cast<const uint32x4 *>(bph + (t + 2) * kColStride);
-                        fl1 = *reinterpret_cast<const uint32x4 *>(bpl + (t + 2) * kColStride);
+    for (int hs = 0; hs <= nchunks; hs++) {
+        if ((hs & 1) == team && hs < nchunks) {
+            // =================================================== FRONT phase of chunk k
+            const int k = hs;
+            SD_STAMP(8)
+            // ---- block floating point: the chunk's largest sample goes to [2^13, 2^14)
+            const float amax = fmaxf(fmaxf(red[4 * team], red[4 * team + 1]), fmaxf(red[4 * team + 2], red[4 * team + 3]));
+            se = 13 - (int)((__float_as_uint(amax) >> 23) & 0xffu) + 127;
+            const int lim = power_mode ? 40 : 100;
+            se = amax > 0.0f ? (se < -lim ? -lim : (se > lim ? lim : se)) : 0;
+            se = __builtin_amdgcn_readfirstlane(se);
+            const float sx = pow2f(se);
+            // columns of this chunk and the T-1 carried ones share one scale: the smaller of the two chunks' sample
+            // scales (the carried columns were stored at the neighbour's column scale and are rescaled below)
+            const int se_other = cse_shared[2 + (1 - team)], cse_other = cse_shared[1 - team];
+            cse = scaling != 0 ? 0 : ((k > 0 && se_other < se) ? se_other : se);
+            cse = __builtin_amdgcn_readfirstlane(cse);
+            if (ttid == 0) { cse_shared[team] = cse; cse_shared[2 + team] = se; }
+            // ---- the neighbour chunk's last T-1 columns move to the front of this team's buffer (rescaled to cse)
+            if (k > 0) {
+                const int dexp = (cse - cse_other) * (power_mode ? 2 : 1);
+                const int words = (T - 1) * (kColStride / 2);      // 32-bit words per array
+                for (int i = ttid; i < 2 * words; i += kTeam) {
+                    const bool hi_arr = i < words;
+                    const int w = hi_arr ? i : i - words;
+                    unsigned u = reinterpret_cast<const unsigned *>(hi_arr ? ocolh : ocoll)[kChunk * (kColStride / 2) + w];
+                    if (dexp != 0) {
+                        const int bin = 2 * (w % (kColStride / 2));
+                        union { unsigned u; _Float16 h[2]; } x;
+                        x.u = u;
+                        // the two statistic bins hold a sum of squares: they scale with the square
+                        const bool st0 = norm == 1 && (bin == d.stat_bin || bin == d.stat_bin + 1);
+                        const bool st1 = norm == 1 && (bin + 1 == d.stat_bin || bin == d.stat_bin);
+                        const float f0 = (float)x.h[0] * pow2f(st0 ? 2 * dexp : dexp);
+                        const float f1 = (float)x.h[1] * pow2f(st1 ? 2 * dexp : dexp);
+                        union { decltype(__builtin_amdgcn_cvt_pkrtz(0.f, 0.f)) h; unsigned u; } y;
+                        y.h = __builtin_amdgcn_cvt_pkrtz(f0, f1);
+                        u = y.u;
                     }
-                    z = mfma(afr[t][0], h0, z);               // two accumulation chains: hi*hi on one,
-                    z2 = mfma(afr[t][0], l0, z2);             // the cross terms on the other
-                    z2 = mfma(afr[t][1], h0, z2);
+                    reinterpret_cast<unsigned *>(hi_arr ? colh : coll)[w] = u;
+                }
+                if (norm >= 2 && ttid < T - 1) {
+                    stat[ttid] = ostat[kChunk + ttid];
+                    stat[CS + ttid] = ostat[CS + kChunk + ttid];
                 }
             }
-            z += z2;
-        }
-        SD_STAMP(12)
-        {
-            const int64_t e = jp - (T - 1) + fl;
+            // ---- the chunk after next is fetched during this chunk's matrix work, a load or two per k-step, so the
+            // memory queue never backs up into the wave
+            const __amdgpu_buffer_rsrc_t nrs = chunk_rsrc(k + 2);
+            constexpr int kLoadsPerStep = (NL + KS - 1) / KS;
+            SD_STAMP(2)
+
+            // ---- band-limited DFT of this wave's 16 frames on the matrix cores: four 16-row tiles
+            // (re bins 0-15, re 16-31, im 0-15, im 16-31), 12 MFMAs per k-step of 32 samples.
+            // Software pipeline: while the MFMAs of k-step ks execute, the lane's next 8 samples (already in
+            // registers) are scaled and split into f16 hi/lo and the fragments after that are fetched.
+            floatx4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            floatx4 s0 = *reinterpret_cast<const floatx4 *>(fptr + ko[0]);
+            floatx4 s1 = *reinterpret_cast<const floatx4 *>(fptr + ko[0] + 4);
+            half8 bh, bl;
+            split8(s0 * sx, s1 * sx, bh, bl);
+            if (KS > 1) {
+                s0 = *reinterpret_cast<const floatx4 *>(fptr + ko[1]);
+                s1 = *reinterpret_cast<const floatx4 *>(fptr + ko[1] + 4);
+            }
+            uint32x4 a[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) a[i] = lds_dfrag[i * 64 + lane];
+            __builtin_amdgcn_sched_barrier(0);                    // the prologue's fetches stay out of the loop's groups
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) {
+                half8 ah[4], al[4];
+#pragma unroll
+                for (int m = 0; m < 4; m++) { ah[m] = as_half8(a[2 * m]); al[m] = as_half8(a[2 * m + 1]); }
+                const half8 cbh = bh, cbl = bl;
+                const floatx4 n0 = s0, n1 = s1;
+                if (ks + 1 < KS) {                                // fragments of the next k-step
+#pragma unroll
+                    for (int i = 0; i < 8; i++) a[i] = lds_dfrag[((ks + 1) * 8 + i) * 64 + lane];
+                }
+                if (ks + 2 < KS) {                                // raw samples two k-steps ahead
+                    s0 = *reinterpret_cast<const floatx4 *>(fptr + ko[ks + 2]);
+                    s1 = *reinterpret_cast<const floatx4 *>(fptr + ko[ks + 2] + 4);
+                }
+#pragma unroll
+                for (int j = 0; j < kLoadsPerStep; j++) {         // quads ks*kLoadsPerStep + j of chunk k+2
+                    const int q = ks * kLoadsPerStep + j;
+                    if (q < NL && q < nload) v[q] = __builtin_amdgcn_raw_buffer_load_b128(nrs, 16 * ttid + 16 * kTeam * q, 0, 0);
+                }
+#pragma unroll
+                for (int m = 0; m < 4; m++) acc[m] = mfma(ah[m], cbh, acc[m]);
+#pragma unroll
+                for (int m = 0; m < 4; m++) acc[m] = mfma(ah[m], cbl, acc[m]);
+#pragma unroll
+                for (int m = 0; m < 4; m++) acc[m] = mfma(al[m], cbh, acc[m]);
+                if (ks + 1 < KS) split8(n0 * sx, n1 * sx, bh, bl);   // 32 VALU, scheduled between the MFMAs below
+                // schedule: this k-step's 10 LDS fetches first (their data is used one and two k-steps later),
+                // then each MFMA followed by 3 of the split's VALU instructions
+                __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);      // 10 DS reads
+#pragma unroll
+                for (int i = 0; i < 12; i++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);   // 3 VALU
+                }
+            }
+            SD_STAMP(4)
+
+            // ---- magnitude (zvabs/2 :329-333 or zvmags/4 :270-274), scaling (SyllableDetector.swift:184-212),
+            // statistic, f16 split, column -> LDS.  Result layout: column = frame f, register j of lane group g4 in
+            // tile m = basis row 16m + 4*g4 + j; this lane holds bins 4*g4 + j (i = j) and 16 + 4*g4 + j (i = 4 + j).
+            const float inv = pow2f(-se - 13);                   // accumulators hold X * sx * 2^13
+            // column scale (power of two; col_shift from the basis' largest row sum): |X| * 2^(cse - shift) < 2^13,
+            // |X|^2 * 2^(2 (cse - shift)) < 2^13 with its own shift; log/dB columns are stored unscaled
+            const float cs = scaling != 0 ? 1.0f : (power_mode ? pow2f(2 * (cse - d.col_shift)) : pow2f(cse - d.col_shift));
+            const int fh = d.F - 4 * g4;                          // cval[i] is a band bin iff (i&3) + 16(i>>2) < fh
+            float cval[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const float re = acc[i >> 2][i & 3] * inv, im = acc[2 + (i >> 2)][i & 3] * inv;
+                const float pw = fmaf(re, re, im * im);
+                cval[i] = power_mode ? pw : __builtin_amdgcn_sqrtf(pw);
+            }
+            if (scaling != 0) {
+                const float kk = scaling == 1 ? 0.6931471805599453f : 6.020599913279624f;   // ln 2, 20 log10 2
+#pragma unroll
+                for (int i = 0; i < 8; i++) cval[i] = kk * __builtin_amdgcn_logf(cval[i]);  // v_log_f32 = log2
+            }
+            if (d.F < 32 || scaling != 0) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) cval[i] = ((i & 3) + 16 * (i >> 2)) < fh ? cval[i] : 0.0f;
+            }
+            const int slot = (T - 1) + fl;
+            if (norm == 2) {
+                float st0 = INFINITY, st1 = -INFINITY;
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const bool valid = ((i & 3) + 16 * (i >> 2)) < fh;
+                    st0 = valid ? fminf(st0, cval[i]) : st0;
+                    st1 = valid ? fmaxf(st1, cval[i]) : st1;
+                }
+                st0 = fminf(st0, __shfl_xor(st0, 16, 64)); st0 = fminf(st0, __shfl_xor(st0, 32, 64));
+                st1 = fmaxf(st1, __shfl_xor(st1, 16, 64)); st1 = fmaxf(st1, __shfl_xor(st1, 32, 64));
+                if (g4 == 0) { stat[slot] = st0; stat[CS + slot] = st1; }
+            } else if (norm == 3) {
+                float st0 = 0.0f, st1 = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 8; i++) st0 += cval[i];
+                st0 += __shfl_xor(st0, 16, 64); st0 += __shfl_xor(st0, 32, 64);
+                st0 = st0 / (float)d.F;                           // mean of this frame's column
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const float dlt = cval[i] - st0;
+                    st1 = ((i & 3) + 16 * (i >> 2)) < fh ? fmaf(dlt, dlt, st1) : st1;   // M2 of this frame's column
+                }
+                st1 += __shfl_xor(st1, 16, 64); st1 += __shfl_xor(st1, 32, 64);
+                if (g4 == 0) { stat[slot] = st0; stat[CS + slot] = st1; }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; i++) cval[i] *= cs;
+            if (norm == 1) {
+                // sum of squares of the (scaled) column rides in two spare bins: its top 11 bits in bin F and the
+                // remainder, scaled by 2^11 so that it stays a normal f16, in bin F+1 (weights 1 and 2^-11 in row H
+                // of the first-layer fragments) -- together exact to fp32, whatever the column's level
+                float ss = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 8; i++) ss = fmaf(cval[i], cval[i], ss);
+                ss += __shfl_xor(ss, 16, 64);
+                ss += __shfl_xor(ss, 32, 64);
+                ss *= scaling != 0 ? 0.015625f : 9.5367431640625e-07f;   // 2^-6 (log/dB values) or 2^-20
+                const float ss_hi = __uint_as_float(__float_as_uint(ss) & 0xFFFFE000u);
+                const float ss_lo = (ss - ss_hi) * 2048.0f;
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    cval[i] = (g4 == d.stat_g4 && i == d.stat_i) ? ss_hi : cval[i];
+                    cval[i] = (g4 == d.stat_g4b && i == d.stat_ib) ? ss_lo : cval[i];
+                }
+            }
+            {
+                _Float16 *ph = colh + slot * kColStride + 4 * g4, *pl = coll + slot * kColStride + 4 * g4;
+#pragma unroll
+                for (int m = 0; m < 2; m++) {                     // bins 16m + 4*g4 .. +3: four consecutive halves
+                    unsigned h0, l0, h1, l1;
+                    split_pair(cval[4 * m], cval[4 * m + 1], h0, l0);
+                    split_pair(cval[4 * m + 2], cval[4 * m + 3], h1, l1);
+                    uint32x2 uh = {h0, h1}, ul = {l0, l1};
+                    *reinterpret_cast<uint32x2 *>(ph + 16 * m) = uh;
+                    *reinterpret_cast<uint32x2 *>(pl + 16 * m) = ul;
+                }
+            }
+            SD_STAMP(5)
+        } else if ((hs & 1) != team && hs >= 1) {
+            // =================================================== BACK phase of chunk k = hs - 1
+            const int k = hs - 1;
+            SD_STAMP(9)
+            // ---- samples of chunk k+2 (fetched during the front phase) -> block-max partial + LDS
+            if (k + 2 < nchunks) stage_chunk();
+            SD_STAMP(0)
+            // ---- first layer as a shifted GEMM + the rest of the network in registers.
+            // This wave finishes evaluation slots 16*tw .. +15 of the chunk (slot q: e = e_b + 64k - (T-1) + q, columns
+            // q .. q+T-1): result column = f, rows 4*g4 + j = hidden unit (row H = window sum of squares).
+            const float cs = scaling != 0 ? 1.0f : (power_mode ? pow2f(2 * (cse - d.col_shift)) : pow2f(cse - d.col_shift));
+            const float zs = d.w_unscale / cs;                    // first-layer sums back to true units
+            floatx4 z = {0.0f, 0.0f, 0.0f, 0.0f}, z2 = {0.0f, 0.0f, 0.0f, 0.0f};
+            {
+                const _Float16 *bph = colh + fl * kColStride + 8 * g4, *bpl = coll + fl * kColStride + 8 * g4;
+                uint32x4 fh0 = *reinterpret_cast<const uint32x4 *>(bph), fl0 = *reinterpret_cast<const uint32x4 *>(bpl);
+                uint32x4 fh1 = fh0, fl1 = fl0;
+                if (T > 1) {
+                    fh1 = *reinterpret_cast<const uint32x4 *>(bph + kColStride);
+                    fl1 = *reinterpret_cast<const uint32x4 *>(bpl + kColStride);
+                }
+#pragma unroll
+                for (int t = 0; t < TMAX; t++) {
+                    if (t < T) {
+                        const half8 h0 = as_half8(fh0), l0 = as_half8(fl0);
+                        fh0 = fh1; fl0 = fl1;
+                        if (t + 2 < T) {
+                            fh1 = *reinterpret_cast<const uint32x4 *>(bph + (t + 2) * kColStride);
+                            fl1 = *reinterpret_cast<const uint32x4 *>(bpl + (t + 2) * kColStride);
+                        }
+                        z = mfma(afr[t][0], h0, z);               // two accumulation chains: hi*hi on one,
+                        z2 = mfma(afr[t][0], l0, z2);             // the cross terms on the other
+                        z2 = mfma(afr[t][1], h0, z2);
+                    }
+                }
+                z += z2;
+            }
+            SD_STAMP(12)
+            const int64_t e = e_b + (int64_t)kChunk * k - (T - 1) + fl;
             const bool valid = e >= e_b && e < e_e;
             float alpha = zs, beta = 0.0f;                    // layer-0 input = alpha * z + beta * rvec + bias0
             if (norm == 1) {                                  // L2Normalize, NeuralNet.swift:47-59
@@ -496,7 +506,7 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
                 alpha = d.w_unscale * (scaling != 0 ? 0.125f : 0.0009765625f) * __builtin_amdgcn_rsqf(ssw);   // 2^-3 | 2^-10
             } else if (norm == 2) {                           // Normalize, :69-96
                 float mn = INFINITY, mx = -INFINITY;
-                for (int t = 0; t < T; t++) { mn = fminf(mn, stat[fl + t]); mx = fmaxf(mx, stat[PS + fl + t]); }
+                for (int t = 0; t < T; t++) { mn = fminf(mn, stat[fl + t]); mx = fmaxf(mx, stat[CS + fl + t]); }
                 const float range = mx - mn;
                 if (range == 0.0f) { alpha = 0.0f; beta = -1.0f; }
                 else { alpha = zs * 2.0f / range; beta = (0.0f - mn - mx) / range; }
@@ -505,14 +515,13 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
                 for (int t = 0; t < T; t++) {                 // pairwise-stable combination of per-frame (mean, M2)
                     const float nb = (float)d.F, tot = nn + nb, dlt = stat[fl + t] - mean;
                     mean += dlt * nb / tot;
-                    m2 += stat[PS + fl + t] + dlt * dlt * nn * nb / tot;
+                    m2 += stat[CS + fl + t] + dlt * dlt * nn * nb / tot;
                     nn = tot;
                 }
                 const float sd = sqrtf(m2 / (float)d.I);
                 alpha = zs / sd;
                 beta = -mean / sd;
             }
-            SD_STAMP(13)
             float act[4];                                     // rows past H (padding, statistic) contribute nothing
 #pragma unroll
             for (int j = 0; j < 4; j++)
@@ -521,6 +530,7 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
             const double *thr = reinterpret_cast<const double *>(cst + kCstThr);
             bool hit = false;
             if (n_layers == 2) {
+                float yv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
                 for (int o = 0; o < 4; o++) {
                     if (o < n_out) {
@@ -533,24 +543,30 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
                             y += __shfl_xor(y, 32, 64);
                         }
                         y = transfer_fn(d.tf1, y + c_b1[o]);
-                        for (int k = 0; k < d.n_out_fns; k++) {       // reverse maps, NeuralNet.swift:137-142 / :175-180
-                            const float *op = cst + kCstOut + k * (1 + 2 * n_out);
+                        for (int kf = 0; kf < d.n_out_fns; kf++) {    // reverse maps, NeuralNet.swift:137-142 / :175-180
+                            const float *op = cst + kCstOut + kf * (1 + 2 * n_out);
                             y = (y - op[0]) / op[1 + o] + op[1 + n_out + o];
                         }
-                        pend_y[o] = y;
+                        yv[o] = y;
                         if (o == 0 || d.rule == 1) hit = hit || ((double)y >= thr[o]);
                     }
                 }
-                pend_hit = hit;
-                pend_e = (valid && g4 == 0) ? e : -1;
+                if (valid && g4 == 0) {
+                    if (outputs) {
+#pragma unroll
+                        for (int o = 0; o < 4; o++)
+                            if (o < n_out) outputs[((int64_t)c * E + e) * n_out + o] = yv[o];
+                    }
+                    if (flags) flags[(int64_t)c * E + e] = hit ? 1 : 0;
+                }
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const int h = 4 * g4 + j;
                     if (h < H) {
                         float y = act[j];
-                        for (int k = 0; k < d.n_out_fns; k++) {
-                            const float *op = cst + kCstOut + k * (1 + 2 * n_out);
+                        for (int kf = 0; kf < d.n_out_fns; kf++) {
+                            const float *op = cst + kCstOut + kf * (1 + 2 * n_out);
                             y = (y - op[0]) / op[1 + h] + op[1 + n_out + h];
                         }
                         if (valid && outputs) outputs[((int64_t)c * E + e) * n_out + h] = y;
@@ -562,19 +578,15 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
                 anyhit |= __shfl_xor(anyhit, 32, 64);
                 if (valid && g4 == 0 && flags) flags[(int64_t)c * E + e] = anyhit ? 1 : 0;
             }
+            SD_STAMP(7)
         }
-        SD_STAMP(7)
+        SD_STAMP(13)
+        __syncthreads();                                      // one barrier per half-step
+        SD_STAMP(6)
     }
-    if (pend_e >= 0) {
-        if (outputs) {
-#pragma unroll
-            for (int o = 0; o < 4; o++)
-                if (o < n_out) outputs[((int64_t)c * E + pend_e) * n_out + o] = pend_y[o];
-        }
-        if (flags) flags[(int64_t)c * E + pend_e] = pend_hit ? 1 : 0;
-    }
-    if (STAMP && tid == 0 && d.stamps)
-        for (int i = 0; i < 16; i++) d.stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + i] = tsum[i];
+    if (STAMP && (tid == 0 || tid == kTeam) && d.stamps)
+        for (int i = 0; i < 16; i++)
+            atomicAdd(&d.stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + i], tsum[i] / 2);
 }
 
 template <int KS, int TMAX, int NL, bool EXACT, bool SKEW, bool LEAN = false, bool STAMP = false>

@@ -291,9 +291,9 @@ int run_on_stream(syldet *h, const float *d_samples, int64_t S, int64_t stride, 
             for (size_t i = 0; i < n; i++) sum[i % 16] += (double)host[i];
             double tot = 0;
             for (double v : sum) tot += v;
-            static const char *names[16] = {"shuffle-reduce+red", "barrier A", "scale+stage+carry", "barrier B", "DFT MFMA loop",
-                                            "mag+stat+columns", "barrier C", "layer1+out+compare", "loop back-edge", "max over prefetch (vmcnt)",
-                                            "-", "deferred stores+prefetch issue", "layer-0 GEMM", "alpha/beta", "transfer fn", "-"};
+            static const char *names[16] = {"back: stage next chunk", "-", "front: scale+carry", "-", "front: DFT MFMA loop",
+                                            "front: mag+columns", "barrier wait", "back: layer1+out+stores", "front: entry", "back: entry (vmcnt)",
+                                            "-", "-", "back: layer-0 GEMM", "idle tail before barrier", "back: alpha+transfer", "-"};
             std::fprintf(stderr, "[syldet stamps] runs=%d workgroups=%zu cycles/pass=%.0f\n", d.runs, n / 16, tot / ((double)(n / 16) * d.runs));
             for (int i = 0; i < 16; i++)
                 if (sum[i] > 0) std::fprintf(stderr, "   %-32s %6.0f cycles/pass  %5.1f %%\n", names[i], sum[i] / ((double)(n / 16) * d.runs), 100.0 * sum[i] / tot);

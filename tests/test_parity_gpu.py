@@ -286,3 +286,26 @@ def test_cpp_mirror_of_the_swift_surface(oracle_lib, tmp_path):
     assert detected == int(wfl.sum())
     want_idx = o.detections(wfl, 0.0)
     assert n_idx == len(want_idx) and (n_idx == 0 or first_idx == int(want_idx[0]))
+
+
+@pytest.mark.parametrize("name", ["case_sample_syllables", "case_chain_mapstd_only", "case_chain_none", "case_chain_normalize_db"])
+def test_level_steps_across_tile_boundaries(oracle_lib, name):
+    """Block floating point: the per-tile scale changes by orders of magnitude between neighbouring tiles
+    (level steps every few hundred samples, at positions unrelated to the tiling), with and without a
+    scale-invariant normaliser in front of the network.  Carried columns must be rescaled exactly."""
+    torch = _torch()
+    cfg, x, _ = util.load_case(name)
+    x = x[:60000].copy()
+    rng = np.random.default_rng(7)
+    pos = 0
+    while pos < x.size:
+        n = int(rng.integers(300, 9000))
+        x[pos:pos + n] *= np.float32(10.0 ** rng.uniform(-3.5, 0.0))
+        pos += n
+    o = util.oracle_for(cfg)
+    _, wfl, w64 = o.run(x, po.F64, cfg.rule)
+    with sd.SyllableDetector(cfg, channels=1) as det:
+        out, fl = det.run(torch.from_numpy(x[None]).cuda())
+        torch.cuda.synchronize()
+    util.assert_outputs_close(out.cpu().numpy()[0], w64)
+    util.assert_flags_exact(fl.cpu().numpy()[0], w64, cfg.thresholds, cfg.rule)
