@@ -120,12 +120,11 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
     const int nsmp = (kFusedChunkFrames - 1) * hop + KS * 32;   // samples one chunk's frames read
     const int nload = (nsmp / 4 + team - 1) / team;
     if (nload > kFusedMaxLoads) return no("hop too large for the staging registers");
-    // LDS bank spreading: a lane reads 8 consecutive fp32 samples of its frame with two ds_read_b128;
-    // those are conflict-free when consecutive frames start an odd number of 16-byte slots apart
-    // (hop = 132: 33 slots).  For hop = 0 mod 8 (e.g. 128: 32 slots, every lane on one slot) one slot of
-    // padding is inserted after every hop staged samples; 8-sample groups never straddle the padding
-    // because they start at multiples of 8 inside a frame and hop is then a multiple of 8.
-    const int skew = ((hop / 4) % 2 == 0) ? 4 : 0;
+    // LDS bank spreading: a lane reads 8 consecutive f16 samples of its frame with two ds_read_b64; the 16
+    // frames of a tile are hop/2 dwords apart, which spreads over the 64 banks unless hop is a multiple of 16
+    // (hop = 128: every frame on the same bank).  Then 4 halves of padding follow every hop staged samples;
+    // 8-sample groups never straddle it because they start at multiples of 8 inside a frame.
+    const int skew = (hop % 16 == 0) ? 4 : 0;
     auto skewed = [&](int i) { return i + skew * (i / hop); };
     const int nsmp_p = (skewed(nsmp + 16) + 15) / 8 * 8;
     const int PS = kFusedChunkFrames + T - 1;
@@ -149,7 +148,7 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
     int off = 0;
     auto take = [&off](int bytes) { const int o = off; off += (bytes + 15) / 16 * 16; return o; };
     d.lds_dfrag = take(KS * 8 * 1024);
-    d.lds_smp = take(2 * nsmp_p * 4);                // staged samples (raw fp32), one region per team
+    d.lds_smp = take(2 * 2 * nsmp_p * 2);            // staged samples, f16 hi + lo, one region pair per team
     d.lds_colh = take(2 * PS * kFusedColStride * 2); // |X| columns, f16 hi, one buffer per team
     d.lds_coll = take(2 * PS * kFusedColStride * 2); //              f16 lo
     d.lds_stat = take(2 * 2 * PS * 4);

@@ -95,6 +95,7 @@ struct FusedDesc {
     const float *w1, *b1;       // layer 1, row-major [n_out][H] (2-layer nets)
     const float *out_params;    // per output fn: y, gain[n_out], xoff[n_out]
     const double *thresholds;   // [n_out]
+    int ko;                     // diagnostic build only: knock-out mask (SYLDET_FUSED_KO)
     unsigned long long *stamps; // diagnostic build only: [workgroups][16] phase cycle sums, else null
 };
 

@@ -61,6 +61,12 @@ __device__ __forceinline__ half8 as_half8(uint32x4 v)
     c.u = v;
     return c.h;
 }
+__device__ __forceinline__ uint32x4 as_u4(half8 v)
+{
+    union { uint32x4 u; half8 h; } c;
+    c.h = v;
+    return c.u;
+}
 __device__ __forceinline__ floatx4 as_floatx4(uint32x4 v)
 {
     union { uint32x4 u; floatx4 f; } c;
@@ -134,6 +140,14 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const float *row, in
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(row + first), 0, (int)left * 4, 0x00020000);
 }
 
+// 8 consecutive halves from an 8-byte aligned LDS address (two ds_read_b64)
+__device__ __forceinline__ half8 lds_half8(const _Float16 *p)
+{
+    const uint32x2 lo = *reinterpret_cast<const uint32x2 *>(p), hi = *reinterpret_cast<const uint32x2 *>(p + 4);
+    uint32x4 u = {lo[0], lo[1], hi[0], hi[1]};
+    return as_half8(u);
+}
+
 __device__ __forceinline__ floatx4 mfma(half8 a, half8 b, floatx4 c)
 {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
@@ -144,11 +158,16 @@ __device__ __forceinline__ floatx4 mfma(half8 a, half8 b, floatx4 c)
 #define SD_STAMP(slot)                                                                     \
     if (STAMP) {                                                                           \
         __builtin_amdgcn_sched_barrier(0);                                                 \
-        const unsigned long long now = __builtin_amdgcn_s_memtime();                       \
-        __builtin_amdgcn_s_waitcnt(0xC07F);                                                \
+        tick[slot] = __builtin_amdgcn_s_memtime();  /* no wait here: read at the phase's end */ \
         __builtin_amdgcn_sched_barrier(0);                                                 \
-        tsum[slot] += now - tprev;                                                         \
-        tprev = now;                                                                       \
+    }
+// phase end: the ticks taken since SD_STAMP_BEGIN become per-slot cycle sums
+#define SD_STAMP_FLUSH()                                                                   \
+    if (STAMP) {                                                                           \
+        unsigned long long prev = tick0;                                                   \
+        for (int i_ = 0; i_ < 16; i_++)                                                    \
+            if (tick[i_] != 0) { tsum[i_] += tick[i_] - prev; prev = tick[i_]; tick[i_] = 0; } \
+        tick0 = prev;                                                                      \
     }
 
 // KS: k-steps of 32 samples; TMAX / NL: array sizes for taps and staging quads; EXACT: timeRange == TMAX
@@ -166,7 +185,7 @@ __device__ __forceinline__ floatx4 mfma(half8 a, half8 b, floatx4 c)
 //     next chunk's prefetched samples -> block max partials + LDS; first layer as a shifted GEMM over its
 //     column buffer; rest of the network in registers; results -> HBM
 // so matrix-heavy and VALU/latency-heavy work of different waves overlap on every SIMD.
-template <int KS, int TMAX, int NL, bool EXACT, bool SKEW, bool LEAN, bool STAMP>
+template <int KS, int TMAX, int NL, bool EXACT, bool SKEW, bool LEAN, bool STAMP, int KNOCK>
 __global__ void __launch_bounds__(kBlock, 2)
 fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t stride, int64_t s_eff, int64_t E,
              float *__restrict__ outputs, uint8_t *__restrict__ flags)
@@ -195,8 +214,10 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
     const int n_layers = LEAN ? 2 : d.n_layers, n_out = LEAN ? 1 : d.n_out, tf0 = LEAN ? 0 : d.tf0;
     const int fl = 16 * tw + f;       // this lane's frame / evaluation slot inside the team's chunk
     const int nchunks = 2 * d.runs;
+    constexpr int kom = KNOCK;   // diagnostic knock-outs (stamped instantiation only; results are then wrong)
 
-    float *smp = reinterpret_cast<float *>(smem + d.lds_smp) + team * d.smp_stride;          // this team's staged samples (raw fp32)
+    _Float16 *smph = reinterpret_cast<_Float16 *>(smem + d.lds_smp) + team * 2 * d.smp_stride;  // this team's staged samples, f16 hi
+    _Float16 *smpl = smph + d.smp_stride;                                                       //                             f16 lo
     _Float16 *colh = reinterpret_cast<_Float16 *>(smem + d.lds_colh) + team * CS * kColStride; // this team's columns, hi parts
     _Float16 *coll = reinterpret_cast<_Float16 *>(smem + d.lds_coll) + team * CS * kColStride; //                       lo parts
     const _Float16 *ocolh = reinterpret_cast<const _Float16 *>(smem + d.lds_colh) + (1 - team) * CS * kColStride;
@@ -231,7 +252,8 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
     for (int o = 0; o < 4; o++) c_b1[o] = (n_layers == 2 && o < n_out) ? d.b1[o] : 0.0f;
 
     // this lane's frame in the team's staged stream, and where k-step ks of lane group g4 starts inside it
-    const float *fptr = smp + fl * (d.hop + (SKEW ? d.skew : 0)) + (SKEW ? 0 : 8 * g4);
+    const int foff = fl * (d.hop + (SKEW ? d.skew : 0)) + (SKEW ? 0 : 8 * g4);
+    const _Float16 *fph = smph + foff, *fpl = smpl + foff;
     int ko[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ks++) ko[ks] = SKEW ? d.koff[ks * 4 + g4] : 32 * ks;   // immediates without skew
@@ -241,46 +263,75 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
     auto chunk_rsrc = [&](int k) {
         return tile_rsrc(row, (e_b + (int64_t)kChunk * k) * d.hop + d.gap, k < nchunks ? s_eff : 0, d.nsmp);
     };
-    // block-max partial of the quads in v[] -> red, quads -> this team's sample region
-    auto stage_chunk = [&]() {
+    // block-max partial of the quads in v[] (the next chunk of this team) -> red
+    auto max_partial = [&]() {
         float amax = 0.0f;
 #pragma unroll
         for (int k = 0; k < NL; k++)
             if (k < nload) {
                 const floatx4 q = as_floatx4(v[k]);
                 amax = absmax3(absmax3(amax, q[0], q[1]), q[2], q[3]);
-                const int i = 4 * (ttid + kTeam * k);
-                if (i < d.nsmp)
-                    *reinterpret_cast<floatx4 *>(smp + i + (SKEW ? d.skew * (int)__umulhi((unsigned)i, d.hop_magic) : 0)) = q;
             }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
         if (lane == 0) red[wave] = amax;
     };
+    // block floating point: the chunk's largest sample goes to [2^13, 2^14); returns the scale's exponent
+    auto chunk_scale = [&]() {
+        const float amax = fmaxf(fmaxf(red[4 * team], red[4 * team + 1]), fmaxf(red[4 * team + 2], red[4 * team + 3]));
+        int e = 13 - (int)((__float_as_uint(amax) >> 23) & 0xffu) + 127;
+        const int lim = power_mode ? 40 : 100;
+        e = amax > 0.0f ? (e < -lim ? -lim : (e > lim ? lim : e)) : 0;
+        return __builtin_amdgcn_readfirstlane(e);
+    };
+    // quads in v[] -> scaled, split into f16 hi + lo, -> this team's sample region
+    auto stage_chunk = [&](int e) {
+        const float sx = pow2f(e);
+#pragma unroll
+        for (int k = 0; k < NL; k++)
+            if (k < nload) {
+                const floatx4 q = as_floatx4(v[k]) * sx;
+                const int i = 4 * (ttid + kTeam * k);
+                if (k + 1 < nload || i < d.nsmp) {             // only the last quad set can reach past the chunk
+                    unsigned h0, l0, h1, l1;
+                    split_pair(q[0], q[1], h0, l0);
+                    split_pair(q[2], q[3], h1, l1);
+                    const int p = i + (SKEW ? d.skew * (int)__umulhi((unsigned)i, d.hop_magic) : 0);
+                    uint32x2 uh = {h0, h1}, ul = {l0, l1};
+                    *reinterpret_cast<uint32x2 *>(smph + p) = uh;
+                    *reinterpret_cast<uint32x2 *>(smpl + p) = ul;
+                }
+            }
+    };
+    int se_next;                      // scale exponent of the chunk staged most recently (this team's next front phase)
     {
         const __amdgpu_buffer_rsrc_t rs = chunk_rsrc(team);
 #pragma unroll
         for (int k = 0; k < NL; k++)
             if (k < nload) v[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * ttid + 16 * kTeam * k, 0, 0);
-        stage_chunk();                                         // chunk `team` staged before the first half-step
+        max_partial();
+        __syncthreads();
+        se_next = chunk_scale();
+        stage_chunk(se_next);                                  // chunk `team` staged before the first half-step
     }
     int se = 0, cse = 0;              // sample / column scale exponents of the chunk this team is working on
-    unsigned long long tsum[16] = {0}, tprev = 0;
-    if (STAMP) tprev = __builtin_amdgcn_s_memtime();
+    unsigned long long tsum[16] = {0}, tick[16] = {0}, tick0 = 0;
+    if (STAMP) tick0 = __builtin_amdgcn_s_memtime();
     __syncthreads();
 
     for (int hs = 0; hs <= nchunks; hs++) {
         if ((hs & 1) == team && hs < nchunks) {
             // =================================================== FRONT phase of chunk k
             const int k = hs;
-            SD_STAMP(8)
-            // ---- block floating point: the chunk's largest sample goes to [2^13, 2^14)
-            const float amax = fmaxf(fmaxf(red[4 * team], red[4 * team + 1]), fmaxf(red[4 * team + 2], red[4 * team + 3]));
-            se = 13 - (int)((__float_as_uint(amax) >> 23) & 0xffu) + 127;
-            const int lim = power_mode ? 40 : 100;
-            se = amax > 0.0f ? (se < -lim ? -lim : (se > lim ? lim : se)) : 0;
-            se = __builtin_amdgcn_readfirstlane(se);
-            const float sx = pow2f(se);
+            SD_STAMP(1)
+            se = se_next;                                         // scale of this chunk, fixed when it was staged
+            // ---- the chunk after next starts its way from HBM now; it is needed at the end of this phase
+            {
+                const __amdgpu_buffer_rsrc_t nrs = chunk_rsrc(k + 2);
+#pragma unroll
+                for (int q = 0; q < NL; q++)
+                    if (q < nload && !(kom & 4)) v[q] = __builtin_amdgcn_raw_buffer_load_b128(nrs, 16 * ttid + 16 * kTeam * q, 0, 0);
+            }
             // columns of this chunk and the T-1 carried ones share one scale: the smaller of the two chunks' sample
             // scales (the carried columns were stored at the neighbour's column scale and are rescaled below)
             const int se_other = cse_shared[2 + (1 - team)], cse_other = cse_shared[1 - team];
@@ -288,7 +339,7 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
             cse = __builtin_amdgcn_readfirstlane(cse);
             if (ttid == 0) { cse_shared[team] = cse; cse_shared[2 + team] = se; }
             // ---- the neighbour chunk's last T-1 columns move to the front of this team's buffer (rescaled to cse)
-            if (k > 0) {
+            if (k > 0 && !(kom & 32)) {
                 const int dexp = (cse - cse_other) * (power_mode ? 2 : 1);
                 const int words = (T - 1) * (kColStride / 2);      // 32-bit words per array
                 for (int i = ttid; i < 2 * words; i += kTeam) {
@@ -317,8 +368,6 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
             }
             // ---- the chunk after next is fetched during this chunk's matrix work, a load or two per k-step, so the
             // memory queue never backs up into the wave
-            const __amdgpu_buffer_rsrc_t nrs = chunk_rsrc(k + 2);
-            constexpr int kLoadsPerStep = (NL + KS - 1) / KS;
             SD_STAMP(2)
 
             // ---- band-limited DFT of this wave's 16 frames on the matrix cores: four 16-row tiles
@@ -326,59 +375,48 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
             // Software pipeline: while the MFMAs of k-step ks execute, the lane's next 8 samples (already in
             // registers) are scaled and split into f16 hi/lo and the fragments after that are fetched.
             floatx4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-            floatx4 s0 = *reinterpret_cast<const floatx4 *>(fptr + ko[0]);
-            floatx4 s1 = *reinterpret_cast<const floatx4 *>(fptr + ko[0] + 4);
-            half8 bh, bl;
-            split8(s0 * sx, s1 * sx, bh, bl);
-            if (KS > 1) {
-                s0 = *reinterpret_cast<const floatx4 *>(fptr + ko[1]);
-                s1 = *reinterpret_cast<const floatx4 *>(fptr + ko[1] + 4);
-            }
+            half8 bh = lds_half8(fph + ko[0]), bl = lds_half8(fpl + ko[0]);
             uint32x4 a[8];
 #pragma unroll
             for (int i = 0; i < 8; i++) a[i] = lds_dfrag[i * 64 + lane];
             __builtin_amdgcn_sched_barrier(0);                    // the prologue's fetches stay out of the loop's groups
 #pragma unroll
-            for (int ks = 0; ks < KS; ks++) {
+            for (int ks = 0; ks < ((kom & 256) ? 0 : KS); ks++) {
                 half8 ah[4], al[4];
 #pragma unroll
                 for (int m = 0; m < 4; m++) { ah[m] = as_half8(a[2 * m]); al[m] = as_half8(a[2 * m + 1]); }
                 const half8 cbh = bh, cbl = bl;
-                const floatx4 n0 = s0, n1 = s1;
                 if (ks + 1 < KS) {                                // fragments of the next k-step
 #pragma unroll
-                    for (int i = 0; i < 8; i++) a[i] = lds_dfrag[((ks + 1) * 8 + i) * 64 + lane];
+                    for (int i = 0; i < 8; i++)
+                        if (!(kom & 512) || ((ks + 1) & 3) == 0) a[i] = lds_dfrag[((ks + 1) * 8 + i) * 64 + lane];
+                    if (!(kom & 1024)) {
+                        bh = lds_half8(fph + ko[ks + 1]);
+                        bl = lds_half8(fpl + ko[ks + 1]);
+                    }
                 }
-                if (ks + 2 < KS) {                                // raw samples two k-steps ahead
-                    s0 = *reinterpret_cast<const floatx4 *>(fptr + ko[ks + 2]);
-                    s1 = *reinterpret_cast<const floatx4 *>(fptr + ko[ks + 2] + 4);
-                }
-#pragma unroll
-                for (int j = 0; j < kLoadsPerStep; j++) {         // quads ks*kLoadsPerStep + j of chunk k+2
-                    const int q = ks * kLoadsPerStep + j;
-                    if (q < NL && q < nload) v[q] = __builtin_amdgcn_raw_buffer_load_b128(nrs, 16 * ttid + 16 * kTeam * q, 0, 0);
-                }
+                if (!(kom & 1)) {
 #pragma unroll
                 for (int m = 0; m < 4; m++) acc[m] = mfma(ah[m], cbh, acc[m]);
 #pragma unroll
                 for (int m = 0; m < 4; m++) acc[m] = mfma(ah[m], cbl, acc[m]);
 #pragma unroll
                 for (int m = 0; m < 4; m++) acc[m] = mfma(al[m], cbh, acc[m]);
-                if (ks + 1 < KS) split8(n0 * sx, n1 * sx, bh, bl);   // 32 VALU, scheduled between the MFMAs below
-                // schedule: this k-step's 10 LDS fetches first (their data is used one and two k-steps later),
-                // then each MFMA followed by 3 of the split's VALU instructions
-                __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);      // 10 DS reads
+                } else {
 #pragma unroll
-                for (int i = 0; i < 12; i++) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);   // 3 VALU
+                for (int m = 0; m < 4; m++) asm volatile("" ::"v"(ah[m]), "v"(al[m]));
+                asm volatile("" ::"v"(cbh), "v"(cbl));
                 }
+                // schedule: this k-step's LDS fetches first (their data is used one k-step later), then the MFMAs
+                if (!(kom & (512 | 1024))) __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);      // 8 + 4 DS reads
+                __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);      // 12 MFMA
             }
-            SD_STAMP(4)
+            SD_STAMP(3)
 
             // ---- magnitude (zvabs/2 :329-333 or zvmags/4 :270-274), scaling (SyllableDetector.swift:184-212),
             // statistic, f16 split, column -> LDS.  Result layout: column = frame f, register j of lane group g4 in
             // tile m = basis row 16m + 4*g4 + j; this lane holds bins 4*g4 + j (i = j) and 16 + 4*g4 + j (i = 4 + j).
+            if (!(kom & 64)) {
             const float inv = pow2f(-se - 13);                   // accumulators hold X * sx * 2^13
             // column scale (power of two; col_shift from the basis' largest row sum): |X| * 2^(cse - shift) < 2^13,
             // |X|^2 * 2^(2 (cse - shift)) < 2^13 with its own shift; log/dB columns are stored unscaled
@@ -458,36 +496,46 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
                     *reinterpret_cast<uint32x2 *>(pl + 16 * m) = ul;
                 }
             }
+            } else if (acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] == 12345.0f) colh[lane] = (_Float16)1.0f;
+            SD_STAMP(4)
+            // block-max partial of the chunk fetched during this phase (staged, scaled, in the back phase)
+            if (k + 2 < nchunks) max_partial();
             SD_STAMP(5)
         } else if ((hs & 1) != team && hs >= 1) {
             // =================================================== BACK phase of chunk k = hs - 1
             const int k = hs - 1;
-            SD_STAMP(9)
+            SD_STAMP(6)
             // ---- samples of chunk k+2 (fetched during the front phase) -> block-max partial + LDS
-            if (k + 2 < nchunks) stage_chunk();
-            SD_STAMP(0)
+            if (k + 2 < nchunks) {
+                se_next = chunk_scale();
+                if (!(kom & 2)) stage_chunk(se_next);
+            }
+            SD_STAMP(7)
             // ---- first layer as a shifted GEMM + the rest of the network in registers.
             // This wave finishes evaluation slots 16*tw .. +15 of the chunk (slot q: e = e_b + 64k - (T-1) + q, columns
             // q .. q+T-1): result column = f, rows 4*g4 + j = hidden unit (row H = window sum of squares).
             const float cs = scaling != 0 ? 1.0f : (power_mode ? pow2f(2 * (cse - d.col_shift)) : pow2f(cse - d.col_shift));
             const float zs = d.w_unscale / cs;                    // first-layer sums back to true units
             floatx4 z = {0.0f, 0.0f, 0.0f, 0.0f}, z2 = {0.0f, 0.0f, 0.0f, 0.0f};
-            {
+            if (!(kom & 16)) {
                 const _Float16 *bph = colh + fl * kColStride + 8 * g4, *bpl = coll + fl * kColStride + 8 * g4;
-                uint32x4 fh0 = *reinterpret_cast<const uint32x4 *>(bph), fl0 = *reinterpret_cast<const uint32x4 *>(bpl);
-                uint32x4 fh1 = fh0, fl1 = fl0;
-                if (T > 1) {
-                    fh1 = *reinterpret_cast<const uint32x4 *>(bph + kColStride);
-                    fl1 = *reinterpret_cast<const uint32x4 *>(bpl + kColStride);
-                }
+                // column fragments are fetched kAhead taps ahead of the MFMAs that use them (LDS latency under
+                // load is several MFMA times); the registers are the ones the DFT's fragments occupy in the front phase
+                constexpr int kAhead = 5;
+                uint32x4 bh_q[kAhead], bl_q[kAhead];
+#pragma unroll
+                for (int t = 0; t < kAhead; t++)
+                    if (t < T) {
+                        bh_q[t] = *reinterpret_cast<const uint32x4 *>(bph + t * kColStride);
+                        bl_q[t] = *reinterpret_cast<const uint32x4 *>(bpl + t * kColStride);
+                    }
 #pragma unroll
                 for (int t = 0; t < TMAX; t++) {
                     if (t < T) {
-                        const half8 h0 = as_half8(fh0), l0 = as_half8(fl0);
-                        fh0 = fh1; fl0 = fl1;
-                        if (t + 2 < T) {
-                            fh1 = *reinterpret_cast<const uint32x4 *>(bph + (t + 2) * kColStride);
-                            fl1 = *reinterpret_cast<const uint32x4 *>(bpl + (t + 2) * kColStride);
+                        const half8 h0 = as_half8(bh_q[t % kAhead]), l0 = as_half8(bl_q[t % kAhead]);
+                        if (t + kAhead < T) {
+                            bh_q[t % kAhead] = *reinterpret_cast<const uint32x4 *>(bph + (t + kAhead) * kColStride);
+                            bl_q[t % kAhead] = *reinterpret_cast<const uint32x4 *>(bpl + (t + kAhead) * kColStride);
                         }
                         z = mfma(afr[t][0], h0, z);               // two accumulation chains: hi*hi on one,
                         z2 = mfma(afr[t][0], l0, z2);             // the cross terms on the other
@@ -496,7 +544,8 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
                 }
                 z += z2;
             }
-            SD_STAMP(12)
+            SD_STAMP(8)
+            if (!(kom & 128)) {
             const int64_t e = e_b + (int64_t)kChunk * k - (T - 1) + fl;
             const bool valid = e >= e_b && e < e_e;
             float alpha = zs, beta = 0.0f;                    // layer-0 input = alpha * z + beta * rvec + bias0
@@ -526,7 +575,7 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
 #pragma unroll
             for (int j = 0; j < 4; j++)
                 act[j] = (4 * g4 + j) < H ? transfer_fn(tf0, fmaf(alpha, z[j], fmaf(beta, c_rv[j], c_b0[j]))) : 0.0f;
-            SD_STAMP(14)
+            SD_STAMP(9)
             const double *thr = reinterpret_cast<const double *>(cst + kCstThr);
             bool hit = false;
             if (n_layers == 2) {
@@ -551,7 +600,7 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
                         if (o == 0 || d.rule == 1) hit = hit || ((double)y >= thr[o]);
                     }
                 }
-                if (valid && g4 == 0) {
+                if (valid && g4 == 0 && !(kom & 8)) {
                     if (outputs) {
 #pragma unroll
                         for (int o = 0; o < 4; o++)
@@ -578,22 +627,24 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
                 anyhit |= __shfl_xor(anyhit, 32, 64);
                 if (valid && g4 == 0 && flags) flags[(int64_t)c * E + e] = anyhit ? 1 : 0;
             }
-            SD_STAMP(7)
+            } else if (z[0] + z[1] == 12345.0f && flags) flags[0] = 1;
+            SD_STAMP(10)
         }
-        SD_STAMP(13)
+        SD_STAMP(11)
         __syncthreads();                                      // one barrier per half-step
-        SD_STAMP(6)
+        SD_STAMP(12)
+        SD_STAMP_FLUSH()
     }
     if (STAMP && (tid == 0 || tid == kTeam) && d.stamps)
         for (int i = 0; i < 16; i++)
             atomicAdd(&d.stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + i], tsum[i] / 2);
 }
 
-template <int KS, int TMAX, int NL, bool EXACT, bool SKEW, bool LEAN = false, bool STAMP = false>
+template <int KS, int TMAX, int NL, bool EXACT, bool SKEW, bool LEAN = false, bool STAMP = false, int KNOCK = 0>
 hipError_t launch_one(const FusedDesc &d, const float *samples, int64_t stride, int C, int64_t s_eff, int64_t E,
                       float *outputs, uint8_t *flags, hipStream_t stream)
 {
-    auto kern = fused_kernel<KS, TMAX, NL, EXACT, SKEW, LEAN, STAMP>;
+    auto kern = fused_kernel<KS, TMAX, NL, EXACT, SKEW, LEAN, STAMP, KNOCK>;
     hipError_t st = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, d.lds_total);
     if (st != hipSuccess) return st;
     const int64_t segs = (E + d.seg_evals - 1) / d.seg_evals;
@@ -617,6 +668,10 @@ hipError_t launch_fused(const FusedDesc &d, const float *samples, int64_t stride
     // the reference's example shape (W = 256, hop 132, timeRange 10) gets an instantiation with exact sizes
     if (d.KS == 8 && d.T == 10 && d.nload == 9 && !skew) {
         const bool lean = d.norm == 1 && d.scaling == 0 && d.power_mode == 0 && d.n_layers == 2 && d.tf0 == 0 && d.n_out == 1 && d.H <= 4;
+#ifdef SYLDET_KNOCKOUTS
+#define SD_KO_CASE(m) case m: return launch_one<8, 10, 9, true, false, true, false, m>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
+        if (lean) switch (d.ko) { SD_KO_CASE(1) SD_KO_CASE(2) SD_KO_CASE(4) SD_KO_CASE(8) SD_KO_CASE(16) SD_KO_CASE(32) SD_KO_CASE(64) SD_KO_CASE(128) SD_KO_CASE(144) SD_KO_CASE(255) SD_KO_CASE(256) SD_KO_CASE(511) SD_KO_CASE(254) SD_KO_CASE(250) SD_KO_CASE(507) SD_KO_CASE(512) SD_KO_CASE(766) SD_KO_CASE(1024) SD_KO_CASE(1278) default: break; }
+#endif
         if (lean && d.stamps) return launch_one<8, 10, 9, true, false, true, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
         if (lean) return launch_one<8, 10, 9, true, false, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
         return launch_one<8, 10, 9, true, false>(d, samples, stride, C, s_eff, E, outputs, flags, stream);

@@ -275,6 +275,9 @@ int run_on_stream(syldet *h, const float *d_samples, int64_t S, int64_t stride, 
         FusedDesc d = h->fused.desc;
         fused_segmentation(d, E, C);
         d.stamps = nullptr;
+        // diagnostic only: SYLDET_FUSED_KO=<mask> runs an instantiation with parts of the kernel knocked out
+        static const int want_ko = std::getenv("SYLDET_FUSED_KO") ? std::atoi(std::getenv("SYLDET_FUSED_KO")) : 0;
+        d.ko = want_ko;
         // diagnostic only: SYLDET_FUSED_STAMPS=1 runs the stamped instantiation and prints where a
         // workgroup pass spends its cycles (never set in tests or the benchmark)
         static const bool want_stamps = std::getenv("SYLDET_FUSED_STAMPS") != nullptr;
@@ -283,7 +286,10 @@ int run_on_stream(syldet *h, const float *d_samples, int64_t S, int64_t stride, 
             if (int st = h->d_stamps.reserve(n * sizeof(unsigned long long))) return st;
             SYLDET_HIP(hipMemsetAsync(h->d_stamps.ptr, 0, n * sizeof(unsigned long long), stream));
             d.stamps = (unsigned long long *)h->d_stamps.ptr;
-            SYLDET_HIP(launch_fused(d, d_samples, stride, C, S, J, E, d_outputs, d_flags, stream));
+            {
+                KernelTimer t(h, stream, "fused_kernel");
+                SYLDET_HIP(launch_fused(d, d_samples, stride, C, S, J, E, d_outputs, d_flags, stream));
+            }
             std::vector<unsigned long long> host(n);
             SYLDET_HIP(hipMemcpyAsync(host.data(), h->d_stamps.ptr, n * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
             SYLDET_HIP(hipStreamSynchronize(stream));
@@ -291,9 +297,9 @@ int run_on_stream(syldet *h, const float *d_samples, int64_t S, int64_t stride, 
             for (size_t i = 0; i < n; i++) sum[i % 16] += (double)host[i];
             double tot = 0;
             for (double v : sum) tot += v;
-            static const char *names[16] = {"back: stage next chunk", "-", "front: scale+carry", "-", "front: DFT MFMA loop",
-                                            "front: mag+columns", "barrier wait", "back: layer1+out+stores", "front: entry", "back: entry (vmcnt)",
-                                            "-", "-", "back: layer-0 GEMM", "idle tail before barrier", "back: alpha+transfer", "-"};
+            static const char *names[16] = {"-", "front: entry (scales, issue loads)", "front: carry columns", "front: DFT MFMA loop", "front: mag+columns",
+                                            "front: block-max partial (vmcnt)", "back: entry", "back: stage next chunk", "back: layer-0 GEMM",
+                                            "back: alpha+transfer", "back: layer1+out+stores", "idle tail before barrier", "barrier", "-", "-", "-"};
             std::fprintf(stderr, "[syldet stamps] runs=%d workgroups=%zu cycles/pass=%.0f\n", d.runs, n / 16, tot / ((double)(n / 16) * d.runs));
             for (int i = 0; i < 16; i++)
                 if (sum[i] > 0) std::fprintf(stderr, "   %-32s %6.0f cycles/pass  %5.1f %%\n", names[i], sum[i] / ((double)(n / 16) * d.runs), 100.0 * sum[i] / tot);

@@ -1,0 +1,90 @@
+// Calibration microbenchmarks for gfx950 (diagnostic, not part of the product):
+//   mfma:   back-to-back v_mfma_f32_16x16x32_f16 with 4 independent accumulators, W waves per CU
+//   lds:    ds_read_b128 streaming from a 64 KB table, W waves per CU
+//   both:   the fused kernel's k-step shape: 8 b128 + 4 b64 reads, 12 MFMAs
+// prints cycles (s_memtime) and wall-clock per inner iteration.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef unsigned int uint32x4 __attribute__((ext_vector_type(4)));
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+template <int MODE>
+__global__ void __launch_bounds__(512) k(int iters, unsigned long long *cyc, float *sink)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32x4 *tab = reinterpret_cast<uint32x4 *>(smem);
+    const int lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < 4096; i += blockDim.x) tab[i] = uint32x4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+    __syncthreads();
+    floatx4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    uint32x4 a[8];
+    for (int i = 0; i < 8; i++) a[i] = tab[i * 64 + lane];
+    uint32x4 b0 = tab[lane], b1 = tab[64 + lane];
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; it++) {
+        union { uint32x4 u; half8 h; } A[8], B0, B1;
+        for (int i = 0; i < 8; i++) A[i].u = a[i];
+        B0.u = b0; B1.u = b1;
+        if (MODE != 0) {   // lds or both: fetch the next fragments
+            const int ks = (it + 1) & 7;
+#pragma unroll
+            for (int i = 0; i < 8; i++) a[i] = tab[(ks * 8 + i) * 64 + lane];
+            b0 = tab[(ks * 8) * 64 + ((lane * 5) & 63)];
+            b1 = tab[(ks * 8 + 1) * 64 + ((lane * 5) & 63)];
+        }
+        if (MODE != 1) {   // mfma or both
+#pragma unroll
+            for (int m = 0; m < 4; m++) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[2 * m].h, B0.h, acc[m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < 4; m++) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[2 * m].h, B1.h, acc[m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < 4; m++) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[2 * m + 1].h, B0.h, acc[m], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; i++) asm volatile("" ::"v"(A[i].u));
+            asm volatile("" ::"v"(B0.u), "v"(B1.u));
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (lane == 0) cyc[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
+    float s = 0;
+    for (int m = 0; m < 4; m++) s += acc[m][0] + acc[m][1] + acc[m][2] + acc[m][3];
+    for (int i = 0; i < 8; i++) s += (float)a[i][0];
+    if (s == 12345.678f) sink[0] = s;
+}
+
+template <int MODE>
+void run(const char *name, int waves, int iters)
+{
+    unsigned long long *cyc; float *sink;
+    const int blocks = 256;
+    CK(hipMalloc(&cyc, blocks * 16 * sizeof(unsigned long long)));
+    CK(hipMalloc(&sink, 4));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipFuncSetAttribute((const void *)k<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    for (int rep = 0; rep < 2; rep++) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(64 * waves), 150 * 1024, 0, iters, cyc, sink);   // 150 KB LDS: one block per CU
+        CK(hipEventRecord(e1));
+        CK(hipDeviceSynchronize());
+    }
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    std::vector<unsigned long long> h(blocks * waves);
+    CK(hipMemcpy(h.data(), cyc, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    double avg = 0; for (auto v : h) avg += (double)v; avg /= h.size();
+    printf("%-5s waves/CU=%2d  memtime ticks/iter=%8.1f   wall ns/iter=%8.2f   (ticks/us=%.1f)\n", name, waves, avg / iters, ms * 1e6 / iters, avg / (ms * 1e3));
+    CK(hipFree(cyc)); CK(hipFree(sink));
+}
+
+int main()
+{
+    const int iters = 20000;
+    for (int w : {4, 8}) run<0>("mfma", w, iters);
+    for (int w : {4, 8}) run<1>("lds", w, iters);
+    for (int w : {4, 8}) run<2>("both", w, iters);
+    return 0;
+}
