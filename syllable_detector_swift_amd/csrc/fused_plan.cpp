@@ -116,9 +116,8 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
 
     // ---- geometry of a pass
     const int hop = g.hop;
-    const int team = kFusedBlock / 2;             // threads per team
-    const int nsmp = (kFusedChunkFrames - 1) * hop + KS * 32;   // samples one chunk's frames read
-    const int nload = (nsmp / 4 + team - 1) / team;
+    const int nsmp = (kFusedTileFrames - 1) * hop + KS * 32;    // samples one pass's frames read
+    const int nload = (nsmp / 4 + kFusedBlock - 1) / kFusedBlock;
     if (nload > kFusedMaxLoads) return no("hop too large for the staging registers");
     // LDS bank spreading: a lane reads 8 consecutive f16 samples of its frame with two ds_read_b64; the 16
     // frames of a tile are hop/2 dwords apart, which spreads over the 64 banks unless hop is a multiple of 16
@@ -127,7 +126,7 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
     const int skew = (hop % 16 == 0) ? 4 : 0;
     auto skewed = [&](int i) { return i + skew * (i / hop); };
     const int nsmp_p = (skewed(nsmp + 16) + 15) / 8 * 8;
-    const int PS = kFusedChunkFrames + T - 1;
+    const int PS = kFusedTileFrames + T - 1;
 
     FusedDesc &d = p.desc;
     d.W = W; d.KS = KS; d.hop = hop; d.gap = g.gap; d.F = F; d.T = T; d.H = H; d.norm = norm;
@@ -148,10 +147,10 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
     int off = 0;
     auto take = [&off](int bytes) { const int o = off; off += (bytes + 15) / 16 * 16; return o; };
     d.lds_dfrag = take(KS * 8 * 1024);
-    d.lds_smp = take(2 * 2 * nsmp_p * 2);            // staged samples, f16 hi + lo, one region pair per team
-    d.lds_colh = take(2 * PS * kFusedColStride * 2); // |X| columns, f16 hi, one buffer per team
-    d.lds_coll = take(2 * PS * kFusedColStride * 2); //              f16 lo
-    d.lds_stat = take(2 * 2 * PS * 4);
+    d.lds_smp = take(2 * nsmp_p * 2);                // staged samples of one pass, f16 hi + lo
+    d.lds_colh = take(PS * kFusedColStride * 2);     // |X| columns, f16 hi
+    d.lds_coll = take(PS * kFusedColStride * 2);     //              f16 lo
+    d.lds_stat = take(2 * PS * 4);
     d.lds_red = take(64);
     d.lds_cst = take((32 + kMaxFns * 33) * 4);       // thresholds + output maps (kCst* in kernels_fused.hip)
     d.lds_total = off;

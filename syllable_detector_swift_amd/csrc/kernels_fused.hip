@@ -49,8 +49,7 @@ typedef unsigned int uint32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kBlock = kFusedBlock;            // 512 threads = 8 waves
 constexpr int kWaves = kBlock / 64;
-constexpr int kTeam = kBlock / 2;              // 256 threads = 4 waves per team
-constexpr int kChunk = kFusedChunkFrames;      // 64 frames per team chunk = 16 per wave
+constexpr int kPass = kFusedTileFrames;        // 128 frames per pass = 16 per wave
 constexpr int kColStride = kFusedColStride;
 // layout of the constant block in LDS (floats)
 constexpr int kCstThr = 0 /* 16 doubles */, kCstOut = 32;
@@ -60,12 +59,6 @@ __device__ __forceinline__ half8 as_half8(uint32x4 v)
     union { uint32x4 u; half8 h; } c;
     c.u = v;
     return c.h;
-}
-__device__ __forceinline__ uint32x4 as_u4(half8 v)
-{
-    union { uint32x4 u; half8 h; } c;
-    c.h = v;
-    return c.u;
 }
 __device__ __forceinline__ floatx4 as_floatx4(uint32x4 v)
 {
@@ -86,18 +79,6 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned &hi, unsig
     cl.h = __builtin_amdgcn_cvt_pkrtz(a - ah, b - bh);
     hi = ch.u;
     lo = cl.u;
-}
-
-__device__ __forceinline__ void split8(floatx4 lo4, floatx4 hi4, half8 &h, half8 &l)
-{
-    uint32x4 uh, ul;
-    unsigned a, b;
-    split_pair(lo4[0], lo4[1], a, b); uh[0] = a; ul[0] = b;
-    split_pair(lo4[2], lo4[3], a, b); uh[1] = a; ul[1] = b;
-    split_pair(hi4[0], hi4[1], a, b); uh[2] = a; ul[2] = b;
-    split_pair(hi4[2], hi4[3], a, b); uh[3] = a; ul[3] = b;
-    h = as_half8(uh);
-    l = as_half8(ul);
 }
 
 __device__ __forceinline__ float pow2f(int e)   // 2^e for e in [-126, 127]
@@ -153,38 +134,47 @@ __device__ __forceinline__ floatx4 mfma(half8 a, half8 b, floatx4 c)
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 
-// Diagnostic stamps (STAMP instantiation only; never the shipped path): s_memtime at phase
-// boundaries, summed per workgroup by thread 0 and stored to d.stamps[workgroup][phase].
-#define SD_STAMP(slot)                                                                     \
+// x*sx -> f16 hi (round to nearest) and f16 lo = the exact remainder x*sx - hi rounded to f16, for two
+// values at once (packed words): hi + lo == x*sx to 2^-22 relative.  v_fma_mix computes in fp32 from
+// mixed-width sources and writes one half of the destination, so a pair costs 4 VALU instructions
+// and the scaling rides along for free.
+__device__ __forceinline__ void split_pair_scaled(float a, float b, float sx, unsigned &hi, unsigned &lo)
+{
+    unsigned h, l;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(a), "v"(sx));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(b), "v"(sx));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(a), "v"(sx), "v"(h));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(b), "v"(sx), "v"(h));
+    hi = h;
+    lo = l;
+}
+
+// Diagnostic stamps (STAMP instantiation only; never the shipped path): s_memtime at phase boundaries,
+// read back (one wait) at the end of the pass so the stamps do not drain the memory pipelines in between.
+#define SD_TICK(slot)                                                                      \
     if (STAMP) {                                                                           \
         __builtin_amdgcn_sched_barrier(0);                                                 \
-        tick[slot] = __builtin_amdgcn_s_memtime();  /* no wait here: read at the phase's end */ \
+        tick[slot] = __builtin_amdgcn_s_memtime();                                         \
         __builtin_amdgcn_sched_barrier(0);                                                 \
-    }
-// phase end: the ticks taken since SD_STAMP_BEGIN become per-slot cycle sums
-#define SD_STAMP_FLUSH()                                                                   \
-    if (STAMP) {                                                                           \
-        unsigned long long prev = tick0;                                                   \
-        for (int i_ = 0; i_ < 16; i_++)                                                    \
-            if (tick[i_] != 0) { tsum[i_] += tick[i_] - prev; prev = tick[i_]; tick[i_] = 0; } \
-        tick0 = prev;                                                                      \
     }
 
 // KS: k-steps of 32 samples; TMAX / NL: array sizes for taps and staging quads; EXACT: timeRange == TMAX
 // and nload == NL are compile-time facts (no guards); SKEW: staged samples carry bank-spreading padding;
 // LEAN: the configuration class of the reference's example detector is a compile-time fact --
 // l2normalize first, linear |X| columns, two layers, TanSig hidden units (at most 4), one output --
-// so that instantiation carries only the code it runs.
+// so that instantiation carries only the code it runs.  KNOCK: diagnostic knock-out mask (0 in every
+// shipped instantiation).
 //
-// Two-team pipeline.  Waves 0-3 (team 0) and 4-7 (team 1) own alternate 64-frame chunks of the
-// workgroup's segment and run half a period apart; each SIMD hosts one wave of each team.  In one
-// half-step (one workgroup barrier) a team is either in its FRONT phase on chunk k
-//     scale <- block max of the staged samples; carry the neighbour chunk's last T-1 columns over;
-//     DFT of its 4 x 16 frames on the matrix cores; magnitudes -> column buffer (LDS)
-// or in its BACK phase on the chunk it fronted one half-step earlier
-//     next chunk's prefetched samples -> block max partials + LDS; first layer as a shifted GEMM over its
-//     column buffer; rest of the network in registers; results -> HBM
-// so matrix-heavy and VALU/latency-heavy work of different waves overlap on every SIMD.
+// One pass = 128 frames = 16 per wave, all eight waves in the same phase (two per SIMD: while one waits for
+// LDS the other feeds the matrix pipe -- a single wave cannot, its LDS fetch rate is capped at ~32 B/clk):
+//     [carry the last T-1 columns of the previous pass to the front of the column buffer]
+//     DFT of the wave's 16 frames from the staged samples (f16 hi + lo, block floating point)
+//     magnitudes -> column buffer;  block-max partial of the NEXT pass's samples (already in registers)
+//   barrier
+//     next pass's samples: scale, split, -> LDS (the staged region is free now);  issue the loads of the
+//     pass after that (a whole pass of lead time)
+//     first layer as a shifted GEMM over the column buffer, rest of the network in registers, stores
+//   barrier
 template <int KS, int TMAX, int NL, bool EXACT, bool SKEW, bool LEAN, bool STAMP, int KNOCK>
 __global__ void __launch_bounds__(kBlock, 2)
 fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t stride, int64_t s_eff, int64_t E,
@@ -192,15 +182,13 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32x4 *lds_dfrag = reinterpret_cast<uint32x4 *>(smem + d.lds_dfrag);
-    float *red = reinterpret_cast<float *>(smem + d.lds_red);        // [2 teams][4 waves] block-max partials, then [2] column scale exponents
-    int *cse_shared = reinterpret_cast<int *>(red + 8);
+    float *red = reinterpret_cast<float *>(smem + d.lds_red);        // [8 waves] block-max partials
     float *cst = reinterpret_cast<float *>(smem + d.lds_cst);
+    constexpr int kom = KNOCK;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int team = wave >> 2, tw = wave & 3;      // team, wave inside the team
-    const int ttid = tid & (kTeam - 1);             // thread inside the team
     const int f = lane & 15;          // frame (DFT) / evaluation (first layer) column inside the wave's tile
     const int g4 = lane >> 4;         // k block 8*g4..8*g4+7 of an operand; rows 4*g4..4*g4+3 of a result
     const int c = blockIdx.y;
@@ -208,22 +196,18 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
     if (e_b >= E) return;
     const int64_t e_e = (e_b + d.seg_evals < E) ? e_b + d.seg_evals : E;
     const float *row = samples + (int64_t)c * stride;
-    const int CS = d.ps, T = EXACT ? TMAX : d.T, H = d.H;      // CS: column slots per team buffer = 64 + T - 1
+    const int PS = d.ps, T = EXACT ? TMAX : d.T, H = d.H;      // PS: column slots = 128 + T - 1
     const int nload = EXACT ? NL : d.nload;
     const int norm = LEAN ? 1 : d.norm, scaling = LEAN ? 0 : d.scaling, power_mode = LEAN ? 0 : d.power_mode;
     const int n_layers = LEAN ? 2 : d.n_layers, n_out = LEAN ? 1 : d.n_out, tf0 = LEAN ? 0 : d.tf0;
-    const int fl = 16 * tw + f;       // this lane's frame / evaluation slot inside the team's chunk
-    const int nchunks = 2 * d.runs;
-    constexpr int kom = KNOCK;   // diagnostic knock-outs (stamped instantiation only; results are then wrong)
+    const int fl = 16 * wave + f;     // this lane's frame / evaluation slot inside the pass
+    const int runs = d.runs;
 
-    _Float16 *smph = reinterpret_cast<_Float16 *>(smem + d.lds_smp) + team * 2 * d.smp_stride;  // this team's staged samples, f16 hi
-    _Float16 *smpl = smph + d.smp_stride;                                                       //                             f16 lo
-    _Float16 *colh = reinterpret_cast<_Float16 *>(smem + d.lds_colh) + team * CS * kColStride; // this team's columns, hi parts
-    _Float16 *coll = reinterpret_cast<_Float16 *>(smem + d.lds_coll) + team * CS * kColStride; //                       lo parts
-    const _Float16 *ocolh = reinterpret_cast<const _Float16 *>(smem + d.lds_colh) + (1 - team) * CS * kColStride;
-    const _Float16 *ocoll = reinterpret_cast<const _Float16 *>(smem + d.lds_coll) + (1 - team) * CS * kColStride;
-    float *stat = reinterpret_cast<float *>(smem + d.lds_stat) + team * 2 * CS;               // [2][CS] per-frame min/max or mean/M2
-    const float *ostat = reinterpret_cast<const float *>(smem + d.lds_stat) + (1 - team) * 2 * CS;
+    _Float16 *smph = reinterpret_cast<_Float16 *>(smem + d.lds_smp);    // staged samples of one pass, f16 hi
+    _Float16 *smpl = smph + d.smp_stride;                                //                             f16 lo
+    _Float16 *colh = reinterpret_cast<_Float16 *>(smem + d.lds_colh);   // [PS][kColStride] |X| columns, hi parts
+    _Float16 *coll = reinterpret_cast<_Float16 *>(smem + d.lds_coll);   //                               lo parts
+    float *stat = reinterpret_cast<float *>(smem + d.lds_stat);          // [2][PS] per-frame min/max or mean/M2
 
     // ---- once per workgroup: constants
     for (int i = tid; i < KS * 8 * 64; i += kBlock) lds_dfrag[i] = reinterpret_cast<const uint32x4 *>(d.dfrag)[i];
@@ -251,19 +235,25 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
 #pragma unroll
     for (int o = 0; o < 4; o++) c_b1[o] = (n_layers == 2 && o < n_out) ? d.b1[o] : 0.0f;
 
-    // this lane's frame in the team's staged stream, and where k-step ks of lane group g4 starts inside it
+    // this lane's frame in the staged stream, and where k-step ks of lane group g4 starts inside it
     const int foff = fl * (d.hop + (SKEW ? d.skew : 0)) + (SKEW ? 0 : 8 * g4);
     const _Float16 *fph = smph + foff, *fpl = smpl + foff;
     int ko[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ks++) ko[ks] = SKEW ? d.koff[ks * 4 + g4] : 32 * ks;   // immediates without skew
 
-    // raw samples of one chunk: quads 4*(ttid + 256 k), k < nload, through a bounds-checked descriptor
+    // raw samples of one pass: quads 4*(tid + 512 k), k < nload, through a bounds-checked descriptor
     uint32x4 v[NL];
-    auto chunk_rsrc = [&](int k) {
-        return tile_rsrc(row, (e_b + (int64_t)kChunk * k) * d.hop + d.gap, k < nchunks ? s_eff : 0, d.nsmp);
+    auto pass_rsrc = [&](int p) {
+        return tile_rsrc(row, (e_b + (int64_t)kPass * p) * d.hop + d.gap, p < runs ? s_eff : 0, d.nsmp);
     };
-    // block-max partial of the quads in v[] (the next chunk of this team) -> red
+    auto load_pass = [&](int p) {
+        const __amdgpu_buffer_rsrc_t rs = pass_rsrc(p);
+#pragma unroll
+        for (int k = 0; k < NL; k++)
+            if (k < nload && !(kom & 4)) v[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * tid + 16 * kBlock * k, 0, 0);
+    };
+    // block-max partial of the quads in v[] -> red
     auto max_partial = [&]() {
         float amax = 0.0f;
 #pragma unroll
@@ -276,26 +266,27 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
         for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
         if (lane == 0) red[wave] = amax;
     };
-    // block floating point: the chunk's largest sample goes to [2^13, 2^14); returns the scale's exponent
-    auto chunk_scale = [&]() {
-        const float amax = fmaxf(fmaxf(red[4 * team], red[4 * team + 1]), fmaxf(red[4 * team + 2], red[4 * team + 3]));
+    // block floating point: the pass's largest sample goes to [2^13, 2^14); returns the scale's exponent
+    auto pass_scale = [&]() {
+        const floatx4 r0 = *reinterpret_cast<const floatx4 *>(red), r1 = *reinterpret_cast<const floatx4 *>(red + 4);
+        const float amax = fmaxf(fmaxf(fmaxf(r0[0], r0[1]), fmaxf(r0[2], r0[3])), fmaxf(fmaxf(r1[0], r1[1]), fmaxf(r1[2], r1[3])));
         int e = 13 - (int)((__float_as_uint(amax) >> 23) & 0xffu) + 127;
         const int lim = power_mode ? 40 : 100;
         e = amax > 0.0f ? (e < -lim ? -lim : (e > lim ? lim : e)) : 0;
         return __builtin_amdgcn_readfirstlane(e);
     };
-    // quads in v[] -> scaled, split into f16 hi + lo, -> this team's sample region
-    auto stage_chunk = [&](int e) {
+    // quads in v[] -> scaled, split into f16 hi + lo, -> the staged region
+    auto stage_pass = [&](int e) {
         const float sx = pow2f(e);
 #pragma unroll
         for (int k = 0; k < NL; k++)
-            if (k < nload) {
-                const floatx4 q = as_floatx4(v[k]) * sx;
-                const int i = 4 * (ttid + kTeam * k);
-                if (k + 1 < nload || i < d.nsmp) {             // only the last quad set can reach past the chunk
+            if (k < nload && !(kom & 2)) {
+                const floatx4 q = as_floatx4(v[k]);
+                const int i = 4 * (tid + kBlock * k);
+                if (k + 1 < nload || i < d.nsmp) {             // only the last quad set can reach past the pass
                     unsigned h0, l0, h1, l1;
-                    split_pair(q[0], q[1], h0, l0);
-                    split_pair(q[2], q[3], h1, l1);
+                    split_pair_scaled(q[0], q[1], sx, h0, l0);
+                    split_pair_scaled(q[2], q[3], sx, h1, l1);
                     const int p = i + (SKEW ? d.skew * (int)__umulhi((unsigned)i, d.hop_magic) : 0);
                     uint32x2 uh = {h0, h1}, ul = {l0, l1};
                     *reinterpret_cast<uint32x2 *>(smph + p) = uh;
@@ -303,78 +294,60 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
                 }
             }
     };
-    int se_next;                      // scale exponent of the chunk staged most recently (this team's next front phase)
-    {
-        const __amdgpu_buffer_rsrc_t rs = chunk_rsrc(team);
-#pragma unroll
-        for (int k = 0; k < NL; k++)
-            if (k < nload) v[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * ttid + 16 * kTeam * k, 0, 0);
-        max_partial();
-        __syncthreads();
-        se_next = chunk_scale();
-        stage_chunk(se_next);                                  // chunk `team` staged before the first half-step
-    }
-    int se = 0, cse = 0;              // sample / column scale exponents of the chunk this team is working on
-    unsigned long long tsum[16] = {0}, tick[16] = {0}, tick0 = 0;
-    if (STAMP) tick0 = __builtin_amdgcn_s_memtime();
+    int se_next;                      // scale exponent of the pass staged most recently
+    load_pass(0);
+    max_partial();
+    __syncthreads();
+    se_next = pass_scale();
+    stage_pass(se_next);
+    load_pass(1);                     // arrives during the first pass's matrix work
+    int se = 0, cse = 0, se_prev = 0, cse_prev = 0;   // sample / column scale exponents of this pass and the one before
+    unsigned long long tsum[16] = {0}, tick[12] = {0};
+    if (STAMP) tick[9] = __builtin_amdgcn_s_memtime();
     __syncthreads();
 
-    for (int hs = 0; hs <= nchunks; hs++) {
-        if ((hs & 1) == team && hs < nchunks) {
-            // =================================================== FRONT phase of chunk k
-            const int k = hs;
-            SD_STAMP(1)
-            se = se_next;                                         // scale of this chunk, fixed when it was staged
-            // ---- the chunk after next starts its way from HBM now; it is needed at the end of this phase
-            {
-                const __amdgpu_buffer_rsrc_t nrs = chunk_rsrc(k + 2);
-#pragma unroll
-                for (int q = 0; q < NL; q++)
-                    if (q < nload && !(kom & 4)) v[q] = __builtin_amdgcn_raw_buffer_load_b128(nrs, 16 * ttid + 16 * kTeam * q, 0, 0);
-            }
-            // columns of this chunk and the T-1 carried ones share one scale: the smaller of the two chunks' sample
-            // scales (the carried columns were stored at the neighbour's column scale and are rescaled below)
-            const int se_other = cse_shared[2 + (1 - team)], cse_other = cse_shared[1 - team];
-            cse = scaling != 0 ? 0 : ((k > 0 && se_other < se) ? se_other : se);
-            cse = __builtin_amdgcn_readfirstlane(cse);
-            if (ttid == 0) { cse_shared[team] = cse; cse_shared[2 + team] = se; }
-            // ---- the neighbour chunk's last T-1 columns move to the front of this team's buffer (rescaled to cse)
-            if (k > 0 && !(kom & 32)) {
-                const int dexp = (cse - cse_other) * (power_mode ? 2 : 1);
-                const int words = (T - 1) * (kColStride / 2);      // 32-bit words per array
-                for (int i = ttid; i < 2 * words; i += kTeam) {
-                    const bool hi_arr = i < words;
-                    const int w = hi_arr ? i : i - words;
-                    unsigned u = reinterpret_cast<const unsigned *>(hi_arr ? ocolh : ocoll)[kChunk * (kColStride / 2) + w];
-                    if (dexp != 0) {
-                        const int bin = 2 * (w % (kColStride / 2));
-                        union { unsigned u; _Float16 h[2]; } x;
-                        x.u = u;
-                        // the two statistic bins hold a sum of squares: they scale with the square
-                        const bool st0 = norm == 1 && (bin == d.stat_bin || bin == d.stat_bin + 1);
-                        const bool st1 = norm == 1 && (bin + 1 == d.stat_bin || bin == d.stat_bin);
-                        const float f0 = (float)x.h[0] * pow2f(st0 ? 2 * dexp : dexp);
-                        const float f1 = (float)x.h[1] * pow2f(st1 ? 2 * dexp : dexp);
-                        union { decltype(__builtin_amdgcn_cvt_pkrtz(0.f, 0.f)) h; unsigned u; } y;
-                        y.h = __builtin_amdgcn_cvt_pkrtz(f0, f1);
-                        u = y.u;
-                    }
-                    reinterpret_cast<unsigned *>(hi_arr ? colh : coll)[w] = u;
+    for (int p = 0; p < runs; p++) {
+        se_prev = se; cse_prev = cse;
+        se = se_next;
+        // columns of this pass and the T-1 carried ones share one scale: the smaller of the two passes' sample
+        // scales (the carried columns were stored at the previous column scale and are rescaled below)
+        cse = scaling != 0 ? 0 : ((p > 0 && se_prev < se) ? se_prev : se);
+        // ---- the previous pass's last T-1 columns move to the front of the column buffer (rescaled to cse); done by
+        // the wave that overwrites their old slots later in this pass, so program order keeps the two apart
+        if (p > 0 && wave == kWaves - 1 && !(kom & 32)) {
+            const int dexp = (cse - cse_prev) * (power_mode ? 2 : 1);
+            const int words = (T - 1) * (kColStride / 2);      // 32-bit words per array
+            for (int i = lane; i < 2 * words; i += 64) {
+                const bool hi_arr = i < words;
+                const int w = hi_arr ? i : i - words;
+                unsigned u = reinterpret_cast<const unsigned *>(hi_arr ? colh : coll)[kPass * (kColStride / 2) + w];
+                if (dexp != 0) {
+                    const int bin = 2 * (w % (kColStride / 2));
+                    union { unsigned u; _Float16 h[2]; } x;
+                    x.u = u;
+                    // the two statistic bins hold a sum of squares: they scale with the square
+                    const bool st0 = norm == 1 && (bin == d.stat_bin || bin == d.stat_bin + 1);
+                    const bool st1 = norm == 1 && (bin + 1 == d.stat_bin || bin == d.stat_bin);
+                    const float f0 = (float)x.h[0] * pow2f(st0 ? 2 * dexp : dexp);
+                    const float f1 = (float)x.h[1] * pow2f(st1 ? 2 * dexp : dexp);
+                    union { decltype(__builtin_amdgcn_cvt_pkrtz(0.f, 0.f)) h; unsigned u; } y;
+                    y.h = __builtin_amdgcn_cvt_pkrtz(f0, f1);
+                    u = y.u;
                 }
-                if (norm >= 2 && ttid < T - 1) {
-                    stat[ttid] = ostat[kChunk + ttid];
-                    stat[CS + ttid] = ostat[CS + kChunk + ttid];
-                }
+                reinterpret_cast<unsigned *>(hi_arr ? colh : coll)[w] = u;
             }
-            // ---- the chunk after next is fetched during this chunk's matrix work, a load or two per k-step, so the
-            // memory queue never backs up into the wave
-            SD_STAMP(2)
+            if (norm >= 2 && lane < T - 1) {
+                stat[lane] = stat[kPass + lane];
+                stat[PS + lane] = stat[PS + kPass + lane];
+            }
+        }
+        SD_TICK(0)
 
-            // ---- band-limited DFT of this wave's 16 frames on the matrix cores: four 16-row tiles
-            // (re bins 0-15, re 16-31, im 0-15, im 16-31), 12 MFMAs per k-step of 32 samples.
-            // Software pipeline: while the MFMAs of k-step ks execute, the lane's next 8 samples (already in
-            // registers) are scaled and split into f16 hi/lo and the fragments after that are fetched.
-            floatx4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        // ---- band-limited DFT of this wave's 16 frames on the matrix cores: four 16-row tiles
+        // (re bins 0-15, re 16-31, im 0-15, im 16-31), 12 MFMAs per k-step of 32 samples; the fragments of
+        // k-step ks+1 are fetched while the MFMAs of k-step ks execute.
+        floatx4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        {
             half8 bh = lds_half8(fph + ko[0]), bl = lds_half8(fpl + ko[0]);
             uint32x4 a[8];
 #pragma unroll
@@ -388,35 +361,33 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
                 const half8 cbh = bh, cbl = bl;
                 if (ks + 1 < KS) {                                // fragments of the next k-step
 #pragma unroll
-                    for (int i = 0; i < 8; i++)
-                        if (!(kom & 512) || ((ks + 1) & 3) == 0) a[i] = lds_dfrag[((ks + 1) * 8 + i) * 64 + lane];
-                    if (!(kom & 1024)) {
-                        bh = lds_half8(fph + ko[ks + 1]);
-                        bl = lds_half8(fpl + ko[ks + 1]);
-                    }
+                    for (int i = 0; i < 8; i++) a[i] = lds_dfrag[((ks + 1) * 8 + i) * 64 + lane];
+                    bh = lds_half8(fph + ko[ks + 1]);
+                    bl = lds_half8(fpl + ko[ks + 1]);
                 }
                 if (!(kom & 1)) {
 #pragma unroll
-                for (int m = 0; m < 4; m++) acc[m] = mfma(ah[m], cbh, acc[m]);
+                    for (int m = 0; m < 4; m++) acc[m] = mfma(ah[m], cbh, acc[m]);
 #pragma unroll
-                for (int m = 0; m < 4; m++) acc[m] = mfma(ah[m], cbl, acc[m]);
+                    for (int m = 0; m < 4; m++) acc[m] = mfma(ah[m], cbl, acc[m]);
 #pragma unroll
-                for (int m = 0; m < 4; m++) acc[m] = mfma(al[m], cbh, acc[m]);
+                    for (int m = 0; m < 4; m++) acc[m] = mfma(al[m], cbh, acc[m]);
                 } else {
 #pragma unroll
-                for (int m = 0; m < 4; m++) asm volatile("" ::"v"(ah[m]), "v"(al[m]));
-                asm volatile("" ::"v"(cbh), "v"(cbl));
+                    for (int m = 0; m < 4; m++) asm volatile("" ::"v"(ah[m]), "v"(al[m]));
+                    asm volatile("" ::"v"(cbh), "v"(cbl));
                 }
                 // schedule: this k-step's LDS fetches first (their data is used one k-step later), then the MFMAs
-                if (!(kom & (512 | 1024))) __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);      // 8 + 4 DS reads
+                __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);      // 8 + 4 DS reads
                 __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);      // 12 MFMA
             }
-            SD_STAMP(3)
+        }
+        SD_TICK(1)
 
-            // ---- magnitude (zvabs/2 :329-333 or zvmags/4 :270-274), scaling (SyllableDetector.swift:184-212),
-            // statistic, f16 split, column -> LDS.  Result layout: column = frame f, register j of lane group g4 in
-            // tile m = basis row 16m + 4*g4 + j; this lane holds bins 4*g4 + j (i = j) and 16 + 4*g4 + j (i = 4 + j).
-            if (!(kom & 64)) {
+        // ---- magnitude (zvabs/2 :329-333 or zvmags/4 :270-274), scaling (SyllableDetector.swift:184-212),
+        // statistic, f16 split, column -> LDS.  Result layout: column = frame f, register j of lane group g4 in
+        // tile m = basis row 16m + 4*g4 + j; this lane holds bins 4*g4 + j (i = j) and 16 + 4*g4 + j (i = 4 + j).
+        if (!(kom & 64)) {
             const float inv = pow2f(-se - 13);                   // accumulators hold X * sx * 2^13
             // column scale (power of two; col_shift from the basis' largest row sum): |X| * 2^(cse - shift) < 2^13,
             // |X|^2 * 2^(2 (cse - shift)) < 2^13 with its own shift; log/dB columns are stored unscaled
@@ -449,7 +420,7 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
                 }
                 st0 = fminf(st0, __shfl_xor(st0, 16, 64)); st0 = fminf(st0, __shfl_xor(st0, 32, 64));
                 st1 = fmaxf(st1, __shfl_xor(st1, 16, 64)); st1 = fmaxf(st1, __shfl_xor(st1, 32, 64));
-                if (g4 == 0) { stat[slot] = st0; stat[CS + slot] = st1; }
+                if (g4 == 0) { stat[slot] = st0; stat[PS + slot] = st1; }
             } else if (norm == 3) {
                 float st0 = 0.0f, st1 = 0.0f;
 #pragma unroll
@@ -462,7 +433,7 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
                     st1 = ((i & 3) + 16 * (i >> 2)) < fh ? fmaf(dlt, dlt, st1) : st1;   // M2 of this frame's column
                 }
                 st1 += __shfl_xor(st1, 16, 64); st1 += __shfl_xor(st1, 32, 64);
-                if (g4 == 0) { stat[slot] = st0; stat[CS + slot] = st1; }
+                if (g4 == 0) { stat[slot] = st0; stat[PS + slot] = st1; }
             }
 #pragma unroll
             for (int i = 0; i < 8; i++) cval[i] *= cs;
@@ -489,155 +460,157 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
 #pragma unroll
                 for (int m = 0; m < 2; m++) {                     // bins 16m + 4*g4 .. +3: four consecutive halves
                     unsigned h0, l0, h1, l1;
-                    split_pair(cval[4 * m], cval[4 * m + 1], h0, l0);
-                    split_pair(cval[4 * m + 2], cval[4 * m + 3], h1, l1);
+                    split_pair_scaled(cval[4 * m], cval[4 * m + 1], 1.0f, h0, l0);
+                    split_pair_scaled(cval[4 * m + 2], cval[4 * m + 3], 1.0f, h1, l1);
                     uint32x2 uh = {h0, h1}, ul = {l0, l1};
                     *reinterpret_cast<uint32x2 *>(ph + 16 * m) = uh;
                     *reinterpret_cast<uint32x2 *>(pl + 16 * m) = ul;
                 }
             }
-            } else if (acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] == 12345.0f) colh[lane] = (_Float16)1.0f;
-            SD_STAMP(4)
-            // block-max partial of the chunk fetched during this phase (staged, scaled, in the back phase)
-            if (k + 2 < nchunks) max_partial();
-            SD_STAMP(5)
-        } else if ((hs & 1) != team && hs >= 1) {
-            // =================================================== BACK phase of chunk k = hs - 1
-            const int k = hs - 1;
-            SD_STAMP(6)
-            // ---- samples of chunk k+2 (fetched during the front phase) -> block-max partial + LDS
-            if (k + 2 < nchunks) {
-                se_next = chunk_scale();
-                if (!(kom & 2)) stage_chunk(se_next);
-            }
-            SD_STAMP(7)
-            // ---- first layer as a shifted GEMM + the rest of the network in registers.
-            // This wave finishes evaluation slots 16*tw .. +15 of the chunk (slot q: e = e_b + 64k - (T-1) + q, columns
-            // q .. q+T-1): result column = f, rows 4*g4 + j = hidden unit (row H = window sum of squares).
-            const float cs = scaling != 0 ? 1.0f : (power_mode ? pow2f(2 * (cse - d.col_shift)) : pow2f(cse - d.col_shift));
-            const float zs = d.w_unscale / cs;                    // first-layer sums back to true units
-            floatx4 z = {0.0f, 0.0f, 0.0f, 0.0f}, z2 = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (!(kom & 16)) {
-                const _Float16 *bph = colh + fl * kColStride + 8 * g4, *bpl = coll + fl * kColStride + 8 * g4;
-                // column fragments are fetched kAhead taps ahead of the MFMAs that use them (LDS latency under
-                // load is several MFMA times); the registers are the ones the DFT's fragments occupy in the front phase
-                constexpr int kAhead = 5;
-                uint32x4 bh_q[kAhead], bl_q[kAhead];
-#pragma unroll
-                for (int t = 0; t < kAhead; t++)
-                    if (t < T) {
-                        bh_q[t] = *reinterpret_cast<const uint32x4 *>(bph + t * kColStride);
-                        bl_q[t] = *reinterpret_cast<const uint32x4 *>(bpl + t * kColStride);
-                    }
-#pragma unroll
-                for (int t = 0; t < TMAX; t++) {
-                    if (t < T) {
-                        const half8 h0 = as_half8(bh_q[t % kAhead]), l0 = as_half8(bl_q[t % kAhead]);
-                        if (t + kAhead < T) {
-                            bh_q[t % kAhead] = *reinterpret_cast<const uint32x4 *>(bph + (t + kAhead) * kColStride);
-                            bl_q[t % kAhead] = *reinterpret_cast<const uint32x4 *>(bpl + (t + kAhead) * kColStride);
-                        }
-                        z = mfma(afr[t][0], h0, z);               // two accumulation chains: hi*hi on one,
-                        z2 = mfma(afr[t][0], l0, z2);             // the cross terms on the other
-                        z2 = mfma(afr[t][1], h0, z2);
-                    }
-                }
-                z += z2;
-            }
-            SD_STAMP(8)
-            if (!(kom & 128)) {
-            const int64_t e = e_b + (int64_t)kChunk * k - (T - 1) + fl;
-            const bool valid = e >= e_b && e < e_e;
-            float alpha = zs, beta = 0.0f;                    // layer-0 input = alpha * z + beta * rvec + bias0
-            if (norm == 1) {                                  // L2Normalize, NeuralNet.swift:47-59
-                const float zst = d.stat_row & 2 ? (d.stat_row & 1 ? z[3] : z[2]) : (d.stat_row & 1 ? z[1] : z[0]);
-                const float ssw = __shfl(zst, (d.stat_row >> 2) * 16 + f, 64);
-                alpha = d.w_unscale * (scaling != 0 ? 0.125f : 0.0009765625f) * __builtin_amdgcn_rsqf(ssw);   // 2^-3 | 2^-10
-            } else if (norm == 2) {                           // Normalize, :69-96
-                float mn = INFINITY, mx = -INFINITY;
-                for (int t = 0; t < T; t++) { mn = fminf(mn, stat[fl + t]); mx = fmaxf(mx, stat[CS + fl + t]); }
-                const float range = mx - mn;
-                if (range == 0.0f) { alpha = 0.0f; beta = -1.0f; }
-                else { alpha = zs * 2.0f / range; beta = (0.0f - mn - mx) / range; }
-            } else if (norm == 3) {                           // NormalizeStd, :105-108 (population sigma)
-                float nn = 0.0f, mean = 0.0f, m2 = 0.0f;
-                for (int t = 0; t < T; t++) {                 // pairwise-stable combination of per-frame (mean, M2)
-                    const float nb = (float)d.F, tot = nn + nb, dlt = stat[fl + t] - mean;
-                    mean += dlt * nb / tot;
-                    m2 += stat[CS + fl + t] + dlt * dlt * nn * nb / tot;
-                    nn = tot;
-                }
-                const float sd = sqrtf(m2 / (float)d.I);
-                alpha = zs / sd;
-                beta = -mean / sd;
-            }
-            float act[4];                                     // rows past H (padding, statistic) contribute nothing
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-                act[j] = (4 * g4 + j) < H ? transfer_fn(tf0, fmaf(alpha, z[j], fmaf(beta, c_rv[j], c_b0[j]))) : 0.0f;
-            SD_STAMP(9)
-            const double *thr = reinterpret_cast<const double *>(cst + kCstThr);
-            bool hit = false;
-            if (n_layers == 2) {
-                float yv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-                for (int o = 0; o < 4; o++) {
-                    if (o < n_out) {
-                        float y = c_w1[o][0] * act[0];        // padding rows carry zero weights
-                        y = fmaf(c_w1[o][1], act[1], y);
-                        y = fmaf(c_w1[o][2], act[2], y);
-                        y = fmaf(c_w1[o][3], act[3], y);
-                        if (!LEAN && H > 4) {
-                            y += __shfl_xor(y, 16, 64);
-                            y += __shfl_xor(y, 32, 64);
-                        }
-                        y = transfer_fn(d.tf1, y + c_b1[o]);
-                        for (int kf = 0; kf < d.n_out_fns; kf++) {    // reverse maps, NeuralNet.swift:137-142 / :175-180
-                            const float *op = cst + kCstOut + kf * (1 + 2 * n_out);
-                            y = (y - op[0]) / op[1 + o] + op[1 + n_out + o];
-                        }
-                        yv[o] = y;
-                        if (o == 0 || d.rule == 1) hit = hit || ((double)y >= thr[o]);
-                    }
-                }
-                if (valid && g4 == 0 && !(kom & 8)) {
-                    if (outputs) {
-#pragma unroll
-                        for (int o = 0; o < 4; o++)
-                            if (o < n_out) outputs[((int64_t)c * E + e) * n_out + o] = yv[o];
-                    }
-                    if (flags) flags[(int64_t)c * E + e] = hit ? 1 : 0;
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const int h = 4 * g4 + j;
-                    if (h < H) {
-                        float y = act[j];
-                        for (int kf = 0; kf < d.n_out_fns; kf++) {
-                            const float *op = cst + kCstOut + kf * (1 + 2 * n_out);
-                            y = (y - op[0]) / op[1 + h] + op[1 + n_out + h];
-                        }
-                        if (valid && outputs) outputs[((int64_t)c * E + e) * n_out + h] = y;
-                        if (h == 0 || d.rule == 1) hit = hit || ((double)y >= thr[h]);
-                    }
-                }
-                int anyhit = hit ? 1 : 0;
-                anyhit |= __shfl_xor(anyhit, 16, 64);
-                anyhit |= __shfl_xor(anyhit, 32, 64);
-                if (valid && g4 == 0 && flags) flags[(int64_t)c * E + e] = anyhit ? 1 : 0;
-            }
-            } else if (z[0] + z[1] == 12345.0f && flags) flags[0] = 1;
-            SD_STAMP(10)
+        } else if (acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] == 12345.0f) colh[lane] = (_Float16)1.0f;
+        SD_TICK(2)
+        // block-max partial of the next pass's samples (fetched a pass ago)
+        if (p + 1 < runs) max_partial();
+        SD_TICK(3)
+        __syncthreads();
+        SD_TICK(4)
+
+        // ---- next pass: scale, split, -> LDS; then the loads of the pass after it start their way from HBM
+        if (p + 1 < runs) {
+            se_next = pass_scale();
+            stage_pass(se_next);
+            load_pass(p + 2);
         }
-        SD_STAMP(11)
-        __syncthreads();                                      // one barrier per half-step
-        SD_STAMP(12)
-        SD_STAMP_FLUSH()
+        SD_TICK(5)
+
+        // ---- first layer as a shifted GEMM + the rest of the network in registers.
+        // This wave finishes evaluation slots 16*wave .. +15 of the pass (slot q: e = e_b + 128p - (T-1) + q, columns
+        // q .. q+T-1): result column = f, rows 4*g4 + j = hidden unit (row H = window sum of squares).
+        const float cs = scaling != 0 ? 1.0f : (power_mode ? pow2f(2 * (cse - d.col_shift)) : pow2f(cse - d.col_shift));
+        const float zs = d.w_unscale / cs;                    // first-layer sums back to true units
+        floatx4 z = {0.0f, 0.0f, 0.0f, 0.0f}, z2 = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (!(kom & 16)) {
+            const _Float16 *bph = colh + fl * kColStride + 8 * g4, *bpl = coll + fl * kColStride + 8 * g4;
+            // column fragments are fetched kAhead taps ahead of the MFMAs that use them (LDS latency under
+            // load is several MFMA times)
+            constexpr int kAhead = 5;
+            uint32x4 bh_q[kAhead], bl_q[kAhead];
+#pragma unroll
+            for (int t = 0; t < kAhead; t++)
+                if (t < T) {
+                    bh_q[t] = *reinterpret_cast<const uint32x4 *>(bph + t * kColStride);
+                    bl_q[t] = *reinterpret_cast<const uint32x4 *>(bpl + t * kColStride);
+                }
+#pragma unroll
+            for (int t = 0; t < TMAX; t++) {
+                if (t < T) {
+                    const half8 h0 = as_half8(bh_q[t % kAhead]), l0 = as_half8(bl_q[t % kAhead]);
+                    if (t + kAhead < T) {
+                        bh_q[t % kAhead] = *reinterpret_cast<const uint32x4 *>(bph + (t + kAhead) * kColStride);
+                        bl_q[t % kAhead] = *reinterpret_cast<const uint32x4 *>(bpl + (t + kAhead) * kColStride);
+                    }
+                    z = mfma(afr[t][0], h0, z);               // two accumulation chains: hi*hi on one,
+                    z2 = mfma(afr[t][0], l0, z2);             // the cross terms on the other
+                    z2 = mfma(afr[t][1], h0, z2);
+                }
+            }
+            z += z2;
+        }
+        SD_TICK(6)
+        if (!(kom & 128)) {
+        const int64_t e = e_b + (int64_t)kPass * p - (T - 1) + fl;
+        const bool valid = e >= e_b && e < e_e;
+        float alpha = zs, beta = 0.0f;                    // layer-0 input = alpha * z + beta * rvec + bias0
+        if (norm == 1) {                                  // L2Normalize, NeuralNet.swift:47-59
+            const float zst = d.stat_row & 2 ? (d.stat_row & 1 ? z[3] : z[2]) : (d.stat_row & 1 ? z[1] : z[0]);
+            const float ssw = __shfl(zst, (d.stat_row >> 2) * 16 + f, 64);
+            alpha = d.w_unscale * (scaling != 0 ? 0.125f : 0.0009765625f) * __builtin_amdgcn_rsqf(ssw);   // 2^-3 | 2^-10
+        } else if (norm == 2) {                           // Normalize, :69-96
+            float mn = INFINITY, mx = -INFINITY;
+            for (int t = 0; t < T; t++) { mn = fminf(mn, stat[fl + t]); mx = fmaxf(mx, stat[PS + fl + t]); }
+            const float range = mx - mn;
+            if (range == 0.0f) { alpha = 0.0f; beta = -1.0f; }
+            else { alpha = zs * 2.0f / range; beta = (0.0f - mn - mx) / range; }
+        } else if (norm == 3) {                           // NormalizeStd, :105-108 (population sigma)
+            float nn = 0.0f, mean = 0.0f, m2 = 0.0f;
+            for (int t = 0; t < T; t++) {                 // pairwise-stable combination of per-frame (mean, M2)
+                const float nb = (float)d.F, tot = nn + nb, dlt = stat[fl + t] - mean;
+                mean += dlt * nb / tot;
+                m2 += stat[PS + fl + t] + dlt * dlt * nn * nb / tot;
+                nn = tot;
+            }
+            const float sd = sqrtf(m2 / (float)d.I);
+            alpha = zs / sd;
+            beta = -mean / sd;
+        }
+        float act[4];                                     // rows past H (padding, statistic) contribute nothing
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            act[j] = (4 * g4 + j) < H ? transfer_fn(tf0, fmaf(alpha, z[j], fmaf(beta, c_rv[j], c_b0[j]))) : 0.0f;
+        const double *thr = reinterpret_cast<const double *>(cst + kCstThr);
+        bool hit = false;
+        if (n_layers == 2) {
+            float yv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int o = 0; o < 4; o++) {
+                if (o < n_out) {
+                    float y = c_w1[o][0] * act[0];        // padding rows carry zero weights
+                    y = fmaf(c_w1[o][1], act[1], y);
+                    y = fmaf(c_w1[o][2], act[2], y);
+                    y = fmaf(c_w1[o][3], act[3], y);
+                    if (!LEAN && H > 4) {
+                        y += __shfl_xor(y, 16, 64);
+                        y += __shfl_xor(y, 32, 64);
+                    }
+                    y = transfer_fn(d.tf1, y + c_b1[o]);
+                    for (int kf = 0; kf < d.n_out_fns; kf++) {    // reverse maps, NeuralNet.swift:137-142 / :175-180
+                        const float *op = cst + kCstOut + kf * (1 + 2 * n_out);
+                        y = (y - op[0]) / op[1 + o] + op[1 + n_out + o];
+                    }
+                    yv[o] = y;
+                    if (o == 0 || d.rule == 1) hit = hit || ((double)y >= thr[o]);
+                }
+            }
+            if (valid && g4 == 0 && !(kom & 8)) {
+                if (outputs) {
+#pragma unroll
+                    for (int o = 0; o < 4; o++)
+                        if (o < n_out) outputs[((int64_t)c * E + e) * n_out + o] = yv[o];
+                }
+                if (flags) flags[(int64_t)c * E + e] = hit ? 1 : 0;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int h = 4 * g4 + j;
+                if (h < H) {
+                    float y = act[j];
+                    for (int kf = 0; kf < d.n_out_fns; kf++) {
+                        const float *op = cst + kCstOut + kf * (1 + 2 * n_out);
+                        y = (y - op[0]) / op[1 + h] + op[1 + n_out + h];
+                    }
+                    if (valid && outputs) outputs[((int64_t)c * E + e) * n_out + h] = y;
+                    if (h == 0 || d.rule == 1) hit = hit || ((double)y >= thr[h]);
+                }
+            }
+            int anyhit = hit ? 1 : 0;
+            anyhit |= __shfl_xor(anyhit, 16, 64);
+            anyhit |= __shfl_xor(anyhit, 32, 64);
+            if (valid && g4 == 0 && flags) flags[(int64_t)c * E + e] = anyhit ? 1 : 0;
+        }
+        } else if (z[0] + z[1] == 12345.0f && flags) flags[0] = 1;
+        SD_TICK(7)
+        __syncthreads();
+        SD_TICK(8)
+        if (STAMP) {                                          // one wait for all of this pass's ticks
+            tsum[0] += tick[0] - tick[9];
+#pragma unroll
+            for (int i = 1; i < 9; i++) tsum[i] += tick[i] - tick[i - 1];
+            tick[9] = tick[8];
+        }
     }
-    if (STAMP && (tid == 0 || tid == kTeam) && d.stamps)
-        for (int i = 0; i < 16; i++)
-            atomicAdd(&d.stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + i], tsum[i] / 2);
+    if (STAMP && tid == 0 && d.stamps)
+        for (int i = 0; i < 16; i++) atomicAdd(&d.stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + i], tsum[i]);
 }
 
 template <int KS, int TMAX, int NL, bool EXACT, bool SKEW, bool LEAN = false, bool STAMP = false, int KNOCK = 0>
@@ -670,7 +643,7 @@ hipError_t launch_fused(const FusedDesc &d, const float *samples, int64_t stride
         const bool lean = d.norm == 1 && d.scaling == 0 && d.power_mode == 0 && d.n_layers == 2 && d.tf0 == 0 && d.n_out == 1 && d.H <= 4;
 #ifdef SYLDET_KNOCKOUTS
 #define SD_KO_CASE(m) case m: return launch_one<8, 10, 9, true, false, true, false, m>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
-        if (lean) switch (d.ko) { SD_KO_CASE(1) SD_KO_CASE(2) SD_KO_CASE(4) SD_KO_CASE(8) SD_KO_CASE(16) SD_KO_CASE(32) SD_KO_CASE(64) SD_KO_CASE(128) SD_KO_CASE(144) SD_KO_CASE(255) SD_KO_CASE(256) SD_KO_CASE(511) SD_KO_CASE(254) SD_KO_CASE(250) SD_KO_CASE(507) SD_KO_CASE(512) SD_KO_CASE(766) SD_KO_CASE(1024) SD_KO_CASE(1278) default: break; }
+        if (lean) switch (d.ko) { SD_KO_CASE(1) SD_KO_CASE(2) SD_KO_CASE(4) SD_KO_CASE(16) SD_KO_CASE(64) SD_KO_CASE(128) SD_KO_CASE(144) SD_KO_CASE(256) SD_KO_CASE(254) SD_KO_CASE(507) SD_KO_CASE(511) default: break; }
 #endif
         if (lean && d.stamps) return launch_one<8, 10, 9, true, false, true, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
         if (lean) return launch_one<8, 10, 9, true, false, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);

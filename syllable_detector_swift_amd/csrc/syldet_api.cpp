@@ -297,9 +297,9 @@ int run_on_stream(syldet *h, const float *d_samples, int64_t S, int64_t stride, 
             for (size_t i = 0; i < n; i++) sum[i % 16] += (double)host[i];
             double tot = 0;
             for (double v : sum) tot += v;
-            static const char *names[16] = {"-", "front: entry (scales, issue loads)", "front: carry columns", "front: DFT MFMA loop", "front: mag+columns",
-                                            "front: block-max partial (vmcnt)", "back: entry", "back: stage next chunk", "back: layer-0 GEMM",
-                                            "back: alpha+transfer", "back: layer1+out+stores", "idle tail before barrier", "barrier", "-", "-", "-"};
+            static const char *names[16] = {"carry columns", "DFT MFMA loop", "mag+columns", "block-max partial (vmcnt)", "barrier 1",
+                                            "stage next pass + issue loads", "layer-0 GEMM", "rest of network + stores", "barrier 0",
+                                            "-", "-", "-", "-", "-", "-", "-"};
             std::fprintf(stderr, "[syldet stamps] runs=%d workgroups=%zu cycles/pass=%.0f\n", d.runs, n / 16, tot / ((double)(n / 16) * d.runs));
             for (int i = 0; i < 16; i++)
                 if (sum[i] > 0) std::fprintf(stderr, "   %-32s %6.0f cycles/pass  %5.1f %%\n", names[i], sum[i] / ((double)(n / 16) * d.runs), 100.0 * sum[i] / tot);
