@@ -70,7 +70,7 @@ __device__ __forceinline__ floatx4 as_floatx4(uint32x4 v)
 // f32 pair -> packed f16 hi pair + packed f16 lo pair, hi = the top 11 significand bits (the
 // conversion is then exact in any rounding mode), lo = the exact remainder rounded toward zero:
 // hi + lo == x to 2^-21 relative.  6 VALU instructions per pair.
-__device__ __forceinline__ void split_pair(float a, float b, unsigned &hi, unsigned &lo)
+__device__ __forceinline__ void split_pair_unused(float a, float b, unsigned &hi, unsigned &lo)
 {
     const float ah = __uint_as_float(__float_as_uint(a) & 0xFFFFE000u);
     const float bh = __uint_as_float(__float_as_uint(b) & 0xFFFFE000u);
@@ -94,21 +94,16 @@ __device__ __forceinline__ float absmax3(float m, float x, float y)
     return r;
 }
 
-// Transfer functions (NeuralNet.swift:185-228).  tanh/logistic through the hardware exp2/rcp:
-// absolute error below 4e-7, far inside the 1e-5 bar, at a tenth of the library call's cost.
-// NaN in, NaN out (silence gives 0/0 in l2normalize; the reference then never detects).
+// Transfer functions (NeuralNet.swift:185-228).  tanh/logistic through the hardware exp2/rcp, written so
+// that NaN and the infinities fall out of the arithmetic itself (no selects, no branches: silence gives 0/0 in
+// l2normalize and the reference then never detects): absolute error below 4e-7, far inside the 1e-5 bar.
 __device__ __forceinline__ float transfer_fn(int tf, float x)
 {
-    if (tf == 0) {                                   // TanSig
-        const float t = __builtin_amdgcn_exp2f(fminf(fabsf(x), 20.0f) * 2.885390081777927f);   // e^{2|x|}
-        const float r = 1.0f - 2.0f * __builtin_amdgcn_rcpf(t + 1.0f);
-        return x != x ? x : copysignf(r, x);
-    }
-    if (tf == 1) {                                   // LogSig
-        const float t = __builtin_amdgcn_exp2f(fminf(fmaxf(-x, -80.0f), 80.0f) * 1.4426950408889634f);
-        return x != x ? x : __builtin_amdgcn_rcpf(t + 1.0f);
-    }
-    if (tf == 3) return x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x);   // SatLin
+    if (tf == 0)                                     // TanSig: 1 - 2 / (e^{2x} + 1); e^{2x} = inf gives 1, 0 gives -1
+        return fmaf(-2.0f, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(x * 2.885390081777927f) + 1.0f), 1.0f);
+    if (tf == 1)                                     // LogSig: 1 / (1 + e^{-x})
+        return __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(x * -1.4426950408889634f) + 1.0f);
+    if (tf == 3) return x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x);   // SatLin (NaN falls through both tests)
     return x;                                        // PureLin
 }
 
@@ -199,7 +194,7 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
     const int PS = d.ps, T = EXACT ? TMAX : d.T, H = d.H;      // PS: column slots = 128 + T - 1
     const int nload = EXACT ? NL : d.nload;
     const int norm = LEAN ? 1 : d.norm, scaling = LEAN ? 0 : d.scaling, power_mode = LEAN ? 0 : d.power_mode;
-    const int n_layers = LEAN ? 2 : d.n_layers, n_out = LEAN ? 1 : d.n_out, tf0 = LEAN ? 0 : d.tf0;
+    const int n_layers = LEAN ? 2 : d.n_layers, n_out = LEAN ? 1 : d.n_out, tf0 = LEAN ? 0 : d.tf0, tf1 = LEAN ? 2 : d.tf1;
     const int fl = 16 * wave + f;     // this lane's frame / evaluation slot inside the pass
     const int runs = d.runs;
 
@@ -235,6 +230,15 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
 #pragma unroll
     for (int o = 0; o < 4; o++) c_b1[o] = (n_layers == 2 && o < n_out) ? d.b1[o] : 0.0f;
 
+    // results leave through bounds-checked descriptors of this channel's rows: a lane with nothing to store uses an
+    // offset past the end (dropped by the hardware), so the evaluation carries no branches
+    const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(
+        outputs ? outputs + (int64_t)c * E * n_out : nullptr, 0, outputs ? (int)(E * n_out * 4) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t flg_rs = __builtin_amdgcn_make_buffer_rsrc(flags ? flags + (int64_t)c * E : nullptr, 0, flags ? (int)E : 0, 0x00020000);
+    // LEAN: at most one output map, applied unconditionally (identity when there is none)
+    float lean_oa = 0.0f, lean_og = 1.0f, lean_ob = 0.0f;
+    if (LEAN && d.n_out_fns == 1) { lean_oa = d.out_params[0]; lean_og = d.out_params[1]; lean_ob = d.out_params[2]; }
+
     // this lane's frame in the staged stream, and where k-step ks of lane group g4 starts inside it
     const int foff = fl * (d.hop + (SKEW ? d.skew : 0)) + (SKEW ? 0 : 8 * g4);
     const _Float16 *fph = smph + foff, *fpl = smpl + foff;
@@ -267,8 +271,7 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
         if (lane == 0) red[wave] = amax;
     };
     // block floating point: the pass's largest sample goes to [2^13, 2^14); returns the scale's exponent
-    auto pass_scale = [&]() {
-        const floatx4 r0 = *reinterpret_cast<const floatx4 *>(red), r1 = *reinterpret_cast<const floatx4 *>(red + 4);
+    auto pass_scale = [&](floatx4 r0, floatx4 r1) {
         const float amax = fmaxf(fmaxf(fmaxf(r0[0], r0[1]), fmaxf(r0[2], r0[3])), fmaxf(fmaxf(r1[0], r1[1]), fmaxf(r1[2], r1[3])));
         int e = 13 - (int)((__float_as_uint(amax) >> 23) & 0xffu) + 127;
         const int lim = power_mode ? 40 : 100;
@@ -298,22 +301,209 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
     load_pass(0);
     max_partial();
     __syncthreads();
-    se_next = pass_scale();
+    se_next = pass_scale(*reinterpret_cast<const floatx4 *>(red), *reinterpret_cast<const floatx4 *>(red + 4));
     stage_pass(se_next);
     load_pass(1);                     // arrives during the first pass's matrix work
     int se = 0, cse = 0, se_prev = 0, cse_prev = 0;   // sample / column scale exponents of this pass and the one before
-    unsigned long long tsum[16] = {0}, tick[12] = {0};
-    if (STAMP) tick[9] = __builtin_amdgcn_s_memtime();
+    unsigned long long tsum[16] = {0}, tick[8] = {0};
+    if (STAMP) tick[5] = __builtin_amdgcn_s_memtime();
     __syncthreads();
 
+    // ---- evaluation of one pass in eight steps, so that it can ride along with the NEXT pass's matrix work:
+    // the first layer as a shifted GEMM over the column buffer (steps 0-2), the rest of the network in registers
+    // (3-5), stores (6).  This wave finishes evaluation slots 16*wave .. +15 of the pass (slot q: e = e_b + 128 pp -
+    // (T-1) + q, columns q .. q+T-1): result column = f, rows 4*g4 + j = hidden unit (row H = window sum of squares).
+    floatx4 z = {0.0f, 0.0f, 0.0f, 0.0f}, z2 = {0.0f, 0.0f, 0.0f, 0.0f};
+    float alpha = 0.0f, beta = 0.0f, act[4] = {0.0f, 0.0f, 0.0f, 0.0f}, yv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    bool hit = false;
+    constexpr int kAhead = 3;                                 // column fragments are fetched this many taps ahead
+    uint32x4 bh_q[kAhead], bl_q[kAhead];
+    const _Float16 *bph = colh + fl * kColStride + 8 * g4, *bpl = coll + fl * kColStride + 8 * g4;
+    auto gemm0_taps = [&](int t0, int t1) {
+#pragma unroll
+        for (int t = 0; t < TMAX; t++) {
+            if (t >= t0 && t < t1 && t < T && !(kom & 16)) {
+                const half8 h0 = as_half8(bh_q[t % kAhead]), l0 = as_half8(bl_q[t % kAhead]);
+                if (t + kAhead < T) {
+                    bh_q[t % kAhead] = *reinterpret_cast<const uint32x4 *>(bph + (t + kAhead) * kColStride);
+                    bl_q[t % kAhead] = *reinterpret_cast<const uint32x4 *>(bpl + (t + kAhead) * kColStride);
+                }
+                z = mfma(afr[t][0], h0, z);                   // two accumulation chains: hi*hi on one,
+                z2 = mfma(afr[t][0], l0, z2);                 // the cross terms on the other
+                z2 = mfma(afr[t][1], h0, z2);
+            }
+        }
+    };
+    auto post_step = [&](int step, int pp, int cse_pp) {
+        const int n0 = (T + 2) / 3, n1 = n0 + (T - n0 + 1) / 2;   // taps [0,n0), [n0,n1), [n1,T)
+        if (step == 0) {
+            z = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+            z2 = z;
+#pragma unroll
+            for (int t = 0; t < kAhead; t++)
+                if (t < T && !(kom & 16)) {
+                    bh_q[t] = *reinterpret_cast<const uint32x4 *>(bph + t * kColStride);
+                    bl_q[t] = *reinterpret_cast<const uint32x4 *>(bpl + t * kColStride);
+                }
+            gemm0_taps(0, n0);
+        } else if (step == 1) {
+            gemm0_taps(n0, n1);
+        } else if (step == 2) {
+            gemm0_taps(n1, T);
+            z += z2;
+        } else if (step == 3) {
+            const float cs = scaling != 0 ? 1.0f : (power_mode ? pow2f(2 * (cse_pp - d.col_shift)) : pow2f(cse_pp - d.col_shift));
+            const float zs = d.w_unscale / cs;                // first-layer sums back to true units
+            alpha = zs; beta = 0.0f;                          // layer-0 input = alpha * z + beta * rvec + bias0
+            if (norm == 1) {                                  // L2Normalize, NeuralNet.swift:47-59
+                const float zst = d.stat_row & 2 ? (d.stat_row & 1 ? z[3] : z[2]) : (d.stat_row & 1 ? z[1] : z[0]);
+                const float ssw = __shfl(zst, (d.stat_row >> 2) * 16 + f, 64);
+                alpha = d.w_unscale * (scaling != 0 ? 0.125f : 0.0009765625f) * __builtin_amdgcn_rsqf(ssw);   // 2^-3 | 2^-10
+            } else if (norm == 2) {                           // Normalize, :69-96
+                float mn = INFINITY, mx = -INFINITY;
+                for (int t = 0; t < T; t++) { mn = fminf(mn, stat[fl + t]); mx = fmaxf(mx, stat[PS + fl + t]); }
+                const float range = mx - mn;
+                if (range == 0.0f) { alpha = 0.0f; beta = -1.0f; }
+                else { alpha = zs * 2.0f / range; beta = (0.0f - mn - mx) / range; }
+            } else if (norm == 3) {                           // NormalizeStd, :105-108 (population sigma)
+                float nn = 0.0f, mean = 0.0f, m2 = 0.0f;
+                for (int t = 0; t < T; t++) {                 // pairwise-stable combination of per-frame (mean, M2)
+                    const float nb = (float)d.F, tot = nn + nb, dlt = stat[fl + t] - mean;
+                    mean += dlt * nb / tot;
+                    m2 += stat[PS + fl + t] + dlt * dlt * nn * nb / tot;
+                    nn = tot;
+                }
+                const float sd = sqrtf(m2 / (float)d.I);
+                alpha = zs / sd;
+                beta = -mean / sd;
+            }
+        } else if (step == 4) {                               // rows past H (padding, statistic) contribute nothing
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                act[j] = (LEAN || (4 * g4 + j) < H) ? transfer_fn(tf0, fmaf(alpha, z[j], fmaf(beta, c_rv[j], c_b0[j]))) : 0.0f;   // LEAN: padding rows meet zero weights
+        } else if (step == 5) {
+            const double *thr = reinterpret_cast<const double *>(cst + kCstThr);
+            hit = false;
+            if (n_layers == 2) {
+#pragma unroll
+                for (int o = 0; o < 4; o++) {
+                    if (o < n_out) {
+                        float y = c_w1[o][0] * act[0];        // padding rows carry zero weights
+                        y = fmaf(c_w1[o][1], act[1], y);
+                        y = fmaf(c_w1[o][2], act[2], y);
+                        y = fmaf(c_w1[o][3], act[3], y);
+                        if (!LEAN && H > 4) {
+                            y += __shfl_xor(y, 16, 64);
+                            y += __shfl_xor(y, 32, 64);
+                        }
+                        y = transfer_fn(tf1, y + c_b1[o]);
+                        if (LEAN) y = (y - lean_oa) / lean_og + lean_ob;
+                        else
+                            for (int kf = 0; kf < d.n_out_fns; kf++) {    // reverse maps, NeuralNet.swift:137-142 / :175-180
+                                const float *op = cst + kCstOut + kf * (1 + 2 * n_out);
+                                y = (y - op[0]) / op[1 + o] + op[1 + n_out + o];
+                            }
+                        yv[o] = y;
+                        hit = hit | ((o == 0 || d.rule == 1) & ((double)y >= thr[o]));
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int h = 4 * g4 + j;
+                    float y = act[j];
+                    for (int kf = 0; kf < d.n_out_fns; kf++) {
+                        const float *op = cst + kCstOut + kf * (1 + 2 * n_out);
+                        y = (y - op[0]) / op[1 + (h < H ? h : 0)] + op[1 + n_out + (h < H ? h : 0)];
+                    }
+                    yv[j] = y;
+                    if (h < H && (h == 0 || d.rule == 1)) hit = hit || ((double)y >= thr[h]);
+                }
+                int anyhit = hit ? 1 : 0;
+                anyhit |= __shfl_xor(anyhit, 16, 64);
+                anyhit |= __shfl_xor(anyhit, 32, 64);
+                hit = anyhit != 0;
+            }
+        } else if (step == 6) {
+            const int64_t e = e_b + (int64_t)kPass * pp - (T - 1) + fl;
+            const bool valid = e >= e_b && e < e_e && pp >= 0 && !(kom & 8);
+            const unsigned off = (unsigned)e;                 // E * n_out * 4 < 2^32 is checked by the launcher
+            if (n_layers == 2) {
+                const bool st = valid && g4 == 0;
+#pragma unroll
+                for (int o = 0; o < 4; o++)
+                    if (o < n_out)
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(yv[o]), out_rs, st ? (off * n_out + o) * 4u : 0xFFFFFFFFu, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(hit ? 1 : 0), flg_rs, st ? off : 0xFFFFFFFFu, 0, 0);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(yv[j]), out_rs,
+                                                          (valid && (4 * g4 + j) < H) ? (off * n_out + 4 * g4 + j) * 4u : 0xFFFFFFFFu, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(hit ? 1 : 0), flg_rs, (valid && g4 == 0) ? off : 0xFFFFFFFFu, 0, 0);
+            }
+        }
+    };
+
+    int cse_post = 0;                                         // column scale of the pass being evaluated
     for (int p = 0; p < runs; p++) {
+        // ================= block M: DFT of pass p  ||  evaluation of pass p-1  ||  block max of pass p+1
+        // band-limited DFT of this wave's 16 frames on the matrix cores: four 16-row tiles (re bins 0-15, re 16-31,
+        // im 0-15, im 16-31), 12 MFMAs per k-step of 32 samples; the fragments of k-step ks+1 are fetched while the
+        // MFMAs of k-step ks execute.  The evaluation of the previous pass (its columns are complete, pass -1 is a dry
+        // run whose stores are masked) is cut into steps that fill the VALU / LDS slots between the MFMAs.
+        floatx4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        {
+            half8 bh = lds_half8(fph + ko[0]), bl = lds_half8(fpl + ko[0]);
+            uint32x4 a[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) a[i] = lds_dfrag[i * 64 + lane];
+#pragma unroll
+            for (int ks = 0; ks < ((kom & 256) ? 0 : KS); ks++) {
+                half8 ah[4], al[4];
+#pragma unroll
+                for (int m = 0; m < 4; m++) { ah[m] = as_half8(a[2 * m]); al[m] = as_half8(a[2 * m + 1]); }
+                const half8 cbh = bh, cbl = bl;
+                if (ks + 1 < KS) {                                // fragments of the next k-step
+#pragma unroll
+                    for (int i = 0; i < 8; i++) a[i] = lds_dfrag[((ks + 1) * 8 + i) * 64 + lane];
+                    bh = lds_half8(fph + ko[ks + 1]);
+                    bl = lds_half8(fpl + ko[ks + 1]);
+                }
+                if (!(kom & 1)) {
+#pragma unroll
+                    for (int m = 0; m < 4; m++) acc[m] = mfma(ah[m], cbh, acc[m]);
+#pragma unroll
+                    for (int m = 0; m < 4; m++) acc[m] = mfma(ah[m], cbl, acc[m]);
+#pragma unroll
+                    for (int m = 0; m < 4; m++) acc[m] = mfma(al[m], cbh, acc[m]);
+                } else {
+#pragma unroll
+                    for (int m = 0; m < 4; m++) asm volatile("" ::"v"(ah[m]), "v"(al[m]));
+                    asm volatile("" ::"v"(cbh), "v"(cbl));
+                }
+                // the previous pass's evaluation, one or two steps per k-step
+                if (!(kom & 128)) {
+                    if (KS == 8) post_step(ks, p - 1, cse_post);
+                    else { post_step(2 * ks, p - 1, cse_post); post_step(2 * ks + 1, p - 1, cse_post); }
+                }
+            }
+        }
+        // block-max partial of the next pass's samples (fetched a pass ago)
+        if (p + 1 < runs) max_partial();
+        SD_TICK(0)
+        __syncthreads();          // all reads of the staged samples and of the columns are done; partial maxima are in
+        SD_TICK(1)
+        const floatx4 red0 = *reinterpret_cast<const floatx4 *>(red), red1 = *reinterpret_cast<const floatx4 *>(red + 4);
+
         se_prev = se; cse_prev = cse;
         se = se_next;
         // columns of this pass and the T-1 carried ones share one scale: the smaller of the two passes' sample
         // scales (the carried columns were stored at the previous column scale and are rescaled below)
         cse = scaling != 0 ? 0 : ((p > 0 && se_prev < se) ? se_prev : se);
+        cse_post = cse;
         // ---- the previous pass's last T-1 columns move to the front of the column buffer (rescaled to cse); done by
-        // the wave that overwrites their old slots later in this pass, so program order keeps the two apart
+        // the wave that overwrites their old slots right after, so program order keeps the two apart
         if (p > 0 && wave == kWaves - 1 && !(kom & 32)) {
             const int dexp = (cse - cse_prev) * (power_mode ? 2 : 1);
             const int words = (T - 1) * (kColStride / 2);      // 32-bit words per array
@@ -341,74 +531,37 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
                 stat[PS + lane] = stat[PS + kPass + lane];
             }
         }
-        SD_TICK(0)
-
-        // ---- band-limited DFT of this wave's 16 frames on the matrix cores: four 16-row tiles
-        // (re bins 0-15, re 16-31, im 0-15, im 16-31), 12 MFMAs per k-step of 32 samples; the fragments of
-        // k-step ks+1 are fetched while the MFMAs of k-step ks execute.
-        floatx4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-        {
-            half8 bh = lds_half8(fph + ko[0]), bl = lds_half8(fpl + ko[0]);
-            uint32x4 a[8];
-#pragma unroll
-            for (int i = 0; i < 8; i++) a[i] = lds_dfrag[i * 64 + lane];
-            __builtin_amdgcn_sched_barrier(0);                    // the prologue's fetches stay out of the loop's groups
-#pragma unroll
-            for (int ks = 0; ks < ((kom & 256) ? 0 : KS); ks++) {
-                half8 ah[4], al[4];
-#pragma unroll
-                for (int m = 0; m < 4; m++) { ah[m] = as_half8(a[2 * m]); al[m] = as_half8(a[2 * m + 1]); }
-                const half8 cbh = bh, cbl = bl;
-                if (ks + 1 < KS) {                                // fragments of the next k-step
-#pragma unroll
-                    for (int i = 0; i < 8; i++) a[i] = lds_dfrag[((ks + 1) * 8 + i) * 64 + lane];
-                    bh = lds_half8(fph + ko[ks + 1]);
-                    bl = lds_half8(fpl + ko[ks + 1]);
-                }
-                if (!(kom & 1)) {
-#pragma unroll
-                    for (int m = 0; m < 4; m++) acc[m] = mfma(ah[m], cbh, acc[m]);
-#pragma unroll
-                    for (int m = 0; m < 4; m++) acc[m] = mfma(ah[m], cbl, acc[m]);
-#pragma unroll
-                    for (int m = 0; m < 4; m++) acc[m] = mfma(al[m], cbh, acc[m]);
-                } else {
-#pragma unroll
-                    for (int m = 0; m < 4; m++) asm volatile("" ::"v"(ah[m]), "v"(al[m]));
-                    asm volatile("" ::"v"(cbh), "v"(cbl));
-                }
-                // schedule: this k-step's LDS fetches first (their data is used one k-step later), then the MFMAs
-                __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);      // 8 + 4 DS reads
-                __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);      // 12 MFMA
-            }
-        }
-        SD_TICK(1)
 
         // ---- magnitude (zvabs/2 :329-333 or zvmags/4 :270-274), scaling (SyllableDetector.swift:184-212),
         // statistic, f16 split, column -> LDS.  Result layout: column = frame f, register j of lane group g4 in
         // tile m = basis row 16m + 4*g4 + j; this lane holds bins 4*g4 + j (i = j) and 16 + 4*g4 + j (i = 4 + j).
         if (!(kom & 64)) {
-            const float inv = pow2f(-se - 13);                   // accumulators hold X * sx * 2^13
-            // column scale (power of two; col_shift from the basis' largest row sum): |X| * 2^(cse - shift) < 2^13,
-            // |X|^2 * 2^(2 (cse - shift)) < 2^13 with its own shift; log/dB columns are stored unscaled
+            // accumulators hold X * sx * 2^13.  Column scale (power of two; col_shift from the basis' largest row sum):
+            // |X| * 2^(cse - shift) < 2^13, |X|^2 * 2^(2 (cse - shift)) < 2^13 with its own shift; log/dB columns are
+            // stored unscaled.  For linear columns the two scales are applied together after the square root.
+            const float inv = pow2f(-se - 13);
             const float cs = scaling != 0 ? 1.0f : (power_mode ? pow2f(2 * (cse - d.col_shift)) : pow2f(cse - d.col_shift));
             const int fh = d.F - 4 * g4;                          // cval[i] is a band bin iff (i&3) + 16(i>>2) < fh
+            const bool plain = scaling == 0 && !power_mode && norm <= 1;   // |X| columns, no per-frame statistic on raw values
             float cval[8];
 #pragma unroll
             for (int i = 0; i < 8; i++) {
-                const float re = acc[i >> 2][i & 3] * inv, im = acc[2 + (i >> 2)][i & 3] * inv;
-                const float pw = fmaf(re, re, im * im);
-                cval[i] = power_mode ? pw : __builtin_amdgcn_sqrtf(pw);
+                if (plain) {
+                    const float re = acc[i >> 2][i & 3], im = acc[2 + (i >> 2)][i & 3];
+                    cval[i] = __builtin_amdgcn_sqrtf(fmaf(re, re, im * im)) * (inv * cs);   // |acc| < 2^40: no overflow
+                } else {
+                    const float re = acc[i >> 2][i & 3] * inv, im = acc[2 + (i >> 2)][i & 3] * inv;
+                    const float pw = fmaf(re, re, im * im);
+                    cval[i] = power_mode ? pw : __builtin_amdgcn_sqrtf(pw);
+                }
             }
             if (scaling != 0) {
                 const float kk = scaling == 1 ? 0.6931471805599453f : 6.020599913279624f;   // ln 2, 20 log10 2
 #pragma unroll
                 for (int i = 0; i < 8; i++) cval[i] = kk * __builtin_amdgcn_logf(cval[i]);  // v_log_f32 = log2
-            }
-            if (d.F < 32 || scaling != 0) {
 #pragma unroll
-                for (int i = 0; i < 8; i++) cval[i] = ((i & 3) + 16 * (i >> 2)) < fh ? cval[i] : 0.0f;
-            }
+                for (int i = 0; i < 8; i++) cval[i] = ((i & 3) + 16 * (i >> 2)) < fh ? cval[i] : 0.0f;   // log(0) rows
+            }                                                     // (linear: basis rows past F are zero, so are their |X|)
             const int slot = (T - 1) + fl;
             if (norm == 2) {
                 float st0 = INFINITY, st1 = -INFINITY;
@@ -435,8 +588,10 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
                 st1 += __shfl_xor(st1, 16, 64); st1 += __shfl_xor(st1, 32, 64);
                 if (g4 == 0) { stat[slot] = st0; stat[PS + slot] = st1; }
             }
+            if (!plain) {
 #pragma unroll
-            for (int i = 0; i < 8; i++) cval[i] *= cs;
+                for (int i = 0; i < 8; i++) cval[i] *= cs;
+            }
             if (norm == 1) {
                 // sum of squares of the (scaled) column rides in two spare bins: its top 11 bits in bin F and the
                 // remainder, scaled by 2^11 so that it stays a normal f16, in bin F+1 (weights 1 and 2^-11 in row H
@@ -469,145 +624,27 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
             }
         } else if (acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] == 12345.0f) colh[lane] = (_Float16)1.0f;
         SD_TICK(2)
-        // block-max partial of the next pass's samples (fetched a pass ago)
-        if (p + 1 < runs) max_partial();
-        SD_TICK(3)
-        __syncthreads();
-        SD_TICK(4)
 
         // ---- next pass: scale, split, -> LDS; then the loads of the pass after it start their way from HBM
         if (p + 1 < runs) {
-            se_next = pass_scale();
+            se_next = pass_scale(red0, red1);
             stage_pass(se_next);
             load_pass(p + 2);
         }
-        SD_TICK(5)
-
-        // ---- first layer as a shifted GEMM + the rest of the network in registers.
-        // This wave finishes evaluation slots 16*wave .. +15 of the pass (slot q: e = e_b + 128p - (T-1) + q, columns
-        // q .. q+T-1): result column = f, rows 4*g4 + j = hidden unit (row H = window sum of squares).
-        const float cs = scaling != 0 ? 1.0f : (power_mode ? pow2f(2 * (cse - d.col_shift)) : pow2f(cse - d.col_shift));
-        const float zs = d.w_unscale / cs;                    // first-layer sums back to true units
-        floatx4 z = {0.0f, 0.0f, 0.0f, 0.0f}, z2 = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (!(kom & 16)) {
-            const _Float16 *bph = colh + fl * kColStride + 8 * g4, *bpl = coll + fl * kColStride + 8 * g4;
-            // column fragments are fetched kAhead taps ahead of the MFMAs that use them (LDS latency under
-            // load is several MFMA times)
-            constexpr int kAhead = 5;
-            uint32x4 bh_q[kAhead], bl_q[kAhead];
-#pragma unroll
-            for (int t = 0; t < kAhead; t++)
-                if (t < T) {
-                    bh_q[t] = *reinterpret_cast<const uint32x4 *>(bph + t * kColStride);
-                    bl_q[t] = *reinterpret_cast<const uint32x4 *>(bpl + t * kColStride);
-                }
-#pragma unroll
-            for (int t = 0; t < TMAX; t++) {
-                if (t < T) {
-                    const half8 h0 = as_half8(bh_q[t % kAhead]), l0 = as_half8(bl_q[t % kAhead]);
-                    if (t + kAhead < T) {
-                        bh_q[t % kAhead] = *reinterpret_cast<const uint32x4 *>(bph + (t + kAhead) * kColStride);
-                        bl_q[t % kAhead] = *reinterpret_cast<const uint32x4 *>(bpl + (t + kAhead) * kColStride);
-                    }
-                    z = mfma(afr[t][0], h0, z);               // two accumulation chains: hi*hi on one,
-                    z2 = mfma(afr[t][0], l0, z2);             // the cross terms on the other
-                    z2 = mfma(afr[t][1], h0, z2);
-                }
-            }
-            z += z2;
-        }
-        SD_TICK(6)
-        if (!(kom & 128)) {
-        const int64_t e = e_b + (int64_t)kPass * p - (T - 1) + fl;
-        const bool valid = e >= e_b && e < e_e;
-        float alpha = zs, beta = 0.0f;                    // layer-0 input = alpha * z + beta * rvec + bias0
-        if (norm == 1) {                                  // L2Normalize, NeuralNet.swift:47-59
-            const float zst = d.stat_row & 2 ? (d.stat_row & 1 ? z[3] : z[2]) : (d.stat_row & 1 ? z[1] : z[0]);
-            const float ssw = __shfl(zst, (d.stat_row >> 2) * 16 + f, 64);
-            alpha = d.w_unscale * (scaling != 0 ? 0.125f : 0.0009765625f) * __builtin_amdgcn_rsqf(ssw);   // 2^-3 | 2^-10
-        } else if (norm == 2) {                           // Normalize, :69-96
-            float mn = INFINITY, mx = -INFINITY;
-            for (int t = 0; t < T; t++) { mn = fminf(mn, stat[fl + t]); mx = fmaxf(mx, stat[PS + fl + t]); }
-            const float range = mx - mn;
-            if (range == 0.0f) { alpha = 0.0f; beta = -1.0f; }
-            else { alpha = zs * 2.0f / range; beta = (0.0f - mn - mx) / range; }
-        } else if (norm == 3) {                           // NormalizeStd, :105-108 (population sigma)
-            float nn = 0.0f, mean = 0.0f, m2 = 0.0f;
-            for (int t = 0; t < T; t++) {                 // pairwise-stable combination of per-frame (mean, M2)
-                const float nb = (float)d.F, tot = nn + nb, dlt = stat[fl + t] - mean;
-                mean += dlt * nb / tot;
-                m2 += stat[PS + fl + t] + dlt * dlt * nn * nb / tot;
-                nn = tot;
-            }
-            const float sd = sqrtf(m2 / (float)d.I);
-            alpha = zs / sd;
-            beta = -mean / sd;
-        }
-        float act[4];                                     // rows past H (padding, statistic) contribute nothing
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-            act[j] = (4 * g4 + j) < H ? transfer_fn(tf0, fmaf(alpha, z[j], fmaf(beta, c_rv[j], c_b0[j]))) : 0.0f;
-        const double *thr = reinterpret_cast<const double *>(cst + kCstThr);
-        bool hit = false;
-        if (n_layers == 2) {
-            float yv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-            for (int o = 0; o < 4; o++) {
-                if (o < n_out) {
-                    float y = c_w1[o][0] * act[0];        // padding rows carry zero weights
-                    y = fmaf(c_w1[o][1], act[1], y);
-                    y = fmaf(c_w1[o][2], act[2], y);
-                    y = fmaf(c_w1[o][3], act[3], y);
-                    if (!LEAN && H > 4) {
-                        y += __shfl_xor(y, 16, 64);
-                        y += __shfl_xor(y, 32, 64);
-                    }
-                    y = transfer_fn(d.tf1, y + c_b1[o]);
-                    for (int kf = 0; kf < d.n_out_fns; kf++) {    // reverse maps, NeuralNet.swift:137-142 / :175-180
-                        const float *op = cst + kCstOut + kf * (1 + 2 * n_out);
-                        y = (y - op[0]) / op[1 + o] + op[1 + n_out + o];
-                    }
-                    yv[o] = y;
-                    if (o == 0 || d.rule == 1) hit = hit || ((double)y >= thr[o]);
-                }
-            }
-            if (valid && g4 == 0 && !(kom & 8)) {
-                if (outputs) {
-#pragma unroll
-                    for (int o = 0; o < 4; o++)
-                        if (o < n_out) outputs[((int64_t)c * E + e) * n_out + o] = yv[o];
-                }
-                if (flags) flags[(int64_t)c * E + e] = hit ? 1 : 0;
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int h = 4 * g4 + j;
-                if (h < H) {
-                    float y = act[j];
-                    for (int kf = 0; kf < d.n_out_fns; kf++) {
-                        const float *op = cst + kCstOut + kf * (1 + 2 * n_out);
-                        y = (y - op[0]) / op[1 + h] + op[1 + n_out + h];
-                    }
-                    if (valid && outputs) outputs[((int64_t)c * E + e) * n_out + h] = y;
-                    if (h == 0 || d.rule == 1) hit = hit || ((double)y >= thr[h]);
-                }
-            }
-            int anyhit = hit ? 1 : 0;
-            anyhit |= __shfl_xor(anyhit, 16, 64);
-            anyhit |= __shfl_xor(anyhit, 32, 64);
-            if (valid && g4 == 0 && flags) flags[(int64_t)c * E + e] = anyhit ? 1 : 0;
-        }
-        } else if (z[0] + z[1] == 12345.0f && flags) flags[0] = 1;
-        SD_TICK(7)
-        __syncthreads();
-        SD_TICK(8)
+        SD_TICK(3)
+        __syncthreads();          // columns of pass p and staged samples of pass p+1 are complete
+        SD_TICK(4)
         if (STAMP) {                                          // one wait for all of this pass's ticks
-            tsum[0] += tick[0] - tick[9];
+            tsum[0] += tick[0] - tick[5];
 #pragma unroll
-            for (int i = 1; i < 9; i++) tsum[i] += tick[i] - tick[i - 1];
-            tick[9] = tick[8];
+            for (int i = 1; i < 5; i++) tsum[i] += tick[i] - tick[i - 1];
+            tick[5] = tick[4];
         }
+    }
+    // ---- evaluation of the last pass
+    if (!(kom & 128)) {
+#pragma unroll
+        for (int step = 0; step < 7; step++) post_step(step, runs - 1, cse_post);
     }
     if (STAMP && tid == 0 && d.stamps)
         for (int i = 0; i < 16; i++) atomicAdd(&d.stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + i], tsum[i]);
@@ -640,7 +677,8 @@ hipError_t launch_fused(const FusedDesc &d, const float *samples, int64_t stride
     const bool skew = d.skew != 0;
     // the reference's example shape (W = 256, hop 132, timeRange 10) gets an instantiation with exact sizes
     if (d.KS == 8 && d.T == 10 && d.nload == 9 && !skew) {
-        const bool lean = d.norm == 1 && d.scaling == 0 && d.power_mode == 0 && d.n_layers == 2 && d.tf0 == 0 && d.n_out == 1 && d.H <= 4;
+        const bool lean = d.norm == 1 && d.scaling == 0 && d.power_mode == 0 && d.n_layers == 2 && d.tf0 == 0 /* TanSig */ && d.tf1 == 2 /* PureLin */ &&
+                          d.n_out == 1 && d.H <= 4 && d.n_out_fns <= 1;
 #ifdef SYLDET_KNOCKOUTS
 #define SD_KO_CASE(m) case m: return launch_one<8, 10, 9, true, false, true, false, m>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
         if (lean) switch (d.ko) { SD_KO_CASE(1) SD_KO_CASE(2) SD_KO_CASE(4) SD_KO_CASE(16) SD_KO_CASE(64) SD_KO_CASE(128) SD_KO_CASE(144) SD_KO_CASE(256) SD_KO_CASE(254) SD_KO_CASE(507) SD_KO_CASE(511) default: break; }

@@ -271,7 +271,8 @@ int run_on_stream(syldet *h, const float *d_samples, int64_t S, int64_t stride, 
     if (E <= 0) return SYLDET_OK;
     SYLDET_HIP(hipSetDevice(h->device));
     h->timed_kernels = 0;
-    if (h->engine == SYLDET_ENGINE_FUSED) {
+    // the fused kernel addresses a channel's results with 32-bit byte offsets; longer rows take the generic engine
+    if (h->engine == SYLDET_ENGINE_FUSED && (uint64_t)E * (uint64_t)h->geom.outputs * 4u < 0xFFFFFFF0ull) {
         FusedDesc d = h->fused.desc;
         fused_segmentation(d, E, C);
         d.stamps = nullptr;
@@ -297,9 +298,8 @@ int run_on_stream(syldet *h, const float *d_samples, int64_t S, int64_t stride, 
             for (size_t i = 0; i < n; i++) sum[i % 16] += (double)host[i];
             double tot = 0;
             for (double v : sum) tot += v;
-            static const char *names[16] = {"carry columns", "DFT MFMA loop", "mag+columns", "block-max partial (vmcnt)", "barrier 1",
-                                            "stage next pass + issue loads", "layer-0 GEMM", "rest of network + stores", "barrier 0",
-                                            "-", "-", "-", "-", "-", "-", "-"};
+            static const char *names[16] = {"DFT(p) || evaluate(p-1) || block max(p+1)", "barrier 1", "carry + mag + columns", "stage next pass + issue loads",
+                                            "barrier 0", "-", "-", "-", "-", "-", "-", "-", "-", "-", "-", "-"};
             std::fprintf(stderr, "[syldet stamps] runs=%d workgroups=%zu cycles/pass=%.0f\n", d.runs, n / 16, tot / ((double)(n / 16) * d.runs));
             for (int i = 0; i < 16; i++)
                 if (sum[i] > 0) std::fprintf(stderr, "   %-32s %6.0f cycles/pass  %5.1f %%\n", names[i], sum[i] / ((double)(n / 16) * d.runs), 100.0 * sum[i] / tot);
