@@ -16,8 +16,8 @@
 //      sample stream at offset j*hop (no per-frame copy, no ring).  Every operand is split into f16
 //      hi + lo (block floating point, power-of-two scales): hi*hi + hi*lo + lo*hi reproduces an fp32
 //      product to ~2^-21 and the fp32 accumulate keeps the sum; measured error against the fp64
-//      anchor is below an fp32 FFT's.  The split of the samples is done on the fragment a lane has
-//      just read from LDS, in the issue slots the matrix pipe leaves free.
+//      anchor is below an fp32 FFT's.  The samples are split once, when they are staged
+//      (v_fma_mixlo/mixhi_f16: two VALU instructions per sample, the block scale rides in the FMA).
 //   2. |X| columns (f16 hi/lo) go to a small LDS buffer [frame][bin].  The first network layer,
 //      folded with the affine input maps into W' = W0 o gain, is  Z[h, e] = sum_t W'_t[h, :] . C[:, e+t]:
 //      again a GEMM (K = 32 bins per tap) whose B operand for tap t is the column buffer at row
@@ -26,13 +26,11 @@
 //      then finishes in registers: scale, transfer function, second layer, reverse map, threshold.
 // Every frame is transformed once (the reference re-reads each column T times).
 //
-// Workgroup = 8 waves = two teams of 4 (one wave of each team per SIMD); a team owns alternate 64-frame
-// chunks (16 frames per wave) of the workgroup's segment of one channel, and the teams run half a period
-// apart so that one team's matrix work overlaps the other's staging / evaluation work (see fused_kernel).
-// LDS -- 64 KB of basis fragments + 2 x 34 KB of samples + 2 x 12 KB of columns -- allows one workgroup
-// per CU.  HBM traffic = every sample once (+ W - hop samples of overlap per chunk, L2 hits) + 5 bytes per
-// evaluation.  Buffer loads with hardware bounds instead of guards; a chunk's samples are fetched two
-// half-steps ahead, a load or two per k-step inside the MFMA loop.
+// Workgroup = 8 waves x 16 frames = one 128-frame pass at a time over the workgroup's segment of one
+// channel, all waves in the same phase (see fused_kernel).  LDS -- 64 KB of basis fragments + 68 KB of
+// staged samples + 22 KB of columns -- allows one workgroup per CU.  HBM traffic = every sample once
+// (+ W - hop samples of overlap per pass, L2 hits) + 5 bytes per evaluation.  Buffer loads with hardware
+// bounds instead of guards, issued a whole pass ahead of their use.
 //
 // gfx950 only.  wave = 64.
 
@@ -65,20 +63,6 @@ __device__ __forceinline__ floatx4 as_floatx4(uint32x4 v)
     union { uint32x4 u; floatx4 f; } c;
     c.u = v;
     return c.f;
-}
-
-// f32 pair -> packed f16 hi pair + packed f16 lo pair, hi = the top 11 significand bits (the
-// conversion is then exact in any rounding mode), lo = the exact remainder rounded toward zero:
-// hi + lo == x to 2^-21 relative.  6 VALU instructions per pair.
-__device__ __forceinline__ void split_pair_unused(float a, float b, unsigned &hi, unsigned &lo)
-{
-    const float ah = __uint_as_float(__float_as_uint(a) & 0xFFFFE000u);
-    const float bh = __uint_as_float(__float_as_uint(b) & 0xFFFFE000u);
-    union { decltype(__builtin_amdgcn_cvt_pkrtz(0.f, 0.f)) h; unsigned u; } ch, cl;
-    ch.h = __builtin_amdgcn_cvt_pkrtz(ah, bh);
-    cl.h = __builtin_amdgcn_cvt_pkrtz(a - ah, b - bh);
-    hi = ch.u;
-    lo = cl.u;
 }
 
 __device__ __forceinline__ float pow2f(int e)   // 2^e for e in [-126, 127]
@@ -162,13 +146,15 @@ __device__ __forceinline__ void split_pair_scaled(float a, float b, float sx, un
 //
 // One pass = 128 frames = 16 per wave, all eight waves in the same phase (two per SIMD: while one waits for
 // LDS the other feeds the matrix pipe -- a single wave cannot, its LDS fetch rate is capped at ~32 B/clk):
-//     [carry the last T-1 columns of the previous pass to the front of the column buffer]
-//     DFT of the wave's 16 frames from the staged samples (f16 hi + lo, block floating point)
-//     magnitudes -> column buffer;  block-max partial of the NEXT pass's samples (already in registers)
+//     block M:  DFT of the wave's 16 frames from the staged samples (f16 hi + lo, block floating point)
+//               || evaluation of the PREVIOUS pass (first layer as a shifted GEMM over the column buffer, rest of
+//                  the network in registers, stores), cut into steps that sit between the k-steps -- branch-free,
+//                  so the whole block is one scheduling region
+//               || block-max partial of the NEXT pass's samples (already in registers)
 //   barrier
-//     next pass's samples: scale, split, -> LDS (the staged region is free now);  issue the loads of the
-//     pass after that (a whole pass of lead time)
-//     first layer as a shifted GEMM over the column buffer, rest of the network in registers, stores
+//     carry the last T-1 columns to the front of the column buffer;  magnitudes of this pass -> column buffer;
+//     next pass's samples: scale, split, -> LDS (the staged region is free now);  issue the loads of the pass
+//     after that (a whole pass of lead time)
 //   barrier
 template <int KS, int TMAX, int NL, bool EXACT, bool SKEW, bool LEAN, bool STAMP, int KNOCK>
 __global__ void __launch_bounds__(kBlock, 2)
