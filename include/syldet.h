@@ -226,6 +226,40 @@ int syldet_last_detected(const syldet_t *h, int32_t channel);
 /* seenSyllable(), :220-230: drains every pending evaluation, 1 if any was detected       */
 int syldet_seen_syllable(syldet_t *h, int32_t channel);
 
+/* ---- ingest: the steps immediately before the path ----
+ * Frame-major (interleaved) audio, as a decoder or a multi-channel device delivers it:
+ * appendInterleavedData(_:withSamples:fromChannel:ofTotalChannels:),
+ * CircularShortTimeFourierTransform.swift:203-217, for every channel at once.
+ * interleaved [n_frames][total_channels] fp32 -> rows of channels first_channel ..
+ * first_channel + n_channels - 1 in out [n_channels][out_stride].                        */
+int syldet_deinterleave_device(const float *d_interleaved, int64_t n_frames, int32_t total_channels,
+                               int32_t first_channel, int32_t n_channels, float *d_out, int64_t out_stride,
+                               void *hip_stream);
+/* The batch call on interleaved audio (total_channels == syldet_channels(h)): de-interleave
+ * on the device, then exactly syldet_run_device / syldet_run.                             */
+int syldet_run_interleaved_device(syldet_t *h, const float *d_interleaved, int64_t n_frames, int32_t total_channels,
+                                  float *d_outputs, uint8_t *d_flags, void *hip_stream);
+int syldet_run_interleaved(syldet_t *h, const float *interleaved, int64_t n_frames, int32_t total_channels,
+                           float *outputs, uint8_t *flags);
+
+/* ResamplerLinear, Common/Resampler.swift:20-76 (used when the device rate differs from the
+ * network's: Processor.swift:116-121, ViewControllerProcessor.swift:247-250), for n_channels
+ * independent streams fed in lock-step.  Stateful like the reference: the fractional
+ * position (`offset`) and the last input sample of every channel carry over to the next
+ * call.  Results are bit-identical to the reference's arithmetic order (fp32, no FMA).    */
+typedef struct syldet_resampler syldet_resampler_t;
+int syldet_resampler_create(double rate_in, double rate_out, int32_t n_channels, int32_t device,
+                            syldet_resampler_t **out);
+int syldet_resampler_destroy(syldet_resampler_t *r);
+/* samples per channel the next call produces from n_in input samples (:40)               */
+int64_t syldet_resampler_count(const syldet_resampler_t *r, int64_t n_in);
+/* resampleVector(_:ofLength:), :36-69.  in [C][in_stride] -> out [C][out_stride]; *n_out
+ * (host) receives the per-channel output length (= syldet_resampler_count before the call) */
+int syldet_resample_device(syldet_resampler_t *r, const float *d_in, int64_t n_in, int64_t in_stride, float *d_out,
+                           int64_t out_stride, int64_t *n_out, void *hip_stream);
+int syldet_resample(syldet_resampler_t *r, const float *in, int64_t n_in, int64_t in_stride, float *out,
+                    int64_t out_stride, int64_t *n_out);
+
 #ifdef __cplusplus
 }
 #endif

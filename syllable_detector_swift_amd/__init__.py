@@ -10,7 +10,8 @@ from .config import (InvalidValue, MismatchedLength, MissingValue, NeuralNet, Ne
                      ProcessingFunction, SyllableDetectorConfig, SyllableDetectorError, UnableToOpenPath,
                      createWindow, frequencyIndexRange)
 from .detector import SyllableDetector
+from .resampler import ResamplerLinear, deinterleave
 
 __all__ = ["SyllableDetector", "SyllableDetectorConfig", "NeuralNet", "NeuralNetLayer", "ProcessingFunction",
            "ParseError", "UnableToOpenPath", "MissingValue", "InvalidValue", "MismatchedLength",
-           "SyllableDetectorError", "frequencyIndexRange", "createWindow"]
+           "SyllableDetectorError", "frequencyIndexRange", "createWindow", "ResamplerLinear", "deinterleave"]

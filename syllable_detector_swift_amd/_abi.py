@@ -109,6 +109,14 @@ SIGNATURES = {
     "syldet_last_outputs": (C.c_int, [Handle, C.c_int32, c_float_p]),
     "syldet_last_detected": (C.c_int, [Handle, C.c_int32]),
     "syldet_seen_syllable": (C.c_int, [Handle, C.c_int32]),
+    "syldet_deinterleave_device": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
+    "syldet_run_interleaved_device": (C.c_int, [Handle, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "syldet_run_interleaved": (C.c_int, [Handle, c_float_p, C.c_int64, C.c_int32, c_float_p, c_uint8_p]),
+    "syldet_resampler_create": (C.c_int, [C.c_double, C.c_double, C.c_int32, C.c_int32, C.POINTER(Handle)]),
+    "syldet_resampler_destroy": (C.c_int, [Handle]),
+    "syldet_resampler_count": (C.c_int64, [Handle, C.c_int64]),
+    "syldet_resample_device": (C.c_int, [Handle, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, c_int64_p, C.c_void_p]),
+    "syldet_resample": (C.c_int, [Handle, c_float_p, C.c_int64, C.c_int64, c_float_p, C.c_int64, c_int64_p]),
 }
 
 

@@ -99,6 +99,13 @@ struct FusedDesc {
     unsigned long long *stamps; // diagnostic build only: [workgroups][16] phase cycle sums, else null
 };
 
+// ResamplerLinear (Common/Resampler.swift:36-69) for C channels at once; `last` is the per-channel carry on the device
+hipError_t launch_resample_linear(const float *in, int64_t n_in, int64_t in_stride, float *out, int64_t n_out,
+                                  int64_t out_stride, int C, float step, float offset, float *last, hipStream_t stream);
+// frame-major [n_frames][total] -> channel-major rows of channels first .. first+C-1
+hipError_t launch_deinterleave(const float *in, int64_t n_frames, int total, int first, int C, float *out,
+                               int64_t out_stride, hipStream_t stream);
+
 hipError_t launch_fused(const FusedDesc &d, const float *samples, int64_t stride, int C, int64_t S, int64_t J,
                         int64_t E, float *outputs, uint8_t *flags, hipStream_t stream);
 // taps the register-resident first-layer fragments are instantiated for (0: timeRange too long)

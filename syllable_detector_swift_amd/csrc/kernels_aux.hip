@@ -1,0 +1,94 @@
+// kernels_aux.hip -- the two data-movement steps either side of the hot path:
+//   resample_linear_kernel   ResamplerLinear.resampleVector, Common/Resampler.swift:36-69
+//   deinterleave_kernel      appendInterleavedData's strided copy, Common/CircularShortTimeFourierTransform.swift:203-217,
+//                            for all channels of a frame-major buffer at once
+// Both are HBM-bound gathers: no matrix work, coalesced on the wide side, one pass over the data.
+//
+// gfx950 only.  wave = 64.
+
+#include "kernels.hpp"
+
+// bit-exact float bookkeeping below: this file is compiled with -ffp-contract=off (see the Makefile), every
+// multiply and add rounds on its own exactly as in the reference's vDSP calls
+
+namespace sd {
+
+namespace {
+
+// One output sample per thread.  The arithmetic is the reference's, operation by operation and without
+// contraction (so that results are bit-identical to the restatement in oracle/):
+//   index  b = offset + float(i) * step                      vDSP_vramp   :52
+//          b = 0 for i == 0 when the previous call left a negative offset       :54-56
+//   value  a[k] + (b - k) * (a[k+1] - a[k]),  k = floor(b)   vDSP_vlint   :59
+//          out[0] = last * (0 - offset) + data[0] * (1 + offset) in that case   :61-63
+//   carry  last = data[n_in - 1]                                                :66
+// (the new offset depends on sizes only and is computed by the host, see syldet_resample_device)
+__global__ void __launch_bounds__(256)
+resample_linear_kernel(const float *__restrict__ in, int64_t n_in, int64_t in_stride, float *__restrict__ out,
+                       int64_t n_out, int64_t out_stride, float step, float offset, float *__restrict__ last)
+{
+    const int c = blockIdx.y;
+    const float *a = in + (int64_t)c * in_stride;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_out) return;
+    const bool across = offset < 0.0f;
+    float b = offset + (float)i * step;
+    if (i == 0 && across) b = 0.0f;
+    const int64_t k = (int64_t)floorf(b);
+    const float frac = b - (float)k;
+    const float a0 = a[k], a1 = (k + 1 < n_in) ? a[k + 1] : a0;
+    float y = a0 + frac * (a1 - a0);
+    if (i == 0) {
+        if (across) y = (last[c] * (0.0f - offset)) + (a[0] * (1.0f + offset));
+        last[c] = a[n_in - 1];
+    }
+    out[(int64_t)c * out_stride + i] = y;
+}
+
+// Frame-major [n_frames][total] -> channel-major rows for channels first .. first + C - 1.
+// A workgroup moves a tile of 256 frames x 32 channels through LDS: reads run along the interleaved
+// buffer (consecutive lanes = consecutive channels of a frame), writes along each channel's row.
+constexpr int kTileFrames = 256, kTileCh = 32;
+
+__global__ void __launch_bounds__(256)
+deinterleave_kernel(const float *__restrict__ in, int64_t n_frames, int total, int first, int C, float *__restrict__ out,
+                    int64_t out_stride)
+{
+    __shared__ float tile[kTileFrames][kTileCh + 1];
+    const int64_t f0 = (int64_t)blockIdx.x * kTileFrames;
+    const int c0 = blockIdx.y * kTileCh;
+    const int nc = min(kTileCh, C - c0);
+    const int tid = threadIdx.x;
+    // load: element e of the tile = (frame e / nc, channel e % nc)
+    const int nf = (int)min((int64_t)kTileFrames, n_frames - f0);
+    for (int e = tid; e < nf * nc; e += 256) {
+        const int fr = e / nc, ch = e - fr * nc;
+        tile[fr][ch] = in[(f0 + fr) * (int64_t)total + first + c0 + ch];
+    }
+    __syncthreads();
+    for (int ch = 0; ch < nc; ch++)
+        if (tid < nf) out[(int64_t)(c0 + ch) * out_stride + f0 + tid] = tile[tid][ch];
+}
+
+}  // namespace
+
+hipError_t launch_resample_linear(const float *in, int64_t n_in, int64_t in_stride, float *out, int64_t n_out,
+                                  int64_t out_stride, int C, float step, float offset, float *last, hipStream_t stream)
+{
+    if (n_out <= 0 || C <= 0) return hipSuccess;
+    dim3 grid((unsigned)((n_out + 255) / 256), (unsigned)C);
+    hipLaunchKernelGGL(resample_linear_kernel, grid, dim3(256), 0, stream, in, n_in, in_stride, out, n_out, out_stride, step,
+                       offset, last);
+    return hipGetLastError();
+}
+
+hipError_t launch_deinterleave(const float *in, int64_t n_frames, int total, int first, int C, float *out,
+                               int64_t out_stride, hipStream_t stream)
+{
+    if (n_frames <= 0 || C <= 0) return hipSuccess;
+    dim3 grid((unsigned)((n_frames + kTileFrames - 1) / kTileFrames), (unsigned)((C + kTileCh - 1) / kTileCh));
+    hipLaunchKernelGGL(deinterleave_kernel, grid, dim3(256), 0, stream, in, n_frames, total, first, C, out, out_stride);
+    return hipGetLastError();
+}
+
+}  // namespace sd

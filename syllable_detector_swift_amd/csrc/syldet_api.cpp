@@ -92,6 +92,7 @@ struct syldet {
     DeviceBuffer d_stamps;            // diagnostic stamps (SYLDET_FUSED_STAMPS)
     DeviceBuffer d_fused;             // one blob: dfrag | wfrag | koff | bias0 | rvec | w1 | b1 | out_params
     DeviceBuffer d_stage_in, d_stage_out, d_stage_flags, d_stage_idx, d_stage_cnt;
+    DeviceBuffer d_planar;            // channel-major copy of interleaved input (syldet_run_interleaved*)
     hipStream_t stream = nullptr;     // used by the host-pointer entry points
 
     std::vector<std::unique_ptr<ChannelStream>> streams;
@@ -397,7 +398,7 @@ int syldet_destroy(syldet_t *h)
         (void)hipStreamDestroy(h->stream);
     }
     for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
-    for (DeviceBuffer *b : {&h->d_window, &h->d_tw, &h->d_sw, &h->d_params, &h->d_thr, &h->d_columns, &h->d_fused, &h->d_stamps, &h->d_stage_in,
+    for (DeviceBuffer *b : {&h->d_window, &h->d_tw, &h->d_sw, &h->d_params, &h->d_thr, &h->d_columns, &h->d_fused, &h->d_stamps, &h->d_planar, &h->d_stage_in,
                             &h->d_stage_out, &h->d_stage_flags, &h->d_stage_idx, &h->d_stage_cnt})
         b->release();
     delete h;
@@ -489,6 +490,50 @@ int syldet_run(syldet_t *h, const float *samples, int64_t n_samples, int64_t cha
                                 hipMemcpyHostToDevice, h->stream));
     if (int st = run_on_stream(h, (const float *)h->d_stage_in.ptr, n_samples, n_samples, C, (float *)h->d_stage_out.ptr,
                                (uint8_t *)h->d_stage_flags.ptr, h->stream))
+        return st;
+    if (outputs) SYLDET_HIP(hipMemcpyAsync(outputs, h->d_stage_out.ptr, out_bytes, hipMemcpyDeviceToHost, h->stream));
+    if (flags) SYLDET_HIP(hipMemcpyAsync(flags, h->d_stage_flags.ptr, fl_bytes, hipMemcpyDeviceToHost, h->stream));
+    SYLDET_HIP(hipStreamSynchronize(h->stream));
+    return SYLDET_OK;
+}
+
+// ---- interleaved (frame-major) audio: de-interleave on the device, then the batch path ----
+
+int syldet_run_interleaved_device(syldet_t *h, const float *d_interleaved, int64_t n_frames, int32_t total_channels,
+                                  float *d_outputs, uint8_t *d_flags, void *hip_stream)
+{
+    if (!h) return fail(SYLDET_ERR_INVALID_ARGUMENT, "NULL handle");
+    if (total_channels != h->channels) return fail(SYLDET_ERR_INVALID_ARGUMENT, "total_channels must equal the bank's channel count");
+    if (n_frames < 0) return fail(SYLDET_ERR_INVALID_ARGUMENT, "n_frames must be >= 0");
+    if (count_evals(h, n_frames) <= 0) return SYLDET_OK;
+    if (!d_interleaved) return fail(SYLDET_ERR_INVALID_ARGUMENT, "NULL buffer");
+    SYLDET_HIP(hipSetDevice(h->device));
+    const int C = h->channels;
+    if (int st = h->d_planar.reserve((size_t)C * (size_t)n_frames * sizeof(float))) return st;
+    SYLDET_HIP(launch_deinterleave(d_interleaved, n_frames, C, 0, C, (float *)h->d_planar.ptr, n_frames, (hipStream_t)hip_stream));
+    return run_on_stream(h, (const float *)h->d_planar.ptr, n_frames, n_frames, C, d_outputs, d_flags, (hipStream_t)hip_stream);
+}
+
+int syldet_run_interleaved(syldet_t *h, const float *interleaved, int64_t n_frames, int32_t total_channels, float *outputs,
+                           uint8_t *flags)
+{
+    if (!h) return fail(SYLDET_ERR_INVALID_ARGUMENT, "NULL handle");
+    if (total_channels != h->channels) return fail(SYLDET_ERR_INVALID_ARGUMENT, "total_channels must equal the bank's channel count");
+    if (n_frames < 0) return fail(SYLDET_ERR_INVALID_ARGUMENT, "n_frames must be >= 0");
+    const int C = h->channels;
+    const int64_t E = count_evals(h, n_frames);
+    if (E <= 0) return SYLDET_OK;
+    if (!interleaved) return fail(SYLDET_ERR_INVALID_ARGUMENT, "NULL buffer");
+    SYLDET_HIP(hipSetDevice(h->device));
+    const size_t in_bytes = (size_t)C * (size_t)n_frames * sizeof(float);
+    const size_t out_bytes = (size_t)C * (size_t)E * (size_t)h->geom.outputs * sizeof(float);
+    const size_t fl_bytes = (size_t)C * (size_t)E;
+    if (int st = h->d_stage_in.reserve(in_bytes)) return st;
+    if (int st = h->d_stage_out.reserve(out_bytes)) return st;
+    if (int st = h->d_stage_flags.reserve(fl_bytes)) return st;
+    SYLDET_HIP(hipMemcpyAsync(h->d_stage_in.ptr, interleaved, in_bytes, hipMemcpyHostToDevice, h->stream));
+    if (int st = syldet_run_interleaved_device(h, (const float *)h->d_stage_in.ptr, n_frames, total_channels,
+                                               (float *)h->d_stage_out.ptr, (uint8_t *)h->d_stage_flags.ptr, h->stream))
         return st;
     if (outputs) SYLDET_HIP(hipMemcpyAsync(outputs, h->d_stage_out.ptr, out_bytes, hipMemcpyDeviceToHost, h->stream));
     if (flags) SYLDET_HIP(hipMemcpyAsync(flags, h->d_stage_flags.ptr, fl_bytes, hipMemcpyDeviceToHost, h->stream));

@@ -120,6 +120,33 @@ class SyllableDetector:
                                          outputs.data_ptr(), flags.data_ptr(), self._stream_ptr(stream)))
         return outputs, flags
 
+    def runInterleaved(self, frames, outputs=None, flags=None, stream=None):
+        """frames [n, C] (frame-major, as a decoder delivers audio) -> (outputs, flags) like run()."""
+        torch = _torch()
+        if not (frames.is_cuda and frames.dtype == torch.float32 and frames.dim() == 2 and frames.is_contiguous()):
+            raise ValueError("frames must be a contiguous 2-D float32 CUDA tensor [n_frames, channels]")
+        if frames.shape[1] != self.channels or frames.device.index != self.device:
+            raise ValueError("frames must have one column per channel and live on the detector's device")
+        n = int(frames.shape[0])
+        E = max(self.countEvaluations(n), 0)
+        if outputs is None:
+            outputs = torch.empty((self.channels, E, self.geometry.outputs), dtype=torch.float32, device=frames.device)
+        if flags is None:
+            flags = torch.empty((self.channels, E), dtype=torch.uint8, device=frames.device)
+        check(_abi.lib.syldet_run_interleaved_device(self._h, frames.data_ptr(), n, self.channels, outputs.data_ptr(),
+                                                     flags.data_ptr(), self._stream_ptr(stream)))
+        return outputs, flags
+
+    def runInterleavedHost(self, frames: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+        a = np.ascontiguousarray(frames, dtype=np.float32).reshape(-1, self.channels)
+        n = a.shape[0]
+        E = max(self.countEvaluations(n), 0)
+        out = np.zeros((self.channels, E, self.geometry.outputs), np.float32)
+        fl = np.zeros((self.channels, E), np.uint8)
+        check(_abi.lib.syldet_run_interleaved(self._h, a.ctypes.data_as(_abi.c_float_p), n, self.channels,
+                                              out.ctypes.data_as(_abi.c_float_p), fl.ctypes.data_as(_abi.c_uint8_p)))
+        return out, fl
+
     def spectrogram(self, samples, stream=None):
         """samples [C, S] -> columns [C, J, bins] f32 (what processFourierData appends)."""
         torch = _torch()

@@ -1,0 +1,119 @@
+"""The steps either side of the hot path on the device, through the C ABI:
+ResamplerLinear (bit-identical to the oracle's restatement of Resampler.swift:36-69, call after call),
+interleaved -> channel-major (exact), the interleaved batch entry points, and the wide network of
+BASELINE configs[4] on the generic engine."""
+import numpy as np
+import pytest
+
+import pyoracle as po
+import util
+import syllable_detector_swift_amd as sd
+from syllable_detector_swift_amd import _abi, nets, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _torch():
+    import torch
+    return torch
+
+
+@pytest.mark.parametrize("rates", [(44100.0, 22050.0), (48000.0, 44100.0), (44100.0, 48000.0), (22050.0, 44100.0),
+                                   (96000.0, 44100.0), (44100.0, 44100.0), (44100.0, 8000.0)])
+def test_resampler_linear_is_bit_identical_call_after_call(oracle_lib, rates):
+    torch = _torch()
+    C = 3
+    rng = np.random.default_rng(17)
+    chunks = [1000, 1, 2, 777, 4096, 3, 50001, 64, 5]
+    with sd.ResamplerLinear(rates[0], rates[1], channels=C) as r:
+        refs = [po.Resampler(*rates) for _ in range(C)]
+        for n in chunks:
+            x = rng.standard_normal((C, n)).astype(np.float32)
+            want = [refs[c].resample(x[c]) for c in range(C)]
+            assert r.countOutput(n) == len(want[0])
+            got = r.resampleVector(torch.from_numpy(x).cuda())
+            torch.cuda.synchronize()
+            got = got.cpu().numpy()
+            assert got.shape == (C, len(want[0]))
+            for c in range(C):
+                assert np.array_equal(got[c], want[c]), (rates, n, c)
+
+
+def test_resampler_host_arrays_and_single_channel(oracle_lib):
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal(12345).astype(np.float32)
+    ref = po.Resampler(48000.0, 44100.0)
+    with sd.ResamplerLinear(48000.0, 44100.0) as r:
+        for lo, hi in [(0, 5000), (5000, 5001), (5001, 12345)]:
+            assert np.array_equal(r.resampleArray(x[lo:hi]), ref.resample(x[lo:hi]))
+
+
+def test_resampler_feeds_the_detector(oracle_lib):
+    """48 kHz audio -> ResamplerLinear -> detector at 44.1 kHz, all on the device, against the oracle chain."""
+    torch = _torch()
+    cfg = nets.from_npz()
+    x48 = synth.channel(3 * 48000, 5, fs=48000.0)
+    y_ref = po.Resampler(48000.0, 44100.0).resample(x48)
+    o = po.Oracle(po.from_config(cfg))
+    want, _, want64 = o.run(y_ref, po.F64)
+    with sd.ResamplerLinear(48000.0, 44100.0) as r, sd.SyllableDetector(cfg, channels=1) as det:
+        y = r.resampleVector(torch.from_numpy(x48).cuda().reshape(1, -1))
+        out, fl = det.run(y)
+        torch.cuda.synchronize()
+        assert np.array_equal(y.cpu().numpy()[0], y_ref)
+        util.assert_outputs_close(out.cpu().numpy()[0], want)
+        util.assert_flags_exact(fl.cpu().numpy()[0], want64, cfg.thresholds, cfg.rule)
+
+
+@pytest.mark.parametrize("total,first,count,n", [(2, 0, 2, 100000), (7, 2, 3, 4097), (64, 0, 64, 3001), (1, 0, 1, 513), (40, 5, 35, 255)])
+def test_deinterleave_exact(total, first, count, n):
+    torch = _torch()
+    rng = np.random.default_rng(total * 1000 + n)
+    a = rng.standard_normal((n, total)).astype(np.float32)
+    got = sd.deinterleave(torch.from_numpy(a).cuda(), first, count)
+    torch.cuda.synchronize()
+    assert np.array_equal(got.cpu().numpy(), a[:, first:first + count].T)
+
+
+@pytest.mark.parametrize("engine", [_abi.ENGINE_GENERIC, _abi.ENGINE_AUTO])
+def test_interleaved_batch_equals_channel_major_batch(engine):
+    torch = _torch()
+    cfg = nets.from_npz()
+    C, S = 5, 60000
+    x = synth.channels(C, S, first=40, fs=cfg.samplingRate)
+    with sd.SyllableDetector(cfg, channels=C, engine=engine) as det:
+        out, fl = det.run(torch.from_numpy(x).cuda())
+        out_i, fl_i = det.runInterleaved(torch.from_numpy(np.ascontiguousarray(x.T)).cuda())
+        torch.cuda.synchronize()
+        assert torch.equal(out, out_i) and torch.equal(fl, fl_i)
+        out_h, fl_h = det.runInterleavedHost(np.ascontiguousarray(x.T))
+        assert np.array_equal(out_h, out.cpu().numpy()) and np.array_equal(fl_h, fl.cpu().numpy())
+        # too short for one evaluation: nothing happens
+        o0, f0 = det.runInterleavedHost(np.zeros((100, C), np.float32))
+        assert o0.shape == (C, 0, 1) and f0.shape == (C, 0)
+
+
+def test_interleaved_batch_rejects_a_wrong_channel_count():
+    cfg = nets.from_npz()
+    with sd.SyllableDetector(cfg, channels=2) as det:
+        a = np.zeros((5000, 3), np.float32)
+        out = np.zeros((2, 1, 1), np.float32)
+        st = _abi.lib.syldet_run_interleaved(det._h, a.ctypes.data_as(_abi.c_float_p), 5000, 3,
+                                             out.ctypes.data_as(_abi.c_float_p), None)
+        assert st == _abi.ERR_INVALID_ARGUMENT
+
+
+def test_wide_network_config5_on_the_generic_engine(oracle_lib):
+    """BASELINE configs[4]: sample.txt front end, 290 -> 4096 TanSig -> 1 PureLin.  fp32 here (the bf16 MFMA
+    epilogue is future work), so the 1e-5 bar applies unchanged."""
+    torch = _torch()
+    cfg = nets.wide_mlp(nets.from_npz())
+    x = synth.channel(40000, 9, fs=cfg.samplingRate)
+    o = po.Oracle(po.from_config(cfg))
+    want, _, want64 = o.run(x, po.F64)
+    with sd.SyllableDetector(cfg, channels=1) as det:
+        assert det.geometry.engine == _abi.ENGINE_GENERIC
+        out, fl = det.run(torch.from_numpy(x).cuda().reshape(1, -1))
+        torch.cuda.synchronize()
+        util.assert_outputs_close(out.cpu().numpy()[0], want)
+        util.assert_flags_exact(fl.cpu().numpy()[0], want64, cfg.thresholds, cfg.rule)
