@@ -8,6 +8,7 @@
 //   appendAudioData(_:withSamples:)                               :129-132
 //   processNewValue() -> Bool                                     :153-217
 //   lastOutputs / lastDetected / seenSyllable()                   :26-31, :220-230
+//   ResamplerLinear(fromRate:toRate:).resampleVector / resampleArray  Common/Resampler.swift:20-76
 // Swift's fatalError becomes syldetxx::FatalError (a std::runtime_error carrying the status);
 // ParseError keeps its four kinds.  A detector here is one channel of a bank; `SyllableDetectorBank`
 // is the batched form the MI355X engine is built around.
@@ -136,6 +137,40 @@ public:
 private:
     SyllableDetectorBank &bank_;
     int channel_;
+};
+
+// ResamplerLinear (Resampler.swift:20-76) for `channels` streams fed in lock-step; state carries over between calls.
+class ResamplerLinear {
+public:
+    ResamplerLinear(double fromRate, double toRate, int channels = 1, int device = 0) : channels_(channels)
+    {
+        check(syldet_resampler_create(fromRate, toRate, channels, device, &r_));
+    }
+    ~ResamplerLinear() { syldet_resampler_destroy(r_); }
+    ResamplerLinear(const ResamplerLinear &) = delete;
+    ResamplerLinear &operator=(const ResamplerLinear &) = delete;
+
+    // host rows [channels][n] -> [channels][returned length]   (resampleArray, :71-75)
+    std::vector<float> resampleArray(const std::vector<float> &arr)
+    {
+        const int64_t n = (int64_t)(arr.size() / (size_t)channels_), m = syldet_resampler_count(r_, n);
+        std::vector<float> out((size_t)channels_ * (size_t)(m > 0 ? m : 0));
+        int64_t got = 0;
+        check(syldet_resample(r_, arr.data(), n, n, out.data(), m > 0 ? m : 1, &got));
+        return out;
+    }
+    // device rows, asynchronous on `hipStream`   (resampleVector, :36-69)
+    int64_t resampleVector(const float *d_data, int64_t n, int64_t stride, float *d_out, int64_t out_stride, void *hipStream)
+    {
+        int64_t got = 0;
+        check(syldet_resample_device(r_, d_data, n, stride, d_out, out_stride, &got, hipStream));
+        return got;
+    }
+    int64_t countOutput(int64_t n) const { return syldet_resampler_count(r_, n); }
+
+private:
+    syldet_resampler_t *r_ = nullptr;
+    int channels_;
 };
 
 }  // namespace syldetxx
