@@ -128,6 +128,40 @@ __device__ __forceinline__ void split_pair_scaled(float a, float b, float sx, un
     lo = l;
 }
 
+// Cross-lane helpers without LDS round trips (a ds_bpermute costs an LDS latency on the critical path each):
+// gfx950's v_permlane16_swap / v_permlane32_swap exchange 16-lane rows / 32-lane halves between two registers.
+// With both operands = x the two results are x and its xor-16 (xor-32) partner, in some order per lane.
+__device__ __forceinline__ float xor16_sum(float x)
+{
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor32_sum(float x)
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// value of the lane 16 rows up (lane + 16) for lanes of even rows; own value for odd rows
+__device__ __forceinline__ float from_next_row(float x)
+{
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[1]);
+}
+// maximum over the wave of a non-negative float (compared as bit patterns), wave-uniform result
+__device__ __forceinline__ float wave_max_nonneg(float x)
+{
+    unsigned u = __float_as_uint(x);
+    u = max(u, (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0xB1, 0xF, 0xF, false));    // quad_perm [1,0,3,2]
+    u = max(u, (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0x4E, 0xF, 0xF, false));    // quad_perm [2,3,0,1]
+    u = max(u, (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0x141, 0xF, 0xF, false));   // row_half_mirror
+    u = max(u, (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0x140, 0xF, 0xF, false));   // row_mirror
+    auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    u = max(r[0], r[1]);
+    r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    u = max(r[0], r[1]);
+    return __uint_as_float(__builtin_amdgcn_readfirstlane(u));
+}
+
 // Diagnostic stamps (STAMP instantiation only; never the shipped path): s_memtime at phase boundaries,
 // read back (one wait) at the end of the pass so the stamps do not drain the memory pipelines in between.
 #define SD_TICK(slot)                                                                      \
@@ -252,8 +286,7 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
                 const floatx4 q = as_floatx4(v[k]);
                 amax = absmax3(absmax3(amax, q[0], q[1]), q[2], q[3]);
             }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+        amax = wave_max_nonneg(amax);                        // v_max3 drops NaNs: amax is a plain non-negative number
         if (lane == 0) red[wave] = amax;
     };
     // block floating point: the pass's largest sample goes to [2^13, 2^14); returns the scale's exponent
@@ -343,7 +376,8 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
             alpha = zs; beta = 0.0f;                          // layer-0 input = alpha * z + beta * rvec + bias0
             if (norm == 1) {                                  // L2Normalize, NeuralNet.swift:47-59
                 const float zst = d.stat_row & 2 ? (d.stat_row & 1 ? z[3] : z[2]) : (d.stat_row & 1 ? z[1] : z[0]);
-                const float ssw = __shfl(zst, (d.stat_row >> 2) * 16 + f, 64);
+                // the statistic row lives in lane group stat_row >> 2; LEAN: group 0 (own lane) or 1 (the next row)
+                const float ssw = LEAN ? ((d.stat_row >> 2) ? from_next_row(zst) : zst) : __shfl(zst, (d.stat_row >> 2) * 16 + f, 64);
                 alpha = d.w_unscale * (scaling != 0 ? 0.125f : 0.0009765625f) * __builtin_amdgcn_rsqf(ssw);   // 2^-3 | 2^-10
             } else if (norm == 2) {                           // Normalize, :69-96
                 float mn = INFINITY, mx = -INFINITY;
@@ -585,8 +619,7 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
                 float ss = 0.0f;
 #pragma unroll
                 for (int i = 0; i < 8; i++) ss = fmaf(cval[i], cval[i], ss);
-                ss += __shfl_xor(ss, 16, 64);
-                ss += __shfl_xor(ss, 32, 64);
+                ss = xor32_sum(xor16_sum(ss));
                 ss *= scaling != 0 ? 0.015625f : 9.5367431640625e-07f;   // 2^-6 (log/dB values) or 2^-20
                 const float ss_hi = __uint_as_float(__float_as_uint(ss) & 0xFFFFE000u);
                 const float ss_lo = (ss - ss_hi) * 2048.0f;
