@@ -377,7 +377,8 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
             if (norm == 1) {                                  // L2Normalize, NeuralNet.swift:47-59
                 const float zst = d.stat_row & 2 ? (d.stat_row & 1 ? z[3] : z[2]) : (d.stat_row & 1 ? z[1] : z[0]);
                 // the statistic row lives in lane group stat_row >> 2; LEAN: group 0 (own lane) or 1 (the next row)
-                const float ssw = LEAN ? ((d.stat_row >> 2) ? from_next_row(zst) : zst) : __shfl(zst, (d.stat_row >> 2) * 16 + f, 64);
+                const float zst_up = from_next_row(zst);      // unconditional: a cross-lane operation inside a select becomes a branch
+                const float ssw = LEAN ? ((d.stat_row >> 2) ? zst_up : zst) : __shfl(zst, (d.stat_row >> 2) * 16 + f, 64);
                 alpha = d.w_unscale * (scaling != 0 ? 0.125f : 0.0009765625f) * __builtin_amdgcn_rsqf(ssw);   // 2^-3 | 2^-10
             } else if (norm == 2) {                           // Normalize, :69-96
                 float mn = INFINITY, mx = -INFINITY;
