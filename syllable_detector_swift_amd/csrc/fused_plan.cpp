@@ -101,9 +101,8 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
         else if (k0 == SYLDET_FN_NORMALIZE) { norm = 2; first_affine = 1; }
         else if (k0 == SYLDET_FN_NORMALIZESTD) { norm = 3; first_affine = 1; }
     }
-    // l2normalize: the sum of squares takes two spare bins (F, F+1) and one spare result row (index H)
-    if (F > (norm == 1 ? 30 : 32)) return no("too many bins");
-    if (H > (norm == 1 ? 15 : 16)) return no("first layer too wide");
+    if (F > 32) return no("too many bins");
+    if (H > 16) return no("first layer too wide");
     std::vector<double> a((size_t)I, 1.0), b((size_t)I, 0.0);
     for (int k = first_affine; k < c.n_input_fns; k++) {
         const syldet_fn_t &f = c.input_fns[k];
@@ -137,13 +136,6 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
     d.nsmp = nsmp; d.nload = nload; d.skew = skew;
     d.hop_magic = (unsigned)((0x100000000ull + (unsigned)hop - 1) / (unsigned)hop);
     d.ps = PS; d.smp_stride = nsmp_p;
-    // a lane of group g4 holds bins 4*g4 + j (value index j) and 16 + 4*g4 + j (value index 4 + j)
-    d.stat_bin = norm == 1 ? F : -1;
-    d.stat_g4 = (F & 15) >> 2;
-    d.stat_i = 4 * (F >> 4) + (F & 3);
-    d.stat_g4b = ((F + 1) & 15) >> 2;
-    d.stat_ib = 4 * ((F + 1) >> 4) + ((F + 1) & 3);
-    d.stat_row = H;
     int off = 0;
     auto take = [&off](int bytes) { const int o = off; off += (bytes + 15) / 16 * 16; return o; };
     d.lds_dfrag = take(KS * 8 * 1024);
@@ -201,7 +193,6 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
 
     // ---- folded first layer, one fragment pair per tap: A operand of v_mfma_f32_16x16x32_f16, lane l holds
     // row l&15 (hidden unit), k = 8*(l>>4) + j (bin):  W'_t[h][f] = W0[h][t*F+f] * a[t*F+f], scaled by 2^wexp.
-    // l2normalize adds row H with a unit weight on bin F (where the kernel puts the column's sum of squares).
     double wmax = 0.0;
     for (int h = 0; h < H; h++)
         for (int i = 0; i < I; i++) wmax = std::max(wmax, std::fabs((double)L0.weights[(size_t)h * I + i] * a[(size_t)i]));
@@ -217,8 +208,6 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
                 const int h = l & 15, bin = 8 * (l >> 4) + j;
                 double v = 0.0;
                 if (h < H && bin < F) v = (double)L0.weights[(size_t)h * I + t * F + bin] * a[(size_t)(t * F + bin)] * wscale;
-                else if (norm == 1 && h == H && bin == F) v = 1.0;
-                else if (norm == 1 && h == H && bin == F + 1) v = 1.0 / 2048.0;
                 uint16_t hi, lo;
                 split_half(v, hi, lo);
                 p.afrag[(((size_t)t * 2 + 0) * 64 + l) * 8 + j] = hi;

@@ -82,8 +82,6 @@ struct FusedDesc {
     int runs, seg_evals;        // passes per workgroup, evaluations per workgroup segment
     int ps;                     // column slots per team buffer (chunk frames + T - 1)
     int smp_stride;             // floats between the two teams' sample regions
-    int stat_bin, stat_g4, stat_i, stat_g4b, stat_ib, stat_row;   // l2normalize: the sum of squares rides in bins F, F+1
-                                // (lane group, value index inside the lane); row H of the first-layer result
     int col_shift;              // |X| columns are stored as |X| * 2^(cse - col_shift) (2x for |X|^2)
     float w_unscale;            // 1 / (power-of-two scale of the folded first-layer weights)
     int lds_dfrag, lds_smp, lds_colh, lds_coll, lds_stat, lds_red, lds_cst, lds_total;   // byte offsets

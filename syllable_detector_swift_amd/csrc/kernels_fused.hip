@@ -21,9 +21,9 @@
 //   2. |X| columns (f16 hi/lo) go to a small LDS buffer [frame][bin].  The first network layer,
 //      folded with the affine input maps into W' = W0 o gain, is  Z[h, e] = sum_t W'_t[h, :] . C[:, e+t]:
 //      again a GEMM (K = 32 bins per tap) whose B operand for tap t is the column buffer at row
-//      offset e + t.  For l2normalize the per-frame sum of squares rides along in two spare bins with
-//      weights in one more row, so the window's norm falls out of the same MFMAs.  An evaluation
-//      then finishes in registers: scale, transfer function, second layer, reverse map, threshold.
+//      offset e + t.  The normalisers' per-frame statistics (sum of squares, min/max, mean/M2) sit in a
+//      small fp32 array next to the columns and are combined per window.  An evaluation then finishes
+//      in registers: scale, transfer function, second layer, reverse map, threshold.
 // Every frame is transformed once (the reference re-reads each column T times).
 //
 // Workgroup = 8 waves x 16 frames = one 128-frame pass at a time over the workgroup's segment of one
@@ -140,12 +140,6 @@ __device__ __forceinline__ float xor32_sum(float x)
 {
     const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-// value of the lane 16 rows up (lane + 16) for lanes of even rows; own value for odd rows
-__device__ __forceinline__ float from_next_row(float x)
-{
-    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-    return __uint_as_float(r[1]);
 }
 // maximum over the wave of a non-negative float (compared as bit patterns), wave-uniform result
 __device__ __forceinline__ float wave_max_nonneg(float x)
@@ -331,8 +325,9 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
     // ---- evaluation of one pass in eight steps, so that it can ride along with the NEXT pass's matrix work:
     // the first layer as a shifted GEMM over the column buffer (steps 0-2), the rest of the network in registers
     // (3-5), stores (6).  This wave finishes evaluation slots 16*wave .. +15 of the pass (slot q: e = e_b + 128 pp -
-    // (T-1) + q, columns q .. q+T-1): result column = f, rows 4*g4 + j = hidden unit (row H = window sum of squares).
+    // (T-1) + q, columns q .. q+T-1): result column = f, rows 4*g4 + j = hidden unit.
     floatx4 z = {0.0f, 0.0f, 0.0f, 0.0f}, z2 = {0.0f, 0.0f, 0.0f, 0.0f};
+    float ssw = 1.0f;                                         // l2normalize: the window's sum of squares
     float alpha = 0.0f, beta = 0.0f, act[4] = {0.0f, 0.0f, 0.0f, 0.0f}, yv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     bool hit = false;
     constexpr int kAhead = 3;                                 // column fragments are fetched this many taps ahead
@@ -370,16 +365,20 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
         } else if (step == 2) {
             gemm0_taps(n1, T);
             z += z2;
+            if (norm == 1) {                                  // sum of squares of the window = of its T frames (fp32, LDS)
+                float acc_ss = 0.0f;
+#pragma unroll
+                for (int t = 0; t < TMAX; t++)
+                    if (t < T) acc_ss += stat[fl + t];
+                ssw = acc_ss;
+            }
         } else if (step == 3) {
             const float cs = scaling != 0 ? 1.0f : (power_mode ? pow2f(2 * (cse_pp - d.col_shift)) : pow2f(cse_pp - d.col_shift));
             const float zs = d.w_unscale / cs;                // first-layer sums back to true units
             alpha = zs; beta = 0.0f;                          // layer-0 input = alpha * z + beta * rvec + bias0
             if (norm == 1) {                                  // L2Normalize, NeuralNet.swift:47-59
-                const float zst = d.stat_row & 2 ? (d.stat_row & 1 ? z[3] : z[2]) : (d.stat_row & 1 ? z[1] : z[0]);
-                // the statistic row lives in lane group stat_row >> 2; LEAN: group 0 (own lane) or 1 (the next row)
-                const float zst_up = from_next_row(zst);      // unconditional: a cross-lane operation inside a select becomes a branch
-                const float ssw = LEAN ? ((d.stat_row >> 2) ? zst_up : zst) : __shfl(zst, (d.stat_row >> 2) * 16 + f, 64);
-                alpha = d.w_unscale * (scaling != 0 ? 0.125f : 0.0009765625f) * __builtin_amdgcn_rsqf(ssw);   // 2^-3 | 2^-10
+                // z and the per-frame sums of squares are both in column units: layer-0 input = W0 . v / |v|
+                alpha = d.w_unscale * __builtin_amdgcn_rsqf(ssw);
             } else if (norm == 2) {                           // Normalize, :69-96
                 float mn = INFINITY, mx = -INFINITY;
                 for (int t = 0; t < T; t++) { mn = fminf(mn, stat[fl + t]); mx = fmaxf(mx, stat[PS + fl + t]); }
@@ -533,20 +532,17 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
                 const int w = hi_arr ? i : i - words;
                 unsigned u = reinterpret_cast<const unsigned *>(hi_arr ? colh : coll)[kPass * (kColStride / 2) + w];
                 if (dexp != 0) {
-                    const int bin = 2 * (w % (kColStride / 2));
                     union { unsigned u; _Float16 h[2]; } x;
                     x.u = u;
-                    // the two statistic bins hold a sum of squares: they scale with the square
-                    const bool st0 = norm == 1 && (bin == d.stat_bin || bin == d.stat_bin + 1);
-                    const bool st1 = norm == 1 && (bin + 1 == d.stat_bin || bin == d.stat_bin);
-                    const float f0 = (float)x.h[0] * pow2f(st0 ? 2 * dexp : dexp);
-                    const float f1 = (float)x.h[1] * pow2f(st1 ? 2 * dexp : dexp);
+                    const float f0 = (float)x.h[0] * pow2f(dexp);
+                    const float f1 = (float)x.h[1] * pow2f(dexp);
                     union { decltype(__builtin_amdgcn_cvt_pkrtz(0.f, 0.f)) h; unsigned u; } y;
                     y.h = __builtin_amdgcn_cvt_pkrtz(f0, f1);
                     u = y.u;
                 }
                 reinterpret_cast<unsigned *>(hi_arr ? colh : coll)[w] = u;
             }
+            if (norm == 1 && lane < T - 1) stat[lane] = stat[kPass + lane] * pow2f(2 * dexp);   // sums of squares of scaled columns
             if (norm >= 2 && lane < T - 1) {
                 stat[lane] = stat[kPass + lane];
                 stat[PS + lane] = stat[PS + kPass + lane];
@@ -614,21 +610,12 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
                 for (int i = 0; i < 8; i++) cval[i] *= cs;
             }
             if (norm == 1) {
-                // sum of squares of the (scaled) column rides in two spare bins: its top 11 bits in bin F and the
-                // remainder, scaled by 2^11 so that it stays a normal f16, in bin F+1 (weights 1 and 2^-11 in row H
-                // of the first-layer fragments) -- together exact to fp32, whatever the column's level
+                // sum of squares of the (scaled) column, fp32, one value per frame next to the columns
                 float ss = 0.0f;
 #pragma unroll
                 for (int i = 0; i < 8; i++) ss = fmaf(cval[i], cval[i], ss);
                 ss = xor32_sum(xor16_sum(ss));
-                ss *= scaling != 0 ? 0.015625f : 9.5367431640625e-07f;   // 2^-6 (log/dB values) or 2^-20
-                const float ss_hi = __uint_as_float(__float_as_uint(ss) & 0xFFFFE000u);
-                const float ss_lo = (ss - ss_hi) * 2048.0f;
-#pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    cval[i] = (g4 == d.stat_g4 && i == d.stat_i) ? ss_hi : cval[i];
-                    cval[i] = (g4 == d.stat_g4b && i == d.stat_ib) ? ss_lo : cval[i];
-                }
+                if (g4 == 0) stat[slot] = ss;
             }
             {
                 _Float16 *ph = colh + slot * kColStride + 4 * g4, *pl = coll + slot * kColStride + 4 * g4;

@@ -1,0 +1,98 @@
+"""Seeded random sweep over the configuration space the fused engine accepts (windows, gaps, zero padding, bin
+ranges, timeRange, layer shapes, input chains, scalings, spectrum modes, output rules, lengths, channel counts):
+every draw is checked against the oracle's fp64 anchor to the 1e-5 bar, flags exactly, on whichever engine
+`AUTO` selects -- and most draws must land on the fused one."""
+import os
+
+import numpy as np
+import pytest
+
+import pyoracle as po
+import util
+import syllable_detector_swift_amd as sd
+from syllable_detector_swift_amd import _abi, nets, synth
+from syllable_detector_swift_amd.config import SyllableDetectorConfig, frequencyIndexRange
+
+pytestmark = pytest.mark.gpu
+
+FS = 44100.0
+
+
+def draw(rng):
+    W = int(rng.choice([32, 64, 96, 128, 192, 256]))
+    N = 1 << int(np.ceil(np.log2(W)))
+    if rng.random() < 0.3 and N < 512:
+        N *= 2                                                   # zero padding
+    if rng.random() < 0.15:
+        ov = -4 * int(rng.integers(1, 9))                        # a gap between windows
+    else:
+        ov = 4 * int(rng.integers(0, W // 8 + 1))                # hop = W - ov stays a multiple of 4
+        ov = min(ov, W - 4)
+    hop = max(0, -ov) + W - max(0, ov)
+    if hop % 4 or hop > 140:
+        ov = W - 4 * int(rng.integers(max(1, (W - 140 + 3) // 4), W // 4))
+        ov = min(max(ov, -32), W - 4)
+    # a band of at most 30 bins somewhere below Nyquist
+    f0 = int(rng.integers(0, N // 2 - 2))
+    F = int(rng.integers(1, min(30, N // 2 - f0) + 1))
+    lo, hi = (f0 - 0.4) * FS / N, (f0 + F - 1 + 0.4) * FS / N
+    lo = max(lo, 0.0)
+    r = frequencyIndexRange(N, FS, lo, hi)
+    F = r[1] - r[0]
+    T = int(rng.integers(1, 13))
+    chain = [(), ("l2normalize",), ("l2normalize", "mapminmax"), ("normalize",), ("normalizestd", "mapstd"), ("mapminmax",),
+             ("mapstd", "mapminmax")][int(rng.integers(0, 7))]
+    scaling = ["linear", "linear", "log", "db"][int(rng.integers(0, 4))]
+    two_layers = rng.random() < 0.8
+    H = int(rng.integers(1, 15 if chain[:1] == ("l2normalize",) else 16))
+    n_out = int(rng.integers(1, 5)) if two_layers else H
+    if not two_layers:
+        n_out = min(H, 4)
+        H = n_out
+    tfs = ["TanSig", "LogSig", "PureLin", "SatLin"]
+    net = nets.random_net(rng, F * T, (H,) if two_layers else (), n_out,
+                          transfer=(tfs[int(rng.integers(0, 4))], tfs[int(rng.integers(0, 4))]), in_fns=chain,
+                          out_fns=[(), ("mapminmax",), ("mapstd",), ("mapminmax", "mapstd")][int(rng.integers(0, 4))])
+    cfg = SyllableDetectorConfig(FS, N, W, ov, (lo, hi), T, scaling, [float(x) for x in rng.uniform(-0.5, 0.8, n_out)], net,
+                                 window=int(rng.integers(0, 4)), spectrum=int(rng.integers(0, 2)), rule=int(rng.integers(0, 2)))
+    return cfg
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SYLDET_FUZZ_DRAWS", "48"))))   # more draws: SYLDET_FUZZ_DRAWS=1000
+def test_random_configuration(oracle_lib, seed):
+    import torch
+    rng = np.random.default_rng(9000 + seed)
+    cfg = draw(rng)
+    C = int(rng.integers(1, 4))
+    hop = max(0, -cfg.windowOverlap) + cfg.windowLength - max(0, cfg.windowOverlap)
+    frames = int(rng.integers(cfg.timeRange, 700))
+    S = max(0, -cfg.windowOverlap) + cfg.windowLength + (frames - 1) * hop + int(rng.integers(0, hop))
+    level = float(10.0 ** rng.uniform(-3, 1))
+    x = (synth.channels(C, S, first=seed * 7, fs=FS) * level).astype(np.float32)
+    o = util.oracle_for(cfg)
+    with sd.SyllableDetector(cfg, channels=C) as det:
+        out, fl = det.run(torch.from_numpy(x).cuda())
+        torch.cuda.synchronize()
+        out, fl = out.cpu().numpy(), fl.cpu().numpy()
+        engine = det.geometry.engine
+    for c in range(C):
+        w32, _, w64 = o.run(x[c], po.F64, cfg.rule)
+        ok = np.isfinite(w64).all(axis=1)
+        assert out[c].shape == w64.shape
+        assert (np.isfinite(out[c]).all(axis=1) == ok).all(), "NaN/inf evaluations must coincide"
+        # log / dB of near-empty bins is ill-conditioned: where the oracle's own fp32 port is off by more than the bar,
+        # the bar widens to twice that (the reference computes in fp32 too)
+        o32 = o.run(x[c], po.F32, cfg.rule)[0]
+        own = float((np.abs(o32[ok] - w64[ok]) / np.maximum(1.0, np.abs(w64[ok]))).max()) if ok.any() else 0.0
+        tol = max(util.TOL, 2.0 * own)
+        util.assert_outputs_close(out[c][ok], w64[ok], tol)
+        util.assert_flags_exact(fl[c][ok], w64[ok], cfg.thresholds, cfg.rule, tol)
+        assert not fl[c][~ok].any()
+    test_random_configuration.engines = getattr(test_random_configuration, "engines", []) + [engine]
+
+
+def test_most_draws_run_on_the_fused_engine():
+    engines = getattr(test_random_configuration, "engines", [])
+    if len(engines) < 40:
+        pytest.skip("runs after the sweep")
+    assert sum(e == _abi.ENGINE_FUSED for e in engines) >= len(engines) * 0.6, engines
