@@ -80,6 +80,9 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
     p = FusedPlan();
     auto no = [&p](const char *why) { p.reason = why; return false; };
     const int N = c.fourier_length, W = c.window_length, F = g.bins, T = c.time_range;
+    // |X|^2 columns (extractMagnitude, CircularShortTimeFourierTransform.swift:221-278; never used by the detector) square the
+    // dynamic range: one f16 scale per pass cannot hold a quiet pass next to a loud one.  Generic engine.
+    if (c.spectrum == SYLDET_SPECTRUM_MAGNITUDE) return no("|X|^2 columns");
     if (g.hop % 4 != 0) return no("hop is not a multiple of 4");
     if (W > 256) return no("window longer than 256 samples");
     if (W % 4 != 0) return no("window length is not a multiple of 4");
@@ -125,11 +128,11 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
     const int skew = (hop % 16 == 0) ? 4 : 0;
     auto skewed = [&](int i) { return i + skew * (i / hop); };
     const int nsmp_p = (skewed(nsmp + 16) + 15) / 8 * 8;
-    const int PS = kFusedTileFrames + T - 1;
+    const int PS = kFusedTileFrames + 2 * (T - 1);   // transition strip + the pass's own columns
 
     FusedDesc &d = p.desc;
     d.W = W; d.KS = KS; d.hop = hop; d.gap = g.gap; d.F = F; d.T = T; d.H = H; d.norm = norm;
-    d.scaling = c.scaling; d.power_mode = c.spectrum == SYLDET_SPECTRUM_MAGNITUDE ? 1 : 0;
+    d.scaling = c.scaling;
     d.n_layers = c.n_layers; d.n_out = n_out; d.tf0 = L0.transfer;
     d.tf1 = c.n_layers == 2 ? c.layers[1].transfer : SYLDET_TF_PURELIN;
     d.rule = c.rule; d.n_out_fns = c.n_output_fns; d.I = I;
@@ -188,7 +191,6 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
             rowsum_max = std::max(rowsum_max, std::sqrt(sr * sr + si * si));
         }
         d.col_shift = (int)std::ceil(std::log2(rowsum_max)) + 1;   // 2^14 * rowsum * 2^-shift <= 2^13
-        if (d.power_mode) d.col_shift += 7;                         // squares: 2^(2 * 13) * 2^-(2*7) = 2^12 ... stays < 2^13
     }
 
     // ---- folded first layer, one fragment pair per tap: A operand of v_mfma_f32_16x16x32_f16, lane l holds

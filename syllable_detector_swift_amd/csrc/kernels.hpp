@@ -73,15 +73,15 @@ struct FusedDesc {
     int hop, gap, F, T;         // frame advance, leading gap, bins, timeRange
     int H;                      // first-layer outputs
     int norm;                   // 0 none, 1 l2normalize, 2 normalize, 3 normalizestd (first input fn)
-    int scaling, power_mode;
+    int scaling;
     int n_layers, n_out, tf0, tf1, rule, n_out_fns;
     int I;                      // F*T
     int nsmp, nload;            // samples staged per pass, float4 loads per thread
     int skew;                   // floats of padding after every `hop` staged samples (bank spreading)
     unsigned hop_magic;         // ceil(2^32 / hop): i / hop == umulhi(i, hop_magic) for i < 2^16
     int runs, seg_evals;        // passes per workgroup, evaluations per workgroup segment
-    int ps;                     // column slots per team buffer (chunk frames + T - 1)
-    int smp_stride;             // floats between the two teams' sample regions
+    int ps;                     // column slots: 2 (T - 1) for the transition strip + 128 for the pass
+    int smp_stride;             // halves between the hi and the lo array of the staged samples
     int col_shift;              // |X| columns are stored as |X| * 2^(cse - col_shift) (2x for |X|^2)
     float w_unscale;            // 1 / (power-of-two scale of the folded first-layer weights)
     int lds_dfrag, lds_smp, lds_colh, lds_coll, lds_stat, lds_red, lds_cst, lds_total;   // byte offsets

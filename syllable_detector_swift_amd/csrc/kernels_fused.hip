@@ -205,9 +205,10 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
     if (e_b >= E) return;
     const int64_t e_e = (e_b + d.seg_evals < E) ? e_b + d.seg_evals : E;
     const float *row = samples + (int64_t)c * stride;
-    const int PS = d.ps, T = EXACT ? TMAX : d.T, H = d.H;      // PS: column slots = 128 + T - 1
+    const int PS = d.ps, T = EXACT ? TMAX : d.T, H = d.H;      // PS: column slots = 2 (T - 1) transition slots + 128
+    const int XS = 2 * (T - 1);                                 // the pass's own columns start at slot XS
     const int nload = EXACT ? NL : d.nload;
-    const int norm = LEAN ? 1 : d.norm, scaling = LEAN ? 0 : d.scaling, power_mode = LEAN ? 0 : d.power_mode;
+    const int norm = LEAN ? 1 : d.norm, scaling = LEAN ? 0 : d.scaling;
     const int n_layers = LEAN ? 2 : d.n_layers, n_out = LEAN ? 1 : d.n_out, tf0 = LEAN ? 0 : d.tf0, tf1 = LEAN ? 2 : d.tf1;
     const int fl = 16 * wave + f;     // this lane's frame / evaluation slot inside the pass
     const int runs = d.runs;
@@ -287,8 +288,7 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
     auto pass_scale = [&](floatx4 r0, floatx4 r1) {
         const float amax = fmaxf(fmaxf(fmaxf(r0[0], r0[1]), fmaxf(r0[2], r0[3])), fmaxf(fmaxf(r1[0], r1[1]), fmaxf(r1[2], r1[3])));
         int e = 13 - (int)((__float_as_uint(amax) >> 23) & 0xffu) + 127;
-        const int lim = power_mode ? 40 : 100;
-        e = amax > 0.0f ? (e < -lim ? -lim : (e > lim ? lim : e)) : 0;
+        e = amax > 0.0f ? (e < -100 ? -100 : (e > 100 ? 100 : e)) : 0;
         return __builtin_amdgcn_readfirstlane(e);
     };
     // quads in v[] -> scaled, split into f16 hi + lo, -> the staged region
@@ -317,7 +317,7 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
     se_next = pass_scale(*reinterpret_cast<const floatx4 *>(red), *reinterpret_cast<const floatx4 *>(red + 4));
     stage_pass(se_next);
     load_pass(1);                     // arrives during the first pass's matrix work
-    int se = 0, cse = 0, se_prev = 0, cse_prev = 0;   // sample / column scale exponents of this pass and the one before
+    int se = 0, cse = 0, se_prev = 0;   // sample / column scale exponents of this pass, sample scale of the one before
     unsigned long long tsum[16] = {0}, tick[8] = {0};
     if (STAMP) tick[5] = __builtin_amdgcn_s_memtime();
     __syncthreads();
@@ -332,7 +332,11 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
     bool hit = false;
     constexpr int kAhead = 3;                                 // column fragments are fetched this many taps ahead
     uint32x4 bh_q[kAhead], bl_q[kAhead];
-    const _Float16 *bph = colh + fl * kColStride + 8 * g4, *bpl = coll + fl * kColStride + 8 * g4;
+    // Evaluation slot q < T-1 straddles two passes: its window is the transition strip [T-1 carried columns | copies of
+    // this pass's first T-1 columns], kept at a scale both passes fit in; every other window reads the pass's own
+    // columns at the pass's own scale.  Either way the window is T consecutive slots starting at `wslot`.
+    const int wslot = fl < T - 1 ? fl : XS + fl - (T - 1);
+    const _Float16 *bph = colh + wslot * kColStride + 8 * g4, *bpl = coll + wslot * kColStride + 8 * g4;
     auto gemm0_taps = [&](int t0, int t1) {
 #pragma unroll
         for (int t = 0; t < TMAX; t++) {
@@ -348,7 +352,8 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
             }
         }
     };
-    auto post_step = [&](int step, int pp, int cse_pp) {
+    auto post_step = [&](int step, int pp, int cse_own, int cse_x) {
+        const int cse_pp = fl < T - 1 ? cse_x : cse_own;      // column scale of this lane's window
         const int n0 = (T + 2) / 3, n1 = n0 + (T - n0 + 1) / 2;   // taps [0,n0), [n0,n1), [n1,T)
         if (step == 0) {
             z = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -369,11 +374,11 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
                 float acc_ss = 0.0f;
 #pragma unroll
                 for (int t = 0; t < TMAX; t++)
-                    if (t < T) acc_ss += stat[fl + t];
+                    if (t < T) acc_ss += stat[wslot + t];
                 ssw = acc_ss;
             }
         } else if (step == 3) {
-            const float cs = scaling != 0 ? 1.0f : (power_mode ? pow2f(2 * (cse_pp - d.col_shift)) : pow2f(cse_pp - d.col_shift));
+            const float cs = scaling != 0 ? 1.0f : pow2f(cse_pp - d.col_shift);
             const float zs = d.w_unscale / cs;                // first-layer sums back to true units
             alpha = zs; beta = 0.0f;                          // layer-0 input = alpha * z + beta * rvec + bias0
             if (norm == 1) {                                  // L2Normalize, NeuralNet.swift:47-59
@@ -381,16 +386,16 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
                 alpha = d.w_unscale * __builtin_amdgcn_rsqf(ssw);
             } else if (norm == 2) {                           // Normalize, :69-96
                 float mn = INFINITY, mx = -INFINITY;
-                for (int t = 0; t < T; t++) { mn = fminf(mn, stat[fl + t]); mx = fmaxf(mx, stat[PS + fl + t]); }
+                for (int t = 0; t < T; t++) { mn = fminf(mn, stat[wslot + t]); mx = fmaxf(mx, stat[PS + wslot + t]); }
                 const float range = mx - mn;
                 if (range == 0.0f) { alpha = 0.0f; beta = -1.0f; }
                 else { alpha = zs * 2.0f / range; beta = (0.0f - mn - mx) / range; }
             } else if (norm == 3) {                           // NormalizeStd, :105-108 (population sigma)
                 float nn = 0.0f, mean = 0.0f, m2 = 0.0f;
                 for (int t = 0; t < T; t++) {                 // pairwise-stable combination of per-frame (mean, M2)
-                    const float nb = (float)d.F, tot = nn + nb, dlt = stat[fl + t] - mean;
+                    const float nb = (float)d.F, tot = nn + nb, dlt = stat[wslot + t] - mean;
                     mean += dlt * nb / tot;
-                    m2 += stat[PS + fl + t] + dlt * dlt * nn * nb / tot;
+                    m2 += stat[PS + wslot + t] + dlt * dlt * nn * nb / tot;
                     nn = tot;
                 }
                 const float sd = sqrtf(m2 / (float)d.I);
@@ -465,7 +470,7 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
         }
     };
 
-    int cse_post = 0;                                         // column scale of the pass being evaluated
+    int cse_post = 0, csx_post = 0;                           // column scales (own, transition strip) of the pass being evaluated
     for (int p = 0; p < runs; p++) {
         // ================= block M: DFT of pass p  ||  evaluation of pass p-1  ||  block max of pass p+1
         // band-limited DFT of this wave's 16 frames on the matrix cores: four 16-row tiles (re bins 0-15, re 16-31,
@@ -504,8 +509,8 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
                 }
                 // the previous pass's evaluation, one or two steps per k-step
                 if (!(kom & 128)) {
-                    if (KS == 8) post_step(ks, p - 1, cse_post);
-                    else { post_step(2 * ks, p - 1, cse_post); post_step(2 * ks + 1, p - 1, cse_post); }
+                    if (KS == 8) post_step(ks, p - 1, cse_post, csx_post);
+                    else { post_step(2 * ks, p - 1, cse_post, csx_post); post_step(2 * ks + 1, p - 1, cse_post, csx_post); }
                 }
             }
         }
@@ -516,21 +521,24 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
         SD_TICK(1)
         const floatx4 red0 = *reinterpret_cast<const floatx4 *>(red), red1 = *reinterpret_cast<const floatx4 *>(red + 4);
 
-        se_prev = se; cse_prev = cse;
+        se_prev = se;
         se = se_next;
-        // columns of this pass and the T-1 carried ones share one scale: the smaller of the two passes' sample
-        // scales (the carried columns were stored at the previous column scale and are rescaled below)
-        cse = scaling != 0 ? 0 : ((p > 0 && se_prev < se) ? se_prev : se);
+        // this pass's columns are stored at its own sample scale; the transition strip (the previous pass's last T-1
+        // columns + copies of this pass's first T-1) at the smaller of the two passes' scales, where neither overflows
+        cse = scaling != 0 ? 0 : se;
+        const int csx = scaling != 0 ? 0 : ((p > 0 && se_prev < se) ? se_prev : se);
         cse_post = cse;
-        // ---- the previous pass's last T-1 columns move to the front of the column buffer (rescaled to cse); done by
-        // the wave that overwrites their old slots right after, so program order keeps the two apart
+        csx_post = csx;
+        // ---- the previous pass's last T-1 columns -> the front of the transition strip (rescaled from their own scale);
+        // done by the wave that overwrites their slots right after, so program order keeps the two apart
         if (p > 0 && wave == kWaves - 1 && !(kom & 32)) {
-            const int dexp = (cse - cse_prev) * (power_mode ? 2 : 1);
+            const int dexp = scaling != 0 ? 0 : csx - se_prev;     // <= 0
             const int words = (T - 1) * (kColStride / 2);      // 32-bit words per array
+            const int src = (XS + kPass - (T - 1)) * (kColStride / 2);
             for (int i = lane; i < 2 * words; i += 64) {
                 const bool hi_arr = i < words;
                 const int w = hi_arr ? i : i - words;
-                unsigned u = reinterpret_cast<const unsigned *>(hi_arr ? colh : coll)[kPass * (kColStride / 2) + w];
+                unsigned u = reinterpret_cast<const unsigned *>(hi_arr ? colh : coll)[src + w];
                 if (dexp != 0) {
                     union { unsigned u; _Float16 h[2]; } x;
                     x.u = u;
@@ -542,24 +550,24 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
                 }
                 reinterpret_cast<unsigned *>(hi_arr ? colh : coll)[w] = u;
             }
-            if (norm == 1 && lane < T - 1) stat[lane] = stat[kPass + lane] * pow2f(2 * dexp);   // sums of squares of scaled columns
+            const int ssrc = XS + kPass - (T - 1);
+            if (norm == 1 && lane < T - 1) stat[lane] = stat[ssrc + lane] * pow2f(2 * dexp);   // sums of squares of scaled columns
             if (norm >= 2 && lane < T - 1) {
-                stat[lane] = stat[kPass + lane];
-                stat[PS + lane] = stat[PS + kPass + lane];
+                stat[lane] = stat[ssrc + lane];
+                stat[PS + lane] = stat[PS + ssrc + lane];
             }
         }
 
-        // ---- magnitude (zvabs/2 :329-333 or zvmags/4 :270-274), scaling (SyllableDetector.swift:184-212),
+        // ---- magnitude (zvabs/2 :329-333), scaling (SyllableDetector.swift:184-212),
         // statistic, f16 split, column -> LDS.  Result layout: column = frame f, register j of lane group g4 in
         // tile m = basis row 16m + 4*g4 + j; this lane holds bins 4*g4 + j (i = j) and 16 + 4*g4 + j (i = 4 + j).
         if (!(kom & 64)) {
             // accumulators hold X * sx * 2^13.  Column scale (power of two; col_shift from the basis' largest row sum):
-            // |X| * 2^(cse - shift) < 2^13, |X|^2 * 2^(2 (cse - shift)) < 2^13 with its own shift; log/dB columns are
-            // stored unscaled.  For linear columns the two scales are applied together after the square root.
+            // |X| * 2^(cse - shift) < 2^13; log/dB columns are stored unscaled.  For linear columns the two scales are applied together after the square root.
             const float inv = pow2f(-se - 13);
-            const float cs = scaling != 0 ? 1.0f : (power_mode ? pow2f(2 * (cse - d.col_shift)) : pow2f(cse - d.col_shift));
+            const float cs = scaling != 0 ? 1.0f : pow2f(cse - d.col_shift);
             const int fh = d.F - 4 * g4;                          // cval[i] is a band bin iff (i&3) + 16(i>>2) < fh
-            const bool plain = scaling == 0 && !power_mode && norm <= 1;   // |X| columns, no per-frame statistic on raw values
+            const bool plain = scaling == 0 && norm <= 1;         // linear |X| columns, no per-frame statistic on raw values
             float cval[8];
 #pragma unroll
             for (int i = 0; i < 8; i++) {
@@ -569,7 +577,7 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
                 } else {
                     const float re = acc[i >> 2][i & 3] * inv, im = acc[2 + (i >> 2)][i & 3] * inv;
                     const float pw = fmaf(re, re, im * im);
-                    cval[i] = power_mode ? pw : __builtin_amdgcn_sqrtf(pw);
+                    cval[i] = __builtin_amdgcn_sqrtf(pw);
                 }
             }
             if (scaling != 0) {
@@ -579,7 +587,8 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
 #pragma unroll
                 for (int i = 0; i < 8; i++) cval[i] = ((i & 3) + 16 * (i >> 2)) < fh ? cval[i] : 0.0f;   // log(0) rows
             }                                                     // (linear: basis rows past F are zero, so are their |X|)
-            const int slot = (T - 1) + fl;
+            const int slot = XS + fl;                             // own column; frames fl < T-1 also feed the transition strip
+            const int xslot = (T - 1) + fl;
             if (norm == 2) {
                 float st0 = INFINITY, st1 = -INFINITY;
 #pragma unroll
@@ -590,7 +599,10 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
                 }
                 st0 = fminf(st0, __shfl_xor(st0, 16, 64)); st0 = fminf(st0, __shfl_xor(st0, 32, 64));
                 st1 = fmaxf(st1, __shfl_xor(st1, 16, 64)); st1 = fmaxf(st1, __shfl_xor(st1, 32, 64));
-                if (g4 == 0) { stat[slot] = st0; stat[PS + slot] = st1; }
+                if (g4 == 0) {
+                    stat[slot] = st0; stat[PS + slot] = st1;
+                    if (fl < T - 1) { stat[xslot] = st0; stat[PS + xslot] = st1; }
+                }
             } else if (norm == 3) {
                 float st0 = 0.0f, st1 = 0.0f;
 #pragma unroll
@@ -603,7 +615,10 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
                     st1 = ((i & 3) + 16 * (i >> 2)) < fh ? fmaf(dlt, dlt, st1) : st1;   // M2 of this frame's column
                 }
                 st1 += __shfl_xor(st1, 16, 64); st1 += __shfl_xor(st1, 32, 64);
-                if (g4 == 0) { stat[slot] = st0; stat[PS + slot] = st1; }
+                if (g4 == 0) {
+                    stat[slot] = st0; stat[PS + slot] = st1;
+                    if (fl < T - 1) { stat[xslot] = st0; stat[PS + xslot] = st1; }
+                }
             }
             if (!plain) {
 #pragma unroll
@@ -615,7 +630,10 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
 #pragma unroll
                 for (int i = 0; i < 8; i++) ss = fmaf(cval[i], cval[i], ss);
                 ss = xor32_sum(xor16_sum(ss));
-                if (g4 == 0) stat[slot] = ss;
+                if (g4 == 0) {
+                    stat[slot] = ss;
+                    if (fl < T - 1) stat[xslot] = ss * pow2f(2 * (csx - cse));
+                }
             }
             {
                 _Float16 *ph = colh + slot * kColStride + 4 * g4, *pl = coll + slot * kColStride + 4 * g4;
@@ -624,6 +642,19 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
                     unsigned h0, l0, h1, l1;
                     split_pair_scaled(cval[4 * m], cval[4 * m + 1], 1.0f, h0, l0);
                     split_pair_scaled(cval[4 * m + 2], cval[4 * m + 3], 1.0f, h1, l1);
+                    uint32x2 uh = {h0, h1}, ul = {l0, l1};
+                    *reinterpret_cast<uint32x2 *>(ph + 16 * m) = uh;
+                    *reinterpret_cast<uint32x2 *>(pl + 16 * m) = ul;
+                }
+            }
+            if (wave == 0 && fl < T - 1) {                        // copies for the transition strip, at its scale
+                const float xs = pow2f(csx - cse);                // <= 1: a much quieter pass may underflow here, next to
+                _Float16 *ph = colh + xslot * kColStride + 4 * g4, *pl = coll + xslot * kColStride + 4 * g4;   // columns 2^|.| louder
+#pragma unroll
+                for (int m = 0; m < 2; m++) {
+                    unsigned h0, l0, h1, l1;
+                    split_pair_scaled(cval[4 * m], cval[4 * m + 1], xs, h0, l0);
+                    split_pair_scaled(cval[4 * m + 2], cval[4 * m + 3], xs, h1, l1);
                     uint32x2 uh = {h0, h1}, ul = {l0, l1};
                     *reinterpret_cast<uint32x2 *>(ph + 16 * m) = uh;
                     *reinterpret_cast<uint32x2 *>(pl + 16 * m) = ul;
@@ -651,7 +682,7 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
     // ---- evaluation of the last pass
     if (!(kom & 128)) {
 #pragma unroll
-        for (int step = 0; step < 7; step++) post_step(step, runs - 1, cse_post);
+        for (int step = 0; step < 7; step++) post_step(step, runs - 1, cse_post, csx_post);
     }
     if (STAMP && tid == 0 && d.stamps)
         for (int i = 0; i < 16; i++) atomicAdd(&d.stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + i], tsum[i]);
@@ -684,7 +715,7 @@ hipError_t launch_fused(const FusedDesc &d, const float *samples, int64_t stride
     const bool skew = d.skew != 0;
     // the reference's example shape (W = 256, hop 132, timeRange 10) gets an instantiation with exact sizes
     if (d.KS == 8 && d.T == 10 && d.nload == 9 && !skew) {
-        const bool lean = d.norm == 1 && d.scaling == 0 && d.power_mode == 0 && d.n_layers == 2 && d.tf0 == 0 /* TanSig */ && d.tf1 == 2 /* PureLin */ &&
+        const bool lean = d.norm == 1 && d.scaling == 0 && d.n_layers == 2 && d.tf0 == 0 /* TanSig */ && d.tf1 == 2 /* PureLin */ &&
                           d.n_out == 1 && d.H <= 4 && d.n_out_fns <= 1;
 #ifdef SYLDET_KNOCKOUTS
 #define SD_KO_CASE(m) case m: return launch_one<8, 10, 9, true, false, true, false, m>(d, samples, stride, C, s_eff, E, outputs, flags, stream);

@@ -364,14 +364,12 @@ int syldet_create(const syldet_config_t *cfg, int32_t n_channels, int32_t device
     h->channels = n_channels;
     h->engine = SYLDET_ENGINE_GENERIC;
     if (engine != SYLDET_ENGINE_GENERIC) {
-        // The fused engine hands columns to the first layer as f16 hi + lo pairs under one power-of-two scale per pass.
-        // For the detector's own mode (|X|, linear) that is below fp32 noise; log / dB values (magnitude up to ~100,
-        // 2^-22 relative = a few 1e-5 absolute) and |X|^2 columns (dynamic range squared: bins 50 dB under the pass
-        // maximum lose their lo half) can leave the 1e-5 parity bar.  AUTO therefore keeps those modes on the generic
-        // engine; the fused one stays available on request.
-        const bool strict_ok = h->cfg.view.scaling == SYLDET_SCALING_LINEAR && h->cfg.view.spectrum == SYLDET_SPECTRUM_POWER;
+        // The fused engine hands columns to the first layer as f16 hi + lo pairs.  For linear |X| columns that is below
+        // fp32 noise; log / dB values (magnitude up to ~100, 2^-22 relative = a few 1e-5 absolute) can leave the 1e-5
+        // parity bar.  AUTO therefore keeps those scalings on the generic engine; the fused one stays available on request.
+        const bool strict_ok = h->cfg.view.scaling == SYLDET_SCALING_LINEAR;
         if (engine == SYLDET_ENGINE_AUTO && !strict_ok) {
-            h->fused.reason = "log/dB scaling or |X|^2 columns: AUTO keeps the generic engine for 1e-5 parity";
+            h->fused.reason = "log/dB scaling: AUTO keeps the generic engine for 1e-5 parity";
         } else if (make_fused_plan(h->cfg.view, h->geom, h->fused)) {
             h->engine = SYLDET_ENGINE_FUSED;
         } else if (engine == SYLDET_ENGINE_FUSED) {

@@ -68,16 +68,26 @@ def test_random_configuration(oracle_lib, seed):
     frames = int(rng.integers(cfg.timeRange, 700))
     S = max(0, -cfg.windowOverlap) + cfg.windowLength + (frames - 1) * hop + int(rng.integers(0, hop))
     level = float(10.0 ** rng.uniform(-3, 1))
-    x = (synth.channels(C, S, first=seed * 7, fs=FS) * level).astype(np.float32)
+    x = synth.channels(C, S, first=seed * 7, fs=FS) * level
+    if rng.random() < 0.4:
+        # level steps: block scales change between passes, and inside a pass the quiet part rides on the loud part's
+        # scale.  Up to 50 dB per step here; the fused engine is block floating point per 128-frame pass and degrades
+        # gradually once a frame sits ~70 dB under the loudest sample of its pass (numerics notes).
+        env = np.ones(S)
+        for _ in range(int(rng.integers(1, 4))):
+            at = int(rng.integers(0, S))
+            env[at:] *= float(10.0 ** rng.uniform(-2.5, 2.5))
+        x = x * np.clip(env, 1e-3, 1e3)[None, :]
+    x = x.astype(np.float32)
     o = util.oracle_for(cfg)
     runs = []
     with sd.SyllableDetector(cfg, channels=C) as det:
         out, fl = det.run(torch.from_numpy(x).cuda())
         torch.cuda.synchronize()
         runs.append((out.cpu().numpy(), fl.cpu().numpy(), det.geometry.engine, 1.0))
-    if runs[0][2] != _abi.ENGINE_FUSED and (cfg.spectrogramScaling != "linear" or cfg.spectrum != _abi.SPECTRUM_POWER):
-        # AUTO keeps log / dB scalings and |X|^2 columns on the generic engine (the fused one hands columns to the first
-        # layer as f16 hi + lo pairs under one scale per pass); the fused engine is checked on request, to a wider bar
+    if runs[0][2] != _abi.ENGINE_FUSED and cfg.spectrogramScaling != "linear":
+        # AUTO keeps log / dB scalings on the generic engine (the fused one hands columns to the first layer as f16 hi + lo
+        # pairs: 2^-22 relative on values up to ~100); there the fused engine is checked on request, to a wider bar
         try:
             with sd.SyllableDetector(cfg, channels=C, engine=_abi.ENGINE_FUSED) as det:
                 out, fl = det.run(torch.from_numpy(x).cuda())
@@ -103,11 +113,13 @@ def test_random_configuration(oracle_lib, seed):
                 util.assert_outputs_close(out[c][ok], w64[ok], tol)
                 util.assert_flags_exact(fl[c][ok], w64[ok], cfg.thresholds, cfg.rule, tol)
             assert not fl[c][~ok].any()
-    test_random_configuration.engines = getattr(test_random_configuration, "engines", []) + [r[2] for r in runs]
+    if cfg.spectrogramScaling == "linear" and cfg.spectrum == _abi.SPECTRUM_POWER:
+        test_random_configuration.engines = getattr(test_random_configuration, "engines", []) + [runs[0][2]]
 
 
-def test_most_draws_run_on_the_fused_engine():
+def test_most_draws_of_the_detectors_mode_run_on_the_fused_engine():
     engines = getattr(test_random_configuration, "engines", [])
-    if len(engines) < 40:
+    if len(engines) < 8:
         pytest.skip("runs after the sweep")
-    assert sum(e == _abi.ENGINE_FUSED for e in engines) >= len(engines) * 0.5, engines
+    # draws in the detector's own mode (|X|, linear): the fused engine takes all but the odd shape it cannot hold
+    assert sum(e == _abi.ENGINE_FUSED for e in engines) >= len(engines) * 0.8, engines
