@@ -180,7 +180,8 @@ __device__ __forceinline__ float wave_max_nonneg(float x)
 //                  so the whole block is one scheduling region
 //               || block-max partial of the NEXT pass's samples (already in registers)
 //   barrier
-//     carry the last T-1 columns to the front of the column buffer;  magnitudes of this pass -> column buffer;
+//     previous pass's last T-1 columns -> transition strip;  magnitudes of this pass -> column buffer (own scale,
+//     first T-1 also into the strip);
 //     next pass's samples: scale, split, -> LDS (the staged region is free now);  issue the loads of the pass
 //     after that (a whole pass of lead time)
 //   barrier
