@@ -123,3 +123,34 @@ def test_most_draws_of_the_detectors_mode_run_on_the_fused_engine():
         pytest.skip("runs after the sweep")
     # draws in the detector's own mode (|X|, linear): the fused engine takes all but the odd shape it cannot hold
     assert sum(e == _abi.ENGINE_FUSED for e in engines) >= len(engines) * 0.8, engines
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_configuration_streaming(oracle_lib, seed):
+    """The reference's per-detector calls (appendAudioData / processNewValue / lastOutputs) with ragged appends on
+    random configurations -- gaps, zero padding, short windows -- against the oracle's batch run."""
+    rng = np.random.default_rng(500 + seed)
+    cfg = draw(rng)
+    if cfg.spectrogramScaling != "linear":
+        cfg.spectrogramScaling = "linear"
+    hop = max(0, -cfg.windowOverlap) + cfg.windowLength - max(0, cfg.windowOverlap)
+    frames = int(rng.integers(cfg.timeRange + 1, 260))
+    S = max(0, -cfg.windowOverlap) + cfg.windowLength + (frames - 1) * hop + int(rng.integers(0, hop))
+    x = synth.channel(S, 900 + seed, fs=FS).astype(np.float32)
+    o = util.oracle_for(cfg)
+    w32, _, w64 = o.run(x, po.F64, cfg.rule)
+    with sd.SyllableDetector(cfg, channels=1) as det:
+        got, pos = [], 0
+        while pos < S:
+            n = int(rng.integers(1, 4 * hop + 50))
+            det.appendAudioData(x[pos:pos + n])
+            pos += n
+            while det.processNewValue():
+                got.append(det.lastOutputs)
+        got = np.array(got, np.float64).reshape(-1, w64.shape[1])
+    assert got.shape == w64.shape
+    ok = np.isfinite(w64).all(axis=1)
+    o32 = o.run(x, po.F32, cfg.rule)[0]
+    own = float((np.abs(o32[ok] - w64[ok]) / np.maximum(1.0, np.abs(w64[ok]))).max()) if ok.any() else 0.0
+    if ok.any():
+        util.assert_outputs_close(got[ok], w64[ok], max(util.TOL, 4.0 * own) if cfg.spectrum == _abi.SPECTRUM_POWER else max(1e-4, 30 * own))
