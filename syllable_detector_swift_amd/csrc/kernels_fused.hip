@@ -715,6 +715,12 @@ hipError_t launch_fused(const FusedDesc &d, const float *samples, int64_t stride
     const int64_t s_eff = (J - 1) * (int64_t)d.hop + d.gap + d.W;
     const bool skew = d.skew != 0;
     // the reference's example shape (W = 256, hop 132, timeRange 10) gets an instantiation with exact sizes
+    if (d.KS == 8 && d.T == 10 && d.nload == 9 && skew) {      // the same shape at hop 128 (bank-spread staging)
+        const bool lean = d.norm == 1 && d.scaling == 0 && d.n_layers == 2 && d.tf0 == 0 /* TanSig */ && d.tf1 == 2 /* PureLin */ &&
+                          d.n_out == 1 && d.H <= 4 && d.n_out_fns <= 1;
+        if (lean) return launch_one<8, 10, 9, true, true, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
+        return launch_one<8, 10, 9, true, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
+    }
     if (d.KS == 8 && d.T == 10 && d.nload == 9 && !skew) {
         const bool lean = d.norm == 1 && d.scaling == 0 && d.n_layers == 2 && d.tf0 == 0 /* TanSig */ && d.tf1 == 2 /* PureLin */ &&
                           d.n_out == 1 && d.H <= 4 && d.n_out_fns <= 1;

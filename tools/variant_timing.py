@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Diagnostic: kernel time of the fused engine on the benchmark batch for network shapes outside the compile-time-exact
+instantiation (wider hidden layer, several outputs, other input chains)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import syllable_detector_swift_amd as sd
+from syllable_detector_swift_amd import nets, synth, _abi
+
+base = nets.from_npz()
+C, S = 64, 1 << 24
+x = synth.channels_on_device(C, S, torch.device("cuda", 0), fs=base.samplingRate)
+rng = np.random.default_rng(1)
+cases = {
+    "sample.txt (LEAN)": base,
+    "H=8, 1 output": nets.variant(base, net=nets.random_net(rng, 290, (8,), 1)),
+    "H=16, 4 outputs": nets.variant(base, net=nets.random_net(rng, 290, (16,), 4), thresholds=[0.5] * 4),
+    "H=4, normalize chain": nets.variant(base, net=nets.random_net(rng, 290, (4,), 1, in_fns=("normalize",))),
+    "H=4, no chain, LogSig": nets.variant(base, net=nets.random_net(rng, 290, (4,), 1, transfer=("LogSig", "PureLin"), in_fns=())),
+    "T=12": nets.variant(base, timeRange=12, net=nets.random_net(rng, 29 * 12, (4,), 1)),
+    "hop 128": nets.variant(base, windowOverlap=128),
+}
+for name, cfg in cases.items():
+    with sd.SyllableDetector(cfg, channels=C, engine=_abi.ENGINE_FUSED) as det:
+        E = det.countEvaluations(S)
+        out = torch.empty((C, E, det.geometry.outputs), dtype=torch.float32, device="cuda")
+        fl = torch.empty((C, E), dtype=torch.uint8, device="cuda")
+        det.profile(True)
+        ms = []
+        for i in range(6):
+            det.run(x, out, fl)
+            if i >= 2:
+                ms.append(det.lastTimings()[0][1])
+        J = det.countFrames(S)
+        print("%-26s %.3f ms   %.3g frames/s" % (name, sum(ms) / len(ms), C * J / (sum(ms) / len(ms) * 1e-3)), flush=True)
