@@ -25,24 +25,24 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b)
     return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
 
-__device__ __forceinline__ float wave_sum(float v)
+// Wave-wide reductions in registers: quad / half-row / row steps through DPP, rows and halves through gfx950's
+// v_permlane16_swap / v_permlane32_swap (with both operands = x the two results are x and its partner).  Every
+// lane ends up with the result.
+template <typename Op>
+__device__ __forceinline__ float wave_reduce(float v, Op op)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
-    return v;
+    v = op(v, __uint_as_float(__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0xB1, 0xF, 0xF, false)));    // lane ^ 1
+    v = op(v, __uint_as_float(__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x4E, 0xF, 0xF, false)));    // lane ^ 2
+    v = op(v, __uint_as_float(__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x141, 0xF, 0xF, false)));   // the other quad of the half row
+    v = op(v, __uint_as_float(__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x140, 0xF, 0xF, false)));   // the other half of the row
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = op(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return op(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
-__device__ __forceinline__ float wave_min(float v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, kWave));
-    return v;
-}
-__device__ __forceinline__ float wave_max(float v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, kWave));
-    return v;
-}
+__device__ __forceinline__ float wave_sum(float v) { return wave_reduce(v, [](float a, float b) { return a + b; }); }
+__device__ __forceinline__ float wave_min(float v) { return wave_reduce(v, [](float a, float b) { return fminf(a, b); }); }
+__device__ __forceinline__ float wave_max(float v) { return wave_reduce(v, [](float a, float b) { return fmaxf(a, b); }); }
 
 // ------------------------------------------------------------------------------------
 // STFT: one frame per group of TPF = min(256, M/2) threads, G = 256/TPF frames per pass.
@@ -258,6 +258,188 @@ mlp_generic_kernel(NetDesc n, int F, const float *__restrict__ columns, int64_t 
 }
 
 // ------------------------------------------------------------------------------------
+// The same evaluation for networks whose first layer fits a wave's registers (inputs <= 64 KI, first layer <=
+// HMAX wide, at most two layers, <= 8 outputs): one wave walks a run of consecutive evaluations with the input
+// vector spread over its lanes (element i in lane i % 64, register i / 64) and the first-layer weights held in
+// registers for the whole run -- no LDS, no barriers, reductions through DPP.  Operation order per evaluation is
+// the reference's (scaling, input functions in file order, layers, reverse maps), nothing folded.
+// ------------------------------------------------------------------------------------
+constexpr int kSmallRun = 32;    // evaluations per wave
+
+template <int KI, int HMAX>
+__global__ void __launch_bounds__(kBlock)
+mlp_small_kernel(NetDesc n, int F, const float *__restrict__ columns, int64_t J, int64_t E,
+                 float *__restrict__ outputs, uint8_t *__restrict__ flags)
+{
+    const int wave = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
+    const int c = blockIdx.y;
+    const float *cols = columns + (int64_t)c * J * F;
+    const float *P = n.params;
+    const int I = n.I;
+    const DevLayer L0 = n.layers[0];
+    const int H = L0.out;
+
+    float w[HMAX][KI];                                          // first-layer rows, this lane's elements
+#pragma unroll
+    for (int h = 0; h < HMAX; h++)
+#pragma unroll
+        for (int k = 0; k < KI; k++) {
+            const int i = lane + kWave * k;
+            w[h][k] = (h < H && i < I) ? P[L0.w + (size_t)h * I + i] : 0.0f;
+        }
+    const float b0 = lane < H ? P[L0.b + lane] : 0.0f;          // lane h finishes hidden unit h
+    // the first affine input maps keep their per-element parameters in registers too
+    constexpr int NCACHE = KI <= 5 ? 2 : 1;
+    float axo[NCACHE][KI], aga[NCACHE][KI];
+    {
+        int slot = 0;
+        for (int q = 0; q < n.n_in_fns; q++) {
+            if (n.in_fns[q].kind < 3 || slot >= NCACHE) continue;
+#pragma unroll
+            for (int u = 0; u < NCACHE; u++)
+                if (u == slot)
+#pragma unroll
+                    for (int k = 0; k < KI; k++) {
+                        const int i = lane + kWave * k;
+                        axo[u][k] = i < I ? P[n.in_fns[q].xoff + i] : 0.0f;
+                        aga[u][k] = i < I ? P[n.in_fns[q].gain + i] : 0.0f;
+                    }
+            slot++;
+        }
+    }
+
+    const int64_t e0 = ((int64_t)blockIdx.x * (kBlock / kWave) + wave) * kSmallRun;
+    if (e0 >= E) return;
+    float xn[KI];                                               // the next evaluation's inputs, fetched one ahead
+#pragma unroll
+    for (int k = 0; k < KI; k++) xn[k] = lane + kWave * k < I ? cols[e0 * F + lane + kWave * k] : 0.0f;
+    for (int r = 0; r < kSmallRun; r++) {
+        const int64_t e = e0 + r;
+        if (e >= E) return;                                     // wave-uniform
+        float x[KI];
+#pragma unroll
+        for (int k = 0; k < KI; k++) x[k] = xn[k];
+        if (r + 1 < kSmallRun && e + 1 < E) {
+#pragma unroll
+            for (int k = 0; k < KI; k++) xn[k] = lane + kWave * k < I ? cols[(e + 1) * F + lane + kWave * k] : 0.0f;
+        }
+        if (n.scaling != 0) {
+#pragma unroll
+            for (int k = 0; k < KI; k++) {
+                const float v = n.scaling == 1 ? logf(x[k])                 // vvlogf, SyllableDetector.swift:207
+                                               : 20.0f * log10f(x[k]);      // vDSP_vdbcon ref 1, amplitude flag :195
+                x[k] = lane + kWave * k < I ? v : 0.0f;
+            }
+        }
+        int slot = 0;
+        for (int q = 0; q < n.n_in_fns; q++) {
+            const DevFn fn = n.in_fns[q];
+            if (fn.kind == 0) {                                  // L2Normalize :47-59
+                float s = 0.0f;
+#pragma unroll
+                for (int k = 0; k < KI; k++) s += x[k] * x[k];
+                s = sqrtf(wave_sum(s));
+#pragma unroll
+                for (int k = 0; k < KI; k++) x[k] = x[k] / s;
+            } else if (fn.kind == 1) {                           // Normalize :69-96
+                float mn = INFINITY, mx = -INFINITY;
+#pragma unroll
+                for (int k = 0; k < KI; k++)
+                    if (lane + kWave * k < I) { mn = fminf(mn, x[k]); mx = fmaxf(mx, x[k]); }
+                mn = wave_min(mn);
+                mx = wave_max(mx);
+                const float range = mx - mn;
+                const float slope = 2.0f / range, intercept = (0.0f - mn - mx) / range;
+#pragma unroll
+                for (int k = 0; k < KI; k++) x[k] = range == 0.0f ? -1.0f : x[k] * slope + intercept;
+            } else if (fn.kind == 2) {                           // NormalizeStd :105-108 (population sigma)
+                float s = 0.0f;
+#pragma unroll
+                for (int k = 0; k < KI; k++) s += x[k];
+                const float mean = wave_sum(s) / (float)I;
+                float qq = 0.0f;
+#pragma unroll
+                for (int k = 0; k < KI; k++)
+                    if (lane + kWave * k < I) { const float dlt = x[k] - mean; qq += dlt * dlt; }
+                const float sd = sqrtf(wave_sum(qq) / (float)I);
+#pragma unroll
+                for (int k = 0; k < KI; k++) x[k] = (x[k] - mean) / sd;
+            } else {                                             // MapMinMax.apply :127-131, MapStd.apply :162-169
+                bool done = false;
+#pragma unroll
+                for (int u = 0; u < NCACHE; u++)
+                    if (u == slot) {
+#pragma unroll
+                        for (int k = 0; k < KI; k++) x[k] = (x[k] - axo[u][k]) * aga[u][k] + fn.y;
+                        done = true;
+                    }
+                if (!done) {
+#pragma unroll
+                    for (int k = 0; k < KI; k++) {
+                        const int i = lane + kWave * k;
+                        if (i < I) x[k] = (x[k] - P[fn.xoff + i]) * P[fn.gain + i] + fn.y;
+                    }
+                }
+                slot++;
+            }
+#pragma unroll
+            for (int k = 0; k < KI; k++) x[k] = lane + kWave * k < I ? x[k] : 0.0f;   // padding stays out of every sum
+        }
+        // first layer: one dot product per row (every lane gets the sum); lane h then finishes unit h, so the
+        // transfer function runs once per evaluation, and the activations come back as wave-uniform values
+        float mine = 0.0f;
+#pragma unroll
+        for (int h = 0; h < HMAX; h++) {
+            if (h < H) {                                        // wave-uniform
+                float acc = 0.0f;
+#pragma unroll
+                for (int k = 0; k < KI; k++) acc = fmaf(w[h][k], x[k], acc);
+                acc = wave_sum(acc);
+                mine = lane == h ? acc : mine;
+            }
+        }
+        const float act = transfer(L0.tf, mine + b0);
+        float a[HMAX];
+#pragma unroll
+        for (int h = 0; h < HMAX; h++) a[h] = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(act), h));
+        // second layer (if any) and reverse maps: a handful of values, every lane computes them
+        float y[8];
+        int n_out = H;
+#pragma unroll
+        for (int o = 0; o < 8; o++) y[o] = o < HMAX ? a[o < HMAX ? o : 0] : 0.0f;
+        if (n.n_layers == 2) {
+            const DevLayer L1 = n.layers[1];
+            n_out = L1.out;
+#pragma unroll
+            for (int o = 0; o < 8; o++) {
+                float acc = 0.0f;
+                if (o < n_out) {
+#pragma unroll
+                    for (int h = 0; h < HMAX; h++)
+                        if (h < H) acc = fmaf(P[L1.w + o * H + h], a[h], acc);
+                    acc = transfer(L1.tf, acc + P[L1.b + o]);
+                }
+                y[o] = acc;
+            }
+        }
+        uint8_t hit = 0;
+#pragma unroll
+        for (int o = 0; o < 8; o++) {
+            if (o < n_out) {
+                float v = y[o];
+                for (int q = 0; q < n.n_out_fns; q++) {          // reverse maps, NeuralNet.swift:137-142 / :175-180
+                    const DevFn fn = n.out_fns[q];
+                    v = (v - fn.y) / P[fn.gain + o] + P[fn.xoff + o];
+                }
+                if (lane == 0 && outputs) outputs[(((int64_t)c * E) + e) * n_out + o] = v;
+                if (o == 0 || n.rule != 0) hit |= ((double)v >= n.thresholds[o]) ? 1 : 0;
+            }
+        }
+        if (lane == 0 && flags) flags[(int64_t)c * E + e] = hit;
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // Detection sample numbers with debounce (TrackDetector.swift:39-43, :65-100): a greedy
 // scan along time, one wave per channel, 64 flags per step; the wave skips ahead with
 // ballots so quiet stretches cost one load per 64 evaluations.
@@ -315,6 +497,20 @@ hipError_t launch_mlp_generic(const NetDesc &n, int F, const float *columns, int
                               float *outputs, uint8_t *flags, hipStream_t stream)
 {
     if (E <= 0 || C <= 0) return hipSuccess;
+    // small first layer: the register-resident kernel
+    if (n.n_layers >= 1 && n.n_layers <= 2 && n.n_out <= 8 && (n.n_layers == 1 || n.layers[1].in == n.layers[0].out)) {
+        const int H = n.layers[0].out;
+        const int64_t per_block = (int64_t)(kBlock / kWave) * kSmallRun;
+        dim3 grid((unsigned)((E + per_block - 1) / per_block), (unsigned)C);
+        if (n.I <= 64 * 5 && H <= 8) {
+            hipLaunchKernelGGL((mlp_small_kernel<5, 8>), grid, dim3(kBlock), 0, stream, n, F, columns, J, E, outputs, flags);
+            return hipGetLastError();
+        }
+        if (n.I <= 64 * 20 && H <= 4) {
+            hipLaunchKernelGGL((mlp_small_kernel<20, 4>), grid, dim3(kBlock), 0, stream, n, F, columns, J, E, outputs, flags);
+            return hipGetLastError();
+        }
+    }
     const size_t lds = (size_t)(kBlock / kWave) * 2 * n.max_width * sizeof(float);
     const int64_t per_block = (int64_t)(kBlock / kWave) * kMlpPasses;
     dim3 grid((unsigned)((E + per_block - 1) / per_block), (unsigned)C);
