@@ -732,10 +732,21 @@ hipError_t launch_fused(const FusedDesc &d, const float *samples, int64_t stride
         if (lean) return launch_one<8, 10, 9, true, false, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
         return launch_one<8, 10, 9, true, false>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
     }
-    if (d.KS == 8) return skew ? launch_one<8, 12, kFusedMaxLoads, false, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream)
-                               : launch_one<8, 12, kFusedMaxLoads, false, false>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
-    if (d.KS == 4) return skew ? launch_one<4, 12, kFusedMaxLoads, false, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream)
-                               : launch_one<4, 12, kFusedMaxLoads, false, false>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
+    // everything else: runtime sizes, with the tap array (8 registers per tap) sized to the next of 4 / 8 / 12
+#define SD_GENERIC(KS_, TM_)                                                                                               \
+    return skew ? launch_one<KS_, TM_, kFusedMaxLoads, false, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream) \
+                : launch_one<KS_, TM_, kFusedMaxLoads, false, false>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
+    if (d.KS == 8) {
+        if (d.T <= 4) { SD_GENERIC(8, 4) }
+        if (d.T <= 8) { SD_GENERIC(8, 8) }
+        SD_GENERIC(8, 12)
+    }
+    if (d.KS == 4) {
+        if (d.T <= 4) { SD_GENERIC(4, 4) }
+        if (d.T <= 8) { SD_GENERIC(4, 8) }
+        SD_GENERIC(4, 12)
+    }
+#undef SD_GENERIC
     return hipErrorInvalidValue;
 }
 

@@ -20,6 +20,8 @@ cases = {
     "H=4, normalize chain": nets.variant(base, net=nets.random_net(rng, 290, (4,), 1, in_fns=("normalize",))),
     "H=4, no chain, LogSig": nets.variant(base, net=nets.random_net(rng, 290, (4,), 1, transfer=("LogSig", "PureLin"), in_fns=())),
     "T=12": nets.variant(base, timeRange=12, net=nets.random_net(rng, 29 * 12, (4,), 1)),
+    "T=4": nets.variant(base, timeRange=4, net=nets.random_net(rng, 29 * 4, (4,), 1)),
+    "T=8, hop 100": nets.variant(base, timeRange=8, windowOverlap=156, net=nets.random_net(rng, 29 * 8, (4,), 1)),
     "hop 128": nets.variant(base, windowOverlap=128),
 }
 for name, cfg in cases.items():
