@@ -28,6 +28,7 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_BF16_PEAK_TFLOPS = 2500.0 # MI355X_MICROARCH.md: dense bf16 matrix peak (no sparsity)
 
 
 def cpu_baseline(cfg, samples_host, budget_s=10.0, threads=1):
@@ -81,7 +82,7 @@ def main():
     ap.add_argument("--channels", type=int, default=64, help="channels per GPU")
     ap.add_argument("--log2-samples", type=int, default=24, help="samples per channel = 2^k")
     ap.add_argument("--overlap", type=int, default=None, help="override windowOverlap (128 => the hop-128 variant)")
-    ap.add_argument("--workload", default="sample", choices=["sample", "config3"])
+    ap.add_argument("--workload", default="sample", choices=["sample", "config3", "config5"])
     ap.add_argument("--engine", type=int, default=0, help="0 auto, 1 generic, 2 fused")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -106,6 +107,12 @@ def main():
         cfg = nets.config3()
         C, S = (512 if args.channels == 64 else args.channels), 1 << (21 if args.log2_samples == 24 else args.log2_samples)
         name = "BASELINE configs[2]: 1024-pt FFT hop 256, synthetic 1160-4-1 network"
+    elif args.workload == "config5":
+        cfg = nets.wide_mlp(nets.from_npz())
+        C, S = args.channels, 1 << args.log2_samples
+        name = "BASELINE configs[4]: sample.txt front end, 290 -> 4096 TanSig -> 1 network, bf16 MFMA GEMM"
+        if args.engine == 0:
+            args.engine = 3                      # the wide engine is opt-in (bf16 numerics)
     else:
         cfg = nets.from_npz()
         C, S = args.channels, 1 << args.log2_samples
@@ -162,15 +169,16 @@ def main():
         # several kernels each is charged the whole frame's algorithmic bytes (none moves fewer)
         achieved = C * J * b_frame / (means[dom] * 1e-3) / 1e9
         line = {
-            "metric": "audio frames/sec (256-pt STFT + 2-layer MLP), whole job" if args.workload == "sample"
-                      else "audio frames/sec (1024-pt STFT + 2-layer MLP), whole job",
+            "metric": {"sample": "audio frames/sec (256-pt STFT + 2-layer MLP), whole job",
+                       "config3": "audio frames/sec (1024-pt STFT + 2-layer MLP), whole job",
+                       "config5": "audio frames/sec (256-pt STFT + 4096-hidden MLP as bf16 MFMA GEMM), whole job"}[args.workload],
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "per_gpu": value / world,
             "config": {"workload": name, "channels_per_gpu": C, "samples_per_channel": S, "frames_per_channel": J,
                        "evaluations_per_channel": E, "fourier_length": cfg.fourierLength, "hop": g.hop,
-                       "bins": [g.f0, g.f1], "time_range": cfg.timeRange, "engine": {1: "generic", 2: "fused"}.get(g.engine, str(g.engine)),
+                       "bins": [g.f0, g.f1], "time_range": cfg.timeRange, "engine": {1: "generic", 2: "fused", 3: "wide_bf16"}.get(g.engine, str(g.engine)),
                        "sharding": "channels, %d per GPU; one all-gather of flags per step" % C if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
@@ -178,6 +186,15 @@ def main():
                          "algorithmic_bytes_per_launch": C * J * b_frame,
                          "algorithmic_bytes_per_frame": b_frame, "kernel_ms": means},
         }
+        if g.engine == 3:
+            # the wide engine's roof is the bf16 matrix pipe: flops of the two layers per evaluation
+            L = cfg.net.layers
+            f_frame = 2 * L[0].inputs * L[0].outputs + 2 * L[0].outputs * L[1].outputs
+            tf = C * E * f_frame / (means["wide_gemm_kernel"] * 1e-3) / 1e12
+            line["dtype"] = "bf16"
+            line["roofline"] = {"bound": "mfma", "kernel": "wide_gemm_kernel", "achieved": tf, "peak": MFMA_BF16_PEAK_TFLOPS,
+                                "unit": "TFLOP/s", "frac": tf / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                                "algorithmic_flops_per_launch": C * E * f_frame, "algorithmic_flops_per_frame": f_frame, "kernel_ms": means}
         if world == 1 and not args.no_cpu_baseline:
             # the boundary also takes host buffers (syldet_run): H2D + kernel + D2H, pageable memory, bounded sample.
             # Reported beside the headline, never as `value`.

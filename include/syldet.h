@@ -133,7 +133,11 @@ typedef struct {
     int32_t engine;                  /* which kernel family create selected (syldet_engine_t) */
 } syldet_geometry_t;
 
-typedef enum { SYLDET_ENGINE_AUTO = 0, SYLDET_ENGINE_GENERIC = 1, SYLDET_ENGINE_FUSED = 2 } syldet_engine_t;
+/* SYLDET_ENGINE_WIDE_BF16: two-layer networks with a wide hidden layer (BASELINE: 4096 units) evaluated as a bf16
+ * MFMA GEMM over thousands of evaluations, fp32 accumulate.  Inputs and first-layer weights are rounded to bf16, so
+ * results agree with the fp32 engines to ~1e-3, not 1e-5: opt-in only, never selected by AUTO.                   */
+typedef enum { SYLDET_ENGINE_AUTO = 0, SYLDET_ENGINE_GENERIC = 1, SYLDET_ENGINE_FUSED = 2,
+               SYLDET_ENGINE_WIDE_BF16 = 3 } syldet_engine_t;
 
 typedef struct syldet syldet_t;
 

@@ -38,7 +38,7 @@ SPECTRUM_POWER, SPECTRUM_MAGNITUDE = 0, 1
 FN_L2NORMALIZE, FN_NORMALIZE, FN_NORMALIZESTD, FN_MAPMINMAX, FN_MAPSTD = 0, 1, 2, 3, 4
 TF_TANSIG, TF_LOGSIG, TF_PURELIN, TF_SATLIN = 0, 1, 2, 3
 RULE_FIRST, RULE_ANY = 0, 1
-ENGINE_AUTO, ENGINE_GENERIC, ENGINE_FUSED = 0, 1, 2
+ENGINE_AUTO, ENGINE_GENERIC, ENGINE_FUSED, ENGINE_WIDE_BF16 = 0, 1, 2, 3
 
 c_float_p = C.POINTER(C.c_float)
 c_double_p = C.POINTER(C.c_double)

@@ -56,6 +56,25 @@ hipError_t launch_detections(const uint8_t *flags, int C, int64_t E, int64_t fir
                              int64_t debounce_frames, int64_t *indices, int64_t capacity, int64_t *counts,
                              hipStream_t stream);
 
+// ---- wide-network engine (kernels_wide.hip): first layer as a bf16 MFMA GEMM over many evaluations ----
+constexpr int kWideBlock = 1024;           // 16 waves, 32 evaluations each
+constexpr int kWideTile = 512;             // evaluations per workgroup
+constexpr int kWideK = 320;                // inputs per evaluation, zero padded (20 k-steps of 16)
+constexpr int kWideChunkBytes = 20 * 64 * 16 + (32 + 4 * 32) * 4;   // 32 hidden units: A fragments, then b0[32], w1[4][32]
+
+struct WideDesc {
+    int H, n_chunks;            // first-layer outputs, chunks of 32 of them (zero padded)
+    int n_out, tf0, tf1, rule, n_out_fns;
+    const uint4 *wpack;         // [n_chunks][kWideChunkBytes / 16]
+    const float *b1;            // [n_out]
+    const float *out_params;    // per output fn: y, gain[n_out], xoff[n_out]
+    const double *thresholds;   // [n_out]
+};
+// columns [C][J][F] -> xn [C*E][kWideK] bf16 (scaling + input functions applied)
+hipError_t launch_wide_prep(const NetDesc &n, int F, const float *columns, int C, int64_t J, int64_t E, void *xn, hipStream_t stream);
+// xn [NE][kWideK] -> outputs [NE][n_out], flags [NE]
+hipError_t launch_wide_gemm(const WideDesc &d, const void *xn, int64_t NE, float *outputs, uint8_t *flags, hipStream_t stream);
+
 // ---- fused engine (kernels_fused.hip) ----------------------------------------------------
 // One kernel: samples -> outputs + flags.  The band-limited windowed DFT of 32 frames at a
 // time is a GEMM on the matrix cores (f16 hi/lo split operands, fp32 accumulate), the first

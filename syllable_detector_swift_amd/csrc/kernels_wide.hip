@@ -1,0 +1,271 @@
+// kernels_wide.hip -- the wide-network engine (BASELINE configs[4]: a 4096-unit hidden layer): when the first
+// layer is wide enough, many evaluations together make a dense GEMM, and that belongs on the matrix cores.
+//
+//   NeuralNet.apply (Common/NeuralNet.swift:294-326) for a batch of evaluations:
+//     wide_prep_kernel   scaling + input functions per evaluation, exactly as the generic engine does them
+//                        (fp32, the reference's operation order), result rounded to bf16:  Xn [evaluations][320]
+//     wide_gemm_kernel   hidden = f0(W0 . x + b0) as  D[unit, evaluation] = W0[unit, :] . Xn[evaluation, :]  with
+//                        v_mfma_f32_32x32x16_bf16 (bf16 operands, fp32 accumulate); the second layer
+//                        (a handful of outputs) is folded into the epilogue:  y[o] += w1[o, unit] * f0(.),
+//                        then f1, reverse maps, threshold.  The hidden layer never exists in memory.
+//
+// Data flow of the GEMM: a wave owns 32 evaluations for the whole kernel and keeps their bf16 inputs in
+// registers as MFMA B operands (20 k-steps x 4 registers); the weights stream through LDS in chunks of 32 hidden
+// units (20 KB of A operands, packed in fragment order on the host; LDS-DMA, double-buffered), every chunk is read by all 16
+// waves and used for 20 MFMAs each: 125 B/clk of LDS traffic per CU against 256 available; 4 waves per SIMD, so
+// the matrix pipe has three other instruction streams to draw from while one wave is in its epilogue.  Roof: bf16 MFMA, 2.38 MFLOP per
+// evaluation at H = 4096.
+//
+// Precision is bf16's (8-bit significands on inputs and weights): this engine is opt-in
+// (SYLDET_ENGINE_WIDE_BF16), never chosen by AUTO, and its parity bar is stated separately (1e-2).
+//
+// gfx950 only.  wave = 64.
+
+#include "kernels.hpp"
+
+namespace sd {
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int kBlock = kWideBlock;            // 1024 threads = 16 waves
+constexpr int kWave = 64;
+constexpr int kKSteps = kWideK / 16;          // 20 k-steps of 16
+constexpr int kChunkU4 = kWideChunkBytes / 16;     // 1320
+constexpr int kChunkU4Pad = 21 * 64;               // an LDS buffer holds whole 64-element spans (the DMA writes base + 16 lane)
+
+__device__ __forceinline__ float wave_reduce_sum(float v)
+{
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0xB1, 0xF, 0xF, false));
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x4E, 0xF, 0xF, false));
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x141, 0xF, 0xF, false));
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x140, 0xF, 0xF, false));
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+template <typename Op>
+__device__ __forceinline__ float wave_reduce(float v, Op op)
+{
+    v = op(v, __uint_as_float(__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0xB1, 0xF, 0xF, false)));
+    v = op(v, __uint_as_float(__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x4E, 0xF, 0xF, false)));
+    v = op(v, __uint_as_float(__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x141, 0xF, 0xF, false)));
+    v = op(v, __uint_as_float(__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x140, 0xF, 0xF, false)));
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = op(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return op(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
+// Transfer functions (NeuralNet.swift:185-228) through the hardware exp2 / rcp; NaN and the infinities fall out
+// of the arithmetic (see kernels_fused.hip).
+__device__ __forceinline__ float transfer_fast(int tf, float x)
+{
+    if (tf == 0) return fmaf(-2.0f, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(x * 2.885390081777927f) + 1.0f), 1.0f);
+    if (tf == 1) return __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(x * -1.4426950408889634f) + 1.0f);
+    if (tf == 3) return x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x);
+    return x;
+}
+
+// ------------------------------------------------------------------------------------
+// Inputs of every evaluation, normalised, as bf16 rows of kWideK (zero padded).  One wave walks a run of
+// evaluations with the vector spread over its lanes (element i in lane i % 64, register i / 64); the input
+// chain is the generic engine's (SyllableDetector.swift:184-212, NeuralNet.swift:41-182).
+// ------------------------------------------------------------------------------------
+constexpr int kPrepRun = 32;
+constexpr int kKI = kWideK / kWave;           // 5 registers per lane
+
+__global__ void __launch_bounds__(256)
+wide_prep_kernel(NetDesc n, int F, const float *__restrict__ columns, int64_t J, int64_t E, __bf16 *__restrict__ xn)
+{
+    const int wave = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
+    const int c = blockIdx.y;
+    const float *cols = columns + (int64_t)c * J * F;
+    const float *P = n.params;
+    const int I = n.I;
+    const int64_t e0 = ((int64_t)blockIdx.x * (256 / kWave) + wave) * kPrepRun;
+    for (int r = 0; r < kPrepRun; r++) {
+        const int64_t e = e0 + r;
+        if (e >= E) return;
+        float x[kKI];
+#pragma unroll
+        for (int k = 0; k < kKI; k++) {
+            const int i = lane + kWave * k;
+            float v = i < I ? cols[e * F + i] : 0.0f;
+            if (n.scaling == 1) v = logf(v);
+            else if (n.scaling == 2) v = 20.0f * log10f(v);
+            x[k] = i < I ? v : 0.0f;
+        }
+        for (int q = 0; q < n.n_in_fns; q++) {
+            const DevFn fn = n.in_fns[q];
+            if (fn.kind == 0) {                                  // L2Normalize :47-59
+                float s = 0.0f;
+#pragma unroll
+                for (int k = 0; k < kKI; k++) s += x[k] * x[k];
+                s = sqrtf(wave_reduce_sum(s));
+#pragma unroll
+                for (int k = 0; k < kKI; k++) x[k] = x[k] / s;
+            } else if (fn.kind == 1) {                           // Normalize :69-96
+                float mn = INFINITY, mx = -INFINITY;
+#pragma unroll
+                for (int k = 0; k < kKI; k++)
+                    if (lane + kWave * k < I) { mn = fminf(mn, x[k]); mx = fmaxf(mx, x[k]); }
+                mn = wave_reduce(mn, [](float a, float b) { return fminf(a, b); });
+                mx = wave_reduce(mx, [](float a, float b) { return fmaxf(a, b); });
+                const float range = mx - mn;
+                const float slope = 2.0f / range, intercept = (0.0f - mn - mx) / range;
+#pragma unroll
+                for (int k = 0; k < kKI; k++) x[k] = range == 0.0f ? -1.0f : x[k] * slope + intercept;
+            } else if (fn.kind == 2) {                           // NormalizeStd :105-108
+                float s = 0.0f;
+#pragma unroll
+                for (int k = 0; k < kKI; k++) s += x[k];
+                const float mean = wave_reduce_sum(s) / (float)I;
+                float qq = 0.0f;
+#pragma unroll
+                for (int k = 0; k < kKI; k++)
+                    if (lane + kWave * k < I) { const float dlt = x[k] - mean; qq += dlt * dlt; }
+                const float sd = sqrtf(wave_reduce_sum(qq) / (float)I);
+#pragma unroll
+                for (int k = 0; k < kKI; k++) x[k] = (x[k] - mean) / sd;
+            } else {                                             // MapMinMax.apply :127-131, MapStd.apply :162-169
+#pragma unroll
+                for (int k = 0; k < kKI; k++) {
+                    const int i = lane + kWave * k;
+                    if (i < I) x[k] = (x[k] - P[fn.xoff + i]) * P[fn.gain + i] + fn.y;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < kKI; k++) x[k] = lane + kWave * k < I ? x[k] : 0.0f;
+        }
+        __bf16 *dst = xn + ((int64_t)c * E + e) * kWideK;
+#pragma unroll
+        for (int k = 0; k < kKI; k++) dst[lane + kWave * k] = (__bf16)x[k];      // v_cvt_pk_bf16_f32: round to nearest even
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// The GEMM + epilogue.  MFMA operand layouts (v_mfma_f32_32x32x16_bf16):
+//   A [32 units x 16 k]:   lane l holds unit l % 32, k = 8 (l / 32) + 0..7      (from LDS, host-packed)
+//   B [16 k x 32 evals]:   lane l holds evaluation l % 32, k = 8 (l / 32) + 0..7 (registers, loaded once)
+//   D [32 units x 32 evals]: lane l holds evaluation l % 32; register i holds unit 8 (i / 4) + 4 (l / 32) + i % 4
+// ------------------------------------------------------------------------------------
+template <int NOUT>
+__global__ void __launch_bounds__(kBlock, 1)
+wide_gemm_kernel(WideDesc d, const uint4 *__restrict__ xn, int64_t NE, float *__restrict__ outputs, uint8_t *__restrict__ flags)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint4 *buf0 = reinterpret_cast<uint4 *>(smem), *buf1 = buf0 + kChunkU4Pad;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, col = lane & 31;
+    const int64_t ev = (int64_t)blockIdx.x * kWideTile + wave * 32 + col;      // this lane's evaluation (both halves)
+
+    // this wave's 32 evaluations as B operands, in registers for the whole kernel
+    bf16x8 B[kKSteps];
+#pragma unroll
+    for (int ks = 0; ks < kKSteps; ks++) {
+        union { uint4 u; bf16x8 v; } b;
+        b.u = ev < NE ? xn[ev * (kWideK / 8) + 2 * ks + half] : uint4{0, 0, 0, 0};
+        B[ks] = b.v;
+    }
+    float ysum[NOUT];
+#pragma unroll
+    for (int o = 0; o < NOUT; o++) ysum[o] = 0.0f;
+
+    // Weight chunks go global -> LDS without passing through registers (LDS-DMA: lane l of a wave lands at base + 16 l);
+    // chunk c+1 is in flight while chunk c is multiplied.
+    auto fetch_chunk = [&](int ch, uint4 *dst) {
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int i0 = (wave + (kBlock / 64) * j) * 64;       // this wave's 64 consecutive 16-byte elements
+            if (i0 < kChunkU4) {
+                const int i = i0 + lane < kChunkU4 ? i0 + lane : kChunkU4 - 1;   // the chunk ends inside the last span
+                __builtin_amdgcn_global_load_lds(d.wpack + (size_t)ch * kChunkU4 + i, dst + i0, 16, 0, 0);
+            }
+        }
+    };
+    fetch_chunk(0, buf0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                           // vmcnt(0): the LDS-DMA has landed
+    __syncthreads();
+    for (int ch = 0; ch < d.n_chunks; ch++) {
+        const uint4 *cur = (ch & 1) ? buf1 : buf0;
+        if (ch + 1 < d.n_chunks) fetch_chunk(ch + 1, (ch & 1) ? buf0 : buf1);
+        floatx16 acc = {0};
+#pragma unroll
+        for (int ks = 0; ks < kKSteps; ks++) {
+            union { uint4 u; bf16x8 v; } a;
+            a.u = cur[ks * 64 + lane];
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, B[ks], acc, 0, 0, 0);
+        }
+        // epilogue: bias, transfer function, second-layer weights (this chunk's constants follow its fragments in LDS)
+        const float *cst = reinterpret_cast<const float *>(cur + kKSteps * 64);
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const int u0 = 8 * g + 4 * half;                      // units u0 .. u0 + 3 live in registers 4g .. 4g + 3
+            const float4 b0 = *reinterpret_cast<const float4 *>(cst + u0);
+            float4 w1[NOUT];
+#pragma unroll
+            for (int o = 0; o < NOUT; o++) w1[o] = o < d.n_out ? *reinterpret_cast<const float4 *>(cst + 32 + 32 * o + u0) : float4{0.f, 0.f, 0.f, 0.f};
+            const float bb[4] = {b0.x, b0.y, b0.z, b0.w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float a0 = transfer_fast(d.tf0, acc[4 * g + j] + bb[j]);
+#pragma unroll
+                for (int o = 0; o < NOUT; o++) {
+                    const float ww = j == 0 ? w1[o].x : (j == 1 ? w1[o].y : (j == 2 ? w1[o].z : w1[o].w));
+                    ysum[o] = fmaf(a0, ww, ysum[o]);
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);                       // the next chunk has landed (this wave's part)
+        __syncthreads();
+    }
+    // the two lane halves hold disjoint units of the same evaluations
+#pragma unroll
+    for (int o = 0; o < NOUT; o++) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(ysum[o]), __float_as_uint(ysum[o]), false, false);
+        ysum[o] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    if (half == 0 && ev < NE) {
+        bool hit = false;
+#pragma unroll
+        for (int o = 0; o < NOUT; o++) {
+            if (o >= d.n_out) break;
+            float y = transfer_fast(d.tf1, ysum[o] + d.b1[o]);
+            for (int q = 0; q < d.n_out_fns; q++) {               // reverse maps, NeuralNet.swift:137-142 / :175-180
+                const float *op = d.out_params + q * (1 + 2 * d.n_out);
+                y = (y - op[0]) / op[1 + o] + op[1 + d.n_out + o];
+            }
+            if (outputs) outputs[ev * d.n_out + o] = y;
+            if (o == 0 || d.rule == 1) hit = hit || ((double)y >= d.thresholds[o]);
+        }
+        if (flags) flags[ev] = hit ? 1 : 0;
+    }
+}
+
+}  // namespace
+
+hipError_t launch_wide_prep(const NetDesc &n, int F, const float *columns, int C, int64_t J, int64_t E, void *xn, hipStream_t stream)
+{
+    if (E <= 0 || C <= 0) return hipSuccess;
+    const int64_t per_block = (int64_t)(256 / kWave) * kPrepRun;
+    dim3 grid((unsigned)((E + per_block - 1) / per_block), (unsigned)C);
+    hipLaunchKernelGGL(wide_prep_kernel, grid, dim3(256), 0, stream, n, F, columns, J, E, (__bf16 *)xn);
+    return hipGetLastError();
+}
+
+hipError_t launch_wide_gemm(const WideDesc &d, const void *xn, int64_t NE, float *outputs, uint8_t *flags, hipStream_t stream)
+{
+    if (NE <= 0) return hipSuccess;
+    dim3 grid((unsigned)((NE + kWideTile - 1) / kWideTile));
+    auto kern = d.n_out == 1 ? wide_gemm_kernel<1> : wide_gemm_kernel<4>;
+    hipError_t st = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kChunkU4Pad * 16);
+    if (st != hipSuccess) return st;
+    hipLaunchKernelGGL(kern, grid, dim3(kBlock), 2 * kChunkU4Pad * 16, stream, d, (const uint4 *)xn, NE, outputs, flags);
+    return hipGetLastError();
+}
+
+}  // namespace sd

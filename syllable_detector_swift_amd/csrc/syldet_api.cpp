@@ -93,6 +93,11 @@ struct syldet {
     DeviceBuffer d_fused;             // one blob: dfrag | wfrag | koff | bias0 | rvec | w1 | b1 | out_params
     DeviceBuffer d_stage_in, d_stage_out, d_stage_flags, d_stage_idx, d_stage_cnt;
     DeviceBuffer d_planar;            // channel-major copy of interleaved input (syldet_run_interleaved*)
+
+    // wide-network engine (SYLDET_ENGINE_WIDE_BF16)
+    WideDesc wide{};
+    DeviceBuffer d_wide;              // packed first-layer chunks | b1 | output maps
+    DeviceBuffer d_xn;                // [C*E][kWideK] bf16 normalised inputs
     hipStream_t stream = nullptr;     // used by the host-pointer entry points
 
     std::vector<std::unique_ptr<ChannelStream>> streams;
@@ -195,6 +200,65 @@ int build_tables(syldet *h)
     SYLDET_HIP(hipMemcpy(h->d_thr.ptr, c.thresholds, (size_t)c.n_thresholds * sizeof(double), hipMemcpyHostToDevice));
     n.params = (const float *)h->d_params.ptr;
     n.thresholds = (const double *)h->d_thr.ptr;
+    return SYLDET_OK;
+}
+
+// float -> bf16, round to nearest even (what v_cvt_pk_bf16_f32 does on the device)
+uint16_t to_bf16(float f)
+{
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+// Wide-network engine tables: the first layer in MFMA A-operand order, 32 hidden units per chunk (kernels_wide.hip).
+int upload_wide(syldet *h, std::string &why)
+{
+    const syldet_config_t &c = h->cfg.view;
+    if (c.n_layers != 2) { why = "needs exactly two layers"; return SYLDET_ERR_UNSUPPORTED; }
+    const syldet_layer_t &L0 = c.layers[0], &L1 = c.layers[1];
+    if (L0.inputs > kWideK) { why = "more than 320 network inputs"; return SYLDET_ERR_UNSUPPORTED; }
+    if (L0.outputs < 32) { why = "hidden layer narrower than 32 units"; return SYLDET_ERR_UNSUPPORTED; }
+    if (L1.outputs > 4) { why = "more than 4 outputs"; return SYLDET_ERR_UNSUPPORTED; }
+    const int I = L0.inputs, H = L0.outputs, n_out = L1.outputs, n_chunks = (H + 31) / 32;
+    const size_t chunk_u16 = kWideChunkBytes / 2;
+    std::vector<uint16_t> pack((size_t)n_chunks * chunk_u16, 0);
+    for (int ch = 0; ch < n_chunks; ch++) {
+        uint16_t *frag = pack.data() + (size_t)ch * chunk_u16;
+        for (int ks = 0; ks < kWideK / 16; ks++)
+            for (int l = 0; l < 64; l++)
+                for (int j = 0; j < 8; j++) {
+                    const int unit = 32 * ch + (l & 31), k = 16 * ks + 8 * (l >> 5) + j;
+                    const float v = (unit < H && k < I) ? L0.weights[(size_t)unit * I + k] : 0.0f;
+                    frag[((size_t)ks * 64 + l) * 8 + j] = to_bf16(v);
+                }
+        float *cst = reinterpret_cast<float *>(frag + (size_t)(kWideK / 16) * 64 * 8);
+        for (int u = 0; u < 32; u++) {
+            const int unit = 32 * ch + u;
+            cst[u] = unit < H ? L0.biases[unit] : 0.0f;
+            for (int o = 0; o < 4; o++) cst[32 + 32 * o + u] = (unit < H && o < n_out) ? L1.weights[(size_t)o * H + unit] : 0.0f;
+        }
+    }
+    std::vector<float> misc(L1.biases, L1.biases + n_out);
+    for (int k = 0; k < c.n_output_fns; k++) {
+        const syldet_fn_t &f = c.output_fns[k];
+        misc.push_back(f.y);
+        misc.insert(misc.end(), f.gains, f.gains + n_out);
+        misc.insert(misc.end(), f.x_offsets, f.x_offsets + n_out);
+    }
+    const size_t pack_bytes = pack.size() * 2, misc_bytes = misc.size() * sizeof(float);
+    if (int st = h->d_wide.reserve(pack_bytes + misc_bytes)) return st;
+    SYLDET_HIP(hipMemcpy(h->d_wide.ptr, pack.data(), pack_bytes, hipMemcpyHostToDevice));
+    SYLDET_HIP(hipMemcpy((char *)h->d_wide.ptr + pack_bytes, misc.data(), misc_bytes, hipMemcpyHostToDevice));
+    WideDesc &d = h->wide;
+    d.H = H; d.n_chunks = n_chunks; d.n_out = n_out; d.tf0 = L0.transfer; d.tf1 = L1.transfer; d.rule = c.rule;
+    d.n_out_fns = c.n_output_fns;
+    d.wpack = (const uint4 *)h->d_wide.ptr;
+    d.b1 = (const float *)((const char *)h->d_wide.ptr + pack_bytes);
+    d.out_params = d.b1 + n_out;
+    d.thresholds = (const double *)h->d_thr.ptr;
     return SYLDET_OK;
 }
 
@@ -311,6 +375,20 @@ int run_on_stream(syldet *h, const float *d_samples, int64_t S, int64_t stride, 
         return SYLDET_OK;
     }
     if (int st = h->d_columns.reserve((size_t)C * (size_t)J * (size_t)h->geom.bins * sizeof(float))) return st;
+    if (h->engine == SYLDET_ENGINE_WIDE_BF16) {
+        if (int st = h->d_xn.reserve((size_t)C * (size_t)E * (size_t)kWideK * 2)) return st;
+        {
+            KernelTimer t(h, stream, "stft_generic_kernel");
+            SYLDET_HIP(launch_stft_generic(h->stft, d_samples, stride, C, J, (float *)h->d_columns.ptr, stream));
+        }
+        {
+            KernelTimer t(h, stream, "wide_prep_kernel");
+            SYLDET_HIP(launch_wide_prep(h->net, h->geom.bins, (const float *)h->d_columns.ptr, C, J, E, h->d_xn.ptr, stream));
+        }
+        KernelTimer t(h, stream, "wide_gemm_kernel");
+        SYLDET_HIP(launch_wide_gemm(h->wide, h->d_xn.ptr, (int64_t)C * E, d_outputs, d_flags, stream));
+        return SYLDET_OK;
+    }
     {
         KernelTimer t(h, stream, "stft_generic_kernel");
         SYLDET_HIP(launch_stft_generic(h->stft, d_samples, stride, C, J, (float *)h->d_columns.ptr, stream));
@@ -343,7 +421,7 @@ int syldet_create(const syldet_config_t *cfg, int32_t n_channels, int32_t device
     *out = nullptr;
     if (n_channels <= 0 || n_channels > 65535)
         return fail(SYLDET_ERR_INVALID_ARGUMENT, "n_channels must be in [1, 65535]");
-    if (engine != SYLDET_ENGINE_AUTO && engine != SYLDET_ENGINE_GENERIC && engine != SYLDET_ENGINE_FUSED)
+    if (engine != SYLDET_ENGINE_AUTO && engine != SYLDET_ENGINE_GENERIC && engine != SYLDET_ENGINE_FUSED && engine != SYLDET_ENGINE_WIDE_BF16)
         return fail(SYLDET_ERR_INVALID_ARGUMENT, "unknown engine");
     std::unique_ptr<syldet> h(new (std::nothrow) syldet());
     if (!h) return fail(SYLDET_ERR_OUT_OF_MEMORY, "out of memory");
@@ -363,7 +441,7 @@ int syldet_create(const syldet_config_t *cfg, int32_t n_channels, int32_t device
     h->device = device;
     h->channels = n_channels;
     h->engine = SYLDET_ENGINE_GENERIC;
-    if (engine != SYLDET_ENGINE_GENERIC) {
+    if (engine != SYLDET_ENGINE_GENERIC && engine != SYLDET_ENGINE_WIDE_BF16) {
         // The fused engine hands columns to the first layer as f16 hi + lo pairs.  For linear |X| columns that is below
         // fp32 noise; log / dB values (magnitude up to ~100, 2^-22 relative = a few 1e-5 absolute) can leave the 1e-5
         // parity bar.  AUTO therefore keeps those scalings on the generic engine; the fused one stays available on request.
@@ -388,6 +466,15 @@ int syldet_create(const syldet_config_t *cfg, int32_t n_channels, int32_t device
             return st;
         }
     }
+    if (engine == SYLDET_ENGINE_WIDE_BF16) {
+        std::string why;
+        if (int st = upload_wide(h.get(), why)) {
+            syldet_destroy(h.release());
+            return why.empty() ? st : fail(st, "wide-network engine not available for this configuration: " + why);
+        }
+        h->engine = SYLDET_ENGINE_WIDE_BF16;
+        h->geom.engine = h->engine;
+    }
     h->streams.resize((size_t)n_channels);
     for (auto &s : h->streams) {
         s.reset(new ChannelStream());
@@ -406,7 +493,7 @@ int syldet_destroy(syldet_t *h)
         (void)hipStreamDestroy(h->stream);
     }
     for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
-    for (DeviceBuffer *b : {&h->d_window, &h->d_tw, &h->d_sw, &h->d_params, &h->d_thr, &h->d_columns, &h->d_fused, &h->d_stamps, &h->d_planar, &h->d_stage_in,
+    for (DeviceBuffer *b : {&h->d_window, &h->d_tw, &h->d_sw, &h->d_params, &h->d_thr, &h->d_columns, &h->d_fused, &h->d_stamps, &h->d_planar, &h->d_wide, &h->d_xn, &h->d_stage_in,
                             &h->d_stage_out, &h->d_stage_flags, &h->d_stage_idx, &h->d_stage_cnt})
         b->release();
     delete h;

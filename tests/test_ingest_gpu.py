@@ -117,3 +117,46 @@ def test_wide_network_config5_on_the_generic_engine(oracle_lib):
         torch.cuda.synchronize()
         util.assert_outputs_close(out.cpu().numpy()[0], want)
         util.assert_flags_exact(fl.cpu().numpy()[0], want64, cfg.thresholds, cfg.rule)
+
+
+WIDE_TOL = 1e-2      # bf16 inputs and first-layer weights (8-bit significands), fp32 accumulate: BASELINE configs[4]'s own bar
+
+
+@pytest.mark.parametrize("shape", ["config5", "H96_3out_logsig", "H40_normalize"])
+def test_wide_network_bf16_mfma_engine(oracle_lib, shape):
+    """The opt-in wide engine (first layer as a bf16 MFMA GEMM over thousands of evaluations) against the fp64 anchor,
+    to bf16's bar; flags wherever the anchor is farther than that from the threshold."""
+    torch = _torch()
+    base = nets.from_npz()
+    rng = np.random.default_rng(3)
+    if shape == "config5":
+        cfg = nets.wide_mlp(base)
+    elif shape == "H96_3out_logsig":
+        cfg = nets.variant(base, net=nets.random_net(rng, 290, (96,), 3, transfer=("LogSig", "TanSig")), thresholds=[0.1, 0.2, 0.3],
+                           rule=_abi.RULE_ANY)
+    else:
+        cfg = nets.variant(base, net=nets.random_net(rng, 290, (40,), 1, transfer=("SatLin", "PureLin"), in_fns=("normalize",), out_fns=()))
+    C, S = 3, 70000                                      # 3 x 521 evaluations: several 512-evaluation tiles, ragged end
+    x = synth.channels(C, S, first=60, fs=cfg.samplingRate)
+    o = po.Oracle(po.from_config(cfg))
+    with sd.SyllableDetector(cfg, channels=C, engine=_abi.ENGINE_WIDE_BF16) as det:
+        assert det.geometry.engine == _abi.ENGINE_WIDE_BF16
+        out, fl = det.run(torch.from_numpy(x).cuda())
+        torch.cuda.synchronize()
+        out, fl = out.cpu().numpy(), fl.cpu().numpy()
+    worst = 0.0
+    for c in range(C):
+        _, _, w64 = o.run(x[c], po.F64, cfg.rule)
+        util.assert_outputs_close(out[c], w64, WIDE_TOL)
+        util.assert_flags_exact(fl[c], w64, cfg.thresholds, cfg.rule, WIDE_TOL)
+        worst = max(worst, float(np.abs(out[c] - w64).max()))
+    assert worst > 1e-7, "bf16 rounding should be visible: is the engine really running?"
+
+
+def test_wide_engine_is_opt_in_and_checks_the_shape():
+    base = nets.from_npz()
+    with sd.SyllableDetector(nets.wide_mlp(base), channels=1) as det:          # AUTO never picks bf16
+        assert det.geometry.engine == _abi.ENGINE_GENERIC
+    with pytest.raises(sd.SyllableDetectorError) as ei:                        # sample.txt: 4 hidden units
+        sd.SyllableDetector(base, channels=1, engine=_abi.ENGINE_WIDE_BF16)
+    assert ei.value.status == _abi.ERR_UNSUPPORTED
