@@ -112,6 +112,8 @@ struct FusedDesc {
     const float *w1, *b1;       // layer 1, row-major [n_out][H] (2-layer nets)
     const float *out_params;    // per output fn: y, gain[n_out], xoff[n_out]
     const double *thresholds;   // [n_out]
+    float *spect_out;           // spectrogram instantiation only: [C][J][F] columns
+    int spect_power;            //   0: |X|, 1: |X|^2
     int ko;                     // diagnostic build only: knock-out mask (SYLDET_FUSED_KO)
     unsigned long long *stamps; // diagnostic build only: [workgroups][16] phase cycle sums, else null
 };
@@ -125,6 +127,8 @@ hipError_t launch_deinterleave(const float *in, int64_t n_frames, int total, int
 
 hipError_t launch_fused(const FusedDesc &d, const float *samples, int64_t stride, int C, int64_t S, int64_t J,
                         int64_t E, float *outputs, uint8_t *flags, hipStream_t stream);
+// the DFT front half alone: samples -> [C][J][F] columns; d: a plan for timeRange 1 with spect_out / spect_power set
+hipError_t launch_fused_spectrogram(const FusedDesc &d, const float *samples, int64_t stride, int C, int64_t J, hipStream_t stream);
 // taps the register-resident first-layer fragments are instantiated for (0: timeRange too long)
 int fused_taps_max(int T);
 

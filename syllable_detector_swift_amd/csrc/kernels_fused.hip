@@ -185,7 +185,7 @@ __device__ __forceinline__ float wave_max_nonneg(float x)
 //     next pass's samples: scale, split, -> LDS (the staged region is free now);  issue the loads of the pass
 //     after that (a whole pass of lead time)
 //   barrier
-template <int KS, int TMAX, int NL, bool EXACT, bool SKEW, bool LEAN, bool STAMP, int KNOCK>
+template <int KS, int TMAX, int NL, bool EXACT, bool SKEW, bool LEAN, bool STAMP, int KNOCK, bool SPECT>
 __global__ void __launch_bounds__(kBlock, 2)
 fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t stride, int64_t s_eff, int64_t E,
              float *__restrict__ outputs, uint8_t *__restrict__ flags)
@@ -222,8 +222,8 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
 
     // ---- once per workgroup: constants
     for (int i = tid; i < KS * 8 * 64; i += kBlock) lds_dfrag[i] = reinterpret_cast<const uint32x4 *>(d.dfrag)[i];
-    if (tid < 16) reinterpret_cast<double *>(cst + kCstThr)[tid] = tid < n_out ? d.thresholds[tid] : 0.0;
-    for (int i = tid; i < d.n_out_fns * (1 + 2 * n_out); i += kBlock) cst[kCstOut + i] = d.out_params[i];
+    if (!SPECT && tid < 16) reinterpret_cast<double *>(cst + kCstThr)[tid] = tid < n_out ? d.thresholds[tid] : 0.0;
+    for (int i = tid; i < (SPECT ? 0 : d.n_out_fns * (1 + 2 * n_out)); i += kBlock) cst[kCstOut + i] = d.out_params[i];
     // first-layer fragments, one (hi, lo) pair per tap: A operand, lane l holds row l&15 (hidden unit, or the
     // statistic row), k = 8*(l>>4) + j (bin)
     half8 afr[TMAX][2];
@@ -231,26 +231,29 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
     for (int t = 0; t < TMAX; t++)
 #pragma unroll
         for (int p = 0; p < 2; p++)
-            afr[t][p] = as_half8(reinterpret_cast<const uint32x4 *>(d.afrag)[((t < T ? t : 0) * 2 + p) * 64 + lane]);
+            afr[t][p] = SPECT ? half8{} : as_half8(reinterpret_cast<const uint32x4 *>(d.afrag)[((t < T ? t : 0) * 2 + p) * 64 + lane]);
     // evaluation-phase constants of the 4 hidden units this lane group owns (rows 4*g4 + j of a result)
     float c_b0[4], c_rv[4], c_w1[4][4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int h = 4 * g4 + j;
-        c_b0[j] = h < H ? d.bias0[h] : 0.0f;
-        c_rv[j] = h < H ? d.rvec[h] : 0.0f;
+        c_b0[j] = (!SPECT && h < H) ? d.bias0[h] : 0.0f;
+        c_rv[j] = (!SPECT && h < H) ? d.rvec[h] : 0.0f;
 #pragma unroll
-        for (int o = 0; o < 4; o++) c_w1[o][j] = (n_layers == 2 && h < H && o < n_out) ? d.w1[o * H + h] : 0.0f;
+        for (int o = 0; o < 4; o++) c_w1[o][j] = (!SPECT && n_layers == 2 && h < H && o < n_out) ? d.w1[o * H + h] : 0.0f;
     }
     float c_b1[4];
 #pragma unroll
-    for (int o = 0; o < 4; o++) c_b1[o] = (n_layers == 2 && o < n_out) ? d.b1[o] : 0.0f;
+    for (int o = 0; o < 4; o++) c_b1[o] = (!SPECT && n_layers == 2 && o < n_out) ? d.b1[o] : 0.0f;
 
     // results leave through bounds-checked descriptors of this channel's rows: a lane with nothing to store uses an
     // offset past the end (dropped by the hardware), so the evaluation carries no branches
     const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(
         outputs ? outputs + (int64_t)c * E * n_out : nullptr, 0, outputs ? (int)(E * n_out * 4) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t flg_rs = __builtin_amdgcn_make_buffer_rsrc(flags ? flags + (int64_t)c * E : nullptr, 0, flags ? (int)E : 0, 0x00020000);
+    // SPECT: the columns themselves leave, [C][J][F] fp32 (E counts frames then)
+    const __amdgpu_buffer_rsrc_t spc_rs = __builtin_amdgcn_make_buffer_rsrc(
+        SPECT ? d.spect_out + (int64_t)c * E * d.F : nullptr, 0, SPECT ? (int)(E * d.F * 4) : 0, 0x00020000);
     // LEAN: at most one output map, applied unconditionally (identity when there is none)
     float lean_oa = 0.0f, lean_og = 1.0f, lean_ob = 0.0f;
     if (LEAN && d.n_out_fns == 1) { lean_oa = d.out_params[0]; lean_og = d.out_params[1]; lean_ob = d.out_params[2]; }
@@ -509,7 +512,7 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
                     asm volatile("" ::"v"(cbh), "v"(cbl));
                 }
                 // the previous pass's evaluation, one or two steps per k-step
-                if (!(kom & 128)) {
+                if (!(kom & 128) && !SPECT) {
                     if (KS == 8) post_step(ks, p - 1, cse_post, csx_post);
                     else { post_step(2 * ks, p - 1, cse_post, csx_post); post_step(2 * ks + 1, p - 1, cse_post, csx_post); }
                 }
@@ -532,7 +535,7 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
         csx_post = csx;
         // ---- the previous pass's last T-1 columns -> the front of the transition strip (rescaled from their own scale);
         // done by the wave that overwrites their slots right after, so program order keeps the two apart
-        if (p > 0 && wave == kWaves - 1 && !(kom & 32)) {
+        if (!SPECT && p > 0 && wave == kWaves - 1 && !(kom & 32)) {
             const int dexp = scaling != 0 ? 0 : csx - se_prev;     // <= 0
             const int words = (T - 1) * (kColStride / 2);      // 32-bit words per array
             const int src = (XS + kPass - (T - 1)) * (kColStride / 2);
@@ -562,7 +565,20 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
         // ---- magnitude (zvabs/2 :329-333), scaling (SyllableDetector.swift:184-212),
         // statistic, f16 split, column -> LDS.  Result layout: column = frame f, register j of lane group g4 in
         // tile m = basis row 16m + 4*g4 + j; this lane holds bins 4*g4 + j (i = j) and 16 + 4*g4 + j (i = 4 + j).
-        if (!(kom & 64)) {
+        if (SPECT) {
+            // spectrogram only: |X| (zvabs/2, :329-333) or |X|^2 (zvmags/4, :270-274) of this lane's 8 bins -> HBM
+            const float inv = pow2f(-se - 13);
+            const int64_t jf = e_b + (int64_t)kPass * p + fl;
+            const bool live = jf < e_e;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const float re = acc[i >> 2][i & 3] * inv, im = acc[2 + (i >> 2)][i & 3] * inv;
+                const float pw = fmaf(re, re, im * im);
+                const int bin = (i & 3) + 16 * (i >> 2) + 4 * g4;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d.spect_power ? pw : __builtin_amdgcn_sqrtf(pw)), spc_rs,
+                                                      (live && bin < d.F) ? ((unsigned)jf * (unsigned)d.F + bin) * 4u : 0xFFFFFFFFu, 0, 0);
+            }
+        } else if (!(kom & 64)) {
             // accumulators hold X * sx * 2^13.  Column scale (power of two; col_shift from the basis' largest row sum):
             // |X| * 2^(cse - shift) < 2^13; log/dB columns are stored unscaled.  For linear columns the two scales are applied together after the square root.
             const float inv = pow2f(-se - 13);
@@ -681,7 +697,7 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
         }
     }
     // ---- evaluation of the last pass
-    if (!(kom & 128)) {
+    if (!(kom & 128) && !SPECT) {
 #pragma unroll
         for (int step = 0; step < 7; step++) post_step(step, runs - 1, cse_post, csx_post);
     }
@@ -689,11 +705,11 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
         for (int i = 0; i < 16; i++) atomicAdd(&d.stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + i], tsum[i]);
 }
 
-template <int KS, int TMAX, int NL, bool EXACT, bool SKEW, bool LEAN = false, bool STAMP = false, int KNOCK = 0>
+template <int KS, int TMAX, int NL, bool EXACT, bool SKEW, bool LEAN = false, bool STAMP = false, int KNOCK = 0, bool SPECT = false>
 hipError_t launch_one(const FusedDesc &d, const float *samples, int64_t stride, int C, int64_t s_eff, int64_t E,
                       float *outputs, uint8_t *flags, hipStream_t stream)
 {
-    auto kern = fused_kernel<KS, TMAX, NL, EXACT, SKEW, LEAN, STAMP, KNOCK>;
+    auto kern = fused_kernel<KS, TMAX, NL, EXACT, SKEW, LEAN, STAMP, KNOCK, SPECT>;
     hipError_t st = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, d.lds_total);
     if (st != hipSuccess) return st;
     const int64_t segs = (E + d.seg_evals - 1) / d.seg_evals;
@@ -747,6 +763,22 @@ hipError_t launch_fused(const FusedDesc &d, const float *samples, int64_t stride
         SD_GENERIC(4, 12)
     }
 #undef SD_GENERIC
+    return hipErrorInvalidValue;
+}
+
+// The DFT front half alone: samples -> [C][J][F] columns (|X| or |X|^2) in HBM.  `d` is a plan built for timeRange 1.
+hipError_t launch_fused_spectrogram(const FusedDesc &d, const float *samples, int64_t stride, int C, int64_t J, hipStream_t stream)
+{
+    if (J <= 0 || C <= 0) return hipSuccess;
+    if ((uint64_t)J * (uint64_t)d.F * 4u >= 0xFFFFFFF0ull) return hipErrorInvalidValue;    // 32-bit byte offsets per channel
+    const int64_t s_eff = (J - 1) * (int64_t)d.hop + d.gap + d.W;
+    const bool skew = d.skew != 0;
+#define SD_SPECT(KS_)                                                                                                        \
+    return skew ? launch_one<KS_, 4, kFusedMaxLoads, false, true, false, false, 0, true>(d, samples, stride, C, s_eff, J, nullptr, nullptr, stream) \
+                : launch_one<KS_, 4, kFusedMaxLoads, false, false, false, false, 0, true>(d, samples, stride, C, s_eff, J, nullptr, nullptr, stream);
+    if (d.KS == 8) { SD_SPECT(8) }
+    if (d.KS == 4) { SD_SPECT(4) }
+#undef SD_SPECT
     return hipErrorInvalidValue;
 }
 

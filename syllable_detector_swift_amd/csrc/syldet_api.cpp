@@ -94,6 +94,11 @@ struct syldet {
     DeviceBuffer d_stage_in, d_stage_out, d_stage_flags, d_stage_idx, d_stage_cnt;
     DeviceBuffer d_planar;            // channel-major copy of interleaved input (syldet_run_interleaved*)
 
+    // the fused engine's DFT front half as the STFT of the other engines (W <= 256, F <= 32, hop % 4 == 0)
+    FusedPlan dft;
+    DeviceBuffer d_dft;
+    bool has_dft = false;
+
     // wide-network engine (SYLDET_ENGINE_WIDE_BF16)
     WideDesc wide{};
     DeviceBuffer d_wide;              // packed first-layer chunks | b1 | output maps
@@ -262,9 +267,8 @@ int upload_wide(syldet *h, std::string &why)
     return SYLDET_OK;
 }
 
-int upload_fused(syldet *h)
+int upload_plan(syldet *h, FusedPlan &p, DeviceBuffer &buf)
 {
-    FusedPlan &p = h->fused;
     std::vector<unsigned char> blob;
     auto put = [&blob](const void *src, size_t bytes) {
         const size_t off = (blob.size() + 255) / 256 * 256;
@@ -276,9 +280,9 @@ int upload_fused(syldet *h)
     const size_t o_k = put(p.koff.data(), p.koff.size() * 4), o_b = put(p.bias0.data(), p.bias0.size() * 4);
     const size_t o_r = put(p.rvec.data(), p.rvec.size() * 4), o_w1 = put(p.w1.data(), p.w1.size() * 4);
     const size_t o_b1 = put(p.b1.data(), p.b1.size() * 4), o_op = put(p.out_params.data(), p.out_params.size() * 4);
-    if (int st = h->d_fused.reserve(blob.size())) return st;
-    SYLDET_HIP(hipMemcpy(h->d_fused.ptr, blob.data(), blob.size(), hipMemcpyHostToDevice));
-    unsigned char *base = (unsigned char *)h->d_fused.ptr;
+    if (int st = buf.reserve(blob.size())) return st;
+    SYLDET_HIP(hipMemcpy(buf.ptr, blob.data(), blob.size(), hipMemcpyHostToDevice));
+    unsigned char *base = (unsigned char *)buf.ptr;
     FusedDesc &d = p.desc;
     d.dfrag = (const uint4 *)(base + o_d);
     d.afrag = (const uint4 *)(base + o_w);
@@ -289,6 +293,31 @@ int upload_fused(syldet *h)
     d.b1 = (const float *)(base + o_b1);
     d.out_params = (const float *)(base + o_op);
     d.thresholds = (const double *)h->d_thr.ptr;
+    return SYLDET_OK;
+}
+
+int upload_fused(syldet *h) { return upload_plan(h, h->fused, h->d_fused); }
+
+// A plan for the DFT front half alone: the real STFT geometry with a one-frame, one-unit stand-in network (the
+// spectrogram instantiation never touches the network tables).
+int build_dft_plan(syldet *h)
+{
+    const syldet_config_t &c = h->cfg.view;
+    syldet_config_t sc = c;
+    const int F = h->geom.bins;
+    std::vector<float> w((size_t)F, 0.0f), b(1, 0.0f);
+    syldet_layer_t layer{};
+    layer.inputs = F; layer.outputs = 1; layer.transfer = SYLDET_TF_PURELIN; layer.weights = w.data(); layer.biases = b.data();
+    double thr = 0.0;
+    sc.time_range = 1; sc.scaling = SYLDET_SCALING_LINEAR; sc.spectrum = SYLDET_SPECTRUM_POWER;
+    sc.n_input_fns = 0; sc.input_fns = nullptr; sc.n_output_fns = 0; sc.output_fns = nullptr;
+    sc.n_layers = 1; sc.layers = &layer; sc.n_thresholds = 1; sc.thresholds = &thr;
+    syldet_geometry_t sg = h->geom;
+    sg.inputs = F; sg.outputs = 1;
+    if (!make_fused_plan(sc, sg, h->dft)) return SYLDET_OK;          // not applicable: the generic FFT stays
+    if (int st = upload_plan(h, h->dft, h->d_dft)) return st;
+    h->dft.desc.spect_power = c.spectrum == SYLDET_SPECTRUM_MAGNITUDE ? 1 : 0;
+    h->has_dft = true;
     return SYLDET_OK;
 }
 
@@ -328,6 +357,29 @@ struct KernelTimer {
         if (slot >= 0) (void)hipEventRecord(h->events[(size_t)(2 * slot + 1)], stream);
     }
 };
+
+// samples -> [C][J][F] columns: the fused engine's DFT half where its shape allows (and the handle was not created
+// for the generic engine outright), the generic FFT otherwise
+int stft_on_stream(syldet *h, const float *d_samples, int64_t stride, int C, int64_t J, float *d_columns, hipStream_t stream,
+                   bool for_network = true)
+{
+    // columns that go through log / dB keep the generic FFT: its error is relative to the frame, the block-floating-point
+    // DFT's to the loudest sample of the 128-frame pass, and the logarithm turns relative error of weak bins into absolute
+    const bool log_input = for_network && h->cfg.view.scaling != SYLDET_SCALING_LINEAR;
+    if (h->has_dft && !log_input && (uint64_t)J * (uint64_t)h->geom.bins * 4u < 0xFFFFFFF0ull) {
+        FusedDesc d = h->dft.desc;
+        fused_segmentation(d, J, C);
+        d.spect_out = d_columns;
+        d.stamps = nullptr;
+        d.ko = 0;
+        KernelTimer t(h, stream, "fused_kernel (spectrogram)");
+        SYLDET_HIP(launch_fused_spectrogram(d, d_samples, stride, C, J, stream));
+        return SYLDET_OK;
+    }
+    KernelTimer t(h, stream, "stft_generic_kernel");
+    SYLDET_HIP(launch_stft_generic(h->stft, d_samples, stride, C, J, d_columns, stream));
+    return SYLDET_OK;
+}
 
 int run_on_stream(syldet *h, const float *d_samples, int64_t S, int64_t stride, int C, float *d_outputs,
                   uint8_t *d_flags, hipStream_t stream)
@@ -377,10 +429,7 @@ int run_on_stream(syldet *h, const float *d_samples, int64_t S, int64_t stride, 
     if (int st = h->d_columns.reserve((size_t)C * (size_t)J * (size_t)h->geom.bins * sizeof(float))) return st;
     if (h->engine == SYLDET_ENGINE_WIDE_BF16) {
         if (int st = h->d_xn.reserve((size_t)C * (size_t)E * (size_t)kWideK * 2)) return st;
-        {
-            KernelTimer t(h, stream, "stft_generic_kernel");
-            SYLDET_HIP(launch_stft_generic(h->stft, d_samples, stride, C, J, (float *)h->d_columns.ptr, stream));
-        }
+        if (int st = stft_on_stream(h, d_samples, stride, C, J, (float *)h->d_columns.ptr, stream)) return st;
         {
             KernelTimer t(h, stream, "wide_prep_kernel");
             SYLDET_HIP(launch_wide_prep(h->net, h->geom.bins, (const float *)h->d_columns.ptr, C, J, E, h->d_xn.ptr, stream));
@@ -389,10 +438,7 @@ int run_on_stream(syldet *h, const float *d_samples, int64_t S, int64_t stride, 
         SYLDET_HIP(launch_wide_gemm(h->wide, h->d_xn.ptr, (int64_t)C * E, d_outputs, d_flags, stream));
         return SYLDET_OK;
     }
-    {
-        KernelTimer t(h, stream, "stft_generic_kernel");
-        SYLDET_HIP(launch_stft_generic(h->stft, d_samples, stride, C, J, (float *)h->d_columns.ptr, stream));
-    }
+    if (int st = stft_on_stream(h, d_samples, stride, C, J, (float *)h->d_columns.ptr, stream)) return st;
     {
         KernelTimer t(h, stream, "mlp_generic_kernel");
         SYLDET_HIP(launch_mlp_generic(h->net, h->geom.bins, (const float *)h->d_columns.ptr, C, J, E, d_outputs,
@@ -466,6 +512,12 @@ int syldet_create(const syldet_config_t *cfg, int32_t n_channels, int32_t device
             return st;
         }
     }
+    if (engine != SYLDET_ENGINE_GENERIC) {
+        if (int st = build_dft_plan(h.get())) {
+            syldet_destroy(h.release());
+            return st;
+        }
+    }
     if (engine == SYLDET_ENGINE_WIDE_BF16) {
         std::string why;
         if (int st = upload_wide(h.get(), why)) {
@@ -493,7 +545,7 @@ int syldet_destroy(syldet_t *h)
         (void)hipStreamDestroy(h->stream);
     }
     for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
-    for (DeviceBuffer *b : {&h->d_window, &h->d_tw, &h->d_sw, &h->d_params, &h->d_thr, &h->d_columns, &h->d_fused, &h->d_stamps, &h->d_planar, &h->d_wide, &h->d_xn, &h->d_stage_in,
+    for (DeviceBuffer *b : {&h->d_window, &h->d_tw, &h->d_sw, &h->d_params, &h->d_thr, &h->d_columns, &h->d_fused, &h->d_stamps, &h->d_planar, &h->d_wide, &h->d_xn, &h->d_dft, &h->d_stage_in,
                             &h->d_stage_out, &h->d_stage_flags, &h->d_stage_idx, &h->d_stage_cnt})
         b->release();
     delete h;
@@ -549,8 +601,8 @@ int syldet_spectrogram_device(syldet_t *h, const float *d_samples, int64_t n_sam
     if (!d_columns) return fail(SYLDET_ERR_INVALID_ARGUMENT, "NULL argument");
     SYLDET_HIP(hipSetDevice(h->device));
     const int64_t J = count_frames(h, n_samples);
-    SYLDET_HIP(launch_stft_generic(h->stft, d_samples, channel_stride, h->channels, J, d_columns, (hipStream_t)hip_stream));
-    return SYLDET_OK;
+    h->timed_kernels = 0;
+    return stft_on_stream(h, d_samples, channel_stride, h->channels, J, d_columns, (hipStream_t)hip_stream, false);
 }
 
 int syldet_detections_device(syldet_t *h, const uint8_t *d_flags, int64_t n_evals, double debounce_seconds,
@@ -651,7 +703,8 @@ int syldet_spectrogram(syldet_t *h, const float *samples, int64_t n_samples, int
     SYLDET_HIP(hipMemcpy2DAsync(h->d_stage_in.ptr, (size_t)n_samples * sizeof(float), samples,
                                 (size_t)channel_stride * sizeof(float), (size_t)n_samples * sizeof(float), (size_t)C,
                                 hipMemcpyHostToDevice, h->stream));
-    SYLDET_HIP(launch_stft_generic(h->stft, (const float *)h->d_stage_in.ptr, n_samples, C, J, (float *)h->d_columns.ptr, h->stream));
+    h->timed_kernels = 0;
+    if (int st = stft_on_stream(h, (const float *)h->d_stage_in.ptr, n_samples, C, J, (float *)h->d_columns.ptr, h->stream, false)) return st;
     SYLDET_HIP(hipMemcpyAsync(columns, h->d_columns.ptr, col_bytes, hipMemcpyDeviceToHost, h->stream));
     SYLDET_HIP(hipStreamSynchronize(h->stream));
     return SYLDET_OK;
