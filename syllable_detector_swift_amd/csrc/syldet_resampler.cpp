@@ -51,10 +51,18 @@ int syldet_resampler_create(double rate_in, double rate_out, int32_t n_channels,
     if (!r) return fail(SYLDET_ERR_OUT_OF_MEMORY, "out of memory");
     r->rate_in = rate_in; r->rate_out = rate_out; r->channels = n_channels; r->device = device;
     r->step = (float)(rate_in / rate_out);
-    SYLDET_HIP(hipSetDevice(device));
-    SYLDET_HIP(hipMalloc((void **)&r->d_last, (size_t)n_channels * sizeof(float)));
-    SYLDET_HIP(hipMemset(r->d_last, 0, (size_t)n_channels * sizeof(float)));
-    SYLDET_HIP(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
+    // device resources; on any failure the partially built handle is torn down like a finished one
+    auto bring_up = [&]() -> int {
+        SYLDET_HIP(hipSetDevice(device));
+        SYLDET_HIP(hipMalloc((void **)&r->d_last, (size_t)n_channels * sizeof(float)));
+        SYLDET_HIP(hipMemset(r->d_last, 0, (size_t)n_channels * sizeof(float)));
+        SYLDET_HIP(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
+        return SYLDET_OK;
+    };
+    if (int st = bring_up()) {
+        syldet_resampler_destroy(r.release());
+        return st;
+    }
     *out = r.release();
     return SYLDET_OK;
 }

@@ -160,3 +160,41 @@ def test_product_does_not_import_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "pyoracle" not in text and "syldet_oracle" not in text and "orc_" not in text, f
+
+
+def test_ingest_entry_points_validate_before_touching_a_device():
+    """Resampler / de-interleave argument checks (no GPU needed: they come before any HIP call)."""
+    lib = _abi.lib
+    h = _abi.Handle()
+    assert lib.syldet_resampler_create(0.0, 44100.0, 1, 0, C.byref(h)) == _abi.ERR_INVALID_ARGUMENT
+    assert lib.syldet_resampler_create(48000.0, -1.0, 1, 0, C.byref(h)) == _abi.ERR_INVALID_ARGUMENT
+    assert lib.syldet_resampler_create(48000.0, 44100.0, 0, 0, C.byref(h)) == _abi.ERR_INVALID_ARGUMENT
+    assert lib.syldet_resampler_create(48000.0, 44100.0, 1, 0, None) == _abi.ERR_INVALID_ARGUMENT
+    assert lib.syldet_resampler_count(None, 1000) == 0
+    assert lib.syldet_resampler_destroy(None) == 0
+    assert lib.syldet_resample(None, None, 10, 10, None, 10, None) == _abi.ERR_INVALID_ARGUMENT
+    # channel selections outside the interleaved layout
+    for total, first, count in [(0, 0, 1), (2, -1, 1), (2, 1, 2), (2, 0, 0)]:
+        assert lib.syldet_deinterleave_device(None, 10, total, first, count, None, 10, None) == _abi.ERR_INVALID_ARGUMENT
+    assert lib.syldet_deinterleave_device(None, 0, 2, 0, 2, None, 0, None) == 0        # nothing to do
+    assert lib.syldet_run_interleaved(None, None, 10, 1, None, None) == _abi.ERR_INVALID_ARGUMENT
+
+
+def test_resampler_needs_a_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(sd.SyllableDetectorError) as ei:
+        sd.ResamplerLinear(48000.0, 44100.0)
+    assert ei.value.status == _abi.ERR_NO_DEVICE
+
+
+def test_wide_engine_is_declared_and_needs_a_device():
+    import torch
+    assert _abi.ENGINE_WIDE_BF16 == 3
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from syllable_detector_swift_amd import nets
+    with pytest.raises(sd.SyllableDetectorError) as ei:
+        sd.SyllableDetector(nets.wide_mlp(util.sample_net()), engine=_abi.ENGINE_WIDE_BF16)
+    assert ei.value.status == _abi.ERR_NO_DEVICE
