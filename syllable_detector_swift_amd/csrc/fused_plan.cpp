@@ -162,7 +162,7 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
         for (int m = 0; m < 4; m++)
             for (int l = 0; l < 64; l++)
                 for (int j = 0; j < 8; j++) {
-                    const int r = 16 * (m & 1) + (l & 15), n = 32 * ks + 8 * (l >> 4) + j;
+                    const int r = 16 * (m & 1) + (l & 15), n = 8 * (ks + KS * (l >> 4)) + j;   // k-step ks, lane group g: sample block ks + KS g
                     const bool imag = m >= 2;
                     double v = 0.0;
                     if (r < F && n < W) {
@@ -241,7 +241,7 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
     p.koff.resize((size_t)KS * 4);
     for (int ks = 0; ks < KS; ks++)
         for (int h = 0; h < 4; h++) {
-            const int o = 32 * ks + 8 * h;
+            const int o = 8 * (ks + KS * h);
             p.koff[(size_t)ks * 4 + h] = o + skew * (o / hop);
         }
     p.ok = true;

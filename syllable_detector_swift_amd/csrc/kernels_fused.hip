@@ -259,11 +259,13 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
     if (LEAN && d.n_out_fns == 1) { lean_oa = d.out_params[0]; lean_og = d.out_params[1]; lean_ob = d.out_params[2]; }
 
     // this lane's frame in the staged stream, and where k-step ks of lane group g4 starts inside it
-    const int foff = fl * (d.hop + (SKEW ? d.skew : 0)) + (SKEW ? 0 : 8 * g4);
+    // A k-step's 32 samples are four 8-sample blocks KS blocks apart (block ks + KS g4 for lane group g4), not four
+    // neighbours: the lane groups of one ds_read then sit 4 KS dwords apart and, at hop 132, on disjoint banks.
+    const int foff = fl * (d.hop + (SKEW ? d.skew : 0)) + (SKEW ? 0 : 8 * KS * g4);
     const _Float16 *fph = smph + foff, *fpl = smpl + foff;
     int ko[KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ks++) ko[ks] = SKEW ? d.koff[ks * 4 + g4] : 32 * ks;   // immediates without skew
+    for (int ks = 0; ks < KS; ks++) ko[ks] = SKEW ? d.koff[ks * 4 + g4] : 8 * ks;   // immediates without skew
 
     // raw samples of one pass: quads 4*(tid + 512 k), k < nload, through a bounds-checked descriptor
     uint32x4 v[NL];
