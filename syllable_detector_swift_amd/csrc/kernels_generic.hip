@@ -45,6 +45,137 @@ __device__ __forceinline__ float wave_min(float v) { return wave_reduce(v, [](fl
 __device__ __forceinline__ float wave_max(float v) { return wave_reduce(v, [](float a, float b) { return fmaxf(a, b); }); }
 
 // ------------------------------------------------------------------------------------
+// 1024-point frames (BASELINE configs[2]): the 512-point complex FFT of the packed real frame as 8 x 8 x 8,
+// one wave per frame, eight points per lane, three radix-8 passes in registers with two transposes through a
+// wave-private 4.5 KB of LDS -- no workgroup barriers, 6 LDS round trips per point instead of 18.
+//   n = 64 a + b, k = c + 8 d:     X[c + 8 d] = sum_b W64^(b d) . W512^(b c) . sum_a z[64 a + b] W8^(a c)
+//   b = 8 a' + b', d = c' + 8 d':  (64-point part) = sum_b' W8^(b' d') . W64^(b' c') . sum_a' y[c][8 a' + b'] W8^(a' c')
+// Window, packing, real split and |X| are those of stft_generic_kernel.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ void dft8(float2 (&v)[8])
+{
+    // radix-2 decimation in frequency: X[2m] from a = v[j] + v[j+4], X[2m+1] from b = (v[j] - v[j+4]) W8^j, each a 4-point DFT
+    const float h = 0.70710678118654752f;
+    float2 a[4], b[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        a[j] = make_float2(v[j].x + v[j + 4].x, v[j].y + v[j + 4].y);
+        b[j] = make_float2(v[j].x - v[j + 4].x, v[j].y - v[j + 4].y);
+    }
+    b[1] = make_float2(h * (b[1].x + b[1].y), h * (b[1].y - b[1].x));       // (1 - i)/sqrt2
+    b[2] = make_float2(b[2].y, -b[2].x);                                    // -i
+    b[3] = make_float2(h * (b[3].y - b[3].x), -h * (b[3].x + b[3].y));      // (-1 - i)/sqrt2
+    auto dft4 = [](const float2 (&u)[4], float2 &y0, float2 &y1, float2 &y2, float2 &y3) {
+        const float2 p0 = make_float2(u[0].x + u[2].x, u[0].y + u[2].y), p1 = make_float2(u[0].x - u[2].x, u[0].y - u[2].y);
+        const float2 q0 = make_float2(u[1].x + u[3].x, u[1].y + u[3].y);
+        const float2 q1 = make_float2(u[1].y - u[3].y, -(u[1].x - u[3].x));   // (u1 - u3) . (-i)
+        y0 = make_float2(p0.x + q0.x, p0.y + q0.y);
+        y1 = make_float2(p1.x + q1.x, p1.y + q1.y);
+        y2 = make_float2(p0.x - q0.x, p0.y - q0.y);
+        y3 = make_float2(p1.x - q1.x, p1.y - q1.y);
+    };
+    dft4(a, v[0], v[2], v[4], v[6]);
+    dft4(b, v[1], v[3], v[5], v[7]);
+}
+
+constexpr int kR8Frames = 8;          // frames per wave
+constexpr int kR8Lds = 8 * 72;        // float2 per wave: rows of 64 (+8) / 8 x 8 rows of 8 (+1) / 512 in natural order
+
+__global__ void __launch_bounds__(kBlock)
+stft_r8_kernel(StftDesc d, const float *__restrict__ samples, int64_t stride, int64_t J, float *__restrict__ columns)
+{
+    __shared__ float2 lds_all[(kBlock / kWave) * kR8Lds];
+    const int wave = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
+    float2 *buf = lds_all + wave * kR8Lds;
+    const int c = blockIdx.y;
+    const float *chan = samples + (int64_t)c * stride;
+    float *cols = columns + (int64_t)c * J * d.F;
+    const int hi3 = lane >> 3, lo3 = lane & 7;
+    auto w1024 = [&](int idx) {                                   // e^{-2 pi i idx / 1024} from the half table
+        idx &= 1023;
+        const float2 w = d.sw[idx & 511];
+        return idx & 512 ? make_float2(-w.x, -w.y) : w;
+    };
+    // per-lane constants: window for points 64 a + lane, twiddles of the two inter-pass multiplications
+    float wre[8], wim[8];
+    float2 tw1[8], tw2[8];
+#pragma unroll
+    for (int a = 0; a < 8; a++) {
+        const int n0 = 2 * (64 * a + lane);
+        wre[a] = n0 < d.W ? d.window[n0] : 0.0f;
+        wim[a] = n0 + 1 < d.W ? d.window[n0 + 1] : 0.0f;
+        tw1[a] = w1024(2 * lane * a);                             // W512^(b c), b = lane, c = a
+        tw2[a] = w1024(16 * lo3 * a);                             // W64^(b' c'), b' = lane & 7, c' = a
+    }
+    const int64_t j0 = ((int64_t)blockIdx.x * (kBlock / kWave) + wave) * kR8Frames;
+    if (j0 >= J) return;
+    // raw samples of a frame: points 64 a + lane, as (even, odd) pairs; the next frame is fetched while this one is transformed
+    auto fetch = [&](int64_t j, float2 (&raw)[8]) {
+        const float *x = chan + j * d.hop + d.gap;
+        if ((reinterpret_cast<uintptr_t>(x) & 7) == 0 && d.W == 1024) {   // wave-uniform: whole aligned frames take 8-byte loads
+#pragma unroll
+            for (int a = 0; a < 8; a++) raw[a] = reinterpret_cast<const float2 *>(x)[64 * a + lane];
+        } else {
+#pragma unroll
+            for (int a = 0; a < 8; a++) {
+                const int n0 = 2 * (64 * a + lane);
+                raw[a] = make_float2(n0 < d.W ? x[n0] : 0.0f, n0 + 1 < d.W ? x[n0 + 1] : 0.0f);
+            }
+        }
+    };
+    float2 nxt[8];
+    fetch(j0, nxt);
+    for (int r = 0; r < kR8Frames; r++) {
+        const int64_t j = j0 + r;
+        if (j >= J) return;                                       // wave-uniform
+        float2 v[8];
+#pragma unroll
+        for (int a = 0; a < 8; a++)                               // window multiply (vDSP_vmul :311); zero pad (:110) via zero window entries
+            v[a] = make_float2(nxt[a].x * wre[a], nxt[a].y * wim[a]);
+        if (r + 1 < kR8Frames && j + 1 < J) fetch(j + 1, nxt);
+        dft8(v);                                                  // over a -> index c
+#pragma unroll
+        for (int cc = 0; cc < 8; cc++) buf[cc * 72 + lane] = cc ? cmul(v[cc], tw1[cc]) : v[cc];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int a = 0; a < 8; a++) v[a] = buf[hi3 * 72 + 8 * a + lo3];        // lane = (c, b'): y[c][8 a' + b']
+        __builtin_amdgcn_wave_barrier();
+        dft8(v);                                                  // over a' -> index c'
+#pragma unroll
+        for (int cc = 0; cc < 8; cc++) buf[(hi3 * 8 + cc) * 9 + lo3] = cc ? cmul(v[cc], tw2[cc]) : v[cc];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int a = 0; a < 8; a++) v[a] = buf[(hi3 * 8 + lo3) * 9 + a];       // lane = (c, c'): z[c][c'][b']
+        __builtin_amdgcn_wave_barrier();
+        dft8(v);                                                  // over b' -> index d'
+#pragma unroll
+        for (int dd = 0; dd < 8; dd++) buf[hi3 + 8 * lo3 + 64 * dd] = v[dd];   // Z[c + 8 c' + 64 d'], natural order
+        __builtin_amdgcn_wave_barrier();
+        // real split + magnitude for the band only; Nyquist is dropped (:323)
+        for (int f = lane; f < d.F; f += kWave) {
+            const int k = d.f0 + f;
+            float re2, im2;
+            if (k == 0) {
+                const float2 z0 = buf[0];
+                re2 = 2.0f * (z0.x + z0.y);
+                im2 = 0.0f;
+            } else {
+                const float2 zk = buf[k], zm = buf[512 - k];
+                const float2 w = d.sw[k];
+                const float ar = zk.x + zm.x, ai = zk.y - zm.y;
+                const float br = zk.x - zm.x, bi = zk.y + zm.y;
+                const float tr = br * w.x - bi * w.y, ti = br * w.y + bi * w.x;
+                re2 = ar + ti;
+                im2 = ai - tr;
+            }
+            const float p = re2 * re2 + im2 * im2;
+            cols[j * d.F + f] = d.power_mode ? p * 0.25f : sqrtf(p) * 0.5f;   // zvmags/4 :270-274, zvabs/2 :329-333
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // STFT: one frame per group of TPF = min(256, M/2) threads, G = 256/TPF frames per pass.
 // Packed real FFT: z[m] = xw[2m] + i xw[2m+1] (the vDSP_ctoz step :314-316), M-point
 // complex Stockham radix-2 through two LDS buffers, then the real split restricted to the
@@ -479,6 +610,12 @@ hipError_t launch_stft_generic(const StftDesc &d, const float *samples, int64_t 
                                float *columns, hipStream_t stream)
 {
     if (J <= 0 || C <= 0) return hipSuccess;
+    if (d.M == 512) {                              // 1024-point frames: the radix-8 wave-per-frame kernel
+        const int64_t per_block = (int64_t)(kBlock / kWave) * kR8Frames;
+        dim3 grid((unsigned)((J + per_block - 1) / per_block), (unsigned)C);
+        hipLaunchKernelGGL(stft_r8_kernel, grid, dim3(kBlock), 0, stream, d, samples, stride, J, columns);
+        return hipGetLastError();
+    }
     const int half = d.M / 2;
     const int TPF = half < kBlock ? (half < 1 ? 1 : half) : kBlock;
     const int G = kBlock / TPF;
