@@ -65,6 +65,7 @@ constexpr int kWideChunkBytes = 20 * 64 * 16 + (32 + 4 * 32) * 4;   // 32 hidden
 struct WideDesc {
     int H, n_chunks;            // first-layer outputs, chunks of 32 of them (zero padded)
     int n_out, tf0, tf1, rule, n_out_fns;
+    int sig;                    // TanSig / LogSig hidden layer folded into the tables (see wide_gemm_kernel)
     const uint4 *wpack;         // [n_chunks][kWideChunkBytes / 16]
     const float *b1;            // [n_out]
     const float *out_params;    // per output fn: y, gain[n_out], xoff[n_out]

@@ -153,7 +153,10 @@ wide_prep_kernel(NetDesc n, int F, const float *__restrict__ columns, int64_t J,
 //   B [16 k x 32 evals]:   lane l holds evaluation l % 32, k = 8 (l / 32) + 0..7 (registers, loaded once)
 //   D [32 units x 32 evals]: lane l holds evaluation l % 32; register i holds unit 8 (i / 4) + 4 (l / 32) + i % 4
 // ------------------------------------------------------------------------------------
-template <int NOUT>
+// SIG: the hidden transfer function is TanSig or LogSig and the host has folded it into the tables -- weights and biases
+// pre-scaled so that the accumulator (initialised with the bias) is the exponent, second-layer weights and bias rewritten
+// so that  y += w1' / (2^acc + 1)  is all the epilogue does: exp2, add, rcp, fma per hidden value.
+template <int NOUT, bool SIG>
 __global__ void __launch_bounds__(kBlock, 1)
 wide_gemm_kernel(WideDesc d, const uint4 *__restrict__ xn, int64_t NE, float *__restrict__ outputs, uint8_t *__restrict__ flags)
 {
@@ -193,26 +196,32 @@ wide_gemm_kernel(WideDesc d, const uint4 *__restrict__ xn, int64_t NE, float *__
     for (int ch = 0; ch < d.n_chunks; ch++) {
         const uint4 *cur = (ch & 1) ? buf1 : buf0;
         if (ch + 1 < d.n_chunks) fetch_chunk(ch + 1, (ch & 1) ? buf0 : buf1);
+        const float *cst = reinterpret_cast<const float *>(cur + kKSteps * 64);   // this chunk's constants follow its fragments
         floatx16 acc = {0};
+        {                                                         // the accumulator starts at the bias: register i holds unit 8 (i/4) + 4 half + i%4
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const float4 b0 = *reinterpret_cast<const float4 *>(cst + 8 * g + 4 * half);
+                acc[4 * g] = b0.x; acc[4 * g + 1] = b0.y; acc[4 * g + 2] = b0.z; acc[4 * g + 3] = b0.w;
+            }
+        }
 #pragma unroll
         for (int ks = 0; ks < kKSteps; ks++) {
             union { uint4 u; bf16x8 v; } a;
             a.u = cur[ks * 64 + lane];
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, B[ks], acc, 0, 0, 0);
         }
-        // epilogue: bias, transfer function, second-layer weights (this chunk's constants follow its fragments in LDS)
-        const float *cst = reinterpret_cast<const float *>(cur + kKSteps * 64);
+        // epilogue: transfer function, second-layer weights
 #pragma unroll
         for (int g = 0; g < 4; g++) {
             const int u0 = 8 * g + 4 * half;                      // units u0 .. u0 + 3 live in registers 4g .. 4g + 3
-            const float4 b0 = *reinterpret_cast<const float4 *>(cst + u0);
             float4 w1[NOUT];
 #pragma unroll
             for (int o = 0; o < NOUT; o++) w1[o] = o < d.n_out ? *reinterpret_cast<const float4 *>(cst + 32 + 32 * o + u0) : float4{0.f, 0.f, 0.f, 0.f};
-            const float bb[4] = {b0.x, b0.y, b0.z, b0.w};
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const float a0 = transfer_fast(d.tf0, acc[4 * g + j] + bb[j]);
+                const float a0 = SIG ? __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(acc[4 * g + j]) + 1.0f)
+                                     : transfer_fast(d.tf0, acc[4 * g + j]);
 #pragma unroll
                 for (int o = 0; o < NOUT; o++) {
                     const float ww = j == 0 ? w1[o].x : (j == 1 ? w1[o].y : (j == 2 ? w1[o].z : w1[o].w));
@@ -261,7 +270,8 @@ hipError_t launch_wide_gemm(const WideDesc &d, const void *xn, int64_t NE, float
 {
     if (NE <= 0) return hipSuccess;
     dim3 grid((unsigned)((NE + kWideTile - 1) / kWideTile));
-    auto kern = d.n_out == 1 ? wide_gemm_kernel<1> : wide_gemm_kernel<4>;
+    auto kern = d.sig ? (d.n_out == 1 ? wide_gemm_kernel<1, true> : wide_gemm_kernel<4, true>)
+                      : (d.n_out == 1 ? wide_gemm_kernel<1, false> : wide_gemm_kernel<4, false>);
     hipError_t st = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kChunkU4Pad * 16);
     if (st != hipSuccess) return st;
     hipLaunchKernelGGL(kern, grid, dim3(kBlock), 2 * kChunkU4Pad * 16, stream, d, (const uint4 *)xn, NE, outputs, flags);

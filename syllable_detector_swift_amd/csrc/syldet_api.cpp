@@ -230,23 +230,35 @@ int upload_wide(syldet *h, std::string &why)
     const int I = L0.inputs, H = L0.outputs, n_out = L1.outputs, n_chunks = (H + 31) / 32;
     const size_t chunk_u16 = kWideChunkBytes / 2;
     std::vector<uint16_t> pack((size_t)n_chunks * chunk_u16, 0);
+    // TanSig / LogSig hidden layers are folded into the tables: tanh(x) = 1 - 2 / (2^(s x) + 1) with s = 2 log2(e),
+    // logsig(x) = 1 / (2^(s x) + 1) with s = -log2(e).  The kernel then computes r = 1 / (2^acc + 1) with acc = s (W0 x + b0)
+    // and y += w1' r, where w1' = -2 w1 and b1' = b1 + sum w1 for tanh, unchanged for logsig.
+    const bool sig = L0.transfer == SYLDET_TF_TANSIG || L0.transfer == SYLDET_TF_LOGSIG;
+    const double sc = !sig ? 1.0 : (L0.transfer == SYLDET_TF_TANSIG ? 2.8853900817779268 : -1.4426950408889634);
+    const double w1s = (sig && L0.transfer == SYLDET_TF_TANSIG) ? -2.0 : 1.0;
     for (int ch = 0; ch < n_chunks; ch++) {
         uint16_t *frag = pack.data() + (size_t)ch * chunk_u16;
         for (int ks = 0; ks < kWideK / 16; ks++)
             for (int l = 0; l < 64; l++)
                 for (int j = 0; j < 8; j++) {
                     const int unit = 32 * ch + (l & 31), k = 16 * ks + 8 * (l >> 5) + j;
-                    const float v = (unit < H && k < I) ? L0.weights[(size_t)unit * I + k] : 0.0f;
+                    const float v = (unit < H && k < I) ? (float)(sc * (double)L0.weights[(size_t)unit * I + k]) : 0.0f;
                     frag[((size_t)ks * 64 + l) * 8 + j] = to_bf16(v);
                 }
         float *cst = reinterpret_cast<float *>(frag + (size_t)(kWideK / 16) * 64 * 8);
         for (int u = 0; u < 32; u++) {
             const int unit = 32 * ch + u;
-            cst[u] = unit < H ? L0.biases[unit] : 0.0f;
-            for (int o = 0; o < 4; o++) cst[32 + 32 * o + u] = (unit < H && o < n_out) ? L1.weights[(size_t)o * H + unit] : 0.0f;
+            cst[u] = unit < H ? (float)(sc * (double)L0.biases[unit]) : 0.0f;
+            for (int o = 0; o < 4; o++) cst[32 + 32 * o + u] = (unit < H && o < n_out) ? (float)(w1s * (double)L1.weights[(size_t)o * H + unit]) : 0.0f;
         }
     }
-    std::vector<float> misc(L1.biases, L1.biases + n_out);
+    std::vector<float> misc((size_t)n_out);
+    for (int o = 0; o < n_out; o++) {
+        double b = (double)L1.biases[o];
+        if (sig && L0.transfer == SYLDET_TF_TANSIG)
+            for (int u = 0; u < H; u++) b += (double)L1.weights[(size_t)o * H + u];
+        misc[(size_t)o] = (float)b;
+    }
     for (int k = 0; k < c.n_output_fns; k++) {
         const syldet_fn_t &f = c.output_fns[k];
         misc.push_back(f.y);
@@ -260,6 +272,7 @@ int upload_wide(syldet *h, std::string &why)
     WideDesc &d = h->wide;
     d.H = H; d.n_chunks = n_chunks; d.n_out = n_out; d.tf0 = L0.transfer; d.tf1 = L1.transfer; d.rule = c.rule;
     d.n_out_fns = c.n_output_fns;
+    d.sig = sig ? 1 : 0;
     d.wpack = (const uint4 *)h->d_wide.ptr;
     d.b1 = (const float *)((const char *)h->d_wide.ptr + pack_bytes);
     d.out_params = d.b1 + n_out;
