@@ -87,17 +87,26 @@ wide_prep_kernel(NetDesc n, int F, const float *__restrict__ columns, int64_t J,
     const float *P = n.params;
     const int I = n.I;
     const int64_t e0 = ((int64_t)blockIdx.x * (256 / kWave) + wave) * kPrepRun;
+    if (e0 >= E) return;
+    float nxt[kKI];                                             // the next evaluation's inputs, fetched one ahead
+#pragma unroll
+    for (int k = 0; k < kKI; k++) nxt[k] = lane + kWave * k < I ? cols[e0 * F + lane + kWave * k] : 0.0f;
     for (int r = 0; r < kPrepRun; r++) {
         const int64_t e = e0 + r;
         if (e >= E) return;
         float x[kKI];
 #pragma unroll
-        for (int k = 0; k < kKI; k++) {
-            const int i = lane + kWave * k;
-            float v = i < I ? cols[e * F + i] : 0.0f;
-            if (n.scaling == 1) v = logf(v);
-            else if (n.scaling == 2) v = 20.0f * log10f(v);
-            x[k] = i < I ? v : 0.0f;
+        for (int k = 0; k < kKI; k++) x[k] = nxt[k];
+        if (r + 1 < kPrepRun && e + 1 < E) {
+#pragma unroll
+            for (int k = 0; k < kKI; k++) nxt[k] = lane + kWave * k < I ? cols[(e + 1) * F + lane + kWave * k] : 0.0f;
+        }
+        if (n.scaling != 0) {
+#pragma unroll
+            for (int k = 0; k < kKI; k++) {
+                const float v = n.scaling == 1 ? logf(x[k]) : 20.0f * log10f(x[k]);
+                x[k] = lane + kWave * k < I ? v : 0.0f;
+            }
         }
         for (int q = 0; q < n.n_in_fns; q++) {
             const DevFn fn = n.in_fns[q];
