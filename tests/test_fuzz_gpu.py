@@ -69,7 +69,8 @@ def test_random_configuration(oracle_lib, seed):
     S = max(0, -cfg.windowOverlap) + cfg.windowLength + (frames - 1) * hop + int(rng.integers(0, hop))
     level = float(10.0 ** rng.uniform(-3, 1))
     x = synth.channels(C, S, first=seed * 7, fs=FS) * level
-    if rng.random() < 0.4:
+    stepped = rng.random() < 0.4
+    if stepped:
         # level steps: block scales change between passes, and inside a pass the quiet part rides on the loud part's
         # scale.  Up to 50 dB per step here; the fused engine is block floating point per 128-frame pass and degrades
         # gradually once a frame sits ~70 dB under the loudest sample of its pass (numerics notes).
@@ -104,7 +105,15 @@ def test_random_configuration(oracle_lib, seed):
         # there, so those draws only have to stay within 30x of it (this sweep is for bugs, which show up as 1e-2).
         o32 = o.run(x[c], po.F32, cfg.rule)[0]
         own = float((np.abs(o32[ok] - w64[ok]) / np.maximum(1.0, np.abs(w64[ok]))).max()) if ok.any() else 0.0
-        strict = cfg.spectrogramScaling == "linear" and cfg.spectrum == _abi.SPECTRUM_POWER
+        names = [f.function for f in cfg.net.inputProcessing]
+        normalised = bool(names) and names[0] in ("l2normalize", "normalize", "normalizestd")
+        few = cfg.net.layers[0].inputs <= 8 and any(f in ("normalize", "normalizestd") for f in names)
+        if few and cfg.net.layers[0].inputs <= 3:
+            continue            # (a - b) / |a - b| of two or three nearly equal values: a sign, not a number to compare
+        # strict = the detector's own mode with a normaliser in front (or a steady level): without one the outputs carry the
+        # input level, and so does every implementation's rounding error (the fp32 port's too)
+        strict = (cfg.spectrogramScaling == "linear" and cfg.spectrum == _abi.SPECTRUM_POWER and not few
+                  and (normalised or not stepped))
         for out, fl, engine, widen in runs:
             assert out[c].shape == w64.shape
             assert (np.isfinite(out[c]).all(axis=1) == ok).all(), "NaN/inf evaluations must coincide"
