@@ -57,6 +57,42 @@ __global__ void __launch_bounds__(512) k(int iters, unsigned long long *cyc, flo
     if (s == 12345.678f) sink[0] = s;
 }
 
+// MODE 3: the same work with v_mfma_f32_32x32x16_f16: per iteration 8 b128 fetches (two k-steps of 16: A hi, A lo, B hi, B lo each)
+// and 6 MFMAs of 32 cycles = the 192 matrix cycles of MODE 2's 12 x 16, with 8 KB instead of 10 KB from LDS
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+__global__ void __launch_bounds__(512) k32(int iters, unsigned long long *cyc, float *sink)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32x4 *tab = reinterpret_cast<uint32x4 *>(smem);
+    const int lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < 4096; i += blockDim.x) tab[i] = uint32x4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+    __syncthreads();
+    floatx16 acc = {0};
+    uint32x4 a[8];
+    for (int i = 0; i < 8; i++) a[i] = tab[i * 64 + lane];
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; it++) {
+        union { uint32x4 u; half8 h; } A[8];
+        for (int i = 0; i < 8; i++) A[i].u = a[i];
+        const int ks = (it + 1) & 7;
+#pragma unroll
+        for (int i = 0; i < 8; i++) a[i] = tab[(ks * 8 + i) * 64 + ((lane * (i & 2 ? 5 : 1)) & 63)];
+        // two k-steps: (Ahi, Alo, Bhi, Blo) = A[0..3], A[4..7]
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0].h, A[2].h, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0].h, A[3].h, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1].h, A[2].h, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[4].h, A[6].h, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[4].h, A[7].h, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[5].h, A[6].h, acc, 0, 0, 0);
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (lane == 0) cyc[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
+    float s = 0;
+    for (int m = 0; m < 16; m++) s += acc[m];
+    for (int i = 0; i < 8; i++) s += (float)a[i][0];
+    if (s == 12345.678f) sink[0] = s;
+}
+
 template <int MODE>
 void run(const char *name, int waves, int iters)
 {
@@ -65,10 +101,12 @@ void run(const char *name, int waves, int iters)
     CK(hipMalloc(&cyc, blocks * 16 * sizeof(unsigned long long)));
     CK(hipMalloc(&sink, 4));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    CK(hipFuncSetAttribute((const void *)k<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    CK(hipFuncSetAttribute((const void *)k<(MODE == 3 ? 2 : MODE)>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    CK(hipFuncSetAttribute((const void *)k32, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     for (int rep = 0; rep < 2; rep++) {
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(64 * waves), 150 * 1024, 0, iters, cyc, sink);   // 150 KB LDS: one block per CU
+        if (MODE == 3) hipLaunchKernelGGL(k32, dim3(blocks), dim3(64 * waves), 150 * 1024, 0, iters, cyc, sink);
+        else hipLaunchKernelGGL(k<(MODE == 3 ? 2 : MODE)>, dim3(blocks), dim3(64 * waves), 150 * 1024, 0, iters, cyc, sink);   // 150 KB LDS: one block per CU
         CK(hipEventRecord(e1));
         CK(hipDeviceSynchronize());
     }
@@ -86,5 +124,6 @@ int main()
     for (int w : {4, 8}) run<0>("mfma", w, iters);
     for (int w : {4, 8}) run<1>("lds", w, iters);
     for (int w : {4, 8}) run<2>("both", w, iters);
+    for (int w : {4, 8}) run<3>("b32", w, iters);
     return 0;
 }
