@@ -397,7 +397,9 @@ mlp_generic_kernel(NetDesc n, int F, const float *__restrict__ columns, int64_t 
 // ------------------------------------------------------------------------------------
 constexpr int kSmallRun = 32;    // evaluations per wave
 
-template <int KI, int HMAX>
+// WLDS: the first-layer rows live in LDS (one copy per workgroup, [row][element]) instead of registers -- for long input
+// vectors, where 80 registers of weights would leave two waves per SIMD to hide every latency.
+template <int KI, int HMAX, bool WLDS>
 __global__ void __launch_bounds__(kBlock)
 mlp_small_kernel(NetDesc n, int F, const float *__restrict__ columns, int64_t J, int64_t E,
                  float *__restrict__ outputs, uint8_t *__restrict__ flags)
@@ -410,19 +412,40 @@ mlp_small_kernel(NetDesc n, int F, const float *__restrict__ columns, int64_t J,
     const DevLayer L0 = n.layers[0];
     const int H = L0.out;
 
-    float w[HMAX][KI];                                          // first-layer rows, this lane's elements
-#pragma unroll
-    for (int h = 0; h < HMAX; h++)
-#pragma unroll
-        for (int k = 0; k < KI; k++) {
-            const int i = lane + kWave * k;
-            w[h][k] = (h < H && i < I) ? P[L0.w + (size_t)h * I + i] : 0.0f;
+    extern __shared__ float wlds[];                             // WLDS: [HMAX][KI * 64]
+    float w[WLDS ? 1 : HMAX][WLDS ? 1 : KI];                    // else: first-layer rows, this lane's elements
+    if (WLDS) {
+        for (int i = threadIdx.x; i < HMAX * KI * kWave; i += kBlock) {
+            const int h = i / (KI * kWave), e = i - h * (KI * kWave);
+            wlds[i] = (h < H && e < I) ? P[L0.w + (size_t)h * I + e] : 0.0f;
         }
+        __syncthreads();
+    } else {
+#pragma unroll
+        for (int h = 0; h < HMAX; h++)
+#pragma unroll
+            for (int k = 0; k < KI; k++) {
+                const int i = lane + kWave * k;
+                w[WLDS ? 0 : h][WLDS ? 0 : k] = (h < H && i < I) ? P[L0.w + (size_t)h * I + i] : 0.0f;
+            }
+    }
     const float b0 = lane < H ? P[L0.b + lane] : 0.0f;          // lane h finishes hidden unit h
     // the first affine input maps keep their per-element parameters in registers too
     constexpr int NCACHE = KI <= 5 ? 2 : 1;
-    float axo[NCACHE][KI], aga[NCACHE][KI];
-    {
+    float axo[WLDS ? 1 : NCACHE][WLDS ? 1 : KI], aga[WLDS ? 1 : NCACHE][WLDS ? 1 : KI];
+    float *alds = wlds + HMAX * KI * kWave;                     // WLDS: [offset | gain][KI * 64] of the first affine map
+    if (WLDS) {
+        int slot = 0;
+        for (int q = 0; q < n.n_in_fns; q++) {
+            if (n.in_fns[q].kind < 3) continue;
+            if (slot++ == 0)
+                for (int i = threadIdx.x; i < KI * kWave; i += kBlock) {
+                    alds[i] = i < I ? P[n.in_fns[q].xoff + i] : 0.0f;
+                    alds[KI * kWave + i] = i < I ? P[n.in_fns[q].gain + i] : 0.0f;
+                }
+        }
+        __syncthreads();
+    } else {
         int slot = 0;
         for (int q = 0; q < n.n_in_fns; q++) {
             if (n.in_fns[q].kind < 3 || slot >= NCACHE) continue;
@@ -432,8 +455,8 @@ mlp_small_kernel(NetDesc n, int F, const float *__restrict__ columns, int64_t J,
 #pragma unroll
                     for (int k = 0; k < KI; k++) {
                         const int i = lane + kWave * k;
-                        axo[u][k] = i < I ? P[n.in_fns[q].xoff + i] : 0.0f;
-                        aga[u][k] = i < I ? P[n.in_fns[q].gain + i] : 0.0f;
+                        axo[WLDS ? 0 : u][WLDS ? 0 : k] = i < I ? P[n.in_fns[q].xoff + i] : 0.0f;
+                        aga[WLDS ? 0 : u][WLDS ? 0 : k] = i < I ? P[n.in_fns[q].gain + i] : 0.0f;
                     }
             slot++;
         }
@@ -462,6 +485,8 @@ mlp_small_kernel(NetDesc n, int F, const float *__restrict__ columns, int64_t J,
                 x[k] = lane + kWave * k < I ? v : 0.0f;
             }
         }
+        int wl = lane;
+        if (WLDS) asm volatile("" : "+v"(wl));                  // keeps the LDS reads inside the loop (hoisted, they are 120 registers)
         int slot = 0;
         for (int q = 0; q < n.n_in_fns; q++) {
             const DevFn fn = n.in_fns[q];
@@ -469,9 +494,9 @@ mlp_small_kernel(NetDesc n, int F, const float *__restrict__ columns, int64_t J,
                 float s = 0.0f;
 #pragma unroll
                 for (int k = 0; k < KI; k++) s += x[k] * x[k];
-                s = sqrtf(wave_sum(s));
+                const float inv = 1.0f / sqrtf(wave_sum(s));
 #pragma unroll
-                for (int k = 0; k < KI; k++) x[k] = x[k] / s;
+                for (int k = 0; k < KI; k++) x[k] = x[k] * inv;   // one division per vector (vDSP_vsdiv divides each; <= 1 ulp apart)
             } else if (fn.kind == 1) {                           // Normalize :69-96
                 float mn = INFINITY, mx = -INFINITY;
 #pragma unroll
@@ -492,16 +517,18 @@ mlp_small_kernel(NetDesc n, int F, const float *__restrict__ columns, int64_t J,
 #pragma unroll
                 for (int k = 0; k < KI; k++)
                     if (lane + kWave * k < I) { const float dlt = x[k] - mean; qq += dlt * dlt; }
-                const float sd = sqrtf(wave_sum(qq) / (float)I);
+                const float isd = 1.0f / sqrtf(wave_sum(qq) / (float)I);
 #pragma unroll
-                for (int k = 0; k < KI; k++) x[k] = (x[k] - mean) / sd;
+                for (int k = 0; k < KI; k++) x[k] = (x[k] - mean) * isd;
             } else {                                             // MapMinMax.apply :127-131, MapStd.apply :162-169
                 bool done = false;
 #pragma unroll
                 for (int u = 0; u < NCACHE; u++)
                     if (u == slot) {
 #pragma unroll
-                        for (int k = 0; k < KI; k++) x[k] = (x[k] - axo[u][k]) * aga[u][k] + fn.y;
+                        for (int k = 0; k < KI; k++)
+                            x[k] = WLDS ? (x[k] - alds[k * kWave + wl]) * alds[(KI + k) * kWave + wl] + fn.y
+                                        : (x[k] - axo[WLDS ? 0 : u][WLDS ? 0 : k]) * aga[WLDS ? 0 : u][WLDS ? 0 : k] + fn.y;
                         done = true;
                     }
                 if (!done) {
@@ -524,7 +551,7 @@ mlp_small_kernel(NetDesc n, int F, const float *__restrict__ columns, int64_t J,
             if (h < H) {                                        // wave-uniform
                 float acc = 0.0f;
 #pragma unroll
-                for (int k = 0; k < KI; k++) acc = fmaf(w[h][k], x[k], acc);
+                for (int k = 0; k < KI; k++) acc = fmaf(WLDS ? wlds[(h * KI + k) * kWave + wl] : w[WLDS ? 0 : h][WLDS ? 0 : k], x[k], acc);
                 acc = wave_sum(acc);
                 mine = lane == h ? acc : mine;
             }
@@ -640,11 +667,11 @@ hipError_t launch_mlp_generic(const NetDesc &n, int F, const float *columns, int
         const int64_t per_block = (int64_t)(kBlock / kWave) * kSmallRun;
         dim3 grid((unsigned)((E + per_block - 1) / per_block), (unsigned)C);
         if (n.I <= 64 * 5 && H <= 8) {
-            hipLaunchKernelGGL((mlp_small_kernel<5, 8>), grid, dim3(kBlock), 0, stream, n, F, columns, J, E, outputs, flags);
+            hipLaunchKernelGGL((mlp_small_kernel<5, 8, false>), grid, dim3(kBlock), 0, stream, n, F, columns, J, E, outputs, flags);
             return hipGetLastError();
         }
         if (n.I <= 64 * 20 && H <= 4) {
-            hipLaunchKernelGGL((mlp_small_kernel<20, 4>), grid, dim3(kBlock), 0, stream, n, F, columns, J, E, outputs, flags);
+            hipLaunchKernelGGL((mlp_small_kernel<20, 4, true>), grid, dim3(kBlock), (4 + 2) * 20 * kWave * sizeof(float), stream, n, F, columns, J, E, outputs, flags);
             return hipGetLastError();
         }
     }
