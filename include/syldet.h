@@ -214,7 +214,10 @@ int syldet_profile(syldet_t *h, int enable);
 int syldet_last_timings(syldet_t *h, double *milliseconds, const char **names, int32_t capacity, int32_t *count);
 
 /* ---- streaming: the reference's per-detector API, one call per channel ----
- * appendAudioData(_:withSamples:), SyllableDetector.swift:129-132                         */
+ * Each channel owns a single-producer / single-consumer sample ring like the reference's
+ * TPCircularBuffer (TPCircularBuffer.h:14,102-189): append* never locks or allocates and may run
+ * on an audio I/O thread (AudioInterface.swift:67-70 -> Processor.swift:124) while another thread
+ * processes.  appendAudioData(_:withSamples:), SyllableDetector.swift:129-132              */
 int syldet_append(syldet_t *h, int32_t channel, const float *data, int64_t n_samples);
 /* appendInterleavedData(_:withSamples:fromChannel:ofTotalChannels:),
  * CircularShortTimeFourierTransform.swift:203-217: de-interleaves frame-major audio into
@@ -223,6 +226,14 @@ int syldet_append_interleaved(syldet_t *h, const float *data, int64_t n_frames, 
 /* processNewValue() -> Bool, SyllableDetector.swift:153-217: 1 = a new evaluation is in
  * last_outputs, 0 = not enough data yet                                                  */
 int syldet_process_new_value(syldet_t *h, int32_t channel);
+/* The consumer loop of a multi-channel Processor (`for d in detectors { while d.processNewValue() … }`,
+ * Processor.swift:128-141) in one device round trip: evaluates everything every channel has pending
+ * (one staged copy + one launch per distinct evaluation count, i.e. one when the channels are fed
+ * together) and queues the results; the following syldet_process_new_value calls hand them out one by
+ * one without touching the device.  *n_queued (optional) = evaluations added over all channels.      */
+int syldet_process_all(syldet_t *h, int64_t *n_queued);
+/* evaluations computed and not yet handed out by syldet_process_new_value                */
+int64_t syldet_pending_evaluations(const syldet_t *h, int32_t channel);
 /* lastOutputs, :26 (zeros before the first evaluation, :70)                              */
 int syldet_last_outputs(const syldet_t *h, int32_t channel, float *out);
 /* lastDetected, :27-31                                                                   */

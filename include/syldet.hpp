@@ -103,6 +103,15 @@ public:
     {
         check(syldet_run_device(h_, d_samples, n, stride, d_outputs, d_flags, hipStream));
     }
+    // live use: everything every channel has pending in one device round trip (the consumer loop of
+    // Processor.swift:128-141 over all detectors); the detectors' processNewValue() then hand the results out
+    int64_t processAll()
+    {
+        int64_t queued = 0;
+        check(syldet_process_all(h_, &queued));
+        return queued;
+    }
+    void appendInterleavedData(const float *data, int64_t frames) { check(syldet_append_interleaved(h_, data, frames, channels())); }
     // TrackDetector's sample numbering and debounce (TrackDetector.swift:39-43, :65-100)
     std::vector<int64_t> detections(const uint8_t *flags, int64_t nEvals, double debounceSeconds, int channel)
     {

@@ -33,6 +33,14 @@ final class SyllableDetectorBank {
     }
 
     deinit { syldet_destroy(handle) }
+
+    /// Live use: evaluates what every channel has pending in one device round trip; the detectors'
+    /// `processNewValue()` then hand the results out (Processor.swift:128-141 calls this first).
+    @discardableResult func processAll() -> Int {
+        var queued: Int64 = 0
+        syldet_process_all(handle, &queued)
+        return Int(queued)
+    }
 }
 
 class SyllableDetector: NSObject {

@@ -106,6 +106,8 @@ SIGNATURES = {
     "syldet_append": (C.c_int, [Handle, C.c_int32, c_float_p, C.c_int64]),
     "syldet_append_interleaved": (C.c_int, [Handle, c_float_p, C.c_int64, C.c_int32]),
     "syldet_process_new_value": (C.c_int, [Handle, C.c_int32]),
+    "syldet_process_all": (C.c_int, [Handle, c_int64_p]),
+    "syldet_pending_evaluations": (C.c_int64, [Handle, C.c_int32]),
     "syldet_last_outputs": (C.c_int, [Handle, C.c_int32, c_float_p]),
     "syldet_last_detected": (C.c_int, [Handle, C.c_int32]),
     "syldet_seen_syllable": (C.c_int, [Handle, C.c_int32]),

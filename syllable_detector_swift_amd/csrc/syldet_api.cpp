@@ -7,11 +7,13 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <new>
@@ -59,15 +61,53 @@ struct DeviceBuffer {
     }
 };
 
-// Per-channel streaming state: the reference's two rings restated as "samples not yet
-// fully consumed" + a queue of evaluations already computed on the device.
+struct PinnedBuffer {
+    void *ptr = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes)
+    {
+        if (bytes <= cap) return SYLDET_OK;
+        if (ptr) (void)hipHostFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+        hipError_t e = hipHostMalloc(&ptr, bytes, hipHostMallocDefault);
+        if (e != hipSuccess) {
+            ptr = nullptr;
+            return fail(SYLDET_ERR_OUT_OF_MEMORY, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+        }
+        cap = bytes;
+        return SYLDET_OK;
+    }
+    void release()
+    {
+        if (ptr) (void)hipHostFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+    }
+};
+
+// Per-channel streaming state: the reference's two rings restated as one single-producer /
+// single-consumer sample ring ("samples from the first frame of the next evaluation onward") + a queue of
+// evaluations already computed on the device.  The producer side (append) touches only the ring's tail and
+// reads head / frames_done -- no lock, no allocation: it can sit on an audio I/O thread like
+// TPCircularBufferProduceBytes does (TPCircularBuffer.h:14,177-185).
 struct ChannelStream {
-    std::vector<float> pending;       // samples from the first frame of the next evaluation onward
-    int64_t appended = 0;             // total samples ever appended
-    int64_t frames_done = 0;          // STFT frames the reference would have extracted so far
-    std::deque<std::vector<float>> ready;   // evaluated outputs not yet handed out
-    std::vector<float> last;          // lastOutputs
-    std::mutex mu;                    // producer (append) vs consumer (process)
+    std::vector<float> ring;                 // power-of-two capacity
+    uint64_t mask = 0;
+    std::atomic<uint64_t> tail{0};           // producer: total samples ever appended
+    std::atomic<uint64_t> head{0};           // consumer: first sample of the next evaluation
+    std::atomic<int64_t> frames_done{0};     // STFT frames the reference would have extracted so far
+    // consumer side only
+    std::deque<std::vector<float>> ready;    // evaluated outputs not yet handed out
+    std::vector<float> last;                 // lastOutputs
+    std::mutex mu;                           // ready / last (consumer vs. readers of last*; never taken by append)
+
+    void copy_out(uint64_t from, float *dst, size_t n) const
+    {
+        const size_t at = (size_t)(from & mask), first = std::min(n, ring.size() - at);
+        std::memcpy(dst, ring.data() + at, first * sizeof(float));
+        if (n > first) std::memcpy(dst + first, ring.data(), (n - first) * sizeof(float));
+    }
 };
 
 }  // namespace
@@ -106,6 +146,8 @@ struct syldet {
     hipStream_t stream = nullptr;     // used by the host-pointer entry points
 
     std::vector<std::unique_ptr<ChannelStream>> streams;
+    std::mutex pump_mu;               // the staging buffers and the stream below belong to one pump at a time
+    PinnedBuffer p_stage_in, p_stage_out;
 
     // optional per-kernel timing (syldet_profile)
     bool profiling = false;
@@ -115,6 +157,8 @@ struct syldet {
 };
 
 namespace {
+
+const int64_t kSampleRingBytes = 409600;   // CircularShortTimeFourierTransform.init(buffer:) default :61
 
 int build_tables(syldet *h)
 {
@@ -544,6 +588,12 @@ int syldet_create(const syldet_config_t *cfg, int32_t n_channels, int32_t device
     for (auto &s : h->streams) {
         s.reset(new ChannelStream());
         s->last.assign((size_t)h->geom.outputs, 0.0f);   // lastOutputs zeros, SyllableDetector.swift:70
+        // the reference's sample ring (409 600 bytes) + what its feature ring would still hold as columns
+        uint64_t need = (uint64_t)(kSampleRingBytes / 4) + (uint64_t)h->geom.gap + (uint64_t)h->cfg.view.window_length +
+                        (uint64_t)(h->cfg.view.time_range + 1) * (uint64_t)h->geom.hop, cap = 1;
+        while (cap < need) cap <<= 1;
+        s->ring.assign((size_t)cap, 0.0f);
+        s->mask = cap - 1;
     }
     *out = h.release();
     return SYLDET_OK;
@@ -561,6 +611,8 @@ int syldet_destroy(syldet_t *h)
     for (DeviceBuffer *b : {&h->d_window, &h->d_tw, &h->d_sw, &h->d_params, &h->d_thr, &h->d_columns, &h->d_fused, &h->d_stamps, &h->d_planar, &h->d_wide, &h->d_xn, &h->d_dft, &h->d_stage_in,
                             &h->d_stage_out, &h->d_stage_flags, &h->d_stage_idx, &h->d_stage_cnt})
         b->release();
+    h->p_stage_in.release();
+    h->p_stage_out.release();
     delete h;
     return SYLDET_OK;
 }
@@ -755,19 +807,19 @@ int syldet_detections(syldet_t *h, const uint8_t *flags, int64_t n_evals, double
 // the consumer asks for a value and none is queued, every evaluation those samples allow
 // is computed in one device pass and queued.  Results are the batch engine's.
 
-static const int64_t kSampleRingBytes = 409600;   // CircularShortTimeFourierTransform.init(buffer:) default :61
-
 static int stream_append(syldet *h, ChannelStream &cs, const float *data, int64_t n, int64_t step)
 {
-    std::lock_guard<std::mutex> lock(cs.mu);
     // TPCircularBufferProduceBytes fails when fewer than n*4 bytes are free (TPCircularBuffer.h:177-185);
     // the bytes in the reference's ring are the samples no extracted frame has consumed yet.
-    const int64_t unconsumed = cs.appended - cs.frames_done * h->geom.hop;
+    const uint64_t tail = cs.tail.load(std::memory_order_relaxed);
+    const int64_t unconsumed = (int64_t)tail - cs.frames_done.load(std::memory_order_acquire) * h->geom.hop;
     if ((unconsumed + n) * 4 > kSampleRingBytes) return fail(SYLDET_ERR_BUFFER_FULL, "Insufficient space on buffer.");
-    const size_t old = cs.pending.size();
-    cs.pending.resize(old + (size_t)n);
-    for (int64_t i = 0; i < n; i++) cs.pending[old + (size_t)i] = data[i * step];
-    cs.appended += n;
+    // (cannot overrun the un-evaluated samples: the ring is sized for the bound above plus the evaluation carry)
+    if ((int64_t)(tail - cs.head.load(std::memory_order_acquire)) + n > (int64_t)cs.ring.size())
+        return fail(SYLDET_ERR_BUFFER_FULL, "Insufficient space on buffer.");
+    float *ring = cs.ring.data();
+    for (int64_t i = 0; i < n; i++) ring[(size_t)((tail + (uint64_t)i) & cs.mask)] = data[i * step];
+    cs.tail.store(tail + (uint64_t)n, std::memory_order_release);
     return SYLDET_OK;
 }
 
@@ -787,44 +839,87 @@ int syldet_append_interleaved(syldet_t *h, const float *data, int64_t n_frames, 
     return SYLDET_OK;
 }
 
+// Evaluates what the listed channels have pending: channels with the same number of new evaluations share one
+// pinned staging block, one H2D copy, one launch and one D2H copy; the results join each channel's queue of
+// computed evaluations.  Adds the number queued to *queued.
+static int pump(syldet *h, const int32_t *channels, int32_t n, int64_t *queued)
+{
+    std::lock_guard<std::mutex> pump_lock(h->pump_mu);
+    const int n_out = h->geom.outputs;
+    const int64_t hop = h->geom.hop, frame = (int64_t)h->geom.gap + h->cfg.view.window_length;
+    std::map<int64_t, std::vector<int32_t>> groups;          // evaluations -> channels
+    for (int32_t i = 0; i < n; i++) {
+        ChannelStream &cs = *h->streams[(size_t)channels[i]];
+        const uint64_t tail = cs.tail.load(std::memory_order_acquire);
+        // `while processFourierData() {}` (SyllableDetector.swift:155): every whole frame is extracted now
+        cs.frames_done.store(count_frames(h, (int64_t)tail), std::memory_order_release);
+        const int64_t E = count_evals(h, (int64_t)(tail - cs.head.load(std::memory_order_relaxed)));
+        if (E > 0) groups[E].push_back(channels[i]);
+    }
+    if (groups.empty()) return SYLDET_OK;
+    SYLDET_HIP(hipSetDevice(h->device));
+    for (auto &g : groups) {
+        const int64_t E = g.first, S = frame + (E + h->cfg.view.time_range - 2) * hop;   // samples E evaluations span
+        const size_t nc = g.second.size();
+        if (int st = h->p_stage_in.reserve(nc * (size_t)S * sizeof(float))) return st;
+        if (int st = h->p_stage_out.reserve(nc * (size_t)E * (size_t)n_out * sizeof(float))) return st;
+        if (int st = h->d_stage_in.reserve(nc * (size_t)S * sizeof(float))) return st;
+        if (int st = h->d_stage_out.reserve(nc * (size_t)E * (size_t)n_out * sizeof(float))) return st;
+        float *in = (float *)h->p_stage_in.ptr, *outs = (float *)h->p_stage_out.ptr;
+        for (size_t k = 0; k < nc; k++) {
+            const ChannelStream &cs = *h->streams[(size_t)g.second[k]];
+            cs.copy_out(cs.head.load(std::memory_order_relaxed), in + k * (size_t)S, (size_t)S);
+        }
+        SYLDET_HIP(hipMemcpyAsync(h->d_stage_in.ptr, in, nc * (size_t)S * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        if (int st = run_on_stream(h, (const float *)h->d_stage_in.ptr, S, S, (int)nc, (float *)h->d_stage_out.ptr, nullptr, h->stream))
+            return st;
+        SYLDET_HIP(hipMemcpyAsync(outs, h->d_stage_out.ptr, nc * (size_t)E * (size_t)n_out * sizeof(float), hipMemcpyDeviceToHost,
+                                  h->stream));
+        SYLDET_HIP(hipStreamSynchronize(h->stream));
+        for (size_t k = 0; k < nc; k++) {
+            ChannelStream &cs = *h->streams[(size_t)g.second[k]];
+            const float *o = outs + k * (size_t)E * (size_t)n_out;
+            {
+                std::lock_guard<std::mutex> lock(cs.mu);
+                for (int64_t e = 0; e < E; e++) cs.ready.emplace_back(o + (size_t)e * (size_t)n_out, o + (size_t)(e + 1) * (size_t)n_out);
+            }
+            // each evaluation consumes one column = hop samples (:175-178)
+            cs.head.store(cs.head.load(std::memory_order_relaxed) + (uint64_t)(E * hop), std::memory_order_release);
+            if (queued) *queued += E;
+        }
+    }
+    return SYLDET_OK;
+}
+
 int syldet_process_new_value(syldet_t *h, int32_t channel)
 {
     if (!h || channel < 0 || channel >= h->channels) return fail(SYLDET_ERR_INVALID_ARGUMENT, "bad argument");
     ChannelStream &cs = *h->streams[(size_t)channel];
-    std::vector<float> chunk;
-    int64_t E = 0;
-    {
-        std::lock_guard<std::mutex> lock(cs.mu);
-        // `while processFourierData() {}` (SyllableDetector.swift:155): every whole frame is extracted now
-        cs.frames_done = count_frames(h, cs.appended);
-        if (cs.ready.empty()) {
-            E = count_evals(h, (int64_t)cs.pending.size());
-            if (E > 0) chunk = cs.pending;   // snapshot; the producer may keep appending
-        }
-    }
-    if (E > 0) {
-        const int n_out = h->geom.outputs;
-        const int64_t S = (int64_t)chunk.size();
-        SYLDET_HIP(hipSetDevice(h->device));
-        if (int st = h->d_stage_in.reserve((size_t)S * sizeof(float))) return st;
-        if (int st = h->d_stage_out.reserve((size_t)E * (size_t)n_out * sizeof(float))) return st;
-        SYLDET_HIP(hipMemcpyAsync(h->d_stage_in.ptr, chunk.data(), (size_t)S * sizeof(float), hipMemcpyHostToDevice, h->stream));
-        if (int st = run_on_stream(h, (const float *)h->d_stage_in.ptr, S, S, 1, (float *)h->d_stage_out.ptr, nullptr, h->stream))
-            return st;
-        std::vector<float> outs((size_t)E * (size_t)n_out);
-        SYLDET_HIP(hipMemcpyAsync(outs.data(), h->d_stage_out.ptr, outs.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-        SYLDET_HIP(hipStreamSynchronize(h->stream));
-        std::lock_guard<std::mutex> lock(cs.mu);
-        for (int64_t e = 0; e < E; e++)
-            cs.ready.emplace_back(outs.begin() + (size_t)e * (size_t)n_out, outs.begin() + (size_t)(e + 1) * (size_t)n_out);
-        // each evaluation consumes one column = hop samples (:175-178)
-        cs.pending.erase(cs.pending.begin(), cs.pending.begin() + (size_t)(E * h->geom.hop));
-    }
+    if (int st = pump(h, &channel, 1, nullptr)) return st;
     std::lock_guard<std::mutex> lock(cs.mu);
     if (cs.ready.empty()) return 0;
     cs.last = std::move(cs.ready.front());
     cs.ready.pop_front();
     return 1;
+}
+
+int syldet_process_all(syldet_t *h, int64_t *n_queued)
+{
+    if (!h) return fail(SYLDET_ERR_INVALID_ARGUMENT, "NULL argument");
+    std::vector<int32_t> all((size_t)h->channels);
+    for (int32_t c = 0; c < h->channels; c++) all[(size_t)c] = c;
+    int64_t queued = 0;
+    if (int st = pump(h, all.data(), h->channels, &queued)) return st;
+    if (n_queued) *n_queued = queued;
+    return SYLDET_OK;
+}
+
+int64_t syldet_pending_evaluations(const syldet_t *h, int32_t channel)
+{
+    if (!h || channel < 0 || channel >= h->channels) return fail(SYLDET_ERR_INVALID_ARGUMENT, "bad argument");
+    ChannelStream &cs = *h->streams[(size_t)channel];
+    std::lock_guard<std::mutex> lock(cs.mu);
+    return (int64_t)cs.ready.size();
 }
 
 int syldet_last_outputs(const syldet_t *h, int32_t channel, float *out)

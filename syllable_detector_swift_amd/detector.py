@@ -72,6 +72,17 @@ class SyllableDetector:
     def processNewValue(self, channel: int = 0) -> bool:
         return check(_abi.lib.syldet_process_new_value(self._h, channel)) == 1
 
+    def processAll(self) -> int:
+        """Evaluates what every channel has pending in one device round trip (the consumer loop of
+        Processor.swift:128-141 over all detectors); returns the evaluations queued.  The following
+        processNewValue calls hand them out without touching the device."""
+        n = C.c_int64(0)
+        check(_abi.lib.syldet_process_all(self._h, C.byref(n)))
+        return n.value
+
+    def pendingEvaluations(self, channel: int = 0) -> int:
+        return check(_abi.lib.syldet_pending_evaluations(self._h, channel))
+
     def lastOutputsFor(self, channel: int) -> List[float]:
         out = np.zeros(self.geometry.outputs, np.float32)
         check(_abi.lib.syldet_last_outputs(self._h, channel, out.ctypes.data_as(_abi.c_float_p)))

@@ -39,6 +39,7 @@ int main(int argc, char **argv)
             detector.appendAudioData(x.data() + pos, (int64_t)m);
             pos += m;
             chunk = chunk * 3 % 1777 + 1;
+            if (chunk & 1) bank.processAll();                     // the batched consumer step, every other round
             while (detector.processNewValue()) {
                 const std::vector<float> o = detector.lastOutputs();
                 streamed.insert(streamed.end(), o.begin(), o.end());

@@ -160,3 +160,124 @@ def test_wide_engine_is_opt_in_and_checks_the_shape():
     with pytest.raises(sd.SyllableDetectorError) as ei:                        # sample.txt: 4 hidden units
         sd.SyllableDetector(base, channels=1, engine=_abi.ENGINE_WIDE_BF16)
     assert ei.value.status == _abi.ERR_UNSUPPORTED
+
+
+# ---- live multi-channel use: SPSC sample rings + one device round trip for all channels -----------
+
+def _drain(det, c):
+    outs = []
+    while det.processNewValue(c):
+        outs.append(det.lastOutputsFor(c))
+    return outs
+
+
+def test_process_all_equals_per_channel_processing(oracle_lib):
+    """Interleaved device callbacks of 512 frames: processAll() then per-channel draining gives what the
+    oracle gives for each channel's whole recording (TPCircularBuffer-style carry across callbacks)."""
+    cfg = util.sample_net()
+    o = util.oracle_for(cfg)
+    C, S = 6, 20000
+    x = np.stack([synth.channel(S, 40 + c) for c in range(C)])
+    got = [[] for _ in range(C)]
+    with sd.SyllableDetector(cfg, channels=C) as det:
+        assert det.processAll() == 0
+        queued = 0
+        for pos in range(0, S, 512):
+            det.appendInterleavedData(x[:, pos:pos + 512].T.copy())
+            n = det.processAll()
+            queued += n
+            assert sum(det.pendingEvaluations(c) for c in range(C)) == n
+            for c in range(C):
+                got[c] += _drain(det, c)
+                assert det.pendingEvaluations(c) == 0
+        E = o.run(x[0], po.F64)[2].shape[0]
+        assert queued == C * E
+    for c in range(C):
+        util.assert_outputs_close(np.array(got[c]).reshape(-1, 1), o.run(x[c], po.F64)[2])
+
+
+def test_process_all_with_channels_fed_unevenly(oracle_lib):
+    """Channels that received different amounts of audio land in different launch groups."""
+    cfg = util.sample_net()
+    o = util.oracle_for(cfg)
+    rng = np.random.default_rng(5)
+    C, S = 4, 12000
+    x = np.stack([synth.channel(S, 60 + c) for c in range(C)])
+    pos = [0] * C
+    got = [[] for _ in range(C)]
+    with sd.SyllableDetector(cfg, channels=C) as det:
+        while min(pos) < S:
+            for c in range(C):
+                n = int(rng.integers(0, 1500)) if c else 700
+                det.appendAudioData(x[c, pos[c]:pos[c] + n], channel=c)
+                pos[c] = min(S, pos[c] + n)
+            det.processAll()
+            if rng.integers(0, 2):                               # sometimes leave results queued over a round
+                for c in range(C):
+                    got[c] += _drain(det, c)
+        for c in range(C):
+            got[c] += _drain(det, c)
+    for c in range(C):
+        util.assert_outputs_close(np.array(got[c]).reshape(-1, 1), o.run(x[c], po.F64)[2])
+
+
+def test_sample_ring_wraps_many_times(oracle_lib):
+    """A long stream in large appends: the ring (131 072 samples here) wraps several times."""
+    cfg = util.sample_net()
+    o = util.oracle_for(cfg)
+    S = 600000
+    x = synth.channel(S, 77)
+    got = []
+    with sd.SyllableDetector(cfg, channels=1) as det:
+        for pos in range(0, S, 90001):
+            det.appendAudioData(x[pos:pos + 90001])
+            det.processAll()
+            got += _drain(det, 0)
+    want = o.run(x, po.F64)[2]
+    util.assert_outputs_close(np.array(got).reshape(-1, 1), want)
+
+
+def test_producer_thread_against_consumer_thread(oracle_lib):
+    """One producer (append, as the audio I/O thread) and one consumer (processAll + drain) running
+    concurrently: every evaluation arrives, in order, with the oracle's values."""
+    import threading
+    import time
+    cfg = util.sample_net()
+    o = util.oracle_for(cfg)
+    C, S = 2, 120000
+    x = np.stack([synth.channel(S, 90 + c) for c in range(C)])
+    got = [[] for _ in range(C)]
+    with sd.SyllableDetector(cfg, channels=C) as det:
+        done = threading.Event()
+        errors = []
+
+        def produce():
+            try:
+                for pos in range(0, S, 441):
+                    blk = x[:, pos:pos + 441].T.copy()
+                    while True:
+                        try:
+                            det.appendInterleavedData(blk)
+                            break
+                        except sd.SyllableDetectorError as e:    # ring full: the consumer is behind
+                            if e.status != _abi.ERR_BUFFER_FULL:
+                                raise
+                            time.sleep(0.0005)
+            except Exception as e:                               # pragma: no cover
+                errors.append(e)
+            finally:
+                done.set()
+
+        t = threading.Thread(target=produce)
+        t.start()
+        while not done.is_set():
+            det.processAll()
+            for c in range(C):
+                got[c] += _drain(det, c)
+        t.join()
+        det.processAll()
+        for c in range(C):
+            got[c] += _drain(det, c)
+        assert not errors
+    for c in range(C):
+        util.assert_outputs_close(np.array(got[c]).reshape(-1, 1), o.run(x[c], po.F64)[2])
