@@ -108,6 +108,26 @@ __device__ __forceinline__ half8 lds_half8(const _Float16 *p)
     return as_half8(u);
 }
 
+// LDS byte address of a pointer into shared memory (the low half of its flat address)
+__device__ __forceinline__ unsigned lds_addr(const void *p) { return (unsigned)(uintptr_t)p; }
+
+// The fragment fetches of one k-step as volatile instructions: issued where they are written (a whole k-step ahead of
+// their MFMAs), not where the scheduler would sink them.  The data is in flight until frags_wait.
+template <int KSN>
+__device__ __forceinline__ void frags_fetch(unsigned a_addr, unsigned bh_addr, unsigned bl_addr, uint32x4 (&a)[8], uint32x4 &bh, uint32x4 &bl)
+{
+    asm volatile("ds_read2_b64 %0, %1 offset1:1" : "=v"(bh) : "v"(bh_addr));
+    asm volatile("ds_read2_b64 %0, %1 offset1:1" : "=v"(bl) : "v"(bl_addr));
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a[i]) : "v"(a_addr), "n"((KSN * 8 + i) * 1024));
+}
+__device__ __forceinline__ void frags_wait(uint32x4 (&a)[8], uint32x4 &bh, uint32x4 &bl)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(bh), "+v"(bl));
+}
+
 __device__ __forceinline__ floatx4 mfma(half8 a, half8 b, floatx4 c)
 {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
@@ -485,6 +505,30 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
         // run whose stores are masked) is cut into steps that fill the VALU / LDS slots between the MFMAs.
         floatx4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         {
+#ifdef SYLDET_ASM_PREFETCH
+            uint32x4 a[8], bhu, blu;
+            const unsigned a_addr = lds_addr(lds_dfrag + lane);
+            frags_fetch<0>(a_addr, lds_addr(fph + ko[0]), lds_addr(fpl + ko[0]), a, bhu, blu);
+#pragma unroll
+            for (int ks = 0; ks < ((kom & 256) ? 0 : KS); ks++) {
+                frags_wait(a, bhu, blu);
+                half8 ah[4], al[4];
+#pragma unroll
+                for (int m = 0; m < 4; m++) { ah[m] = as_half8(a[2 * m]); al[m] = as_half8(a[2 * m + 1]); }
+                const half8 cbh = as_half8(bhu), cbl = as_half8(blu);
+                if (ks + 1 < KS) {                                // fragments of the next k-step
+                    const unsigned ha = lds_addr(fph + ko[ks + 1 < KS ? ks + 1 : 0]), la = lds_addr(fpl + ko[ks + 1 < KS ? ks + 1 : 0]);
+                    switch (ks + 1) {
+                    case 1: frags_fetch<1>(a_addr, ha, la, a, bhu, blu); break;
+                    case 2: frags_fetch<2>(a_addr, ha, la, a, bhu, blu); break;
+                    case 3: frags_fetch<3>(a_addr, ha, la, a, bhu, blu); break;
+                    case 4: frags_fetch<4>(a_addr, ha, la, a, bhu, blu); break;
+                    case 5: frags_fetch<5>(a_addr, ha, la, a, bhu, blu); break;
+                    case 6: frags_fetch<6>(a_addr, ha, la, a, bhu, blu); break;
+                    default: frags_fetch<7>(a_addr, ha, la, a, bhu, blu); break;
+                    }
+                }
+#else
             half8 bh = lds_half8(fph + ko[0]), bl = lds_half8(fpl + ko[0]);
             uint32x4 a[8];
 #pragma unroll
@@ -501,6 +545,7 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
                     bh = lds_half8(fph + ko[ks + 1]);
                     bl = lds_half8(fpl + ko[ks + 1]);
                 }
+#endif
                 if (!(kom & 1)) {
 #pragma unroll
                     for (int m = 0; m < 4; m++) acc[m] = mfma(ah[m], cbh, acc[m]);

@@ -807,35 +807,44 @@ int syldet_detections(syldet_t *h, const uint8_t *flags, int64_t n_evals, double
 // the consumer asks for a value and none is queued, every evaluation those samples allow
 // is computed in one device pass and queued.  Results are the batch engine's.
 
-static int stream_append(syldet *h, ChannelStream &cs, const float *data, int64_t n, int64_t step)
+// TPCircularBufferProduceBytes fails when fewer than n*4 bytes are free (TPCircularBuffer.h:177-185);
+// the bytes in the reference's ring are the samples no extracted frame has consumed yet.
+static bool stream_has_room(const syldet *h, const ChannelStream &cs, int64_t n)
 {
-    // TPCircularBufferProduceBytes fails when fewer than n*4 bytes are free (TPCircularBuffer.h:177-185);
-    // the bytes in the reference's ring are the samples no extracted frame has consumed yet.
     const uint64_t tail = cs.tail.load(std::memory_order_relaxed);
     const int64_t unconsumed = (int64_t)tail - cs.frames_done.load(std::memory_order_acquire) * h->geom.hop;
-    if ((unconsumed + n) * 4 > kSampleRingBytes) return fail(SYLDET_ERR_BUFFER_FULL, "Insufficient space on buffer.");
+    if ((unconsumed + n) * 4 > kSampleRingBytes) return false;
     // (cannot overrun the un-evaluated samples: the ring is sized for the bound above plus the evaluation carry)
-    if ((int64_t)(tail - cs.head.load(std::memory_order_acquire)) + n > (int64_t)cs.ring.size())
-        return fail(SYLDET_ERR_BUFFER_FULL, "Insufficient space on buffer.");
+    return (int64_t)(tail - cs.head.load(std::memory_order_acquire)) + n <= (int64_t)cs.ring.size();
+}
+
+static void stream_write(ChannelStream &cs, const float *data, int64_t n, int64_t step)
+{
+    const uint64_t tail = cs.tail.load(std::memory_order_relaxed);
     float *ring = cs.ring.data();
     for (int64_t i = 0; i < n; i++) ring[(size_t)((tail + (uint64_t)i) & cs.mask)] = data[i * step];
     cs.tail.store(tail + (uint64_t)n, std::memory_order_release);
-    return SYLDET_OK;
 }
 
 int syldet_append(syldet_t *h, int32_t channel, const float *data, int64_t n_samples)
 {
     if (!h || channel < 0 || channel >= h->channels || n_samples < 0 || (n_samples > 0 && !data))
         return fail(SYLDET_ERR_INVALID_ARGUMENT, "bad argument");
-    return stream_append(h, *h->streams[(size_t)channel], data, n_samples, 1);
+    ChannelStream &cs = *h->streams[(size_t)channel];
+    if (!stream_has_room(h, cs, n_samples)) return fail(SYLDET_ERR_BUFFER_FULL, "Insufficient space on buffer.");
+    stream_write(cs, data, n_samples, 1);
+    return SYLDET_OK;
 }
 
 int syldet_append_interleaved(syldet_t *h, const float *data, int64_t n_frames, int32_t total_channels)
 {
     if (!h || n_frames < 0 || (n_frames > 0 && !data) || total_channels != h->channels)
         return fail(SYLDET_ERR_INVALID_ARGUMENT, "bad argument");
+    // all channels or none: a caller that retries after "buffer full" must not double a block on some of them
+    // (room only grows between the check and the writes: the consumer is the only other party)
     for (int c = 0; c < h->channels; c++)
-        if (int st = stream_append(h, *h->streams[(size_t)c], data + c, n_frames, total_channels)) return st;
+        if (!stream_has_room(h, *h->streams[(size_t)c], n_frames)) return fail(SYLDET_ERR_BUFFER_FULL, "Insufficient space on buffer.");
+    for (int c = 0; c < h->channels; c++) stream_write(*h->streams[(size_t)c], data + c, n_frames, total_channels);
     return SYLDET_OK;
 }
 

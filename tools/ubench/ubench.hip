@@ -93,6 +93,59 @@ __global__ void __launch_bounds__(512) k32(int iters, unsigned long long *cyc, f
     if (s == 12345.678f) sink[0] = s;
 }
 
+// coissue: do matrix and vector instructions overlap on one SIMD?  Per iteration NM MFMAs (4 independent
+// accumulators) and NV v_fma_f32 (16 independent chains).  ROLE 0: every wave issues both (same wave);
+// ROLE 1: waves 0-3 (one per SIMD) issue the MFMAs, waves 4-7 the FMAs; NM or NV = 0 gives each alone.
+template <int NM, int NV, int ROLE>
+__global__ void __launch_bounds__(512) kco(int iters, unsigned long long *cyc, float *sink)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    floatx4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    half8 A, B;
+    for (int i = 0; i < 8; i++) { A[i] = (_Float16)(lane * 0.001f); B[i] = (_Float16)(i * 0.01f); }
+    float f[16];
+    for (int i = 0; i < 16; i++) f[i] = lane + i;
+    const float m = 1.0f + 1e-7f * lane, c = 1e-3f;
+    const bool do_m = ROLE == 0 || wave < 4, do_v = ROLE == 0 || wave >= 4;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; it++) {
+        if (do_m) {
+#pragma unroll
+            for (int q = 0; q < NM; q++) acc[q & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, B, acc[q & 3], 0, 0, 0);
+        }
+        if (do_v) {
+#pragma unroll
+            for (int q = 0; q < NV; q++) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f[q & 15]) : "v"(m), "v"(c));
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (lane == 0) cyc[blockIdx.x * (blockDim.x / 64) + wave] = t1 - t0;
+    float s = 0;
+    for (int q = 0; q < 4; q++) s += acc[q][0] + acc[q][1] + acc[q][2] + acc[q][3];
+    for (int i = 0; i < 16; i++) s += f[i];
+    if (s == 12345.678f) sink[0] = s;
+}
+
+template <int NM, int NV, int ROLE>
+void run_co(const char *name, int waves, int iters)
+{
+    unsigned long long *cyc; float *sink;
+    const int blocks = 256;
+    CK(hipMalloc(&cyc, blocks * 16 * sizeof(unsigned long long)));
+    CK(hipMalloc(&sink, 4));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipFuncSetAttribute((const void *)kco<NM, NV, ROLE>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    for (int rep = 0; rep < 2; rep++) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL((kco<NM, NV, ROLE>), dim3(blocks), dim3(64 * waves), 150 * 1024, 0, iters, cyc, sink);
+        CK(hipEventRecord(e1));
+        CK(hipDeviceSynchronize());
+    }
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("%-34s waves/CU=%2d  MFMA/iter=%2d FMA/iter=%2d   wall ns/iter=%8.2f\n", name, waves, NM, NV, ms * 1e6 / iters);
+    CK(hipFree(cyc)); CK(hipFree(sink));
+}
+
 template <int MODE>
 void run(const char *name, int waves, int iters)
 {
@@ -121,6 +174,17 @@ void run(const char *name, int waves, int iters)
 int main()
 {
     const int iters = 20000;
+    // one wave per SIMD: MFMA alone, FMA alone, both in one wave
+    run_co<8, 0, 0>("mfma alone (1 wave/SIMD)", 4, iters);
+    run_co<0, 24, 0>("fma alone (1 wave/SIMD)", 4, iters);
+    run_co<8, 24, 0>("both, same wave (1 wave/SIMD)", 4, iters);
+    run_co<8, 8, 0>("both, same wave (1 wave/SIMD)", 4, iters);
+    // two waves per SIMD: each alone, both in every wave, and split by role
+    run_co<8, 0, 0>("mfma alone (2 waves/SIMD)", 8, iters);
+    run_co<0, 24, 0>("fma alone (2 waves/SIMD)", 8, iters);
+    run_co<8, 24, 0>("both, same wave (2 waves/SIMD)", 8, iters);
+    run_co<8, 24, 1>("mfma waves + fma waves (1+1/SIMD)", 8, iters);
+    run_co<8, 48, 1>("mfma waves + fma waves (1+1/SIMD)", 8, iters);
     for (int w : {4, 8}) run<0>("mfma", w, iters);
     for (int w : {4, 8}) run<1>("lds", w, iters);
     for (int w : {4, 8}) run<2>("both", w, iters);
