@@ -101,7 +101,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const float *row, in
 }
 
 // 8 consecutive halves from an 8-byte aligned LDS address (two ds_read_b64)
-__device__ __forceinline__ half8 lds_half8(const _Float16 *p)
+[[maybe_unused]] __device__ __forceinline__ half8 lds_half8(const _Float16 *p)
 {
     const uint32x2 lo = *reinterpret_cast<const uint32x2 *>(p), hi = *reinterpret_cast<const uint32x2 *>(p + 4);
     uint32x4 u = {lo[0], lo[1], hi[0], hi[1]};
@@ -109,12 +109,13 @@ __device__ __forceinline__ half8 lds_half8(const _Float16 *p)
 }
 
 // LDS byte address of a pointer into shared memory (the low half of its flat address)
-__device__ __forceinline__ unsigned lds_addr(const void *p) { return (unsigned)(uintptr_t)p; }
+[[maybe_unused]] __device__ __forceinline__ unsigned lds_addr(const void *p) { return (unsigned)(uintptr_t)p; }
 
-// The fragment fetches of one k-step as volatile instructions: issued where they are written (a whole k-step ahead of
-// their MFMAs), not where the scheduler would sink them.  The data is in flight until frags_wait.
+// Diagnostic variant (-DSYLDET_ASM_PREFETCH; not the shipped build -- measured 4 % slower):
+// the fragment fetches of one k-step as volatile instructions, issued where they are written (a whole k-step ahead
+// of their MFMAs), not where the scheduler would sink them.  The data is in flight until frags_wait.
 template <int KSN>
-__device__ __forceinline__ void frags_fetch(unsigned a_addr, unsigned bh_addr, unsigned bl_addr, uint32x4 (&a)[8], uint32x4 &bh, uint32x4 &bl)
+[[maybe_unused]] __device__ __forceinline__ void frags_fetch(unsigned a_addr, unsigned bh_addr, unsigned bl_addr, uint32x4 (&a)[8], uint32x4 &bh, uint32x4 &bl)
 {
     asm volatile("ds_read2_b64 %0, %1 offset1:1" : "=v"(bh) : "v"(bh_addr));
     asm volatile("ds_read2_b64 %0, %1 offset1:1" : "=v"(bl) : "v"(bl_addr));
@@ -122,7 +123,7 @@ __device__ __forceinline__ void frags_fetch(unsigned a_addr, unsigned bh_addr, u
     for (int i = 0; i < 8; i++)
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a[i]) : "v"(a_addr), "n"((KSN * 8 + i) * 1024));
 }
-__device__ __forceinline__ void frags_wait(uint32x4 (&a)[8], uint32x4 &bh, uint32x4 &bl)
+[[maybe_unused]] __device__ __forceinline__ void frags_wait(uint32x4 (&a)[8], uint32x4 &bh, uint32x4 &bl)
 {
     asm volatile("s_waitcnt lgkmcnt(0)"
                  : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(bh), "+v"(bl));
