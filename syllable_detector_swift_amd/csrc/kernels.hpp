@@ -128,10 +128,6 @@ hipError_t launch_deinterleave(const float *in, int64_t n_frames, int total, int
 
 hipError_t launch_fused(const FusedDesc &d, const float *samples, int64_t stride, int C, int64_t S, int64_t J,
                         int64_t E, float *outputs, uint8_t *flags, hipStream_t stream);
-// 64-frame passes with LDS-resident raw samples (the reference's example class; `d` as for launch_fused, segmentation done)
-bool fused64_applies(const FusedDesc &d);
-hipError_t launch_fused64(const FusedDesc &d, const float *samples, int64_t stride, int C, int64_t J, int64_t E,
-                          float *outputs, uint8_t *flags, hipStream_t stream);
 // the DFT front half alone: samples -> [C][J][F] columns; d: a plan for timeRange 1 with spect_out / spect_power set
 hipError_t launch_fused_spectrogram(const FusedDesc &d, const float *samples, int64_t stride, int C, int64_t J, hipStream_t stream);
 // taps the register-resident first-layer fragments are instantiated for (0: timeRange too long)

@@ -34,8 +34,6 @@
 //
 // gfx950 only.  wave = 64.
 
-#include <type_traits>
-
 #include "kernels.hpp"
 
 namespace sd {
@@ -755,295 +753,6 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
         for (int i = 0; i < 16; i++) atomicAdd(&d.stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + i], tsum[i]);
 }
 
-// =====================================================================================================
-// 64-frame passes with the raw samples double-buffered in LDS (the reference's example class only: W = 256,
-// l2normalize first, linear |X| columns, two layers, TanSig hidden units (at most 4), one output, hop a multiple
-// of 4 but not of 16).  What changes against fused_kernel:
-//   * samples go HBM -> LDS directly (buffer_load ... lds, 16 bytes per lane), fp32, into the buffer the DFT of
-//     the pass before last has finished reading: no staging registers, no staging phase;
-//   * scale + f16 hi/lo split happen when a B fragment is fetched (two ds_read_b128 of fp32, then four
-//     v_fma_mix pairs), under the MFMAs of block M;
-//   * a wave owns 16 frames x one half of the basis rows (re and im of bins 16 rh .. 16 rh + 15): 4 A fragments
-//     + 1 B fragment per 6 MFMAs; magnitudes need no exchange; waves 0-3 (rh = 0) evaluate the previous pass;
-//   * phase 2 is: issue the DMA of pass p+2, block max of pass p+1 (from LDS), transition strip, magnitudes.
-// The plan tables (basis, first layer) are fused_kernel's; the launcher re-derives the LDS layout.
-constexpr int kP64 = 64;
-
-template <int TMAX, int NL, int KNOCK>
-__global__ void __launch_bounds__(kBlock, 2)
-fused64_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t stride, int64_t s_eff, int64_t E,
-               float *__restrict__ outputs, uint8_t *__restrict__ flags)
-{
-    constexpr int KS = 8, T = TMAX;
-    constexpr int kom = KNOCK;   // diagnostic knock-outs (0 in the shipped instantiation): 1 split, 2 evaluation, 4 magnitudes, 8 DMA + block max, 16 DFT MFMAs
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32x4 *lds_dfrag = reinterpret_cast<uint32x4 *>(smem + d.lds_dfrag);
-    float *red = reinterpret_cast<float *>(smem + d.lds_red);
-    float *cst = reinterpret_cast<float *>(smem + d.lds_cst);
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ft = wave & 3, rh = wave >> 2;     // frame tile, row half
-    const int f = lane & 15, g4 = lane >> 4;
-    const int c = blockIdx.y;
-    const int64_t e_b = (int64_t)blockIdx.x * d.seg_evals;
-    if (e_b >= E) return;
-    const int64_t e_e = (e_b + d.seg_evals < E) ? e_b + d.seg_evals : E;
-    const float *row = samples + (int64_t)c * stride;
-    const int PS = d.ps, XS = 2 * (T - 1);
-    const int fl = 16 * ft + f;
-    const int runs = d.runs;
-    const int bufw = d.smp_stride;               // floats per sample buffer
-
-    float *smp = reinterpret_cast<float *>(smem + d.lds_smp);            // [2][bufw] raw samples
-    _Float16 *colh = reinterpret_cast<_Float16 *>(smem + d.lds_colh);
-    _Float16 *coll = reinterpret_cast<_Float16 *>(smem + d.lds_coll);
-    float *stat = reinterpret_cast<float *>(smem + d.lds_stat);          // [2 row halves][PS] sums of squares
-
-    for (int i = tid; i < KS * 8 * 64; i += kBlock) lds_dfrag[i] = reinterpret_cast<const uint32x4 *>(d.dfrag)[i];
-    if (tid < 16) reinterpret_cast<double *>(cst + kCstThr)[tid] = tid < 1 ? d.thresholds[tid] : 0.0;
-    half8 afr[TMAX][2];
-#pragma unroll
-    for (int t = 0; t < TMAX; t++)
-#pragma unroll
-        for (int q = 0; q < 2; q++) afr[t][q] = as_half8(reinterpret_cast<const uint32x4 *>(d.afrag)[(t * 2 + q) * 64 + lane]);
-    float c_b0[4], c_w1[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int h = 4 * g4 + j;
-        c_b0[j] = h < d.H ? d.bias0[h] : 0.0f;
-        c_w1[j] = h < d.H ? d.w1[h] : 0.0f;
-    }
-    const float c_b1 = d.b1[0];
-    float lean_oa = 0.0f, lean_og = 1.0f, lean_ob = 0.0f;
-    if (d.n_out_fns == 1) { lean_oa = d.out_params[0]; lean_og = d.out_params[1]; lean_ob = d.out_params[2]; }
-    const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(
-        outputs ? outputs + (int64_t)c * E : nullptr, 0, outputs ? (int)(E * 4) : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t flg_rs = __builtin_amdgcn_make_buffer_rsrc(flags ? flags + (int64_t)c * E : nullptr, 0, flags ? (int)E : 0, 0x00020000);
-
-    // ---- samples of pass p: HBM -> LDS buffer `buf`, quads tid + 512 k (zeros past the end of the stream)
-    auto dma_pass = [&](int p, int buf) {
-        const __amdgpu_buffer_rsrc_t rs = tile_rsrc(row, (e_b + (int64_t)kP64 * p) * d.hop + d.gap, s_eff, d.nsmp);
-#pragma unroll
-        for (int k = 0; k < NL; k++)      // whole quads of 512 lanes: the buffers are sized for them, the descriptor zero-fills past nsmp
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(smp + buf * bufw + 256 * wave + 4 * kBlock * k),
-                                                     16, 16 * (tid + kBlock * k), 0, 0, 0);
-    };
-    auto max_partial = [&](int buf) {
-        float amax = 0.0f;
-        floatx4 v[NL];
-#pragma unroll
-        for (int k = 0; k < NL; k++) v[k] = *reinterpret_cast<const floatx4 *>(smp + buf * bufw + 4 * (tid + kBlock * k));
-#pragma unroll
-        for (int k = 0; k < NL; k++) amax = absmax3(absmax3(amax, v[k][0], v[k][1]), v[k][2], v[k][3]);
-        amax = wave_max_nonneg(amax);
-        if (lane == 0) red[wave] = amax;
-    };
-    auto pass_scale = [&]() {
-        const floatx4 r0 = *reinterpret_cast<const floatx4 *>(red), r1 = *reinterpret_cast<const floatx4 *>(red + 4);
-        const float amax = fmaxf(fmaxf(fmaxf(r0[0], r0[1]), fmaxf(r0[2], r0[3])), fmaxf(fmaxf(r1[0], r1[1]), fmaxf(r1[2], r1[3])));
-        int e = 13 - (int)((__float_as_uint(amax) >> 23) & 0xffu) + 127;
-        e = amax > 0.0f ? (e < -100 ? -100 : (e > 100 ? 100 : e)) : 0;
-        return __builtin_amdgcn_readfirstlane(e);
-    };
-
-    dma_pass(0, 0);
-    if (runs > 1) dma_pass(1, 1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    max_partial(0);
-    __syncthreads();
-    int se = pass_scale(), se_last = 0;          // sample scale exponents of this pass and of the one before
-
-    // ---- evaluation (waves 0-3), as in fused_kernel's LEAN instantiation
-    floatx4 z = {0.0f, 0.0f, 0.0f, 0.0f}, z2 = {0.0f, 0.0f, 0.0f, 0.0f};
-    float ssw = 1.0f, alpha = 0.0f, act[4] = {0.0f, 0.0f, 0.0f, 0.0f}, yv = 0.0f;
-    bool hit = false;
-    constexpr int kAhead = 3;
-    uint32x4 bh_q[kAhead], bl_q[kAhead];
-    const int wslot = fl < T - 1 ? fl : XS + fl - (T - 1);
-    const _Float16 *bph = colh + wslot * kColStride + 8 * g4, *bpl = coll + wslot * kColStride + 8 * g4;
-    auto gemm0_taps = [&](int t0, int t1) {
-#pragma unroll
-        for (int t = 0; t < TMAX; t++) {
-            if (t >= t0 && t < t1) {
-                const half8 h0 = as_half8(bh_q[t % kAhead]), l0 = as_half8(bl_q[t % kAhead]);
-                if (t + kAhead < T) {
-                    bh_q[t % kAhead] = *reinterpret_cast<const uint32x4 *>(bph + (t + kAhead) * kColStride);
-                    bl_q[t % kAhead] = *reinterpret_cast<const uint32x4 *>(bpl + (t + kAhead) * kColStride);
-                }
-                z = mfma(afr[t][0], h0, z);
-                z2 = mfma(afr[t][0], l0, z2);
-                z2 = mfma(afr[t][1], h0, z2);
-            }
-        }
-    };
-    auto post_step = [&](int step, int pp) {
-        constexpr int n0 = (T + 2) / 3, n1 = n0 + (T - n0 + 1) / 2;
-        if (step == 0) {
-            z = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
-            z2 = z;
-#pragma unroll
-            for (int t = 0; t < kAhead; t++) {
-                bh_q[t] = *reinterpret_cast<const uint32x4 *>(bph + t * kColStride);
-                bl_q[t] = *reinterpret_cast<const uint32x4 *>(bpl + t * kColStride);
-            }
-            gemm0_taps(0, n0);
-        } else if (step == 1) {
-            gemm0_taps(n0, n1);
-        } else if (step == 2) {
-            gemm0_taps(n1, T);
-            z += z2;
-            float acc_ss = 0.0f;
-#pragma unroll
-            for (int t = 0; t < T; t++) acc_ss += stat[wslot + t] + stat[PS + wslot + t];
-            ssw = acc_ss;
-        } else if (step == 3) {
-            alpha = d.w_unscale * __builtin_amdgcn_rsqf(ssw);     // W0 . v / |v|, both in column units
-        } else if (step == 4) {
-#pragma unroll
-            for (int j = 0; j < 4; j++) act[j] = transfer_fn(0, fmaf(alpha, z[j], c_b0[j]));
-        } else if (step == 5) {
-            const double *thr = reinterpret_cast<const double *>(cst + kCstThr);
-            float y = c_w1[0] * act[0];
-            y = fmaf(c_w1[1], act[1], y);
-            y = fmaf(c_w1[2], act[2], y);
-            y = fmaf(c_w1[3], act[3], y);
-            y = y + c_b1;
-            yv = (y - lean_oa) / lean_og + lean_ob;
-            hit = (double)yv >= thr[0];
-        } else if (step == 6) {
-            const int64_t e = e_b + (int64_t)kP64 * pp - (T - 1) + fl;
-            const bool st = e >= e_b && e < e_e && pp >= 0 && g4 == 0;
-            const unsigned off = (unsigned)e;
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(yv), out_rs, st ? off * 4u : 0xFFFFFFFFu, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(hit ? 1 : 0), flg_rs, st ? off : 0xFFFFFFFFu, 0, 0);
-        }
-    };
-
-    // DFT operand addresses: A fragments {re, im} x {hi, lo} of row half rh; B = 8 fp32 samples of frame fl, sample
-    // block ks + KS g4 (the 16 frames of a ds_read_b128 phase sit hop dwords apart: disjoint banks at hop % 16 == 4)
-    const uint32x4 *ap = lds_dfrag + 2 * rh * 64 + lane;
-    const int boff = fl * d.hop + 8 * KS * g4;
-    floatx4 acc_re = {0.f, 0.f, 0.f, 0.f}, acc_im = {0.f, 0.f, 0.f, 0.f};
-
-    auto block_m = [&](auto ev_tag, int p) {
-        constexpr bool EV = decltype(ev_tag)::value;
-        const float sx = pow2f(se);
-        const float *bp = smp + (p & 1) * bufw + boff;
-        floatx4 are = {0.f, 0.f, 0.f, 0.f}, aim = are, bre = are, bim = are;
-        uint32x4 a[4];
-        floatx4 b0 = *reinterpret_cast<const floatx4 *>(bp), b1 = *reinterpret_cast<const floatx4 *>(bp + 4);
-        a[0] = ap[0]; a[1] = ap[64]; a[2] = ap[256]; a[3] = ap[320];
-#pragma unroll
-        for (int ks = 0; ks < KS; ks++) {
-            const half8 reh = as_half8(a[0]), rel = as_half8(a[1]), imh = as_half8(a[2]), iml = as_half8(a[3]);
-            const floatx4 q0 = b0, q1 = b1;
-            if (ks + 1 < KS) {
-                a[0] = ap[(ks + 1) * 512]; a[1] = ap[(ks + 1) * 512 + 64]; a[2] = ap[(ks + 1) * 512 + 256]; a[3] = ap[(ks + 1) * 512 + 320];
-                b0 = *reinterpret_cast<const floatx4 *>(bp + 8 * (ks + 1));
-                b1 = *reinterpret_cast<const floatx4 *>(bp + 8 * (ks + 1) + 4);
-            }
-            unsigned h0, l0, h1, l1, h2, l2, h3, l3;
-            if (kom & 1) {
-                h0 = __float_as_uint(q0[0]); l0 = __float_as_uint(q0[1]); h1 = __float_as_uint(q0[2]); l1 = __float_as_uint(q0[3]);
-                h2 = __float_as_uint(q1[0]); l2 = __float_as_uint(q1[1]); h3 = __float_as_uint(q1[2]); l3 = __float_as_uint(q1[3]);
-            } else {
-                split_pair_scaled(q0[0], q0[1], sx, h0, l0);
-                split_pair_scaled(q0[2], q0[3], sx, h1, l1);
-                split_pair_scaled(q1[0], q1[1], sx, h2, l2);
-                split_pair_scaled(q1[2], q1[3], sx, h3, l3);
-            }
-            const half8 bh = as_half8(uint32x4{h0, h1, h2, h3}), bl = as_half8(uint32x4{l0, l1, l2, l3});
-            if (!(kom & 16)) {
-                are = mfma(reh, bh, are);
-                aim = mfma(imh, bh, aim);
-                bre = mfma(reh, bl, bre);
-                bim = mfma(imh, bl, bim);
-                bre = mfma(rel, bh, bre);
-                bim = mfma(iml, bh, bim);
-            } else {
-                asm volatile("" ::"v"(reh), "v"(rel), "v"(imh), "v"(iml), "v"(bh), "v"(bl));
-            }
-            if (EV && !(kom & 2)) post_step(ks, p - 1);
-        }
-        acc_re = are + bre;
-        acc_im = aim + bim;
-    };
-
-    for (int p = 0; p < runs; p++) {
-        // ================= block M: DFT of pass p (|| evaluation of pass p-1 on waves 0-3)
-        if (rh == 0) block_m(std::true_type{}, p);
-        else block_m(std::false_type{}, p);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of pass p+1 has landed
-        __syncthreads();          // A: every read of buffer p&1 and of the columns is done; pass p+1 is visible
-        if (p + 2 < runs && !(kom & 8)) dma_pass(p + 2, p & 1);
-        if (p + 1 < runs && !(kom & 8)) max_partial((p + 1) & 1);
-
-        const int cse = se;
-        const int csx = (p > 0 && se_last < se) ? se_last : se;
-        // ---- the previous pass's last T-1 columns -> the front of the transition strip, each half of the bins by
-        // the wave that overwrites it right after (waves 3 and 7: frames 48-63)
-        if (p > 0 && ft == 3 && !(kom & 4)) {
-            const int dexp = csx - se_last;                      // <= 0
-            const int src = XS + kP64 - (T - 1);
-            for (int i = lane; i < 2 * (T - 1) * 8; i += 64) {   // 8 words = 16 bins per column and array
-                const bool hi_arr = i < (T - 1) * 8;
-                const int w = hi_arr ? i : i - (T - 1) * 8;
-                const int col = w >> 3, word = (w & 7) + 8 * rh;
-                unsigned *arr = reinterpret_cast<unsigned *>(hi_arr ? colh : coll);
-                unsigned u = arr[(src + col) * (kColStride / 2) + word];
-                if (dexp != 0) {
-                    union { unsigned u; _Float16 h[2]; } x;
-                    x.u = u;
-                    const float f0 = (float)x.h[0] * pow2f(dexp), f1 = (float)x.h[1] * pow2f(dexp);
-                    union { decltype(__builtin_amdgcn_cvt_pkrtz(0.f, 0.f)) h; unsigned u; } y;
-                    y.h = __builtin_amdgcn_cvt_pkrtz(f0, f1);
-                    u = y.u;
-                }
-                arr[col * (kColStride / 2) + word] = u;
-            }
-            if (lane < T - 1) stat[rh * PS + lane] = stat[rh * PS + src + lane] * pow2f(2 * dexp);
-        }
-        // ---- magnitudes of this wave's 16 bins x 16 frames -> columns (scale 2^(cse - shift); with the sample
-        // scale's 2^-se the factor is a constant), sums of squares per frame and row half
-        if (kom & 4) {
-            if (acc_re[0] + acc_im[1] == 12345.0f) colh[lane] = (_Float16)1.0f;
-        } else {
-            const float k = pow2f(-13 - d.col_shift);
-            float cval[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) cval[j] = __builtin_amdgcn_sqrtf(fmaf(acc_re[j], acc_re[j], acc_im[j] * acc_im[j])) * k;
-            const int slot = XS + fl, xslot = (T - 1) + fl;
-            float ss = fmaf(cval[0], cval[0], fmaf(cval[1], cval[1], fmaf(cval[2], cval[2], cval[3] * cval[3])));
-            ss = xor32_sum(xor16_sum(ss));
-            if (g4 == 0) {
-                stat[rh * PS + slot] = ss;
-                if (fl < T - 1) stat[rh * PS + xslot] = ss * pow2f(2 * (csx - cse));
-            }
-            unsigned h0, l0, h1, l1;
-            split_pair_scaled(cval[0], cval[1], 1.0f, h0, l0);
-            split_pair_scaled(cval[2], cval[3], 1.0f, h1, l1);
-            *reinterpret_cast<uint32x2 *>(colh + slot * kColStride + 16 * rh + 4 * g4) = uint32x2{h0, h1};
-            *reinterpret_cast<uint32x2 *>(coll + slot * kColStride + 16 * rh + 4 * g4) = uint32x2{l0, l1};
-            if (ft == 0 && fl < T - 1) {                          // copies for the transition strip, at its scale
-                const float xs = pow2f(csx - cse);
-                split_pair_scaled(cval[0], cval[1], xs, h0, l0);
-                split_pair_scaled(cval[2], cval[3], xs, h1, l1);
-                *reinterpret_cast<uint32x2 *>(colh + xslot * kColStride + 16 * rh + 4 * g4) = uint32x2{h0, h1};
-                *reinterpret_cast<uint32x2 *>(coll + xslot * kColStride + 16 * rh + 4 * g4) = uint32x2{l0, l1};
-            }
-        }
-        __syncthreads();          // B: columns of pass p and the block max of pass p+1 are complete
-        se_last = se;
-        if (p + 1 < runs) se = pass_scale();
-    }
-    if (rh == 0 && !(kom & 2)) {
-#pragma unroll
-        for (int step = 0; step < 7; step++) post_step(step, runs - 1);
-    }
-}
-
 template <int KS, int TMAX, int NL, bool EXACT, bool SKEW, bool LEAN = false, bool STAMP = false, int KNOCK = 0, bool SPECT = false>
 hipError_t launch_one(const FusedDesc &d, const float *samples, int64_t stride, int C, int64_t s_eff, int64_t E,
                       float *outputs, uint8_t *flags, hipStream_t stream)
@@ -1103,62 +812,6 @@ hipError_t launch_fused(const FusedDesc &d, const float *samples, int64_t stride
     }
 #undef SD_GENERIC
     return hipErrorInvalidValue;
-}
-
-// fused64_kernel applies to the reference's example class at hops that need no bank spreading
-bool fused64_applies(const FusedDesc &d)
-{
-    const bool lean = d.norm == 1 && d.scaling == 0 && d.n_layers == 2 && d.tf0 == 0 /* TanSig */ && d.tf1 == 2 /* PureLin */ &&
-                      d.n_out == 1 && d.H <= 4 && d.n_out_fns <= 1;
-    const int nq = ((kP64 - 1) * d.hop + d.KS * 32 + 3) / 4;
-    return lean && d.KS == 8 && d.T == 10 && d.skew == 0 && d.hop % 4 == 0 && d.gap % 4 == 0 && (nq + kBlock - 1) / kBlock <= 5;   // two whole-quad sample buffers next to the basis: 5 x 8 KB each
-}
-
-hipError_t launch_fused64(const FusedDesc &d0, const float *samples, int64_t stride, int C, int64_t J, int64_t E,
-                          float *outputs, uint8_t *flags, hipStream_t stream)
-{
-    if (E <= 0 || C <= 0) return hipSuccess;
-    if (!fused64_applies(d0)) return hipErrorInvalidValue;
-    FusedDesc d = d0;
-    d.nsmp = (kP64 - 1) * d.hop + d.KS * 32;
-    const int nq = (d.nsmp + 3) / 4;
-    d.nload = (nq + kBlock - 1) / kBlock;
-    d.ps = kP64 + 2 * (d.T - 1);
-    d.nload = 5;
-    d.smp_stride = d.nload * kBlock * 4;              // floats per buffer: whole quads of 512 lanes
-    d.runs = 2 * d0.runs;                             // the same segments as fused_kernel's 128-frame passes
-    int off = 0;
-    auto take = [&off](int bytes) { const int o = off; off += (bytes + 15) / 16 * 16; return o; };
-    d.lds_dfrag = take(d.KS * 8 * 1024);
-    d.lds_smp = take(2 * d.smp_stride * 4);
-    d.lds_colh = take(d.ps * kColStride * 2);
-    d.lds_coll = take(d.ps * kColStride * 2);
-    d.lds_stat = take(2 * d.ps * 4);
-    d.lds_red = take(64);
-    d.lds_cst = take(32 * 4);
-    d.lds_total = off;
-    if (off > 160 * 1024) return hipErrorInvalidValue;
-    const int64_t s_eff = (J - 1) * (int64_t)d.hop + d.gap + d.W;
-    const int64_t segs = (E + d.seg_evals - 1) / d.seg_evals;
-    auto go = [&](auto kern) {
-        hipError_t st = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, d.lds_total);
-        if (st != hipSuccess) return st;
-        hipLaunchKernelGGL(kern, dim3((unsigned)segs, (unsigned)C), dim3(kBlock), (size_t)d.lds_total, stream, d, samples, stride, s_eff, E, outputs, flags);
-        return hipGetLastError();
-    };
-#ifdef SYLDET_KNOCKOUTS
-    switch (d.ko) {
-    case 1: return go(fused64_kernel<10, 5, 1>);
-    case 2: return go(fused64_kernel<10, 5, 2>);
-    case 4: return go(fused64_kernel<10, 5, 4>);
-    case 8: return go(fused64_kernel<10, 5, 8>);
-    case 16: return go(fused64_kernel<10, 5, 16>);
-    case 17: return go(fused64_kernel<10, 5, 17>);
-    case 31: return go(fused64_kernel<10, 5, 31>);
-    default: break;
-    }
-#endif
-    return go(fused64_kernel<10, 5, 0>);
 }
 
 // The DFT front half alone: samples -> [C][J][F] columns (|X| or |X|^2) in HBM.  `d` is a plan built for timeRange 1.

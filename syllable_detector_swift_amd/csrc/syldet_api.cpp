@@ -479,13 +479,6 @@ int run_on_stream(syldet *h, const float *d_samples, int64_t S, int64_t stride, 
                 if (sum[i] > 0) std::fprintf(stderr, "   %-32s %6.0f cycles/pass  %5.1f %%\n", names[i], sum[i] / ((double)(n / 16) * d.runs), 100.0 * sum[i] / tot);
             return SYLDET_OK;
         }
-        // experimental: SYLDET_FUSED64=1 takes the 64-frame-pass kernel where it applies
-        static const bool want_64 = std::getenv("SYLDET_FUSED64") != nullptr;
-        if (want_64 && fused64_applies(d)) {
-            KernelTimer t(h, stream, "fused64_kernel");
-            SYLDET_HIP(launch_fused64(d, d_samples, stride, C, J, E, d_outputs, d_flags, stream));
-            return SYLDET_OK;
-        }
         KernelTimer t(h, stream, "fused_kernel");
         SYLDET_HIP(launch_fused(d, d_samples, stride, C, S, J, E, d_outputs, d_flags, stream));
         return SYLDET_OK;
