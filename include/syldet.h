@@ -23,8 +23,10 @@
  *   - channels are independent detectors (Processor.swift:57-59: one SyllableDetector
  *     per channel; main.swift:86-89: one per track); batch layouts are channel-major;
  *   - threading: one producer (append) + one consumer (process/read) per channel, as
- *     TPCircularBuffer.h:14 guarantees in the reference; run* is not re-entrant on one
- *     handle; distinct handles are independent.
+ *     TPCircularBuffer.h:14 guarantees in the reference (append never locks; it allocates
+ *     once, on a channel's first samples); the host-pointer batch calls and the streaming
+ *     consumers of one handle serialise on its staging buffers; the *_device batch calls are
+ *     not re-entrant on one handle; distinct handles are independent.
  *   - there is NO CPU fallback: without a gfx950 device create fails with
  *     SYLDET_ERR_NO_DEVICE.
  */

@@ -92,7 +92,7 @@ struct PinnedBuffer {
 // reads head / frames_done -- no lock, no allocation: it can sit on an audio I/O thread like
 // TPCircularBufferProduceBytes does (TPCircularBuffer.h:14,177-185).
 struct ChannelStream {
-    std::vector<float> ring;                 // power-of-two capacity
+    std::vector<float> ring;                 // power-of-two capacity `mask + 1`; allocated by the first append (batch-only banks never pay for it)
     uint64_t mask = 0;
     std::atomic<uint64_t> tail{0};           // producer: total samples ever appended
     std::atomic<uint64_t> head{0};           // consumer: first sample of the next evaluation
@@ -104,7 +104,7 @@ struct ChannelStream {
 
     void copy_out(uint64_t from, float *dst, size_t n) const
     {
-        const size_t at = (size_t)(from & mask), first = std::min(n, ring.size() - at);
+        const size_t at = (size_t)(from & mask), first = std::min(n, ring.size() - at);   // n > 0 only after an append: the ring exists
         std::memcpy(dst, ring.data() + at, first * sizeof(float));
         if (n > first) std::memcpy(dst + first, ring.data(), (n - first) * sizeof(float));
     }
@@ -584,16 +584,20 @@ int syldet_create(const syldet_config_t *cfg, int32_t n_channels, int32_t device
         h->engine = SYLDET_ENGINE_WIDE_BF16;
         h->geom.engine = h->engine;
     }
-    h->streams.resize((size_t)n_channels);
-    for (auto &s : h->streams) {
-        s.reset(new ChannelStream());
-        s->last.assign((size_t)h->geom.outputs, 0.0f);   // lastOutputs zeros, SyllableDetector.swift:70
-        // the reference's sample ring (409 600 bytes) + what its feature ring would still hold as columns
-        uint64_t need = (uint64_t)(kSampleRingBytes / 4) + (uint64_t)h->geom.gap + (uint64_t)h->cfg.view.window_length +
-                        (uint64_t)(h->cfg.view.time_range + 1) * (uint64_t)h->geom.hop, cap = 1;
-        while (cap < need) cap <<= 1;
-        s->ring.assign((size_t)cap, 0.0f);
-        s->mask = cap - 1;
+    // the reference's sample ring (409 600 bytes) + what its feature ring would still hold as columns
+    uint64_t need = (uint64_t)(kSampleRingBytes / 4) + (uint64_t)h->geom.gap + (uint64_t)h->cfg.view.window_length +
+                    (uint64_t)(h->cfg.view.time_range + 1) * (uint64_t)h->geom.hop, cap = 1;
+    while (cap < need) cap <<= 1;
+    try {
+        h->streams.resize((size_t)n_channels);
+        for (auto &s : h->streams) {
+            s.reset(new ChannelStream());
+            s->last.assign((size_t)h->geom.outputs, 0.0f);   // lastOutputs zeros, SyllableDetector.swift:70
+            s->mask = cap - 1;
+        }
+    } catch (const std::bad_alloc &) {
+        syldet_destroy(h.release());
+        return fail(SYLDET_ERR_OUT_OF_MEMORY, "out of memory");
     }
     *out = h.release();
     return SYLDET_OK;
@@ -687,6 +691,7 @@ int syldet_detections_device(syldet_t *h, const uint8_t *d_flags, int64_t n_eval
 int syldet_run(syldet_t *h, const float *samples, int64_t n_samples, int64_t channel_stride, float *outputs, uint8_t *flags)
 {
     if (int st = check_batch_args(h, samples, n_samples, channel_stride)) return st;
+    std::lock_guard<std::mutex> staging(h->pump_mu);   // the staging buffers and h->stream: one user at a time
     SYLDET_HIP(hipSetDevice(h->device));
     const int C = h->channels;
     const int64_t E = count_evals(h, n_samples);
@@ -736,6 +741,7 @@ int syldet_run_interleaved(syldet_t *h, const float *interleaved, int64_t n_fram
     const int64_t E = count_evals(h, n_frames);
     if (E <= 0) return SYLDET_OK;
     if (!interleaved) return fail(SYLDET_ERR_INVALID_ARGUMENT, "NULL buffer");
+    std::lock_guard<std::mutex> staging(h->pump_mu);   // the staging buffers and h->stream: one user at a time
     SYLDET_HIP(hipSetDevice(h->device));
     const size_t in_bytes = (size_t)C * (size_t)n_frames * sizeof(float);
     const size_t out_bytes = (size_t)C * (size_t)E * (size_t)h->geom.outputs * sizeof(float);
@@ -757,6 +763,7 @@ int syldet_spectrogram(syldet_t *h, const float *samples, int64_t n_samples, int
 {
     if (int st = check_batch_args(h, samples, n_samples, channel_stride)) return st;
     if (!columns) return fail(SYLDET_ERR_INVALID_ARGUMENT, "NULL argument");
+    std::lock_guard<std::mutex> staging(h->pump_mu);   // the staging buffers and h->stream: one user at a time
     SYLDET_HIP(hipSetDevice(h->device));
     const int C = h->channels;
     const int64_t J = count_frames(h, n_samples);
@@ -780,6 +787,7 @@ int syldet_detections(syldet_t *h, const uint8_t *flags, int64_t n_evals, double
 {
     if (!h || !flags || !counts || n_evals < 0 || capacity < 0 || (capacity > 0 && !indices))
         return fail(SYLDET_ERR_INVALID_ARGUMENT, "bad argument");
+    std::lock_guard<std::mutex> staging(h->pump_mu);   // the staging buffers and h->stream: one user at a time
     SYLDET_HIP(hipSetDevice(h->device));
     const int C = h->channels;
     const size_t fl_bytes = std::max<size_t>((size_t)C * (size_t)n_evals, 1);
@@ -815,7 +823,20 @@ static bool stream_has_room(const syldet *h, const ChannelStream &cs, int64_t n)
     const int64_t unconsumed = (int64_t)tail - cs.frames_done.load(std::memory_order_acquire) * h->geom.hop;
     if ((unconsumed + n) * 4 > kSampleRingBytes) return false;
     // (cannot overrun the un-evaluated samples: the ring is sized for the bound above plus the evaluation carry)
-    return (int64_t)(tail - cs.head.load(std::memory_order_acquire)) + n <= (int64_t)cs.ring.size();
+    return (int64_t)(tail - cs.head.load(std::memory_order_acquire)) + n <= (int64_t)(cs.mask + 1);
+}
+
+// The ring comes into being with a channel's first samples (the only allocation the producer side ever makes);
+// the consumer never looks at it before `tail` says there is something in it.
+static int stream_ensure_ring(ChannelStream &cs)
+{
+    if (!cs.ring.empty()) return SYLDET_OK;
+    try {
+        cs.ring.assign((size_t)(cs.mask + 1), 0.0f);
+    } catch (const std::bad_alloc &) {
+        return fail(SYLDET_ERR_OUT_OF_MEMORY, "out of memory");
+    }
+    return SYLDET_OK;
 }
 
 static void stream_write(ChannelStream &cs, const float *data, int64_t n, int64_t step)
@@ -832,6 +853,7 @@ int syldet_append(syldet_t *h, int32_t channel, const float *data, int64_t n_sam
         return fail(SYLDET_ERR_INVALID_ARGUMENT, "bad argument");
     ChannelStream &cs = *h->streams[(size_t)channel];
     if (!stream_has_room(h, cs, n_samples)) return fail(SYLDET_ERR_BUFFER_FULL, "Insufficient space on buffer.");
+    if (int st = stream_ensure_ring(cs)) return st;
     stream_write(cs, data, n_samples, 1);
     return SYLDET_OK;
 }
@@ -844,6 +866,8 @@ int syldet_append_interleaved(syldet_t *h, const float *data, int64_t n_frames, 
     // (room only grows between the check and the writes: the consumer is the only other party)
     for (int c = 0; c < h->channels; c++)
         if (!stream_has_room(h, *h->streams[(size_t)c], n_frames)) return fail(SYLDET_ERR_BUFFER_FULL, "Insufficient space on buffer.");
+    for (int c = 0; c < h->channels; c++)
+        if (int st = stream_ensure_ring(*h->streams[(size_t)c])) return st;
     for (int c = 0; c < h->channels; c++) stream_write(*h->streams[(size_t)c], data + c, n_frames, total_channels);
     return SYLDET_OK;
 }
@@ -851,7 +875,7 @@ int syldet_append_interleaved(syldet_t *h, const float *data, int64_t n_frames, 
 // Evaluates what the listed channels have pending: channels with the same number of new evaluations share one
 // pinned staging block, one H2D copy, one launch and one D2H copy; the results join each channel's queue of
 // computed evaluations.  Adds the number queued to *queued.
-static int pump(syldet *h, const int32_t *channels, int32_t n, int64_t *queued)
+static int pump_impl(syldet *h, const int32_t *channels, int32_t n, int64_t *queued)
 {
     std::lock_guard<std::mutex> pump_lock(h->pump_mu);
     const int n_out = h->geom.outputs;
@@ -900,6 +924,15 @@ static int pump(syldet *h, const int32_t *channels, int32_t n, int64_t *queued)
     return SYLDET_OK;
 }
 
+static int pump(syldet *h, const int32_t *channels, int32_t n, int64_t *queued)
+{
+    try {                                                        // no exception crosses the C boundary
+        return pump_impl(h, channels, n, queued);
+    } catch (const std::bad_alloc &) {
+        return fail(SYLDET_ERR_OUT_OF_MEMORY, "out of memory");
+    }
+}
+
 int syldet_process_new_value(syldet_t *h, int32_t channel)
 {
     if (!h || channel < 0 || channel >= h->channels) return fail(SYLDET_ERR_INVALID_ARGUMENT, "bad argument");
@@ -915,7 +948,12 @@ int syldet_process_new_value(syldet_t *h, int32_t channel)
 int syldet_process_all(syldet_t *h, int64_t *n_queued)
 {
     if (!h) return fail(SYLDET_ERR_INVALID_ARGUMENT, "NULL argument");
-    std::vector<int32_t> all((size_t)h->channels);
+    std::vector<int32_t> all;
+    try {
+        all.resize((size_t)h->channels);
+    } catch (const std::bad_alloc &) {
+        return fail(SYLDET_ERR_OUT_OF_MEMORY, "out of memory");
+    }
     for (int32_t c = 0; c < h->channels; c++) all[(size_t)c] = c;
     int64_t queued = 0;
     if (int st = pump(h, all.data(), h->channels, &queued)) return st;
