@@ -587,20 +587,33 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
             const int dexp = scaling != 0 ? 0 : csx - se_prev;     // <= 0
             const int words = (T - 1) * (kColStride / 2);      // 32-bit words per array
             const int src = (XS + kPass - (T - 1)) * (kColStride / 2);
-            for (int i = lane; i < 2 * words; i += 64) {
+            // all reads first, then all writes: one LDS round trip instead of one per 64 words (this wave is the
+            // last one through the phase, so its latency is the workgroup's)
+            constexpr int kIt = (2 * (TMAX - 1) * (kColStride / 2) + 63) / 64;
+            unsigned u[kIt];
+#pragma unroll
+            for (int k = 0; k < kIt; k++) {
+                const int i = lane + 64 * k;
                 const bool hi_arr = i < words;
                 const int w = hi_arr ? i : i - words;
-                unsigned u = reinterpret_cast<const unsigned *>(hi_arr ? colh : coll)[src + w];
+                u[k] = i < 2 * words ? reinterpret_cast<const unsigned *>(hi_arr ? colh : coll)[src + w] : 0u;
+            }
+#pragma unroll
+            for (int k = 0; k < kIt; k++) {
+                const int i = lane + 64 * k;
+                const bool hi_arr = i < words;
+                const int w = hi_arr ? i : i - words;
+                unsigned uu = u[k];
                 if (dexp != 0) {
                     union { unsigned u; _Float16 h[2]; } x;
-                    x.u = u;
+                    x.u = uu;
                     const float f0 = (float)x.h[0] * pow2f(dexp);
                     const float f1 = (float)x.h[1] * pow2f(dexp);
                     union { decltype(__builtin_amdgcn_cvt_pkrtz(0.f, 0.f)) h; unsigned u; } y;
                     y.h = __builtin_amdgcn_cvt_pkrtz(f0, f1);
-                    u = y.u;
+                    uu = y.u;
                 }
-                reinterpret_cast<unsigned *>(hi_arr ? colh : coll)[w] = u;
+                if (i < 2 * words) reinterpret_cast<unsigned *>(hi_arr ? colh : coll)[w] = uu;
             }
             const int ssrc = XS + kPass - (T - 1);
             if (norm == 1 && lane < T - 1) stat[lane] = stat[ssrc + lane] * pow2f(2 * dexp);   // sums of squares of scaled columns
@@ -750,7 +763,9 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
         for (int step = 0; step < 7; step++) post_step(step, runs - 1, cse_post, csx_post);
     }
     if (STAMP && tid == 0 && d.stamps)
-        for (int i = 0; i < 16; i++) atomicAdd(&d.stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + i], tsum[i]);
+        for (int i = 0; i < 8; i++) atomicAdd(&d.stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + i], tsum[i]);
+    if (STAMP && tid == 64 * (kWaves - 1) && d.stamps)       // the youngest wave's view of the same phases, slots 8..
+        for (int i = 0; i < 8; i++) atomicAdd(&d.stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + 8 + i], tsum[i]);
 }
 
 template <int KS, int TMAX, int NL, bool EXACT, bool SKEW, bool LEAN = false, bool STAMP = false, int KNOCK = 0, bool SPECT = false>
