@@ -176,12 +176,15 @@ stft_r8_kernel(StftDesc d, const float *__restrict__ samples, int64_t stride, in
 }
 
 // ------------------------------------------------------------------------------------
-// STFT: one frame per group of TPF = min(256, M/2) threads, G = 256/TPF frames per pass.
+// STFT: one frame per group of TPF = min(256, M/4) threads, G = 256/TPF frames per pass.
 // Packed real FFT: z[m] = xw[2m] + i xw[2m+1] (the vDSP_ctoz step :314-316), M-point
-// complex Stockham radix-2 through two LDS buffers, then the real split restricted to the
-// band:  2X[k] = (Z[k] + conj Z[M-k]) - i e^{-2 pi i k/N} (Z[k] - conj Z[M-k]).
+// complex Stockham autosort through two LDS buffers -- radix-4 stages, one radix-2 stage
+// last when log2 M is odd (half the barriers and LDS round trips of a radix-2 chain) --
+// then the real split restricted to the band:
+//   2X[k] = (Z[k] + conj Z[M-k]) - i e^{-2 pi i k/N} (Z[k] - conj Z[M-k]).
 // ------------------------------------------------------------------------------------
 constexpr int kStftPasses = 8;   // frames per block = G * kStftPasses
+constexpr int kStftTableM = 2048;  // up to this M the twiddle (M/2 float2) and window (<= 2M floats) tables live in LDS
 
 __global__ void __launch_bounds__(kBlock)
 stft_generic_kernel(StftDesc d, const float *__restrict__ samples, int64_t stride, int64_t J,
@@ -189,17 +192,37 @@ stft_generic_kernel(StftDesc d, const float *__restrict__ samples, int64_t strid
 {
     extern __shared__ float2 lds[];
     const int M = d.M;
-    const int half = M >> 1;
-    const int TPF = half < kBlock ? (half < 1 ? 1 : half) : kBlock;
+    const int half = M >> 1, quarter = M >> 2;
+    const int TPF = quarter < kBlock ? (quarter < 1 ? 1 : quarter) : kBlock;
     const int G = kBlock / TPF;
     const int g = threadIdx.x / TPF;
     const int t = threadIdx.x - g * TPF;
     const int c = blockIdx.y;
     float2 *bufA = lds + (size_t)g * 2 * M;
     float2 *bufB = bufA + M;
+    // small transforms keep the twiddle and window tables in LDS too (a global load per butterfly input costs a
+    // memory latency in every stage); the launcher sizes the allocation to match
+    const bool tables_in_lds = M <= kStftTableM;
+    float2 *lds_tw = lds + (size_t)G * 2 * M;
+    float2 *lds_sw = lds_tw + half;                             // split twiddles of the band: e^{-2 pi i (f0 + f) / N}
+    float *lds_win = reinterpret_cast<float *>(lds_sw + d.F);
+    if (tables_in_lds) {
+        for (int i = threadIdx.x; i < half; i += kBlock) lds_tw[i] = d.tw[i];
+        for (int i = threadIdx.x; i < d.F; i += kBlock) lds_sw[i] = d.sw[d.f0 + i];
+        for (int i = threadIdx.x; i < d.W; i += kBlock) lds_win[i] = d.window[i];
+        __syncthreads();
+    }
+    const float2 *twp = tables_in_lds ? lds_tw : d.tw;
+    const float2 *swp = tables_in_lds ? lds_sw : d.sw + d.f0;
+    const float *winp = tables_in_lds ? lds_win : d.window;
     const float *chan = samples + (int64_t)c * stride;
     float *cols = columns + (int64_t)c * J * d.F;
 
+    // a frame whose threads all sit in one wave needs no workgroup barrier: a wave's LDS operations execute in order
+    auto frame_sync = [&]() {
+        if (TPF <= kWave) __builtin_amdgcn_wave_barrier();
+        else __syncthreads();
+    };
     for (int pass = 0; pass < kStftPasses; pass++) {
         const int64_t j = ((int64_t)blockIdx.x * kStftPasses + pass) * G + g;
         const bool valid = j < J;
@@ -210,26 +233,48 @@ stft_generic_kernel(StftDesc d, const float *__restrict__ samples, int64_t strid
             const int n0 = 2 * m;
             float a = 0.0f, b = 0.0f;
             if (valid) {
-                if (n0 < d.W) a = x[n0] * d.window[n0];
-                if (n0 + 1 < d.W) b = x[n0 + 1] * d.window[n0 + 1];
+                if (n0 < d.W) a = x[n0] * winp[n0];
+                if (n0 + 1 < d.W) b = x[n0 + 1] * winp[n0 + 1];
             }
             bufA[m] = make_float2(a, b);
         }
-        __syncthreads();
+        frame_sync();
 
         float2 *in = bufA, *out = bufB;
-        for (int Ns = 1; Ns < M; Ns <<= 1) {
-            const int tw_stride = half / Ns;          // twiddle e^{-2 pi i k / (2 Ns)} = tw[k * M/(2Ns)]
-            for (int jj = t; jj < half; jj += TPF) {
+        // twiddle e^{-2 pi i u / M} for u < M from the half table (tw[u], u < M/2)
+        auto twiddle = [&](int u) {
+            const float2 w = twp[u < half ? u : u - half];
+            return u < half ? w : make_float2(-w.x, -w.y);
+        };
+        int Ns = 1;
+        for (; Ns * 4 <= M; Ns <<= 2) {                           // radix-4 stages
+            const int tw_stride = quarter / Ns;                  // e^{-2 pi i k / (4 Ns)} = twiddle(k * M/(4 Ns))
+            for (int jj = t; jj < quarter; jj += TPF) {
                 const int k = jj & (Ns - 1);
-                const float2 w = d.tw[k * tw_stride];
                 const float2 v0 = in[jj];
-                const float2 v1 = cmul(in[jj + half], w);
-                const int j0 = ((jj - k) << 1) + k;
-                out[j0] = make_float2(v0.x + v1.x, v0.y + v1.y);
-                out[j0 + Ns] = make_float2(v0.x - v1.x, v0.y - v1.y);
+                const float2 v1 = cmul(in[jj + quarter], twiddle(k * tw_stride));
+                const float2 v2 = cmul(in[jj + 2 * quarter], twiddle(2 * k * tw_stride));
+                const float2 v3 = cmul(in[jj + 3 * quarter], twiddle(3 * k * tw_stride));
+                const float2 p0 = make_float2(v0.x + v2.x, v0.y + v2.y), p1 = make_float2(v0.x - v2.x, v0.y - v2.y);
+                const float2 q0 = make_float2(v1.x + v3.x, v1.y + v3.y);
+                const float2 q1 = make_float2(v1.y - v3.y, -(v1.x - v3.x));   // (v1 - v3) . (-i)
+                const int j0 = ((jj - k) << 2) + k;
+                out[j0] = make_float2(p0.x + q0.x, p0.y + q0.y);
+                out[j0 + Ns] = make_float2(p1.x + q1.x, p1.y + q1.y);
+                out[j0 + 2 * Ns] = make_float2(p0.x - q0.x, p0.y - q0.y);
+                out[j0 + 3 * Ns] = make_float2(p1.x - q1.x, p1.y - q1.y);
             }
-            __syncthreads();
+            frame_sync();
+            float2 *tmp = in; in = out; out = tmp;
+        }
+        if (Ns < M) {                                             // log2 M odd: one radix-2 stage, Ns == M / 2
+            for (int jj = t; jj < half; jj += TPF) {
+                const float2 v0 = in[jj];
+                const float2 v1 = cmul(in[jj + half], twp[jj]);   // k == jj, e^{-2 pi i k / M}
+                out[jj] = make_float2(v0.x + v1.x, v0.y + v1.y);
+                out[jj + half] = make_float2(v0.x - v1.x, v0.y - v1.y);
+            }
+            frame_sync();
             float2 *tmp = in; in = out; out = tmp;
         }
 
@@ -243,7 +288,7 @@ stft_generic_kernel(StftDesc d, const float *__restrict__ samples, int64_t strid
                 im2 = 0.0f;
             } else {
                 const float2 zk = in[k], zm = in[M - k];
-                const float2 w = d.sw[k];
+                const float2 w = swp[f];
                 const float ar = zk.x + zm.x, ai = zk.y - zm.y;
                 const float br = zk.x - zm.x, bi = zk.y + zm.y;
                 const float tr = br * w.x - bi * w.y, ti = br * w.y + bi * w.x;
@@ -254,7 +299,7 @@ stft_generic_kernel(StftDesc d, const float *__restrict__ samples, int64_t strid
             const float v = d.power_mode ? p * 0.25f : sqrtf(p) * 0.5f;   // zvmags/4 :270-274, zvabs/2 :329-333
             if (valid) cols[j * d.F + f] = v;
         }
-        __syncthreads();
+        frame_sync();
     }
 }
 
@@ -643,10 +688,10 @@ hipError_t launch_stft_generic(const StftDesc &d, const float *samples, int64_t 
         hipLaunchKernelGGL(stft_r8_kernel, grid, dim3(kBlock), 0, stream, d, samples, stride, J, columns);
         return hipGetLastError();
     }
-    const int half = d.M / 2;
-    const int TPF = half < kBlock ? (half < 1 ? 1 : half) : kBlock;
+    const int quarter = d.M / 4;
+    const int TPF = quarter < kBlock ? (quarter < 1 ? 1 : quarter) : kBlock;
     const int G = kBlock / TPF;
-    const size_t lds = (size_t)G * 2 * d.M * sizeof(float2);
+    const size_t lds = (size_t)G * 2 * d.M * sizeof(float2) + (d.M <= kStftTableM ? (size_t)(d.M / 2 + d.F) * sizeof(float2) + (size_t)d.W * sizeof(float) : 0);
     const int64_t per_block = (int64_t)G * kStftPasses;
     dim3 grid((unsigned)((J + per_block - 1) / per_block), (unsigned)C);
     if (lds > 64 * 1024) {
