@@ -643,6 +643,135 @@ mlp_small_kernel(NetDesc n, int F, const float *__restrict__ columns, int64_t J,
 }
 
 // ------------------------------------------------------------------------------------
+// mlp_small_kernel for the input chains the training script writes -- [l2normalize,] one affine map (mapminmax /
+// mapstd) -- in front of a two-layer network with at most two outputs and at most one output map: the chain is a
+// compile-time fact, every parameter of the second layer and of the output map sits in registers, and the run of
+// evaluations is straight-line code (the interpretive kernel spends most of its time on scalar loads of the chain
+// description, branches and per-evaluation parameter fetches).  Same operation order, nothing folded.
+// ------------------------------------------------------------------------------------
+template <int KI, int HMAX, bool WLDS, bool L2>
+__global__ void __launch_bounds__(kBlock)
+mlp_chain_kernel(NetDesc n, int F, const float *__restrict__ columns, int64_t J, int64_t E,
+                 float *__restrict__ outputs, uint8_t *__restrict__ flags)
+{
+    const int wave = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
+    const int c = blockIdx.y;
+    const float *cols = columns + (int64_t)c * J * F;
+    const float *P = n.params;
+    const int I = n.I;
+    const DevLayer L0 = n.layers[0], L1 = n.layers[1];
+    const int H = L0.out, n_out = L1.out;
+    const DevFn aff = n.in_fns[L2 ? 1 : 0];
+
+    extern __shared__ float wlds[];                             // WLDS: [HMAX][KI * 64] rows, then offsets and gains [2][KI * 64]
+    float *alds = wlds + HMAX * KI * kWave;
+    float w[WLDS ? 1 : HMAX][WLDS ? 1 : KI], axo[WLDS ? 1 : KI], aga[WLDS ? 1 : KI];
+    if (WLDS) {
+        for (int i = threadIdx.x; i < HMAX * KI * kWave; i += kBlock) {
+            const int h = i / (KI * kWave), e = i - h * (KI * kWave);
+            wlds[i] = (h < H && e < I) ? P[L0.w + (size_t)h * I + e] : 0.0f;
+        }
+        for (int i = threadIdx.x; i < KI * kWave; i += kBlock) {
+            alds[i] = i < I ? P[aff.xoff + i] : 0.0f;
+            alds[KI * kWave + i] = i < I ? P[aff.gain + i] : 0.0f;
+        }
+        __syncthreads();
+    } else {
+#pragma unroll
+        for (int k = 0; k < KI; k++) {
+            const int i = lane + kWave * k;
+#pragma unroll
+            for (int h = 0; h < HMAX; h++) w[WLDS ? 0 : h][WLDS ? 0 : k] = (h < H && i < I) ? P[L0.w + (size_t)h * I + i] : 0.0f;
+            axo[WLDS ? 0 : k] = i < I ? P[aff.xoff + i] : 0.0f;
+            aga[WLDS ? 0 : k] = i < I ? P[aff.gain + i] : 0.0f;
+        }
+    }
+    const float b0 = lane < H ? P[L0.b + lane] : 0.0f;          // lane h finishes hidden unit h
+    float w1[2][HMAX], b1[2], og[2], ox[2];
+#pragma unroll
+    for (int o = 0; o < 2; o++) {
+#pragma unroll
+        for (int h = 0; h < HMAX; h++) w1[o][h] = (o < n_out && h < H) ? P[L1.w + o * H + h] : 0.0f;
+        b1[o] = o < n_out ? P[L1.b + o] : 0.0f;
+        og[o] = (n.n_out_fns == 1 && o < n_out) ? P[n.out_fns[0].gain + o] : 1.0f;
+        ox[o] = (n.n_out_fns == 1 && o < n_out) ? P[n.out_fns[0].xoff + o] : 0.0f;
+    }
+    const float oy = n.n_out_fns == 1 ? n.out_fns[0].y : 0.0f;
+    const double thr0 = n.thresholds[0], thr1 = n_out > 1 ? n.thresholds[1] : 0.0;
+    const int scaling = n.scaling, tf0 = L0.tf, tf1 = L1.tf;
+    const bool any_rule = n.rule != 0;
+
+    const int64_t e0 = ((int64_t)blockIdx.x * (kBlock / kWave) + wave) * kSmallRun;
+    if (e0 >= E) return;
+    float xn[KI];                                               // the next evaluation's inputs, fetched one ahead
+#pragma unroll
+    for (int k = 0; k < KI; k++) xn[k] = lane + kWave * k < I ? cols[e0 * F + lane + kWave * k] : 0.0f;
+    for (int r = 0; r < kSmallRun; r++) {
+        const int64_t e = e0 + r;
+        if (e >= E) return;                                     // wave-uniform
+        float x[KI];
+#pragma unroll
+        for (int k = 0; k < KI; k++) x[k] = xn[k];
+        if (r + 1 < kSmallRun && e + 1 < E) {
+#pragma unroll
+            for (int k = 0; k < KI; k++) xn[k] = lane + kWave * k < I ? cols[(e + 1) * F + lane + kWave * k] : 0.0f;
+        }
+        if (scaling != 0) {
+#pragma unroll
+            for (int k = 0; k < KI; k++) {
+                const float v = scaling == 1 ? logf(x[k])                   // vvlogf, SyllableDetector.swift:207
+                                             : 20.0f * log10f(x[k]);        // vDSP_vdbcon ref 1, amplitude flag :195
+                x[k] = lane + kWave * k < I ? v : 0.0f;
+            }
+        }
+        int wl = lane;
+        if (WLDS) asm volatile("" : "+v"(wl));                  // keeps the LDS reads inside the loop (hoisted, they are 120 registers)
+        if (L2) {                                               // L2Normalize, NeuralNet.swift:47-59
+            float ss = 0.0f;
+#pragma unroll
+            for (int k = 0; k < KI; k++) ss += x[k] * x[k];
+            const float inv = 1.0f / sqrtf(wave_sum(ss));
+#pragma unroll
+            for (int k = 0; k < KI; k++) x[k] = x[k] * inv;     // one division per vector (vDSP_vsdiv divides each; <= 1 ulp apart)
+        }
+#pragma unroll
+        for (int k = 0; k < KI; k++)                            // MapMinMax.apply :127-131, MapStd.apply :162-169
+            x[k] = WLDS ? (x[k] - alds[k * kWave + wl]) * alds[(KI + k) * kWave + wl] + aff.y
+                        : (x[k] - axo[WLDS ? 0 : k]) * aga[WLDS ? 0 : k] + aff.y;   // padding lanes meet zero weights below
+        float mine = 0.0f;
+#pragma unroll
+        for (int h = 0; h < HMAX; h++) {
+            if (h < H) {                                        // wave-uniform
+                float acc = 0.0f;
+#pragma unroll
+                for (int k = 0; k < KI; k++) acc = fmaf(WLDS ? wlds[(h * KI + k) * kWave + wl] : w[WLDS ? 0 : h][WLDS ? 0 : k], x[k], acc);
+                acc = wave_sum(acc);
+                mine = lane == h ? acc : mine;
+            }
+        }
+        const float act = transfer(tf0, mine + b0);
+        float y[2] = {0.0f, 0.0f};
+#pragma unroll
+        for (int h = 0; h < HMAX; h++) {
+            const float a = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(act), h));
+            y[0] = fmaf(w1[0][h], a, y[0]);                     // rows past H and outputs past n_out carry zero weights
+            y[1] = fmaf(w1[1][h], a, y[1]);
+        }
+        uint8_t hit = 0;
+#pragma unroll
+        for (int o = 0; o < 2; o++) {
+            if (o < n_out) {                                    // wave-uniform
+                float v = transfer(tf1, y[o] + b1[o]);         // vDSP_mmul, then the bias (NeuralNet.swift:366-377)
+                if (n.n_out_fns == 1) v = (v - oy) / og[o] + ox[o];   // reverse map, NeuralNet.swift:137-142 / :175-180
+                if (lane == 0 && outputs) outputs[(((int64_t)c * E) + e) * n_out + o] = v;
+                if (o == 0 || any_rule) hit |= ((double)v >= (o == 0 ? thr0 : thr1)) ? 1 : 0;
+            }
+        }
+        if (lane == 0 && flags) flags[(int64_t)c * E + e] = hit;
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // Detection sample numbers with debounce (TrackDetector.swift:39-43, :65-100): a greedy
 // scan along time, one wave per channel, 64 flags per step; the wave skips ahead with
 // ballots so quiet stretches cost one load per 64 evaluations.
@@ -711,12 +840,24 @@ hipError_t launch_mlp_generic(const NetDesc &n, int F, const float *columns, int
         const int H = n.layers[0].out;
         const int64_t per_block = (int64_t)(kBlock / kWave) * kSmallRun;
         dim3 grid((unsigned)((E + per_block - 1) / per_block), (unsigned)C);
+        // the chains the training script writes get the straight-line kernel: [l2normalize,] one affine map, two layers,
+        // at most two outputs, at most one output map
+        const bool affine_last = n.n_in_fns >= 1 && n.in_fns[n.n_in_fns - 1].kind >= 3;
+        const bool chain_l2 = n.n_in_fns == 2 && n.in_fns[0].kind == 0 && affine_last;
+        const bool chain_ok = n.n_layers == 2 && n.n_out <= 2 && n.n_out_fns <= 1 && (chain_l2 || (n.n_in_fns == 1 && affine_last));
         if (n.I <= 64 * 5 && H <= 8) {
-            hipLaunchKernelGGL((mlp_small_kernel<5, 8, false>), grid, dim3(kBlock), 0, stream, n, F, columns, J, E, outputs, flags);
+            if (chain_ok && H <= 4 && chain_l2) hipLaunchKernelGGL((mlp_chain_kernel<5, 4, false, true>), grid, dim3(kBlock), 0, stream, n, F, columns, J, E, outputs, flags);
+            else if (chain_ok && H <= 4) hipLaunchKernelGGL((mlp_chain_kernel<5, 4, false, false>), grid, dim3(kBlock), 0, stream, n, F, columns, J, E, outputs, flags);
+            else if (chain_ok && chain_l2) hipLaunchKernelGGL((mlp_chain_kernel<5, 8, false, true>), grid, dim3(kBlock), 0, stream, n, F, columns, J, E, outputs, flags);
+            else if (chain_ok) hipLaunchKernelGGL((mlp_chain_kernel<5, 8, false, false>), grid, dim3(kBlock), 0, stream, n, F, columns, J, E, outputs, flags);
+            else hipLaunchKernelGGL((mlp_small_kernel<5, 8, false>), grid, dim3(kBlock), 0, stream, n, F, columns, J, E, outputs, flags);
             return hipGetLastError();
         }
         if (n.I <= 64 * 20 && H <= 4) {
-            hipLaunchKernelGGL((mlp_small_kernel<20, 4, true>), grid, dim3(kBlock), (4 + 2) * 20 * kWave * sizeof(float), stream, n, F, columns, J, E, outputs, flags);
+            const size_t lds = (4 + 2) * 20 * kWave * sizeof(float);
+            if (chain_ok && chain_l2) hipLaunchKernelGGL((mlp_chain_kernel<20, 4, true, true>), grid, dim3(kBlock), lds, stream, n, F, columns, J, E, outputs, flags);
+            else if (chain_ok) hipLaunchKernelGGL((mlp_chain_kernel<20, 4, true, false>), grid, dim3(kBlock), lds, stream, n, F, columns, J, E, outputs, flags);
+            else hipLaunchKernelGGL((mlp_small_kernel<20, 4, true>), grid, dim3(kBlock), lds, stream, n, F, columns, J, E, outputs, flags);
             return hipGetLastError();
         }
     }
