@@ -156,6 +156,64 @@ wide_prep_kernel(NetDesc n, int F, const float *__restrict__ columns, int64_t J,
     }
 }
 
+// The same for the input chains the training script writes -- [l2normalize,] one affine map: the chain is a
+// compile-time fact and the map's parameters sit in registers (see mlp_chain_kernel in kernels_generic.hip).
+template <bool L2>
+__global__ void __launch_bounds__(256)
+wide_prep_chain_kernel(NetDesc n, int F, const float *__restrict__ columns, int64_t J, int64_t E, __bf16 *__restrict__ xn)
+{
+    const int wave = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
+    const int c = blockIdx.y;
+    const float *cols = columns + (int64_t)c * J * F;
+    const float *P = n.params;
+    const int I = n.I, scaling = n.scaling;
+    const DevFn aff = n.in_fns[L2 ? 1 : 0];
+    float axo[kKI], aga[kKI];
+#pragma unroll
+    for (int k = 0; k < kKI; k++) {
+        const int i = lane + kWave * k;
+        axo[k] = i < I ? P[aff.xoff + i] : 0.0f;
+        aga[k] = i < I ? P[aff.gain + i] : 0.0f;
+    }
+    const int64_t e0 = ((int64_t)blockIdx.x * (256 / kWave) + wave) * kPrepRun;
+    if (e0 >= E) return;
+    float nxt[kKI];
+#pragma unroll
+    for (int k = 0; k < kKI; k++) nxt[k] = lane + kWave * k < I ? cols[e0 * F + lane + kWave * k] : 0.0f;
+    for (int r = 0; r < kPrepRun; r++) {
+        const int64_t e = e0 + r;
+        if (e >= E) return;
+        float x[kKI];
+#pragma unroll
+        for (int k = 0; k < kKI; k++) x[k] = nxt[k];
+        if (r + 1 < kPrepRun && e + 1 < E) {
+#pragma unroll
+            for (int k = 0; k < kKI; k++) nxt[k] = lane + kWave * k < I ? cols[(e + 1) * F + lane + kWave * k] : 0.0f;
+        }
+        if (scaling != 0) {
+#pragma unroll
+            for (int k = 0; k < kKI; k++) {
+                const float v = scaling == 1 ? logf(x[k]) : 20.0f * log10f(x[k]);
+                x[k] = lane + kWave * k < I ? v : 0.0f;
+            }
+        }
+        if (L2) {                                               // L2Normalize :47-59
+            float s = 0.0f;
+#pragma unroll
+            for (int k = 0; k < kKI; k++) s += x[k] * x[k];
+            const float inv = 1.0f / sqrtf(wave_reduce_sum(s));
+#pragma unroll
+            for (int k = 0; k < kKI; k++) x[k] = x[k] * inv;
+        }
+        __bf16 *dst = xn + ((int64_t)c * E + e) * kWideK;
+#pragma unroll
+        for (int k = 0; k < kKI; k++) {                         // MapMinMax.apply :127-131, MapStd.apply :162-169; zero padding
+            const float v = lane + kWave * k < I ? (x[k] - axo[k]) * aga[k] + aff.y : 0.0f;
+            dst[lane + kWave * k] = (__bf16)v;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // The GEMM + epilogue.  MFMA operand layouts (v_mfma_f32_32x32x16_bf16):
 //   A [32 units x 16 k]:   lane l holds unit l % 32, k = 8 (l / 32) + 0..7      (from LDS, host-packed)
@@ -271,7 +329,13 @@ hipError_t launch_wide_prep(const NetDesc &n, int F, const float *columns, int C
     if (E <= 0 || C <= 0) return hipSuccess;
     const int64_t per_block = (int64_t)(256 / kWave) * kPrepRun;
     dim3 grid((unsigned)((E + per_block - 1) / per_block), (unsigned)C);
-    hipLaunchKernelGGL(wide_prep_kernel, grid, dim3(256), 0, stream, n, F, columns, J, E, (__bf16 *)xn);
+    const bool affine_last = n.n_in_fns >= 1 && n.in_fns[n.n_in_fns - 1].kind >= 3;
+    if (n.n_in_fns == 2 && n.in_fns[0].kind == 0 && affine_last)
+        hipLaunchKernelGGL(wide_prep_chain_kernel<true>, grid, dim3(256), 0, stream, n, F, columns, J, E, (__bf16 *)xn);
+    else if (n.n_in_fns == 1 && affine_last)
+        hipLaunchKernelGGL(wide_prep_chain_kernel<false>, grid, dim3(256), 0, stream, n, F, columns, J, E, (__bf16 *)xn);
+    else
+        hipLaunchKernelGGL(wide_prep_kernel, grid, dim3(256), 0, stream, n, F, columns, J, E, (__bf16 *)xn);
     return hipGetLastError();
 }
 
