@@ -259,6 +259,14 @@ int syldet_run_interleaved_device(syldet_t *h, const float *d_interleaved, int64
 int syldet_run_interleaved(syldet_t *h, const float *interleaved, int64_t n_frames, int32_t total_channels,
                            float *outputs, uint8_t *flags);
 
+/* ---- the exchange step of the multi-GPU path (no reference counterpart: the reference runs one process) ----
+ * Channels shard across GPUs with no data-path collective; the one exchange is the gather of the detection
+ * flags, and it travels as bits: bit b of byte t of a row = flag 8 t + b, rows padded to whole bytes
+ * ((row_len + 7) / 8 bytes per row).  Device pointers (d_flags of the unpack 8-byte aligned), asynchronous on
+ * `hip_stream`; rows <= 65535.                                                                            */
+int syldet_pack_flags_device(const uint8_t *d_flags, int64_t rows, int64_t row_len, uint8_t *d_bits, void *hip_stream);
+int syldet_unpack_flags_device(const uint8_t *d_bits, int64_t rows, int64_t row_len, uint8_t *d_flags, void *hip_stream);
+
 /* ResamplerLinear, Common/Resampler.swift:20-76 (used when the device rate differs from the
  * network's: Processor.swift:116-121, ViewControllerProcessor.swift:247-250), for n_channels
  * independent streams fed in lock-step.  Stateful like the reference: the fractional

@@ -114,6 +114,8 @@ SIGNATURES = {
     "syldet_deinterleave_device": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     "syldet_run_interleaved_device": (C.c_int, [Handle, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "syldet_run_interleaved": (C.c_int, [Handle, c_float_p, C.c_int64, C.c_int32, c_float_p, c_uint8_p]),
+    "syldet_pack_flags_device": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
+    "syldet_unpack_flags_device": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
     "syldet_resampler_create": (C.c_int, [C.c_double, C.c_double, C.c_int32, C.c_int32, C.POINTER(Handle)]),
     "syldet_resampler_destroy": (C.c_int, [Handle]),
     "syldet_resampler_count": (C.c_int64, [Handle, C.c_int64]),

@@ -126,6 +126,10 @@ hipError_t launch_resample_linear(const float *in, int64_t n_in, int64_t in_stri
 hipError_t launch_deinterleave(const float *in, int64_t n_frames, int total, int first, int C, float *out,
                                int64_t out_stride, hipStream_t stream);
 
+// detection flags <-> bits (bit b of byte t of a row = flag 8 t + b), rows padded to whole bytes
+hipError_t launch_pack_flags(const uint8_t *flags, int64_t rows, int64_t row_len, uint8_t *bits, hipStream_t stream);
+hipError_t launch_unpack_flags(const uint8_t *bits, int64_t rows, int64_t row_len, uint8_t *flags, hipStream_t stream);
+
 hipError_t launch_fused(const FusedDesc &d, const float *samples, int64_t stride, int C, int64_t S, int64_t J,
                         int64_t E, float *outputs, uint8_t *flags, hipStream_t stream);
 // the DFT front half alone: samples -> [C][J][F] columns; d: a plan for timeRange 1 with spect_out / spect_power set

@@ -82,6 +82,68 @@ hipError_t launch_resample_linear(const float *in, int64_t n_in, int64_t in_stri
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------
+// Detection flags as bits, for the one exchange of the multi-GPU path (the gather of the
+// `uint8 [C/G][E]` flags is latency- and wire-bound; packed it is an eighth of the bytes).
+// bits[row][t] bit b = flags[row][8 t + b] != 0; rows are padded to whole bytes.
+// ------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+pack_flags_kernel(const uint8_t *__restrict__ flags, int64_t row_len, int64_t row_bytes, uint8_t *__restrict__ bits)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= row_bytes) return;
+    const uint8_t *src = flags + (int64_t)blockIdx.y * row_len + 8 * t;
+    const int64_t left = row_len - 8 * t;
+    unsigned b = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) b |= (k < left && src[k] != 0) ? (1u << k) : 0u;
+    bits[(int64_t)blockIdx.y * row_bytes + t] = (uint8_t)b;
+}
+
+__global__ void __launch_bounds__(256)
+unpack_flags_kernel(const uint8_t *__restrict__ bits, int64_t rows, int64_t row_len, int64_t row_bytes, uint8_t *__restrict__ flags)
+{
+    // one aligned 8-byte store per thread over the flat [rows * row_len] output; a thread's eight flags may straddle two rows
+    const int64_t q = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8, total = rows * row_len;
+    if (q >= total) return;
+    int64_t row = q / row_len, i = q - row * row_len;
+    uint64_t out = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        if (q + k < total) {
+            const unsigned b = bits[row * row_bytes + (i >> 3)];
+            out |= (uint64_t)((b >> (i & 7)) & 1u) << (8 * k);
+            if (++i == row_len) { i = 0; row++; }
+        }
+    }
+    if (q + 8 <= total) {
+        *reinterpret_cast<uint64_t *>(flags + q) = out;          // hipMalloc'ed bases are 256-byte aligned; q is a multiple of 8
+    } else {
+        for (int k = 0; q + k < total; k++) flags[q + k] = (uint8_t)(out >> (8 * k));
+    }
+}
+
+hipError_t launch_pack_flags(const uint8_t *flags, int64_t rows, int64_t row_len, uint8_t *bits, hipStream_t stream)
+{
+    if (rows <= 0 || row_len <= 0) return hipSuccess;
+    const int64_t row_bytes = (row_len + 7) / 8;
+    dim3 grid((unsigned)((row_bytes + 255) / 256), (unsigned)rows);
+    hipLaunchKernelGGL(pack_flags_kernel, grid, dim3(256), 0, stream, flags, row_len, row_bytes, bits);
+    return hipGetLastError();
+}
+
+hipError_t launch_unpack_flags(const uint8_t *bits, int64_t rows, int64_t row_len, uint8_t *flags, hipStream_t stream)
+{
+    if (rows <= 0 || row_len <= 0) return hipSuccess;
+    const int64_t row_bytes = (row_len + 7) / 8;
+    const int64_t threads = (rows * row_len + 7) / 8;
+    const bool aligned = (reinterpret_cast<uintptr_t>(flags) & 7) == 0;
+    if (!aligned || threads > 0x7fffffffLL * 256) return hipErrorInvalidValue;
+    dim3 grid((unsigned)((threads + 255) / 256));
+    hipLaunchKernelGGL(unpack_flags_kernel, grid, dim3(256), 0, stream, bits, rows, row_len, row_bytes, flags);
+    return hipGetLastError();
+}
+
 hipError_t launch_deinterleave(const float *in, int64_t n_frames, int total, int first, int C, float *out,
                                int64_t out_stride, hipStream_t stream)
 {

@@ -153,4 +153,22 @@ int syldet_deinterleave_device(const float *d_interleaved, int64_t n_frames, int
     return SYLDET_OK;
 }
 
+int syldet_pack_flags_device(const uint8_t *d_flags, int64_t rows, int64_t row_len, uint8_t *d_bits, void *hip_stream)
+{
+    if (rows < 0 || row_len < 0 || rows > 65535) return fail(SYLDET_ERR_INVALID_ARGUMENT, "rows must be in [0, 65535], row_len >= 0");
+    if (rows == 0 || row_len == 0) return SYLDET_OK;
+    if (!d_flags || !d_bits) return fail(SYLDET_ERR_INVALID_ARGUMENT, "NULL buffer");
+    SYLDET_HIP(launch_pack_flags(d_flags, rows, row_len, d_bits, (hipStream_t)hip_stream));
+    return SYLDET_OK;
+}
+
+int syldet_unpack_flags_device(const uint8_t *d_bits, int64_t rows, int64_t row_len, uint8_t *d_flags, void *hip_stream)
+{
+    if (rows < 0 || row_len < 0 || rows > 65535) return fail(SYLDET_ERR_INVALID_ARGUMENT, "rows must be in [0, 65535], row_len >= 0");
+    if (rows == 0 || row_len == 0) return SYLDET_OK;
+    if (!d_flags || !d_bits) return fail(SYLDET_ERR_INVALID_ARGUMENT, "NULL buffer");
+    SYLDET_HIP(launch_unpack_flags(d_bits, rows, row_len, d_flags, (hipStream_t)hip_stream));
+    return SYLDET_OK;
+}
+
 }  // extern "C"

@@ -21,12 +21,46 @@ def shard_channels(total_channels: int, world_size: int, rank: int) -> Tuple[int
     return first, base + (1 if rank < extra else 0)
 
 
-def gather_flags(local_flags, total_channels: int, group=None):
+def pack_flags(flags):
+    """[rows, E] uint8 flags on a GPU -> [rows, ceil(E / 8)] bytes, bit b of byte t = flag 8 t + b (libsyldet kernel)."""
+    import torch
+    from . import _abi
+    from .config import check
+    rows, E = int(flags.shape[0]), int(flags.shape[1])
+    flags = flags.contiguous()
+    bits = torch.empty((rows, (E + 7) // 8), dtype=torch.uint8, device=flags.device)
+    check(_abi.lib.syldet_pack_flags_device(flags.data_ptr(), rows, E, bits.data_ptr(),
+                                            torch.cuda.current_stream(flags.device).cuda_stream))
+    return bits
+
+
+def unpack_flags(bits, E: int):
+    """Inverse of pack_flags: [rows, ceil(E / 8)] bytes -> [rows, E] uint8 flags (0 / 1)."""
+    import torch
+    from . import _abi
+    from .config import check
+    rows = int(bits.shape[0])
+    bits = bits.contiguous()
+    flags = torch.empty((rows, E), dtype=torch.uint8, device=bits.device)
+    check(_abi.lib.syldet_unpack_flags_device(bits.data_ptr(), rows, E, flags.data_ptr(),
+                                              torch.cuda.current_stream(bits.device).cuda_stream))
+    return flags
+
+
+def gather_flags(local_flags, total_channels: int, group=None, packed=None):
     """All ranks receive the full [total_channels, E] flag tensor.  `local_flags` is this rank's
     [count, E] uint8 tensor (CUDA with nccl/RCCL, CPU with gloo).  Equal shards use one
-    all_gather_into_tensor; ragged shards pad to the largest shard."""
+    all_gather_into_tensor; ragged shards pad to the largest shard.  On GPUs the flags travel as
+    bits (`packed`, default for CUDA tensors): an eighth of the bytes on the xGMI links, packed and
+    unpacked by two small kernels on either side of the one collective."""
     import torch
     import torch.distributed as dist
+    if packed is None:
+        packed = bool(local_flags.is_cuda)
+    if packed:
+        E = int(local_flags.shape[1])
+        bits = gather_flags(pack_flags(local_flags), total_channels, group, packed=False)
+        return unpack_flags(bits, E)
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     E = int(local_flags.shape[1])

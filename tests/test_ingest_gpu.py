@@ -281,3 +281,47 @@ def test_producer_thread_against_consumer_thread(oracle_lib):
         assert not errors
     for c in range(C):
         util.assert_outputs_close(np.array(got[c]).reshape(-1, 1), o.run(x[c], po.F64)[2])
+
+
+# ---- the multi-GPU exchange travels as bits -------------------------------------------------------
+
+@pytest.mark.parametrize("shape", [(1, 1), (3, 7), (5, 8), (4, 127090), (64, 1000), (2, 65)])
+def test_flag_bits_round_trip(shape):
+    torch = _torch()
+    from syllable_detector_swift_amd.dist import pack_flags, unpack_flags
+    rng = np.random.default_rng(shape[1])
+    fl = (rng.random(shape) < 0.3).astype(np.uint8)
+    d = torch.from_numpy(fl).cuda()
+    bits = pack_flags(d)
+    want = np.packbits(fl, axis=1, bitorder="little")
+    assert np.array_equal(bits.cpu().numpy(), want)
+    assert np.array_equal(unpack_flags(bits, shape[1]).cpu().numpy(), fl)
+    # any non-zero byte counts as a raised flag
+    d2 = torch.from_numpy((fl * 200).astype(np.uint8)).cuda()
+    assert np.array_equal(pack_flags(d2).cpu().numpy(), want)
+
+
+def test_packed_gather_over_rccl_single_rank(tmp_path):
+    """The packed gather through a real RCCL process group (world size 1 on the one GPU of the test box; the
+    world-size-2 case runs on gloo in tests/test_dist_cpu.py)."""
+    import os
+    import subprocess
+    import sys
+    script = tmp_path / "gather1.py"
+    script.write_text(
+        "import os, sys, numpy as np, torch, torch.distributed as dist\n"
+        "sys.path.insert(0, %r)\n"
+        "from syllable_detector_swift_amd.dist import gather_flags\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group(backend='nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))\n"
+        "rng = np.random.default_rng(3)\n"
+        "fl = (rng.random((6, 12345)) < 0.2).astype(np.uint8)\n"
+        "out = gather_flags(torch.from_numpy(fl).cuda(), 6)\n"
+        "assert out.shape == (6, 12345) and np.array_equal(out.cpu().numpy(), fl)\n"
+        "plain = gather_flags(torch.from_numpy(fl).cuda(), 6, packed=False)\n"
+        "assert np.array_equal(plain.cpu().numpy(), fl)\n"
+        "dist.destroy_process_group()\n"
+        "print('ok')\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29591", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
