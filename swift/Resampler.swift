@@ -40,7 +40,7 @@ class ResamplerLinear: Resampler {
     }
 
     func resampleArray(_ arr: [Float]) -> [Float] {
-        var arr = arr
-        return self.resampleVector(&arr, ofLength: arr.count)
+        guard !arr.isEmpty else { return [] }
+        return arr.withUnsafeBufferPointer { resampleVector($0.baseAddress!, ofLength: $0.count) }
     }
 }
