@@ -229,6 +229,8 @@ stft_generic_kernel(StftDesc d, const float *__restrict__ samples, int64_t strid
         if (TPF <= kWave) __builtin_amdgcn_wave_barrier();
         else __syncthreads();
     };
+    // every frame of this channel starts 8-byte aligned (block-uniform): sample pairs come in one load
+    const bool pairs = (d.hop & 1) == 0 && (reinterpret_cast<uintptr_t>(chan + d.gap) & 7) == 0;
     for (int pass = 0; pass < kStftPasses; pass++) {
         const int64_t j = ((int64_t)blockIdx.x * kStftPasses + pass) * G + g;
         const bool valid = j < J;
@@ -239,8 +241,14 @@ stft_generic_kernel(StftDesc d, const float *__restrict__ samples, int64_t strid
             const int n0 = 2 * m;
             float a = 0.0f, b = 0.0f;
             if (valid) {
-                if (n0 < d.W) a = x[n0] * winp[n0];
-                if (n0 + 1 < d.W) b = x[n0 + 1] * winp[n0 + 1];
+                if (pairs && n0 + 1 < d.W) {                      // one 8-byte load per (even, odd) pair
+                    const float2 s2 = reinterpret_cast<const float2 *>(x)[m];
+                    a = s2.x * winp[n0];
+                    b = s2.y * winp[n0 + 1];
+                } else {
+                    if (n0 < d.W) a = x[n0] * winp[n0];
+                    if (n0 + 1 < d.W) b = x[n0 + 1] * winp[n0 + 1];
+                }
             }
             bufA[m] = make_float2(a, b);
         }
