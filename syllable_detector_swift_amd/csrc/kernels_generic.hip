@@ -236,8 +236,8 @@ stft_generic_kernel(StftDesc d, const float *__restrict__ samples, int64_t strid
         const bool valid = j < J;
         const float *x = chan + j * d.hop + d.gap;
 
-        // window multiply (vDSP_vmul :311) + zero pad (:110) + even/odd packing
-        for (int m = t; m < M; m += TPF) {
+        // window multiply (vDSP_vmul :311) + zero pad (:110) + even/odd packing: z[m] = xw[2m] + i xw[2m+1]
+        auto packed = [&](int m) {
             const int n0 = 2 * m;
             float a = 0.0f, b = 0.0f;
             if (valid) {
@@ -250,9 +250,13 @@ stft_generic_kernel(StftDesc d, const float *__restrict__ samples, int64_t strid
                     if (n0 + 1 < d.W) b = x[n0 + 1] * winp[n0 + 1];
                 }
             }
-            bufA[m] = make_float2(a, b);
+            return make_float2(a, b);
+        };
+        const bool first_from_memory = M >= 4;                    // the first radix-4 stage (all twiddles 1) reads the samples itself
+        if (!first_from_memory) {
+            for (int m = t; m < M; m += TPF) bufA[m] = packed(m);
+            frame_sync();
         }
-        frame_sync();
 
         float2 *in = bufA, *out = bufB;
         // twiddle e^{-2 pi i u / M} for u < M from the half table (tw[u], u < M/2)
@@ -261,6 +265,20 @@ stft_generic_kernel(StftDesc d, const float *__restrict__ samples, int64_t strid
             return u < half ? w : make_float2(-w.x, -w.y);
         };
         int Ns = 1;
+        if (first_from_memory) {
+            for (int jj = t; jj < quarter; jj += TPF) {
+                const float2 v0 = packed(jj), v1 = packed(jj + quarter), v2 = packed(jj + 2 * quarter), v3 = packed(jj + 3 * quarter);
+                const float2 p0 = make_float2(v0.x + v2.x, v0.y + v2.y), p1 = make_float2(v0.x - v2.x, v0.y - v2.y);
+                const float2 q0 = make_float2(v1.x + v3.x, v1.y + v3.y);
+                const float2 q1 = make_float2(v1.y - v3.y, -(v1.x - v3.x));   // (v1 - v3) . (-i)
+                bufA[4 * jj] = make_float2(p0.x + q0.x, p0.y + q0.y);
+                bufA[4 * jj + 1] = make_float2(p1.x + q1.x, p1.y + q1.y);
+                bufA[4 * jj + 2] = make_float2(p0.x - q0.x, p0.y - q0.y);
+                bufA[4 * jj + 3] = make_float2(p1.x - q1.x, p1.y - q1.y);
+            }
+            frame_sync();
+            Ns = 4;
+        }
         for (; Ns * 4 <= M; Ns <<= 2) {                           // radix-4 stages
             const int tw_stride = quarter / Ns;                  // e^{-2 pi i k / (4 Ns)} = twiddle(k * M/(4 Ns))
             for (int jj = t; jj < quarter; jj += TPF) {
