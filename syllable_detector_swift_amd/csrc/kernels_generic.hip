@@ -299,27 +299,27 @@ stft_generic_kernel(StftDesc d, const float *__restrict__ samples, int64_t strid
             frame_sync();
             float2 *tmp = in; in = out; out = tmp;
         }
-        if (Ns < M) {                                             // log2 M odd: one radix-2 stage, Ns == M / 2
-            for (int jj = t; jj < half; jj += TPF) {
-                const float2 v0 = in[jj];
-                const float2 v1 = cmul(in[jj + half], twp[jj]);   // k == jj, e^{-2 pi i k / M}
-                out[jj] = make_float2(v0.x + v1.x, v0.y + v1.y);
-                out[jj + half] = make_float2(v0.x - v1.x, v0.y - v1.y);
-            }
-            frame_sync();
-            float2 *tmp = in; in = out; out = tmp;
-        }
+        // log2 M odd: one radix-2 stage is left (Ns == M / 2).  It is not run: the real split below needs only the band's
+        // Z[k] and Z[M - k], and computes those two butterflies itself from the stage's input
+        const bool last_in_split = Ns < M;
+        auto spectrum = [&](int u) {                              // Z[u]
+            if (!last_in_split) return in[u];
+            const int jj = u & (half - 1);
+            const float2 v0 = in[jj];
+            const float2 v1 = cmul(in[jj + half], twp[jj]);       // e^{-2 pi i jj / M}
+            return u < half ? make_float2(v0.x + v1.x, v0.y + v1.y) : make_float2(v0.x - v1.x, v0.y - v1.y);
+        };
 
         // real split + magnitude for the band only; Nyquist is dropped (:323)
         for (int f = t; f < d.F; f += TPF) {
             const int k = d.f0 + f;
             float re2, im2;
             if (k == 0) {
-                const float2 z0 = in[0];
+                const float2 z0 = spectrum(0);
                 re2 = 2.0f * (z0.x + z0.y);
                 im2 = 0.0f;
             } else {
-                const float2 zk = in[k], zm = in[M - k];
+                const float2 zk = spectrum(k), zm = spectrum(M - k);
                 const float2 w = swp[f];
                 const float ar = zk.x + zm.x, ai = zk.y - zm.y;
                 const float br = zk.x - zm.x, bi = zk.y + zm.y;
