@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsyldet.so")
+# SYLDET_LIB: a diagnostic build of the same library (knock-out timing runs); never a different implementation
+LIB_PATH = os.environ.get("SYLDET_LIB") or os.path.join(_HERE, "lib", "libsyldet.so")
 
 ABI_VERSION = 1
 

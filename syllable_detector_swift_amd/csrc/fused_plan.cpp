@@ -150,6 +150,24 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
     d.lds_cst = take((32 + kMaxFns * 33) * 4);       // thresholds + output maps (kCst* in kernels_fused.hip)
     d.lds_total = off;
     if (off > 160 * 1024) return no("LDS budget exceeded");
+    {   // the register-resident-basis kernel's own pass geometry and LDS layout
+        const int rn = (kFusedRTileFrames - 1) * hop + KS * 32;
+        const int rl = (rn / 4 + kFusedRBlock - 1) / kFusedRBlock;
+        // every thread always stages all of its quads: room for 1024 rl samples (those past rn are zeros nobody reads)
+        const int rn_p = (skewed(std::max(rn, 4 * kFusedRBlock * rl) + 16) + 15) / 8 * 8;
+        const int rps = kFusedRTileFrames + 2 * (T - 1);
+        int roff = 0;
+        auto rtake = [&roff](int bytes) { const int o = roff; roff += (bytes + 15) / 16 * 16; return o; };
+        d.r_nsmp = rn; d.r_nload = rl; d.r_ps = rps; d.r_smp_stride = rn_p;
+        d.r_lds_smp = rtake(2 * 2 * rn_p * 2);           // two buffers of f16 hi + lo
+        d.r_lds_colh = rtake(rps * kFusedColStride * 2);
+        d.r_lds_coll = rtake(rps * kFusedColStride * 2);
+        d.r_lds_stat = rtake(2 * rps * 4);
+        d.r_lds_red = rtake(64);
+        d.r_lds_cst = rtake((32 + kMaxFns * 33) * 4);
+        d.r_lds_total = roff;
+        d.r_ok = (rl <= kFusedRMaxLoads && roff <= 160 * 1024) ? 1 : 0;
+    }
 
     // ---- DFT basis fragments: A operand of v_mfma_f32_16x16x32_f16, lane l holds row l&15 of its tile,
     // k = 8*(l>>4) + j.  Tiles: re bins 0-15, re 16-31, im 0-15, im 16-31.  Basis row r < F:
@@ -257,6 +275,11 @@ void fused_segmentation(FusedDesc &d, int64_t E, int C)
     runs = std::max<int64_t>(1, std::min<int64_t>(16, runs));
     d.runs = (int)runs;
     d.seg_evals = (int)(runs * kFusedTileFrames - (d.T - 1));
+    // the 64-frame-pass kernel: the same segment length in samples, twice the passes
+    int64_t rr = (frames * (int64_t)C) / ((int64_t)kFusedRTileFrames * 2048);
+    rr = std::max<int64_t>(1, std::min<int64_t>(32, rr));
+    d.r_runs = (int)rr;
+    d.r_seg_evals = (int)(rr * kFusedRTileFrames - (d.T - 1));
 }
 
 }  // namespace sd

@@ -85,6 +85,9 @@ constexpr int kFusedBlock = 512;        // 8 waves
 constexpr int kFusedChunkFrames = 64;   // frames per team chunk (4 waves x 16); a workgroup = 2 teams
 constexpr int kFusedTileFrames = 128;   // frames per workgroup period (two chunks)
 constexpr int kFusedMaxLoads = 10;      // float4 loads per thread per pass
+constexpr int kFusedRBlock = 256;       // register-resident-basis kernel (kernels_fused_r.hip): 4 waves, one per SIMD
+constexpr int kFusedRTileFrames = 64;   //   16 frames per wave and pass
+constexpr int kFusedRMaxLoads = 10;     //   float4 loads per thread per pass
 constexpr int kFusedColStride = 40;     // halves per column row in LDS: 32 bins + 8 of padding (80 B rows: 16-byte
                                         // aligned, and 16 consecutive rows cover all 64 banks once for ds_read_b128)
 
@@ -105,6 +108,10 @@ struct FusedDesc {
     int col_shift;              // |X| columns are stored as |X| * 2^(cse - col_shift) (2x for |X|^2)
     float w_unscale;            // 1 / (power-of-two scale of the folded first-layer weights)
     int lds_dfrag, lds_smp, lds_colh, lds_coll, lds_stat, lds_red, lds_cst, lds_total;   // byte offsets
+    // layout of the register-resident-basis kernel (64-frame passes, staged samples double-buffered, no basis in LDS);
+    // r_ok = 0 when the shape does not fit it (long hops)
+    int r_ok, r_nsmp, r_nload, r_ps, r_smp_stride, r_runs, r_seg_evals;
+    int r_lds_smp, r_lds_colh, r_lds_coll, r_lds_stat, r_lds_red, r_lds_cst, r_lds_total;   // second sample buffer: r_lds_smp + 4 r_smp_stride
     const uint4 *dfrag;         // [KS][re 0-15, re 16-31, im 0-15, im 16-31][hi,lo][64 lanes] A-operand fragments of the DFT basis
     const uint4 *afrag;         // [T][hi,lo][64 lanes] A-operand fragments of the folded first layer (16x16x32)
     const int *koff;            // [KS][4] staged-sample offset of k-step ks for lane group g4 (skew applied)
@@ -134,6 +141,10 @@ hipError_t launch_fused(const FusedDesc &d, const float *samples, int64_t stride
                         int64_t E, float *outputs, uint8_t *flags, hipStream_t stream);
 // the DFT front half alone: samples -> [C][J][F] columns; d: a plan for timeRange 1 with spect_out / spect_power set
 hipError_t launch_fused_spectrogram(const FusedDesc &d, const float *samples, int64_t stride, int C, int64_t J, hipStream_t stream);
+// the same contract on the register-resident-basis kernel; only called when d.r_ok and fused_r_applicable(d)
+bool fused_r_applicable(const FusedDesc &d);
+hipError_t launch_fused_r(const FusedDesc &d, const float *samples, int64_t stride, int C, int64_t S, int64_t J,
+                          int64_t E, float *outputs, uint8_t *flags, hipStream_t stream);
 // taps the register-resident first-layer fragments are instantiated for (0: timeRange too long)
 int fused_taps_max(int T);
 

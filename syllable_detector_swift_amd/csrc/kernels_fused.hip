@@ -34,82 +34,20 @@
 //
 // gfx950 only.  wave = 64.
 
-#include "kernels.hpp"
+#include <cstdlib>
+
+#include "fused_common.hpp"
 
 namespace sd {
 
 namespace {
 
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef float floatx4 __attribute__((ext_vector_type(4)));
-typedef unsigned int uint32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned int uint32x4 __attribute__((ext_vector_type(4)));
+using namespace fused_dev;
 
 constexpr int kBlock = kFusedBlock;            // 512 threads = 8 waves
 constexpr int kWaves = kBlock / 64;
 constexpr int kPass = kFusedTileFrames;        // 128 frames per pass = 16 per wave
 constexpr int kColStride = kFusedColStride;
-// layout of the constant block in LDS (floats)
-constexpr int kCstThr = 0 /* 16 doubles */, kCstOut = 32;
-
-__device__ __forceinline__ half8 as_half8(uint32x4 v)
-{
-    union { uint32x4 u; half8 h; } c;
-    c.u = v;
-    return c.h;
-}
-__device__ __forceinline__ floatx4 as_floatx4(uint32x4 v)
-{
-    union { uint32x4 u; floatx4 f; } c;
-    c.u = v;
-    return c.f;
-}
-
-__device__ __forceinline__ float pow2f(int e)   // 2^e for e in [-126, 127]
-{
-    return __uint_as_float((unsigned)(e + 127) << 23);
-}
-
-// max(m, |x|, |y|) in one instruction (fmaxf's NaN canonicalisation costs an extra op per value)
-__device__ __forceinline__ float absmax3(float m, float x, float y)
-{
-    float r;
-    asm("v_max3_f32 %0, |%1|, |%2|, %3" : "=v"(r) : "v"(x), "v"(y), "v"(m));
-    return r;
-}
-
-// Transfer functions (NeuralNet.swift:185-228).  tanh/logistic through the hardware exp2/rcp, written so
-// that NaN and the infinities fall out of the arithmetic itself (no selects, no branches: silence gives 0/0 in
-// l2normalize and the reference then never detects): absolute error below 4e-7, far inside the 1e-5 bar.
-__device__ __forceinline__ float transfer_fn(int tf, float x)
-{
-    if (tf == 0)                                     // TanSig: 1 - 2 / (e^{2x} + 1); e^{2x} = inf gives 1, 0 gives -1
-        return fmaf(-2.0f, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(x * 2.885390081777927f) + 1.0f), 1.0f);
-    if (tf == 1)                                     // LogSig: 1 / (1 + e^{-x})
-        return __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(x * -1.4426950408889634f) + 1.0f);
-    if (tf == 3) return x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x);   // SatLin (NaN falls through both tests)
-    return x;                                        // PureLin
-}
-
-// The buffer descriptor of one pass's samples ends one past the last sample any existing frame
-// reads, so quads beyond it come back as zeros from the hardware bounds check: no per-lane guards.
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const float *row, int64_t first, int64_t s_eff, int nsmp)
-{
-    int64_t left = s_eff - first;
-    left = left < 0 ? 0 : (left > nsmp ? nsmp : left);
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(row + first), 0, (int)left * 4, 0x00020000);
-}
-
-// 8 consecutive halves from an 8-byte aligned LDS address (two ds_read_b64)
-[[maybe_unused]] __device__ __forceinline__ half8 lds_half8(const _Float16 *p)
-{
-    const uint32x2 lo = *reinterpret_cast<const uint32x2 *>(p), hi = *reinterpret_cast<const uint32x2 *>(p + 4);
-    uint32x4 u = {lo[0], lo[1], hi[0], hi[1]};
-    return as_half8(u);
-}
-
-// LDS byte address of a pointer into shared memory (the low half of its flat address)
-[[maybe_unused]] __device__ __forceinline__ unsigned lds_addr(const void *p) { return (unsigned)(uintptr_t)p; }
 
 // Diagnostic variant (-DSYLDET_ASM_PREFETCH; not the shipped build -- measured 4 % slower):
 // the fragment fetches of one k-step as volatile instructions, issued where they are written (a whole k-step ahead
@@ -127,54 +65,6 @@ template <int KSN>
 {
     asm volatile("s_waitcnt lgkmcnt(0)"
                  : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(bh), "+v"(bl));
-}
-
-__device__ __forceinline__ floatx4 mfma(half8 a, half8 b, floatx4 c)
-{
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
-}
-
-// x*sx -> f16 hi (round to nearest) and f16 lo = the exact remainder x*sx - hi rounded to f16, for two
-// values at once (packed words): hi + lo == x*sx to 2^-22 relative.  v_fma_mix computes in fp32 from
-// mixed-width sources and writes one half of the destination, so a pair costs 4 VALU instructions
-// and the scaling rides along for free.
-__device__ __forceinline__ void split_pair_scaled(float a, float b, float sx, unsigned &hi, unsigned &lo)
-{
-    unsigned h, l;
-    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(a), "v"(sx));
-    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(b), "v"(sx));
-    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(a), "v"(sx), "v"(h));
-    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(b), "v"(sx), "v"(h));
-    hi = h;
-    lo = l;
-}
-
-// Cross-lane helpers without LDS round trips (a ds_bpermute costs an LDS latency on the critical path each):
-// gfx950's v_permlane16_swap / v_permlane32_swap exchange 16-lane rows / 32-lane halves between two registers.
-// With both operands = x the two results are x and its xor-16 (xor-32) partner, in some order per lane.
-__device__ __forceinline__ float xor16_sum(float x)
-{
-    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-__device__ __forceinline__ float xor32_sum(float x)
-{
-    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-// maximum over the wave of a non-negative float (compared as bit patterns), wave-uniform result
-__device__ __forceinline__ float wave_max_nonneg(float x)
-{
-    unsigned u = __float_as_uint(x);
-    u = max(u, (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0xB1, 0xF, 0xF, false));    // quad_perm [1,0,3,2]
-    u = max(u, (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0x4E, 0xF, 0xF, false));    // quad_perm [2,3,0,1]
-    u = max(u, (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0x141, 0xF, 0xF, false));   // row_half_mirror
-    u = max(u, (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0x140, 0xF, 0xF, false));   // row_mirror
-    auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-    u = max(r[0], r[1]);
-    r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    u = max(r[0], r[1]);
-    return __uint_as_float(__builtin_amdgcn_readfirstlane(u));
 }
 
 // Diagnostic stamps (STAMP instantiation only; never the shipped path): s_memtime at phase boundaries,
@@ -349,154 +239,7 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
     if (STAMP) tick[5] = __builtin_amdgcn_s_memtime();
     __syncthreads();
 
-    // ---- evaluation of one pass in eight steps, so that it can ride along with the NEXT pass's matrix work:
-    // the first layer as a shifted GEMM over the column buffer (steps 0-2), the rest of the network in registers
-    // (3-5), stores (6).  This wave finishes evaluation slots 16*wave .. +15 of the pass (slot q: e = e_b + 128 pp -
-    // (T-1) + q, columns q .. q+T-1): result column = f, rows 4*g4 + j = hidden unit.
-    floatx4 z = {0.0f, 0.0f, 0.0f, 0.0f}, z2 = {0.0f, 0.0f, 0.0f, 0.0f};
-    float ssw = 1.0f;                                         // l2normalize: the window's sum of squares
-    float alpha = 0.0f, beta = 0.0f, act[4] = {0.0f, 0.0f, 0.0f, 0.0f}, yv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    bool hit = false;
-    constexpr int kAhead = 3;                                 // column fragments are fetched this many taps ahead
-    uint32x4 bh_q[kAhead], bl_q[kAhead];
-    // Evaluation slot q < T-1 straddles two passes: its window is the transition strip [T-1 carried columns | copies of
-    // this pass's first T-1 columns], kept at a scale both passes fit in; every other window reads the pass's own
-    // columns at the pass's own scale.  Either way the window is T consecutive slots starting at `wslot`.
-    const int wslot = fl < T - 1 ? fl : XS + fl - (T - 1);
-    const _Float16 *bph = colh + wslot * kColStride + 8 * g4, *bpl = coll + wslot * kColStride + 8 * g4;
-    auto gemm0_taps = [&](int t0, int t1) {
-#pragma unroll
-        for (int t = 0; t < TMAX; t++) {
-            if (t >= t0 && t < t1 && t < T && !(kom & 16)) {
-                const half8 h0 = as_half8(bh_q[t % kAhead]), l0 = as_half8(bl_q[t % kAhead]);
-                if (t + kAhead < T) {
-                    bh_q[t % kAhead] = *reinterpret_cast<const uint32x4 *>(bph + (t + kAhead) * kColStride);
-                    bl_q[t % kAhead] = *reinterpret_cast<const uint32x4 *>(bpl + (t + kAhead) * kColStride);
-                }
-                z = mfma(afr[t][0], h0, z);                   // two accumulation chains: hi*hi on one,
-                z2 = mfma(afr[t][0], l0, z2);                 // the cross terms on the other
-                z2 = mfma(afr[t][1], h0, z2);
-            }
-        }
-    };
-    auto post_step = [&](int step, int pp, int cse_own, int cse_x) {
-        const int cse_pp = fl < T - 1 ? cse_x : cse_own;      // column scale of this lane's window
-        const int n0 = (T + 2) / 3, n1 = n0 + (T - n0 + 1) / 2;   // taps [0,n0), [n0,n1), [n1,T)
-        if (step == 0) {
-            z = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
-            z2 = z;
-#pragma unroll
-            for (int t = 0; t < kAhead; t++)
-                if (t < T && !(kom & 16)) {
-                    bh_q[t] = *reinterpret_cast<const uint32x4 *>(bph + t * kColStride);
-                    bl_q[t] = *reinterpret_cast<const uint32x4 *>(bpl + t * kColStride);
-                }
-            gemm0_taps(0, n0);
-        } else if (step == 1) {
-            gemm0_taps(n0, n1);
-        } else if (step == 2) {
-            gemm0_taps(n1, T);
-            z += z2;
-            if (norm == 1) {                                  // sum of squares of the window = of its T frames (fp32, LDS)
-                float acc_ss = 0.0f;
-#pragma unroll
-                for (int t = 0; t < TMAX; t++)
-                    if (t < T) acc_ss += stat[wslot + t];
-                ssw = acc_ss;
-            }
-        } else if (step == 3) {
-            const float cs = scaling != 0 ? 1.0f : pow2f(cse_pp - d.col_shift);
-            const float zs = d.w_unscale / cs;                // first-layer sums back to true units
-            alpha = zs; beta = 0.0f;                          // layer-0 input = alpha * z + beta * rvec + bias0
-            if (norm == 1) {                                  // L2Normalize, NeuralNet.swift:47-59
-                // z and the per-frame sums of squares are both in column units: layer-0 input = W0 . v / |v|
-                alpha = d.w_unscale * __builtin_amdgcn_rsqf(ssw);
-            } else if (norm == 2) {                           // Normalize, :69-96
-                float mn = INFINITY, mx = -INFINITY;
-                for (int t = 0; t < T; t++) { mn = fminf(mn, stat[wslot + t]); mx = fmaxf(mx, stat[PS + wslot + t]); }
-                const float range = mx - mn;
-                if (range == 0.0f) { alpha = 0.0f; beta = -1.0f; }
-                else { alpha = zs * 2.0f / range; beta = (0.0f - mn - mx) / range; }
-            } else if (norm == 3) {                           // NormalizeStd, :105-108 (population sigma)
-                float nn = 0.0f, mean = 0.0f, m2 = 0.0f;
-                for (int t = 0; t < T; t++) {                 // pairwise-stable combination of per-frame (mean, M2)
-                    const float nb = (float)d.F, tot = nn + nb, dlt = stat[wslot + t] - mean;
-                    mean += dlt * nb / tot;
-                    m2 += stat[PS + wslot + t] + dlt * dlt * nn * nb / tot;
-                    nn = tot;
-                }
-                const float sd = sqrtf(m2 / (float)d.I);
-                alpha = zs / sd;
-                beta = -mean / sd;
-            }
-        } else if (step == 4) {                               // rows past H (padding, statistic) contribute nothing
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-                act[j] = (LEAN || (4 * g4 + j) < H) ? transfer_fn(tf0, fmaf(alpha, z[j], fmaf(beta, c_rv[j], c_b0[j]))) : 0.0f;   // LEAN: padding rows meet zero weights
-        } else if (step == 5) {
-            const double *thr = reinterpret_cast<const double *>(cst + kCstThr);
-            hit = false;
-            if (n_layers == 2) {
-#pragma unroll
-                for (int o = 0; o < 4; o++) {
-                    if (o < n_out) {
-                        float y = c_w1[o][0] * act[0];        // padding rows carry zero weights
-                        y = fmaf(c_w1[o][1], act[1], y);
-                        y = fmaf(c_w1[o][2], act[2], y);
-                        y = fmaf(c_w1[o][3], act[3], y);
-                        if (!LEAN && H > 4) {
-                            y += __shfl_xor(y, 16, 64);
-                            y += __shfl_xor(y, 32, 64);
-                        }
-                        y = transfer_fn(tf1, y + c_b1[o]);
-                        if (LEAN) y = (y - lean_oa) / lean_og + lean_ob;
-                        else
-                            for (int kf = 0; kf < d.n_out_fns; kf++) {    // reverse maps, NeuralNet.swift:137-142 / :175-180
-                                const float *op = cst + kCstOut + kf * (1 + 2 * n_out);
-                                y = (y - op[0]) / op[1 + o] + op[1 + n_out + o];
-                            }
-                        yv[o] = y;
-                        hit = hit | ((o == 0 || d.rule == 1) & ((double)y >= thr[o]));
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const int h = 4 * g4 + j;
-                    float y = act[j];
-                    for (int kf = 0; kf < d.n_out_fns; kf++) {
-                        const float *op = cst + kCstOut + kf * (1 + 2 * n_out);
-                        y = (y - op[0]) / op[1 + (h < H ? h : 0)] + op[1 + n_out + (h < H ? h : 0)];
-                    }
-                    yv[j] = y;
-                    if (h < H && (h == 0 || d.rule == 1)) hit = hit || ((double)y >= thr[h]);
-                }
-                int anyhit = hit ? 1 : 0;
-                anyhit |= __shfl_xor(anyhit, 16, 64);
-                anyhit |= __shfl_xor(anyhit, 32, 64);
-                hit = anyhit != 0;
-            }
-        } else if (step == 6) {
-            const int64_t e = e_b + (int64_t)kPass * pp - (T - 1) + fl;
-            const bool valid = e >= e_b && e < e_e && pp >= 0 && !(kom & 8);
-            const unsigned off = (unsigned)e;                 // E * n_out * 4 < 2^32 is checked by the launcher
-            if (n_layers == 2) {
-                const bool st = valid && g4 == 0;
-#pragma unroll
-                for (int o = 0; o < 4; o++)
-                    if (o < n_out)
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(yv[o]), out_rs, st ? (off * n_out + o) * 4u : 0xFFFFFFFFu, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(hit ? 1 : 0), flg_rs, st ? off : 0xFFFFFFFFu, 0, 0);
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; j++)
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(yv[j]), out_rs,
-                                                          (valid && (4 * g4 + j) < H) ? (off * n_out + 4 * g4 + j) * 4u : 0xFFFFFFFFu, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(hit ? 1 : 0), flg_rs, (valid && g4 == 0) ? off : 0xFFFFFFFFu, 0, 0);
-            }
-        }
-    };
-
+#include "fused_eval.inc"
     int cse_post = 0, csx_post = 0;                           // column scales (own, transition strip) of the pass being evaluated
     for (int p = 0; p < runs; p++) {
         // ================= block M: DFT of pass p  ||  evaluation of pass p-1  ||  block max of pass p+1
@@ -581,48 +324,7 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
         const int csx = scaling != 0 ? 0 : ((p > 0 && se_prev < se) ? se_prev : se);
         cse_post = cse;
         csx_post = csx;
-        // ---- the previous pass's last T-1 columns -> the front of the transition strip (rescaled from their own scale);
-        // done by the wave that overwrites their slots right after, so program order keeps the two apart
-        if (!SPECT && p > 0 && wave == kWaves - 1 && !(kom & 32)) {
-            const int dexp = scaling != 0 ? 0 : csx - se_prev;     // <= 0
-            const int words = (T - 1) * (kColStride / 2);      // 32-bit words per array
-            const int src = (XS + kPass - (T - 1)) * (kColStride / 2);
-            // all reads first, then all writes: one LDS round trip instead of one per 64 words (this wave is the
-            // last one through the phase, so its latency is the workgroup's)
-            constexpr int kIt = (2 * (TMAX - 1) * (kColStride / 2) + 63) / 64;
-            unsigned u[kIt];
-#pragma unroll
-            for (int k = 0; k < kIt; k++) {
-                const int i = lane + 64 * k;
-                const bool hi_arr = i < words;
-                const int w = hi_arr ? i : i - words;
-                u[k] = i < 2 * words ? reinterpret_cast<const unsigned *>(hi_arr ? colh : coll)[src + w] : 0u;
-            }
-#pragma unroll
-            for (int k = 0; k < kIt; k++) {
-                const int i = lane + 64 * k;
-                const bool hi_arr = i < words;
-                const int w = hi_arr ? i : i - words;
-                unsigned uu = u[k];
-                if (dexp != 0) {
-                    union { unsigned u; _Float16 h[2]; } x;
-                    x.u = uu;
-                    const float f0 = (float)x.h[0] * pow2f(dexp);
-                    const float f1 = (float)x.h[1] * pow2f(dexp);
-                    union { decltype(__builtin_amdgcn_cvt_pkrtz(0.f, 0.f)) h; unsigned u; } y;
-                    y.h = __builtin_amdgcn_cvt_pkrtz(f0, f1);
-                    uu = y.u;
-                }
-                if (i < 2 * words) reinterpret_cast<unsigned *>(hi_arr ? colh : coll)[w] = uu;
-            }
-            const int ssrc = XS + kPass - (T - 1);
-            if (norm == 1 && lane < T - 1) stat[lane] = stat[ssrc + lane] * pow2f(2 * dexp);   // sums of squares of scaled columns
-            if (norm >= 2 && lane < T - 1) {
-                stat[lane] = stat[ssrc + lane];
-                stat[PS + lane] = stat[PS + ssrc + lane];
-            }
-        }
-
+#include "fused_strip.inc"
         // ---- magnitude (zvabs/2 :329-333), scaling (SyllableDetector.swift:184-212),
         // statistic, f16 split, column -> LDS.  Result layout: column = frame f, register j of lane group g4 in
         // tile m = basis row 16m + 4*g4 + j; this lane holds bins 4*g4 + j (i = j) and 16 + 4*g4 + j (i = 4 + j).
@@ -640,104 +342,7 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
                                                       (live && bin < d.F) ? ((unsigned)jf * (unsigned)d.F + bin) * 4u : 0xFFFFFFFFu, 0, 0);
             }
         } else if (!(kom & 64)) {
-            // accumulators hold X * sx * 2^13.  Column scale (power of two; col_shift from the basis' largest row sum):
-            // |X| * 2^(cse - shift) < 2^13; log/dB columns are stored unscaled.  For linear columns the two scales are applied together after the square root.
-            const float inv = pow2f(-se - 13);
-            const float cs = scaling != 0 ? 1.0f : pow2f(cse - d.col_shift);
-            const int fh = d.F - 4 * g4;                          // cval[i] is a band bin iff (i&3) + 16(i>>2) < fh
-            const bool plain = scaling == 0 && norm <= 1;         // linear |X| columns, no per-frame statistic on raw values
-            float cval[8];
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                if (plain) {
-                    const float re = acc[i >> 2][i & 3], im = acc[2 + (i >> 2)][i & 3];
-                    cval[i] = __builtin_amdgcn_sqrtf(fmaf(re, re, im * im)) * (inv * cs);   // |acc| < 2^40: no overflow
-                } else {
-                    const float re = acc[i >> 2][i & 3] * inv, im = acc[2 + (i >> 2)][i & 3] * inv;
-                    const float pw = fmaf(re, re, im * im);
-                    cval[i] = __builtin_amdgcn_sqrtf(pw);
-                }
-            }
-            if (scaling != 0) {
-                const float kk = scaling == 1 ? 0.6931471805599453f : 6.020599913279624f;   // ln 2, 20 log10 2
-#pragma unroll
-                for (int i = 0; i < 8; i++) cval[i] = kk * __builtin_amdgcn_logf(cval[i]);  // v_log_f32 = log2
-#pragma unroll
-                for (int i = 0; i < 8; i++) cval[i] = ((i & 3) + 16 * (i >> 2)) < fh ? cval[i] : 0.0f;   // log(0) rows
-            }                                                     // (linear: basis rows past F are zero, so are their |X|)
-            const int slot = XS + fl;                             // own column; frames fl < T-1 also feed the transition strip
-            const int xslot = (T - 1) + fl;
-            if (norm == 2) {
-                float st0 = INFINITY, st1 = -INFINITY;
-#pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    const bool valid = ((i & 3) + 16 * (i >> 2)) < fh;
-                    st0 = valid ? fminf(st0, cval[i]) : st0;
-                    st1 = valid ? fmaxf(st1, cval[i]) : st1;
-                }
-                st0 = fminf(st0, __shfl_xor(st0, 16, 64)); st0 = fminf(st0, __shfl_xor(st0, 32, 64));
-                st1 = fmaxf(st1, __shfl_xor(st1, 16, 64)); st1 = fmaxf(st1, __shfl_xor(st1, 32, 64));
-                if (g4 == 0) {
-                    stat[slot] = st0; stat[PS + slot] = st1;
-                    if (fl < T - 1) { stat[xslot] = st0; stat[PS + xslot] = st1; }
-                }
-            } else if (norm == 3) {
-                float st0 = 0.0f, st1 = 0.0f;
-#pragma unroll
-                for (int i = 0; i < 8; i++) st0 += cval[i];
-                st0 += __shfl_xor(st0, 16, 64); st0 += __shfl_xor(st0, 32, 64);
-                st0 = st0 / (float)d.F;                           // mean of this frame's column
-#pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    const float dlt = cval[i] - st0;
-                    st1 = ((i & 3) + 16 * (i >> 2)) < fh ? fmaf(dlt, dlt, st1) : st1;   // M2 of this frame's column
-                }
-                st1 += __shfl_xor(st1, 16, 64); st1 += __shfl_xor(st1, 32, 64);
-                if (g4 == 0) {
-                    stat[slot] = st0; stat[PS + slot] = st1;
-                    if (fl < T - 1) { stat[xslot] = st0; stat[PS + xslot] = st1; }
-                }
-            }
-            if (!plain) {
-#pragma unroll
-                for (int i = 0; i < 8; i++) cval[i] *= cs;
-            }
-            if (norm == 1) {
-                // sum of squares of the (scaled) column, fp32, one value per frame next to the columns
-                float ss = 0.0f;
-#pragma unroll
-                for (int i = 0; i < 8; i++) ss = fmaf(cval[i], cval[i], ss);
-                ss = xor32_sum(xor16_sum(ss));
-                if (g4 == 0) {
-                    stat[slot] = ss;
-                    if (fl < T - 1) stat[xslot] = ss * pow2f(2 * (csx - cse));
-                }
-            }
-            {
-                _Float16 *ph = colh + slot * kColStride + 4 * g4, *pl = coll + slot * kColStride + 4 * g4;
-#pragma unroll
-                for (int m = 0; m < 2; m++) {                     // bins 16m + 4*g4 .. +3: four consecutive halves
-                    unsigned h0, l0, h1, l1;
-                    split_pair_scaled(cval[4 * m], cval[4 * m + 1], 1.0f, h0, l0);
-                    split_pair_scaled(cval[4 * m + 2], cval[4 * m + 3], 1.0f, h1, l1);
-                    uint32x2 uh = {h0, h1}, ul = {l0, l1};
-                    *reinterpret_cast<uint32x2 *>(ph + 16 * m) = uh;
-                    *reinterpret_cast<uint32x2 *>(pl + 16 * m) = ul;
-                }
-            }
-            if (wave == 0 && fl < T - 1) {                        // copies for the transition strip, at its scale
-                const float xs = pow2f(csx - cse);                // <= 1: a much quieter pass may underflow here, next to
-                _Float16 *ph = colh + xslot * kColStride + 4 * g4, *pl = coll + xslot * kColStride + 4 * g4;   // columns 2^|.| louder
-#pragma unroll
-                for (int m = 0; m < 2; m++) {
-                    unsigned h0, l0, h1, l1;
-                    split_pair_scaled(cval[4 * m], cval[4 * m + 1], xs, h0, l0);
-                    split_pair_scaled(cval[4 * m + 2], cval[4 * m + 3], xs, h1, l1);
-                    uint32x2 uh = {h0, h1}, ul = {l0, l1};
-                    *reinterpret_cast<uint32x2 *>(ph + 16 * m) = uh;
-                    *reinterpret_cast<uint32x2 *>(pl + 16 * m) = ul;
-                }
-            }
+#include "fused_mag.inc"
         } else if (acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] == 12345.0f) colh[lane] = (_Float16)1.0f;
         SD_TICK(2)
 
@@ -788,8 +393,10 @@ int fused_taps_max(int T) { return T <= 12 ? 12 : 0; }
 hipError_t launch_fused(const FusedDesc &d, const float *samples, int64_t stride, int C, int64_t S, int64_t J,
                         int64_t E, float *outputs, uint8_t *flags, hipStream_t stream)
 {
-    (void)S;
     if (E <= 0 || C <= 0) return hipSuccess;
+    // the register-resident-basis kernel where it is instantiated (SYLDET_FUSED_CLASSIC=1 keeps this file's kernel: A/B runs)
+    static const bool classic = std::getenv("SYLDET_FUSED_CLASSIC") != nullptr;
+    if (!classic && !d.ko && fused_r_applicable(d)) return launch_fused_r(d, samples, stride, C, S, J, E, outputs, flags, stream);
     // one past the last sample an existing frame reads: frame J-1 covers [(J-1)*hop + gap, ... + W)
     const int64_t s_eff = (J - 1) * (int64_t)d.hop + d.gap + d.W;
     const bool skew = d.skew != 0;

@@ -457,7 +457,9 @@ int run_on_stream(syldet *h, const float *d_samples, int64_t S, int64_t stride, 
         // workgroup pass spends its cycles (never set in tests or the benchmark)
         static const bool want_stamps = std::getenv("SYLDET_FUSED_STAMPS") != nullptr;
         if (want_stamps) {
-            const size_t n = (size_t)((E + d.seg_evals - 1) / d.seg_evals) * (size_t)C * 16;
+            const bool rk = fused_r_applicable(d) && !std::getenv("SYLDET_FUSED_CLASSIC");   // which kernel the launcher picks
+            const int64_t seg = rk ? d.r_seg_evals : d.seg_evals;
+            const size_t n = (size_t)((E + seg - 1) / seg) * (size_t)C * 16;
             if (int st = h->d_stamps.reserve(n * sizeof(unsigned long long))) return st;
             SYLDET_HIP(hipMemsetAsync(h->d_stamps.ptr, 0, n * sizeof(unsigned long long), stream));
             d.stamps = (unsigned long long *)h->d_stamps.ptr;
@@ -472,9 +474,15 @@ int run_on_stream(syldet *h, const float *d_samples, int64_t S, int64_t stride, 
             for (size_t i = 0; i < n; i++) sum[i % 16] += (double)host[i];
             double tot = 0;
             for (int i = 0; i < 8; i++) tot += sum[i];            // wave 0's phases add up to the pass; wave 7's are a second view
-            static const char *names[16] = {"DFT(p) || evaluate(p-1) || block max(p+1)", "barrier 1", "carry + mag + columns", "stage next pass + issue loads",
+            const char *names[16] = {"DFT(p) || evaluate(p-1) || block max(p+1)", "barrier 1", "carry + mag + columns", "stage next pass + issue loads",
                                             "barrier 0", "-", "-", "-", "wave 7: DFT || evaluate || block max", "wave 7: barrier 1", "wave 7: carry + mag + columns",
                                             "wave 7: stage + issue loads", "wave 7: barrier 0", "-", "-", "-"};
+            if (rk) {
+                names[0] = "block M: DFT || evaluate || stage || reload"; names[1] = "barrier A"; names[2] = "strip + magnitudes + columns";
+                names[3] = "block max (waits for the loads)"; names[4] = "barrier B";
+                for (int i = 0; i < 5; i++) names[8 + i] = names[i];
+                d.runs = d.r_runs;
+            }
             std::fprintf(stderr, "[syldet stamps] runs=%d workgroups=%zu cycles/pass=%.0f\n", d.runs, n / 16, tot / ((double)(n / 16) * d.runs));
             for (int i = 0; i < 16; i++)
                 if (sum[i] > 0) std::fprintf(stderr, "   %-32s %6.0f cycles/pass  %5.1f %%\n", names[i], sum[i] / ((double)(n / 16) * d.runs), 100.0 * sum[i] / tot);
