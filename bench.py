@@ -60,14 +60,15 @@ def cpu_baseline(cfg, samples_host, budget_s=10.0, threads=1):
                       % (threads, S, reps, dt)}
 
 
-def measured_traffic(C, S, hop, engine):
+def measured_traffic(C, S, hop, engine, kernel=None):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r01_traffic.json:
     FETCH_SIZE and WRITE_SIZE collected separately, gfx950 FETCH_SIZE x2 correction), if they were taken on
     exactly this workload; else None."""
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
         w = t["workload"]
-        if (w["channels_per_gpu"], w["samples_per_channel"], w["hop"], w["engine"]) == (C, S, hop, engine):
+        if (w["channels_per_gpu"], w["samples_per_channel"], w["hop"], w["engine"]) == (C, S, hop, engine) and \
+                (kernel is None or t.get("kernel", kernel) == kernel):
             return t["hbm_bytes_per_launch"]
     except Exception:
         pass
@@ -182,7 +183,7 @@ def main():
                        "sharding": "channels, %d per GPU; one all-gather of flags per step" % C if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic(C, S, g.hop, {1: "generic", 2: "fused"}.get(g.engine, "")),
+                         "traffic": measured_traffic(C, S, g.hop, {1: "generic", 2: "fused"}.get(g.engine, ""), dom),
                          "algorithmic_bytes_per_launch": C * J * b_frame,
                          "algorithmic_bytes_per_frame": b_frame, "kernel_ms": means},
         }

@@ -160,9 +160,9 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
         auto rtake = [&roff](int bytes) { const int o = roff; roff += (bytes + 15) / 16 * 16; return o; };
         d.r_nsmp = rn; d.r_nload = rl; d.r_ps = rps; d.r_smp_stride = rn_p;
         d.r_lds_smp = rtake(2 * 2 * rn_p * 2);           // two buffers of f16 hi + lo
-        d.r_lds_colh = rtake(rps * kFusedColStride * 2);
-        d.r_lds_coll = rtake(rps * kFusedColStride * 2);
-        d.r_lds_stat = rtake(2 * rps * 4);
+        d.r_lds_colh = rtake(2 * (rps + 1) * kFusedColStride * 2);   // two column buffers (pass parity), one spare slot each
+        d.r_lds_coll = rtake(2 * (rps + 1) * kFusedColStride * 2);
+        d.r_lds_stat = rtake(2 * (rps + 2) * 4);
         d.r_lds_red = rtake(64);
         d.r_lds_cst = rtake((32 + kMaxFns * 33) * 4);
         d.r_lds_total = roff;

@@ -38,11 +38,12 @@ constexpr int kWaves = kBlock / 64;
 constexpr int kPass = kFusedRTileFrames;       // 64 frames per pass = 16 per wave
 constexpr int kColStride = kFusedColStride;
 
-// KS: k-steps of 32 samples (the basis takes 32 KS registers); TMAX: taps the first-layer fragment array is sized
-// for; NL: staging quads per thread (all NL are always loaded and staged: quads past the pass come back as zeros
-// from the descriptor's bounds check and land in LDS words no frame reads); EXACT: timeRange == TMAX; SKEW: staged
-// samples carry bank-spreading padding; LEAN: the reference's example configuration class as a compile-time fact.
-template <int KS, int TMAX, int NL, bool EXACT, bool SKEW, bool LEAN, bool STAMP>
+// KS: k-steps of 32 samples (the basis takes 32 KS registers); T: timeRange; NL: staging quads per thread (all NL are
+// always loaded and staged: quads past the pass come back as zeros from the descriptor's bounds check and land in LDS
+// words no frame reads); SKEW: staged samples carry bank-spreading padding; STAMP: diagnostic phase timing.
+// The network class is the reference's example detector's (kernels_fused.hip's LEAN): l2normalize first, linear |X|
+// columns, two layers, TanSig hidden units (at most 4), one output, at most one output map.
+template <int KS, int T, int NL, bool SKEW, bool STAMP>
 __global__ void __launch_bounds__(kBlock, 1)
 fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t stride, int64_t s_eff, int64_t E,
                float *__restrict__ outputs, uint8_t *__restrict__ flags)
@@ -50,8 +51,8 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *red = reinterpret_cast<float *>(smem + d.r_lds_red);      // [4 waves] block-max partials
     float *cst = reinterpret_cast<float *>(smem + d.r_lds_cst);
-    constexpr int kom = 0;                // the shared blocks' diagnostic switches: none here
-    constexpr bool SPECT = false;
+    constexpr int kom = 0, TMAX = T;      // the shared evaluation block's switches
+    constexpr bool SPECT = false, LEAN = true;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -63,34 +64,34 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
     if (e_b >= E) return;
     const int64_t e_e = (e_b + d.r_seg_evals < E) ? e_b + d.r_seg_evals : E;
     const float *row = samples + (int64_t)c * stride;
-    const int PS = d.r_ps, T = EXACT ? TMAX : d.T, H = d.H;    // PS: column slots = 2 (T - 1) transition slots + 64
-    const int XS = 2 * (T - 1);                                 // the pass's own columns start at slot XS
-    const int norm = LEAN ? 1 : d.norm, scaling = LEAN ? 0 : d.scaling;
-    const int n_layers = LEAN ? 2 : d.n_layers, n_out = LEAN ? 1 : d.n_out, tf0 = LEAN ? 0 : d.tf0, tf1 = LEAN ? 2 : d.tf1;
+    const int PS = d.r_ps, H = d.H;                             // PS: column slots = 2 (T - 1) transition slots + 64
+    constexpr int XS = 2 * (T - 1);                             // the pass's own columns start at slot XS
+    constexpr int norm = 1, scaling = 0, n_layers = 2, n_out = 1, tf0 = 0, tf1 = 2;
     const int fl = 16 * wave + f;     // this lane's frame / evaluation slot inside the pass
     const int runs = d.r_runs;
 
     // staged samples: [buffer 0 hi | buffer 0 lo | buffer 1 hi | buffer 1 lo], r_smp_stride halves each
     _Float16 *smp0 = reinterpret_cast<_Float16 *>(smem + d.r_lds_smp);
     const int buf_halves = 2 * d.r_smp_stride;
-    _Float16 *colh = reinterpret_cast<_Float16 *>(smem + d.r_lds_colh);   // [PS][kColStride] |X| columns, hi parts
-    _Float16 *coll = reinterpret_cast<_Float16 *>(smem + d.r_lds_coll);   //                               lo parts
-    float *stat = reinterpret_cast<float *>(smem + d.r_lds_stat);          // [2][PS] per-frame statistics
+    // |X| columns, two buffers (pass parity) of [PS + 1][kColStride] f16 hi and lo (slot PS: where lanes with nothing
+    // to write write), per-frame sums of squares next to them
+    _Float16 *colh = reinterpret_cast<_Float16 *>(smem + d.r_lds_colh);
+    _Float16 *coll = reinterpret_cast<_Float16 *>(smem + d.r_lds_coll);
+    float *stat = reinterpret_cast<float *>(smem + d.r_lds_stat);
+    const int col_halves = (PS + 1) * kColStride, stat_floats = PS + 2;
 
     // ---- once per workgroup: constants
     if (tid < 16) reinterpret_cast<double *>(cst + kCstThr)[tid] = tid < n_out ? d.thresholds[tid] : 0.0;
-    for (int i = tid; i < d.n_out_fns * (1 + 2 * n_out); i += kBlock) cst[kCstOut + i] = d.out_params[i];
     // the DFT basis: A-operand fragments [k-step][re 0-15, re 16-31, im 0-15, im 16-31][hi, lo], one quad per lane each
     uint32x4 a[KS * 8];
 #pragma unroll
     for (int i = 0; i < KS * 8; i++) a[i] = reinterpret_cast<const uint32x4 *>(d.dfrag)[i * 64 + lane];
     // first-layer fragments, one (hi, lo) pair per tap
-    half8 afr[TMAX][2];
+    half8 afr[T][2];
 #pragma unroll
-    for (int t = 0; t < TMAX; t++)
+    for (int t = 0; t < T; t++)
 #pragma unroll
-        for (int p = 0; p < 2; p++)
-            afr[t][p] = as_half8(reinterpret_cast<const uint32x4 *>(d.afrag)[((t < T ? t : 0) * 2 + p) * 64 + lane]);
+        for (int p = 0; p < 2; p++) afr[t][p] = as_half8(reinterpret_cast<const uint32x4 *>(d.afrag)[(t * 2 + p) * 64 + lane]);
     float c_b0[4], c_rv[4], c_w1[4][4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -98,17 +99,17 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
         c_b0[j] = h < H ? d.bias0[h] : 0.0f;
         c_rv[j] = h < H ? d.rvec[h] : 0.0f;
 #pragma unroll
-        for (int o = 0; o < 4; o++) c_w1[o][j] = (n_layers == 2 && h < H && o < n_out) ? d.w1[o * H + h] : 0.0f;
+        for (int o = 0; o < 4; o++) c_w1[o][j] = (h < H && o < n_out) ? d.w1[o * H + h] : 0.0f;
     }
     float c_b1[4];
 #pragma unroll
-    for (int o = 0; o < 4; o++) c_b1[o] = (n_layers == 2 && o < n_out) ? d.b1[o] : 0.0f;
+    for (int o = 0; o < 4; o++) c_b1[o] = o < n_out ? d.b1[o] : 0.0f;
 
     const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(
         outputs ? outputs + (int64_t)c * E * n_out : nullptr, 0, outputs ? (int)(E * n_out * 4) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t flg_rs = __builtin_amdgcn_make_buffer_rsrc(flags ? flags + (int64_t)c * E : nullptr, 0, flags ? (int)E : 0, 0x00020000);
     float lean_oa = 0.0f, lean_og = 1.0f, lean_ob = 0.0f;
-    if (LEAN && d.n_out_fns == 1) { lean_oa = d.out_params[0]; lean_og = d.out_params[1]; lean_ob = d.out_params[2]; }
+    if (d.n_out_fns == 1) { lean_oa = d.out_params[0]; lean_og = d.out_params[1]; lean_ob = d.out_params[2]; }
 
     // this lane's frame in a staged buffer, and where k-step ks of lane group g4 starts inside it (see kernels_fused.hip)
     const int foff = fl * (d.hop + (SKEW ? d.skew : 0)) + (SKEW ? 0 : 8 * KS * g4);
@@ -145,29 +146,28 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
         const int i = 4 * (tid + kBlock * k);
         spos[k] = SKEW ? i + d.skew * (int)__umulhi((unsigned)i, d.hop_magic) : i;
     }
-    // quad k: scale, split into f16 hi + lo, -> staged buffer `wh` (lo array r_smp_stride halves further)
-    auto stage_quad = [&](int k, float sx, _Float16 *wh) {
-        const floatx4 q = as_floatx4(v[k]);
-        unsigned h0, l0, h1, l1;
-        split_pair_scaled(q[0], q[1], sx, h0, l0);
-        split_pair_scaled(q[2], q[3], sx, h1, l1);
-        uint32x2 uh = {h0, h1}, ul = {l0, l1};
-        _Float16 *ph = wh + (SKEW ? spos[k] : 4 * tid + 4 * kBlock * k);
-        *reinterpret_cast<uint32x2 *>(ph) = uh;
-        *reinterpret_cast<uint32x2 *>(ph + d.r_smp_stride) = ul;
-    };
 
     // ---- prologue: pass 0 staged, pass 1 in the staging registers with its block maximum published
-    int se, se_prev = 0;                  // sample scale exponents of the pass in the matrix block, and of the one before
+    int se_cur, se_m1 = 0, se_m2 = 0;     // sample scale exponents of the pass in the matrix block and of the two before it
     {
         const __amdgpu_buffer_rsrc_t rs = pass_rsrc(0);
 #pragma unroll
         for (int k = 0; k < NL; k++) v[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * tid + 16 * kBlock * k, 0, 0);
         max_partial();
         __syncthreads();
-        se = pass_scale();
+        se_cur = pass_scale();
+        const float sx = pow2f(se_cur);
 #pragma unroll
-        for (int k = 0; k < NL; k++) stage_quad(k, pow2f(se), smp0);
+        for (int k = 0; k < NL; k++) {
+            const floatx4 q = as_floatx4(v[k]);
+            unsigned h0, l0, h1, l1;
+            split_pair_scaled(q[0], q[1], sx, h0, l0);
+            split_pair_scaled(q[2], q[3], sx, h1, l1);
+            uint32x2 uh = {h0, h1}, ul = {l0, l1};
+            _Float16 *ph = smp0 + (SKEW ? spos[k] : 4 * tid + 4 * kBlock * k);
+            *reinterpret_cast<uint32x2 *>(ph) = uh;
+            *reinterpret_cast<uint32x2 *>(ph + d.r_smp_stride) = ul;
+        }
         const __amdgpu_buffer_rsrc_t rs1 = pass_rsrc(1);
 #pragma unroll
         for (int k = 0; k < NL; k++) v[k] = __builtin_amdgcn_raw_buffer_load_b128(rs1, 16 * tid + 16 * kBlock * k, 0, 0);
@@ -175,7 +175,6 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
         max_partial();
         __syncthreads();
     }
-    int cse = 0;
     // diagnostic instantiation only (SYLDET_FUSED_STAMPS=1): s_memtime at the phase boundaries of every pass
     unsigned long long tsum[8] = {0}, tick[8] = {0};
 #define SD_RTICK(slot)                                                                     \
@@ -188,109 +187,216 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
 
 #include "fused_eval.inc"
 
-    // The evaluation, re-cut for a lone wave: one slot between every two groups of four DFT MFMAs (3 per k-step).  A
-    // column fragment is fetched two slots before the MFMAs that use it, the window's statistics two slots before
-    // they are summed -- no LDS round trip is waited for in the slot that issues it.
-    // Its MFMAs are ordered assembly statements like the DFT's (three accumulation chains, so that consecutive uses of
-    // one accumulator are a slot apart), and the statistics pass through an empty ordered statement where they are
-    // consumed: otherwise the compiler moves the consumers up to the fetches and waits there.
+    // ---- The three stages in flight.  In the matrix block of pass q this wave also finishes pass q-1 (magnitudes of
+    // the accumulators it kept -> the column buffer of that parity, transition strip) and evaluates pass q-2 (from the
+    // other column buffer): everything that crosses waves crosses a pass boundary, so one barrier per pass is enough,
+    // and none of this work waits for the matrix pipe or has the matrix pipe wait for it.
+    //
+    // A lone wave issues in order: while it waits at an MFMA for the matrix pipe it issues nothing else, so vector work
+    // hides under the matrix work only if it sits BETWEEN the MFMAs in program order (about three vector instructions
+    // fit under each).  The block is therefore written as 12 KS "ticks", one per DFT MFMA, and every other piece of work
+    // is cut into micro-steps assigned to ticks.  MFMAs are ordered assembly statements (also because the basis, only
+    // ever an A operand, must live in the 256 accumulation registers, which the allocator will not do by itself); the
+    // compiler keeps memory instructions on their side of such a statement, and vector instructions are held in place
+    // by passing their inputs / results through empty ordered statements (pin).  Hazards the compiler cannot see:
+    // accumulators are written by nothing else inside the block, consecutive uses of one accumulator are at least
+    // three MFMAs apart, s_nops separate the last MFMA from vector reads of its result, and two wait states in front of
+    // every MFMA cover a register-file move of an operand that the allocator may place right in front of it.
+#define SD_PIN(x) asm volatile("" : "+v"(x))
+    float amax_run = 0.0f;
+    floatx4 accP[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // pass q-1's DFT
+    int cse_e = 0, csx_e = 0;             // column scales (own, transition strip) of the pass being evaluated (q-2)
+
+    // -- evaluation of pass pp from column buffer `par`: 24 slots, one every four ticks
     uint32x4 cq_h[3], cq_l[3];
-    float wst[TMAX];
+    float wst[T];
     floatx4 z3 = {0.0f, 0.0f, 0.0f, 0.0f};
-    auto eval_slot = [&](int s, int pp, int cse_own, int cse_x) {
-        if (s < T) {                                              // fetch tap s
-            cq_h[s % 3] = *reinterpret_cast<const uint32x4 *>(bph + s * kColStride);
-            cq_l[s % 3] = *reinterpret_cast<const uint32x4 *>(bpl + s * kColStride);
+    const int wofs = wslot * kColStride + 8 * g4;                 // this lane's window in a column buffer (halves)
+    auto eval_slot = [&](int s, int pp, int par) {
+        const _Float16 *ebh = colh + par * col_halves + wofs, *ebl = coll + par * col_halves + wofs;
+        if (s < T) {                                              // fetch tap s (used two slots later)
+            cq_h[s % 3] = *reinterpret_cast<const uint32x4 *>(ebh + s * kColStride);
+            cq_l[s % 3] = *reinterpret_cast<const uint32x4 *>(ebl + s * kColStride);
         }
         if (s >= 2 && s - 2 < T) {                                // multiply tap s - 2: hi*hi, hi*lo, lo*hi
             const int t = s - 2;
             if (t == 0) {
-                asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(z) : "v"(afr[t][0]), "v"(cq_h[t % 3]));
-                asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(z2) : "v"(afr[t][0]), "v"(cq_l[t % 3]));
-                asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(z3) : "v"(afr[t][1]), "v"(cq_h[t % 3]));
+                asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(z) : "v"(afr[t][0]), "v"(cq_h[t % 3]));
+                asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(z2) : "v"(afr[t][0]), "v"(cq_l[t % 3]));
+                asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(z3) : "v"(afr[t][1]), "v"(cq_h[t % 3]));
             } else {
-                asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(z) : "v"(afr[t][0]), "v"(cq_h[t % 3]));
-                asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(z2) : "v"(afr[t][0]), "v"(cq_l[t % 3]));
-                asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(z3) : "v"(afr[t][1]), "v"(cq_h[t % 3]));
+                asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(z) : "v"(afr[t][0]), "v"(cq_h[t % 3]));
+                asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(z2) : "v"(afr[t][0]), "v"(cq_l[t % 3]));
+                asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(z3) : "v"(afr[t][1]), "v"(cq_h[t % 3]));
             }
         }
-        if (s == T && norm == 1) {
+        if (s == T) {
+            const float *est = stat + par * stat_floats + wslot;
 #pragma unroll
-            for (int t = 0; t < TMAX; t++)
-                if (t < T) wst[t] = stat[wslot + t];
+            for (int t = 0; t < T; t++) wst[t] = est[t];
         }
         if (s == T + 2) {
             asm volatile("s_nop 7" : "+v"(z), "+v"(z2), "+v"(z3));   // (the last tap's MFMAs are a slot back: long done)
             z += z2 + z3;
-            if (norm == 1) {
-                float acc_ss = 0.0f;
+            float acc_ss = 0.0f;
 #pragma unroll
-                for (int t = 0; t < TMAX; t++)
-                    if (t < T) {
-                        asm volatile("" : "+v"(wst[t]));
-                        acc_ss += wst[t];
-                    }
-                ssw = acc_ss;
+            for (int t = 0; t < T; t++) {
+                SD_PIN(wst[t]);
+                acc_ss += wst[t];
             }
+            ssw = acc_ss;
         }
-        if (s >= T + 3 && s <= T + 6) post_step(s - T, pp, cse_own, cse_x);
+        if (s >= T + 3 && s <= T + 6) post_step(s - T, pp, cse_e, csx_e);
     };
 
-    int cse_post = 0, csx_post = 0;       // column scales (own, transition strip) of the pass being evaluated
-    for (int p = 0; p < runs; p++) {
-        // ================= block M: DFT(p)  ||  evaluation of pass p-1  ||  stage pass p+1  ||  reload for pass p+2
-        const int se_next = pass_scale();                             // pass p+1 (its partial maxima are in)
+    // -- magnitudes of pass q-1 (zvabs/2, CircularShortTimeFourierTransform.swift:329-333) -> columns of parity `par`.
+    // Result layout: column = frame f, register j of lane group g4 in tile m = basis row 16m + 4*g4 + j; this lane holds
+    // bins 4*g4 + j (i = j) and 16 + 4*g4 + j (i = 4 + j).  accP holds X * 2^(se + 13); columns are stored as
+    // |X| * 2^(se - col_shift), so the two scales cancel into one constant.  Micro-steps j = 0 .. kMagSteps-1.
+    constexpr int kMagSteps = 8 + 4 + 1 + 4;
+    float cval[8], mss = 0.0f;
+    const float kmag = pow2f(-13 - d.col_shift);
+    auto mag_micro = [&](int j, int par, int csx_m, int cse_m) {
+        if (j < 8) {                                              // |X| of one bin
+            const int i = j;
+            float re = accP[i >> 2][i & 3], im = accP[2 + (i >> 2)][i & 3];
+            SD_PIN(re);
+            SD_PIN(im);
+            cval[i] = __builtin_amdgcn_sqrtf(fmaf(re, re, im * im)) * kmag;
+            SD_PIN(cval[i]);
+        } else if (j < 12) {                                      // the frame's sum of squares (l2normalize works from these)
+            const int i = 2 * (j - 8);
+            if (j == 8) mss = 0.0f;
+            mss = fmaf(cval[i], cval[i], mss);
+            mss = fmaf(cval[i + 1], cval[i + 1], mss);
+            if (j == 11) mss = xor32_sum(xor16_sum(mss));
+            SD_PIN(mss);
+        } else if (j == 12) {
+            float *sp = stat + par * stat_floats;
+            sp[g4 == 0 ? XS + fl : PS] = mss;
+            sp[(g4 == 0 && fl < T - 1) ? (T - 1) + fl : PS + 1] = mss * pow2f(2 * (csx_m - cse_m));
+        } else if (j < 17) {                                      // f16 hi + lo of four bins (one tile m's share)
+            const int i = j - 13;                                 // 0, 1: the pass's own column (tiles 0, 1); 2, 3: the strip's copy
+            const int m = i & 1;
+            const float xs = i < 2 ? 1.0f : pow2f(csx_m - cse_m);   // (<= 1: a much quieter pass may underflow next to one 2^|.| louder)
+            unsigned h0, h1, l0, l1;
+            asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h0) : "v"(cval[4 * m]), "v"(xs));
+            asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h1) : "v"(cval[4 * m + 2]), "v"(xs));
+            asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h0) : "v"(cval[4 * m + 1]), "v"(xs));
+            asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h1) : "v"(cval[4 * m + 3]), "v"(xs));
+            asm volatile("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l0) : "v"(cval[4 * m]), "v"(xs), "v"(h0));
+            asm volatile("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l1) : "v"(cval[4 * m + 2]), "v"(xs), "v"(h1));
+            asm volatile("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l0) : "v"(cval[4 * m + 1]), "v"(xs), "v"(h0));
+            asm volatile("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l1) : "v"(cval[4 * m + 3]), "v"(xs), "v"(h1));
+            // bins 16m + 4*g4 .. +3: four consecutive halves
+            const int slot = i < 2 ? XS + fl : (fl < T - 1 ? (T - 1) + fl : PS);
+            _Float16 *ph = colh + par * col_halves + slot * kColStride + 4 * g4 + 16 * m, *pl = coll + par * col_halves + slot * kColStride + 4 * g4 + 16 * m;
+            uint32x2 uh = {h0, h1}, ul = {l0, l1};
+            *reinterpret_cast<uint32x2 *>(ph) = uh;
+            *reinterpret_cast<uint32x2 *>(pl) = ul;
+        }
+    };
+    // -- transition strip of pass q-1: the last T-1 columns of pass q-2 (other buffer), rescaled by 2^dexp, -> slots
+    // 0 .. T-2 of buffer `par`, a word or two per thread of the workgroup.  Micro-steps 0 .. kCarrySteps-1.
+    constexpr int kCarryWords = (T - 1) * (kColStride / 2), kCarryIt = (2 * kCarryWords + kBlock - 1) / kBlock;
+    constexpr int kCarrySteps = 1 + kCarryIt + 1;
+    unsigned cu[kCarryIt];
+    float cst_ss = 0.0f;
+    auto carry_micro = [&](int j, int par, int dexp) {
+        const int srcw = (XS + kPass - (T - 1)) * (kColStride / 2);
+        if (j == 0) {
+#pragma unroll
+            for (int k = 0; k < kCarryIt; k++) {
+                const int i = tid + kBlock * k;
+                const bool hi_arr = i < kCarryWords;
+                const int w = hi_arr ? i : i - kCarryWords;
+                const unsigned *src = reinterpret_cast<const unsigned *>((hi_arr ? colh : coll) + (par ^ 1) * col_halves);
+                cu[k] = src[srcw + (i < 2 * kCarryWords ? w : 0)];
+            }
+            cst_ss = stat[(par ^ 1) * stat_floats + XS + kPass - (T - 1) + (tid < T - 1 ? tid : 0)];
+        } else if (j <= kCarryIt) {
+            const int k = j - 1;
+            SD_PIN(cu[k]);
+            union { unsigned u; _Float16 h[2]; } x;
+            x.u = cu[k];
+            const float sc = pow2f(dexp);
+            union { decltype(__builtin_amdgcn_cvt_pkrtz(0.f, 0.f)) h; unsigned u; } y;
+            y.h = __builtin_amdgcn_cvt_pkrtz((float)x.h[0] * sc, (float)x.h[1] * sc);   // exact for dexp = 0
+            cu[k] = y.u;
+            SD_PIN(cu[k]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < kCarryIt; k++) {
+                const int i = tid + kBlock * k;
+                const bool hi_arr = i < kCarryWords;
+                const int w = hi_arr ? i : i - kCarryWords;
+                unsigned *dst = reinterpret_cast<unsigned *>((hi_arr ? colh : coll) + par * col_halves);
+                dst[i < 2 * kCarryWords ? w : PS * (kColStride / 2)] = cu[k];
+            }
+            stat[par * stat_floats + (tid < T - 1 ? tid : PS + 1)] = cst_ss * pow2f(2 * dexp);   // sums of squares of scaled columns
+        }
+    };
+
+    for (int q = 0; q < runs; q++) {
+        const _Float16 *fph = smp0 + (q & 1) * buf_halves + foff, *fpl = fph + d.r_smp_stride;
+        half8 bh = lds_half8(fph + ko[0]), bl = lds_half8(fpl + ko[0]);   // first B fragments: in flight while the scale is worked out
+        const int se_next = pass_scale();                             // pass q+1 (its partial maxima are in)
         const float sx_next = pow2f(se_next);
-        const _Float16 *fph = smp0 + (p & 1) * buf_halves + foff, *fpl = fph + d.r_smp_stride;
-        _Float16 *wh = smp0 + ((p + 1) & 1) * buf_halves;
-        const __amdgpu_buffer_rsrc_t rs2 = pass_rsrc(p + 2);
-        // The DFT's matrix instructions are written as ordered assembly statements for two reasons.  Register files: the
-        // basis is only ever an A operand, so it lives in the 256 accumulation registers (the matrix pipe reads A operands
-        // from there directly) and leaves the 256 architectural registers to everything else -- left to itself the
-        // allocator does the opposite and then serialises the block to relieve the pressure.  Order: a lone wave has
-        // nobody to hide an LDS round trip behind, so every LDS / memory instruction of the block has a fixed place
-        // between two groups of four MFMAs (the compiler keeps memory instructions on their side of such a statement);
-        // vector instructions and the evaluation's own MFMAs move freely.  Hazards the compiler cannot see: the
-        // accumulators are written by nothing else inside the block, consecutive uses of one accumulator are three
-        // MFMAs apart, s_nops follow the last group before vector code reads the results, and two wait states in
-        // front of every MFMA (an s_nop and the ordered vector instruction behind the previous MFMA; two s_nops in
-        // the evaluation) cover a v_accvgpr_write / v_accvgpr_read of an operand placed right in front of it (the
-        // allocator parks a few quads in the other register file when it runs short).
+        _Float16 *wh = smp0 + ((q + 1) & 1) * buf_halves;
+        const __amdgpu_buffer_rsrc_t rs2 = pass_rsrc(q + 2);
+        // pass q-1: its columns are stored at its own sample scale; its transition strip (pass q-2's last T-1 columns +
+        // copies of its own first T-1) at the smaller of the two passes' scales, where neither overflows
+        const int cse_m = se_m1, csx_m = (q > 1 && se_m2 < se_m1) ? se_m2 : se_m1;
+        const int dexp = q > 1 ? (csx_m - se_m2 < -126 ? -126 : csx_m - se_m2) : 0;
+        const int par_m = (q + 1) & 1, par_e = q & 1;                 // column buffers of pass q-1 (written) and q-2 (read)
         floatx4 acc[4];
         {
-            half8 bh = lds_half8(fph + ko[0]), bl = lds_half8(fpl + ko[0]);
-            // A lone wave issues in order: while it waits at an MFMA for the matrix pipe it issues nothing else, so vector
-            // work hides under the matrix work only if it sits BETWEEN the MFMAs in program order -- about three vector
-            // instructions fit under each.  The next pass's staging (scale, f16 hi/lo split, two LDS writes, reload of the
-            // quad with pass p+2) is therefore cut into single instructions, ordered statements like the MFMAs, one after
-            // each DFT MFMA.
+            // the next pass's staging (scale, f16 hi/lo split, two LDS writes, reload of the quad with pass p+2), one
+            // instruction per micro-step
             unsigned mh0 = 0, ml0 = 0, mh1 = 0, ml1 = 0;
-            auto micro = [&](int i) {
+            auto stage_micro = [&](int i) {
                 const int k = i / 11, j = i % 11;
                 if (k >= NL) return;
-#ifndef SYLDET_R_NOSTAGE
-                const floatx4 q = as_floatx4(v[k]);
-                if (j == 0) asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(mh0) : "v"(q[0]), "v"(sx_next));
-                if (j == 1) asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(mh0) : "v"(q[1]), "v"(sx_next));
-                if (j == 2) asm volatile("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(ml0) : "v"(q[0]), "v"(sx_next), "v"(mh0));
-                if (j == 3) asm volatile("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(ml0) : "v"(q[1]), "v"(sx_next), "v"(mh0));
-                if (j == 4) asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(mh1) : "v"(q[2]), "v"(sx_next));
-                if (j == 5) asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(mh1) : "v"(q[3]), "v"(sx_next));
-                if (j == 6) asm volatile("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(ml1) : "v"(q[2]), "v"(sx_next), "v"(mh1));
-                if (j == 7) asm volatile("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(ml1) : "v"(q[3]), "v"(sx_next), "v"(mh1));
+                const floatx4 qv = as_floatx4(v[k]);
+                // (lo / hi halves of one register are never written by neighbouring instructions: that costs a wait state)
+                if (j == 0) asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(mh0) : "v"(qv[0]), "v"(sx_next));
+                if (j == 1) asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(mh1) : "v"(qv[2]), "v"(sx_next));
+                if (j == 2) asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(mh0) : "v"(qv[1]), "v"(sx_next));
+                if (j == 3) asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(mh1) : "v"(qv[3]), "v"(sx_next));
+                if (j == 4) asm volatile("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(ml0) : "v"(qv[0]), "v"(sx_next), "v"(mh0));
+                if (j == 5) asm volatile("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(ml1) : "v"(qv[2]), "v"(sx_next), "v"(mh1));
+                if (j == 6) asm volatile("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(ml0) : "v"(qv[1]), "v"(sx_next), "v"(mh0));
+                if (j == 7) asm volatile("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(ml1) : "v"(qv[3]), "v"(sx_next), "v"(mh1));
                 _Float16 *ph = wh + (SKEW ? spos[k] : 4 * tid + 4 * kBlock * k);
                 if (j == 8) { uint32x2 uh = {mh0, mh1}; *reinterpret_cast<uint32x2 *>(ph) = uh; }
                 if (j == 9) { uint32x2 ul = {ml0, ml1}; *reinterpret_cast<uint32x2 *>(ph + d.r_smp_stride) = ul; }
-#endif
-#ifndef SYLDET_R_NOLOAD
                 if (j == 10) v[k] = __builtin_amdgcn_raw_buffer_load_b128(rs2, 16 * tid + 16 * kBlock * k, 0, 0);
-#endif
             };
-            auto slot = [&](int sl) {
-#ifndef SYLDET_R_NOEVAL
-                eval_slot(sl, p - 1, cse_post, csx_post);
-#endif
+            // tick i: what rides behind the i-th DFT MFMA.  First half: staging, two micro-steps a tick (the reloads are
+            // then issued early enough to have landed when the block maximum wants them) + the evaluation's MFMA phase;
+            // second half: magnitudes and transition strip of pass q-1 + the evaluation's vector phase.
+            constexpr int kTicks = 12 * KS, kHalf = (11 * NL + 1) / 2;
+            auto tick_work = [&](int i) {
+                if (i < kHalf) { stage_micro(2 * i); stage_micro(2 * i + 1); }
+                if (i % 4 == 0) eval_slot(i / 4, q - 2, par_e);
+                const int jm = i - 4 * (T + 7);                        // magnitudes: one micro-step a tick, after the evaluation's stores
+                if (jm >= 0 && jm < kMagSteps) mag_micro(jm, par_m, csx_m, cse_m);
+                const int jc = i - (kTicks - 2 * kCarrySteps);        // transition strip: every other tick at the end
+                if (jc >= 0 && jc % 2 == 0 && jc / 2 < kCarrySteps) carry_micro(jc / 2, par_m, dexp);
+                const int jx = i - (kTicks - NL - 4);                  // block maximum of pass q+2, a quad a tick (its loads left in the
+                if (jx >= 0 && jx < NL) {                              // first half), then the wave's maximum, published before the last tick
+                    if (jx == 0) amax_run = 0.0f;
+                    const floatx4 qv = as_floatx4(v[jx]);
+                    amax_run = absmax3(absmax3(amax_run, qv[0], qv[1]), qv[2], qv[3]);
+                    SD_PIN(amax_run);
+                }
+                if (jx == NL) {                                        // v_max3 drops NaNs: a plain non-negative number
+                    amax_run = wave_max_nonneg(amax_run);
+                    SD_PIN(amax_run);
+                }
+                if (jx == NL + 2 && lane == 0) red[wave] = amax_run;
             };
+            static_assert(4 * (T + 7) + kMagSteps <= kTicks && 2 * kCarrySteps <= kTicks && kHalf <= kTicks - NL - 4, "tick schedule");
 #pragma unroll
             for (int ks = 0; ks < KS; ks++) {
                 const half8 cbh = bh, cbl = bl;
@@ -298,74 +404,71 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
                     bh = lds_half8(fph + ko[ks + 1]);
                     bl = lds_half8(fpl + ko[ks + 1]);
                 }
-                slot(3 * ks);
 #pragma unroll
                 for (int m = 0; m < 4; m++) {
-                    if (ks == 0) asm volatile("s_nop 0\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(acc[m]) : "a"(a[ks * 8 + 2 * m]), "v"(cbh));
-                    else asm volatile("s_nop 0\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[m]) : "a"(a[ks * 8 + 2 * m]), "v"(cbh));
-                    micro(12 * ks + m);
+                    if (ks == 0) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(acc[m]) : "a"(a[ks * 8 + 2 * m]), "v"(cbh));
+                    else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[m]) : "a"(a[ks * 8 + 2 * m]), "v"(cbh));
+                    tick_work(12 * ks + m);
                 }
-                slot(3 * ks + 1);
 #pragma unroll
                 for (int m = 0; m < 4; m++) {
-                    asm volatile("s_nop 0\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[m]) : "a"(a[ks * 8 + 2 * m]), "v"(cbl));
-                    micro(12 * ks + 4 + m);
+                    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[m]) : "a"(a[ks * 8 + 2 * m]), "v"(cbl));
+                    tick_work(12 * ks + 4 + m);
                 }
-                slot(3 * ks + 2);
 #pragma unroll
                 for (int m = 0; m < 4; m++) {
-                    asm volatile("s_nop 0\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[m]) : "a"(a[ks * 8 + 2 * m + 1]), "v"(cbh));
-                    micro(12 * ks + 8 + m);
+                    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[m]) : "a"(a[ks * 8 + 2 * m + 1]), "v"(cbh));
+                    tick_work(12 * ks + 8 + m);
                 }
             }
-#pragma unroll
-            for (int i = 12 * KS; i < 11 * NL; i++) micro(i);         // what is left of the last quad
             asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+#pragma unroll
+            for (int m = 0; m < 4; m++) accP[m] = acc[m];
         }
         SD_RTICK(0)
-        __syncthreads();          // all reads of the columns are done
         SD_RTICK(1)
-        // this pass's columns are stored at its own sample scale; the transition strip (the previous pass's last T-1
-        // columns + copies of this pass's first T-1) at the smaller of the two passes' scales, where neither overflows
-        cse = scaling != 0 ? 0 : se;
-        const int csx = scaling != 0 ? 0 : ((p > 0 && se_prev < se) ? se_prev : se);
-        cse_post = cse;
-        csx_post = csx;
-#ifndef SYLDET_R_NOMAG
-#include "fused_strip.inc"
-        {
-#include "fused_mag.inc"
-        }
-#endif
+        cse_e = cse_m;
+        csx_e = csx_m;
+        se_m2 = se_m1;
+        se_m1 = se_cur;
+        se_cur = se_next;
+        __syncthreads();          // columns of pass q-1, staged samples of pass q+1 and the partial maxima are complete; pass q-2's columns are free
         SD_RTICK(2)
-#ifndef SYLDET_R_NOMAX
-        max_partial();
-#endif
-        SD_RTICK(3)            // pass p+2 (zeros past the segment)
-        se_prev = se;
-        se = se_next;
-        __syncthreads();          // columns of pass p, staged samples of pass p+1 and the partial maxima are complete
-        SD_RTICK(4)
         if (STAMP) {
             tsum[0] += tick[0] - tick[5];
-#pragma unroll
-            for (int i = 1; i < 5; i++) tsum[i] += tick[i] - tick[i - 1];
-            tick[5] = tick[4];
+            tsum[1] += tick[1] - tick[0];
+            tsum[2] += tick[2] - tick[1];
+            tick[5] = tick[2];
         }
     }
-    // ---- evaluation of the last pass
+    // ---- drain: evaluate pass runs-2, finish pass runs-1 (magnitudes, strip), barrier, evaluate it
+    {
+        const int q = runs;
+        const int cse_m = se_m1, csx_m = (q > 1 && se_m2 < se_m1) ? se_m2 : se_m1;
+        const int dexp = q > 1 ? (csx_m - se_m2 < -126 ? -126 : csx_m - se_m2) : 0;
 #pragma unroll
-    for (int sl = 0; sl < 24; sl++) eval_slot(sl, runs - 1, cse_post, csx_post);
+        for (int sl = 0; sl < 24; sl++) eval_slot(sl, q - 2, q & 1);
+#pragma unroll
+        for (int j = 0; j < kMagSteps; j++) mag_micro(j, (q + 1) & 1, csx_m, cse_m);
+#pragma unroll
+        for (int j = 0; j < kCarrySteps; j++) carry_micro(j, (q + 1) & 1, dexp);
+        cse_e = cse_m;
+        csx_e = csx_m;
+        __syncthreads();
+#pragma unroll
+        for (int sl = 0; sl < 24; sl++) eval_slot(sl, q - 1, (q + 1) & 1);
+    }
     if (STAMP && (tid == 0 || tid == 64 * (kWaves - 1)) && d.stamps)       // wave 0's view in slots 0-7, the last wave's in 8-15
         for (int i = 0; i < 8; i++) atomicAdd(&d.stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (tid ? 8 : 0) + i], tsum[i]);
 #undef SD_RTICK
+#undef SD_PIN
 }
 
-template <int KS, int TMAX, int NL, bool EXACT, bool SKEW, bool LEAN = false, bool STAMP = false>
+template <int KS, int T, int NL, bool SKEW, bool STAMP = false>
 hipError_t launch_one(const FusedDesc &d, const float *samples, int64_t stride, int C, int64_t s_eff, int64_t E,
                       float *outputs, uint8_t *flags, hipStream_t stream)
 {
-    auto kern = fused_r_kernel<KS, TMAX, NL, EXACT, SKEW, LEAN, STAMP>;
+    auto kern = fused_r_kernel<KS, T, NL, SKEW, STAMP>;
     hipError_t st = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, d.r_lds_total);
     if (st != hipSuccess) return st;
     const int64_t segs = (E + d.r_seg_evals - 1) / d.r_seg_evals;
@@ -376,13 +479,15 @@ hipError_t launch_one(const FusedDesc &d, const float *samples, int64_t stride, 
 
 }  // namespace
 
-// Shapes this kernel is instantiated for: 256-sample windows (8 k-steps), 9 staging quads per thread (hops 121..140:
-// the reference's 132 and the 128 variant), timeRange 10.  Everything else stays on kernels_fused.hip's kernel.
+// Shapes this kernel is instantiated for: the reference's example detector class (l2normalize first, linear |X| columns,
+// two layers, at most 4 TanSig hidden units, one output, at most one output map), 256-sample windows (8 k-steps),
+// timeRange 10, 9 staging quads per thread (hops 121..140, the reference's 132 among them) and no bank-spreading
+// padding (hop not a multiple of 16).  Everything else stays on kernels_fused.hip's kernel.
 bool fused_r_applicable(const FusedDesc &d)
 {
     const bool lean = d.norm == 1 && d.scaling == 0 && d.n_layers == 2 && d.tf0 == 0 /* TanSig */ && d.tf1 == 2 /* PureLin */ &&
                       d.n_out == 1 && d.H <= 4 && d.n_out_fns <= 1;
-    return d.r_ok && d.KS == 8 && d.T == 10 && d.r_nload == 9 && lean;
+    return d.r_ok && d.KS == 8 && d.T == 10 && d.r_nload == 9 && d.skew == 0 && lean;
 }
 
 hipError_t launch_fused_r(const FusedDesc &d, const float *samples, int64_t stride, int C, int64_t S, int64_t J,
@@ -390,10 +495,10 @@ hipError_t launch_fused_r(const FusedDesc &d, const float *samples, int64_t stri
 {
     (void)S;
     if (E <= 0 || C <= 0) return hipSuccess;
+    if (!fused_r_applicable(d)) return hipErrorInvalidValue;
     const int64_t s_eff = (J - 1) * (int64_t)d.hop + d.gap + d.W;
-    if (d.stamps && d.skew == 0) return launch_one<8, 10, 9, true, false, true, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
-    if (d.skew != 0) return launch_one<8, 10, 9, true, true, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
-    return launch_one<8, 10, 9, true, false, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
+    if (d.stamps) return launch_one<8, 10, 9, false, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
+    return launch_one<8, 10, 9, false>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
 }
 
 }  // namespace sd

@@ -478,9 +478,8 @@ int run_on_stream(syldet *h, const float *d_samples, int64_t S, int64_t stride, 
                                             "barrier 0", "-", "-", "-", "wave 7: DFT || evaluate || block max", "wave 7: barrier 1", "wave 7: carry + mag + columns",
                                             "wave 7: stage + issue loads", "wave 7: barrier 0", "-", "-", "-"};
             if (rk) {
-                names[0] = "block M: DFT || evaluate || stage || reload"; names[1] = "barrier A"; names[2] = "strip + magnitudes + columns";
-                names[3] = "block max (waits for the loads)"; names[4] = "barrier B";
-                for (int i = 0; i < 5; i++) names[8 + i] = names[i];
+                names[0] = "matrix block (DFT(q) || finish q-1 || evaluate q-2 || stage q+1)"; names[1] = "-"; names[2] = "barrier";
+                for (int i = 0; i < 3; i++) names[8 + i] = names[i];
                 d.runs = d.r_runs;
             }
             std::fprintf(stderr, "[syldet stamps] runs=%d workgroups=%zu cycles/pass=%.0f\n", d.runs, n / 16, tot / ((double)(n / 16) * d.runs));
@@ -488,7 +487,8 @@ int run_on_stream(syldet *h, const float *d_samples, int64_t S, int64_t stride, 
                 if (sum[i] > 0) std::fprintf(stderr, "   %-32s %6.0f cycles/pass  %5.1f %%\n", names[i], sum[i] / ((double)(n / 16) * d.runs), 100.0 * sum[i] / tot);
             return SYLDET_OK;
         }
-        KernelTimer t(h, stream, "fused_kernel");
+        // (the launcher picks the register-resident-basis kernel where it is instantiated: named for what runs)
+        KernelTimer t(h, stream, (fused_r_applicable(d) && !std::getenv("SYLDET_FUSED_CLASSIC") && !d.ko) ? "fused_r_kernel" : "fused_kernel");
         SYLDET_HIP(launch_fused(d, d_samples, stride, C, S, J, E, d_outputs, d_flags, stream));
         return SYLDET_OK;
     }

@@ -198,3 +198,23 @@ def test_wide_engine_is_declared_and_needs_a_device():
     with pytest.raises(sd.SyllableDetectorError) as ei:
         sd.SyllableDetector(nets.wide_mlp(util.sample_net()), engine=_abi.ENGINE_WIDE_BF16)
     assert ei.value.status == _abi.ERR_NO_DEVICE
+
+
+def test_mfma_hazard_checker_sees_a_vector_write_in_front_of_a_hand_placed_mfma(tmp_path):
+    """tools/check_mfma_hazards.py guards kernels_fused_r.hip's assembly-statement MFMAs at build time (csrc/Makefile)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("chk", os.path.join(ROOT, "tools", "check_mfma_hazards.py"))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    mfma = "\t;;#ASMSTART\n\tv_mfma_f32_16x16x32_f16 v[0:3], a[8:11], v[20:23], v[0:3]\n\t;;#ASMEND\n"
+    ok = tmp_path / "ok.s"
+    ok.write_text("\tv_accvgpr_write_b32 a9, v5\n\tv_add_f32_e32 v30, v31, v32\n\tds_read_b64 v[40:41], v3\n" + mfma)
+    assert chk.check(str(ok)) == (1, [])
+    for writer in ("\tv_accvgpr_write_b32 a9, v5\n", "\tv_mov_b32_e32 v21, v7\n", "\tv_accvgpr_write_b32 a10, v5\n\tv_add_f32_e32 v30, v31, v32\n"):
+        bad = tmp_path / "bad.s"
+        bad.write_text(writer + mfma)
+        seen, found = chk.check(str(bad))
+        assert seen == 1 and len(found) == 1
+    waited = tmp_path / "waited.s"
+    waited.write_text("\tv_mov_b32_e32 v21, v7\n\ts_nop 1\n" + mfma)
+    assert chk.check(str(waited)) == (1, [])

@@ -330,3 +330,59 @@ def test_transfer_functions_saturate_like_the_reference(oracle_lib, tf, gain):
     util.assert_flags_exact(fl[0], w64, cfg.thresholds, cfg.rule)
     if gain > 1.0 and tf in ("TanSig", "LogSig", "SatLin"):
         assert engine == _abi.ENGINE_FUSED
+
+
+@pytest.mark.parametrize("S,channels", [(44100, 3), (64 * 132 * 5 + 256 + 9 * 132, 1), (300000, 2), (1450, 1)])
+def test_both_fused_kernels_against_the_oracle_and_each_other(oracle_lib, monkeypatch, S, channels):
+    """The reference's example detector runs on the register-resident-basis kernel (kernels_fused_r.hip: 64-frame
+    passes, three passes in flight), everything else and SYLDET_FUSED_CLASSIC=1 on kernels_fused.hip's.  Both meet the
+    oracle; they tile the audio differently (block floating point per 64 / 128 frames), so they agree with each other
+    to a few 1e-7, not bit for bit.  Lengths: several segments, whole passes exactly, a ragged tail, barely one
+    evaluation; level steps of 40 dB inside and across passes."""
+    torch = _torch()
+    cfg = util.sample_net()
+    rng = np.random.default_rng(S)
+    x = np.stack([synth.syllable_channel(S, util.template(), seed=21 + c) if S >= 20000 else
+                  (0.1 * rng.standard_normal(S)) for c in range(channels)]).astype(np.float32)
+    for k in range(0, S, 7001):
+        x[:, k:k + 3500] *= np.float32(0.01)
+    xd = torch.from_numpy(x).cuda()
+    o = util.oracle_for(cfg)
+    got = {}
+    for kernel in ("fused_r_kernel", "fused_kernel"):
+        if kernel == "fused_kernel":
+            monkeypatch.setenv("SYLDET_FUSED_CLASSIC", "1")
+        else:
+            monkeypatch.delenv("SYLDET_FUSED_CLASSIC", raising=False)
+        with sd.SyllableDetector(cfg, channels=channels, engine=_abi.ENGINE_FUSED) as det:
+            det.profile(True)
+            out, fl = det.run(xd)
+            torch.cuda.synchronize()
+            assert [nm for nm, _ in det.lastTimings()] == [kernel]
+            out, fl = out.cpu().numpy(), fl.cpu().numpy()
+        got[kernel] = out
+        for c in range(channels):
+            _, _, w64 = o.run(x[c], po.F64)
+            util.assert_outputs_close(out[c], w64)
+            util.assert_flags_exact(fl[c], w64, cfg.thresholds, cfg.rule)
+    both = np.isfinite(got["fused_kernel"]) & np.isfinite(got["fused_r_kernel"])
+    assert (np.isfinite(got["fused_kernel"]) == np.isfinite(got["fused_r_kernel"])).all()
+    assert np.abs(got["fused_kernel"][both] - got["fused_r_kernel"][both]).max() <= 5e-6
+
+
+def test_register_resident_kernel_is_only_taken_where_it_is_instantiated(oracle_lib):
+    """hop 128 (bank-spread staging), another timeRange, a wider hidden layer: kernels_fused.hip's kernel."""
+    torch = _torch()
+    base = nets.from_npz()
+    rng = np.random.default_rng(5)
+    x = synth.channel(30000, 3)[None].astype(np.float32)
+    xd = torch.from_numpy(x).cuda()
+    for cfg in (nets.variant(base, windowOverlap=128), nets.variant(base, timeRange=8, net=nets.random_net(rng, 29 * 8, (4,), 1)),
+                nets.variant(base, net=nets.random_net(rng, 290, (8,), 1))):
+        with sd.SyllableDetector(cfg, channels=1, engine=_abi.ENGINE_FUSED) as det:
+            det.profile(True)
+            out, fl = det.run(xd)
+            torch.cuda.synchronize()
+            assert [nm for nm, _ in det.lastTimings()] == ["fused_kernel"]
+        _, _, w64 = util.oracle_for(cfg).run(x[0], po.F64)
+        util.assert_outputs_close(out.cpu().numpy()[0], w64)

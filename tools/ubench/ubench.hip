@@ -146,6 +146,61 @@ void run_co(const char *name, int waves, int iters)
     CK(hipFree(cyc)); CK(hipFree(sink));
 }
 
+
+// interleave: one wave per SIMD, every instruction an ordered assembly statement: per iteration 8 x [one MFMA, NV
+// independent v_fma_f32].  ACC 0: C/D in architectural registers and A in accumulation registers (the arrangement of
+// kernels_fused_r.hip's first version); ACC 1: C/D in accumulation registers, A and B architectural (what the compiler
+// picks by itself); ACC 2: C/D and A in accumulation registers, B architectural.
+template <int NV, int ACC>
+__global__ void __launch_bounds__(256, 1) kil(int iters, unsigned long long *cyc, float *sink)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    floatx4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    half8 A, B;
+    for (int i = 0; i < 8; i++) { A[i] = (_Float16)(lane * 0.001f); B[i] = (_Float16)(i * 0.01f); }
+    float f[16];
+    for (int i = 0; i < 16; i++) f[i] = lane + i;
+    const float m = 1.0f + 1e-7f * lane, c = 1e-3f;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            if (ACC == 0) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[q & 3]) : "a"(A), "v"(B));
+            else if (ACC == 1) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[q & 3]) : "v"(A), "v"(B));
+            else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[q & 3]) : "a"(A), "v"(B));
+#pragma unroll
+            for (int r = 0; r < NV; r++) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f[(q * NV + r) & 15]) : "v"(m), "v"(c));
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (lane == 0) cyc[blockIdx.x * (blockDim.x / 64) + wave] = t1 - t0;
+    float s = 0;
+    for (int q = 0; q < 4; q++) s += acc[q][0] + acc[q][1] + acc[q][2] + acc[q][3];
+    for (int i = 0; i < 16; i++) s += f[i];
+    if (s == 12345.678f) sink[0] = s;
+}
+
+template <int NV, int ACC>
+void run_il(int iters)
+{
+    unsigned long long *cyc; float *sink;
+    const int blocks = 256;
+    CK(hipMalloc(&cyc, blocks * 16 * sizeof(unsigned long long)));
+    CK(hipMalloc(&sink, 4));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipFuncSetAttribute((const void *)kil<NV, ACC>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    for (int rep = 0; rep < 2; rep++) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL((kil<NV, ACC>), dim3(blocks), dim3(256), 150 * 1024, 0, iters, cyc, sink);
+        CK(hipEventRecord(e1));
+        CK(hipDeviceSynchronize());
+    }
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("interleaved, 1 wave/SIMD, %s: 8 x [MFMA + %d FMA]   wall ns/iter=%8.2f  = %6.2f ns per MFMA group\n",
+           ACC == 0 ? "C/D arch, A acc " : ACC == 1 ? "C/D acc, A arch " : "C/D acc, A acc  ", NV, ms * 1e6 / iters, ms * 1e6 / iters / 8);
+    CK(hipFree(cyc)); CK(hipFree(sink));
+}
+
 template <int MODE>
 void run(const char *name, int waves, int iters)
 {
@@ -174,6 +229,11 @@ void run(const char *name, int waves, int iters)
 int main()
 {
     const int iters = 20000;
+    run_il<0, 0>(iters); run_il<1, 0>(iters); run_il<2, 0>(iters); run_il<3, 0>(iters); run_il<4, 0>(iters); run_il<6, 0>(iters);
+    run_il<0, 2>(iters); run_il<1, 2>(iters); run_il<2, 2>(iters); run_il<3, 2>(iters); run_il<4, 2>(iters);
+    run_il<5, 2>(iters); run_il<6, 2>(iters); run_il<7, 2>(iters); run_il<8, 2>(iters); run_il<9, 2>(iters); run_il<10, 2>(iters); run_il<12, 2>(iters); run_il<14, 2>(iters);
+    run_il<5, 0>(iters); run_il<7, 0>(iters); run_il<8, 0>(iters); run_il<10, 0>(iters);
+    run_il<0, 1>(iters); run_il<1, 1>(iters); run_il<2, 1>(iters); run_il<3, 1>(iters); run_il<4, 1>(iters); run_il<6, 1>(iters);
     // one wave per SIMD: MFMA alone, FMA alone, both in one wave
     run_co<8, 0, 0>("mfma alone (1 wave/SIMD)", 4, iters);
     run_co<0, 24, 0>("fma alone (1 wave/SIMD)", 4, iters);
