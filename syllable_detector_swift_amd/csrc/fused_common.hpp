@@ -12,6 +12,7 @@ constexpr int kCstThr = 0 /* 16 doubles */, kCstOut = 32;
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef float floatx2 __attribute__((ext_vector_type(2)));
 typedef unsigned int uint32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int uint32x4 __attribute__((ext_vector_type(4)));
 

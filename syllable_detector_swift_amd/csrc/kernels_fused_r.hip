@@ -220,15 +220,20 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
         }
         if (s >= 2 && s - 2 < T) {                                // multiply tap s - 2: hi*hi, hi*lo, lo*hi
             const int t = s - 2;
-            if (t == 0) {
-                asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(z) : "v"(afr[t][0]), "v"(cq_h[t % 3]));
-                asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(z2) : "v"(afr[t][0]), "v"(cq_l[t % 3]));
-                asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(z3) : "v"(afr[t][1]), "v"(cq_h[t % 3]));
-            } else {
-                asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(z) : "v"(afr[t][0]), "v"(cq_h[t % 3]));
-                asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(z2) : "v"(afr[t][0]), "v"(cq_l[t % 3]));
-                asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(z3) : "v"(afr[t][1]), "v"(cq_h[t % 3]));
+            // (the diagnostic instantiation is tighter on registers: there the allocator parks first-layer fragments in the
+            // accumulation registers and fetches them right in front of their MFMA -- two wait states, tools/check_mfma_hazards.py)
+#define SD_EVAL_MFMA(pre)                                                                                                         \
+            if (t == 0) {                                                                                                         \
+                asm volatile(pre "v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(z) : "v"(afr[t][0]), "v"(cq_h[t % 3]));          \
+                asm volatile(pre "v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(z2) : "v"(afr[t][0]), "v"(cq_l[t % 3]));         \
+                asm volatile(pre "v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(z3) : "v"(afr[t][1]), "v"(cq_h[t % 3]));         \
+            } else {                                                                                                              \
+                asm volatile(pre "v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(z) : "v"(afr[t][0]), "v"(cq_h[t % 3]));          \
+                asm volatile(pre "v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(z2) : "v"(afr[t][0]), "v"(cq_l[t % 3]));         \
+                asm volatile(pre "v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(z3) : "v"(afr[t][1]), "v"(cq_h[t % 3]));         \
             }
+            if (STAMP) { SD_EVAL_MFMA("s_nop 1\n\t") } else { SD_EVAL_MFMA("") }
+#undef SD_EVAL_MFMA
         }
         if (s == T) {
             const float *est = stat + par * stat_floats + wslot;
@@ -343,7 +348,11 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
         const int se_next = pass_scale();                             // pass q+1 (its partial maxima are in)
         const float sx_next = pow2f(se_next);
         _Float16 *wh = smp0 + ((q + 1) & 1) * buf_halves;
+#ifdef SYLDET_R_NOLOAD                // (diagnostic builds reload the same cache-resident pass: tools/r_knockouts.sh)
+        const __amdgpu_buffer_rsrc_t rs2 = pass_rsrc(q & 1);
+#else
         const __amdgpu_buffer_rsrc_t rs2 = pass_rsrc(q + 2);
+#endif
         // pass q-1: its columns are stored at its own sample scale; its transition strip (pass q-2's last T-1 columns +
         // copies of its own first T-1) at the smaller of the two passes' scales, where neither overflows
         const int cse_m = se_m1, csx_m = (q > 1 && se_m2 < se_m1) ? se_m2 : se_m1;
@@ -374,15 +383,28 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
             };
             // tick i: what rides behind the i-th DFT MFMA.  First half: staging, two micro-steps a tick (the reloads are
             // then issued early enough to have landed when the block maximum wants them) + the evaluation's MFMA phase;
-            // second half: magnitudes and transition strip of pass q-1 + the evaluation's vector phase.
+            // second half: the evaluation's vector phase, then magnitudes and transition strip of pass q-1.  (Measured
+            // alternatives: one staging step a tick over the whole block with the block maximum behind it, 1.42 ms; hi parts
+            // from v_pk_mul_f32 + v_cvt_pkrtz with one v_fma_mix a tick over three quarters of the block, 1.43 ms; this, 1.37.)
             constexpr int kTicks = 12 * KS, kHalf = (11 * NL + 1) / 2;
             auto tick_work = [&](int i) {
+                if (STAMP && i % 24 == 0) { SD_RTICK(i / 24) }         // quarters of the block, diagnostic instantiation only
+                // (SYLDET_R_NO*: diagnostic builds with one piece knocked out, tools/r_knockouts.sh; never the shipped library)
+#ifndef SYLDET_R_NOSTAGE
                 if (i < kHalf) { stage_micro(2 * i); stage_micro(2 * i + 1); }
+#endif
+#ifndef SYLDET_R_NOEVAL
                 if (i % 4 == 0) eval_slot(i / 4, q - 2, par_e);
+#endif
+#ifndef SYLDET_R_NOMAG
                 const int jm = i - 4 * (T + 7);                        // magnitudes: one micro-step a tick, after the evaluation's stores
                 if (jm >= 0 && jm < kMagSteps) mag_micro(jm, par_m, csx_m, cse_m);
+#endif
+#ifndef SYLDET_R_NOCARRY
                 const int jc = i - (kTicks - 2 * kCarrySteps);        // transition strip: every other tick at the end
                 if (jc >= 0 && jc % 2 == 0 && jc / 2 < kCarrySteps) carry_micro(jc / 2, par_m, dexp);
+#endif
+#ifndef SYLDET_R_NOMAX
                 const int jx = i - (kTicks - NL - 4);                  // block maximum of pass q+2, a quad a tick (its loads left in the
                 if (jx >= 0 && jx < NL) {                              // first half), then the wave's maximum, published before the last tick
                     if (jx == 0) amax_run = 0.0f;
@@ -395,8 +417,21 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
                     SD_PIN(amax_run);
                 }
                 if (jx == NL + 2 && lane == 0) red[wave] = amax_run;
+#endif
             };
             static_assert(4 * (T + 7) + kMagSteps <= kTicks && 2 * kCarrySteps <= kTicks && kHalf <= kTicks - NL - 4, "tick schedule");
+            // The DFT's accumulators live in the accumulation registers (an MFMA whose C/D operands are architectural
+            // registers takes 9.9 ns against 8.4: tools/ubench), which the basis alone would fill: its last four quads are
+            // architectural instead.
+            constexpr int kArchQuads = 4;
+#define SD_DFT_MFMA(m_, ai_, b_, first_)                                                                                           \
+            if ((ai_) >= KS * 8 - kArchQuads) {                                                                                   \
+                if (first_) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&a"(acc[m_]) : "v"(a[ai_]), "v"(b_));         \
+                else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[m_]) : "v"(a[ai_]), "v"(b_));                \
+            } else {                                                                                                              \
+                if (first_) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&a"(acc[m_]) : "a"(a[ai_]), "v"(b_));         \
+                else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[m_]) : "a"(a[ai_]), "v"(b_));                \
+            }
 #pragma unroll
             for (int ks = 0; ks < KS; ks++) {
                 const half8 cbh = bh, cbl = bl;
@@ -406,39 +441,39 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
                 }
 #pragma unroll
                 for (int m = 0; m < 4; m++) {
-                    if (ks == 0) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(acc[m]) : "a"(a[ks * 8 + 2 * m]), "v"(cbh));
-                    else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[m]) : "a"(a[ks * 8 + 2 * m]), "v"(cbh));
+                    SD_DFT_MFMA(m, ks * 8 + 2 * m, cbh, ks == 0)
                     tick_work(12 * ks + m);
                 }
 #pragma unroll
                 for (int m = 0; m < 4; m++) {
-                    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[m]) : "a"(a[ks * 8 + 2 * m]), "v"(cbl));
+                    SD_DFT_MFMA(m, ks * 8 + 2 * m, cbl, false)
                     tick_work(12 * ks + 4 + m);
                 }
 #pragma unroll
                 for (int m = 0; m < 4; m++) {
-                    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[m]) : "a"(a[ks * 8 + 2 * m + 1]), "v"(cbh));
+                    SD_DFT_MFMA(m, ks * 8 + 2 * m + 1, cbh, false)
                     tick_work(12 * ks + 8 + m);
                 }
             }
-            asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+#undef SD_DFT_MFMA
+            asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3]));
 #pragma unroll
             for (int m = 0; m < 4; m++) accP[m] = acc[m];
         }
-        SD_RTICK(0)
-        SD_RTICK(1)
+        SD_RTICK(4)
         cse_e = cse_m;
         csx_e = csx_m;
         se_m2 = se_m1;
         se_m1 = se_cur;
         se_cur = se_next;
         __syncthreads();          // columns of pass q-1, staged samples of pass q+1 and the partial maxima are complete; pass q-2's columns are free
-        SD_RTICK(2)
-        if (STAMP) {
+        SD_RTICK(6)
+        if (STAMP) {                // top of the pass up to the first MFMA, four quarters of the block, barrier
             tsum[0] += tick[0] - tick[5];
-            tsum[1] += tick[1] - tick[0];
-            tsum[2] += tick[2] - tick[1];
-            tick[5] = tick[2];
+#pragma unroll
+            for (int i = 1; i < 5; i++) tsum[i] += tick[i] - tick[i - 1];
+            tsum[5] += tick[6] - tick[4];
+            tick[5] = tick[6];
         }
     }
     // ---- drain: evaluate pass runs-2, finish pass runs-1 (magnitudes, strip), barrier, evaluate it

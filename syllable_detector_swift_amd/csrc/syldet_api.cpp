@@ -478,8 +478,10 @@ int run_on_stream(syldet *h, const float *d_samples, int64_t S, int64_t stride, 
                                             "barrier 0", "-", "-", "-", "wave 7: DFT || evaluate || block max", "wave 7: barrier 1", "wave 7: carry + mag + columns",
                                             "wave 7: stage + issue loads", "wave 7: barrier 0", "-", "-", "-"};
             if (rk) {
-                names[0] = "matrix block (DFT(q) || finish q-1 || evaluate q-2 || stage q+1)"; names[1] = "-"; names[2] = "barrier";
-                for (int i = 0; i < 3; i++) names[8 + i] = names[i];
+                names[0] = "top of the pass (scale, first fragments)"; names[1] = "ticks 0-23 (stage || evaluate: MFMA phase)";
+                names[2] = "ticks 24-47 (stage || evaluate: MFMA phase)"; names[3] = "ticks 48-71 (evaluate: vector phase, magnitudes)";
+                names[4] = "ticks 72-95 (magnitudes, block max, strip)"; names[5] = "barrier";
+                for (int i = 0; i < 6; i++) names[8 + i] = names[i];
                 d.runs = d.r_runs;
             }
             std::fprintf(stderr, "[syldet stamps] runs=%d workgroups=%zu cycles/pass=%.0f\n", d.runs, n / 16, tot / ((double)(n / 16) * d.runs));

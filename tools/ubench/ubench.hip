@@ -165,11 +165,14 @@ __global__ void __launch_bounds__(256, 1) kil(int iters, unsigned long long *cyc
     for (int it = 0; it < iters; it++) {
 #pragma unroll
         for (int q = 0; q < 8; q++) {
-            if (ACC == 0) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[q & 3]) : "a"(A), "v"(B));
+            if (ACC == 0 || ACC == 3) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[q & 3]) : "a"(A), "v"(B));
             else if (ACC == 1) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[q & 3]) : "v"(A), "v"(B));
             else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[q & 3]) : "a"(A), "v"(B));
 #pragma unroll
-            for (int r = 0; r < NV; r++) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f[(q * NV + r) & 15]) : "v"(m), "v"(c));
+            for (int r = 0; r < NV; r++) {
+                if (ACC < 3) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f[(q * NV + r) & 15]) : "v"(m), "v"(c));
+                else asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0" : "+v"(f[(q * NV + r) & 15]) : "v"(m), "v"(c));   // ACC 3: ACC 0's MFMA, the staging's split instruction
+            }
         }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -197,7 +200,7 @@ void run_il(int iters)
     }
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     printf("interleaved, 1 wave/SIMD, %s: 8 x [MFMA + %d FMA]   wall ns/iter=%8.2f  = %6.2f ns per MFMA group\n",
-           ACC == 0 ? "C/D arch, A acc " : ACC == 1 ? "C/D acc, A arch " : "C/D acc, A acc  ", NV, ms * 1e6 / iters, ms * 1e6 / iters / 8);
+           ACC == 3 ? "C/D arch, A acc, v_fma_mixlo_f16" : ACC == 0 ? "C/D arch, A acc " : ACC == 1 ? "C/D acc, A arch " : "C/D acc, A acc  ", NV, ms * 1e6 / iters, ms * 1e6 / iters / 8);
     CK(hipFree(cyc)); CK(hipFree(sink));
 }
 
@@ -230,6 +233,7 @@ int main()
 {
     const int iters = 20000;
     run_il<0, 0>(iters); run_il<1, 0>(iters); run_il<2, 0>(iters); run_il<3, 0>(iters); run_il<4, 0>(iters); run_il<6, 0>(iters);
+    run_il<1, 3>(iters); run_il<2, 3>(iters); run_il<3, 3>(iters); run_il<4, 3>(iters); run_il<6, 3>(iters);
     run_il<0, 2>(iters); run_il<1, 2>(iters); run_il<2, 2>(iters); run_il<3, 2>(iters); run_il<4, 2>(iters);
     run_il<5, 2>(iters); run_il<6, 2>(iters); run_il<7, 2>(iters); run_il<8, 2>(iters); run_il<9, 2>(iters); run_il<10, 2>(iters); run_il<12, 2>(iters); run_il<14, 2>(iters);
     run_il<5, 0>(iters); run_il<7, 0>(iters); run_il<8, 0>(iters); run_il<10, 0>(iters);
