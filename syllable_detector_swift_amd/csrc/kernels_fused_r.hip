@@ -52,7 +52,8 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
     float *red = reinterpret_cast<float *>(smem + d.r_lds_red);      // [4 waves] block-max partials
     float *cst = reinterpret_cast<float *>(smem + d.r_lds_cst);
     constexpr int kom = 0, TMAX = T;      // the shared evaluation block's switches
-    constexpr bool SPECT = false, LEAN = true;
+    [[maybe_unused]] constexpr bool SPECT = false;
+    constexpr bool LEAN = true;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -518,6 +519,15 @@ hipError_t launch_one(const FusedDesc &d, const float *samples, int64_t stride, 
 // two layers, at most 4 TanSig hidden units, one output, at most one output map), 256-sample windows (8 k-steps),
 // timeRange 10, 9 staging quads per thread (hops 121..140, the reference's 132 among them) and no bank-spreading
 // padding (hop not a multiple of 16).  Everything else stays on kernels_fused.hip's kernel.
+bool fused_r_has_stamps()
+{
+#ifdef SYLDET_R_STAMPS
+    return true;
+#else
+    return false;
+#endif
+}
+
 bool fused_r_applicable(const FusedDesc &d)
 {
     const bool lean = d.norm == 1 && d.scaling == 0 && d.n_layers == 2 && d.tf0 == 0 /* TanSig */ && d.tf1 == 2 /* PureLin */ &&
@@ -532,7 +542,9 @@ hipError_t launch_fused_r(const FusedDesc &d, const float *samples, int64_t stri
     if (E <= 0 || C <= 0) return hipSuccess;
     if (!fused_r_applicable(d)) return hipErrorInvalidValue;
     const int64_t s_eff = (J - 1) * (int64_t)d.hop + d.gap + d.W;
+#ifdef SYLDET_R_STAMPS                // diagnostic builds only (-DSYLDET_R_STAMPS): the instantiation with phase timing
     if (d.stamps) return launch_one<8, 10, 9, false, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
+#endif
     return launch_one<8, 10, 9, false>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
 }
 

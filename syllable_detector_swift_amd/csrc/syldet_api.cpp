@@ -457,7 +457,7 @@ int run_on_stream(syldet *h, const float *d_samples, int64_t S, int64_t stride, 
         // workgroup pass spends its cycles (never set in tests or the benchmark)
         static const bool want_stamps = std::getenv("SYLDET_FUSED_STAMPS") != nullptr;
         if (want_stamps) {
-            const bool rk = fused_r_applicable(d) && !std::getenv("SYLDET_FUSED_CLASSIC");   // which kernel the launcher picks
+            const bool rk = fused_r_applicable(d) && fused_r_has_stamps() && !std::getenv("SYLDET_FUSED_CLASSIC");   // which kernel the launcher picks
             const int64_t seg = rk ? d.r_seg_evals : d.seg_evals;
             const size_t n = (size_t)((E + seg - 1) / seg) * (size_t)C * 16;
             if (int st = h->d_stamps.reserve(n * sizeof(unsigned long long))) return st;
