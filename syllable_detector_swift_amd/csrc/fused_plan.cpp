@@ -154,7 +154,8 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
         const int rn = (kFusedRTileFrames - 1) * hop + KS * 32;
         const int rl = (rn / 4 + kFusedRBlock - 1) / kFusedRBlock;
         // every thread always stages all of its quads: room for 1024 rl samples (those past rn are zeros nobody reads)
-        const int rn_p = (skewed(std::max(rn, 4 * kFusedRBlock * rl) + 16) + 15) / 8 * 8;
+        // (the instantiated kernel stages 9 quads a thread whatever the hop: room for those)
+        const int rn_p = (skewed(std::max(rn, 4 * kFusedRBlock * std::max(rl, 9)) + 16) + 15) / 8 * 8;
         const int rps = kFusedRTileFrames + 2 * (T - 1);
         int roff = 0;
         auto rtake = [&roff](int bytes) { const int o = roff; roff += (bytes + 15) / 16 * 16; return o; };

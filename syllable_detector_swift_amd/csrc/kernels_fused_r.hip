@@ -517,8 +517,8 @@ hipError_t launch_one(const FusedDesc &d, const float *samples, int64_t stride, 
 
 // Shapes this kernel is instantiated for: the reference's example detector class (l2normalize first, linear |X| columns,
 // two layers, at most 4 TanSig hidden units, one output, at most one output map), 256-sample windows (8 k-steps),
-// timeRange 10, 9 staging quads per thread (hops 121..140, the reference's 132 among them) and no bank-spreading
-// padding (hop not a multiple of 16).  Everything else stays on kernels_fused.hip's kernel.
+// timeRange 10, at most 9 staging quads per thread and at least 8 (hops 110..140, the reference's 132 among them) and no
+// bank-spreading padding (hop not a multiple of 16).  Everything else stays on kernels_fused.hip's kernel.
 bool fused_r_has_stamps()
 {
 #ifdef SYLDET_R_STAMPS
@@ -532,7 +532,7 @@ bool fused_r_applicable(const FusedDesc &d)
 {
     const bool lean = d.norm == 1 && d.scaling == 0 && d.n_layers == 2 && d.tf0 == 0 /* TanSig */ && d.tf1 == 2 /* PureLin */ &&
                       d.n_out == 1 && d.H <= 4 && d.n_out_fns <= 1;
-    return d.r_ok && d.KS == 8 && d.T == 10 && d.r_nload == 9 && d.skew == 0 && lean;
+    return d.r_ok && d.KS == 8 && d.T == 10 && (d.r_nload == 9 || d.r_nload == 8) && d.skew == 0 && lean;
 }
 
 hipError_t launch_fused_r(const FusedDesc &d, const float *samples, int64_t stride, int C, int64_t S, int64_t J,

@@ -163,3 +163,59 @@ def test_random_configuration_streaming(oracle_lib, seed):
     own = float((np.abs(o32[ok] - w64[ok]) / np.maximum(1.0, np.abs(w64[ok]))).max()) if ok.any() else 0.0
     if ok.any():
         util.assert_outputs_close(got[ok], w64[ok], max(util.TOL, 4.0 * own) if cfg.spectrum == _abi.SPECTRUM_POWER else max(1e-4, 30 * own))
+
+
+def draw_example_class(rng):
+    """The reference's example detector class, which runs on kernels_fused_r.hip: W = N = 256, timeRange 10, hop 116 / 120 /
+    124 / 132 / 136 / 140 (a multiple of 4 in 110..140, not of 16), l2normalize first, <= 4 TanSig hidden units, one linear
+    output, at most one output map; any band, window type, affine maps behind the normaliser, threshold, rule."""
+    hop = int(rng.choice([116, 120, 124, 132, 136, 140]))
+    f0 = int(rng.integers(0, 100))
+    F = int(rng.integers(1, 30))
+    lo, hi = max((f0 - 0.4) * FS / 256, 0.0), (f0 + F - 1 + 0.4) * FS / 256
+    r = frequencyIndexRange(256, FS, lo, hi)
+    F = r[1] - r[0]
+    chain = [("l2normalize",), ("l2normalize", "mapminmax"), ("l2normalize", "mapstd"), ("l2normalize", "mapstd", "mapminmax")][int(rng.integers(0, 4))]
+    net = nets.random_net(rng, F * 10, (int(rng.integers(1, 5)),), 1, transfer=("TanSig", "PureLin"), in_fns=chain,
+                          out_fns=[(), ("mapminmax",), ("mapstd",)][int(rng.integers(0, 3))])
+    return SyllableDetectorConfig(FS, 256, 256, 256 - hop, (lo, hi), 10, "linear", [float(rng.uniform(-0.5, 0.8))], net,
+                                  window=int(rng.integers(0, 4)), spectrum=_abi.SPECTRUM_POWER, rule=int(rng.integers(0, 2)))
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SYLDET_FUZZ_DRAWS", "24"))))
+def test_random_example_class_detector_on_the_register_resident_kernel(oracle_lib, seed):
+    """Lengths around the kernel's own boundaries (64-frame passes, 2039-evaluation segments, three passes in flight: one,
+    two, three passes and their neighbours), several channels, level steps of up to 50 dB inside and across passes."""
+    import torch
+    rng = np.random.default_rng(77000 + seed)
+    cfg = draw_example_class(rng)
+    hop = 256 - cfg.windowOverlap
+    edges = [10, 11, 63, 64, 65, 73, 74, 127, 128, 129, 137, 192, 201, 2047, 2048, 2049, 2057, 2058, 4100]
+    frames = int(edges[seed % len(edges)] if seed < len(edges) else rng.integers(10, 6000))
+    S = 256 + (frames - 1) * hop + int(rng.integers(0, hop))
+    C = int(rng.integers(1, 4))
+    x = synth.channels(C, S, first=seed * 5, fs=FS) * float(10.0 ** rng.uniform(-3, 1))
+    if rng.random() < 0.6:
+        env = np.ones(S)
+        for _ in range(int(rng.integers(1, 5))):
+            env[int(rng.integers(0, S)):] *= float(10.0 ** rng.uniform(-2.5, 2.5))
+        x = x * np.clip(env, 1e-3, 1e3)[None, :]
+    x = x.astype(np.float32)
+    o = util.oracle_for(cfg)
+    with sd.SyllableDetector(cfg, channels=C) as det:
+        det.profile(True)
+        out, fl = det.run(torch.from_numpy(x).cuda())
+        torch.cuda.synchronize()
+        assert [nm for nm, _ in det.lastTimings()] == ["fused_r_kernel"]
+        out, fl = out.cpu().numpy(), fl.cpu().numpy()
+    for c in range(C):
+        w32, _, w64 = o.run(x[c], po.F64, cfg.rule)
+        ok = np.isfinite(w64).all(axis=1)
+        own = float((np.abs(w32[ok] - w64[ok]) / np.maximum(1.0, np.abs(w64[ok]))).max()) if ok.any() else 0.0
+        assert out[c].shape == w64.shape
+        assert (np.isfinite(out[c]).all(axis=1) == ok).all(), "NaN/inf evaluations must coincide"
+        tol = max(util.TOL, 4.0 * own)
+        if ok.any():
+            util.assert_outputs_close(out[c][ok], w64[ok], tol)
+            util.assert_flags_exact(fl[c][ok], w64[ok], cfg.thresholds, cfg.rule, tol)
+        assert not fl[c][~ok].any()
