@@ -267,6 +267,83 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
     return true;
 }
 
+bool make_mlpx_plan(const syldet_config_t &c, const syldet_geometry_t &g, MlpxPlan &p)
+{
+    p = MlpxPlan();
+    auto no = [&p](const char *why) { p.reason = why; return false; };
+    const int F = g.bins, T = c.time_range, I = g.inputs;
+    if (c.spectrum == SYLDET_SPECTRUM_MAGNITUDE || c.scaling != SYLDET_SCALING_LINEAR) return no("not linear |X| columns");
+    if (c.n_layers != 2 || g.outputs != 1) return no("not two layers with one output");
+    const syldet_layer_t &L0 = c.layers[0], &L1 = c.layers[1];
+    const int H = L0.outputs;
+    if (H > 4 || L0.transfer != SYLDET_TF_TANSIG || L1.transfer != SYLDET_TF_PURELIN) return no("not <= 4 TanSig units and a linear output");
+    if (c.n_input_fns < 1 || c.input_fns[0].kind != SYLDET_FN_L2NORMALIZE) return no("input chain does not start with l2normalize");
+    if (c.n_output_fns > 1) return no("more than one output map");
+    if (F % 4 != 0 || F > 128) return no("bins not a multiple of 4 up to 128");
+    // affine tail of the input chain:  x = a o v' + b  (MapMinMax.apply NeuralNet.swift:127-131, MapStd.apply :162-169)
+    std::vector<double> a((size_t)I, 1.0), b((size_t)I, 0.0);
+    for (int k = 1; k < c.n_input_fns; k++) {
+        const syldet_fn_t &f = c.input_fns[k];
+        if (f.kind != SYLDET_FN_MAPMINMAX && f.kind != SYLDET_FN_MAPSTD) return no("a normaliser follows another input function");
+        for (int i = 0; i < I; i++) {
+            a[(size_t)i] = a[(size_t)i] * (double)f.gains[i];
+            b[(size_t)i] = (b[(size_t)i] - (double)f.x_offsets[i]) * (double)f.gains[i] + (double)f.y;
+        }
+    }
+    const int KB = F <= 64 ? 2 : 4;
+    MlpxDesc &d = p.desc;
+    d.F = F; d.T = T; d.KB = KB; d.H = H; d.rule = c.rule;
+    d.col_stride = 32 * KB + 8;                      // 16-byte aligned rows that spread 16 consecutive rows over all banks
+    int off = 0;
+    auto take = [&off](int bytes) { const int o = off; off += (bytes + 15) / 16 * 16; return o; };
+    const int nf = kMlpxTile + T - 1;                // frames one tile's windows cover
+    d.lds_afrag = take(T * KB * 2 * 1024);
+    d.lds_colh = take(nf * d.col_stride * 2);
+    d.lds_coll = take(nf * d.col_stride * 2);
+    d.lds_ss = take(nf * 8);                         // per-frame sums of squares, 64-bit fixed point
+    d.lds_red = take(64);
+    d.lds_total = off;
+    if (off > 160 * 1024) return no("LDS budget exceeded (timeRange x bins too large)");
+    // folded first layer (see make_fused_plan): W'_t[h][f] = W0[h][t*F+f] * a[t*F+f], scaled by 2^wexp, f16 hi + lo;
+    // A operand of v_mfma_f32_16x16x32_f16: lane l holds row l&15 (hidden unit), k = 8*(l>>4) + j (bin 32 kb + k)
+    double wmax = 0.0;
+    for (int h = 0; h < H; h++)
+        for (int i = 0; i < I; i++) wmax = std::max(wmax, std::fabs((double)L0.weights[(size_t)h * I + i] * a[(size_t)i]));
+    int wexp = wmax > 0.0 ? 13 - (int)std::ceil(std::log2(wmax)) : 0;
+    wexp = std::max(-100, std::min(100, wexp));
+    const double wscale = std::ldexp(1.0, wexp);
+    d.w_unscale = (float)std::ldexp(1.0, -wexp);
+    p.afrag.assign((size_t)T * KB * 2 * 64 * 8, 0);
+    for (int t = 0; t < T; t++)
+        for (int kb = 0; kb < KB; kb++)
+            for (int l = 0; l < 64; l++)
+                for (int j = 0; j < 8; j++) {
+                    const int h = l & 15, bin = 32 * kb + 8 * (l >> 4) + j;
+                    double v = 0.0;
+                    if (h < H && bin < F) v = (double)L0.weights[(size_t)h * I + t * F + bin] * a[(size_t)(t * F + bin)] * wscale;
+                    uint16_t hi, lo;
+                    split_half(v, hi, lo);
+                    p.afrag[((((size_t)t * KB + kb) * 2 + 0) * 64 + l) * 8 + j] = hi;
+                    p.afrag[((((size_t)t * KB + kb) * 2 + 1) * 64 + l) * 8 + j] = lo;
+                }
+    p.bias0.assign(4, 0.0f);
+    p.w1.assign(4, 0.0f);
+    for (int h = 0; h < H; h++) {
+        double sb = (double)L0.biases[h];
+        for (int i = 0; i < I; i++) sb += (double)L0.weights[(size_t)h * I + i] * b[(size_t)i];
+        p.bias0[(size_t)h] = (float)sb;
+        p.w1[(size_t)h] = L1.weights[h];
+    }
+    d.b1 = L1.biases[0];
+    d.oa = 0.0f; d.og = 1.0f; d.ob = 0.0f;           // reverse map (y - y0) / gain + xoff (NeuralNet.swift:137-142 / :175-180)
+    if (c.n_output_fns == 1) {
+        if (c.output_fns[0].kind != SYLDET_FN_MAPMINMAX && c.output_fns[0].kind != SYLDET_FN_MAPSTD) return no("output function is not a map");
+        d.oa = c.output_fns[0].y; d.og = c.output_fns[0].gains[0]; d.ob = c.output_fns[0].x_offsets[0];
+    }
+    p.ok = true;
+    return true;
+}
+
 void fused_segmentation(FusedDesc &d, int64_t E, int C)
 {
     // a workgroup segment = `runs` passes of 128 frames, emitting 128*runs - (T-1) evaluations; aim for

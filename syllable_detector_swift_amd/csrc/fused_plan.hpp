@@ -20,6 +20,16 @@ struct FusedPlan {
     std::vector<float> bias0, rvec, w1, b1, out_params;
 };
 
+struct MlpxPlan {
+    bool ok = false;
+    std::string reason;
+    MlpxDesc desc{};
+    std::vector<uint16_t> afrag;
+    std::vector<float> bias0, w1;
+};
+// the matrix-core network stage of the generic engine (kernels_mlpx.hip), when the configuration is of its class
+bool make_mlpx_plan(const syldet_config_t &cfg, const syldet_geometry_t &geom, MlpxPlan &plan);
+
 bool make_fused_plan(const syldet_config_t &cfg, const syldet_geometry_t &geom, FusedPlan &plan);
 // choose passes per workgroup for a batch of E evaluations x C channels
 void fused_segmentation(FusedDesc &d, int64_t E, int C);

@@ -126,6 +126,27 @@ struct FusedDesc {
     unsigned long long *stamps; // diagnostic build only: [workgroups][16] phase cycle sums, else null
 };
 
+// ---- first layer on the matrix cores for spectrograms already in HBM (kernels_mlpx.hip) --------------------
+// The generic engine's network stage for the detector class the training script writes (l2normalize first, affine
+// maps, TanSig hidden layer of at most 4 units, one linear output, at most one output map, linear |X| columns) when the
+// band is too wide or the window too long for the fused engine (BASELINE configs[2]: 116 bins of 1024-point frames):
+// the fused engine's shifted GEMM over f16 hi/lo columns, fed from [C][J][F] columns instead of from its own DFT.
+constexpr int kMlpxBlock = 512;          // 8 waves, 16 evaluations each
+constexpr int kMlpxTile = 128;           // evaluations per tile
+struct MlpxDesc {
+    int F, T, KB, H;            // bins, timeRange, 32-bin blocks per tap (F <= 32 KB), hidden units
+    int rule;
+    int col_stride;             // halves per column row in LDS: 32 KB + 8
+    float w_unscale, b1, oa, og, ob;   // 1 / scale of the folded weights; second layer bias; output map (y - oa) / og + ob
+    int lds_afrag, lds_colh, lds_coll, lds_ss, lds_red, lds_total;   // byte offsets
+    const uint4 *afrag;         // [T][KB][hi,lo][64 lanes] A-operand fragments of the folded first layer
+    const float *bias0, *w1;    // [4] folded first-layer biases, second-layer weights (zero padded)
+    const double *thresholds;   // [1]
+};
+// outputs [C][E][1], flags [C][E] <- columns [C][J][F]
+hipError_t launch_mlpx(const MlpxDesc &d, const float *columns, int C, int64_t J, int64_t E, float *outputs, uint8_t *flags,
+                       hipStream_t stream);
+
 // ResamplerLinear (Common/Resampler.swift:36-69) for C channels at once; `last` is the per-channel carry on the device
 hipError_t launch_resample_linear(const float *in, int64_t n_in, int64_t in_stride, float *out, int64_t n_out,
                                   int64_t out_stride, int C, float step, float offset, float *last, hipStream_t stream);

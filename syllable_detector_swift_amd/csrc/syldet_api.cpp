@@ -139,6 +139,10 @@ struct syldet {
     DeviceBuffer d_dft;
     bool has_dft = false;
 
+    // the generic engine's network stage on the matrix cores, where the configuration is of its class (kernels_mlpx.hip)
+    MlpxPlan mlpx;
+    DeviceBuffer d_mlpx;              // afrag | bias0 | w1
+
     // wide-network engine (SYLDET_ENGINE_WIDE_BF16)
     WideDesc wide{};
     DeviceBuffer d_wide;              // packed first-layer chunks | b1 | output maps
@@ -355,6 +359,24 @@ int upload_plan(syldet *h, FusedPlan &p, DeviceBuffer &buf)
 
 int upload_fused(syldet *h) { return upload_plan(h, h->fused, h->d_fused); }
 
+int upload_mlpx(syldet *h)
+{
+    MlpxPlan &p = h->mlpx;
+    const size_t a_bytes = (p.afrag.size() * 2 + 255) / 256 * 256;
+    std::vector<unsigned char> blob(a_bytes + 64);
+    std::memcpy(blob.data(), p.afrag.data(), p.afrag.size() * 2);
+    std::memcpy(blob.data() + a_bytes, p.bias0.data(), 16);
+    std::memcpy(blob.data() + a_bytes + 16, p.w1.data(), 16);
+    if (int st = h->d_mlpx.reserve(blob.size())) return st;
+    SYLDET_HIP(hipMemcpy(h->d_mlpx.ptr, blob.data(), blob.size(), hipMemcpyHostToDevice));
+    unsigned char *base = (unsigned char *)h->d_mlpx.ptr;
+    p.desc.afrag = (const uint4 *)base;
+    p.desc.bias0 = (const float *)(base + a_bytes);
+    p.desc.w1 = (const float *)(base + a_bytes + 16);
+    p.desc.thresholds = (const double *)h->d_thr.ptr;
+    return SYLDET_OK;
+}
+
 // A plan for the DFT front half alone: the real STFT geometry with a one-frame, one-unit stand-in network (the
 // spectrogram instantiation never touches the network tables).
 int build_dft_plan(syldet *h)
@@ -507,6 +529,11 @@ int run_on_stream(syldet *h, const float *d_samples, int64_t S, int64_t stride, 
         return SYLDET_OK;
     }
     if (int st = stft_on_stream(h, d_samples, stride, C, J, (float *)h->d_columns.ptr, stream)) return st;
+    if (h->mlpx.ok && (uint64_t)E * 4u < 0xFFFFFFF0ull) {
+        KernelTimer t(h, stream, "mlp_mfma_kernel");
+        SYLDET_HIP(launch_mlpx(h->mlpx.desc, (const float *)h->d_columns.ptr, C, J, E, d_outputs, d_flags, stream));
+        return SYLDET_OK;
+    }
     {
         KernelTimer t(h, stream, "mlp_generic_kernel");
         SYLDET_HIP(launch_mlp_generic(h->net, h->geom.bins, (const float *)h->d_columns.ptr, C, J, E, d_outputs,
@@ -580,6 +607,15 @@ int syldet_create(const syldet_config_t *cfg, int32_t n_channels, int32_t device
             return st;
         }
     }
+    // AUTO on the generic engine: the network stage goes to the matrix cores where the configuration is of that kernel's
+    // class (a handle created for SYLDET_ENGINE_GENERIC keeps the reference's operation order throughout)
+    static const bool no_mlpx = std::getenv("SYLDET_NO_MLPX") != nullptr;
+    if (engine == SYLDET_ENGINE_AUTO && h->engine == SYLDET_ENGINE_GENERIC && !no_mlpx && make_mlpx_plan(h->cfg.view, h->geom, h->mlpx)) {
+        if (int st = upload_mlpx(h.get())) {
+            syldet_destroy(h.release());
+            return st;
+        }
+    }
     if (engine != SYLDET_ENGINE_GENERIC) {
         if (int st = build_dft_plan(h.get())) {
             syldet_destroy(h.release());
@@ -623,7 +659,7 @@ int syldet_destroy(syldet_t *h)
         (void)hipStreamDestroy(h->stream);
     }
     for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
-    for (DeviceBuffer *b : {&h->d_window, &h->d_tw, &h->d_sw, &h->d_params, &h->d_thr, &h->d_columns, &h->d_fused, &h->d_stamps, &h->d_planar, &h->d_wide, &h->d_xn, &h->d_dft, &h->d_stage_in,
+    for (DeviceBuffer *b : {&h->d_window, &h->d_tw, &h->d_sw, &h->d_params, &h->d_thr, &h->d_columns, &h->d_fused, &h->d_mlpx, &h->d_stamps, &h->d_planar, &h->d_wide, &h->d_xn, &h->d_dft, &h->d_stage_in,
                             &h->d_stage_out, &h->d_stage_flags, &h->d_stage_idx, &h->d_stage_cnt})
         b->release();
     h->p_stage_in.release();

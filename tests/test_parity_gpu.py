@@ -386,3 +386,40 @@ def test_register_resident_kernel_is_only_taken_where_it_is_instantiated(oracle_
             assert [nm for nm, _ in det.lastTimings()] == ["fused_kernel"]
         _, _, w64 = util.oracle_for(cfg).run(x[0], po.F64)
         util.assert_outputs_close(out.cpu().numpy()[0], w64)
+
+
+@pytest.mark.parametrize("N,lo,hi,T,H", [(1024, 2000.0, 7000.0, 10, 4), (512, 1000.0, 6150.0, 8, 3), (1024, 3000.0, 8500.0, 6, 1), (256, 500.0, 7300.0, 12, 2)])
+def test_network_stage_on_the_matrix_cores(oracle_lib, N, lo, hi, T, H):
+    """Bands too wide / windows too long for the fused engine (BASELINE configs[2] first): under AUTO the generic engine's
+    network stage is kernels_mlpx.hip's when the detector is of its class (l2normalize first, <= 4 TanSig units, one linear
+    output, bins a multiple of 4); a handle created for SYLDET_ENGINE_GENERIC keeps the interpretive kernels.  Both meet
+    the oracle.  Ragged length (the last tile is partial), two channels, a level step, a stretch of silence (0/0 -> NaN)."""
+    torch = _torch()
+    from syllable_detector_swift_amd.config import SyllableDetectorConfig, frequencyIndexRange
+    rng = np.random.default_rng(N + T)
+    f0, f1 = frequencyIndexRange(N, 44100.0, lo, hi)
+    F = f1 - f0
+    assert F % 4 == 0 and F > 32, F
+    net = nets.random_net(rng, F * T, (H,), 1, in_fns=("l2normalize", "mapminmax"), out_fns=("mapminmax",) if H != 3 else ())
+    cfg = SyllableDetectorConfig(44100.0, N, N, N - N // 4, (lo, hi), T, "linear", [0.4], net)
+    S = N + (N // 4) * 700 + 37
+    x = synth.channels(2, S, first=3).astype(np.float32)
+    x[:, S // 2:] *= np.float32(0.003)
+    x[1, 20000:20000 + 40 * N] = 0.0
+    xd = torch.from_numpy(x).cuda()
+    o = util.oracle_for(cfg)
+    for engine, kernel in ((_abi.ENGINE_AUTO, "mlp_mfma_kernel"), (_abi.ENGINE_GENERIC, "mlp_generic_kernel")):
+        with sd.SyllableDetector(cfg, channels=2, engine=engine) as det:
+            det.profile(True)
+            out, fl = det.run(xd)
+            torch.cuda.synchronize()
+            assert [nm for nm, _ in det.lastTimings()][-1] == kernel
+            out, fl = out.cpu().numpy(), fl.cpu().numpy()
+        for c in range(2):
+            _, _, w64 = o.run(x[c], po.F64)
+            ok = np.isfinite(w64).all(axis=1)
+            assert (np.isfinite(out[c]).all(axis=1) == ok).all(), "NaN evaluations must coincide"
+            assert c == 0 or (~ok).any()
+            util.assert_outputs_close(out[c][ok], w64[ok])
+            util.assert_flags_exact(fl[c][ok], w64[ok], cfg.thresholds, cfg.rule)
+            assert not fl[c][~ok].any()
