@@ -290,22 +290,26 @@ bool make_mlpx_plan(const syldet_config_t &c, const syldet_geometry_t &g, MlpxPl
             b[(size_t)i] = (b[(size_t)i] - (double)f.x_offsets[i]) * (double)f.gains[i] + (double)f.y;
         }
     }
+    if (T > 12) return no("timeRange above 12");
     const int KB = F <= 64 ? 2 : 4;
     MlpxDesc &d = p.desc;
     d.F = F; d.T = T; d.KB = KB; d.H = H; d.rule = c.rule;
     d.col_stride = 32 * KB + 8;                      // 16-byte aligned rows that spread 16 consecutive rows over all banks
+    d.p_stride = 48 + 4;                             // floats per frame of tap products: 12 taps x 4 units, padded likewise
     int off = 0;
     auto take = [&off](int bytes) { const int o = off; off += (bytes + 15) / 16 * 16; return o; };
-    const int nf = kMlpxTile + T - 1;                // frames one tile's windows cover
-    d.lds_afrag = take(T * KB * 2 * 1024);
-    d.lds_colh = take(nf * d.col_stride * 2);
-    d.lds_coll = take(nf * d.col_stride * 2);
-    d.lds_ss = take(nf * 8);                         // per-frame sums of squares, 64-bit fixed point
+    d.lds_afrag = take(3 * KB * 2 * 1024);
+    d.lds_colh = take(kMlpxTile * d.col_stride * 2);
+    d.lds_coll = take(kMlpxTile * d.col_stride * 2);
+    d.lds_p = take(kMlpxTile * d.p_stride * 4);
+    d.lds_pq = take(kMlpxTile * 32 * 4);             // sums of squares per quad of column values (at most 32 quads a frame)
+    d.lds_ss = take(2 * kMlpxTile * 4);              // per-frame sums of squares, two tiles (parity)
     d.lds_red = take(64);
     d.lds_total = off;
-    if (off > 160 * 1024) return no("LDS budget exceeded (timeRange x bins too large)");
-    // folded first layer (see make_fused_plan): W'_t[h][f] = W0[h][t*F+f] * a[t*F+f], scaled by 2^wexp, f16 hi + lo;
-    // A operand of v_mfma_f32_16x16x32_f16: lane l holds row l&15 (hidden unit), k = 8*(l>>4) + j (bin 32 kb + k)
+    if (off > 160 * 1024) return no("LDS budget exceeded");
+    // folded first layer (see make_fused_plan): W'_t[h][f] = W0[h][t*F+f] * a[t*F+f], scaled by 2^wexp, f16 hi + lo.
+    // ALL taps are rows of one GEMM: row 4t + h of the A operand (three 16-row tiles hold 12 taps x 4 units), K = bins.
+    // A operand of v_mfma_f32_16x16x32_f16: lane l holds row 16m + (l&15), k = 8*(l>>4) + j (bin 32 kb + k).
     double wmax = 0.0;
     for (int h = 0; h < H; h++)
         for (int i = 0; i < I; i++) wmax = std::max(wmax, std::fabs((double)L0.weights[(size_t)h * I + i] * a[(size_t)i]));
@@ -313,18 +317,18 @@ bool make_mlpx_plan(const syldet_config_t &c, const syldet_geometry_t &g, MlpxPl
     wexp = std::max(-100, std::min(100, wexp));
     const double wscale = std::ldexp(1.0, wexp);
     d.w_unscale = (float)std::ldexp(1.0, -wexp);
-    p.afrag.assign((size_t)T * KB * 2 * 64 * 8, 0);
-    for (int t = 0; t < T; t++)
+    p.afrag.assign((size_t)3 * KB * 2 * 64 * 8, 0);
+    for (int m = 0; m < 3; m++)
         for (int kb = 0; kb < KB; kb++)
             for (int l = 0; l < 64; l++)
                 for (int j = 0; j < 8; j++) {
-                    const int h = l & 15, bin = 32 * kb + 8 * (l >> 4) + j;
+                    const int r = 16 * m + (l & 15), t = r / 4, h = r % 4, bin = 32 * kb + 8 * (l >> 4) + j;
                     double v = 0.0;
-                    if (h < H && bin < F) v = (double)L0.weights[(size_t)h * I + t * F + bin] * a[(size_t)(t * F + bin)] * wscale;
+                    if (t < T && h < H && bin < F) v = (double)L0.weights[(size_t)h * I + t * F + bin] * a[(size_t)(t * F + bin)] * wscale;
                     uint16_t hi, lo;
                     split_half(v, hi, lo);
-                    p.afrag[((((size_t)t * KB + kb) * 2 + 0) * 64 + l) * 8 + j] = hi;
-                    p.afrag[((((size_t)t * KB + kb) * 2 + 1) * 64 + l) * 8 + j] = lo;
+                    p.afrag[((((size_t)m * KB + kb) * 2 + 0) * 64 + l) * 8 + j] = hi;
+                    p.afrag[((((size_t)m * KB + kb) * 2 + 1) * 64 + l) * 8 + j] = lo;
                 }
     p.bias0.assign(4, 0.0f);
     p.w1.assign(4, 0.0f);

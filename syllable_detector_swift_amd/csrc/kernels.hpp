@@ -131,15 +131,16 @@ struct FusedDesc {
 // maps, TanSig hidden layer of at most 4 units, one linear output, at most one output map, linear |X| columns) when the
 // band is too wide or the window too long for the fused engine (BASELINE configs[2]: 116 bins of 1024-point frames):
 // the fused engine's shifted GEMM over f16 hi/lo columns, fed from [C][J][F] columns instead of from its own DFT.
-constexpr int kMlpxBlock = 512;          // 8 waves, 16 evaluations each
-constexpr int kMlpxTile = 128;           // evaluations per tile
+constexpr int kMlpxBlock = 512;          // 8 waves, 16 frames each
+constexpr int kMlpxTile = 128;           // frames per tile (its windows: 128 - timeRange + 1 evaluations)
 struct MlpxDesc {
     int F, T, KB, H;            // bins, timeRange, 32-bin blocks per tap (F <= 32 KB), hidden units
     int rule;
     int col_stride;             // halves per column row in LDS: 32 KB + 8
+    int p_stride;               // floats per frame row of tap products in LDS
     float w_unscale, b1, oa, og, ob;   // 1 / scale of the folded weights; second layer bias; output map (y - oa) / og + ob
-    int lds_afrag, lds_colh, lds_coll, lds_ss, lds_red, lds_total;   // byte offsets
-    const uint4 *afrag;         // [T][KB][hi,lo][64 lanes] A-operand fragments of the folded first layer
+    int lds_afrag, lds_colh, lds_coll, lds_p, lds_pq, lds_ss, lds_red, lds_total;   // byte offsets
+    const uint4 *afrag;         // [3 row tiles][KB][hi,lo][64 lanes] A-operand fragments: row 4 t + h = tap t, hidden unit h
     const float *bias0, *w1;    // [4] folded first-layer biases, second-layer weights (zero padded)
     const double *thresholds;   // [1]
 };

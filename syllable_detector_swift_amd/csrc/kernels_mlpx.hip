@@ -6,15 +6,20 @@
 // (Common/SyllableDetector.swift:27-31), for spectrogram columns that are already in HBM ([C][J][F] fp32, written by the
 // generic STFT kernels: long windows, wide bands -- BASELINE configs[2]).
 //
-// The fused engine's formulation, fed from memory instead of from its own DFT: a tile of 128 evaluations reads its
-// 128 + timeRange - 1 columns once (coalesced quads), scales them by one power of two (the tile's largest value goes to
-// [2^13, 2^14): block floating point), splits them into f16 hi + lo in LDS, and the first layer -- folded on the host with
-// the affine input maps -- is a GEMM on the matrix cores whose B operand for tap t is simply the column buffer at row
-// offset e + t (v_mfma_f32_16x16x32_f16; hi*hi + hi*lo + lo*hi reproduces the fp32 product, fp32 accumulate).  The
-// l2normalize denominator comes from per-frame sums of squares accumulated while the columns are split (64-bit fixed
-// point in LDS, so that the sum does not depend on the order the threads arrive in).  The rest of the network runs in
-// registers.  The interpretive kernels (kernels_generic.hip) evaluate the same network with one wave per evaluation on
-// the vector units: 2.7 ms against this kernel's time on the configs[2] batch.
+// Formulation: with the affine input maps folded into the first layer on the host, the layer's input to unit h for
+// evaluation e is  sum_t W'_t[h, :] . c(e + t)  over the timeRange columns c of its window.  Every column meets every
+// tap exactly once, so ALL taps are the rows of one plain GEMM
+//     P[(t, h), j] = W'_t[h, :] . c(j)          (rows 4 t + h: 12 taps x 4 units = three 16-row tiles; K = bins; N = frames)
+// on the matrix cores (v_mfma_f32_16x16x32_f16; every operand f16 hi + lo, hi*hi + hi*lo + lo*hi reproduces the fp32
+// product, fp32 accumulate), and an evaluation is the diagonal sum  sum_t P[(t, h), e + t]  read back from LDS.  Against
+// one GEMM per tap (the fused kernels' shape: 4 of 16 rows used, every column fetched timeRange times) that is 3.3x
+// fewer MFMAs and 20x less LDS traffic.
+//
+// A tile = 128 frames of one channel (16 per wave): read once as coalesced quads (the next tile's are in flight meanwhile),
+// scaled by one power of two (the tile's largest value goes to [2^13, 2^14): block floating point), split into f16 hi + lo
+// in LDS; the l2normalize denominator comes from sums of squares taken per quad while the columns are split and added per
+// frame in a fixed order (no atomics: results do not depend on the order the threads arrive in); tap products go to LDS;
+// the tile's 128 - timeRange + 1 evaluations finish in registers, one thread each.
 //
 // gfx950 only.  wave = 64.
 
@@ -38,42 +43,47 @@ mlp_mfma_kernel(const MlpxDesc d, const float *__restrict__ columns, int64_t J, 
     uint32x4 *afr = reinterpret_cast<uint32x4 *>(smem + d.lds_afrag);
     _Float16 *colh = reinterpret_cast<_Float16 *>(smem + d.lds_colh);
     _Float16 *coll = reinterpret_cast<_Float16 *>(smem + d.lds_coll);
-    unsigned long long *ss = reinterpret_cast<unsigned long long *>(smem + d.lds_ss);
+    float *pbuf = reinterpret_cast<float *>(smem + d.lds_p);
+    float *pq = reinterpret_cast<float *>(smem + d.lds_pq);          // [frame][F / 4] sums of squares per quad
+    float *ss0 = reinterpret_cast<float *>(smem + d.lds_ss);         // [2 tiles][128] sums of squares per frame
     float *red = reinterpret_cast<float *>(smem + d.lds_red);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int f = lane & 15, g4 = lane >> 4;
     const int c = blockIdx.y;
-    const int F = d.F, T = d.T, CS = d.col_stride;
-    const int nf = kTile + T - 1;                     // frames a tile's windows cover
-    const int nq = nf * F / 4;                        // quads of column values per tile (F is a multiple of 4)
+    const int F = d.F, T = d.T, CS = d.col_stride, PS = d.p_stride;
+    const int step = kTile - (T - 1);                 // evaluations per tile = frames a tile advances by
+    const int nq = kTile * F / 4;                     // quads of column values per tile (F is a multiple of 4)
     const float *chan = columns + (int64_t)c * J * F;
     const unsigned fmagic = (unsigned)((0x100000000ull + (unsigned)(F / 4) - 1) / (unsigned)(F / 4));   // q / (F/4) == umulhi(q, fmagic), q < 2^16
 
     // once per workgroup: the folded first layer's fragments -> LDS
-    for (int i = tid; i < T * KB * 2 * 64; i += kBlock) afr[i] = reinterpret_cast<const uint32x4 *>(d.afrag)[i];
-    float c_b0[4], c_w1[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {                     // rows 4*g4 + j of a result: only lane group 0 holds hidden units (H <= 4)
-        c_b0[j] = g4 == 0 ? d.bias0[j] : 0.0f;
-        c_w1[j] = g4 == 0 ? d.w1[j] : 0.0f;
-    }
+    for (int i = tid; i < 3 * KB * 2 * 64; i += kBlock) afr[i] = reinterpret_cast<const uint32x4 *>(d.afrag)[i];
+    const float b0[4] = {d.bias0[0], d.bias0[1], d.bias0[2], d.bias0[3]}, w1[4] = {d.w1[0], d.w1[1], d.w1[2], d.w1[3]};
     const double thr = d.thresholds[0];
     const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(outputs ? outputs + (int64_t)c * E : nullptr, 0, outputs ? (int)(E * 4) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t flg_rs = __builtin_amdgcn_make_buffer_rsrc(flags ? flags + (int64_t)c * E : nullptr, 0, flags ? (int)E : 0, 0x00020000);
 
-    constexpr int NQ = 9;                             // quads per thread: (128 + 11) * 128 / 4 / 512 rounded up
-    for (int tile = blockIdx.x; tile < tiles_per_channel; tile += gridDim.x) {
-        const int64_t e0 = (int64_t)tile * kTile;     // first evaluation = first frame of the tile
-        // ---- columns of frames e0 .. e0 + nf - 1: contiguous in memory; quads past the channel's last frame read as zeros
-        const int64_t left = (J - e0) * F;            // floats from the tile's first column to the end of the channel
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float *>(chan + e0 * F), 0, (int)((left < (int64_t)nf * F ? left : (int64_t)nf * F) * 4), 0x00020000);
-        uint32x4 v[NQ];
+    constexpr int NQ = 8;                             // quads per thread: 128 frames x 128 bins / 4 / 512
+    // columns of frames e0 .. e0 + 127 are contiguous in memory; quads past the channel's last frame read as zeros
+    auto tile_rs = [&](int tile) {
+        const int64_t e0 = (int64_t)tile * step;
+        int64_t left = tile < tiles_per_channel ? (J - e0) * F : 0;    // floats from the tile's first column to the end of the channel
+        left = left < 0 ? 0 : (left > (int64_t)kTile * F ? (int64_t)kTile * F : left);
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(chan + e0 * F), 0, (int)left * 4, 0x00020000);
+    };
+    uint32x4 v[NQ];
+    {
+        const __amdgpu_buffer_rsrc_t rs = tile_rs(blockIdx.x);
 #pragma unroll
         for (int k = 0; k < NQ; k++) v[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * (tid + kBlock * k), 0, 0);
-        if (tid < nf) ss[tid] = 0ull;
+    }
+    int parity = 0;
+    for (int tile = blockIdx.x; tile < tiles_per_channel; tile += gridDim.x, parity ^= 1) {
+        const int64_t e0 = (int64_t)tile * step;      // first evaluation = first frame of the tile
+        // (the sums alternate between two buffers: the previous tile's evaluations may still be reading theirs)
+        float *ss = ss0 + parity * kTile;
         float amax = 0.0f;
 #pragma unroll
         for (int k = 0; k < NQ; k++) {
@@ -82,7 +92,7 @@ mlp_mfma_kernel(const MlpxDesc d, const float *__restrict__ columns, int64_t J, 
         }
         amax = wave_max_nonneg(amax);
         if (lane == 0) red[wave] = amax;
-        __syncthreads();
+        __syncthreads();          // partial maxima in
         int se;
         {
             const floatx4 r0 = *reinterpret_cast<const floatx4 *>(red), r1 = *reinterpret_cast<const floatx4 *>(red + 4);
@@ -106,56 +116,75 @@ mlp_mfma_kernel(const MlpxDesc d, const float *__restrict__ columns, int64_t J, 
                 *reinterpret_cast<uint32x2 *>(colh + fr * CS + bin) = uh;
                 *reinterpret_cast<uint32x2 *>(coll + fr * CS + bin) = ul;
                 const float a0 = x[0] * sx, a1 = x[1] * sx, a2 = x[2] * sx, a3 = x[3] * sx;
-                const float p = fmaf(a0, a0, fmaf(a1, a1, fmaf(a2, a2, a3 * a3)));      // < 2^30
-                // p * 2^20 as a 64-bit integer (integer sums do not depend on the order the threads arrive in):
-                // p = ph * 4096 + rem exactly, so p * 2^20 = ph * 2^32 + rem * 2^20 with rem * 2^20 < 2^32
-                const unsigned ph = (unsigned)(p * (1.0f / 4096.0f));
-                const unsigned pl = (unsigned)(fmaf(-(float)ph, 4096.0f, p) * 1048576.0f);
-                atomicAdd(&ss[fr], ((unsigned long long)ph << 32) | pl);
+                pq[q] = fmaf(a0, a0, fmaf(a1, a1, fmaf(a2, a2, a3 * a3)));              // summed per frame below, in a fixed order
             }
         }
-        // bins F .. 32 KB - 1 of every row are read by the last k-block: zero them once per tile (the weights there are zero
-        // too, but 0 * NaN from stale LDS is not)
-        for (int i = tid; i < nf * ((32 * KB - F) / 4); i += kBlock) {
+        // the staging registers are free: the next tile's columns start their way from HBM
+        {
+            const __amdgpu_buffer_rsrc_t rs = tile_rs(tile + (int)gridDim.x);
+#pragma unroll
+            for (int k = 0; k < NQ; k++) v[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * (tid + kBlock * k), 0, 0);
+        }
+        // bins F .. 32 KB - 1 of every row are read by the last k-block: zeros (the weights there are zero too, but
+        // 0 * NaN from stale LDS is not)
+        for (int i = tid; i < kTile * ((32 * KB - F) / 4); i += kBlock) {
             const int per = (32 * KB - F) / 4, fr = i / per, bin = F + 4 * (i - fr * per);
             uint32x2 z = {0u, 0u};
             *reinterpret_cast<uint32x2 *>(colh + fr * CS + bin) = z;
             *reinterpret_cast<uint32x2 *>(coll + fr * CS + bin) = z;
         }
         __syncthreads();
-        // ---- first layer: Z[h, e] = sum_t sum_kb W'_{t,kb}[h, :] . C[32 kb .., e + t]; this wave's 16 evaluations
-        const int slot = 16 * wave + f;
-        floatx4 z = {0.f, 0.f, 0.f, 0.f}, z2 = {0.f, 0.f, 0.f, 0.f};
-        const _Float16 *bph = colh + slot * CS + 8 * g4, *bpl = coll + slot * CS + 8 * g4;
-        for (int t = 0; t < T; t++) {
+        // ---- tap products of this wave's 16 frames: P[(t, h), j] for all taps at once, three row tiles
+        {
+            const int fr = 16 * wave + f;
+            const _Float16 *bph = colh + fr * CS + 8 * g4, *bpl = coll + fr * CS + 8 * g4;
+            floatx4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
             for (int kb = 0; kb < KB; kb++) {
-                const half8 bh = as_half8(*reinterpret_cast<const uint32x4 *>(bph + t * CS + 32 * kb));
-                const half8 bl = as_half8(*reinterpret_cast<const uint32x4 *>(bpl + t * CS + 32 * kb));
-                const half8 ah = as_half8(afr[((t * KB + kb) * 2 + 0) * 64 + lane]), al = as_half8(afr[((t * KB + kb) * 2 + 1) * 64 + lane]);
-                z = mfma(ah, bh, z);
-                z2 = mfma(ah, bl, z2);
-                z2 = mfma(al, bh, z2);
-            }
-        }
-        z += z2;
-        // ---- l2normalize (NeuralNet.swift:47-59): z and the sums of squares are both in scaled-column units
-        unsigned long long ssw = 0ull;
-        for (int t = 0; t < T; t++) ssw += ss[slot + t];
-        const float alpha = d.w_unscale * __builtin_amdgcn_rsqf((float)ssw * (1.0f / 1048576.0f));
-        float y = d.b1;
+                const half8 bh = as_half8(*reinterpret_cast<const uint32x4 *>(bph + 32 * kb));
+                const half8 bl = as_half8(*reinterpret_cast<const uint32x4 *>(bpl + 32 * kb));
 #pragma unroll
-        for (int j = 0; j < 4; j++) {                 // TanSig hidden units (padding rows meet zero weights), linear output
-            const float a = fmaf(alpha, z[j], c_b0[j]);
-            const float th = fmaf(-2.0f, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(a * 2.885390081777927f) + 1.0f), 1.0f);
-            y = fmaf(c_w1[j], th, y);
+                for (int m = 0; m < 3; m++) {
+                    const half8 ah = as_half8(afr[((m * KB + kb) * 2 + 0) * 64 + lane]), al = as_half8(afr[((m * KB + kb) * 2 + 1) * 64 + lane]);
+                    acc[m] = mfma(ah, bh, acc[m]);
+                    acc[m] = mfma(ah, bl, acc[m]);
+                    acc[m] = mfma(al, bh, acc[m]);
+                }
+            }
+            // result layout: column = frame f, register i of lane group g4 in tile m = row 16 m + 4 g4 + i = tap 4 m + g4,
+            // unit i: four consecutive floats of the frame's row in pbuf
+#pragma unroll
+            for (int m = 0; m < 3; m++) *reinterpret_cast<floatx4 *>(pbuf + fr * PS + 4 * (4 * m + g4)) = acc[m];
         }
-        y = (y - d.oa) / d.og + d.ob;
-        const int64_t e = e0 + slot;
-        const bool st = g4 == 0 && e < E;
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y), out_rs, st ? (unsigned)e * 4u : 0xFFFFFFFFu, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)((double)y >= thr ? 1 : 0), flg_rs, st ? (unsigned)e : 0xFFFFFFFFu, 0, 0);
-        __syncthreads();          // the column buffer and the sums are free for the next tile
+        if (tid < kTile) {                            // the frame's sum of squares: its F / 4 quads, in order
+            float s = 0.0f;
+            for (int i = 0; i < F / 4; i++) s += pq[tid * (F / 4) + i];
+            ss[tid] = s;
+        }
+        __syncthreads();
+        // ---- evaluations e0 .. e0 + step - 1, one thread each: diagonal sum over the taps, l2normalize
+        // (NeuralNet.swift:47-59: z and the sums of squares are both in scaled-column units), the rest of the network
+        if (tid < step) {
+            floatx4 z = {0.f, 0.f, 0.f, 0.f};
+            float ssw = 0.0f;
+            for (int t = 0; t < T; t++) {
+                z += *reinterpret_cast<const floatx4 *>(pbuf + (tid + t) * PS + 4 * t);
+                ssw += ss[tid + t];
+            }
+            const float alpha = d.w_unscale * __builtin_amdgcn_rsqf(ssw);
+            float y = d.b1;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {             // TanSig hidden units (rows past H meet zero weights), linear output
+                const float a = fmaf(alpha, z[j], b0[j]);
+                const float th = fmaf(-2.0f, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(a * 2.885390081777927f) + 1.0f), 1.0f);
+                y = fmaf(w1[j], th, y);
+            }
+            y = (y - d.oa) / d.og + d.ob;
+            const int64_t e = e0 + tid;
+            const bool st = e < E;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y), out_rs, st ? (unsigned)e * 4u : 0xFFFFFFFFu, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b8((unsigned char)((double)y >= thr ? 1 : 0), flg_rs, st ? (unsigned)e : 0xFFFFFFFFu, 0, 0);
+        }
     }
 }
 
@@ -165,11 +194,12 @@ hipError_t launch_mlpx(const MlpxDesc &d, const float *columns, int C, int64_t J
                        hipStream_t stream)
 {
     if (E <= 0 || C <= 0) return hipSuccess;
-    // 32-bit byte offsets per channel (outputs) and per tile (columns)
+    // 32-bit byte offsets per channel (outputs)
     if ((uint64_t)E * 4u >= 0xFFFFFFF0ull) return hipErrorInvalidValue;
-    const int64_t tiles = (E + kTile - 1) / kTile;
+    const int step = kTile - (d.T - 1);
+    const int64_t tiles = (E + step - 1) / step;
     // a workgroup keeps the first layer's fragments in LDS and walks tiles of one channel: enough workgroups to fill the
-    // chip a few times over, few enough that loading the fragments stays a small part of the work
+    // chip a few times over
     int64_t per_channel = (4096 + C - 1) / C;
     per_channel = per_channel < 1 ? 1 : (per_channel > tiles ? tiles : per_channel);
     dim3 grid((unsigned)per_channel, (unsigned)C);
