@@ -161,9 +161,7 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
         auto rtake = [&roff](int bytes) { const int o = roff; roff += (bytes + 15) / 16 * 16; return o; };
         d.r_nsmp = rn; d.r_nload = rl; d.r_ps = rps; d.r_smp_stride = rn_p;
         d.r_lds_smp = rtake(2 * 2 * rn_p * 2);           // two buffers of f16 hi + lo
-        d.r_lds_colh = rtake(2 * (rps + 1) * kFusedColStride * 2);   // two column buffers (pass parity), one spare slot each
-        d.r_lds_coll = rtake(2 * (rps + 1) * kFusedColStride * 2);
-        d.r_lds_stat = rtake(2 * (rps + 2) * 4);
+        d.r_lds_p = rtake(kFusedRPRows * 52 * 4);        // tap products: a ring of three passes' frames
         d.r_lds_red = rtake(64);
         d.r_lds_cst = rtake((32 + kMaxFns * 33) * 4);
         d.r_lds_total = roff;
@@ -234,6 +232,20 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
                 p.afrag[(((size_t)t * 2 + 0) * 64 + l) * 8 + j] = hi;
                 p.afrag[(((size_t)t * 2 + 1) * 64 + l) * 8 + j] = lo;
             }
+    // the same layer with all taps as the rows of one A operand (kernels_fused_r.hip: every column meets every tap once)
+    p.afrag_t.assign((size_t)3 * 2 * 64 * 8, 0);
+    if (H <= 4)
+        for (int m = 0; m < 3; m++)
+            for (int l = 0; l < 64; l++)
+                for (int j = 0; j < 8; j++) {
+                    const int r = 16 * m + (l & 15), t = r / 4, h = r % 4, gq = l >> 4, bin = j < 4 ? 4 * gq + j : 16 + 4 * gq + (j - 4);
+                    double v = 0.0;
+                    if (t < T && h < H && bin < F) v = (double)L0.weights[(size_t)h * I + t * F + bin] * a[(size_t)(t * F + bin)] * wscale;
+                    uint16_t hi, lo;
+                    split_half(v, hi, lo);
+                    p.afrag_t[(((size_t)m * 2 + 0) * 64 + l) * 8 + j] = hi;
+                    p.afrag_t[(((size_t)m * 2 + 1) * 64 + l) * 8 + j] = lo;
+                }
     p.bias0.resize((size_t)H);
     p.rvec.resize((size_t)H);
     for (int h = 0; h < H; h++) {

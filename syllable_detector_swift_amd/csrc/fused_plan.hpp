@@ -15,7 +15,7 @@ struct FusedPlan {
     std::string reason;              // why the configuration does not fit, when !ok
     FusedDesc desc{};                // device pointers are filled in by the owner after upload
     std::vector<uint16_t> dfrag;     // f16 bit patterns
-    std::vector<uint16_t> afrag;
+    std::vector<uint16_t> afrag, afrag_t;
     std::vector<int> koff;
     std::vector<float> bias0, rvec, w1, b1, out_params;
 };

@@ -88,6 +88,7 @@ constexpr int kFusedMaxLoads = 10;      // float4 loads per thread per pass
 constexpr int kFusedRBlock = 256;       // register-resident-basis kernel (kernels_fused_r.hip): 4 waves, one per SIMD
 constexpr int kFusedRTileFrames = 64;   //   16 frames per wave and pass
 constexpr int kFusedRMaxLoads = 10;     //   float4 loads per thread per pass
+constexpr int kFusedRPRows = 11 + 3 * 64 + 2;   //   rows of its tap-product ring in LDS (52 floats each)
 constexpr int kFusedColStride = 40;     // halves per column row in LDS: 32 bins + 8 of padding (80 B rows: 16-byte
                                         // aligned, and 16 consecutive rows cover all 64 banks once for ds_read_b128)
 
@@ -111,9 +112,12 @@ struct FusedDesc {
     // layout of the register-resident-basis kernel (64-frame passes, staged samples double-buffered, no basis in LDS);
     // r_ok = 0 when the shape does not fit it (long hops)
     int r_ok, r_nsmp, r_nload, r_ps, r_smp_stride, r_runs, r_seg_evals;
-    int r_lds_smp, r_lds_colh, r_lds_coll, r_lds_stat, r_lds_red, r_lds_cst, r_lds_total;   // second sample buffer: r_lds_smp + 4 r_smp_stride
+    int r_lds_smp, r_lds_p, r_lds_red, r_lds_cst, r_lds_total;   // second sample buffer: r_lds_smp + 4 r_smp_stride
     const uint4 *dfrag;         // [KS][re 0-15, re 16-31, im 0-15, im 16-31][hi,lo][64 lanes] A-operand fragments of the DFT basis
     const uint4 *afrag;         // [T][hi,lo][64 lanes] A-operand fragments of the folded first layer (16x16x32)
+    const uint4 *afrag_t;       // [3 row tiles][hi,lo][64 lanes] the same layer with all taps as rows (row 4 t + h), K in the
+                                // bin order of a magnitude result: k = 8 g + j -> bin 4 g + j (j < 4), 16 + 4 g + j - 4 (j >= 4);
+                                // null unless H <= 4
     const int *koff;            // [KS][4] staged-sample offset of k-step ks for lane group g4 (skew applied)
     const float *bias0;         // [H]  b0 + W0 . (constant part of the input maps)
     const float *rvec;          // [H]  (W0 o a) . 1

@@ -37,6 +37,10 @@ constexpr int kBlock = kFusedRBlock;           // 256 threads = 4 waves, one per
 constexpr int kWaves = kBlock / 64;
 constexpr int kPass = kFusedRTileFrames;       // 64 frames per pass = 16 per wave
 constexpr int kColStride = kFusedColStride;
+constexpr int kPStride = 52;                   // floats per frame row of tap products: 48 + the frame's sum of squares + padding
+                                               // (208-byte rows: 16 consecutive rows cover all 64 banks once for b128 accesses)
+constexpr int kPRows = kFusedRPRows;           // T-1 repeated rows (at most 11) + 3 passes x 64 frames + 2 spare
+constexpr int kPLead = 11;                     // ring row 0 sits at row kPLead
 
 // KS: k-steps of 32 samples (the basis takes 32 KS registers); T: timeRange; NL: staging quads per thread (all NL are
 // always loaded and staged: quads past the pass come back as zeros from the descriptor's bounds check and land in LDS
@@ -74,12 +78,13 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
     // staged samples: [buffer 0 hi | buffer 0 lo | buffer 1 hi | buffer 1 lo], r_smp_stride halves each
     _Float16 *smp0 = reinterpret_cast<_Float16 *>(smem + d.r_lds_smp);
     const int buf_halves = 2 * d.r_smp_stride;
-    // |X| columns, two buffers (pass parity) of [PS + 1][kColStride] f16 hi and lo (slot PS: where lanes with nothing
-    // to write write), per-frame sums of squares next to them
-    _Float16 *colh = reinterpret_cast<_Float16 *>(smem + d.r_lds_colh);
-    _Float16 *coll = reinterpret_cast<_Float16 *>(smem + d.r_lds_coll);
-    float *stat = reinterpret_cast<float *>(smem + d.r_lds_stat);
-    const int col_halves = (PS + 1) * kColStride, stat_floats = PS + 2;
+    // tap products: a ring of three passes' frames, [kPRows][kPStride] fp32 -- per frame 12 taps x 4 units, then its sum
+    // of squares (rows 0 .. T-2 repeat the ring's last T-1 frames, so that a window never wraps; two spare rows at the end)
+    float *pbuf = reinterpret_cast<float *>(smem + d.r_lds_p);
+    // (the shared evaluation block names the 8-wave kernel's column buffers in steps this kernel never runs)
+    [[maybe_unused]] _Float16 *colh = reinterpret_cast<_Float16 *>(smem), *coll = colh;
+    [[maybe_unused]] float *stat = pbuf;
+    [[maybe_unused]] const half8 (*afr)[2] = nullptr;
 
     // ---- once per workgroup: constants
     if (tid < 16) reinterpret_cast<double *>(cst + kCstThr)[tid] = tid < n_out ? d.thresholds[tid] : 0.0;
@@ -87,12 +92,14 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
     uint32x4 a[KS * 8];
 #pragma unroll
     for (int i = 0; i < KS * 8; i++) a[i] = reinterpret_cast<const uint32x4 *>(d.dfrag)[i * 64 + lane];
-    // first-layer fragments, one (hi, lo) pair per tap
-    half8 afr[T][2];
+    // first-layer fragments with ALL taps as rows (row 4 t + h: three 16-row tiles), f16 hi + lo; K = this wave's bin
+    // order in a magnitude result (see mag_micro)
+    half8 aft[3][2];
 #pragma unroll
-    for (int t = 0; t < T; t++)
+    for (int m = 0; m < 3; m++)
 #pragma unroll
-        for (int p = 0; p < 2; p++) afr[t][p] = as_half8(reinterpret_cast<const uint32x4 *>(d.afrag)[(t * 2 + p) * 64 + lane]);
+        for (int p = 0; p < 2; p++) aft[m][p] = as_half8(reinterpret_cast<const uint32x4 *>(d.afrag_t)[(m * 2 + p) * 64 + lane]);
+    for (int i = tid; i < kPRows * kPStride / 4; i += kBlock) reinterpret_cast<floatx4 *>(pbuf)[i] = floatx4{0.f, 0.f, 0.f, 0.f};
     float c_b0[4], c_rv[4], c_w1[4][4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -149,7 +156,7 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
     }
 
     // ---- prologue: pass 0 staged, pass 1 in the staging registers with its block maximum published
-    int se_cur, se_m1 = 0, se_m2 = 0;     // sample scale exponents of the pass in the matrix block and of the two before it
+    int se_cur, se_m1 = 0;                // sample scale exponents of the pass in the matrix block and of the one before it
     {
         const __amdgpu_buffer_rsrc_t rs = pass_rsrc(0);
 #pragma unroll
@@ -206,63 +213,59 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
 #define SD_PIN(x) asm volatile("" : "+v"(x))
     float amax_run = 0.0f;
     floatx4 accP[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // pass q-1's DFT
-    int cse_e = 0, csx_e = 0;             // column scales (own, transition strip) of the pass being evaluated (q-2)
+    constexpr int cse_e = 0, csx_e = 0;   // (the shared evaluation block's column scales: unused by l2normalize detectors)
+    const int se_ref = se_cur;            // products are stored relative to the segment's first pass
+    int r3 = 0;                           // q mod 3
 
-    // -- evaluation of pass pp from column buffer `par`: 24 slots, one every four ticks
-    uint32x4 cq_h[3], cq_l[3];
-    float wst[T];
-    floatx4 z3 = {0.0f, 0.0f, 0.0f, 0.0f};
-    const int wofs = wslot * kColStride + 8 * g4;                 // this lane's window in a column buffer (halves)
-    auto eval_slot = [&](int s, int pp, int par) {
-        const _Float16 *ebh = colh + par * col_halves + wofs, *ebl = coll + par * col_halves + wofs;
-        if (s < T) {                                              // fetch tap s (used two slots later)
-            cq_h[s % 3] = *reinterpret_cast<const uint32x4 *>(ebh + s * kColStride);
-            cq_l[s % 3] = *reinterpret_cast<const uint32x4 *>(ebl + s * kColStride);
-        }
-        if (s >= 2 && s - 2 < T) {                                // multiply tap s - 2: hi*hi, hi*lo, lo*hi
-            const int t = s - 2;
-            // (the diagnostic instantiation is tighter on registers: there the allocator parks first-layer fragments in the
-            // accumulation registers and fetches them right in front of their MFMA -- two wait states, tools/check_mfma_hazards.py)
-#define SD_EVAL_MFMA(pre)                                                                                                         \
-            if (t == 0) {                                                                                                         \
-                asm volatile(pre "v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(z) : "v"(afr[t][0]), "v"(cq_h[t % 3]));          \
-                asm volatile(pre "v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(z2) : "v"(afr[t][0]), "v"(cq_l[t % 3]));         \
-                asm volatile(pre "v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(z3) : "v"(afr[t][1]), "v"(cq_h[t % 3]));         \
-            } else {                                                                                                              \
-                asm volatile(pre "v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(z) : "v"(afr[t][0]), "v"(cq_h[t % 3]));          \
-                asm volatile(pre "v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(z2) : "v"(afr[t][0]), "v"(cq_l[t % 3]));         \
-                asm volatile(pre "v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(z3) : "v"(afr[t][1]), "v"(cq_h[t % 3]));         \
-            }
-            if (STAMP) { SD_EVAL_MFMA("s_nop 1\n\t") } else { SD_EVAL_MFMA("") }
-#undef SD_EVAL_MFMA
-        }
-        if (s == T) {
-            const float *est = stat + par * stat_floats + wslot;
+    // -- evaluation of pass pp (ring region re): every column met every tap when its pass was finished, so an evaluation
+    // is the diagonal sum over the taps of the products in LDS (lane group g4 takes taps g4, g4 + 4, g4 + 8; taps past
+    // timeRange are rows of zeros) plus the window's sum of squares, then the rest of the network.  Slots: one every
+    // four ticks; the fetches two slots ahead of the sums.
+    floatx4 pv[3];
+    float sv[3];
+    const float *zero_ss = pbuf + (kPRows - 1) * kPStride + 48;       // a float that stays zero
+    auto eval_slot = [&](int s, int pp, int re) {
+        if (s == 0) {
+            const float *erow = pbuf + (kPLead + 64 * re + fl - (T - 1)) * kPStride;
 #pragma unroll
-            for (int t = 0; t < T; t++) wst[t] = est[t];
-        }
-        if (s == T + 2) {
-            asm volatile("s_nop 7" : "+v"(z), "+v"(z2), "+v"(z3));   // (the last tap's MFMAs are a slot back: long done)
-            z += z2 + z3;
-            float acc_ss = 0.0f;
-#pragma unroll
-            for (int t = 0; t < T; t++) {
-                SD_PIN(wst[t]);
-                acc_ss += wst[t];
+            for (int tt = 0; tt < 3; tt++) {
+                const int t = g4 + 4 * tt;
+                pv[tt] = *reinterpret_cast<const floatx4 *>(erow + t * kPStride + 4 * t);
+                sv[tt] = *(t < T ? erow + t * kPStride + 48 : zero_ss);
             }
-            ssw = acc_ss;
         }
-        if (s >= T + 3 && s <= T + 6) post_step(s - T, pp, cse_e, csx_e);
+        if (s == 2) {
+#pragma unroll
+            for (int tt = 0; tt < 3; tt++) {
+                SD_PIN(pv[tt]);
+                SD_PIN(sv[tt]);
+            }
+            const floatx4 z4 = pv[0] + pv[1] + pv[2];
+#pragma unroll
+            for (int i = 0; i < 4; i++) z[i] = xor32_sum(xor16_sum(z4[i]));
+            ssw = xor32_sum(xor16_sum(sv[0] + sv[1] + sv[2]));
+        }
+        if (s >= 4 && s <= 10 && s % 2 == 0) post_step(s / 2 + 1, pp, cse_e, csx_e);   // steps 3 .. 6: scale, units, output, stores
     };
 
-    // -- magnitudes of pass q-1 (zvabs/2, CircularShortTimeFourierTransform.swift:329-333) -> columns of parity `par`.
-    // Result layout: column = frame f, register j of lane group g4 in tile m = basis row 16m + 4*g4 + j; this lane holds
-    // bins 4*g4 + j (i = j) and 16 + 4*g4 + j (i = 4 + j).  accP holds X * 2^(se + 13); columns are stored as
-    // |X| * 2^(se - col_shift), so the two scales cancel into one constant.  Micro-steps j = 0 .. kMagSteps-1.
-    constexpr int kMagSteps = 8 + 4 + 1 + 4;
+    // -- finishing pass q-1: magnitudes (zvabs/2, CircularShortTimeFourierTransform.swift:329-333), their f16 hi + lo split,
+    // the frame's sum of squares, and the tap products of the first layer.  Result layout of the DFT: column = frame f,
+    // register j of lane group g4 in tile m = basis row 16m + 4*g4 + j; this lane holds bins 4*g4 + j (i = j) and
+    // 16 + 4*g4 + j (i = 4 + j) -- which IS the B operand of an MFMA (lane (f, g4): column f, k = 8 g4 + i) for a first
+    // layer whose columns are permuted accordingly on the host (afrag_t): no LDS round trip for the columns.  accP holds
+    // X * 2^(se + 13); |X| * 2^(se - col_shift) is what is split; products and sums of squares are stored relative to the
+    // segment's first pass (* 2^dsc, dsc = se(first) - se: a power of two), so that a window may straddle passes of
+    // different scales.  Micro-steps j = 0 .. kMagSteps-1.
+    constexpr int kMagSteps = 23;
     float cval[8], mss = 0.0f;
+    unsigned bh[4], bl[4];
+    floatx4 pt[3];
     const float kmag = pow2f(-13 - d.col_shift);
-    auto mag_micro = [&](int j, int par, int csx_m, int cse_m) {
+    auto mag_micro = [&](int j, int rm, int dsc) {
+        // this frame's row in the ring; the ring's last T-1 frames are repeated in front of it (elsewhere: a spare spot)
+        float *prow = pbuf + (kPLead + 64 * rm + fl) * kPStride;
+        float *drow = (rm == 2 && fl >= kPass - (T - 1)) ? pbuf + (kPLead + fl - kPass) * kPStride : nullptr;
+        float *spare = pbuf + (kPRows - 1) * kPStride;             // floats 0 .. 47 and 49 .. of the last row are never read
         if (j < 8) {                                              // |X| of one bin
             const int i = j;
             float re = accP[i >> 2][i & 3], im = accP[2 + (i >> 2)][i & 3];
@@ -278,68 +281,33 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
             if (j == 11) mss = xor32_sum(xor16_sum(mss));
             SD_PIN(mss);
         } else if (j == 12) {
-            float *sp = stat + par * stat_floats;
-            sp[g4 == 0 ? XS + fl : PS] = mss;
-            sp[(g4 == 0 && fl < T - 1) ? (T - 1) + fl : PS + 1] = mss * pow2f(2 * (csx_m - cse_m));
-        } else if (j < 17) {                                      // f16 hi + lo of four bins (one tile m's share)
-            const int i = j - 13;                                 // 0, 1: the pass's own column (tiles 0, 1); 2, 3: the strip's copy
-            const int m = i & 1;
-            const float xs = i < 2 ? 1.0f : pow2f(csx_m - cse_m);   // (<= 1: a much quieter pass may underflow next to one 2^|.| louder)
-            unsigned h0, h1, l0, l1;
-            asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h0) : "v"(cval[4 * m]), "v"(xs));
-            asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h1) : "v"(cval[4 * m + 2]), "v"(xs));
-            asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h0) : "v"(cval[4 * m + 1]), "v"(xs));
-            asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h1) : "v"(cval[4 * m + 3]), "v"(xs));
-            asm volatile("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l0) : "v"(cval[4 * m]), "v"(xs), "v"(h0));
-            asm volatile("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l1) : "v"(cval[4 * m + 2]), "v"(xs), "v"(h1));
-            asm volatile("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l0) : "v"(cval[4 * m + 1]), "v"(xs), "v"(h0));
-            asm volatile("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l1) : "v"(cval[4 * m + 3]), "v"(xs), "v"(h1));
-            // bins 16m + 4*g4 .. +3: four consecutive halves
-            const int slot = i < 2 ? XS + fl : (fl < T - 1 ? (T - 1) + fl : PS);
-            _Float16 *ph = colh + par * col_halves + slot * kColStride + 4 * g4 + 16 * m, *pl = coll + par * col_halves + slot * kColStride + 4 * g4 + 16 * m;
-            uint32x2 uh = {h0, h1}, ul = {l0, l1};
-            *reinterpret_cast<uint32x2 *>(ph) = uh;
-            *reinterpret_cast<uint32x2 *>(pl) = ul;
-        }
-    };
-    // -- transition strip of pass q-1: the last T-1 columns of pass q-2 (other buffer), rescaled by 2^dexp, -> slots
-    // 0 .. T-2 of buffer `par`, a word or two per thread of the workgroup.  Micro-steps 0 .. kCarrySteps-1.
-    constexpr int kCarryWords = (T - 1) * (kColStride / 2), kCarryIt = (2 * kCarryWords + kBlock - 1) / kBlock;
-    constexpr int kCarrySteps = 1 + kCarryIt + 1;
-    unsigned cu[kCarryIt];
-    float cst_ss = 0.0f;
-    auto carry_micro = [&](int j, int par, int dexp) {
-        const int srcw = (XS + kPass - (T - 1)) * (kColStride / 2);
-        if (j == 0) {
+            const float sr = mss * pow2f(2 * dsc);
+            *(g4 == 0 ? prow + 48 : spare + 49) = sr;
+            *((g4 == 0 && drow) ? drow + 48 : spare + 50) = sr;
+        } else if (j < 15) {                                      // f16 hi + lo of four bins: half of the B operand pair
+            const int m = j - 13;
+            asm volatile("v_fma_mixlo_f16 %0, %1, 1.0, 0" : "=v"(bh[2 * m]) : "v"(cval[4 * m]));
+            asm volatile("v_fma_mixlo_f16 %0, %1, 1.0, 0" : "=v"(bh[2 * m + 1]) : "v"(cval[4 * m + 2]));
+            asm volatile("v_fma_mixhi_f16 %0, %1, 1.0, 0" : "+v"(bh[2 * m]) : "v"(cval[4 * m + 1]));
+            asm volatile("v_fma_mixhi_f16 %0, %1, 1.0, 0" : "+v"(bh[2 * m + 1]) : "v"(cval[4 * m + 3]));
+            asm volatile("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(bl[2 * m]) : "v"(cval[4 * m]), "v"(bh[2 * m]));
+            asm volatile("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(bl[2 * m + 1]) : "v"(cval[4 * m + 2]), "v"(bh[2 * m + 1]));
+            asm volatile("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(bl[2 * m]) : "v"(cval[4 * m + 1]), "v"(bh[2 * m]));
+            asm volatile("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(bl[2 * m + 1]) : "v"(cval[4 * m + 3]), "v"(bh[2 * m + 1]));
+        } else if (j >= 16 && j < 19) {                           // tap products: hi*hi, hi*lo, lo*hi, one term of every row tile a step
+            const uint32x4 vbh = {bh[0], bh[1], bh[2], bh[3]}, vbl = {bl[0], bl[1], bl[2], bl[3]};
 #pragma unroll
-            for (int k = 0; k < kCarryIt; k++) {
-                const int i = tid + kBlock * k;
-                const bool hi_arr = i < kCarryWords;
-                const int w = hi_arr ? i : i - kCarryWords;
-                const unsigned *src = reinterpret_cast<const unsigned *>((hi_arr ? colh : coll) + (par ^ 1) * col_halves);
-                cu[k] = src[srcw + (i < 2 * kCarryWords ? w : 0)];
+            for (int m = 0; m < 3; m++) {
+                if (j == 16) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(pt[m]) : "v"(aft[m][0]), "v"(vbh));
+                if (j == 17) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(pt[m]) : "v"(aft[m][0]), "v"(vbl));
+                if (j == 18) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(pt[m]) : "v"(aft[m][1]), "v"(vbh));
             }
-            cst_ss = stat[(par ^ 1) * stat_floats + XS + kPass - (T - 1) + (tid < T - 1 ? tid : 0)];
-        } else if (j <= kCarryIt) {
-            const int k = j - 1;
-            SD_PIN(cu[k]);
-            union { unsigned u; _Float16 h[2]; } x;
-            x.u = cu[k];
-            const float sc = pow2f(dexp);
-            union { decltype(__builtin_amdgcn_cvt_pkrtz(0.f, 0.f)) h; unsigned u; } y;
-            y.h = __builtin_amdgcn_cvt_pkrtz((float)x.h[0] * sc, (float)x.h[1] * sc);   // exact for dexp = 0
-            cu[k] = y.u;
-            SD_PIN(cu[k]);
-        } else {
-#pragma unroll
-            for (int k = 0; k < kCarryIt; k++) {
-                const int i = tid + kBlock * k;
-                const bool hi_arr = i < kCarryWords;
-                const int w = hi_arr ? i : i - kCarryWords;
-                unsigned *dst = reinterpret_cast<unsigned *>((hi_arr ? colh : coll) + par * col_halves);
-                dst[i < 2 * kCarryWords ? w : PS * (kColStride / 2)] = cu[k];
-            }
-            stat[par * stat_floats + (tid < T - 1 ? tid : PS + 1)] = cst_ss * pow2f(2 * dexp);   // sums of squares of scaled columns
+        } else if (j >= 20) {                                     // tile m: taps 4m + g4, units 0..3 of this frame -> its row
+            const int m = j - 20;
+            if (m == 0) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(pt[0]), "+v"(pt[1]), "+v"(pt[2]));
+            const floatx4 r = pt[m] * pow2f(dsc);
+            *reinterpret_cast<floatx4 *>(prow + 4 * (4 * m + g4)) = r;
+            *reinterpret_cast<floatx4 *>((drow ? drow : spare) + 4 * (4 * m + g4) - (drow ? 0 : 4 * g4)) = r;
         }
     };
 
@@ -354,11 +322,9 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
 #else
         const __amdgpu_buffer_rsrc_t rs2 = pass_rsrc(q + 2);
 #endif
-        // pass q-1: its columns are stored at its own sample scale; its transition strip (pass q-2's last T-1 columns +
-        // copies of its own first T-1) at the smaller of the two passes' scales, where neither overflows
-        const int cse_m = se_m1, csx_m = (q > 1 && se_m2 < se_m1) ? se_m2 : se_m1;
-        const int dexp = q > 1 ? (csx_m - se_m2 < -126 ? -126 : csx_m - se_m2) : 0;
-        const int par_m = (q + 1) & 1, par_e = q & 1;                 // column buffers of pass q-1 (written) and q-2 (read)
+        // pass q-1's products go to ring region rm relative to the segment's first pass; pass q-2's are read from region re
+        const int dsc = se_ref - se_m1 < -60 ? -60 : (se_ref - se_m1 > 60 ? 60 : se_ref - se_m1);
+        const int rm = r3 == 0 ? 2 : r3 - 1, re = r3 == 2 ? 0 : r3 + 1;   // (q - 1) mod 3, (q - 2) mod 3
         floatx4 acc[4];
         {
             // the next pass's staging (scale, f16 hi/lo split, two LDS writes, reload of the quad with pass p+2), one
@@ -395,15 +361,11 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
                 if (i < kHalf) { stage_micro(2 * i); stage_micro(2 * i + 1); }
 #endif
 #ifndef SYLDET_R_NOEVAL
-                if (i % 4 == 0) eval_slot(i / 4, q - 2, par_e);
+                if (i % 4 == 0) eval_slot(i / 4, q - 2, re);
 #endif
 #ifndef SYLDET_R_NOMAG
-                const int jm = i - 4 * (T + 7);                        // magnitudes: one micro-step a tick, after the evaluation's stores
-                if (jm >= 0 && jm < kMagSteps) mag_micro(jm, par_m, csx_m, cse_m);
-#endif
-#ifndef SYLDET_R_NOCARRY
-                const int jc = i - (kTicks - 2 * kCarrySteps);        // transition strip: every other tick at the end
-                if (jc >= 0 && jc % 2 == 0 && jc / 2 < kCarrySteps) carry_micro(jc / 2, par_m, dexp);
+                const int jm = i - kHalf;                              // pass q-1: one micro-step a tick, once the staging is through
+                if (jm >= 0 && jm < kMagSteps) mag_micro(jm, rm, dsc);
 #endif
 #ifndef SYLDET_R_NOMAX
                 const int jx = i - (kTicks - NL - 4);                  // block maximum of pass q+2, a quad a tick (its loads left in the
@@ -420,7 +382,7 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
                 if (jx == NL + 2 && lane == 0) red[wave] = amax_run;
 #endif
             };
-            static_assert(4 * (T + 7) + kMagSteps <= kTicks && 2 * kCarrySteps <= kTicks && kHalf <= kTicks - NL - 4, "tick schedule");
+            static_assert(kHalf + kMagSteps <= kTicks && kHalf <= kTicks - NL - 4 && T <= 12, "tick schedule");
             // The DFT's accumulators live in the accumulation registers (an MFMA whose C/D operands are architectural
             // registers takes 9.9 ns against 8.4: tools/ubench), which the basis alone would fill: its last four quads are
             // architectural instead.
@@ -462,12 +424,10 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
             for (int m = 0; m < 4; m++) accP[m] = acc[m];
         }
         SD_RTICK(4)
-        cse_e = cse_m;
-        csx_e = csx_m;
-        se_m2 = se_m1;
         se_m1 = se_cur;
         se_cur = se_next;
-        __syncthreads();          // columns of pass q-1, staged samples of pass q+1 and the partial maxima are complete; pass q-2's columns are free
+        r3 = r3 == 2 ? 0 : r3 + 1;
+        __syncthreads();          // products of pass q-1, staged samples of pass q+1 and the partial maxima are complete
         SD_RTICK(6)
         if (STAMP) {                // top of the pass up to the first MFMA, four quarters of the block, barrier
             tsum[0] += tick[0] - tick[5];
@@ -477,22 +437,18 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
             tick[5] = tick[6];
         }
     }
-    // ---- drain: evaluate pass runs-2, finish pass runs-1 (magnitudes, strip), barrier, evaluate it
+    // ---- drain: evaluate pass runs-2, finish pass runs-1, barrier, evaluate it
     {
         const int q = runs;
-        const int cse_m = se_m1, csx_m = (q > 1 && se_m2 < se_m1) ? se_m2 : se_m1;
-        const int dexp = q > 1 ? (csx_m - se_m2 < -126 ? -126 : csx_m - se_m2) : 0;
+        const int dsc = se_ref - se_m1 < -60 ? -60 : (se_ref - se_m1 > 60 ? 60 : se_ref - se_m1);
+        const int rm = r3 == 0 ? 2 : r3 - 1, re = r3 == 2 ? 0 : r3 + 1;
 #pragma unroll
-        for (int sl = 0; sl < 24; sl++) eval_slot(sl, q - 2, q & 1);
+        for (int sl = 0; sl < 12; sl++) eval_slot(sl, q - 2, re);
 #pragma unroll
-        for (int j = 0; j < kMagSteps; j++) mag_micro(j, (q + 1) & 1, csx_m, cse_m);
-#pragma unroll
-        for (int j = 0; j < kCarrySteps; j++) carry_micro(j, (q + 1) & 1, dexp);
-        cse_e = cse_m;
-        csx_e = csx_m;
+        for (int j = 0; j < kMagSteps; j++) mag_micro(j, rm, dsc);
         __syncthreads();
 #pragma unroll
-        for (int sl = 0; sl < 24; sl++) eval_slot(sl, q - 1, (q + 1) & 1);
+        for (int sl = 0; sl < 12; sl++) eval_slot(sl, q - 1, rm);
     }
     if (STAMP && (tid == 0 || tid == 64 * (kWaves - 1)) && d.stamps)       // wave 0's view in slots 0-7, the last wave's in 8-15
         for (int i = 0; i < 8; i++) atomicAdd(&d.stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (tid ? 8 : 0) + i], tsum[i]);

@@ -341,12 +341,14 @@ int upload_plan(syldet *h, FusedPlan &p, DeviceBuffer &buf)
     const size_t o_k = put(p.koff.data(), p.koff.size() * 4), o_b = put(p.bias0.data(), p.bias0.size() * 4);
     const size_t o_r = put(p.rvec.data(), p.rvec.size() * 4), o_w1 = put(p.w1.data(), p.w1.size() * 4);
     const size_t o_b1 = put(p.b1.data(), p.b1.size() * 4), o_op = put(p.out_params.data(), p.out_params.size() * 4);
+    const size_t o_wt = put(p.afrag_t.data(), p.afrag_t.size() * 2);
     if (int st = buf.reserve(blob.size())) return st;
     SYLDET_HIP(hipMemcpy(buf.ptr, blob.data(), blob.size(), hipMemcpyHostToDevice));
     unsigned char *base = (unsigned char *)buf.ptr;
     FusedDesc &d = p.desc;
     d.dfrag = (const uint4 *)(base + o_d);
     d.afrag = (const uint4 *)(base + o_w);
+    d.afrag_t = (const uint4 *)(base + o_wt);
     d.koff = (const int *)(base + o_k);
     d.bias0 = (const float *)(base + o_b);
     d.rvec = (const float *)(base + o_r);
