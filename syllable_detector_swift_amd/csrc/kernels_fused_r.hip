@@ -25,6 +25,8 @@
 //
 // gfx950 only.  wave = 64.
 
+#include <type_traits>
+
 #include "fused_common.hpp"
 
 namespace sd {
@@ -126,11 +128,12 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
     for (int ks = 0; ks < KS; ks++) ko[ks] = SKEW ? d.koff[ks * 4 + g4] : 8 * ks;
 
     // raw samples of one pass: quads 4*(tid + 256 k), k < NL, through a bounds-checked descriptor
-    uint32x4 v[NL];
+    // two sets: pass q+1 (being staged during the matrix block of pass q) is in set (q+1)&1, pass q+2 arrives in set q&1
+    uint32x4 v0[NL], v1[NL];
     auto pass_rsrc = [&](int p) {
         return tile_rsrc(row, (e_b + (int64_t)kPass * p) * d.hop + d.gap, p < runs ? s_eff : 0, d.r_nsmp);
     };
-    auto max_partial = [&]() {
+    auto max_partial = [&](const uint32x4 (&v)[NL]) {
         float amax = 0.0f;
 #pragma unroll
         for (int k = 0; k < NL; k++) {
@@ -160,14 +163,14 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
     {
         const __amdgpu_buffer_rsrc_t rs = pass_rsrc(0);
 #pragma unroll
-        for (int k = 0; k < NL; k++) v[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * tid + 16 * kBlock * k, 0, 0);
-        max_partial();
+        for (int k = 0; k < NL; k++) v0[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * tid + 16 * kBlock * k, 0, 0);
+        max_partial(v0);
         __syncthreads();
         se_cur = pass_scale();
         const float sx = pow2f(se_cur);
 #pragma unroll
         for (int k = 0; k < NL; k++) {
-            const floatx4 q = as_floatx4(v[k]);
+            const floatx4 q = as_floatx4(v0[k]);
             unsigned h0, l0, h1, l1;
             split_pair_scaled(q[0], q[1], sx, h0, l0);
             split_pair_scaled(q[2], q[3], sx, h1, l1);
@@ -178,9 +181,9 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
         }
         const __amdgpu_buffer_rsrc_t rs1 = pass_rsrc(1);
 #pragma unroll
-        for (int k = 0; k < NL; k++) v[k] = __builtin_amdgcn_raw_buffer_load_b128(rs1, 16 * tid + 16 * kBlock * k, 0, 0);
+        for (int k = 0; k < NL; k++) v1[k] = __builtin_amdgcn_raw_buffer_load_b128(rs1, 16 * tid + 16 * kBlock * k, 0, 0);
         __syncthreads();                  // every wave has read the partial maxima of pass 0
-        max_partial();
+        max_partial(v1);
         __syncthreads();
     }
     // diagnostic instantiation only (SYLDET_FUSED_STAMPS=1): s_memtime at the phase boundaries of every pass
@@ -311,12 +314,16 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
         }
     };
 
-    for (int q = 0; q < runs; q++) {
-        const _Float16 *fph = smp0 + (q & 1) * buf_halves + foff, *fpl = fph + d.r_smp_stride;
+    // One pass, with its parity a compile-time fact (which staging set is staged from, which is loaded into).
+    auto pass_body = [&](auto par_tag, const int q) {
+        constexpr int par = decltype(par_tag)::value;
+        uint32x4 (&vs)[NL] = par ? v0 : v1;                           // pass q+1's samples: staged in this block
+        uint32x4 (&vl)[NL] = par ? v1 : v0;                           // pass q+2's samples: loaded in this block, maximum taken at its end
+        const _Float16 *fph = smp0 + par * buf_halves + foff, *fpl = fph + d.r_smp_stride;
         half8 bh = lds_half8(fph + ko[0]), bl = lds_half8(fpl + ko[0]);   // first B fragments: in flight while the scale is worked out
         const int se_next = pass_scale();                             // pass q+1 (its partial maxima are in)
         const float sx_next = pow2f(se_next);
-        _Float16 *wh = smp0 + ((q + 1) & 1) * buf_halves;
+        _Float16 *wh = smp0 + (par ^ 1) * buf_halves;
 #ifdef SYLDET_R_NOLOAD                // (diagnostic builds reload the same cache-resident pass: tools/r_knockouts.sh)
         const __amdgpu_buffer_rsrc_t rs2 = pass_rsrc(q & 1);
 #else
@@ -327,13 +334,13 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
         const int rm = r3 == 0 ? 2 : r3 - 1, re = r3 == 2 ? 0 : r3 + 1;   // (q - 1) mod 3, (q - 2) mod 3
         floatx4 acc[4];
         {
-            // the next pass's staging (scale, f16 hi/lo split, two LDS writes, reload of the quad with pass p+2), one
-            // instruction per micro-step
+            // the next pass's staging (scale, f16 hi/lo split, two LDS writes), one instruction per micro-step, one
+            // micro-step a tick: v_fma_mix runs at half rate, one rides under an MFMA and a second one does not (tools/ubench)
             unsigned mh0 = 0, ml0 = 0, mh1 = 0, ml1 = 0;
             auto stage_micro = [&](int i) {
-                const int k = i / 11, j = i % 11;
+                const int k = i / 10, j = i % 10;
                 if (k >= NL) return;
-                const floatx4 qv = as_floatx4(v[k]);
+                const floatx4 qv = as_floatx4(vs[k]);
                 // (lo / hi halves of one register are never written by neighbouring instructions: that costs a wait state)
                 if (j == 0) asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(mh0) : "v"(qv[0]), "v"(sx_next));
                 if (j == 1) asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(mh1) : "v"(qv[2]), "v"(sx_next));
@@ -346,32 +353,32 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
                 _Float16 *ph = wh + (SKEW ? spos[k] : 4 * tid + 4 * kBlock * k);
                 if (j == 8) { uint32x2 uh = {mh0, mh1}; *reinterpret_cast<uint32x2 *>(ph) = uh; }
                 if (j == 9) { uint32x2 ul = {ml0, ml1}; *reinterpret_cast<uint32x2 *>(ph + d.r_smp_stride) = ul; }
-                if (j == 10) v[k] = __builtin_amdgcn_raw_buffer_load_b128(rs2, 16 * tid + 16 * kBlock * k, 0, 0);
             };
-            // tick i: what rides behind the i-th DFT MFMA.  First half: staging, two micro-steps a tick (the reloads are
-            // then issued early enough to have landed when the block maximum wants them) + the evaluation's MFMA phase;
-            // second half: the evaluation's vector phase, then magnitudes and transition strip of pass q-1.  (Measured
-            // alternatives: one staging step a tick over the whole block with the block maximum behind it, 1.42 ms; hi parts
-            // from v_pk_mul_f32 + v_cvt_pkrtz with one v_fma_mix a tick over three quarters of the block, 1.43 ms; this, 1.37.)
-            constexpr int kTicks = 12 * KS, kHalf = (11 * NL + 1) / 2;
+            // tick i: what rides behind the i-th DFT MFMA.  The loads of pass q+2 leave in the first ticks (the other staging
+            // set is free) and have the whole block to land before the block maximum reads them in the last ticks; staging
+            // one micro-step a tick throughout; the evaluation of pass q-2 in the first half, the finishing of pass q-1
+            // behind it.  (Measured before the second staging set existed: two staging steps a tick in the first half with
+            // each quad reloaded as soon as it was staged, 1.37 ms; one a tick with the block maximum behind the block, 1.42.)
+            constexpr int kTicks = 12 * KS, kMag0 = 44;               // kMag0: first tick of pass q-1's finishing
             auto tick_work = [&](int i) {
                 if (STAMP && i % 24 == 0) { SD_RTICK(i / 24) }         // quarters of the block, diagnostic instantiation only
                 // (SYLDET_R_NO*: diagnostic builds with one piece knocked out, tools/r_knockouts.sh; never the shipped library)
+                if (i < NL) vl[i] = __builtin_amdgcn_raw_buffer_load_b128(rs2, 16 * tid + 16 * kBlock * i, 0, 0);
 #ifndef SYLDET_R_NOSTAGE
-                if (i < kHalf) { stage_micro(2 * i); stage_micro(2 * i + 1); }
+                stage_micro(i);
 #endif
 #ifndef SYLDET_R_NOEVAL
                 if (i % 4 == 0) eval_slot(i / 4, q - 2, re);
 #endif
 #ifndef SYLDET_R_NOMAG
-                const int jm = i - kHalf;                              // pass q-1: one micro-step a tick, once the staging is through
+                const int jm = i - kMag0;                              // pass q-1: one micro-step a tick, behind the evaluation
                 if (jm >= 0 && jm < kMagSteps) mag_micro(jm, rm, dsc);
 #endif
 #ifndef SYLDET_R_NOMAX
                 const int jx = i - (kTicks - NL - 4);                  // block maximum of pass q+2, a quad a tick (its loads left in the
                 if (jx >= 0 && jx < NL) {                              // first half), then the wave's maximum, published before the last tick
                     if (jx == 0) amax_run = 0.0f;
-                    const floatx4 qv = as_floatx4(v[jx]);
+                    const floatx4 qv = as_floatx4(vl[jx]);
                     amax_run = absmax3(absmax3(amax_run, qv[0], qv[1]), qv[2], qv[3]);
                     SD_PIN(amax_run);
                 }
@@ -382,11 +389,11 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
                 if (jx == NL + 2 && lane == 0) red[wave] = amax_run;
 #endif
             };
-            static_assert(kHalf + kMagSteps <= kTicks && kHalf <= kTicks - NL - 4 && T <= 12, "tick schedule");
+            static_assert(kMag0 + kMagSteps <= kTicks && 10 * NL <= kTicks && T <= 12, "tick schedule");
             // The DFT's accumulators live in the accumulation registers (an MFMA whose C/D operands are architectural
             // registers takes 9.9 ns against 8.4: tools/ubench), which the basis alone would fill: its last four quads are
             // architectural instead.
-            constexpr int kArchQuads = 4;
+            constexpr int kArchQuads = 9;
 #define SD_DFT_MFMA(m_, ai_, b_, first_)                                                                                           \
             if ((ai_) >= KS * 8 - kArchQuads) {                                                                                   \
                 if (first_) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&a"(acc[m_]) : "v"(a[ai_]), "v"(b_));         \
@@ -436,6 +443,10 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
             tsum[5] += tick[6] - tick[4];
             tick[5] = tick[6];
         }
+    };
+    for (int q = 0; q < runs; q += 2) {
+        pass_body(std::integral_constant<int, 0>{}, q);
+        if (q + 1 < runs) pass_body(std::integral_constant<int, 1>{}, q + 1);
     }
     // ---- drain: evaluate pass runs-2, finish pass runs-1, barrier, evaluate it
     {
