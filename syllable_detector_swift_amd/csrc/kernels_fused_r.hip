@@ -224,8 +224,21 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
     // is the diagonal sum over the taps of the products in LDS (lane group g4 takes taps g4, g4 + 4, g4 + 8; taps past
     // timeRange are rows of zeros) plus the window's sum of squares, then the rest of the network.  Slots: one every
     // four ticks; the fetches two slots ahead of the sums.
-    floatx4 pv[3];
-    float sv[3];
+    floatx4 pv[3], zp = {0.f, 0.f, 0.f, 0.f};
+    float sv[3], ssp = 0.0f;
+    // the sums over the four lane groups, one value a tick (ticks 9 .. 13 of the block)
+    auto eval_reduce = [&](int k) {
+        if (k < 4) {
+            float x = zp[k];
+            SD_PIN(x);
+            z[k] = xor32_sum(xor16_sum(x));
+            SD_PIN(z[k]);
+        } else if (k == 4) {
+            SD_PIN(ssp);
+            ssw = xor32_sum(xor16_sum(ssp));
+            SD_PIN(ssw);
+        }
+    };
     const float *zero_ss = pbuf + (kPRows - 1) * kPStride + 48;       // a float that stays zero
     auto eval_slot = [&](int s, int pp, int re) {
         if (s == 0) {
@@ -237,16 +250,14 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
                 sv[tt] = *(t < T ? erow + t * kPStride + 48 : zero_ss);
             }
         }
-        if (s == 2) {
+        if (s == 2) {                                             // this lane group's taps
 #pragma unroll
             for (int tt = 0; tt < 3; tt++) {
                 SD_PIN(pv[tt]);
                 SD_PIN(sv[tt]);
             }
-            const floatx4 z4 = pv[0] + pv[1] + pv[2];
-#pragma unroll
-            for (int i = 0; i < 4; i++) z[i] = xor32_sum(xor16_sum(z4[i]));
-            ssw = xor32_sum(xor16_sum(sv[0] + sv[1] + sv[2]));
+            zp = pv[0] + pv[1] + pv[2];
+            ssp = sv[0] + sv[1] + sv[2];
         }
         if (s >= 4 && s <= 10 && s % 2 == 0) post_step(s / 2 + 1, pp, cse_e, csx_e);   // steps 3 .. 6: scale, units, output, stores
     };
@@ -314,6 +325,14 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
         }
     };
 
+    // pass q+2's samples: where they start, how many are left from there to the end of the stream (clamped into 32 bits once)
+    const float *base2 = row + (e_b + (int64_t)kPass * 2) * d.hop + d.gap;
+    int left2;
+    {
+        int64_t l = s_eff - ((e_b + (int64_t)kPass * 2) * d.hop + d.gap);
+        l = l < -(int64_t)0x3fffffff ? -(int64_t)0x3fffffff : (l > 0x3fffffff ? 0x3fffffff : l);
+        left2 = __builtin_amdgcn_readfirstlane((int)l);
+    }
     // One pass, with its parity a compile-time fact (which staging set is staged from, which is loaded into).
     auto pass_body = [&](auto par_tag, const int q) {
         constexpr int par = decltype(par_tag)::value;
@@ -324,11 +343,17 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
         const int se_next = pass_scale();                             // pass q+1 (its partial maxima are in)
         const float sx_next = pow2f(se_next);
         _Float16 *wh = smp0 + (par ^ 1) * buf_halves;
+        // pass q+2's descriptor, kept incrementally in 32-bit scalar arithmetic (pass_rsrc's 64-bit clamps cost thirty
+        // instructions a pass): samples left from its first one, none past the segment
+        int left = left2 < 0 ? 0 : (left2 > d.r_nsmp ? d.r_nsmp : left2);
+        left = q + 2 < runs ? left : 0;
 #ifdef SYLDET_R_NOLOAD                // (diagnostic builds reload the same cache-resident pass: tools/r_knockouts.sh)
         const __amdgpu_buffer_rsrc_t rs2 = pass_rsrc(q & 1);
 #else
-        const __amdgpu_buffer_rsrc_t rs2 = pass_rsrc(q + 2);
+        const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base2), 0, left * 4, 0x00020000);
 #endif
+        base2 += kPass * d.hop;
+        left2 -= kPass * d.hop;
         // pass q-1's products go to ring region rm relative to the segment's first pass; pass q-2's are read from region re
         const int dsc = se_ref - se_m1 < -60 ? -60 : (se_ref - se_m1 > 60 ? 60 : se_ref - se_m1);
         const int rm = r3 == 0 ? 2 : r3 - 1, re = r3 == 2 ? 0 : r3 + 1;   // (q - 1) mod 3, (q - 2) mod 3
@@ -369,6 +394,7 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
 #endif
 #ifndef SYLDET_R_NOEVAL
                 if (i % 4 == 0) eval_slot(i / 4, q - 2, re);
+                if (i >= 9 && i < 14) eval_reduce(i - 9);
 #endif
 #ifndef SYLDET_R_NOMAG
                 const int jm = i - kMag0;                              // pass q-1: one micro-step a tick, behind the evaluation
@@ -454,12 +480,20 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
         const int dsc = se_ref - se_m1 < -60 ? -60 : (se_ref - se_m1 > 60 ? 60 : se_ref - se_m1);
         const int rm = r3 == 0 ? 2 : r3 - 1, re = r3 == 2 ? 0 : r3 + 1;
 #pragma unroll
-        for (int sl = 0; sl < 12; sl++) eval_slot(sl, q - 2, re);
+        for (int sl = 0; sl < 12; sl++) {
+            eval_slot(sl, q - 2, re);
+            if (sl == 2)
+                for (int k = 0; k < 5; k++) eval_reduce(k);
+        }
 #pragma unroll
         for (int j = 0; j < kMagSteps; j++) mag_micro(j, rm, dsc);
         __syncthreads();
 #pragma unroll
-        for (int sl = 0; sl < 12; sl++) eval_slot(sl, q - 1, rm);
+        for (int sl = 0; sl < 12; sl++) {
+            eval_slot(sl, q - 1, rm);
+            if (sl == 2)
+                for (int k = 0; k < 5; k++) eval_reduce(k);
+        }
     }
     if (STAMP && (tid == 0 || tid == 64 * (kWaves - 1)) && d.stamps)       // wave 0's view in slots 0-7, the last wave's in 8-15
         for (int i = 0; i < 8; i++) atomicAdd(&d.stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (tid ? 8 : 0) + i], tsum[i]);
