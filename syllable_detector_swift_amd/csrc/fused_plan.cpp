@@ -149,7 +149,7 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
     d.lds_red = take(64);
     d.lds_cst = take((32 + kMaxFns * 33) * 4);       // thresholds + output maps (kCst* in kernels_fused.hip)
     d.lds_total = off;
-    if (off > 160 * 1024) return no("LDS budget exceeded");
+    d.classic_ok = off <= 160 * 1024 ? 1 : 0;        // (the register-resident-basis kernel has its own, smaller layout: decided below)
     {   // the register-resident-basis kernel's own pass geometry and LDS layout
         const int rn = (kFusedRTileFrames - 1) * hop + KS * 32;
         const int rl = (rn / 4 + kFusedRBlock - 1) / kFusedRBlock;
@@ -269,6 +269,7 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
         p.out_params.insert(p.out_params.end(), f.gains, f.gains + n_out);
         p.out_params.insert(p.out_params.end(), f.x_offsets, f.x_offsets + n_out);
     }
+    if (!d.classic_ok && !fused_r_applicable(d)) return no("LDS budget exceeded");
     p.koff.resize((size_t)KS * 4);
     for (int ks = 0; ks < KS; ks++)
         for (int h = 0; h < 4; h++) {

@@ -111,6 +111,7 @@ struct FusedDesc {
     int lds_dfrag, lds_smp, lds_colh, lds_coll, lds_stat, lds_red, lds_cst, lds_total;   // byte offsets
     // layout of the register-resident-basis kernel (64-frame passes, staged samples double-buffered, no basis in LDS);
     // r_ok = 0 when the shape does not fit it (long hops)
+    int classic_ok;             // the 8-wave kernel's LDS layout fits (else only the register-resident-basis kernel can run the plan)
     int r_ok, r_nsmp, r_nload, r_ps, r_smp_stride, r_runs, r_seg_evals;
     int r_lds_smp, r_lds_p, r_lds_red, r_lds_cst, r_lds_total;   // second sample buffer: r_lds_smp + 4 r_smp_stride
     const uint4 *dfrag;         // [KS][re 0-15, re 16-31, im 0-15, im 16-31][hi,lo][64 lanes] A-operand fragments of the DFT basis

@@ -44,12 +44,12 @@ constexpr int kPStride = 52;                   // floats per frame row of tap pr
 constexpr int kPRows = kFusedRPRows;           // T-1 repeated rows (at most 11) + 3 passes x 64 frames + 2 spare
 constexpr int kPLead = 11;                     // ring row 0 sits at row kPLead
 
-// KS: k-steps of 32 samples (the basis takes 32 KS registers); T: timeRange; NL: staging quads per thread (all NL are
+// KS: k-steps of 32 samples (the basis takes 32 KS registers); TMAX: largest timeRange; NL: staging quads per thread (all NL are
 // always loaded and staged: quads past the pass come back as zeros from the descriptor's bounds check and land in LDS
 // words no frame reads); SKEW: staged samples carry bank-spreading padding; STAMP: diagnostic phase timing.
 // The network class is the reference's example detector's (kernels_fused.hip's LEAN): l2normalize first, linear |X|
 // columns, two layers, TanSig hidden units (at most 4), one output, at most one output map.
-template <int KS, int T, int NL, bool SKEW, bool STAMP>
+template <int KS, int TMAX, int NL, bool SKEW, bool STAMP>
 __global__ void __launch_bounds__(kBlock, 1)
 fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t stride, int64_t s_eff, int64_t E,
                float *__restrict__ outputs, uint8_t *__restrict__ flags)
@@ -57,7 +57,8 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *red = reinterpret_cast<float *>(smem + d.r_lds_red);      // [4 waves] block-max partials
     float *cst = reinterpret_cast<float *>(smem + d.r_lds_cst);
-    constexpr int kom = 0, TMAX = T;      // the shared evaluation block's switches
+    constexpr int kom = 0;                // the shared evaluation block's switches
+    const int T = d.T;                    // timeRange (taps past it are rows of zeros in the first-layer fragments)
     [[maybe_unused]] constexpr bool SPECT = false;
     constexpr bool LEAN = true;
 
@@ -72,7 +73,7 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
     const int64_t e_e = (e_b + d.r_seg_evals < E) ? e_b + d.r_seg_evals : E;
     const float *row = samples + (int64_t)c * stride;
     const int PS = d.r_ps, H = d.H;                             // PS: column slots = 2 (T - 1) transition slots + 64
-    constexpr int XS = 2 * (T - 1);                             // the pass's own columns start at slot XS
+    [[maybe_unused]] const int XS = 2 * (T - 1);                // (the shared evaluation block's name for the 8-wave kernel's column layout)
     constexpr int norm = 1, scaling = 0, n_layers = 2, n_out = 1, tf0 = 0, tf1 = 2;
     const int fl = 16 * wave + f;     // this lane's frame / evaluation slot inside the pass
     const int runs = d.r_runs;
@@ -415,7 +416,7 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
                 if (jx == NL + 2 && lane == 0) red[wave] = amax_run;
 #endif
             };
-            static_assert(kMag0 + kMagSteps <= kTicks && 10 * NL <= kTicks && T <= 12, "tick schedule");
+            static_assert(kMag0 + kMagSteps <= kTicks && 10 * NL <= kTicks && TMAX <= 12 && TMAX - 1 <= kPLead, "tick schedule");
             // The DFT's accumulators live in the accumulation registers (an MFMA whose C/D operands are architectural
             // registers takes 9.9 ns against 8.4: tools/ubench), which the basis alone would fill: its last four quads are
             // architectural instead.
@@ -501,11 +502,11 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
 #undef SD_PIN
 }
 
-template <int KS, int T, int NL, bool SKEW, bool STAMP = false>
+template <int KS, int TMAX, int NL, bool SKEW, bool STAMP = false>
 hipError_t launch_one(const FusedDesc &d, const float *samples, int64_t stride, int C, int64_t s_eff, int64_t E,
                       float *outputs, uint8_t *flags, hipStream_t stream)
 {
-    auto kern = fused_r_kernel<KS, T, NL, SKEW, STAMP>;
+    auto kern = fused_r_kernel<KS, TMAX, NL, SKEW, STAMP>;
     hipError_t st = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, d.r_lds_total);
     if (st != hipSuccess) return st;
     const int64_t segs = (E + d.r_seg_evals - 1) / d.r_seg_evals;
@@ -517,9 +518,10 @@ hipError_t launch_one(const FusedDesc &d, const float *samples, int64_t stride, 
 }  // namespace
 
 // Shapes this kernel is instantiated for: the reference's example detector class (l2normalize first, linear |X| columns,
-// two layers, at most 4 TanSig hidden units, one output, at most one output map), 256-sample windows (8 k-steps),
-// timeRange 10, at most 9 staging quads per thread and at least 8 (hops 110..140, the reference's 132 among them) and no
-// bank-spreading padding (hop not a multiple of 16).  Everything else stays on kernels_fused.hip's kernel.
+// two layers, at most 4 TanSig hidden units, one output, at most one output map), windows of 132 .. 256 samples (8
+// k-steps), timeRange up to 12, at most 9 staging quads per thread (hop <= 140, the reference's 132 among them), no
+// bank-spreading padding (hop not a multiple of 16: that instantiation spills and measured 1.85 ms against the 8-wave
+// kernel's 1.47 at hop 128).  Everything else stays on kernels_fused.hip's kernel.
 bool fused_r_has_stamps()
 {
 #ifdef SYLDET_R_STAMPS
@@ -533,7 +535,7 @@ bool fused_r_applicable(const FusedDesc &d)
 {
     const bool lean = d.norm == 1 && d.scaling == 0 && d.n_layers == 2 && d.tf0 == 0 /* TanSig */ && d.tf1 == 2 /* PureLin */ &&
                       d.n_out == 1 && d.H <= 4 && d.n_out_fns <= 1;
-    return d.r_ok && d.KS == 8 && d.T == 10 && (d.r_nload == 9 || d.r_nload == 8) && d.skew == 0 && lean;
+    return d.r_ok && d.KS == 8 && d.T <= 12 && d.r_nload <= 9 && d.skew == 0 && lean;
 }
 
 hipError_t launch_fused_r(const FusedDesc &d, const float *samples, int64_t stride, int C, int64_t S, int64_t J,
@@ -544,9 +546,9 @@ hipError_t launch_fused_r(const FusedDesc &d, const float *samples, int64_t stri
     if (!fused_r_applicable(d)) return hipErrorInvalidValue;
     const int64_t s_eff = (J - 1) * (int64_t)d.hop + d.gap + d.W;
 #ifdef SYLDET_R_STAMPS                // diagnostic builds only (-DSYLDET_R_STAMPS): the instantiation with phase timing
-    if (d.stamps) return launch_one<8, 10, 9, false, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
+    if (d.stamps && d.skew == 0) return launch_one<8, 12, 9, false, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
 #endif
-    return launch_one<8, 10, 9, false>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
+    return launch_one<8, 12, 9, false>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
 }
 
 }  // namespace sd

@@ -514,7 +514,7 @@ int run_on_stream(syldet *h, const float *d_samples, int64_t S, int64_t stride, 
             return SYLDET_OK;
         }
         // (the launcher picks the register-resident-basis kernel where it is instantiated: named for what runs)
-        KernelTimer t(h, stream, (fused_r_applicable(d) && !std::getenv("SYLDET_FUSED_CLASSIC") && !d.ko) ? "fused_r_kernel" : "fused_kernel");
+        KernelTimer t(h, stream, (fused_r_applicable(d) && (!std::getenv("SYLDET_FUSED_CLASSIC") || !d.classic_ok) && !d.ko) ? "fused_r_kernel" : "fused_kernel");
         SYLDET_HIP(launch_fused(d, d_samples, stride, C, S, J, E, d_outputs, d_flags, stream));
         return SYLDET_OK;
     }

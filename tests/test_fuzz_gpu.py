@@ -166,19 +166,22 @@ def test_random_configuration_streaming(oracle_lib, seed):
 
 
 def draw_example_class(rng):
-    """The reference's example detector class, which runs on kernels_fused_r.hip: W = N = 256, timeRange 10, hop 116 / 120 /
-    124 / 132 / 136 / 140 (a multiple of 4 in 110..140, not of 16), l2normalize first, <= 4 TanSig hidden units, one linear
-    output, at most one output map; any band, window type, affine maps behind the normaliser, threshold, rule."""
-    hop = int(rng.choice([116, 120, 124, 132, 136, 140]))
+    """The reference's example detector class, which runs on kernels_fused_r.hip: N = 256, windows of 192 or 256 samples,
+    any timeRange up to 12, hop a multiple of 4 up to 140 but not of 16 (those take the 8-wave kernel's bank-spread staging), l2normalize
+    first, <= 4 TanSig hidden units, one linear output, at most one output map; any band, window type, affine maps behind
+    the normaliser, threshold, rule."""
+    hop = int(rng.choice([68, 84, 100, 116, 120, 124, 132, 132, 132, 136, 140]))
+    W = 256 if rng.random() < 0.75 else 192
+    T = 10 if rng.random() < 0.4 else int(rng.integers(1, 13))
     f0 = int(rng.integers(0, 100))
     F = int(rng.integers(1, 30))
     lo, hi = max((f0 - 0.4) * FS / 256, 0.0), (f0 + F - 1 + 0.4) * FS / 256
     r = frequencyIndexRange(256, FS, lo, hi)
     F = r[1] - r[0]
     chain = [("l2normalize",), ("l2normalize", "mapminmax"), ("l2normalize", "mapstd"), ("l2normalize", "mapstd", "mapminmax")][int(rng.integers(0, 4))]
-    net = nets.random_net(rng, F * 10, (int(rng.integers(1, 5)),), 1, transfer=("TanSig", "PureLin"), in_fns=chain,
+    net = nets.random_net(rng, F * T, (int(rng.integers(1, 5)),), 1, transfer=("TanSig", "PureLin"), in_fns=chain,
                           out_fns=[(), ("mapminmax",), ("mapstd",)][int(rng.integers(0, 3))])
-    return SyllableDetectorConfig(FS, 256, 256, 256 - hop, (lo, hi), 10, "linear", [float(rng.uniform(-0.5, 0.8))], net,
+    return SyllableDetectorConfig(FS, 256, W, W - hop, (lo, hi), T, "linear", [float(rng.uniform(-0.5, 0.8))], net,
                                   window=int(rng.integers(0, 4)), spectrum=_abi.SPECTRUM_POWER, rule=int(rng.integers(0, 2)))
 
 
@@ -189,10 +192,10 @@ def test_random_example_class_detector_on_the_register_resident_kernel(oracle_li
     import torch
     rng = np.random.default_rng(77000 + seed)
     cfg = draw_example_class(rng)
-    hop = 256 - cfg.windowOverlap
+    hop = cfg.windowLength - cfg.windowOverlap
     edges = [10, 11, 63, 64, 65, 73, 74, 127, 128, 129, 137, 192, 201, 2047, 2048, 2049, 2057, 2058, 4100]
-    frames = int(edges[seed % len(edges)] if seed < len(edges) else rng.integers(10, 6000))
-    S = 256 + (frames - 1) * hop + int(rng.integers(0, hop))
+    frames = max(cfg.timeRange, int(edges[seed % len(edges)] if seed < len(edges) else rng.integers(10, 6000)))
+    S = cfg.windowLength + (frames - 1) * hop + int(rng.integers(0, hop))
     C = int(rng.integers(1, 4))
     x = synth.channels(C, S, first=seed * 5, fs=FS) * float(10.0 ** rng.uniform(-3, 1))
     if rng.random() < 0.6:

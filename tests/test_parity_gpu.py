@@ -371,13 +371,13 @@ def test_both_fused_kernels_against_the_oracle_and_each_other(oracle_lib, monkey
 
 
 def test_register_resident_kernel_is_only_taken_where_it_is_instantiated(oracle_lib):
-    """hop 128 (bank-spread staging), another timeRange, a wider hidden layer: kernels_fused.hip's kernel."""
+    """A wider hidden layer, two outputs, a short window: kernels_fused.hip's kernel."""
     torch = _torch()
     base = nets.from_npz()
     rng = np.random.default_rng(5)
     x = synth.channel(30000, 3)[None].astype(np.float32)
     xd = torch.from_numpy(x).cuda()
-    for cfg in (nets.variant(base, windowOverlap=128), nets.variant(base, timeRange=8, net=nets.random_net(rng, 29 * 8, (4,), 1)),
+    for cfg in (nets.variant(base, net=nets.random_net(rng, 290, (4,), 2), thresholds=[0.5, 0.5]),
                 nets.variant(base, net=nets.random_net(rng, 290, (8,), 1))):
         with sd.SyllableDetector(cfg, channels=1, engine=_abi.ENGINE_FUSED) as det:
             det.profile(True)
