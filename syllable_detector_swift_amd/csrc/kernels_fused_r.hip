@@ -144,13 +144,13 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
         amax = wave_max_nonneg(amax);
         if (lane == 0) red[wave] = amax;
     };
-    auto pass_scale = [&]() {
-        const floatx4 r0 = *reinterpret_cast<const floatx4 *>(red);
+    auto scale_of = [&](floatx4 r0) {
         const float amax = fmaxf(fmaxf(r0[0], r0[1]), fmaxf(r0[2], r0[3]));
         int e = 13 - (int)((__float_as_uint(amax) >> 23) & 0xffu) + 127;
         e = amax > 0.0f ? (e < -100 ? -100 : (e > 100 ? 100 : e)) : 0;
         return __builtin_amdgcn_readfirstlane(e);
     };
+    auto pass_scale = [&]() { return scale_of(*reinterpret_cast<const floatx4 *>(red)); };
     // where this thread's quad k lands in a staged buffer (halves)
     int spos[NL];
 #pragma unroll
@@ -340,8 +340,18 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
         uint32x4 (&vs)[NL] = par ? v0 : v1;                           // pass q+1's samples: staged in this block
         uint32x4 (&vl)[NL] = par ? v1 : v0;                           // pass q+2's samples: loaded in this block, maximum taken at its end
         const _Float16 *fph = smp0 + par * buf_halves + foff, *fpl = fph + d.r_smp_stride;
-        half8 bh = lds_half8(fph + ko[0]), bl = lds_half8(fpl + ko[0]);   // first B fragments: in flight while the scale is worked out
-        const int se_next = pass_scale();                             // pass q+1 (its partial maxima are in)
+        half8 bh = lds_half8(fph + ko[0]), bl = lds_half8(fpl + ko[0]);   // first B fragments: all the first MFMA waits for
+        floatx4 r0 = *reinterpret_cast<const floatx4 *>(red);             // pass q+1's partial maxima
+        // In the shadow of those fetches: the vector half of finishing pass q-1 (magnitudes, sum of squares, f16 split; it
+        // needs nothing but the accumulators this wave kept), which would otherwise crowd the second half of the block.
+        const int dsc = se_ref - se_m1 < -60 ? -60 : (se_ref - se_m1 > 60 ? 60 : se_ref - se_m1);
+        const int rm = r3 == 0 ? 2 : r3 - 1, re = r3 == 2 ? 0 : r3 + 1;   // (q - 1) mod 3, (q - 2) mod 3
+#ifndef SYLDET_R_NOMAG
+#pragma unroll
+        for (int j = 0; j < 15; j++) mag_micro(j, rm, dsc);
+#endif
+        SD_PIN(r0);
+        const int se_next = scale_of(r0);                             // pass q+1's sample scale
         const float sx_next = pow2f(se_next);
         _Float16 *wh = smp0 + (par ^ 1) * buf_halves;
         // pass q+2's descriptor, kept incrementally in 32-bit scalar arithmetic (pass_rsrc's 64-bit clamps cost thirty
@@ -355,9 +365,7 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
 #endif
         base2 += kPass * d.hop;
         left2 -= kPass * d.hop;
-        // pass q-1's products go to ring region rm relative to the segment's first pass; pass q-2's are read from region re
-        const int dsc = se_ref - se_m1 < -60 ? -60 : (se_ref - se_m1 > 60 ? 60 : se_ref - se_m1);
-        const int rm = r3 == 0 ? 2 : r3 - 1, re = r3 == 2 ? 0 : r3 + 1;   // (q - 1) mod 3, (q - 2) mod 3
+        // (pass q-1's products go to ring region rm relative to the segment's first pass; pass q-2's are read from region re)
         floatx4 acc[4];
         {
             // the next pass's staging (scale, f16 hi/lo split, two LDS writes), one instruction per micro-step, one
@@ -385,7 +393,7 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
             // one micro-step a tick throughout; the evaluation of pass q-2 in the first half, the finishing of pass q-1
             // behind it.  (Measured before the second staging set existed: two staging steps a tick in the first half with
             // each quad reloaded as soon as it was staged, 1.37 ms; one a tick with the block maximum behind the block, 1.42.)
-            constexpr int kTicks = 12 * KS, kMag0 = 44;               // kMag0: first tick of pass q-1's finishing
+            constexpr int kTicks = 12 * KS;
             auto tick_work = [&](int i) {
                 if (STAMP && i % 24 == 0) { SD_RTICK(i / 24) }         // quarters of the block, diagnostic instantiation only
                 // (SYLDET_R_NO*: diagnostic builds with one piece knocked out, tools/r_knockouts.sh; never the shipped library)
@@ -398,8 +406,8 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
                 if (i >= 9 && i < 14) eval_reduce(i - 9);
 #endif
 #ifndef SYLDET_R_NOMAG
-                const int jm = i - kMag0;                              // pass q-1: one micro-step a tick, behind the evaluation
-                if (jm >= 0 && jm < kMagSteps) mag_micro(jm, rm, dsc);
+                const int jm = i + 14;                                 // pass q-1's tap products and their stores: the first ticks
+                if (i >= 1 && jm < kMagSteps) mag_micro(jm, rm, dsc);
 #endif
 #ifndef SYLDET_R_NOMAX
                 const int jx = i - (kTicks - NL - 4);                  // block maximum of pass q+2, a quad a tick (its loads left in the
@@ -416,7 +424,7 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
                 if (jx == NL + 2 && lane == 0) red[wave] = amax_run;
 #endif
             };
-            static_assert(kMag0 + kMagSteps <= kTicks && 10 * NL <= kTicks && TMAX <= 12 && TMAX - 1 <= kPLead, "tick schedule");
+            static_assert(10 * NL <= kTicks && TMAX <= 12 && TMAX - 1 <= kPLead, "tick schedule");
             // The DFT's accumulators live in the accumulation registers (an MFMA whose C/D operands are architectural
             // registers takes 9.9 ns against 8.4: tools/ubench), which the basis alone would fill: its last four quads are
             // architectural instead.
