@@ -370,11 +370,26 @@ void fused_segmentation(FusedDesc &d, int64_t E, int C)
     runs = std::max<int64_t>(1, std::min<int64_t>(16, runs));
     d.runs = (int)runs;
     d.seg_evals = (int)(runs * kFusedTileFrames - (d.T - 1));
-    // the 64-frame-pass kernel: the same segment length in samples, twice the passes
-    int64_t rr = (frames * (int64_t)C) / ((int64_t)kFusedRTileFrames * 2048);
-    rr = std::max<int64_t>(1, std::min<int64_t>(32, rr));
-    d.r_runs = (int)rr;
-    d.r_seg_evals = (int)(rr * kFusedRTileFrames - (d.T - 1));
+    // The 64-frame-pass kernel runs one workgroup per CU, and a workgroup pays a prologue and a drain worth about two passes:
+    // segments as long as the batch allows (up to 64 passes), their number per channel rounded up so that the grid is
+    // whole rounds of the 256 CUs where the channel count allows (64 channels x 32 segments = 8 rounds for the benchmark batch).
+    {
+        const int64_t max_evals = 64 * (int64_t)kFusedRTileFrames - (d.T - 1);
+        int64_t segs = std::max<int64_t>(1, (E + max_evals - 1) / max_evals);
+        if ((int64_t)C * segs >= 1024) {                 // large grids: whole rounds
+            int g = C, m = 256;
+            while (g) { const int t = m % g; m = g; g = t; }   // m = gcd(C, 256)
+            const int64_t mult = 256 / m;
+            segs = (segs + mult - 1) / mult * mult;
+        } else {                                         // small batches: more, shorter segments to fill the chip
+            segs = std::max<int64_t>(segs, std::min<int64_t>((1024 + C - 1) / C, (frames + kFusedRTileFrames - 1) / kFusedRTileFrames));
+        }
+        const int64_t per = (E + segs - 1) / segs;       // evaluations per segment
+        int64_t rr = (per + (d.T - 1) + kFusedRTileFrames - 1) / kFusedRTileFrames;
+        rr = std::max<int64_t>(1, std::min<int64_t>(64, rr));
+        d.r_runs = (int)rr;
+        d.r_seg_evals = (int)(rr * kFusedRTileFrames - (d.T - 1));
+    }
 }
 
 }  // namespace sd
