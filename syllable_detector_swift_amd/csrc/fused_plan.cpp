@@ -371,10 +371,10 @@ void fused_segmentation(FusedDesc &d, int64_t E, int C)
     d.runs = (int)runs;
     d.seg_evals = (int)(runs * kFusedTileFrames - (d.T - 1));
     // The 64-frame-pass kernel runs one workgroup per CU, and a workgroup pays a prologue and a drain worth about two passes:
-    // segments as long as the batch allows (up to 64 passes), their number per channel rounded up so that the grid is
-    // whole rounds of the 256 CUs where the channel count allows (64 channels x 32 segments = 8 rounds for the benchmark batch).
+    // segments as long as the batch allows (up to 128 passes; 256 and 512 measured the same), their number per channel rounded up so that the grid is
+    // whole rounds of the 256 CUs where the channel count allows (64 channels x 16 segments = 4 rounds for the benchmark batch).
     {
-        const int64_t max_evals = 64 * (int64_t)kFusedRTileFrames - (d.T - 1);
+        const int64_t max_evals = 128 * (int64_t)kFusedRTileFrames - (d.T - 1);
         int64_t segs = std::max<int64_t>(1, (E + max_evals - 1) / max_evals);
         if ((int64_t)C * segs >= 1024) {                 // large grids: whole rounds
             int g = C, m = 256;
@@ -386,7 +386,7 @@ void fused_segmentation(FusedDesc &d, int64_t E, int C)
         }
         const int64_t per = (E + segs - 1) / segs;       // evaluations per segment
         int64_t rr = (per + (d.T - 1) + kFusedRTileFrames - 1) / kFusedRTileFrames;
-        rr = std::max<int64_t>(1, std::min<int64_t>(64, rr));
+        rr = std::max<int64_t>(1, std::min<int64_t>(128, rr));
         d.r_runs = (int)rr;
         d.r_seg_evals = (int)(rr * kFusedRTileFrames - (d.T - 1));
     }
