@@ -363,33 +363,31 @@ bool make_mlpx_plan(const syldet_config_t &c, const syldet_geometry_t &g, MlpxPl
 
 void fused_segmentation(FusedDesc &d, int64_t E, int C)
 {
-    // a workgroup segment = `runs` passes of 128 frames, emitting 128*runs - (T-1) evaluations; aim for
-    // >= ~2048 segments in flight-worthy grids, at most 16 passes each
+    // A workgroup segment = `runs` consecutive passes of one channel, emitting pass * runs - (T-1) evaluations.  Both kernels
+    // run one workgroup per CU, and a workgroup pays a prologue and a drain worth about two passes: segments as long as the
+    // batch allows (up to kMax passes; longer measured the same), their number per channel rounded up so that the grid is
+    // whole rounds of the 256 CUs where the channel count allows (64 channels x 16 segments = 4 rounds for the benchmark
+    // batch on the 64-frame-pass kernel); small batches get more, shorter segments to fill the chip.
     const int64_t frames = E + d.T - 1;
-    int64_t runs = (frames * (int64_t)C) / ((int64_t)kFusedTileFrames * 2048);
-    runs = std::max<int64_t>(1, std::min<int64_t>(16, runs));
-    d.runs = (int)runs;
-    d.seg_evals = (int)(runs * kFusedTileFrames - (d.T - 1));
-    // The 64-frame-pass kernel runs one workgroup per CU, and a workgroup pays a prologue and a drain worth about two passes:
-    // segments as long as the batch allows (up to 128 passes; 256 and 512 measured the same), their number per channel rounded up so that the grid is
-    // whole rounds of the 256 CUs where the channel count allows (64 channels x 16 segments = 4 rounds for the benchmark batch).
-    {
-        const int64_t max_evals = 128 * (int64_t)kFusedRTileFrames - (d.T - 1);
+    auto segment = [&](int pass, int kMax, int &runs_out, int &seg_out) {
+        const int64_t max_evals = (int64_t)kMax * pass - (d.T - 1);
         int64_t segs = std::max<int64_t>(1, (E + max_evals - 1) / max_evals);
-        if ((int64_t)C * segs >= 1024) {                 // large grids: whole rounds
+        if ((int64_t)C * segs >= 1024) {
             int g = C, m = 256;
             while (g) { const int t = m % g; m = g; g = t; }   // m = gcd(C, 256)
             const int64_t mult = 256 / m;
             segs = (segs + mult - 1) / mult * mult;
-        } else {                                         // small batches: more, shorter segments to fill the chip
-            segs = std::max<int64_t>(segs, std::min<int64_t>((1024 + C - 1) / C, (frames + kFusedRTileFrames - 1) / kFusedRTileFrames));
+        } else {
+            segs = std::max<int64_t>(segs, std::min<int64_t>((1024 + C - 1) / C, (frames + pass - 1) / pass));
         }
         const int64_t per = (E + segs - 1) / segs;       // evaluations per segment
-        int64_t rr = (per + (d.T - 1) + kFusedRTileFrames - 1) / kFusedRTileFrames;
-        rr = std::max<int64_t>(1, std::min<int64_t>(128, rr));
-        d.r_runs = (int)rr;
-        d.r_seg_evals = (int)(rr * kFusedRTileFrames - (d.T - 1));
-    }
+        int64_t rr = (per + (d.T - 1) + pass - 1) / pass;
+        rr = std::max<int64_t>(1, std::min<int64_t>(kMax, rr));
+        runs_out = (int)rr;
+        seg_out = (int)(rr * pass - (d.T - 1));
+    };
+    segment(kFusedTileFrames, 64, d.runs, d.seg_evals);
+    segment(kFusedRTileFrames, 128, d.r_runs, d.r_seg_evals);
 }
 
 }  // namespace sd
