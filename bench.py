@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--workload", default="sample", choices=["sample", "config3", "config5"])
     ap.add_argument("--engine", type=int, default=0, help="0 auto, 1 generic, 2 fused")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-gather", action="store_true", help="run the flag exchange even with one rank (rehearsal of the multi-GPU step)")
     args = ap.parse_args()
 
     import numpy as np
@@ -97,9 +98,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 or args.force_gather:
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if world == 1:                                   # rehearsal: a one-rank RCCL group
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29593")
+            dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
@@ -121,7 +127,7 @@ def main():
     if args.overlap is not None:
         cfg = nets.variant(cfg, windowOverlap=args.overlap)
 
-    from syllable_detector_swift_amd.dist import gather_flags
+    from syllable_detector_swift_amd.dist import PipelinedFlagGather
     det = sd.SyllableDetector(cfg, channels=C, device=local_rank, engine=args.engine)
     g = det.geometry
     J, E = det.countFrames(S), det.countEvaluations(S)
@@ -129,11 +135,14 @@ def main():
     outputs = torch.empty((C, E, g.outputs), dtype=torch.float32, device=dev)
     flags = torch.empty((C, E), dtype=torch.uint8, device=dev)
     det.profile(True)
+    # ONE collective per batch: [world*C, E] u8 flags on every rank, as bits; the exchange of batch i runs on a side stream
+    # under the kernel of batch i+1 (the timed region ends with every exchange finished: torch.cuda.synchronize below)
+    gather = PipelinedFlagGather(C, E, world * C, dev) if (world > 1 or args.force_gather) else None
 
     def step():
         det.run(x, outputs, flags)
-        if world > 1:
-            gather_flags(flags, world * C)       # ONE collective per batch: [world*C, E] u8 flags on every rank
+        if gather is not None:
+            gather.submit(flags)
 
     for _ in range(args.warmup):
         step()
@@ -180,7 +189,7 @@ def main():
             "config": {"workload": name, "channels_per_gpu": C, "samples_per_channel": S, "frames_per_channel": J,
                        "evaluations_per_channel": E, "fourier_length": cfg.fourierLength, "hop": g.hop,
                        "bins": [g.f0, g.f1], "time_range": cfg.timeRange, "engine": {1: "generic", 2: "fused", 3: "wide_bf16"}.get(g.engine, str(g.engine)),
-                       "sharding": "channels, %d per GPU; one all-gather of flags per step" % C if world > 1 else "single GPU"},
+                       "sharding": "channels, %d per GPU; one all-gather of flags (as bits) per step, on a side stream under the next step's kernel" % C if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": measured_traffic(C, S, g.hop, {1: "generic", 2: "fused"}.get(g.engine, ""), dom),
@@ -218,7 +227,7 @@ def main():
                 line["cpu_baseline_all_cores"] = cpu_baseline(cfg, host, threads=ncpu)
         print(json.dumps(line), flush=True)
     det.close()
-    if world > 1:
+    if world > 1 or args.force_gather:
         dist.destroy_process_group()
 
 

@@ -21,27 +21,30 @@ def shard_channels(total_channels: int, world_size: int, rank: int) -> Tuple[int
     return first, base + (1 if rank < extra else 0)
 
 
-def pack_flags(flags):
-    """[rows, E] uint8 flags on a GPU -> [rows, ceil(E / 8)] bytes, bit b of byte t = flag 8 t + b (libsyldet kernel)."""
+def pack_flags(flags, out=None):
+    """[rows, E] uint8 flags on a GPU -> [rows, ceil(E / 8)] bytes, bit b of byte t = flag 8 t + b (libsyldet kernel,
+    on the current stream; `out`: a buffer to write into)."""
     import torch
     from . import _abi
     from .config import check
     rows, E = int(flags.shape[0]), int(flags.shape[1])
     flags = flags.contiguous()
-    bits = torch.empty((rows, (E + 7) // 8), dtype=torch.uint8, device=flags.device)
+    bits = out if out is not None else torch.empty((rows, (E + 7) // 8), dtype=torch.uint8, device=flags.device)
+    assert bits.shape == (rows, (E + 7) // 8) and bits.is_contiguous() and bits.dtype == torch.uint8
     check(_abi.lib.syldet_pack_flags_device(flags.data_ptr(), rows, E, bits.data_ptr(),
                                             torch.cuda.current_stream(flags.device).cuda_stream))
     return bits
 
 
-def unpack_flags(bits, E: int):
+def unpack_flags(bits, E: int, out=None):
     """Inverse of pack_flags: [rows, ceil(E / 8)] bytes -> [rows, E] uint8 flags (0 / 1)."""
     import torch
     from . import _abi
     from .config import check
     rows = int(bits.shape[0])
     bits = bits.contiguous()
-    flags = torch.empty((rows, E), dtype=torch.uint8, device=bits.device)
+    flags = out if out is not None else torch.empty((rows, E), dtype=torch.uint8, device=bits.device)
+    assert flags.shape == (rows, E) and flags.is_contiguous() and flags.dtype == torch.uint8
     check(_abi.lib.syldet_unpack_flags_device(bits.data_ptr(), rows, E, flags.data_ptr(),
                                               torch.cuda.current_stream(bits.device).cuda_stream))
     return flags
@@ -76,6 +79,60 @@ def gather_flags(local_flags, total_channels: int, group=None, packed=None):
     buf = torch.empty((world * biggest, E), dtype=local_flags.dtype, device=local_flags.device)
     dist.all_gather_into_tensor(buf, padded, group=group)
     return torch.cat([buf[r * biggest: r * biggest + counts[r]] for r in range(world)], dim=0)
+
+
+class PipelinedFlagGather:
+    """gather_flags for a stream of batches on GPUs with equal shards.  The exchange of batch i -- bit-packing on the
+    compute stream (it has to read the flags before the next batch's kernel overwrites them: 10 us), then the one
+    all-gather and the unpacking on a side stream -- runs under the kernels of batch i+1 instead of between them: xGMI is
+    point-to-point, the ring all-gather of 8 ranks is per-link bound, and it is the only thing a rank ever waits for.
+    Buffers alternate between two sets; `result(k)` makes the current stream wait for exchange k."""
+
+    def __init__(self, local_rows: int, E: int, total_channels: int, device, group=None):
+        import torch
+        import torch.distributed as dist
+        world = dist.get_world_size(group)
+        if local_rows * world != total_channels:
+            raise ValueError("PipelinedFlagGather needs equal shards (use gather_flags for ragged ones)")
+        self.E, self.group, self.device = int(E), group, torch.device(device)
+        nb = (self.E + 7) // 8
+        self.bits = [torch.empty((local_rows, nb), dtype=torch.uint8, device=self.device) for _ in range(2)]
+        self.gbits = [torch.empty((total_channels, nb), dtype=torch.uint8, device=self.device) for _ in range(2)]
+        self.out = [torch.empty((total_channels, self.E), dtype=torch.uint8, device=self.device) for _ in range(2)]
+        self.side = torch.cuda.Stream(self.device)
+        self.done = [None, None]
+        self.n = 0
+
+    def submit(self, local_flags) -> int:
+        """Queue the exchange of this batch's flags (written by work already queued on the current stream)."""
+        import torch
+        import torch.distributed as dist
+        k = self.n & 1
+        self.n += 1
+        cur = torch.cuda.current_stream(self.device)
+        if self.done[k] is not None:
+            cur.wait_event(self.done[k])                 # set k's previous exchange has been through (two batches ago)
+        pack_flags(local_flags, out=self.bits[k])
+        packed = torch.cuda.Event()
+        packed.record(cur)
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(packed)
+            dist.all_gather_into_tensor(self.gbits[k], self.bits[k], group=self.group)
+            unpack_flags(self.gbits[k], self.E, out=self.out[k])
+            done = torch.cuda.Event()
+            done.record(self.side)
+        self.done[k] = done
+        return k
+
+    def result(self, k: int):
+        """[total_channels, E] uint8 flags of exchange k, valid for work queued on the current stream after this call
+        (and until the exchange after next reuses the set)."""
+        import torch
+        torch.cuda.current_stream(self.device).wait_event(self.done[k])
+        return self.out[k]
+
+    def synchronize(self):
+        self.side.synchronize()
 
 
 class ShardedSyllableDetector:

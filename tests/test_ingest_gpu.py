@@ -325,3 +325,40 @@ def test_packed_gather_over_rccl_single_rank(tmp_path):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29591", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
+def test_pipelined_gather_over_rccl_single_rank(tmp_path):
+    """PipelinedFlagGather (the multi-GPU benchmark step: the exchange of batch i on a side stream under the kernel of batch
+    i+1) through a real RCCL group of one rank: eight batches whose flags are overwritten in place by the next batch's
+    producer, every exchange equal to its own batch."""
+    import os
+    import subprocess
+    import sys
+    script = tmp_path / "gather2.py"
+    script.write_text(
+        "import os, sys, numpy as np, torch, torch.distributed as dist\n"
+        "sys.path.insert(0, %r)\n"
+        "from syllable_detector_swift_amd.dist import PipelinedFlagGather\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group(backend='nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))\n"
+        "rng = np.random.default_rng(5)\n"
+        "rows, E = 6, 100003\n"
+        "batches = [(rng.random((rows, E)) < 0.3).astype(np.uint8) for _ in range(8)]\n"
+        "dev = [torch.from_numpy(b).cuda() for b in batches]\n"
+        "flags = torch.empty((rows, E), dtype=torch.uint8, device='cuda')\n"
+        "g = PipelinedFlagGather(rows, E, rows, torch.device('cuda', 0))\n"
+        "got = []\n"
+        "for i in range(8):\n"
+        "    flags.copy_(dev[i])                      # the producer overwrites the same buffer every batch\n"
+        "    k = g.submit(flags)\n"
+        "    if i >= 1:\n"
+        "        got.append(g.result((i - 1) & 1).clone())   # read batch i-1 while batch i is in flight\n"
+        "got.append(g.result(7 & 1).clone())\n"
+        "g.synchronize(); torch.cuda.synchronize()\n"
+        "for i in range(8):\n"
+        "    assert np.array_equal(got[i].cpu().numpy(), batches[i]), i\n"
+        "dist.destroy_process_group()\n"
+        "print('ok')\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29592", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
