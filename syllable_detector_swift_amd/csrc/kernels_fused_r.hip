@@ -6,22 +6,23 @@
 //   processNewValue       Common/SyllableDetector.swift:153-217
 //   NeuralNet.apply       Common/NeuralNet.swift:294-326, :366-377
 //   lastDetected          Common/SyllableDetector.swift:27-31),
-// a different use of the CU.  A gfx950 wave that is alone on its SIMD owns 512 registers: the 64 KB of f16 hi/lo
-// basis fragments (A operands of the windowed band-limited DFT) are exactly 256 of them, so
+// a different use of the CU.  A gfx950 wave that is alone on its SIMD owns 512 registers: the 64 KB
+// of f16 hi/lo basis fragments (A operands of the windowed band-limited DFT) are exactly 256 of them, so
 //   * one workgroup = 4 waves, one per SIMD, 16 frames each: 64-frame passes;
-//   * the basis never travels through LDS again -- a k-step fetches two B fragments (staged samples, hi + lo) for
-//     its 12 MFMAs instead of ten fragments, which a lone wave can do under the MFMAs;
-//   * the 64 KB of LDS the basis used to take hold a second staged-sample buffer: pass p+1 is scaled, split and
-//     staged, and pass p+2's loads are issued, INSIDE the matrix block of pass p, together with the evaluation of
-//     pass p-1 -- one branch-free scheduling region in which vector, LDS and memory instructions ride between
-//     the MFMAs of the same wave.  Outside it only the magnitudes, the transition strip and the block maximum
-//     are left.
+//   * the basis never travels through LDS again -- a k-step fetches two B fragments (staged samples, hi + lo) for its 12
+//     MFMAs instead of ten fragments;
+//   * the first layer takes ALL taps as the rows of one GEMM (row 4 t + h) whose B operand is the wave's own magnitudes, still
+//     in the registers the DFT left them in: 9 MFMAs per 16 frames, no |X| columns in LDS, no transition strip; tap products
+//     go to an LDS ring and an evaluation is their diagonal sum;
+//   * three passes are in flight and everything that crosses waves crosses a pass boundary:
 //
-//   block M(p):  DFT(p) from staged buffer p&1  ||  evaluation of pass p-1 (columns)  ||  stage pass p+1 into the
-//                other buffer  ||  reload the staging registers with pass p+2
-//   barrier      (columns no longer read)
-//   transition strip, |X|(p) -> columns, block-max partial of pass p+2
-//   barrier      (columns, staged pass p+1 and the partial maxima are complete)
+//   matrix block of pass q:  DFT(q) from staged buffer q&1
+//                            ||  stage pass q+1 into the other buffer, load pass q+2 into the other staging register set
+//                            ||  finish pass q-1 (magnitudes, tap products -> ring)  ||  evaluate pass q-2 (ring)
+//                            ||  block maximum of pass q+2
+//   barrier
+//
+//   one scheduling region in which every vector, LDS and memory instruction has its place between two MFMAs of the same wave.
 //
 // gfx950 only.  wave = 64.
 
