@@ -241,14 +241,15 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
             SD_PIN(ssw);
         }
     };
-    const float *zero_ss = pbuf + (kPRows - 1) * kPStride + 48;       // a float that stays zero
+    const float *zero_ss = pbuf + (kPRows - 1) * kPStride + 48;       // floats 36 .. 48 of the last row stay zero
     auto eval_slot = [&](int s, int pp, int re) {
         if (s == 0) {
             const float *erow = pbuf + (kPLead + 64 * re + fl - (T - 1)) * kPStride;
 #pragma unroll
             for (int tt = 0; tt < 3; tt++) {
                 const int t = g4 + 4 * tt;
-                pv[tt] = *reinterpret_cast<const floatx4 *>(erow + t * kPStride + 4 * t);
+                // (taps past timeRange: their products are 0 * column, which is NaN for a column with a NaN in it -- read zeros)
+                pv[tt] = *reinterpret_cast<const floatx4 *>(t < T ? erow + t * kPStride + 4 * t : zero_ss - 12);
                 sv[tt] = *(t < T ? erow + t * kPStride + 48 : zero_ss);
             }
         }
@@ -281,7 +282,7 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
         // this frame's row in the ring; the ring's last T-1 frames are repeated in front of it (elsewhere: a spare spot)
         float *prow = pbuf + (kPLead + 64 * rm + fl) * kPStride;
         float *drow = (rm == 2 && fl >= kPass - (T - 1)) ? pbuf + (kPLead + fl - kPass) * kPStride : nullptr;
-        float *spare = pbuf + (kPRows - 1) * kPStride;             // floats 0 .. 47 and 49 .. of the last row are never read
+        float *spare = pbuf + (kPRows - 1) * kPStride;             // floats 0 .. 35 and 49 .. of the last row: where lanes with nothing to store store
         if (j < 8) {                                              // |X| of one bin
             const int i = j;
             float re = accP[i >> 2][i & 3], im = accP[2 + (i >> 2)][i & 3];

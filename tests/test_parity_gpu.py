@@ -423,3 +423,30 @@ def test_network_stage_on_the_matrix_cores(oracle_lib, N, lo, hi, T, H):
             util.assert_outputs_close(out[c][ok], w64[ok])
             util.assert_flags_exact(fl[c][ok], w64[ok], cfg.thresholds, cfg.rule)
             assert not fl[c][~ok].any()
+
+
+@pytest.mark.parametrize("classic", [False, True])
+def test_a_nan_sample_poisons_exactly_the_windows_that_contain_it(oracle_lib, monkeypatch, classic):
+    """The reference propagates a NaN sample into the frames that cover it and from there into the timeRange evaluations
+    whose windows contain those frames -- no more (rows of zero weights in a GEMM still turn a NaN column into NaN
+    products: the register-resident-basis kernel reads zeros for the taps past timeRange instead).  Both fused kernels."""
+    torch = _torch()
+    if classic:
+        monkeypatch.setenv("SYLDET_FUSED_CLASSIC", "1")
+    else:
+        monkeypatch.delenv("SYLDET_FUSED_CLASSIC", raising=False)
+    cfg = util.sample_net()
+    x = synth.syllable_channel(64 * 132 * 5 + 700, util.template(), seed=8).astype(np.float32)
+    x[25000] = np.nan
+    x[31337] = np.nan
+    with sd.SyllableDetector(cfg, channels=1) as det:
+        out, fl = det.run(torch.from_numpy(x[None]).cuda())
+        torch.cuda.synchronize()
+        out, fl = out.cpu().numpy()[0], fl.cpu().numpy()[0]
+    _, _, w64 = util.oracle_for(cfg).run(x, po.F64)
+    ok = np.isfinite(w64).all(axis=1)
+    assert 0 < (~ok).sum() < 40
+    assert (np.isfinite(out).all(axis=1) == ok).all()
+    util.assert_outputs_close(out[ok], w64[ok])
+    util.assert_flags_exact(fl[ok], w64[ok], cfg.thresholds, cfg.rule)
+    assert not fl[~ok].any()
