@@ -2,7 +2,7 @@
 
 - `from_npz`: the reference's example detector (sample.txt: 44.1 kHz, N=W=256, overlap 124,
   2-7 kHz, T=10, linear, l2normalize -> mapminmax, 290 -> 4 TanSig -> 1 PureLin, output
-  mapminmax) re-encoded as arrays in tests/golden/sample_net.npz by tools/make_golden.py;
+  mapminmax) re-encoded as arrays in tests/golden/sample_net.npz by tests/golden/make_golden.py;
 - `config3`: synthetic N=W=1024, overlap 768 (hop 256), 1160 -> 4 -> 1 (BASELINE config 3);
 - `wide_mlp`: sample front-end with a 290 -> 4096 -> 1 network (BASELINE config 5);
 - `variant`: small edits of a configuration for parity cases.
