@@ -47,7 +47,8 @@ constexpr int kPLead = 11;                     // ring row 0 sits at row kPLead
 
 // KS: k-steps of 32 samples (the basis takes 32 KS registers); TMAX: largest timeRange; NL: staging quads per thread (all NL are
 // always loaded and staged: quads past the pass come back as zeros from the descriptor's bounds check and land in LDS
-// words no frame reads); SKEW: staged samples carry bank-spreading padding; STAMP: diagnostic phase timing.
+// words no frame reads); SKEW: staged samples carry bank-spreading padding -- instantiated for hop 128 only, where the
+// padding (4 halves after every 128 samples) is a matter of constants; STAMP: diagnostic phase timing.
 // The network class is the reference's example detector's (kernels_fused.hip's LEAN): l2normalize first, linear |X|
 // columns, two layers, TanSig hidden units (at most 4), one output, at most one output map.
 template <int KS, int TMAX, int NL, bool SKEW, bool STAMP>
@@ -124,10 +125,12 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
     if (d.n_out_fns == 1) { lean_oa = d.out_params[0]; lean_og = d.out_params[1]; lean_ob = d.out_params[2]; }
 
     // this lane's frame in a staged buffer, and where k-step ks of lane group g4 starts inside it (see kernels_fused.hip)
-    const int foff = fl * (d.hop + (SKEW ? d.skew : 0)) + (SKEW ? 0 : 8 * KS * g4);
+    // SKEW (hop 128: every frame would start on the same LDS bank): sample i sits at i + 4 (i >> 7), so frame fl starts at
+    // 132 fl and lane group g4's blocks at 64 g4 + 4 (g4 >> 1) inside it; a k-step's 8 ks < 64 never crosses a padding
+    const int foff = SKEW ? fl * 132 + 64 * g4 + 4 * (g4 >> 1) : fl * d.hop + 8 * KS * g4;
     int ko[KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ks++) ko[ks] = SKEW ? d.koff[ks * 4 + g4] : 8 * ks;
+    for (int ks = 0; ks < KS; ks++) ko[ks] = 8 * ks;
 
     // raw samples of one pass: quads 4*(tid + 256 k), k < NL, through a bounds-checked descriptor
     // two sets: pass q+1 (being staged during the matrix block of pass q) is in set (q+1)&1, pass q+2 arrives in set q&1
@@ -152,13 +155,9 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
         return __builtin_amdgcn_readfirstlane(e);
     };
     auto pass_scale = [&]() { return scale_of(*reinterpret_cast<const floatx4 *>(red)); };
-    // where this thread's quad k lands in a staged buffer (halves)
-    int spos[NL];
-#pragma unroll
-    for (int k = 0; k < NL; k++) {
-        const int i = 4 * (tid + kBlock * k);
-        spos[k] = SKEW ? i + d.skew * (int)__umulhi((unsigned)i, d.hop_magic) : i;
-    }
+    // where this thread's quad k lands in a staged buffer (halves): 4 tid + 1024 k, with SKEW + 4 ((4 tid + 1024 k) >> 7)
+    const int sbase = SKEW ? 4 * tid + 4 * (tid >> 5) : 4 * tid;
+    constexpr int kinc = SKEW ? 4 * kBlock + 32 : 4 * kBlock;
 
     // ---- prologue: pass 0 staged, pass 1 in the staging registers with its block maximum published
     int se_cur, se_m1 = 0;                // sample scale exponents of the pass in the matrix block and of the one before it
@@ -177,7 +176,7 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
             split_pair_scaled(q[0], q[1], sx, h0, l0);
             split_pair_scaled(q[2], q[3], sx, h1, l1);
             uint32x2 uh = {h0, h1}, ul = {l0, l1};
-            _Float16 *ph = smp0 + (SKEW ? spos[k] : 4 * tid + 4 * kBlock * k);
+            _Float16 *ph = smp0 + sbase + kinc * k;
             *reinterpret_cast<uint32x2 *>(ph) = uh;
             *reinterpret_cast<uint32x2 *>(ph + d.r_smp_stride) = ul;
         }
@@ -386,7 +385,7 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
                 if (j == 5) asm volatile("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(ml1) : "v"(qv[2]), "v"(sx_next), "v"(mh1));
                 if (j == 6) asm volatile("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(ml0) : "v"(qv[1]), "v"(sx_next), "v"(mh0));
                 if (j == 7) asm volatile("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(ml1) : "v"(qv[3]), "v"(sx_next), "v"(mh1));
-                _Float16 *ph = wh + (SKEW ? spos[k] : 4 * tid + 4 * kBlock * k);
+                _Float16 *ph = wh + sbase + kinc * k;
                 if (j == 8) { uint32x2 uh = {mh0, mh1}; *reinterpret_cast<uint32x2 *>(ph) = uh; }
                 if (j == 9) { uint32x2 ul = {ml0, ml1}; *reinterpret_cast<uint32x2 *>(ph + d.r_smp_stride) = ul; }
             };
@@ -530,8 +529,9 @@ hipError_t launch_one(const FusedDesc &d, const float *samples, int64_t stride, 
 // Shapes this kernel is instantiated for: the reference's example detector class (l2normalize first, linear |X| columns,
 // two layers, at most 4 TanSig hidden units, one output, at most one output map), windows of 132 .. 256 samples (8
 // k-steps), timeRange up to 12, at most 9 staging quads per thread (hop <= 140, the reference's 132 among them), no
-// bank-spreading padding (hop not a multiple of 16: that instantiation spills and measured 1.85 ms against the 8-wave
-// kernel's 1.47 at hop 128).  Everything else stays on kernels_fused.hip's kernel.
+// bank-spreading padding except at hop 128 (a table-driven instantiation for any multiple of 16 spilled and measured 1.85 ms
+// against the 8-wave kernel's 1.47; at hop 128 the padding is a matter of constants).  Everything else stays on
+// kernels_fused.hip's kernel.
 bool fused_r_has_stamps()
 {
 #ifdef SYLDET_R_STAMPS
@@ -545,7 +545,7 @@ bool fused_r_applicable(const FusedDesc &d)
 {
     const bool lean = d.norm == 1 && d.scaling == 0 && d.n_layers == 2 && d.tf0 == 0 /* TanSig */ && d.tf1 == 2 /* PureLin */ &&
                       d.n_out == 1 && d.H <= 4 && d.n_out_fns <= 1;
-    return d.r_ok && d.KS == 8 && d.T <= 12 && d.r_nload <= 9 && d.skew == 0 && lean;
+    return d.r_ok && d.KS == 8 && d.T <= 12 && d.r_nload <= 9 && (d.skew == 0 || (d.skew == 4 && d.hop == 128)) && lean;
 }
 
 hipError_t launch_fused_r(const FusedDesc &d, const float *samples, int64_t stride, int C, int64_t S, int64_t J,
@@ -558,6 +558,7 @@ hipError_t launch_fused_r(const FusedDesc &d, const float *samples, int64_t stri
 #ifdef SYLDET_R_STAMPS                // diagnostic builds only (-DSYLDET_R_STAMPS): the instantiation with phase timing
     if (d.stamps && d.skew == 0) return launch_one<8, 12, 9, false, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
 #endif
+    if (d.skew != 0) return launch_one<8, 12, 9, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
     return launch_one<8, 12, 9, false>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
 }
 
