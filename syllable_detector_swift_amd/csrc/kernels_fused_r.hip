@@ -217,7 +217,6 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
 #define SD_PIN(x) asm volatile("" : "+v"(x))
     float amax_run = 0.0f;
     floatx4 accP[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // pass q-1's DFT
-    constexpr int cse_e = 0, csx_e = 0;   // (the shared evaluation block's column scales: unused by l2normalize detectors)
     const int se_ref = se_cur;            // products are stored relative to the segment's first pass
     int r3 = 0;                           // q mod 3
 
@@ -227,17 +226,46 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
     // four ticks; the fetches two slots ahead of the sums.
     floatx4 pv[3], zp = {0.f, 0.f, 0.f, 0.f};
     float sv[3], ssp = 0.0f;
-    // the sums over the four lane groups, one value a tick (ticks 9 .. 13 of the block)
+    // The sums over the four lane groups, as a halving butterfly: v_permlane16_swap of (z0, z1) leaves the pair sum of z0 in
+    // the even 16-lane rows and that of z1 in the odd ones, likewise (z2, z3); v_permlane32_swap of the two results leaves
+    // the total of z[g4] in lane group g4 -- three swaps and three adds for the four units, and each lane group then runs
+    // ONE hidden unit (its own) through the transfer function instead of all four.  One step a tick (ticks 9 .. 12).
+    float s01 = 0.0f, s23 = 0.0f, zt = 0.0f;
+    const float b0g = g4 < H ? d.bias0[g4] : 0.0f, w1g = g4 < H ? d.w1[g4] : 0.0f;   // this lane group's hidden unit
     auto eval_reduce = [&](int k) {
-        if (k < 4) {
-            float x = zp[k];
-            SD_PIN(x);
-            z[k] = xor32_sum(xor16_sum(x));
-            SD_PIN(z[k]);
-        } else if (k == 4) {
+        if (k == 0) {
+            const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(zp[0]), __float_as_uint(zp[1]), false, false);
+            s01 = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+            SD_PIN(s01);
+        } else if (k == 1) {
+            const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(zp[2]), __float_as_uint(zp[3]), false, false);
+            s23 = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+            SD_PIN(s23);
+        } else if (k == 2) {
+            const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(s01), __float_as_uint(s23), false, false);
+            zt = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+            SD_PIN(zt);
+        } else if (k == 3) {
             SD_PIN(ssp);
             ssw = xor32_sum(xor16_sum(ssp));
             SD_PIN(ssw);
+        }
+    };
+    // the rest of the network (NeuralNet.swift:47-59 L2Normalize on the folded first layer, :189-194 TanSig, :366-377 second
+    // layer, :137-142 / :175-180 reverse output map; SyllableDetector.swift:27-31 threshold), one step a slot
+    float ypart = 0.0f;
+    auto eval_tail = [&](int k, int pp) {
+        if (k == 0) {                                             // this group's unit: z and the sums of squares are both relative
+            const float a = fmaf(d.w_unscale * __builtin_amdgcn_rsqf(ssw), zt, b0g);
+            ypart = w1g * transfer_fn(0, a);
+            SD_PIN(ypart);
+        } else if (k == 1) {
+            float y = xor32_sum(xor16_sum(ypart)) + c_b1[0];
+            y = (y - lean_oa) / lean_og + lean_ob;
+            yv[0] = y;
+            hit = (double)y >= reinterpret_cast<const double *>(cst + kCstThr)[0];
+        } else if (k == 2) {
+            post_step(6, pp, 0, 0);                               // stores
         }
     };
     const float *zero_ss = pbuf + (kPRows - 1) * kPStride + 48;       // floats 36 .. 48 of the last row stay zero
@@ -261,7 +289,7 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
             zp = pv[0] + pv[1] + pv[2];
             ssp = sv[0] + sv[1] + sv[2];
         }
-        if (s >= 4 && s <= 10 && s % 2 == 0) post_step(s / 2 + 1, pp, cse_e, csx_e);   // steps 3 .. 6: scale, units, output, stores
+        if (s >= 4 && s <= 8 && s % 2 == 0) eval_tail(s / 2 - 2, pp);
     };
 
     // -- finishing pass q-1: magnitudes (zvabs/2, CircularShortTimeFourierTransform.swift:329-333), their f16 hi + lo split,
@@ -404,7 +432,7 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
 #endif
 #ifndef SYLDET_R_NOEVAL
                 if (i % 4 == 0) eval_slot(i / 4, q - 2, re);
-                if (i >= 9 && i < 14) eval_reduce(i - 9);
+                if (i >= 9 && i < 13) eval_reduce(i - 9);
 #endif
 #ifndef SYLDET_R_NOMAG
                 const int jm = i + 14;                                 // pass q-1's tap products and their stores: the first ticks
@@ -493,7 +521,7 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
         for (int sl = 0; sl < 12; sl++) {
             eval_slot(sl, q - 2, re);
             if (sl == 2)
-                for (int k = 0; k < 5; k++) eval_reduce(k);
+                for (int k = 0; k < 4; k++) eval_reduce(k);
         }
 #pragma unroll
         for (int j = 0; j < kMagSteps; j++) mag_micro(j, rm, dsc);
@@ -502,7 +530,7 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
         for (int sl = 0; sl < 12; sl++) {
             eval_slot(sl, q - 1, rm);
             if (sl == 2)
-                for (int k = 0; k < 5; k++) eval_reduce(k);
+                for (int k = 0; k < 4; k++) eval_reduce(k);
         }
     }
     if (STAMP && (tid == 0 || tid == 64 * (kWaves - 1)) && d.stamps)       // wave 0's view in slots 0-7, the last wave's in 8-15
