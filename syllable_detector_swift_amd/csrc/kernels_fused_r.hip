@@ -210,12 +210,14 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
     // is cut into micro-steps assigned to ticks.  MFMAs are ordered assembly statements (also because the basis, only
     // ever an A operand, must live in the 256 accumulation registers, which the allocator will not do by itself); the
     // compiler keeps memory instructions on their side of such a statement, and vector instructions are held in place
-    // by passing their inputs / results through empty ordered statements (pin).  Hazards the compiler cannot see:
+    // by passing their inputs through empty ordered statements (pin) -- only where that matters, i.e. where a value comes
+    // from LDS or memory and its wait must not be moved up: a lone wave is issue-bound, where a vector instruction sits is
+    // immaterial, and a pin right behind a vector instruction costs a wait state.  Hazards the compiler cannot see:
     // accumulators are written by nothing else inside the block, consecutive uses of one accumulator are at least
     // three MFMAs apart, s_nops separate the last MFMA from vector reads of its result, and two wait states in front of
     // every MFMA cover a register-file move of an operand that the allocator may place right in front of it.
 #define SD_PIN(x) asm volatile("" : "+v"(x))
-    float amax_run = 0.0f;
+    float amax_run = 0.0f, amax_b = 0.0f;
     floatx4 accP[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // pass q-1's DFT
     const int se_ref = se_cur;            // products are stored relative to the segment's first pass
     int r3 = 0;                           // q mod 3
@@ -236,36 +238,36 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
         if (k == 0) {
             const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(zp[0]), __float_as_uint(zp[1]), false, false);
             s01 = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-            SD_PIN(s01);
         } else if (k == 1) {
             const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(zp[2]), __float_as_uint(zp[3]), false, false);
             s23 = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-            SD_PIN(s23);
         } else if (k == 2) {
             const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(s01), __float_as_uint(s23), false, false);
             zt = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-            SD_PIN(zt);
         } else if (k == 3) {
-            SD_PIN(ssp);
             ssw = xor32_sum(xor16_sum(ssp));
-            SD_PIN(ssw);
         }
     };
     // the rest of the network (NeuralNet.swift:47-59 L2Normalize on the folded first layer, :189-194 TanSig, :366-377 second
     // layer, :137-142 / :175-180 reverse output map; SyllableDetector.swift:27-31 threshold), one step a slot
     float ypart = 0.0f;
+    const int seg_len = (int)(e_e - e_b);
+    const unsigned e_b32 = (unsigned)e_b;
     auto eval_tail = [&](int k, int pp) {
         if (k == 0) {                                             // this group's unit: z and the sums of squares are both relative
             const float a = fmaf(d.w_unscale * __builtin_amdgcn_rsqf(ssw), zt, b0g);
             ypart = w1g * transfer_fn(0, a);
-            SD_PIN(ypart);
         } else if (k == 1) {
             float y = xor32_sum(xor16_sum(ypart)) + c_b1[0];
             y = (y - lean_oa) / lean_og + lean_ob;
             yv[0] = y;
             hit = (double)y >= reinterpret_cast<const double *>(cst + kCstThr)[0];
-        } else if (k == 2) {
-            post_step(6, pp, 0, 0);                               // stores
+        } else if (k == 2) {                                      // stores, through the bounds-checked descriptors of this channel's rows
+            const int er = kPass * pp - (T - 1) + fl;             // evaluation index inside the segment (32-bit arithmetic)
+            const bool st = pp >= 0 && er >= 0 && er < seg_len && g4 == 0;
+            const unsigned off = e_b32 + (unsigned)er;            // E * 4 < 2^32 is checked by the launcher
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(yv[0]), out_rs, st ? off * 4u : 0xFFFFFFFFu, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(hit ? 1 : 0), flg_rs, st ? off : 0xFFFFFFFFu, 0, 0);
         }
     };
     const float *zero_ss = pbuf + (kPRows - 1) * kPStride + 48;       // floats 36 .. 48 of the last row stay zero
@@ -313,17 +315,13 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
         if (j < 8) {                                              // |X| of one bin
             const int i = j;
             float re = accP[i >> 2][i & 3], im = accP[2 + (i >> 2)][i & 3];
-            SD_PIN(re);
-            SD_PIN(im);
             cval[i] = __builtin_amdgcn_sqrtf(fmaf(re, re, im * im)) * kmag;
-            SD_PIN(cval[i]);
         } else if (j < 12) {                                      // the frame's sum of squares (l2normalize works from these)
             const int i = 2 * (j - 8);
             if (j == 8) mss = 0.0f;
             mss = fmaf(cval[i], cval[i], mss);
             mss = fmaf(cval[i + 1], cval[i + 1], mss);
             if (j == 11) mss = xor32_sum(xor16_sum(mss));
-            SD_PIN(mss);
         } else if (j == 12) {
             const float sr = mss * pow2f(2 * dsc);
             *(g4 == 0 ? prow + 48 : spare + 49) = sr;
@@ -441,15 +439,15 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
 #ifndef SYLDET_R_NOMAX
                 const int jx = i - (kTicks - NL - 4);                  // block maximum of pass q+2, a quad a tick (its loads left in the
                 if (jx >= 0 && jx < NL) {                              // first half), then the wave's maximum, published before the last tick
-                    if (jx == 0) amax_run = 0.0f;
+                    // (the quad passes through an ordered statement HERE, so that the wait for its load is not moved up; two
+                    // running maxima, so that no v_max3 reads the one in front of it)
+                    if (jx == 0) { amax_run = 0.0f; amax_b = 0.0f; }
+                    SD_PIN(vl[jx]);
                     const floatx4 qv = as_floatx4(vl[jx]);
-                    amax_run = absmax3(absmax3(amax_run, qv[0], qv[1]), qv[2], qv[3]);
-                    SD_PIN(amax_run);
+                    amax_run = absmax3(amax_run, qv[0], qv[1]);
+                    amax_b = absmax3(amax_b, qv[2], qv[3]);
                 }
-                if (jx == NL) {                                        // v_max3 drops NaNs: a plain non-negative number
-                    amax_run = wave_max_nonneg(amax_run);
-                    SD_PIN(amax_run);
-                }
+                if (jx == NL) amax_run = wave_max_nonneg(fmaxf(amax_run, amax_b));   // v_max3 drops NaNs: plain non-negative numbers
                 if (jx == NL + 2 && lane == 0) red[wave] = amax_run;
 #endif
             };
