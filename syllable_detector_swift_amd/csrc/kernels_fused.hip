@@ -239,7 +239,153 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
     if (STAMP) tick[5] = __builtin_amdgcn_s_memtime();
     __syncthreads();
 
-#include "fused_eval.inc"
+    // ---- evaluation of one pass in eight steps, so that it can ride along with the NEXT pass's matrix work:
+    // the first layer as a shifted GEMM over the column buffer (steps 0-2), the rest of the network in registers
+    // (3-5), stores (6).  This wave finishes evaluation slots 16*wave .. +15 of the pass (slot q: e = e_b + 128 pp -
+    // (T-1) + q, columns q .. q+T-1): result column = f, rows 4*g4 + j = hidden unit.
+    floatx4 z = {0.0f, 0.0f, 0.0f, 0.0f}, z2 = {0.0f, 0.0f, 0.0f, 0.0f};
+    float ssw = 1.0f;                                         // l2normalize: the window's sum of squares
+    float alpha = 0.0f, beta = 0.0f, act[4] = {0.0f, 0.0f, 0.0f, 0.0f}, yv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    bool hit = false;
+    constexpr int kAhead = 3;                                 // column fragments are fetched this many taps ahead
+    uint32x4 bh_q[kAhead], bl_q[kAhead];
+    // Evaluation slot q < T-1 straddles two passes: its window is the transition strip [T-1 carried columns | copies of
+    // this pass's first T-1 columns], kept at a scale both passes fit in; every other window reads the pass's own
+    // columns at the pass's own scale.  Either way the window is T consecutive slots starting at `wslot`.
+    const int wslot = fl < T - 1 ? fl : XS + fl - (T - 1);
+    const _Float16 *bph = colh + wslot * kColStride + 8 * g4, *bpl = coll + wslot * kColStride + 8 * g4;
+    auto gemm0_taps = [&](int t0, int t1) {
+#pragma unroll
+        for (int t = 0; t < TMAX; t++) {
+            if (t >= t0 && t < t1 && t < T && !(kom & 16)) {
+                const half8 h0 = as_half8(bh_q[t % kAhead]), l0 = as_half8(bl_q[t % kAhead]);
+                if (t + kAhead < T) {
+                    bh_q[t % kAhead] = *reinterpret_cast<const uint32x4 *>(bph + (t + kAhead) * kColStride);
+                    bl_q[t % kAhead] = *reinterpret_cast<const uint32x4 *>(bpl + (t + kAhead) * kColStride);
+                }
+                z = mfma(afr[t][0], h0, z);                   // two accumulation chains: hi*hi on one,
+                z2 = mfma(afr[t][0], l0, z2);                 // the cross terms on the other
+                z2 = mfma(afr[t][1], h0, z2);
+            }
+        }
+    };
+    auto post_step = [&](int step, int pp, int cse_own, int cse_x) {
+        const int cse_pp = fl < T - 1 ? cse_x : cse_own;      // column scale of this lane's window
+        const int n0 = (T + 2) / 3, n1 = n0 + (T - n0 + 1) / 2;   // taps [0,n0), [n0,n1), [n1,T)
+        if (step == 0) {
+            z = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+            z2 = z;
+#pragma unroll
+            for (int t = 0; t < kAhead; t++)
+                if (t < T && !(kom & 16)) {
+                    bh_q[t] = *reinterpret_cast<const uint32x4 *>(bph + t * kColStride);
+                    bl_q[t] = *reinterpret_cast<const uint32x4 *>(bpl + t * kColStride);
+                }
+            gemm0_taps(0, n0);
+        } else if (step == 1) {
+            gemm0_taps(n0, n1);
+        } else if (step == 2) {
+            gemm0_taps(n1, T);
+            z += z2;
+            if (norm == 1) {                                  // sum of squares of the window = of its T frames (fp32, LDS)
+                float acc_ss = 0.0f;
+#pragma unroll
+                for (int t = 0; t < TMAX; t++)
+                    if (t < T) acc_ss += stat[wslot + t];
+                ssw = acc_ss;
+            }
+        } else if (step == 3) {
+            const float cs = scaling != 0 ? 1.0f : pow2f(cse_pp - d.col_shift);
+            const float zs = d.w_unscale / cs;                // first-layer sums back to true units
+            alpha = zs; beta = 0.0f;                          // layer-0 input = alpha * z + beta * rvec + bias0
+            if (norm == 1) {                                  // L2Normalize, NeuralNet.swift:47-59
+                // z and the per-frame sums of squares are both in column units: layer-0 input = W0 . v / |v|
+                alpha = d.w_unscale * __builtin_amdgcn_rsqf(ssw);
+            } else if (norm == 2) {                           // Normalize, :69-96
+                float mn = INFINITY, mx = -INFINITY;
+                for (int t = 0; t < T; t++) { mn = fminf(mn, stat[wslot + t]); mx = fmaxf(mx, stat[PS + wslot + t]); }
+                const float range = mx - mn;
+                if (range == 0.0f) { alpha = 0.0f; beta = -1.0f; }
+                else { alpha = zs * 2.0f / range; beta = (0.0f - mn - mx) / range; }
+            } else if (norm == 3) {                           // NormalizeStd, :105-108 (population sigma)
+                float nn = 0.0f, mean = 0.0f, m2 = 0.0f;
+                for (int t = 0; t < T; t++) {                 // pairwise-stable combination of per-frame (mean, M2)
+                    const float nb = (float)d.F, tot = nn + nb, dlt = stat[wslot + t] - mean;
+                    mean += dlt * nb / tot;
+                    m2 += stat[PS + wslot + t] + dlt * dlt * nn * nb / tot;
+                    nn = tot;
+                }
+                const float sd = sqrtf(m2 / (float)d.I);
+                alpha = zs / sd;
+                beta = -mean / sd;
+            }
+        } else if (step == 4) {                               // rows past H (padding, statistic) contribute nothing
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                act[j] = (LEAN || (4 * g4 + j) < H) ? transfer_fn(tf0, fmaf(alpha, z[j], fmaf(beta, c_rv[j], c_b0[j]))) : 0.0f;   // LEAN: padding rows meet zero weights
+        } else if (step == 5) {
+            const double *thr = reinterpret_cast<const double *>(cst + kCstThr);
+            hit = false;
+            if (n_layers == 2) {
+#pragma unroll
+                for (int o = 0; o < 4; o++) {
+                    if (o < n_out) {
+                        float y = c_w1[o][0] * act[0];        // padding rows carry zero weights
+                        y = fmaf(c_w1[o][1], act[1], y);
+                        y = fmaf(c_w1[o][2], act[2], y);
+                        y = fmaf(c_w1[o][3], act[3], y);
+                        if (!LEAN && H > 4) {
+                            y += __shfl_xor(y, 16, 64);
+                            y += __shfl_xor(y, 32, 64);
+                        }
+                        y = transfer_fn(tf1, y + c_b1[o]);
+                        if (LEAN) y = (y - lean_oa) / lean_og + lean_ob;
+                        else
+                            for (int kf = 0; kf < d.n_out_fns; kf++) {    // reverse maps, NeuralNet.swift:137-142 / :175-180
+                                const float *op = cst + kCstOut + kf * (1 + 2 * n_out);
+                                y = (y - op[0]) / op[1 + o] + op[1 + n_out + o];
+                            }
+                        yv[o] = y;
+                        hit = hit | ((o == 0 || d.rule == 1) & ((double)y >= thr[o]));
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int h = 4 * g4 + j;
+                    float y = act[j];
+                    for (int kf = 0; kf < d.n_out_fns; kf++) {
+                        const float *op = cst + kCstOut + kf * (1 + 2 * n_out);
+                        y = (y - op[0]) / op[1 + (h < H ? h : 0)] + op[1 + n_out + (h < H ? h : 0)];
+                    }
+                    yv[j] = y;
+                    if (h < H && (h == 0 || d.rule == 1)) hit = hit || ((double)y >= thr[h]);
+                }
+                int anyhit = hit ? 1 : 0;
+                anyhit |= __shfl_xor(anyhit, 16, 64);
+                anyhit |= __shfl_xor(anyhit, 32, 64);
+                hit = anyhit != 0;
+            }
+        } else if (step == 6) {
+            const int64_t e = e_b + (int64_t)kPass * pp - (T - 1) + fl;
+            const bool valid = e >= e_b && e < e_e && pp >= 0 && !(kom & 8);
+            const unsigned off = (unsigned)e;                 // E * n_out * 4 < 2^32 is checked by the launcher
+            if (n_layers == 2) {
+                const bool st = valid && g4 == 0;
+#pragma unroll
+                for (int o = 0; o < 4; o++)
+                    if (o < n_out)
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(yv[o]), out_rs, st ? (off * n_out + o) * 4u : 0xFFFFFFFFu, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(hit ? 1 : 0), flg_rs, st ? off : 0xFFFFFFFFu, 0, 0);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(yv[j]), out_rs,
+                                                          (valid && (4 * g4 + j) < H) ? (off * n_out + 4 * g4 + j) * 4u : 0xFFFFFFFFu, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(hit ? 1 : 0), flg_rs, (valid && g4 == 0) ? off : 0xFFFFFFFFu, 0, 0);
+            }
+        }
+    };
     int cse_post = 0, csx_post = 0;                           // column scales (own, transition strip) of the pass being evaluated
     for (int p = 0; p < runs; p++) {
         // ================= block M: DFT of pass p  ||  evaluation of pass p-1  ||  block max of pass p+1
@@ -324,7 +470,47 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
         const int csx = scaling != 0 ? 0 : ((p > 0 && se_prev < se) ? se_prev : se);
         cse_post = cse;
         csx_post = csx;
-#include "fused_strip.inc"
+        // ---- the previous pass's last T-1 columns -> the front of the transition strip (rescaled from their own scale);
+        // done by the wave that overwrites their slots right after, so program order keeps the two apart
+        if (!SPECT && p > 0 && wave == kWaves - 1 && !(kom & 32)) {
+            const int dexp = scaling != 0 ? 0 : csx - se_prev;     // <= 0
+            const int words = (T - 1) * (kColStride / 2);      // 32-bit words per array
+            const int src = (XS + kPass - (T - 1)) * (kColStride / 2);
+            // all reads first, then all writes: one LDS round trip instead of one per 64 words (this wave is the
+            // last one through the phase, so its latency is the workgroup's)
+            constexpr int kIt = (2 * (TMAX - 1) * (kColStride / 2) + 63) / 64;
+            unsigned u[kIt];
+#pragma unroll
+            for (int k = 0; k < kIt; k++) {
+                const int i = lane + 64 * k;
+                const bool hi_arr = i < words;
+                const int w = hi_arr ? i : i - words;
+                u[k] = i < 2 * words ? reinterpret_cast<const unsigned *>(hi_arr ? colh : coll)[src + w] : 0u;
+            }
+#pragma unroll
+            for (int k = 0; k < kIt; k++) {
+                const int i = lane + 64 * k;
+                const bool hi_arr = i < words;
+                const int w = hi_arr ? i : i - words;
+                unsigned uu = u[k];
+                if (dexp != 0) {
+                    union { unsigned u; _Float16 h[2]; } x;
+                    x.u = uu;
+                    const float f0 = (float)x.h[0] * pow2f(dexp);
+                    const float f1 = (float)x.h[1] * pow2f(dexp);
+                    union { decltype(__builtin_amdgcn_cvt_pkrtz(0.f, 0.f)) h; unsigned u; } y;
+                    y.h = __builtin_amdgcn_cvt_pkrtz(f0, f1);
+                    uu = y.u;
+                }
+                if (i < 2 * words) reinterpret_cast<unsigned *>(hi_arr ? colh : coll)[w] = uu;
+            }
+            const int ssrc = XS + kPass - (T - 1);
+            if (norm == 1 && lane < T - 1) stat[lane] = stat[ssrc + lane] * pow2f(2 * dexp);   // sums of squares of scaled columns
+            if (norm >= 2 && lane < T - 1) {
+                stat[lane] = stat[ssrc + lane];
+                stat[PS + lane] = stat[PS + ssrc + lane];
+            }
+        }
         // ---- magnitude (zvabs/2 :329-333), scaling (SyllableDetector.swift:184-212),
         // statistic, f16 split, column -> LDS.  Result layout: column = frame f, register j of lane group g4 in
         // tile m = basis row 16m + 4*g4 + j; this lane holds bins 4*g4 + j (i = j) and 16 + 4*g4 + j (i = 4 + j).
@@ -342,7 +528,104 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
                                                       (live && bin < d.F) ? ((unsigned)jf * (unsigned)d.F + bin) * 4u : 0xFFFFFFFFu, 0, 0);
             }
         } else if (!(kom & 64)) {
-#include "fused_mag.inc"
+            // accumulators hold X * sx * 2^13.  Column scale (power of two; col_shift from the basis' largest row sum):
+            // |X| * 2^(cse - shift) < 2^13; log/dB columns are stored unscaled.  For linear columns the two scales are applied together after the square root.
+            const float inv = pow2f(-se - 13);
+            const float cs = scaling != 0 ? 1.0f : pow2f(cse - d.col_shift);
+            const int fh = d.F - 4 * g4;                          // cval[i] is a band bin iff (i&3) + 16(i>>2) < fh
+            const bool plain = scaling == 0 && norm <= 1;         // linear |X| columns, no per-frame statistic on raw values
+            float cval[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                if (plain) {
+                    const float re = acc[i >> 2][i & 3], im = acc[2 + (i >> 2)][i & 3];
+                    cval[i] = __builtin_amdgcn_sqrtf(fmaf(re, re, im * im)) * (inv * cs);   // |acc| < 2^40: no overflow
+                } else {
+                    const float re = acc[i >> 2][i & 3] * inv, im = acc[2 + (i >> 2)][i & 3] * inv;
+                    const float pw = fmaf(re, re, im * im);
+                    cval[i] = __builtin_amdgcn_sqrtf(pw);
+                }
+            }
+            if (scaling != 0) {
+                const float kk = scaling == 1 ? 0.6931471805599453f : 6.020599913279624f;   // ln 2, 20 log10 2
+#pragma unroll
+                for (int i = 0; i < 8; i++) cval[i] = kk * __builtin_amdgcn_logf(cval[i]);  // v_log_f32 = log2
+#pragma unroll
+                for (int i = 0; i < 8; i++) cval[i] = ((i & 3) + 16 * (i >> 2)) < fh ? cval[i] : 0.0f;   // log(0) rows
+            }                                                     // (linear: basis rows past F are zero, so are their |X|)
+            const int slot = XS + fl;                             // own column; frames fl < T-1 also feed the transition strip
+            const int xslot = (T - 1) + fl;
+            if (norm == 2) {
+                float st0 = INFINITY, st1 = -INFINITY;
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const bool valid = ((i & 3) + 16 * (i >> 2)) < fh;
+                    st0 = valid ? fminf(st0, cval[i]) : st0;
+                    st1 = valid ? fmaxf(st1, cval[i]) : st1;
+                }
+                st0 = fminf(st0, __shfl_xor(st0, 16, 64)); st0 = fminf(st0, __shfl_xor(st0, 32, 64));
+                st1 = fmaxf(st1, __shfl_xor(st1, 16, 64)); st1 = fmaxf(st1, __shfl_xor(st1, 32, 64));
+                if (g4 == 0) {
+                    stat[slot] = st0; stat[PS + slot] = st1;
+                    if (fl < T - 1) { stat[xslot] = st0; stat[PS + xslot] = st1; }
+                }
+            } else if (norm == 3) {
+                float st0 = 0.0f, st1 = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 8; i++) st0 += cval[i];
+                st0 += __shfl_xor(st0, 16, 64); st0 += __shfl_xor(st0, 32, 64);
+                st0 = st0 / (float)d.F;                           // mean of this frame's column
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const float dlt = cval[i] - st0;
+                    st1 = ((i & 3) + 16 * (i >> 2)) < fh ? fmaf(dlt, dlt, st1) : st1;   // M2 of this frame's column
+                }
+                st1 += __shfl_xor(st1, 16, 64); st1 += __shfl_xor(st1, 32, 64);
+                if (g4 == 0) {
+                    stat[slot] = st0; stat[PS + slot] = st1;
+                    if (fl < T - 1) { stat[xslot] = st0; stat[PS + xslot] = st1; }
+                }
+            }
+            if (!plain) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) cval[i] *= cs;
+            }
+            if (norm == 1) {
+                // sum of squares of the (scaled) column, fp32, one value per frame next to the columns
+                float ss = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 8; i++) ss = fmaf(cval[i], cval[i], ss);
+                ss = xor32_sum(xor16_sum(ss));
+                if (g4 == 0) {
+                    stat[slot] = ss;
+                    if (fl < T - 1) stat[xslot] = ss * pow2f(2 * (csx - cse));
+                }
+            }
+            {
+                _Float16 *ph = colh + slot * kColStride + 4 * g4, *pl = coll + slot * kColStride + 4 * g4;
+#pragma unroll
+                for (int m = 0; m < 2; m++) {                     // bins 16m + 4*g4 .. +3: four consecutive halves
+                    unsigned h0, l0, h1, l1;
+                    split_pair_scaled(cval[4 * m], cval[4 * m + 1], 1.0f, h0, l0);
+                    split_pair_scaled(cval[4 * m + 2], cval[4 * m + 3], 1.0f, h1, l1);
+                    uint32x2 uh = {h0, h1}, ul = {l0, l1};
+                    *reinterpret_cast<uint32x2 *>(ph + 16 * m) = uh;
+                    *reinterpret_cast<uint32x2 *>(pl + 16 * m) = ul;
+                }
+            }
+            if (wave == 0 && fl < T - 1) {                        // copies for the transition strip, at its scale
+                const float xs = pow2f(csx - cse);                // <= 1: a much quieter pass may underflow here, next to
+                _Float16 *ph = colh + xslot * kColStride + 4 * g4, *pl = coll + xslot * kColStride + 4 * g4;   // columns 2^|.| louder
+#pragma unroll
+                for (int m = 0; m < 2; m++) {
+                    unsigned h0, l0, h1, l1;
+                    split_pair_scaled(cval[4 * m], cval[4 * m + 1], xs, h0, l0);
+                    split_pair_scaled(cval[4 * m + 2], cval[4 * m + 3], xs, h1, l1);
+                    uint32x2 uh = {h0, h1}, ul = {l0, l1};
+                    *reinterpret_cast<uint32x2 *>(ph + 16 * m) = uh;
+                    *reinterpret_cast<uint32x2 *>(pl + 16 * m) = ul;
+                }
+            }
         } else if (acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] == 12345.0f) colh[lane] = (_Float16)1.0f;
         SD_TICK(2)
 

@@ -39,7 +39,6 @@ using namespace fused_dev;
 constexpr int kBlock = kFusedRBlock;           // 256 threads = 4 waves, one per SIMD
 constexpr int kWaves = kBlock / 64;
 constexpr int kPass = kFusedRTileFrames;       // 64 frames per pass = 16 per wave
-constexpr int kColStride = kFusedColStride;
 constexpr int kPStride = 52;                   // floats per frame row of tap products: 48 + the frame's sum of squares + padding
                                                // (208-byte rows: 16 consecutive rows cover all 64 banks once for b128 accesses)
 constexpr int kPRows = kFusedRPRows;           // T-1 repeated rows (at most 11) + 3 passes x 64 frames + 2 spare
@@ -59,10 +58,7 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *red = reinterpret_cast<float *>(smem + d.r_lds_red);      // [4 waves] block-max partials
     float *cst = reinterpret_cast<float *>(smem + d.r_lds_cst);
-    constexpr int kom = 0;                // the shared evaluation block's switches
     const int T = d.T;                    // timeRange (taps past it are rows of zeros in the first-layer fragments)
-    [[maybe_unused]] constexpr bool SPECT = false;
-    constexpr bool LEAN = true;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -74,9 +70,8 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
     if (e_b >= E) return;
     const int64_t e_e = (e_b + d.r_seg_evals < E) ? e_b + d.r_seg_evals : E;
     const float *row = samples + (int64_t)c * stride;
-    const int PS = d.r_ps, H = d.H;                             // PS: column slots = 2 (T - 1) transition slots + 64
-    [[maybe_unused]] const int XS = 2 * (T - 1);                // (the shared evaluation block's name for the 8-wave kernel's column layout)
-    constexpr int norm = 1, scaling = 0, n_layers = 2, n_out = 1, tf0 = 0, tf1 = 2;
+    const int H = d.H;
+    constexpr int n_out = 1;
     const int fl = 16 * wave + f;     // this lane's frame / evaluation slot inside the pass
     const int runs = d.r_runs;
 
@@ -86,10 +81,6 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
     // tap products: a ring of three passes' frames, [kPRows][kPStride] fp32 -- per frame 12 taps x 4 units, then its sum
     // of squares (rows 0 .. T-2 repeat the ring's last T-1 frames, so that a window never wraps; two spare rows at the end)
     float *pbuf = reinterpret_cast<float *>(smem + d.r_lds_p);
-    // (the shared evaluation block names the 8-wave kernel's column buffers in steps this kernel never runs)
-    [[maybe_unused]] _Float16 *colh = reinterpret_cast<_Float16 *>(smem), *coll = colh;
-    [[maybe_unused]] float *stat = pbuf;
-    [[maybe_unused]] const half8 (*afr)[2] = nullptr;
 
     // ---- once per workgroup: constants
     if (tid < 16) reinterpret_cast<double *>(cst + kCstThr)[tid] = tid < n_out ? d.thresholds[tid] : 0.0;
@@ -105,18 +96,7 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
 #pragma unroll
         for (int p = 0; p < 2; p++) aft[m][p] = as_half8(reinterpret_cast<const uint32x4 *>(d.afrag_t)[(m * 2 + p) * 64 + lane]);
     for (int i = tid; i < kPRows * kPStride / 4; i += kBlock) reinterpret_cast<floatx4 *>(pbuf)[i] = floatx4{0.f, 0.f, 0.f, 0.f};
-    float c_b0[4], c_rv[4], c_w1[4][4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int h = 4 * g4 + j;
-        c_b0[j] = h < H ? d.bias0[h] : 0.0f;
-        c_rv[j] = h < H ? d.rvec[h] : 0.0f;
-#pragma unroll
-        for (int o = 0; o < 4; o++) c_w1[o][j] = (h < H && o < n_out) ? d.w1[o * H + h] : 0.0f;
-    }
-    float c_b1[4];
-#pragma unroll
-    for (int o = 0; o < 4; o++) c_b1[o] = o < n_out ? d.b1[o] : 0.0f;
+    const float c_b1 = d.b1[0];
 
     const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(
         outputs ? outputs + (int64_t)c * E * n_out : nullptr, 0, outputs ? (int)(E * n_out * 4) : 0, 0x00020000);
@@ -197,7 +177,9 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
     }
     SD_RTICK(5)
 
-#include "fused_eval.inc"
+    // the evaluation's running values: this lane group's share of the window's products and sum of squares, the output, its flag
+    float ssw = 1.0f, yv = 0.0f;
+    bool hit = false;
 
     // ---- The three stages in flight.  In the matrix block of pass q this wave also finishes pass q-1 (magnitudes of
     // the accumulators it kept -> the column buffer of that parity, transition strip) and evaluates pass q-2 (from the
@@ -258,15 +240,15 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
             const float a = fmaf(d.w_unscale * __builtin_amdgcn_rsqf(ssw), zt, b0g);
             ypart = w1g * transfer_fn(0, a);
         } else if (k == 1) {
-            float y = xor32_sum(xor16_sum(ypart)) + c_b1[0];
+            float y = xor32_sum(xor16_sum(ypart)) + c_b1;
             y = (y - lean_oa) / lean_og + lean_ob;
-            yv[0] = y;
+            yv = y;
             hit = (double)y >= reinterpret_cast<const double *>(cst + kCstThr)[0];
         } else if (k == 2) {                                      // stores, through the bounds-checked descriptors of this channel's rows
             const int er = kPass * pp - (T - 1) + fl;             // evaluation index inside the segment (32-bit arithmetic)
             const bool st = pp >= 0 && er >= 0 && er < seg_len && g4 == 0;
             const unsigned off = e_b32 + (unsigned)er;            // E * 4 < 2^32 is checked by the launcher
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(yv[0]), out_rs, st ? off * 4u : 0xFFFFFFFFu, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(yv), out_rs, st ? off * 4u : 0xFFFFFFFFu, 0, 0);
             __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(hit ? 1 : 0), flg_rs, st ? off : 0xFFFFFFFFu, 0, 0);
         }
     };
