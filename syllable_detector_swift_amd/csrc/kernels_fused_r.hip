@@ -145,6 +145,9 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
         const __amdgpu_buffer_rsrc_t rs = pass_rsrc(0);
 #pragma unroll
         for (int k = 0; k < NL; k++) v0[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * tid + 16 * kBlock * k, 0, 0);
+        const __amdgpu_buffer_rsrc_t rs1 = pass_rsrc(1);          // pass 1 follows at once: one exposed round trip, not two
+#pragma unroll
+        for (int k = 0; k < NL; k++) v1[k] = __builtin_amdgcn_raw_buffer_load_b128(rs1, 16 * tid + 16 * kBlock * k, 0, 0);
         max_partial(v0);
         __syncthreads();
         se_cur = pass_scale();
@@ -160,9 +163,6 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
             *reinterpret_cast<uint32x2 *>(ph) = uh;
             *reinterpret_cast<uint32x2 *>(ph + d.r_smp_stride) = ul;
         }
-        const __amdgpu_buffer_rsrc_t rs1 = pass_rsrc(1);
-#pragma unroll
-        for (int k = 0; k < NL; k++) v1[k] = __builtin_amdgcn_raw_buffer_load_b128(rs1, 16 * tid + 16 * kBlock * k, 0, 0);
         __syncthreads();                  // every wave has read the partial maxima of pass 0
         max_partial(v1);
         __syncthreads();
