@@ -48,9 +48,10 @@ constexpr int kPLead = 11;                     // ring row 0 sits at row kPLead
 // always loaded and staged: quads past the pass come back as zeros from the descriptor's bounds check and land in LDS
 // words no frame reads); SKEW: staged samples carry bank-spreading padding -- instantiated for hop 128 only, where the
 // padding (4 halves after every 128 samples) is a matter of constants; STAMP: diagnostic phase timing.
-// The network class is the reference's example detector's (kernels_fused.hip's LEAN): l2normalize first, linear |X|
+// GEN: the wider network class -- any transfer functions, with or without l2normalize in front -- as run-time facts; without
+// it the network class is the reference's example detector's (kernels_fused.hip's LEAN): l2normalize first, linear |X|
 // columns, two layers, TanSig hidden units (at most 4), one output, at most one output map.
-template <int KS, int TMAX, int NL, bool SKEW, bool STAMP>
+template <int KS, int TMAX, int NL, bool SKEW, bool STAMP, bool GEN>
 __global__ void __launch_bounds__(kBlock, 1)
 fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t stride, int64_t s_eff, int64_t E,
                float *__restrict__ outputs, uint8_t *__restrict__ flags)
@@ -235,12 +236,16 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
     float ypart = 0.0f;
     const int seg_len = (int)(e_e - e_b);
     const unsigned e_b32 = (unsigned)e_b;
+    // (GEN: without a normaliser the products, kept relative to the segment's first pass, go back to true units by a constant)
+    const int tf0 = GEN ? d.tf0 : 0, tf1 = GEN ? d.tf1 : 2, norm = GEN ? d.norm : 1;
+    const int ush = d.col_shift - se_ref;
+    const float alpha0 = d.w_unscale * pow2f(ush < -120 ? -120 : (ush > 120 ? 120 : ush));
     auto eval_tail = [&](int k, int pp) {
         if (k == 0) {                                             // this group's unit: z and the sums of squares are both relative
-            const float a = fmaf(d.w_unscale * __builtin_amdgcn_rsqf(ssw), zt, b0g);
-            ypart = w1g * transfer_fn(0, a);
+            const float alpha = norm == 1 ? d.w_unscale * __builtin_amdgcn_rsqf(ssw) : alpha0;   // L2Normalize, NeuralNet.swift:47-59
+            ypart = w1g * transfer_fn(tf0, fmaf(alpha, zt, b0g));
         } else if (k == 1) {
-            float y = xor32_sum(xor16_sum(ypart)) + c_b1;
+            float y = transfer_fn(tf1, xor32_sum(xor16_sum(ypart)) + c_b1);
             y = (y - lean_oa) / lean_og + lean_ob;
             yv = y;
             hit = (double)y >= reinterpret_cast<const double *>(cst + kCstThr)[0];
@@ -519,11 +524,11 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
 #undef SD_PIN
 }
 
-template <int KS, int TMAX, int NL, bool SKEW, bool STAMP = false>
+template <int KS, int TMAX, int NL, bool SKEW, bool STAMP = false, bool GEN = false>
 hipError_t launch_one(const FusedDesc &d, const float *samples, int64_t stride, int C, int64_t s_eff, int64_t E,
                       float *outputs, uint8_t *flags, hipStream_t stream)
 {
-    auto kern = fused_r_kernel<KS, TMAX, NL, SKEW, STAMP>;
+    auto kern = fused_r_kernel<KS, TMAX, NL, SKEW, STAMP, GEN>;
     hipError_t st = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, d.r_lds_total);
     if (st != hipSuccess) return st;
     const int64_t segs = (E + d.r_seg_evals - 1) / d.r_seg_evals;
@@ -551,9 +556,10 @@ bool fused_r_has_stamps()
 
 bool fused_r_applicable(const FusedDesc &d)
 {
-    const bool lean = d.norm == 1 && d.scaling == 0 && d.n_layers == 2 && d.tf0 == 0 /* TanSig */ && d.tf1 == 2 /* PureLin */ &&
-                      d.n_out == 1 && d.H <= 4 && d.n_out_fns <= 1;
-    return d.r_ok && d.KS == 8 && d.T <= 12 && d.r_nload <= 9 && (d.skew == 0 || (d.skew == 4 && d.hop == 128)) && lean;
+    // two layers with at most 4 hidden units and one output, linear |X| columns, no normaliser or l2normalize in front of the
+    // affine maps, at most one output map (any transfer functions; the example detector's get the exact instantiation)
+    const bool cls = (d.norm == 0 || d.norm == 1) && d.scaling == 0 && d.n_layers == 2 && d.n_out == 1 && d.H <= 4 && d.n_out_fns <= 1;
+    return d.r_ok && d.KS == 8 && d.T <= 12 && d.r_nload <= 9 && (d.skew == 0 || (d.skew == 4 && d.hop == 128)) && cls;
 }
 
 hipError_t launch_fused_r(const FusedDesc &d, const float *samples, int64_t stride, int C, int64_t S, int64_t J,
@@ -566,8 +572,11 @@ hipError_t launch_fused_r(const FusedDesc &d, const float *samples, int64_t stri
 #ifdef SYLDET_R_STAMPS                // diagnostic builds only (-DSYLDET_R_STAMPS): the instantiation with phase timing
     if (d.stamps && d.skew == 0) return launch_one<8, 12, 9, false, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
 #endif
-    if (d.skew != 0) return launch_one<8, 12, 9, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
-    return launch_one<8, 12, 9, false>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
+    const bool exact = d.norm == 1 && d.tf0 == 0 /* TanSig */ && d.tf1 == 2 /* PureLin */;     // the example detector's class
+    if (d.skew != 0) return exact ? launch_one<8, 12, 9, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream)
+                                  : launch_one<8, 12, 9, true, false, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
+    return exact ? launch_one<8, 12, 9, false>(d, samples, stride, C, s_eff, E, outputs, flags, stream)
+                 : launch_one<8, 12, 9, false, false, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
 }
 
 }  // namespace sd
