@@ -214,6 +214,14 @@ int syldet_detections(syldet_t *h, const uint8_t *flags, int64_t n_evals, double
  * returns up to `capacity` kernel durations in milliseconds, in launch order, with their names.   */
 int syldet_profile(syldet_t *h, int enable);
 int syldet_last_timings(syldet_t *h, double *milliseconds, const char **names, int32_t capacity, int32_t *count);
+/* The fused kernels compute on a block-floating-point grid (one power-of-two scale per 64 / 128 frames).  Evaluations
+ * whose windows that grid cannot hold to the 1e-5 contract -- a quiet stretch right behind a click, an infinite sample, a
+ * level step of hundreds of dB -- are detected on the device and recomputed from the samples in fp64, so that results
+ * (and NaN, which the reference yields exactly for the windows that contain the offending sample: NeuralNet.swift:47-59)
+ * never depend on the tiling.  *items = 16-evaluation work items the last completed batch call of this handle recomputed
+ * (0 for ordinary audio), *overflow = 1 if a work list was ever too small (never, by construction).  Blocks; call it after
+ * the stream the batch call ran on has been synchronised.  No reference counterpart (diagnostic).                       */
+int syldet_fixup_stats(syldet_t *h, int64_t *items, int32_t *overflow);
 
 /* ---- streaming: the reference's per-detector API, one call per channel ----
  * Each channel owns a single-producer / single-consumer sample ring like the reference's

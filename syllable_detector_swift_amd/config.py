@@ -204,6 +204,8 @@ class SyllableDetectorConfig:
             for i, f in enumerate(fl):
                 arr[i].kind = _FN_KINDS[f.function]
                 if f.function in ("mapminmax", "mapstd"):
+                    if np.asarray(f.gains).size != np.asarray(f.xOffsets).size:     # the C side copies `count` of each
+                        raise ValueError("%s: %d gains for %d xOffsets" % (f.function, np.asarray(f.gains).size, np.asarray(f.xOffsets).size))
                     arr[i].count = int(np.asarray(f.xOffsets).size)
                     arr[i].x_offsets = fptr(f.xOffsets)
                     arr[i].gains = fptr(f.gains)

@@ -269,6 +269,54 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
         p.out_params.insert(p.out_params.end(), f.gains, f.gains + n_out);
         p.out_params.insert(p.out_params.end(), f.x_offsets, f.x_offsets + n_out);
     }
+    // ---- precision guard (kernels.hpp, FixItem).  Sensitivity of an output to the network's input vector u, as a bound:
+    // |dz_h| <= ||W'_h||_2 ||du||_2 (W' = W0 o a, the folded first layer in true units), transfer slopes <= 1 (LogSig 1/4),
+    // |dy_o| <= sum_h |w1[o][h]| |dz_h|, every reverse output map divides by |gain_o|.
+    {
+        auto slope = [](int tf) { return tf == SYLDET_TF_LOGSIG ? 0.25 : 1.0; };
+        std::vector<double> rown((size_t)H, 0.0);
+        for (int h = 0; h < H; h++) {
+            double s = 0.0;
+            for (int i = 0; i < I; i++) {
+                const double w = (double)L0.weights[(size_t)h * I + i] * a[(size_t)i];
+                s += w * w;
+            }
+            rown[(size_t)h] = std::sqrt(s) * slope(L0.transfer);
+        }
+        double lip = 0.0;
+        for (int o = 0; o < n_out; o++) {
+            double lo = 0.0;
+            if (c.n_layers == 2) {
+                for (int h = 0; h < H; h++) lo += std::fabs((double)c.layers[1].weights[(size_t)o * H + h]) * rown[(size_t)h];
+                lo *= slope(c.layers[1].transfer);
+            } else {
+                lo = rown[(size_t)o];
+            }
+            for (int k = 0; k < c.n_output_fns; k++) lo /= std::max(1e-30, std::fabs((double)c.output_fns[k].gains[o]));
+            lip = std::max(lip, lo);
+        }
+        if (!(lip > 1e-30)) lip = 1e-30;
+        if (!(lip < 1e30)) lip = 1e30;
+        // Grid floors, in units of a stored column value.  The 8-wave kernel splits every column into f16 hi + lo at the
+        // pass's scale: half an f16 subnormal step (2^-25) per bin plus the sample grid's share.  The register-resident-basis
+        // kernel gives every frame its own column exponent, which leaves the sample grid: 2^-25 per sample of a pass scaled to
+        // 2^14, through the basis (bound 2^-26 per bin, typically 2^-31).
+        const double eps_out = 2e-6, phi_c = std::ldexp(1.0, -24), phi_r = std::ldexp(1.0, -27), rel = std::ldexp(1.0, -21);
+        const double sqI = std::sqrt((double)I);
+        auto sq = [](double v) { return (float)std::min(v * v, 1e30); };
+        d.guard_r = sq(lip * sqI * phi_r / eps_out);
+        d.guard_c = sq(lip * sqI * phi_c / eps_out);
+        d.guard_c_range = (float)std::min((norm == 2 ? 4.0 : 2.0) * lip * sqI * phi_c / eps_out, 1e30);
+        d.guard_rel_r = sq(sqI * phi_r / rel);
+        d.guard_rel_c = sq(sqI * phi_c / rel);
+        // no normaliser: the floor in true units is phi 2^(col_shift - se); it matters once  lip sqrt(I) phi 2^(col_shift - se) > eps
+        auto se_abs = [&](double phi) {
+            const double v = std::log2(lip * sqI * phi / eps_out) + (double)d.col_shift;
+            return (int)std::max(-200.0, std::min(200.0, std::ceil(v)));
+        };
+        d.guard_se_abs_r = se_abs(phi_r);
+        d.guard_se_abs_c = se_abs(phi_c);
+    }
     if (!d.classic_ok && !fused_r_applicable(d)) return no("LDS budget exceeded");
     p.koff.resize((size_t)KS * 4);
     for (int ks = 0; ks < KS; ks++)

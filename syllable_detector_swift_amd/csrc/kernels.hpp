@@ -92,6 +92,26 @@ constexpr int kFusedRPRows = 11 + 3 * 64 + 2;   //   rows of its tap-product rin
 constexpr int kFusedColStride = 40;     // halves per column row in LDS: 32 bins + 8 of padding (80 B rows: 16-byte
                                         // aligned, and 16 consecutive rows cover all 64 banks once for ds_read_b128)
 
+// ---- precision guard + exact recomputation (kernels_fixup.hip) ----------------------------
+// The fused kernels are block floating point: a pass (64 or 128 frames) is scaled by its loudest sample and split into
+// f16 hi + lo.  A window that sits far below that level (a quiet stretch next to a click), a pass with an infinite sample
+// or a level step of hundreds of dB cannot be held on that grid.  The kernels know: an evaluation whose window norm,
+// measured on the grid it was computed on, is too close to the grid's floor for the network's sensitivity (a host-side
+// Lipschitz bound) is reported in a work list, and fixup_kernel recomputes exactly those evaluations from the samples
+// (fp64 DFT by definition, the network unfolded in the reference's operation order) behind the fused kernel on the same
+// stream.  NaN may then appear only where the reference's windows contain the offending sample.
+struct FixItem {
+    int c;                      // channel
+    unsigned first;             // first evaluation (kind 0) / frame (kind 1: spectrogram columns)
+    int count;
+    int kind;
+};
+struct FixList {
+    unsigned *counters;         // [0] items appended, [1] workgroups done, [2] items of the last launch, [3] overflow (sticky)
+    FixItem *items;
+    unsigned capacity;
+};
+
 struct FusedDesc {
     int W, KS;                  // window length, k-steps of 32 samples (KS*32 >= W)
     int hop, gap, F, T;         // frame advance, leading gap, bins, timeRange
@@ -127,6 +147,13 @@ struct FusedDesc {
     const double *thresholds;   // [n_out]
     float *spect_out;           // spectrogram instantiation only: [C][J][F] columns
     int spect_power;            //   0: |X|, 1: |X|^2
+    // precision guard (see FixItem): thresholds on the window statistic in grid units, from fused_plan.cpp
+    float guard_r;              // register-resident-basis kernel: window sum of squares, times 4^(se_ref - se_min)
+    float guard_c;              // 8-wave kernel, l2normalize / no normaliser: window sum of squares
+    float guard_c_range;        //   normalize: window range;  normalizestd: window sigma
+    float guard_rel_r, guard_rel_c;   // no normaliser: the relative criterion that joins the absolute one
+    int guard_se_abs_r, guard_se_abs_c;   // no normaliser: passes scaled below this exponent are loud enough for the floor to matter
+    FixList fix;                // work list of evaluations to recompute (null counters: guard off)
     int ko;                     // diagnostic build only: knock-out mask (SYLDET_FUSED_KO)
     unsigned long long *stamps; // diagnostic build only: [workgroups][16] phase cycle sums, else null
 };
@@ -175,5 +202,16 @@ hipError_t launch_fused_r(const FusedDesc &d, const float *samples, int64_t stri
                           int64_t E, float *outputs, uint8_t *flags, hipStream_t stream);
 // taps the register-resident first-layer fragments are instantiated for (0: timeRange too long)
 int fused_taps_max(int T);
+
+// ---- exact recomputation of the evaluations the fused kernels reported (kernels_fixup.hip) ----
+struct FixDesc {
+    int N, W, hop, gap, f0, F, T;
+    const float *window;        // [W] the fp32 window table (WindowType.createWindow)
+    const double2 *ctab;        // [N] (cos, sin)(2 pi m / N)
+};
+constexpr int kFixMaxCount = 16;            // evaluations (or frames) per work item
+// outputs [C][E][n_out], flags [C][E]: the listed evaluations are overwritten; columns [C][J][F]: the listed frames
+hipError_t launch_fixup(const FixDesc &fd, const NetDesc &n, const float *samples, int64_t stride, int64_t J, int64_t E,
+                        float *outputs, uint8_t *flags, float *columns, const FixList &list, hipStream_t stream);
 
 }  // namespace sd

@@ -202,10 +202,15 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
         if (lane == 0) red[wave] = amax;
     };
     // block floating point: the pass's largest sample goes to [2^13, 2^14); returns the scale's exponent
-    auto pass_scale = [&](floatx4 r0, floatx4 r1) {
+    // (status of the pass for the precision guard: 0 fine, 1 silent -- all samples zero, its columns are exact zeros --, 2 the
+    // grid cannot hold it: an infinite sample, or a level above 2^113; a level below 2^-100 only loses headroom, which the
+    // guard's own criterion sees)
+    auto pass_scale = [&](floatx4 r0, floatx4 r1, int &status) {
         const float amax = fmaxf(fmaxf(fmaxf(r0[0], r0[1]), fmaxf(r0[2], r0[3])), fmaxf(fmaxf(r1[0], r1[1]), fmaxf(r1[2], r1[3])));
-        int e = 13 - (int)((__float_as_uint(amax) >> 23) & 0xffu) + 127;
-        e = amax > 0.0f ? (e < -100 ? -100 : (e > 100 ? 100 : e)) : 0;
+        const int ex = (int)((__float_as_uint(amax) >> 23) & 0xffu);
+        int e = 13 - ex + 127;
+        status = __builtin_amdgcn_readfirstlane(amax > 0.0f ? ((ex == 255 || e < -100) ? 2 : 0) : 1);
+        e = amax > 0.0f ? (e < -100 ? -100 : (e > 113 ? 113 : e)) : 0;       // (2^(-e - 13) must stay a normal number)
         return __builtin_amdgcn_readfirstlane(e);
     };
     // quads in v[] -> scaled, split into f16 hi + lo, -> the staged region
@@ -227,14 +232,19 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
                 }
             }
     };
-    int se_next;                      // scale exponent of the pass staged most recently
+    int se_next, st_next;             // scale exponent and guard status of the pass staged most recently
     load_pass(0);
     max_partial();
     __syncthreads();
-    se_next = pass_scale(*reinterpret_cast<const floatx4 *>(red), *reinterpret_cast<const floatx4 *>(red + 4));
+    se_next = pass_scale(*reinterpret_cast<const floatx4 *>(red), *reinterpret_cast<const floatx4 *>(red + 4), st_next);
     stage_pass(se_next);
     load_pass(1);                     // arrives during the first pass's matrix work
     int se = 0, cse = 0, se_prev = 0;   // sample / column scale exponents of this pass, sample scale of the one before
+    int st = 1, st_prev = 1;            // their guard statuses
+    // the window's sum of squares is kept for l2normalize and, for the precision guard, for linear columns without a normaliser
+    const bool want_ss = norm == 1 || (norm == 0 && scaling == 0);
+    bool badv = false;                  // this lane's evaluation of the pass failed the guard (kernels.hpp, FixItem)
+    const bool guard_on = !SPECT && d.fix.counters != nullptr;
     unsigned long long tsum[16] = {0}, tick[8] = {0};
     if (STAMP) tick[5] = __builtin_amdgcn_s_memtime();
     __syncthreads();
@@ -269,8 +279,9 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
             }
         }
     };
-    auto post_step = [&](int step, int pp, int cse_own, int cse_x) {
+    auto post_step = [&](int step, int pp, int cse_own, int cse_x, int st_own, int st_x) {
         const int cse_pp = fl < T - 1 ? cse_x : cse_own;      // column scale of this lane's window
+        const int st_w = fl < T - 1 ? st_x : st_own;          // guard status of the passes its columns come from
         const int n0 = (T + 2) / 3, n1 = n0 + (T - n0 + 1) / 2;   // taps [0,n0), [n0,n1), [n1,T)
         if (step == 0) {
             z = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -287,7 +298,7 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
         } else if (step == 2) {
             gemm0_taps(n1, T);
             z += z2;
-            if (norm == 1) {                                  // sum of squares of the window = of its T frames (fp32, LDS)
+            if (want_ss) {                                    // sum of squares of the window = of its T frames (fp32, LDS)
                 float acc_ss = 0.0f;
 #pragma unroll
                 for (int t = 0; t < TMAX; t++)
@@ -318,6 +329,26 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
                 const float sd = sqrtf(m2 / (float)d.I);
                 alpha = zs / sd;
                 beta = -mean / sd;
+                ssw = sd;                                     // (the guard's statistic)
+            }
+            // Precision guard: the window's statistic, on the grid its columns were stored on, against the grid's floor
+            // times the network's sensitivity (fused_plan.cpp).  Exact zeros of silent passes are the reference's own values;
+            // a pass the grid cannot hold condemns every window that touches it.  log / dB columns are not guarded beyond that.
+            {
+                const int64_t e = e_b + (int64_t)kPass * pp - (T - 1) + fl;
+                const bool valid = e >= e_b && e < e_e && pp >= 0;
+                float gthr = 0.0f, gstat = ssw;
+                if (scaling == 0) {
+                    if (norm == 1) gthr = d.guard_c;
+                    else if (norm == 0) gthr = cse_pp < d.guard_se_abs_c ? d.guard_rel_c : 0.0f;
+                    else gthr = d.guard_c_range;
+                    if (norm == 2) {
+                        float mn = INFINITY, mx = -INFINITY;
+                        for (int t = 0; t < T; t++) { mn = fminf(mn, stat[wslot + t]); mx = fmaxf(mx, stat[PS + wslot + t]); }
+                        gstat = mx - mn;
+                    }
+                } else gstat = 0.0f;
+                badv = valid && (st_w == 2 || (st_w == 0 && !(gstat >= gthr)));
             }
         } else if (step == 4) {                               // rows past H (padding, statistic) contribute nothing
 #pragma unroll
@@ -387,6 +418,21 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
         }
     };
     int cse_post = 0, csx_post = 0;                           // column scales (own, transition strip) of the pass being evaluated
+    int st_post = 1, stx_post = 1;                            // and the guard statuses of the passes behind them
+    // evaluations of pass pp that failed the guard: this wave's 16 go to the work list as one item (rare; outside block M)
+    auto push_bad = [&](int pp) {
+        if (guard_on && __builtin_amdgcn_ballot_w64(badv) != 0ull) {
+            int64_t lo = e_b + (int64_t)kPass * pp - (T - 1) + 16 * wave, hi = lo + 16;
+            lo = lo < e_b ? e_b : lo;
+            hi = hi > e_e ? e_e : hi;
+            if (lane == 0 && hi > lo) {
+                const unsigned slot = atomicAdd(d.fix.counters, 1u);
+                if (slot < d.fix.capacity) d.fix.items[slot] = FixItem{c, (unsigned)lo, (int)(hi - lo), 0};
+                else d.fix.counters[3] = 1u;
+            }
+        }
+        badv = false;
+    };
     for (int p = 0; p < runs; p++) {
         // ================= block M: DFT of pass p  ||  evaluation of pass p-1  ||  block max of pass p+1
         // band-limited DFT of this wave's 16 frames on the matrix cores: four 16-row tiles (re bins 0-15, re 16-31,
@@ -450,8 +496,8 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
                 }
                 // the previous pass's evaluation, one or two steps per k-step
                 if (!(kom & 128) && !SPECT) {
-                    if (KS == 8) post_step(ks, p - 1, cse_post, csx_post);
-                    else { post_step(2 * ks, p - 1, cse_post, csx_post); post_step(2 * ks + 1, p - 1, cse_post, csx_post); }
+                    if (KS == 8) post_step(ks, p - 1, cse_post, csx_post, st_post, stx_post);
+                    else { post_step(2 * ks, p - 1, cse_post, csx_post, st_post, stx_post); post_step(2 * ks + 1, p - 1, cse_post, csx_post, st_post, stx_post); }
                 }
             }
         }
@@ -461,15 +507,20 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
         __syncthreads();          // all reads of the staged samples and of the columns are done; partial maxima are in
         SD_TICK(1)
         const floatx4 red0 = *reinterpret_cast<const floatx4 *>(red), red1 = *reinterpret_cast<const floatx4 *>(red + 4);
+        if (!SPECT) push_bad(p - 1);
 
         se_prev = se;
         se = se_next;
+        st_prev = st;
+        st = st_next;
         // this pass's columns are stored at its own sample scale; the transition strip (the previous pass's last T-1
         // columns + copies of this pass's first T-1) at the smaller of the two passes' scales, where neither overflows
         cse = scaling != 0 ? 0 : se;
         const int csx = scaling != 0 ? 0 : ((p > 0 && se_prev < se) ? se_prev : se);
         cse_post = cse;
         csx_post = csx;
+        st_post = st;
+        stx_post = p > 0 ? ((st == 2 || st_prev == 2) ? 2 : ((st == 1 && st_prev == 1) ? 1 : 0)) : st;
         // ---- the previous pass's last T-1 columns -> the front of the transition strip (rescaled from their own scale);
         // done by the wave that overwrites their slots right after, so program order keeps the two apart
         if (!SPECT && p > 0 && wave == kWaves - 1 && !(kom & 32)) {
@@ -505,7 +556,7 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
                 if (i < 2 * words) reinterpret_cast<unsigned *>(hi_arr ? colh : coll)[w] = uu;
             }
             const int ssrc = XS + kPass - (T - 1);
-            if (norm == 1 && lane < T - 1) stat[lane] = stat[ssrc + lane] * pow2f(2 * dexp);   // sums of squares of scaled columns
+            if (want_ss && lane < T - 1) stat[lane] = stat[ssrc + lane] * pow2f(2 * dexp);   // sums of squares of scaled columns
             if (norm >= 2 && lane < T - 1) {
                 stat[lane] = stat[ssrc + lane];
                 stat[PS + lane] = stat[PS + ssrc + lane];
@@ -590,7 +641,7 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
 #pragma unroll
                 for (int i = 0; i < 8; i++) cval[i] *= cs;
             }
-            if (norm == 1) {
+            if (want_ss) {
                 // sum of squares of the (scaled) column, fp32, one value per frame next to the columns
                 float ss = 0.0f;
 #pragma unroll
@@ -631,7 +682,7 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
 
         // ---- next pass: scale, split, -> LDS; then the loads of the pass after it start their way from HBM
         if (p + 1 < runs) {
-            se_next = pass_scale(red0, red1);
+            se_next = pass_scale(red0, red1, st_next);
             stage_pass(se_next);
             load_pass(p + 2);
         }
@@ -648,7 +699,8 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
     // ---- evaluation of the last pass
     if (!(kom & 128) && !SPECT) {
 #pragma unroll
-        for (int step = 0; step < 7; step++) post_step(step, runs - 1, cse_post, csx_post);
+        for (int step = 0; step < 7; step++) post_step(step, runs - 1, cse_post, csx_post, st_post, stx_post);
+        push_bad(runs - 1);
     }
     if (STAMP && tid == 0 && d.stamps)
         for (int i = 0; i < 8; i++) atomicAdd(&d.stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + i], tsum[i]);

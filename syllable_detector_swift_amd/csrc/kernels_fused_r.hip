@@ -129,19 +129,25 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
         amax = wave_max_nonneg(amax);
         if (lane == 0) red[wave] = amax;
     };
-    auto scale_of = [&](floatx4 r0) {
+    // (status of the pass for the precision guard: 0 fine, 1 silent -- all samples zero, its columns are exact zeros --, 2 the
+    // grid cannot hold it: an infinite sample, or a level above 2^113; a level below 2^-100 only loses headroom, which the
+    // guard's own criterion sees)
+    auto scale_of = [&](floatx4 r0, int &status) {
         const float amax = fmaxf(fmaxf(r0[0], r0[1]), fmaxf(r0[2], r0[3]));
-        int e = 13 - (int)((__float_as_uint(amax) >> 23) & 0xffu) + 127;
-        e = amax > 0.0f ? (e < -100 ? -100 : (e > 100 ? 100 : e)) : 0;
+        const int ex = (int)((__float_as_uint(amax) >> 23) & 0xffu);
+        int e = 13 - ex + 127;
+        status = __builtin_amdgcn_readfirstlane(amax > 0.0f ? ((ex == 255 || e < -100) ? 2 : 0) : 1);
+        e = amax > 0.0f ? (e < -100 ? -100 : (e > 113 ? 113 : e)) : 0;       // (2^(-e - 13) must stay a normal number)
         return __builtin_amdgcn_readfirstlane(e);
     };
-    auto pass_scale = [&]() { return scale_of(*reinterpret_cast<const floatx4 *>(red)); };
+    auto pass_scale = [&](int &status) { return scale_of(*reinterpret_cast<const floatx4 *>(red), status); };
     // where this thread's quad k lands in a staged buffer (halves): 4 tid + 1024 k, with SKEW + 4 ((4 tid + 1024 k) >> 7)
     const int sbase = SKEW ? 4 * tid + 4 * (tid >> 5) : 4 * tid;
     constexpr int kinc = SKEW ? 4 * kBlock + 32 : 4 * kBlock;
 
     // ---- prologue: pass 0 staged, pass 1 in the staging registers with its block maximum published
     int se_cur, se_m1 = 0;                // sample scale exponents of the pass in the matrix block and of the one before it
+    int st_cur = 1;                       // the guard status of the pass in the matrix block (see scale_of)
     {
         const __amdgpu_buffer_rsrc_t rs = pass_rsrc(0);
 #pragma unroll
@@ -151,7 +157,7 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
         for (int k = 0; k < NL; k++) v1[k] = __builtin_amdgcn_raw_buffer_load_b128(rs1, 16 * tid + 16 * kBlock * k, 0, 0);
         max_partial(v0);
         __syncthreads();
-        se_cur = pass_scale();
+        se_cur = pass_scale(st_cur);
         const float sx = pow2f(se_cur);
 #pragma unroll
         for (int k = 0; k < NL; k++) {
@@ -204,6 +210,24 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
     floatx4 accP[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // pass q-1's DFT
     const int se_ref = se_cur;            // products are stored relative to the segment's first pass
     int r3 = 0;                           // q mod 3
+    // -- precision guard (kernels.hpp, FixItem).  The window's sum of squares in the ring is relative to the segment's first
+    // pass; the grid floor of a pass scaled by 2^se is phi 2^(se_ref - se) there.  An evaluation of pass p reads columns of
+    // passes p-1 and p: its threshold comes from the louder of the two (a silent pass holds exact zeros and does not count;
+    // a pass the grid cannot hold, or one 2^45 away from the segment's first, condemns every window that touches it).
+    // Wave-uniform integer arithmetic: a power of two times the host's constant is an addition to its exponent field.
+    const int gnorm = GEN ? d.norm : 1;
+    auto guard_thr = [&](int se_a, int st_a, int se_b, int st_b) -> unsigned {
+        if (st_a == 2 || st_b == 2) return 0x7f800000u;                   // +inf: nothing passes
+        if (st_a == 1 && st_b == 1) return 0u;                            // exact zeros: the fused result is the reference's (0/0)
+        const int m = st_a == 1 ? se_b : (st_b == 1 ? se_a : (se_a < se_b ? se_a : se_b));
+        const int dm = se_ref - m;
+        if (dm > 45 || dm < -45) return 0x7f800000u;
+        if (gnorm != 1 && m >= d.guard_se_abs_r) return 0u;               // no normaliser: too quiet for the floor to matter
+        return __float_as_uint(gnorm == 1 ? d.guard_r : d.guard_rel_r) + ((unsigned)dm << 24);
+    };
+    unsigned thr_0 = guard_thr(0, 1, se_cur, st_cur), thr_m1 = 0u, thr_m2 = 0u;   // evaluations of passes q, q-1, q-2
+    bool badv = false;                    // this lane's evaluation of the pass failed the guard
+    const bool guard_on = d.fix.counters != nullptr;
 
     // -- evaluation of pass pp (ring region re): every column met every tap when its pass was finished, so an evaluation
     // is the diagonal sum over the taps of the products in LDS (lane group g4 takes taps g4, g4 + 4, g4 + 8; taps past
@@ -240,7 +264,7 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
     const int tf0 = GEN ? d.tf0 : 0, tf1 = GEN ? d.tf1 : 2, norm = GEN ? d.norm : 1;
     const int ush = d.col_shift - se_ref;
     const float alpha0 = d.w_unscale * pow2f(ush < -120 ? -120 : (ush > 120 ? 120 : ush));
-    auto eval_tail = [&](int k, int pp) {
+    auto eval_tail = [&](int k, int pp, unsigned thr) {
         if (k == 0) {                                             // this group's unit: z and the sums of squares are both relative
             const float alpha = norm == 1 ? d.w_unscale * __builtin_amdgcn_rsqf(ssw) : alpha0;   // L2Normalize, NeuralNet.swift:47-59
             ypart = w1g * transfer_fn(tf0, fmaf(alpha, zt, b0g));
@@ -251,14 +275,16 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
             hit = (double)y >= reinterpret_cast<const double *>(cst + kCstThr)[0];
         } else if (k == 2) {                                      // stores, through the bounds-checked descriptors of this channel's rows
             const int er = kPass * pp - (T - 1) + fl;             // evaluation index inside the segment (32-bit arithmetic)
-            const bool st = pp >= 0 && er >= 0 && er < seg_len && g4 == 0;
+            const bool vld = pp >= 0 && er >= 0 && er < seg_len;
+            const bool st = vld && g4 == 0;
+            badv = vld && !(ssw >= __uint_as_float(thr));         // the guard: too close to the grid's floor (or NaN) -> work list
             const unsigned off = e_b32 + (unsigned)er;            // E * 4 < 2^32 is checked by the launcher
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(yv), out_rs, st ? off * 4u : 0xFFFFFFFFu, 0, 0);
             __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(hit ? 1 : 0), flg_rs, st ? off : 0xFFFFFFFFu, 0, 0);
         }
     };
     const float *zero_ss = pbuf + (kPRows - 1) * kPStride + 48;       // floats 36 .. 48 of the last row stay zero
-    auto eval_slot = [&](int s, int pp, int re) {
+    auto eval_slot = [&](int s, int pp, int re, unsigned thr) {
         if (s == 0) {
             const float *erow = pbuf + (kPLead + 64 * re + fl - (T - 1)) * kPStride;
 #pragma unroll
@@ -278,7 +304,21 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
             zp = pv[0] + pv[1] + pv[2];
             ssp = sv[0] + sv[1] + sv[2];
         }
-        if (s >= 4 && s <= 8 && s % 2 == 0) eval_tail(s / 2 - 2, pp);
+        if (s >= 4 && s <= 8 && s % 2 == 0) eval_tail(s / 2 - 2, pp, thr);
+    };
+    // evaluations of pass pp that failed the guard: this wave's 16 go to the work list as one item (rare: a branch outside
+    // the matrix block)
+    auto push_bad = [&](int pp) {
+        if (guard_on && __builtin_amdgcn_ballot_w64(badv) != 0ull) {
+            const int er0 = kPass * pp - (T - 1) + 16 * wave;
+            const int lo = er0 < 0 ? 0 : er0, hi = er0 + 16 < seg_len ? er0 + 16 : seg_len;
+            if (lane == 0 && hi > lo) {
+                const unsigned slot = atomicAdd(d.fix.counters, 1u);
+                if (slot < d.fix.capacity) d.fix.items[slot] = FixItem{c, e_b32 + (unsigned)lo, hi - lo, 0};
+                else d.fix.counters[3] = 1u;
+            }
+        }
+        badv = false;
     };
 
     // -- finishing pass q-1: magnitudes (zvabs/2, CircularShortTimeFourierTransform.swift:329-333), their f16 hi + lo split,
@@ -290,7 +330,7 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
     // segment's first pass (* 2^dsc, dsc = se(first) - se: a power of two), so that a window may straddle passes of
     // different scales.  Micro-steps j = 0 .. kMagSteps-1.
     constexpr int kMagSteps = 23;
-    float cval[8], mss = 0.0f;
+    float cval[8], mss = 0.0f, fs_up = 1.0f, fs_ring = 1.0f;
     unsigned bh[4], bl[4];
     floatx4 pt[3];
     const float kmag = pow2f(-13 - d.col_shift);
@@ -313,16 +353,24 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
             const float sr = mss * pow2f(2 * dsc);
             *(g4 == 0 ? prow + 48 : spare + 49) = sr;
             *((g4 == 0 && drow) ? drow + 48 : spare + 50) = sr;
+            // The frame's own column exponent: its column is split into f16 hi + lo at the scale that puts its norm into
+            // [2^12, 2^13) -- a quiet frame of a loud pass keeps 22 bits of its own level instead of the pass's f16 floor --
+            // and the products come back through fs_ring = 2^dsc / fs_up.  With ex the biased exponent of mss,
+            // t = floor((ex + 1) / 2) = floor(log2 sqrt(mss)) + 64, clamped to [16, 80]: fs_up = 2^(76 - t).
+            unsigned tb = ((__float_as_uint(mss) + 0x800000u) >> 1) & 0x7f800000u;    // t << 23
+            tb = (unsigned)min(max((int)tb, 16 << 23), 80 << 23);                    // v_med3_i32 (NaN / inf: 80; zero: 16)
+            fs_up = __uint_as_float((203u << 23) - tb);
+            fs_ring = __uint_as_float(tb + ((unsigned)(dsc + 51) << 23));
         } else if (j < 15) {                                      // f16 hi + lo of four bins: half of the B operand pair
             const int m = j - 13;
-            asm volatile("v_fma_mixlo_f16 %0, %1, 1.0, 0" : "=v"(bh[2 * m]) : "v"(cval[4 * m]));
-            asm volatile("v_fma_mixlo_f16 %0, %1, 1.0, 0" : "=v"(bh[2 * m + 1]) : "v"(cval[4 * m + 2]));
-            asm volatile("v_fma_mixhi_f16 %0, %1, 1.0, 0" : "+v"(bh[2 * m]) : "v"(cval[4 * m + 1]));
-            asm volatile("v_fma_mixhi_f16 %0, %1, 1.0, 0" : "+v"(bh[2 * m + 1]) : "v"(cval[4 * m + 3]));
-            asm volatile("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(bl[2 * m]) : "v"(cval[4 * m]), "v"(bh[2 * m]));
-            asm volatile("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(bl[2 * m + 1]) : "v"(cval[4 * m + 2]), "v"(bh[2 * m + 1]));
-            asm volatile("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(bl[2 * m]) : "v"(cval[4 * m + 1]), "v"(bh[2 * m]));
-            asm volatile("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(bl[2 * m + 1]) : "v"(cval[4 * m + 3]), "v"(bh[2 * m + 1]));
+            asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(bh[2 * m]) : "v"(cval[4 * m]), "v"(fs_up));
+            asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(bh[2 * m + 1]) : "v"(cval[4 * m + 2]), "v"(fs_up));
+            asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(bh[2 * m]) : "v"(cval[4 * m + 1]), "v"(fs_up));
+            asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(bh[2 * m + 1]) : "v"(cval[4 * m + 3]), "v"(fs_up));
+            asm volatile("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(bl[2 * m]) : "v"(cval[4 * m]), "v"(fs_up), "v"(bh[2 * m]));
+            asm volatile("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(bl[2 * m + 1]) : "v"(cval[4 * m + 2]), "v"(fs_up), "v"(bh[2 * m + 1]));
+            asm volatile("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(bl[2 * m]) : "v"(cval[4 * m + 1]), "v"(fs_up), "v"(bh[2 * m]));
+            asm volatile("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(bl[2 * m + 1]) : "v"(cval[4 * m + 3]), "v"(fs_up), "v"(bh[2 * m + 1]));
         } else if (j >= 16 && j < 19) {                           // tap products: hi*hi, hi*lo, lo*hi, one term of every row tile a step
             const uint32x4 vbh = {bh[0], bh[1], bh[2], bh[3]}, vbl = {bl[0], bl[1], bl[2], bl[3]};
 #pragma unroll
@@ -334,7 +382,7 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
         } else if (j >= 20) {                                     // tile m: taps 4m + g4, units 0..3 of this frame -> its row
             const int m = j - 20;
             if (m == 0) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(pt[0]), "+v"(pt[1]), "+v"(pt[2]));
-            const floatx4 r = pt[m] * pow2f(dsc);
+            const floatx4 r = pt[m] * fs_ring;
             *reinterpret_cast<floatx4 *>(prow + 4 * (4 * m + g4)) = r;
             *reinterpret_cast<floatx4 *>((drow ? drow : spare) + 4 * (4 * m + g4) - (drow ? 0 : 4 * g4)) = r;
         }
@@ -358,14 +406,15 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
         floatx4 r0 = *reinterpret_cast<const floatx4 *>(red);             // pass q+1's partial maxima
         // In the shadow of those fetches: the vector half of finishing pass q-1 (magnitudes, sum of squares, f16 split; it
         // needs nothing but the accumulators this wave kept), which would otherwise crowd the second half of the block.
-        const int dsc = se_ref - se_m1 < -60 ? -60 : (se_ref - se_m1 > 60 ? 60 : se_ref - se_m1);
+        const int dsc = se_ref - se_m1 < -45 ? -45 : (se_ref - se_m1 > 45 ? 45 : se_ref - se_m1);   // (beyond: the guard's business)
         const int rm = r3 == 0 ? 2 : r3 - 1, re = r3 == 2 ? 0 : r3 + 1;   // (q - 1) mod 3, (q - 2) mod 3
 #ifndef SYLDET_R_NOMAG
 #pragma unroll
         for (int j = 0; j < 15; j++) mag_micro(j, rm, dsc);
 #endif
         SD_PIN(r0);
-        const int se_next = scale_of(r0);                             // pass q+1's sample scale
+        int st_next;
+        const int se_next = scale_of(r0, st_next);                    // pass q+1's sample scale
         const float sx_next = pow2f(se_next);
         _Float16 *wh = smp0 + (par ^ 1) * buf_halves;
         // pass q+2's descriptor, kept incrementally in 32-bit scalar arithmetic (pass_rsrc's 64-bit clamps cost thirty
@@ -416,7 +465,7 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
                 stage_micro(i);
 #endif
 #ifndef SYLDET_R_NOEVAL
-                if (i % 4 == 0) eval_slot(i / 4, q - 2, re);
+                if (i % 4 == 0) eval_slot(i / 4, q - 2, re, thr_m2);
                 if (i >= 9 && i < 13) eval_reduce(i - 9);
 #endif
 #ifndef SYLDET_R_NOMAG
@@ -480,10 +529,15 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
             for (int m = 0; m < 4; m++) accP[m] = acc[m];
         }
         SD_RTICK(4)
+        thr_m2 = thr_m1;
+        thr_m1 = thr_0;
+        thr_0 = guard_thr(se_cur, st_cur, se_next, st_next);
         se_m1 = se_cur;
         se_cur = se_next;
+        st_cur = st_next;
         r3 = r3 == 2 ? 0 : r3 + 1;
         __syncthreads();          // products of pass q-1, staged samples of pass q+1 and the partial maxima are complete
+        push_bad(q - 2);
         SD_RTICK(6)
         if (STAMP) {                // top of the pass up to the first MFMA, four quarters of the block, barrier
             tsum[0] += tick[0] - tick[5];
@@ -500,23 +554,25 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
     // ---- drain: evaluate pass runs-2, finish pass runs-1, barrier, evaluate it
     {
         const int q = runs;
-        const int dsc = se_ref - se_m1 < -60 ? -60 : (se_ref - se_m1 > 60 ? 60 : se_ref - se_m1);
+        const int dsc = se_ref - se_m1 < -45 ? -45 : (se_ref - se_m1 > 45 ? 45 : se_ref - se_m1);   // (beyond: the guard's business)
         const int rm = r3 == 0 ? 2 : r3 - 1, re = r3 == 2 ? 0 : r3 + 1;
 #pragma unroll
         for (int sl = 0; sl < 12; sl++) {
-            eval_slot(sl, q - 2, re);
+            eval_slot(sl, q - 2, re, thr_m2);
             if (sl == 2)
                 for (int k = 0; k < 4; k++) eval_reduce(k);
         }
+        push_bad(q - 2);
 #pragma unroll
         for (int j = 0; j < kMagSteps; j++) mag_micro(j, rm, dsc);
         __syncthreads();
 #pragma unroll
         for (int sl = 0; sl < 12; sl++) {
-            eval_slot(sl, q - 1, rm);
+            eval_slot(sl, q - 1, rm, thr_m1);
             if (sl == 2)
                 for (int k = 0; k < 4; k++) eval_reduce(k);
         }
+        push_bad(q - 1);
     }
     if (STAMP && (tid == 0 || tid == 64 * (kWaves - 1)) && d.stamps)       // wave 0's view in slots 0-7, the last wave's in 8-15
         for (int i = 0; i < 8; i++) atomicAdd(&d.stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (tid ? 8 : 0) + i], tsum[i]);

@@ -11,38 +11,20 @@
 //
 // gfx950 only: wave = 64 lanes, 256-thread workgroups.
 
-#include "kernels.hpp"
+#include "generic_eval.hpp"
 
 namespace sd {
 
 namespace {
 
+using namespace generic_dev;
+
 constexpr int kBlock = 256;
-constexpr int kWave = 64;
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b)
 {
     return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
-
-// Wave-wide reductions in registers: quad / half-row / row steps through DPP, rows and halves through gfx950's
-// v_permlane16_swap / v_permlane32_swap (with both operands = x the two results are x and its partner).  Every
-// lane ends up with the result.
-template <typename Op>
-__device__ __forceinline__ float wave_reduce(float v, Op op)
-{
-    v = op(v, __uint_as_float(__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0xB1, 0xF, 0xF, false)));    // lane ^ 1
-    v = op(v, __uint_as_float(__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x4E, 0xF, 0xF, false)));    // lane ^ 2
-    v = op(v, __uint_as_float(__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x141, 0xF, 0xF, false)));   // the other quad of the half row
-    v = op(v, __uint_as_float(__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x140, 0xF, 0xF, false)));   // the other half of the row
-    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    v = op(__uint_as_float(r[0]), __uint_as_float(r[1]));
-    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return op(__uint_as_float(r[0]), __uint_as_float(r[1]));
-}
-__device__ __forceinline__ float wave_sum(float v) { return wave_reduce(v, [](float a, float b) { return a + b; }); }
-__device__ __forceinline__ float wave_min(float v) { return wave_reduce(v, [](float a, float b) { return fminf(a, b); }); }
-__device__ __forceinline__ float wave_max(float v) { return wave_reduce(v, [](float a, float b) { return fmaxf(a, b); }); }
 
 // ------------------------------------------------------------------------------------
 // 1024-point frames (BASELINE configs[2]): the 512-point complex FFT of the packed real frame as 8 x 8 x 8,
@@ -345,16 +327,6 @@ stft_generic_kernel(StftDesc d, const float *__restrict__ samples, int64_t strid
 // ------------------------------------------------------------------------------------
 constexpr int kMlpPasses = 8;    // evaluations per wave
 
-__device__ __forceinline__ float transfer(int tf, float x)
-{
-    switch (tf) {
-    case 0: return tanhf(x);                         // TanSig  NeuralNet.swift:189-194
-    case 1: return 1.0f / (expf(-x) + 1.0f);         // LogSig  :196-215
-    case 3: return x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x);   // SatLin  :223-228 (NaN stays NaN)
-    default: return x;                               // PureLin :217-221
-    }
-}
-
 __global__ void __launch_bounds__(kBlock)
 mlp_generic_kernel(NetDesc n, int F, const float *__restrict__ columns, int64_t J, int64_t E,
                    float *__restrict__ outputs, uint8_t *__restrict__ flags)
@@ -366,102 +338,14 @@ mlp_generic_kernel(NetDesc n, int F, const float *__restrict__ columns, int64_t 
     float *bufA = smem + (size_t)wave * 2 * n.max_width;
     float *bufB = bufA + n.max_width;
     const float *cols = columns + (int64_t)c * J * F;
-    const float *P = n.params;
 
     for (int pass = 0; pass < kMlpPasses; pass++) {
         const int64_t e = ((int64_t)blockIdx.x * kMlpPasses + pass) * (kBlock / kWave) + wave;
         const bool valid = e < E;
         const float *src = cols + e * F;
 
-        for (int i = lane; i < n.I; i += kWave) {
-            float v = valid ? src[i] : 1.0f;
-            if (n.scaling == 1) v = logf(v);                    // vvlogf, SyllableDetector.swift:207
-            else if (n.scaling == 2) v = 20.0f * log10f(v);     // vDSP_vdbcon ref 1, amplitude flag :195
-            bufA[i] = v;
-        }
-        __syncthreads();
-
-        for (int k = 0; k < n.n_in_fns; k++) {
-            const DevFn fn = n.in_fns[k];
-            if (fn.kind == 0) {                                  // L2Normalize :47-59
-                float s = 0.0f;
-                for (int i = lane; i < n.I; i += kWave) s += bufA[i] * bufA[i];
-                s = sqrtf(wave_sum(s));
-                for (int i = lane; i < n.I; i += kWave) bufA[i] = bufA[i] / s;
-            } else if (fn.kind == 1) {                           // Normalize :69-96
-                float mn = INFINITY, mx = -INFINITY;
-                for (int i = lane; i < n.I; i += kWave) { mn = fminf(mn, bufA[i]); mx = fmaxf(mx, bufA[i]); }
-                mn = wave_min(mn);
-                mx = wave_max(mx);
-                const float range = mx - mn;
-                if (range == 0.0f) {
-                    for (int i = lane; i < n.I; i += kWave) bufA[i] = -1.0f;
-                } else {
-                    const float slope = 2.0f / range, intercept = (0.0f - mn - mx) / range;
-                    for (int i = lane; i < n.I; i += kWave) bufA[i] = bufA[i] * slope + intercept;
-                }
-            } else if (fn.kind == 2) {                           // NormalizeStd :105-108 (population sigma)
-                float s = 0.0f;
-                for (int i = lane; i < n.I; i += kWave) s += bufA[i];
-                const float mean = wave_sum(s) / (float)n.I;
-                float q = 0.0f;
-                for (int i = lane; i < n.I; i += kWave) { const float dlt = bufA[i] - mean; q += dlt * dlt; }
-                const float sd = sqrtf(wave_sum(q) / (float)n.I);
-                for (int i = lane; i < n.I; i += kWave) bufA[i] = (bufA[i] - mean) / sd;
-            } else if (fn.kind == 3) {                           // MapMinMax.apply :127-131
-                for (int i = lane; i < n.I; i += kWave)
-                    bufA[i] = (bufA[i] - P[fn.xoff + i]) * P[fn.gain + i] + fn.y;
-            } else {                                             // MapStd.apply :162-169
-                for (int i = lane; i < n.I; i += kWave)
-                    bufA[i] = (bufA[i] - P[fn.xoff + i]) * P[fn.gain + i] + fn.y;
-            }
-            __syncthreads();
-        }
-
-        float *cur = bufA, *nxt = bufB;
-        for (int l = 0; l < n.n_layers; l++) {
-            const DevLayer L = n.layers[l];
-            const float *W = P + L.w;
-            if (L.out < kWave) {
-                // few outputs: the whole wave reduces one dot product at a time
-                for (int o = 0; o < L.out; o++) {
-                    float acc = 0.0f;
-                    const float *wrow = W + (size_t)o * L.in;
-                    for (int i = lane; i < L.in; i += kWave) acc = fmaf(wrow[i], cur[i], acc);
-                    acc = wave_sum(acc);
-                    if (lane == 0) nxt[o] = transfer(L.tf, acc + P[L.b + o]);
-                }
-            } else {
-                // many outputs: each lane owns whole rows
-                for (int o = lane; o < L.out; o += kWave) {
-                    float acc = 0.0f;
-                    const float *wrow = W + (size_t)o * L.in;
-                    for (int i = 0; i < L.in; i++) acc = fmaf(wrow[i], cur[i], acc);
-                    nxt[o] = transfer(L.tf, acc + P[L.b + o]);
-                }
-            }
-            __syncthreads();
-            float *tmp = cur; cur = nxt; nxt = tmp;
-        }
-
-        // reverse maps, (y - yOff)/gain + xOffset, NeuralNet.swift:137-142 / :175-180
-        for (int o = lane; o < n.n_out; o += kWave) {
-            float v = cur[o];
-            for (int k = 0; k < n.n_out_fns; k++) {
-                const DevFn fn = n.out_fns[k];
-                v = (v - fn.y) / P[fn.gain + o] + P[fn.xoff + o];
-            }
-            cur[o] = v;
-            if (valid && outputs) outputs[(((int64_t)c * E) + e) * n.n_out + o] = v;
-        }
-        __syncthreads();
-        if (lane == 0 && valid && flags) {
-            uint8_t hit = 0;
-            const int lim = n.rule == 0 ? 1 : n.n_out;
-            for (int o = 0; o < lim; o++) hit |= ((double)cur[o] >= n.thresholds[o]) ? 1 : 0;
-            flags[(int64_t)c * E + e] = hit;
-        }
-        __syncthreads();
+        mlp_eval_wave(n, src, valid, bufA, bufB, lane, outputs ? outputs + (((int64_t)c * E) + e) * n.n_out : nullptr,
+                      flags ? flags + (int64_t)c * E + e : nullptr);
     }
 }
 

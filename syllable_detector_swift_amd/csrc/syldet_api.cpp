@@ -130,6 +130,11 @@ struct syldet {
     // fused engine tables
     FusedPlan fused;
     DeviceBuffer d_stamps;            // diagnostic stamps (SYLDET_FUSED_STAMPS)
+    // precision guard of the fused kernels (kernels.hpp, FixItem): work list + what the exact recomputation needs
+    DeviceBuffer d_fix;               // 4 counters | items
+    DeviceBuffer d_ctab;              // [N] (cos, sin)(2 pi m / N) fp64
+    FixDesc fixd{};
+    bool has_fix = false;
     DeviceBuffer d_fused;             // one blob: dfrag | wfrag | koff | bias0 | rvec | w1 | b1 | out_params
     DeviceBuffer d_stage_in, d_stage_out, d_stage_flags, d_stage_idx, d_stage_cnt;
     DeviceBuffer d_planar;            // channel-major copy of interleaved input (syldet_run_interleaved*)
@@ -361,6 +366,49 @@ int upload_plan(syldet *h, FusedPlan &p, DeviceBuffer &buf)
 
 int upload_fused(syldet *h) { return upload_plan(h, h->fused, h->d_fused); }
 
+// What fixup_kernel (the exact recomputation behind the fused kernels' precision guard) needs: geometry, the fp32 window
+// table, a trigonometric table in fp64.
+int upload_fix(syldet *h)
+{
+    const syldet_config_t &c = h->cfg.view;
+    const int N = c.fourier_length;
+    std::vector<double> tab((size_t)N * 2);
+    const double two_pi = 6.283185307179586476925286766559;
+    for (int m = 0; m < N; m++) {
+        tab[(size_t)2 * m] = std::cos(two_pi * (double)m / (double)N);
+        tab[(size_t)2 * m + 1] = std::sin(two_pi * (double)m / (double)N);
+    }
+    if (int st = h->d_ctab.reserve(tab.size() * sizeof(double))) return st;
+    SYLDET_HIP(hipMemcpy(h->d_ctab.ptr, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
+    FixDesc &f = h->fixd;
+    f.N = N; f.W = c.window_length; f.hop = h->geom.hop; f.gap = h->geom.gap; f.f0 = h->geom.f0; f.F = h->geom.bins; f.T = c.time_range;
+    f.window = (const float *)h->d_window.ptr;
+    f.ctab = (const double2 *)h->d_ctab.ptr;
+    h->has_fix = true;
+    return SYLDET_OK;
+}
+
+// The work list for one launch over `units` evaluations (or frames) per channel: room for every 16-unit tile of every
+// segment of every channel, so the list cannot overflow; the counters are zeroed when the buffer is (re)allocated and by the
+// recomputation kernel itself after every launch.  SYLDET_NO_GUARD=1 (diagnostic A/B only) turns the guard off.
+int prepare_fix(syldet *h, int C, int64_t units, int64_t segments, hipStream_t stream, FixList &out)
+{
+    out = FixList{nullptr, nullptr, 0};
+    static const bool no_guard = std::getenv("SYLDET_NO_GUARD") != nullptr;
+    if (!h->has_fix || no_guard) return SYLDET_OK;
+    const uint64_t cap = (uint64_t)C * (uint64_t)((units + 15) / 16 + 8 * segments + 16);
+    if (cap > 0x7fffffffull) return SYLDET_OK;              // (rows this long take the generic engine anyway)
+    const size_t bytes = 16 + (size_t)cap * sizeof(FixItem);
+    if (bytes > h->d_fix.cap) {
+        if (int st = h->d_fix.reserve(bytes + bytes / 4)) return st;
+        SYLDET_HIP(hipMemsetAsync(h->d_fix.ptr, 0, 16, stream));
+    }
+    out.counters = (unsigned *)h->d_fix.ptr;
+    out.items = (FixItem *)((char *)h->d_fix.ptr + 16);
+    out.capacity = (unsigned)cap;
+    return SYLDET_OK;
+}
+
 int upload_mlpx(syldet *h)
 {
     MlpxPlan &p = h->mlpx;
@@ -452,6 +500,7 @@ int stft_on_stream(syldet *h, const float *d_samples, int64_t stride, int C, int
         fused_segmentation(d, J, C);
         d.spect_out = d_columns;
         d.stamps = nullptr;
+        d.fix = FixList{nullptr, nullptr, 0};
         d.ko = 0;
         KernelTimer t(h, stream, "fused_kernel (spectrogram)");
         SYLDET_HIP(launch_fused_spectrogram(d, d_samples, stride, C, J, stream));
@@ -474,6 +523,7 @@ int run_on_stream(syldet *h, const float *d_samples, int64_t S, int64_t stride, 
         FusedDesc d = h->fused.desc;
         fused_segmentation(d, E, C);
         d.stamps = nullptr;
+        d.fix = FixList{nullptr, nullptr, 0};
         // diagnostic only: SYLDET_FUSED_KO=<mask> runs an instantiation with parts of the kernel knocked out
         static const int want_ko = std::getenv("SYLDET_FUSED_KO") ? std::atoi(std::getenv("SYLDET_FUSED_KO")) : 0;
         d.ko = want_ko;
@@ -513,9 +563,15 @@ int run_on_stream(syldet *h, const float *d_samples, int64_t S, int64_t stride, 
                 if (sum[i] > 0) std::fprintf(stderr, "   %-32s %6.0f cycles/pass  %5.1f %%\n", names[i], sum[i] / ((double)(n / 16) * d.runs), 100.0 * sum[i] / tot);
             return SYLDET_OK;
         }
-        // (the launcher picks the register-resident-basis kernel where it is instantiated: named for what runs)
-        KernelTimer t(h, stream, (fused_r_applicable(d) && (!std::getenv("SYLDET_FUSED_CLASSIC") || !d.classic_ok) && !d.ko) ? "fused_r_kernel" : "fused_kernel");
-        SYLDET_HIP(launch_fused(d, d_samples, stride, C, S, J, E, d_outputs, d_flags, stream));
+        // the precision guard's work list, and behind the fused kernel the exact recomputation of what it reports
+        const int64_t segs = (E + d.r_seg_evals - 1) / d.r_seg_evals + (E + d.seg_evals - 1) / d.seg_evals;
+        if (int st = prepare_fix(h, C, E, segs, stream, d.fix)) return st;
+        {
+            // (the launcher picks the register-resident-basis kernel where it is instantiated: named for what runs)
+            KernelTimer t(h, stream, (fused_r_applicable(d) && (!std::getenv("SYLDET_FUSED_CLASSIC") || !d.classic_ok) && !d.ko) ? "fused_r_kernel" : "fused_kernel");
+            SYLDET_HIP(launch_fused(d, d_samples, stride, C, S, J, E, d_outputs, d_flags, stream));
+        }
+        SYLDET_HIP(launch_fixup(h->fixd, h->net, d_samples, stride, J, E, d_outputs, d_flags, nullptr, d.fix, stream));
         return SYLDET_OK;
     }
     if (int st = h->d_columns.reserve((size_t)C * (size_t)J * (size_t)h->geom.bins * sizeof(float))) return st;
@@ -604,7 +660,9 @@ int syldet_create(const syldet_config_t *cfg, int32_t n_channels, int32_t device
         return st;
     }
     if (h->engine == SYLDET_ENGINE_FUSED) {
-        if (int st = upload_fused(h.get())) {
+        int st = upload_fused(h.get());
+        if (!st) st = upload_fix(h.get());
+        if (st) {
             syldet_destroy(h.release());
             return st;
         }
@@ -661,7 +719,7 @@ int syldet_destroy(syldet_t *h)
         (void)hipStreamDestroy(h->stream);
     }
     for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
-    for (DeviceBuffer *b : {&h->d_window, &h->d_tw, &h->d_sw, &h->d_params, &h->d_thr, &h->d_columns, &h->d_fused, &h->d_mlpx, &h->d_stamps, &h->d_planar, &h->d_wide, &h->d_xn, &h->d_dft, &h->d_stage_in,
+    for (DeviceBuffer *b : {&h->d_window, &h->d_tw, &h->d_sw, &h->d_params, &h->d_thr, &h->d_columns, &h->d_fused, &h->d_mlpx, &h->d_stamps, &h->d_fix, &h->d_ctab, &h->d_planar, &h->d_wide, &h->d_xn, &h->d_dft, &h->d_stage_in,
                             &h->d_stage_out, &h->d_stage_flags, &h->d_stage_idx, &h->d_stage_cnt})
         b->release();
     h->p_stage_in.release();
@@ -699,6 +757,19 @@ int syldet_last_timings(syldet_t *h, double *milliseconds, const char **names, i
         milliseconds[i] = (double)ms;
         if (names) names[i] = h->event_names[(size_t)i];
     }
+    return SYLDET_OK;
+}
+
+int syldet_fixup_stats(syldet_t *h, int64_t *items, int32_t *overflow)
+{
+    if (!h) return fail(SYLDET_ERR_INVALID_ARGUMENT, "NULL argument");
+    unsigned c[4] = {0, 0, 0, 0};
+    if (h->d_fix.ptr) {
+        SYLDET_HIP(hipSetDevice(h->device));
+        SYLDET_HIP(hipMemcpy(c, h->d_fix.ptr, sizeof(c), hipMemcpyDeviceToHost));
+    }
+    if (items) *items = (int64_t)c[2];
+    if (overflow) *overflow = (int32_t)c[3];
     return SYLDET_OK;
 }
 

@@ -117,12 +117,27 @@ class SyllableDetector:
         if samples.device.index != self.device:
             raise ValueError("samples live on a different device than the detector")
 
+    def _check_results(self, outputs, flags, E, device):
+        """Caller-supplied result tensors go to the kernels as raw pointers: shape, dtype, layout and device must be right."""
+        torch = _torch()
+        if outputs is not None:
+            want = (self.channels, E, self.geometry.outputs)
+            if not (outputs.is_cuda and outputs.dtype == torch.float32 and tuple(outputs.shape) == want and outputs.is_contiguous()
+                    and outputs.device == device):
+                raise ValueError("outputs must be a contiguous float32 CUDA tensor of shape %s on the samples' device" % (want,))
+        if flags is not None:
+            want = (self.channels, E)
+            if not (flags.is_cuda and flags.dtype == torch.uint8 and tuple(flags.shape) == want and flags.is_contiguous()
+                    and flags.device == device):
+                raise ValueError("flags must be a contiguous uint8 CUDA tensor of shape %s on the samples' device" % (want,))
+
     def run(self, samples, outputs=None, flags=None, stream=None):
         """samples [C, S] -> (outputs [C, E, n_out] f32, flags [C, E] u8), asynchronous on `stream`."""
         torch = _torch()
         self._check_samples(samples)
         S = int(samples.shape[1])
         E = self.countEvaluations(S)
+        self._check_results(outputs, flags, E, samples.device)
         if outputs is None:
             outputs = torch.empty((self.channels, E, self.geometry.outputs), dtype=torch.float32, device=samples.device)
         if flags is None:
@@ -140,6 +155,7 @@ class SyllableDetector:
             raise ValueError("frames must have one column per channel and live on the detector's device")
         n = int(frames.shape[0])
         E = max(self.countEvaluations(n), 0)
+        self._check_results(outputs, flags, E, frames.device)
         if outputs is None:
             outputs = torch.empty((self.channels, E, self.geometry.outputs), dtype=torch.float32, device=frames.device)
         if flags is None:
@@ -172,6 +188,9 @@ class SyllableDetector:
     def detections(self, flags, debounce: float = 0.0, capacity: Optional[int] = None, stream=None):
         """flags [C, E] u8 -> (indices [C, capacity] i64, counts [C] i64); TrackDetector.swift:65-100."""
         torch = _torch()
+        if not (flags.is_cuda and flags.dtype == torch.uint8 and flags.dim() == 2 and flags.shape[0] == self.channels
+                and flags.is_contiguous() and flags.device.index == self.device):
+            raise ValueError("flags must be a contiguous uint8 CUDA tensor [channels, n_evals] on the detector's device")
         E = int(flags.shape[1])
         cap = E if capacity is None else int(capacity)
         idx = torch.empty((self.channels, max(cap, 1)), dtype=torch.int64, device=flags.device)
@@ -191,6 +210,13 @@ class SyllableDetector:
         n = C.c_int32()
         check(_abi.lib.syldet_last_timings(self._h, ms, names, 8, C.byref(n)))
         return [(names[i].decode(), float(ms[i])) for i in range(min(n.value, 8))]
+
+    def fixupStats(self):
+        """(work items of 16 evaluations the last batch call recomputed exactly, overflow flag): the fused kernels' precision
+        guard at work (0 for ordinary audio).  Synchronise the call's stream first."""
+        items, over = C.c_int64(), C.c_int32()
+        check(_abi.lib.syldet_fixup_stats(self._h, C.byref(items), C.byref(over)))
+        return int(items.value), int(over.value)
 
     # ---- batch, host arrays -------------------------------------------------------
     def runHost(self, samples: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:

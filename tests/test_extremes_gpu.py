@@ -1,5 +1,6 @@
 """Both fused kernels against the oracle on inputs at the edge of what fp32 audio can hold: silence, NaN and infinite
-samples, recordings scaled by 1e+-30, level steps of 240 dB inside a recording."""
+samples, recordings scaled by 1e+-30, level steps of 240 dB inside a recording.  No allowance: values to 1e-5, flags exact,
+NaN exactly where the reference has it."""
 import numpy as np
 import pytest
 
@@ -43,20 +44,20 @@ def test_extreme_inputs(oracle_lib, monkeypatch, kernel, name):
         torch.cuda.synchronize()
         assert det.lastTimings()[0][0] == kernel
         out, fl = out.cpu().numpy()[0], fl.cpu().numpy()[0]
+        items, over = det.fixupStats()
     _, wfl, w64 = util.oracle_for(cfg).run(x, po.F64)
     ok, okg = np.isfinite(w64).all(axis=1), np.isfinite(out).all(axis=1)
-    assert not (okg & ~ok).any(), "a NaN evaluation of the reference must be one here"
-    both = ok & okg
-    if name in ("one inf", "step 1e-12", "step 1e12"):
-        # block floating point: an infinitely loud sample, or a 240 dB step, costs the pass it falls into (64 frames on the
-        # register-resident-basis kernel, 128 on the 8-wave one) -- NaN there, never a wrong finite number or flag ...
-        assert (ok & ~okg).sum() <= (64 if kernel == "fused_r_kernel" else 128)
-        if kernel == "fused_kernel" and name == "step 1e12":
-            return          # ... except the 8-wave kernel's transition strip across a 240 dB step up (numerics notes)
-    else:
-        assert (ok == okg).all()
-    if both.any():
+    # NaN exactly where the reference has it (the windows that contain the offending sample, NeuralNet.swift:47-59): what the
+    # block-floating-point grid cannot hold is recomputed from the samples (precision guard, include/syldet.h)
+    assert (ok == okg).all(), "NaN evaluations must coincide with the reference's: %d extra, %d missing" % ((ok & ~okg).sum(), (okg & ~ok).sum())
+    if ok.any():
         tol = 1e-5
-        assert np.abs(out[both] - w64[both]).max() <= tol * max(1.0, np.abs(w64[both]).max())
-        assert (fl[both] == wfl[both]).all() or np.abs(w64[both][fl[both] != wfl[both]][:, 0] - cfg.thresholds[0]).max() < 2e-5
+        assert np.abs(out[ok] - w64[ok]).max() <= tol * max(1.0, np.abs(w64[ok]).max())
+        util.assert_flags_exact(fl[ok], w64[ok], cfg.thresholds, cfg.rule, tol)
     assert not fl[~okg].any()
+    # the guard is at work exactly where it has to be: ordinary audio (and whole-recording scalings) never reach the slow path
+    if name in ("plain", "x 1e30"):
+        assert items == 0, "%d work items for ordinary audio" % items
+    if name in ("one inf", "step 1e-12", "step 1e12"):
+        assert items > 0
+    assert over == 0
