@@ -307,8 +307,10 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
         d.guard_r = sq(lip * sqI * phi_r / eps_out);
         d.guard_c = sq(lip * sqI * phi_c / eps_out);
         d.guard_c_range = (float)std::min((norm == 2 ? 4.0 : 2.0) * lip * sqI * phi_c / eps_out, 1e30);
-        d.guard_rel_r = sq(sqI * phi_r / rel);
-        d.guard_rel_c = sq(sqI * phi_c / rel);
+        // no normaliser: every column has to stand on its own (the reference's error is relative to the frame, and nothing
+        // divides a quiet column's error by a loud neighbour's norm): the smallest column sum of squares of the window
+        d.guard_rel_r = sq(std::sqrt((double)F) * phi_r / rel);
+        d.guard_rel_c = sq(std::sqrt((double)F) * phi_c / rel);
         // no normaliser: the floor in true units is phi 2^(col_shift - se); it matters once  lip sqrt(I) phi 2^(col_shift - se) > eps
         auto se_abs = [&](double phi) {
             const double v = std::log2(lip * sqI * phi / eps_out) + (double)d.col_shift;

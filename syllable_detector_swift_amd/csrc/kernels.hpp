@@ -151,7 +151,8 @@ struct FusedDesc {
     float guard_r;              // register-resident-basis kernel: window sum of squares, times 4^(se_ref - se_min)
     float guard_c;              // 8-wave kernel, l2normalize / no normaliser: window sum of squares
     float guard_c_range;        //   normalize: window range;  normalizestd: window sigma
-    float guard_rel_r, guard_rel_c;   // no normaliser: the relative criterion that joins the absolute one
+    float guard_rel_r, guard_rel_c;   // no normaliser: the per-column relative criterion (smallest column sum of squares of the
+                                      // window) that joins the absolute one
     int guard_se_abs_r, guard_se_abs_c;   // no normaliser: passes scaled below this exponent are loud enough for the floor to matter
     FixList fix;                // work list of evaluations to recompute (null counters: guard off)
     int ko;                     // diagnostic build only: knock-out mask (SYLDET_FUSED_KO)

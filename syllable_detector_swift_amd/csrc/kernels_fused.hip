@@ -346,6 +346,10 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
                         float mn = INFINITY, mx = -INFINITY;
                         for (int t = 0; t < T; t++) { mn = fminf(mn, stat[wslot + t]); mx = fmaxf(mx, stat[PS + wslot + t]); }
                         gstat = mx - mn;
+                    } else if (norm == 0) {                   // every column on its own: the quietest one of the window
+                        float mn = INFINITY;
+                        for (int t = 0; t < T; t++) mn = fminf(mn, stat[wslot + t]);
+                        gstat = mn;
                     }
                 } else gstat = 0.0f;
                 badv = valid && (st_w == 2 || (st_w == 0 && !(gstat >= gthr)));

@@ -252,7 +252,14 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
             const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(s01), __float_as_uint(s23), false, false);
             zt = __uint_as_float(r[0]) + __uint_as_float(r[1]);
         } else if (k == 3) {
-            ssw = xor32_sum(xor16_sum(ssp));
+            if (GEN && gnorm == 0) {                              // (the guard's statistic without a normaliser: the quietest column)
+                auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(ssp), __float_as_uint(ssp), false, false);
+                const float m = fminf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+                r = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+                ssw = fminf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+            } else {
+                ssw = xor32_sum(xor16_sum(ssp));
+            }
         }
     };
     // the rest of the network (NeuralNet.swift:47-59 L2Normalize on the folded first layer, :189-194 TanSig, :366-377 second
@@ -302,7 +309,10 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
                 SD_PIN(sv[tt]);
             }
             zp = pv[0] + pv[1] + pv[2];
-            ssp = sv[0] + sv[1] + sv[2];
+            if (GEN && gnorm == 0)                                // no normaliser: the guard wants the quietest column of the window
+                ssp = fminf(fminf(g4 < T ? sv[0] : INFINITY, g4 + 4 < T ? sv[1] : INFINITY), g4 + 8 < T ? sv[2] : INFINITY);
+            else
+                ssp = sv[0] + sv[1] + sv[2];
         }
         if (s >= 4 && s <= 8 && s % 2 == 0) eval_tail(s / 2 - 2, pp, thr);
     };

@@ -25,6 +25,10 @@ def _cases():
     out["x 1e-30"] = (base * np.float32(1e-30)).astype(np.float32)
     z = base.copy(); z[S // 2:] *= np.float32(1e-12); out["step 1e-12"] = z
     z = base.copy(); z[S // 2:] *= np.float32(1e12); out["step 1e12"] = z
+    # what a cage recording does: a click 90 dB above a quiet stretch, a quiet stretch right behind a loud one
+    z = (base * np.float32(3e-5)).astype(np.float32); z[26000] = 1.0; z[41000] = -0.7; out["clicks over quiet audio"] = z
+    z = base.copy(); z[S // 2 + 777:] *= np.float32(1e-4); out["80 dB down"] = z
+    z = base.copy(); z[:S // 2 + 777] *= np.float32(1e-5); out["100 dB up"] = z
     return out
 
 
