@@ -3,27 +3,35 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A step is one pass of the hot path (samples in HBM -> network outputs + detection flags in HBM)
-over one batch of synthetic audio.  At N=1 the workload is BASELINE.json configs[1]: the sample.txt
-network (N=W=256, overlap 124 => hop 132, Hamming, bins [12,41), T=10, 290 -> 4 TanSig -> 1 PureLin),
-64 synthetic channels x 2^24 samples (4 GiB, far past the 256 MiB Infinity Cache), fp32.  For N>1
-(launched by torch.distributed.run, one rank per GPU) every rank holds its own 64 channels (weak
-scaling; channels are independent detectors, so no data-path collective) and the timed step ends
-with ONE RCCL all-gather of the per-channel detection flags (BASELINE config 4's exchange).
+A step is one pass of the hot path (samples in HBM -> network outputs + detection flags in HBM) over one batch of
+synthetic audio.
 
-Rank 0 prints one JSON line.  `roofline` is computed from HIP-event timings of the dominant
-kernel taken inside the timed region on the launch stream; `cpu_baseline` is the oracle's fp32
-port of the reference's per-frame call sequence, single-threaded like the reference (plus an all-core
-figure beside it), on a bounded sample of the same workload (rank 0, N=1 only).
+N = 1: BASELINE.json configs[1] -- the sample.txt network (N=W=256, overlap 124 => hop 132, Hamming, bins [12,41), T=10,
+290 -> 4 TanSig -> 1 PureLin), 64 synthetic channels x 2^24 samples (4 GiB, far past the 256 MiB Infinity Cache), fp32.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): BASELINE.json configs[3] -- the same network, 512 channels x
+2^21 samples per GPU (4096 channels over 8 GPUs; the same 4 GiB and the same 8.13 M frames per GPU as the N = 1 batch), weak
+scaling.  Channels are independent detectors (Processor.swift:57-59, main.swift:86-89), so the data path has no collective;
+the timed step ends with ONE RCCL all-gather of the per-channel detection flags, as bits.  `--total-channels 4096` fixes
+the total instead and shards it over the ranks (strong scaling, dist.shard_channels).
+
+Rank 0 prints one JSON line.  `roofline` is computed from HIP-event timings of the dominant kernel taken inside the timed
+region on the launch stream.  After the timed region the last step's results are spot-checked against the CPU oracle
+(tests/spotcheck.py: head, tail and segment seams of the first, a middle and the last channel) -> `verified`.
+`cpu_baseline` is the oracle's fp32 port of the reference's call sequence in its streaming, frame-at-a-time form, built
+-O3 -march=native on this host, single-threaded like the reference (plus an all-core figure beside it), on a bounded sample
+of the same workload (rank 0, N = 1 only).
 """
 import argparse
+import glob
 import json
 import os
+import statistics
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for p in (ROOT, os.path.join(ROOT, "oracle")):
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
@@ -32,47 +40,52 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0 # MI355X_MICROARCH.md: dense bf16 matrix peak (no
 
 
 def cpu_baseline(cfg, samples_host, budget_s=10.0, threads=1):
-    """Oracle fp32 port (kind "port") on `threads` host threads, each with its own oracle instance working through
-    the channel slice over and over for ~budget_s (ctypes releases the GIL inside the C call)."""
+    """The oracle's fp32 port (kind "port") in the reference's own form: one detector per thread, samples appended in
+    8192-sample buffers, one frame and one evaluation at a time through the two rings (orc_stream_run; TrackDetector.swift:
+    45-105), built -O3 -march=native on this host.  Every thread works through its channel over and over for ~budget_s
+    (ctypes releases the GIL inside the C call); the figure is the median over passes of frames / pass time, times threads."""
     import concurrent.futures as cf
     import pyoracle as po
-    po.build()
+    po.lib(native=True)                                  # builds here, outside the timed loops
     S = samples_host.shape[1]
     t0 = time.perf_counter()
 
     def worker(k):
         o = po.Oracle(po.from_config(cfg))
-        frames, reps = 0, 0
+        J = o.count_frames(S)
+        rates = []
         while True:
-            o.run(samples_host[k % samples_host.shape[0]], po.F32)
-            frames += o.count_frames(S)
-            reps += 1
-            if time.perf_counter() - t0 >= budget_s:
-                return frames, reps
+            t1 = time.perf_counter()
+            o.stream_run(samples_host[k % samples_host.shape[0]], po.F32, chunk=8192, native=True, keep=False)
+            rates.append(J / (time.perf_counter() - t1))
+            if time.perf_counter() - t0 >= budget_s and len(rates) >= 5:
+                return rates
 
     with cf.ThreadPoolExecutor(threads) as ex:
         res = list(ex.map(worker, range(threads)))
     dt = time.perf_counter() - t0
-    frames, reps = sum(r[0] for r in res), sum(r[1] for r in res)
-    return {"value": frames / dt, "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": "%d thread(s) x 1 channel x %d samples of the benchmark input, %d pass(es) in all, %.1f s, "
-                      "oracle fp32 port (one frame at a time, radix-2 packed real FFT, unfolded network)"
-                      % (threads, S, reps, dt)}
+    passes = sum(len(r) for r in res)
+    value = sum(statistics.median(r) for r in res)
+    return {"value": value, "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": "%d thread(s) x 1 channel x %d samples of the benchmark input, streaming frame-at-a-time form "
+                      "(8192-sample buffers, one processNewValue per evaluation), median of %d passes (%.1f s), oracle fp32 "
+                      "port at -O3 -march=native (radix-2 packed real FFT, unfolded network)" % (threads, S, passes, dt)}
 
 
 def measured_traffic(C, S, hop, engine, kernel=None):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r01_traffic.json:
-    FETCH_SIZE and WRITE_SIZE collected separately, gfx950 FETCH_SIZE x2 correction), if they were taken on
-    exactly this workload; else None."""
-    try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-        w = t["workload"]
-        if (w["channels_per_gpu"], w["samples_per_channel"], w["hop"], w["engine"]) == (C, S, hop, engine) and \
-                (kernel is None or t.get("kernel", kernel) == kernel):
-            return t["hbm_bytes_per_launch"]
-    except Exception:
-        pass
-    return None
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r*_traffic*.json: FETCH_SIZE
+    and WRITE_SIZE collected separately, gfx950 FETCH_SIZE x2 correction), newest round first, if they were taken on
+    exactly this workload and kernel; else (None, None).  The run itself does not collect counters."""
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic*.json")), reverse=True):
+        try:
+            t = json.load(open(path))
+            w = t["workload"]
+            if (w["channels_per_gpu"], w["samples_per_channel"], w["hop"], w["engine"]) == (C, S, hop, engine) and \
+                    (kernel is None or t.get("kernel", kernel) == kernel):
+                return t["hbm_bytes_per_launch"], os.path.relpath(path, ROOT) + " (rocprofv3 --pmc passes of this command, committed; not collected by this run)"
+        except Exception:
+            pass
+    return None, None
 
 
 def main():
@@ -80,12 +93,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--channels", type=int, default=64, help="channels per GPU")
-    ap.add_argument("--log2-samples", type=int, default=24, help="samples per channel = 2^k")
+    ap.add_argument("--channels", type=int, default=None, help="channels per GPU (default: 64 at one GPU, 512 at several)")
+    ap.add_argument("--log2-samples", type=int, default=None, help="samples per channel = 2^k (default: 24 at one GPU, 21 at several)")
+    ap.add_argument("--total-channels", type=int, default=None, help="strong scaling: this many channels sharded over the ranks")
     ap.add_argument("--overlap", type=int, default=None, help="override windowOverlap (128 => the hop-128 variant)")
     ap.add_argument("--workload", default="sample", choices=["sample", "config3", "config5"])
     ap.add_argument("--engine", type=int, default=0, help="0 auto, 1 generic, 2 fused")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--force-gather", action="store_true", help="run the flag exchange even with one rank (rehearsal of the multi-GPU step)")
     args = ap.parse_args()
 
@@ -94,11 +109,13 @@ def main():
     import torch.distributed as dist
     import syllable_detector_swift_amd as sd
     from syllable_detector_swift_amd import nets, synth
+    from syllable_detector_swift_amd.dist import PipelinedFlagGather, gather_flags, shard_channels
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 or args.force_gather:
+    exchange = world > 1 or args.force_gather
+    if exchange:
         torch.cuda.set_device(local_rank)
         if world == 1:                                   # rehearsal: a one-rank RCCL group
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -110,39 +127,54 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
+    multi = exchange                                     # the multi-GPU step (or its one-rank rehearsal): configs[3]'s shape
     if args.workload == "config3":
         cfg = nets.config3()
-        C, S = (512 if args.channels == 64 else args.channels), 1 << (21 if args.log2_samples == 24 else args.log2_samples)
-        name = "BASELINE configs[2]: 1024-pt FFT hop 256, synthetic 1160-4-1 network"
+        C = args.channels or 512
+        S = 1 << (args.log2_samples or 21)
+        name = "BASELINE configs[2]: 1024-pt FFT hop 256, 512 channels, synthetic 1160-4-1 network"
     elif args.workload == "config5":
         cfg = nets.wide_mlp(nets.from_npz())
-        C, S = args.channels, 1 << args.log2_samples
+        C = args.channels or 64
+        S = 1 << (args.log2_samples or 24)
         name = "BASELINE configs[4]: sample.txt front end, 290 -> 4096 TanSig -> 1 network, bf16 MFMA GEMM"
         if args.engine == 0:
             args.engine = 3                      # the wide engine is opt-in (bf16 numerics)
     else:
         cfg = nets.from_npz()
-        C, S = args.channels, 1 << args.log2_samples
-        name = "BASELINE configs[1]: sample.txt network, 256-pt FFT, Hamming"
+        C = args.channels or (512 if multi else 64)
+        S = 1 << (args.log2_samples or (21 if multi else 24))
+        name = ("BASELINE configs[3]: sample.txt network, 4096 channels sharded across 8 MI355X (512 x 2^21 samples per GPU), "
+                "RCCL gather of detection flags" if multi else "BASELINE configs[1]: sample.txt network, 64 synthetic channels on 1 MI355X, 256-pt FFT, Hamming")
     if args.overlap is not None:
         cfg = nets.variant(cfg, windowOverlap=args.overlap)
+    scaling, first = "weak", rank * C
+    total = world * C
+    if args.total_channels is not None:                  # strong scaling: a fixed bank sharded over the ranks
+        scaling, total = "strong", args.total_channels
+        first, C = shard_channels(total, world, rank)
+        assert C > 0, "fewer channels than ranks"
 
-    from syllable_detector_swift_amd.dist import PipelinedFlagGather
     det = sd.SyllableDetector(cfg, channels=C, device=local_rank, engine=args.engine)
     g = det.geometry
     J, E = det.countFrames(S), det.countEvaluations(S)
-    x = synth.channels_on_device(C, S, dev, first=rank * C, fs=cfg.samplingRate)
+    x = synth.channels_on_device(C, S, dev, first=first, fs=cfg.samplingRate)
     outputs = torch.empty((C, E, g.outputs), dtype=torch.float32, device=dev)
     flags = torch.empty((C, E), dtype=torch.uint8, device=dev)
     det.profile(True)
-    # ONE collective per batch: [world*C, E] u8 flags on every rank, as bits; the exchange of batch i runs on a side stream
-    # under the kernel of batch i+1 (the timed region ends with every exchange finished: torch.cuda.synchronize below)
-    gather = PipelinedFlagGather(C, E, world * C, dev) if (world > 1 or args.force_gather) else None
+    # ONE collective per batch: [total, E] u8 flags on every rank, as bits; with equal shards the exchange of batch i runs on
+    # a side stream under the kernel of batch i+1 (the timed region ends with every exchange finished: synchronize below)
+    equal = total == world * C
+    gather = PipelinedFlagGather(C, E, total, dev) if (exchange and equal) else None
+    gathered = None
 
     def step():
+        nonlocal gathered
         det.run(x, outputs, flags)
         if gather is not None:
             gather.submit(flags)
+        elif exchange:
+            gathered = gather_flags(flags, total)        # ragged shards: the padded form, on the compute stream
 
     for _ in range(args.warmup):
         step()
@@ -162,13 +194,15 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    frames_local = torch.tensor([float(C * J)], dtype=torch.float64, device=dev)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-
-    frames_per_step = world * C * J
+        dist.all_reduce(frames_local, op=dist.ReduceOp.SUM)
+    frames_per_step = int(frames_local.item())
     value = frames_per_step * args.steps / elapsed
+    fixups, fix_overflow = det.fixupStats()
 
     if rank == 0:
         # algorithmic bytes per frame: unique input bytes + fp32 outputs + 1 flag byte
@@ -178,24 +212,36 @@ def main():
         # the dominant kernel's launch covers C*J frames of this rank; when the path is split over
         # several kernels each is charged the whole frame's algorithmic bytes (none moves fewer)
         achieved = C * J * b_frame / (means[dom] * 1e-3) / 1e9
+        traffic, traffic_source = measured_traffic(C, S, g.hop, {1: "generic", 2: "fused"}.get(g.engine, ""), dom)
+        engine_name = {1: "generic", 2: "fused", 3: "wide_bf16"}.get(g.engine, str(g.engine))
         line = {
             "metric": {"sample": "audio frames/sec (256-pt STFT + 2-layer MLP), whole job",
                        "config3": "audio frames/sec (1024-pt STFT + 2-layer MLP), whole job",
                        "config5": "audio frames/sec (256-pt STFT + 4096-hidden MLP as bf16 MFMA GEMM), whole job"}[args.workload],
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": scaling,
+            "vs_baseline": None,
+            # what the path computes in: fp32 in and out, fp32 accumulation; the DFT and first-layer products run on the matrix
+            # cores as three f16 x f16 products of hi/lo-split operands (2^-22 relative) under power-of-two block scales
+            "dtype": "f32 (I/O and accumulate; products as f16 hi/lo split x3 on MFMA)" if g.engine == 2 else "f32",
+            "data": "synthetic",
             "per_gpu": value / world,
-            "config": {"workload": name, "channels_per_gpu": C, "samples_per_channel": S, "frames_per_channel": J,
+            "config": {"workload": name, "channels_per_gpu": C, "total_channels": total, "samples_per_channel": S, "frames_per_channel": J,
                        "evaluations_per_channel": E, "fourier_length": cfg.fourierLength, "hop": g.hop,
-                       "bins": [g.f0, g.f1], "time_range": cfg.timeRange, "engine": {1: "generic", 2: "fused", 3: "wide_bf16"}.get(g.engine, str(g.engine)),
-                       "sharding": "channels, %d per GPU; one all-gather of flags (as bits) per step, on a side stream under the next step's kernel" % C if world > 1 else "single GPU"},
+                       "bins": [g.f0, g.f1], "time_range": cfg.timeRange, "engine": engine_name,
+                       "sharding": ("contiguous channel blocks, %d on this rank of %d; no data-path collective; one all-gather of flags (as bits) per step%s"
+                                    % (C, total, ", on a side stream under the next step's kernel" if gather is not None else "")) if exchange else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic(C, S, g.hop, {1: "generic", 2: "fused"}.get(g.engine, ""), dom),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": C * J * b_frame,
                          "algorithmic_bytes_per_frame": b_frame, "kernel_ms": means},
+            "fixups": {"work_items_last_step": fixups, "overflow": fix_overflow,
+                       "note": "16-evaluation items the precision guard sent to the exact fp64 recomputation (0 for ordinary audio)"},
         }
+        if exchange:
+            line["rccl_ranks"] = dist.get_world_size()
+            line["gathered_flags_shape"] = [total, E]
+            line["gathered_bytes_per_rank_per_step"] = C * ((E + 7) // 8) if gather is not None else C * E
         if g.engine == 3:
             # the wide engine's roof is the bf16 matrix pipe: flops of the two layers per evaluation
             L = cfg.net.layers
@@ -203,8 +249,19 @@ def main():
             tf = C * E * f_frame / (means["wide_gemm_kernel"] * 1e-3) / 1e12
             line["dtype"] = "bf16"
             line["roofline"] = {"bound": "mfma", "kernel": "wide_gemm_kernel", "achieved": tf, "peak": MFMA_BF16_PEAK_TFLOPS,
-                                "unit": "TFLOP/s", "frac": tf / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                                "unit": "TFLOP/s", "frac": tf / MFMA_BF16_PEAK_TFLOPS, "traffic": None, "traffic_source": None,
                                 "algorithmic_flops_per_launch": C * E * f_frame, "algorithmic_flops_per_frame": f_frame, "kernel_ms": means}
+        if not args.no_verify:
+            # the last timed step's results against the oracle's fp64 anchor where a tiling bug would show (tests/spotcheck.py);
+            # the bf16 engine at its own, separately stated bar
+            import spotcheck
+            try:
+                line["verify"] = spotcheck.check(det, cfg, x, outputs, flags, sorted({0, max(C // 2 - 1, 0), C - 1}),
+                                                 tol=1e-2 if g.engine == 3 else 1e-5)
+                line["verified"] = True
+            except AssertionError as e:
+                line["verified"] = False
+                line["verify"] = {"error": str(e)[:400]}
         if world == 1 and not args.no_cpu_baseline:
             # the boundary also takes host buffers (syldet_run): H2D + kernel + D2H, pageable memory, bounded sample.
             # Reported beside the headline, never as `value`.
@@ -227,7 +284,7 @@ def main():
                 line["cpu_baseline_all_cores"] = cpu_baseline(cfg, host, threads=ncpu)
         print(json.dumps(line), flush=True)
     det.close()
-    if world > 1 or args.force_gather:
+    if exchange:
         dist.destroy_process_group()
 
 

@@ -222,6 +222,10 @@ int syldet_last_timings(syldet_t *h, double *milliseconds, const char **names, i
  * (0 for ordinary audio), *overflow = 1 if a work list was ever too small (never, by construction).  Blocks; call it after
  * the stream the batch call ran on has been synchronised.  No reference counterpart (diagnostic).                       */
 int syldet_fixup_stats(syldet_t *h, int64_t *items, int32_t *overflow);
+/* How the batch call tiles a channel for n_samples per channel: evaluations per workgroup segment of the fused kernels
+ * (consecutive segments of a channel are computed by different workgroups; 0: the engine in use has no such seams).
+ * Results do not depend on it; verification uses it to aim spot checks at the seams.  No reference counterpart.          */
+int64_t syldet_segment_evals(const syldet_t *h, int64_t n_samples);
 
 /* ---- streaming: the reference's per-detector API, one call per channel ----
  * Each channel owns a single-producer / single-consumer sample ring like the reference's

@@ -70,51 +70,69 @@ def build(force: bool = False) -> str:
     return LIB_PATH
 
 
+def build_native() -> str:
+    """The same source at -O3 -march=native, built on the machine that runs it (the timed CPU baseline of bench.py)."""
+    path = os.path.join(os.path.dirname(LIB_PATH), "libsyldet_oracle_native.so")
+    subprocess.run(["make", "-B", "-C", _HERE, "CC=gcc", "native"], check=True, stdout=subprocess.DEVNULL)
+    return path
+
+
 _lib = None
+_lib_native = None
 
 
-def lib():
-    global _lib
+def lib(native: bool = False):
+    global _lib, _lib_native
+    if native:
+        if _lib_native is None:
+            _lib_native = _load(build_native())
+        return _lib_native
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             build()
-        L = C.CDLL(LIB_PATH)
-        cp = C.POINTER(_Config)
-        L.orc_geometry.argtypes = [cp, C.POINTER(_Geom)]
-        L.orc_window.argtypes = [C.c_int, C.c_int, _f32p]
-        L.orc_window.restype = None
-        L.orc_frequency_index_range.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double,
-                                                C.POINTER(C.c_int), C.POINTER(C.c_int)]
-        L.orc_count_frames.argtypes = [cp, C.c_int64]
-        L.orc_count_frames.restype = C.c_int64
-        L.orc_count_evals.argtypes = [cp, C.c_int64]
-        L.orc_count_evals.restype = C.c_int64
-        L.orc_stft_frame.argtypes = [cp, _f32p, C.c_int, _f64p]
-        L.orc_spectrogram.argtypes = [cp, _f32p, C.c_int64, C.c_int, _f64p]
-        L.orc_spectrogram.restype = C.c_int64
-        L.orc_net_apply.argtypes = [cp, _f32p, C.c_int, _f64p]
-        L.orc_run.argtypes = [cp, _f32p, C.c_int64, C.c_int, C.c_int, _f32p, _u8p, _f64p]
-        L.orc_run.restype = C.c_int64
-        L.orc_detections.argtypes = [cp, _u8p, C.c_int64, C.c_double, _i64p, C.c_int64]
-        L.orc_detections.restype = C.c_int64
-        L.orc_stream_create.argtypes = [cp, C.c_int]
-        L.orc_stream_create.restype = C.c_void_p
-        L.orc_stream_destroy.argtypes = [C.c_void_p]
-        L.orc_stream_destroy.restype = None
-        L.orc_stream_append.argtypes = [C.c_void_p, _f32p, C.c_int64]
-        L.orc_stream_process_new_value.argtypes = [C.c_void_p]
-        L.orc_stream_last_outputs.argtypes = [C.c_void_p, _f32p]
-        L.orc_stream_last_outputs.restype = None
-        L.orc_stream_last_detected.argtypes = [C.c_void_p]
-        L.orc_stream_seen_syllable.argtypes = [C.c_void_p]
-        L.orc_resampler_init.argtypes = [C.POINTER(_Resampler), C.c_double, C.c_double]
-        L.orc_resampler_init.restype = None
-        L.orc_resampler_count.argtypes = [C.POINTER(_Resampler), C.c_int64]
-        L.orc_resampler_count.restype = C.c_int64
-        L.orc_resampler_run.argtypes = [C.POINTER(_Resampler), _f32p, C.c_int64, _f32p]
-        L.orc_resampler_run.restype = C.c_int64
-        _lib = L
+        _lib = _load(LIB_PATH)
     return _lib
+
+
+def _load(path: str):
+    L = C.CDLL(path)
+    cp = C.POINTER(_Config)
+    L.orc_geometry.argtypes = [cp, C.POINTER(_Geom)]
+    L.orc_window.argtypes = [C.c_int, C.c_int, _f32p]
+    L.orc_window.restype = None
+    L.orc_frequency_index_range.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double,
+                                            C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.orc_count_frames.argtypes = [cp, C.c_int64]
+    L.orc_count_frames.restype = C.c_int64
+    L.orc_count_evals.argtypes = [cp, C.c_int64]
+    L.orc_count_evals.restype = C.c_int64
+    L.orc_stft_frame.argtypes = [cp, _f32p, C.c_int, _f64p]
+    L.orc_spectrogram.argtypes = [cp, _f32p, C.c_int64, C.c_int, _f64p]
+    L.orc_spectrogram.restype = C.c_int64
+    L.orc_net_apply.argtypes = [cp, _f32p, C.c_int, _f64p]
+    L.orc_run.argtypes = [cp, _f32p, C.c_int64, C.c_int, C.c_int, _f32p, _u8p, _f64p]
+    L.orc_run.restype = C.c_int64
+    L.orc_detections.argtypes = [cp, _u8p, C.c_int64, C.c_double, _i64p, C.c_int64]
+    L.orc_detections.restype = C.c_int64
+    L.orc_stream_create.argtypes = [cp, C.c_int]
+    L.orc_stream_create.restype = C.c_void_p
+    L.orc_stream_destroy.argtypes = [C.c_void_p]
+    L.orc_stream_destroy.restype = None
+    L.orc_stream_append.argtypes = [C.c_void_p, _f32p, C.c_int64]
+    L.orc_stream_process_new_value.argtypes = [C.c_void_p]
+    L.orc_stream_last_outputs.argtypes = [C.c_void_p, _f32p]
+    L.orc_stream_last_outputs.restype = None
+    L.orc_stream_last_detected.argtypes = [C.c_void_p]
+    L.orc_stream_seen_syllable.argtypes = [C.c_void_p]
+    L.orc_resampler_init.argtypes = [C.POINTER(_Resampler), C.c_double, C.c_double]
+    L.orc_resampler_init.restype = None
+    L.orc_resampler_count.argtypes = [C.POINTER(_Resampler), C.c_int64]
+    L.orc_resampler_count.restype = C.c_int64
+    L.orc_resampler_run.argtypes = [C.POINTER(_Resampler), _f32p, C.c_int64, _f32p]
+    L.orc_resampler_run.restype = C.c_int64
+    L.orc_stream_run.argtypes = [cp, C.c_int, _f32p, C.c_int64, C.c_int64, _f32p, _u8p]
+    L.orc_stream_run.restype = C.c_int64
+    return L
 
 
 # ------------------------------------------------------------------ network description
@@ -270,6 +288,18 @@ class Oracle:
             lib().orc_run(C.byref(self.c), s.ctypes.data_as(_f32p), s.size, precision, rule,
                           out.ctypes.data_as(_f32p), fl.ctypes.data_as(_u8p), o64.ctypes.data_as(_f64p))
         return out, fl, o64
+
+    def stream_run(self, samples: np.ndarray, precision: int = F32, chunk: int = 8192, native: bool = False, keep: bool = True):
+        """The reference's consumer loop, frame at a time through its two rings (orc_stream_run): -> (outputs f32, flags u8),
+        or the number of evaluations when keep is False (timing)."""
+        s = np.ascontiguousarray(samples, np.float32)
+        E = max(self.count_evals(s.size), 0)
+        out = np.zeros((E, self.n_out), np.float32) if keep else None
+        fl = np.zeros(E, np.uint8) if keep else None
+        n = lib(native).orc_stream_run(C.byref(self.c), precision, s.ctypes.data_as(_f32p), s.size, chunk,
+                                       out.ctypes.data_as(_f32p) if keep else None, fl.ctypes.data_as(_u8p) if keep else None)
+        assert n == E, (n, E)
+        return (out, fl) if keep else n
 
     def detections(self, flags: np.ndarray, debounce: float = 0.0) -> np.ndarray:
         f = np.ascontiguousarray(flags, np.uint8)

@@ -563,9 +563,13 @@ static int ring_produce_bytes(ring_t *r, const void *src, int32_t len)   /* .h:1
 {
     if (r->length - r->fill < len) return 0;
     const uint8_t *s = (const uint8_t *)src;
-    for (int32_t i = 0; i < len; i++) {
-        int32_t p = (r->head + i) % r->length;
-        r->buf[p] = s[i]; r->buf[p + r->length] = s[i];
+    /* one memcpy into the ring (.h:181; the mirrored mapping makes a write past the end land at the start) + the mirror */
+    int32_t first = r->length - r->head < len ? r->length - r->head : len;
+    memcpy(r->buf + r->head, s, (size_t)first);
+    memcpy(r->buf + r->head + r->length, s, (size_t)first);
+    if (len > first) {
+        memcpy(r->buf, s + first, (size_t)(len - first));
+        memcpy(r->buf + r->length, s + first, (size_t)(len - first));
     }
     r->head = (r->head + len) % r->length;
     r->fill += len;
@@ -684,6 +688,28 @@ int orc_stream_seen_syllable(orc_stream_t *s)                              /* :2
     int ret = 0;
     while (orc_stream_process_new_value(s) == 1) if (orc_stream_last_detected(s)) ret = 1;
     return ret;
+}
+
+/* The reference's whole consumer loop for one channel, frame at a time (TrackDetector.process,
+ * SyllableDetectorCLI/TrackDetector.swift:45-105: append a decoded sample buffer, then `while detector.processNewValue()`),
+ * with `chunk` samples per buffer.  outputs [E][n_out] / flags [E] may be NULL (timing runs).  Returns E.               */
+int64_t orc_stream_run(const orc_config_t *c, int precision, const float *samples, int64_t S, int64_t chunk,
+                       float *outputs, uint8_t *flags)
+{
+    orc_stream_t *s = orc_stream_create(c, precision);
+    if (!s) return -1;
+    int64_t e = 0;
+    for (int64_t pos = 0; pos < S; pos += chunk) {
+        int64_t n = S - pos < chunk ? S - pos : chunk;
+        if (orc_stream_append(s, samples + pos, n) != 0) { orc_stream_destroy(s); return -2; }
+        while (orc_stream_process_new_value(s) == 1) {
+            if (outputs) memcpy(outputs + e * s->g.n_out, s->last, sizeof(float) * (size_t)s->g.n_out);
+            if (flags) flags[e] = (uint8_t)orc_stream_last_detected(s);
+            e++;
+        }
+    }
+    orc_stream_destroy(s);
+    return e;
 }
 
 /* ------------------------------------------------------------------ resampler */

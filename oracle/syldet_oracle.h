@@ -114,6 +114,9 @@ int orc_stream_process_new_value(orc_stream_t *s);                      /* 1/0  
 void orc_stream_last_outputs(const orc_stream_t *s, float *out);
 int orc_stream_last_detected(const orc_stream_t *s);
 int orc_stream_seen_syllable(orc_stream_t *s);
+/* the whole consumer loop of one channel, `chunk` samples per appended buffer (TrackDetector.swift:45-105); returns E */
+int64_t orc_stream_run(const orc_config_t *c, int precision, const float *samples, int64_t S, int64_t chunk,
+                       float *outputs, uint8_t *flags);
 
 /* ResamplerLinear, Common/Resampler.swift:20-76 */
 typedef struct { float step, last, offset; } orc_resampler_t;

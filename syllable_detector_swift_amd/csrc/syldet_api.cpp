@@ -773,6 +773,17 @@ int syldet_fixup_stats(syldet_t *h, int64_t *items, int32_t *overflow)
     return SYLDET_OK;
 }
 
+int64_t syldet_segment_evals(const syldet_t *h, int64_t n_samples)
+{
+    if (!h || h->engine != SYLDET_ENGINE_FUSED) return 0;
+    const int64_t E = count_evals(h, n_samples);
+    if (E <= 0) return 0;
+    FusedDesc d = h->fused.desc;
+    fused_segmentation(d, E, h->channels);
+    const bool r = fused_r_applicable(d) && (!std::getenv("SYLDET_FUSED_CLASSIC") || !d.classic_ok);
+    return r ? d.r_seg_evals : d.seg_evals;
+}
+
 int64_t syldet_count_frames(const syldet_t *h, int64_t n_samples) { return h ? count_frames(h, n_samples) : -1; }
 int64_t syldet_count_evals(const syldet_t *h, int64_t n_samples) { return h ? count_evals(h, n_samples) : -1; }
 

@@ -218,6 +218,10 @@ class SyllableDetector:
         check(_abi.lib.syldet_fixup_stats(self._h, C.byref(items), C.byref(over)))
         return int(items.value), int(over.value)
 
+    def segmentEvaluations(self, n_samples: int) -> int:
+        """Evaluations per workgroup segment of the fused kernels for a batch of this length (0: no seams)."""
+        return int(_abi.lib.syldet_segment_evals(self._h, int(n_samples)))
+
     # ---- batch, host arrays -------------------------------------------------------
     def runHost(self, samples: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
         a = np.ascontiguousarray(samples, dtype=np.float32).reshape(self.channels, -1)

@@ -148,7 +148,13 @@ class ShardedSyllableDetector:
         self.first, self.count = shard_channels(self.total_channels, self.world, self.rank)
         if self.count == 0:
             raise ValueError("fewer channels than ranks: shard by time with a (T-1)*hop + W - hop halo instead")
-        self.detector = SyllableDetector(config, channels=self.count, device=0 if device is None else device, engine=engine)
+        if device is None:
+            # one process per GPU: under torch.distributed.run every rank sees every GPU and owns the one of its LOCAL_RANK
+            import os
+            import torch
+            device = int(os.environ["LOCAL_RANK"]) if "LOCAL_RANK" in os.environ else torch.cuda.current_device()
+        self.device = int(device)
+        self.detector = SyllableDetector(config, channels=self.count, device=self.device, engine=engine)
 
     def run(self, local_samples, gather: bool = True):
         """local_samples: this rank's [count, S] block.  Returns (outputs_local, flags) where flags is

@@ -362,3 +362,37 @@ def test_pipelined_gather_over_rccl_single_rank(tmp_path):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29592", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
+def test_sharded_detector_over_rccl_single_rank(tmp_path):
+    """ShardedSyllableDetector -- this rank's share of a bank on the GPU of its LOCAL_RANK, run + the one gather of flags --
+    through a real RCCL group of one rank, against a plain SyllableDetector over the same channels."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "sharded1.py"
+    script.write_text(
+        "import os, sys, numpy as np, torch, torch.distributed as dist\n"
+        "sys.path[:0] = [%r, %r, %r]\n"
+        "import util\n"
+        "import syllable_detector_swift_amd as sd\n"
+        "from syllable_detector_swift_amd import synth\n"
+        "from syllable_detector_swift_amd.dist import ShardedSyllableDetector\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group(backend='nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))\n"
+        "cfg = util.sample_net()\n"
+        "x = torch.from_numpy(np.stack([synth.syllable_channel(60000, util.template(), seed=c) for c in range(5)])).cuda()\n"
+        "bank = ShardedSyllableDetector(cfg, total_channels=5)          # device from LOCAL_RANK\n"
+        "assert (bank.first, bank.count, bank.device) == (0, 5, 0)\n"
+        "out, fl = bank.run(x)\n"
+        "with sd.SyllableDetector(cfg, channels=5) as det:\n"
+        "    out2, fl2 = det.run(x)\n"
+        "torch.cuda.synchronize()\n"
+        "assert torch.equal(out, out2) and torch.equal(fl, fl2) and int(fl.sum()) > 0\n"
+        "bank.close()\n"
+        "dist.destroy_process_group()\n"
+        "print('ok')\n" % (root, os.path.join(root, "oracle"), os.path.join(root, "tests")))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29594", HSA_ENABLE_IPC_MODE_LEGACY="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]

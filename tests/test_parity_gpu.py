@@ -261,6 +261,41 @@ def test_full_size_properties():
         assert torch.equal(out4, out[perm])
 
 
+@pytest.mark.parametrize("C,log2S,kernel", [(64, 24, "fused_r_kernel"), (64, 24, "fused_kernel"), (512, 21, "fused_r_kernel")])
+def test_benchmark_size_against_the_oracle(oracle_lib, monkeypatch, C, log2S, kernel):
+    """The sizes the headline is quoted on -- BASELINE configs[1] (64 channels x 2^24 samples) and the per-GPU shape of
+    configs[3] (512 x 2^21) -- against the oracle where a tiling bug would show (tests/spotcheck.py): head and tail of the
+    first, a middle and the last channel, both sides of the seams between workgroup segments.  Syllables are planted in the
+    checked stretches, so flags fire there (the BASELINE audio model alone never triggers the example network)."""
+    import spotcheck
+    torch = _torch()
+    if kernel == "fused_kernel":
+        monkeypatch.setenv("SYLDET_FUSED_CLASSIC", "1")
+    else:
+        monkeypatch.delenv("SYLDET_FUSED_CLASSIC", raising=False)
+    cfg = util.sample_net()
+    S = 1 << log2S
+    x = synth.channels_on_device(C, S, "cuda")
+    chans = [0, C // 2 - 1, C - 1]
+    with sd.SyllableDetector(cfg, channels=C) as det:
+        E, seg = det.countEvaluations(S), det.segmentEvaluations(S)
+        assert seg > 0
+        syl = torch.from_numpy(synth.syllable_channel(30000, util.template(), seed=3)).cuda()
+        for c in chans:
+            for e0, e1 in spotcheck.stretches(E, seg):
+                at = min(e0 * 132, S - syl.numel())
+                x[c, at:at + syl.numel()] = syl
+        det.profile(True)
+        out, fl = det.run(x)
+        torch.cuda.synchronize()
+        assert [nm for nm, _ in det.lastTimings()] == [kernel]
+        assert det.fixupStats() == (0, 0)                       # ordinary audio never reaches the slow path
+        res = spotcheck.check(det, cfg, x, out, fl, chans)
+        assert res["evaluations_checked"] >= 3 * 3 * 150 and res["segment_evaluations"] == seg
+        assert int(fl[chans].sum().item()) > 0, "planted syllables must be detected"
+        assert torch.isfinite(out).all()
+
+
 def test_cpp_mirror_of_the_swift_surface(oracle_lib, tmp_path):
     """include/syldet.hpp (SyllableDetectorConfig(fromTextFile:), SyllableDetector.appendAudioData /
     processNewValue / lastOutputs / lastDetected, bank.run, detections) driven from a C++ program."""
