@@ -297,6 +297,16 @@ int syldet_resample_device(syldet_resampler_t *r, const float *d_in, int64_t n_i
 int syldet_resample(syldet_resampler_t *r, const float *in, int64_t n_in, int64_t in_stride, float *out,
                     int64_t out_stride, int64_t *n_out);
 
+/* Whole-recording rate conversion for offline input.  The reference's command line tool never resamples itself: it asks
+ * AVFoundation to deliver every track at the network's rate (audioSettings, SyllableDetector.swift:19-23, handed to
+ * AVAssetReaderTrackOutput at TrackDetector.swift:35).  This is that step for a decoded file: output sample i is the linear
+ * interpolation of the input at position i * rate_in / rate_out, the position computed in fp64 (ResamplerLinear above is a
+ * streaming object for short live buffers: its fp32 position ramp and its buffer carry are not meant for minutes of audio
+ * in one call).  Stateless.  in [C][in_stride] -> out [C][out_stride]; *n_out = syldet_convert_rate_count(n_in, ...).    */
+int64_t syldet_convert_rate_count(int64_t n_in, double rate_in, double rate_out);
+int syldet_convert_rate_device(const float *d_in, int64_t n_in, int64_t in_stride, int32_t n_channels, double rate_in,
+                               double rate_out, float *d_out, int64_t out_stride, int64_t *n_out, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,11 +7,13 @@
 //  TPCircularBuffer.h: one more line in Common/Common-Bridging-Header.h (#include "syldet.h").
 //
 //  Not compiled in this repository (no Swift toolchain in the build image); INTEGRATION.md shows where
-//  it goes.  One SyllableDetector here owns a one-channel bank; Processor-style callers that hold many
+//  it goes.  Every member the reference's callers touch is here: init(config:), config, audioSettings,
+//  processSampleBuffer, captureOutput, appendAudioData, processNewValue, lastOutputs, lastDetected, seenSyllable.  One SyllableDetector here owns a one-channel bank; Processor-style callers that hold many
 //  channels should create one bank for all of them (see SyllableDetectorBank below) so that a batch of
 //  channels is a single kernel launch.
 
 import Foundation
+import AVFoundation
 
 final class SyllableDetectorBank {
     let handle: OpaquePointer
@@ -43,10 +45,18 @@ final class SyllableDetectorBank {
     }
 }
 
-class SyllableDetector: NSObject {
+class SyllableDetector: NSObject, AVCaptureAudioDataOutputSampleBufferDelegate {
     let config: SyllableDetectorConfig
     private let bank: SyllableDetectorBank
     private let channel: Int32
+
+    // the reference's reader settings, unchanged: Float32, non-interleaved, at the network's rate (:19-23; used by
+    // TrackDetector.swift:35 and ViewControllerSimulator.swift:176)
+    var audioSettings: [String: AnyObject] {
+        get {
+            return [AVFormatIDKey: NSNumber(value: kAudioFormatLinearPCM), AVLinearPCMBitDepthKey: NSNumber(value: 32), AVLinearPCMIsFloatKey: true as AnyObject, AVLinearPCMIsNonInterleaved: true as AnyObject, AVSampleRateKey: NSNumber(value: config.samplingRate)]
+        }
+    }
 
     var lastOutputs: [Float] {
         var out = [Float](repeating: 0.0, count: Int(bank.geometry.outputs))
@@ -73,6 +83,32 @@ class SyllableDetector: NSObject {
         if syldet_append(bank.handle, channel, data, Int64(numSamples)) != 0 {
             fatalError("Insufficient space on buffer.")      // CircularShortTimeFourierTransform.swift:199
         }
+    }
+
+    /// Common/SyllableDetector.swift:81-119: the same format checks, then the samples go to this channel's ring
+    /// (callers: TrackDetector.swift:62, ViewControllerSimulator.swift:292)
+    func processSampleBuffer(_ sampleBuffer: CMSampleBuffer) {
+        let numSamples = CMSampleBufferGetNumSamples(sampleBuffer)
+        guard 0 < numSamples else { return }
+        guard let format = CMSampleBufferGetFormatDescription(sampleBuffer) else { return }
+        let audioDescription = CMAudioFormatDescriptionGetStreamBasicDescription(format)
+        let isInterleaved = 1 < (audioDescription?[0].mChannelsPerFrame)! && 0 == ((audioDescription?[0].mFormatFlags)! & kAudioFormatFlagIsNonInterleaved)
+        let isFloat = 0 < ((audioDescription?[0].mFormatFlags)! & kAudioFormatFlagIsFloat)
+        guard audioDescription?[0].mFormatID == kAudioFormatLinearPCM && isFloat && !isInterleaved && audioDescription?[0].mBitsPerChannel == 32 else {
+            fatalError("Invalid audio format.")
+        }
+        guard let audioBuffer = CMSampleBufferGetDataBuffer(sampleBuffer) else { return }
+        var lengthAtOffset: Int = 0, totalLength: Int = 0
+        var inSamples: UnsafeMutablePointer<Int8>? = nil
+        CMBlockBufferGetDataPointer(audioBuffer, 0, &lengthAtOffset, &totalLength, &inSamples)
+        inSamples!.withMemoryRebound(to: Float.self, capacity: numSamples) {
+            appendAudioData($0, withSamples: numSamples)
+        }
+    }
+
+    /// :121-124 (AVCaptureAudioDataOutputSampleBufferDelegate)
+    func captureOutput(_ captureOutput: AVCaptureOutput, didOutput sampleBuffer: CMSampleBuffer, from connection: AVCaptureConnection) {
+        processSampleBuffer(sampleBuffer)
     }
 
     func processNewValue() -> Bool { return syldet_process_new_value(bank.handle, channel) == 1 }

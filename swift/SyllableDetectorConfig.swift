@@ -2,9 +2,18 @@
 //
 //  Keeps the stored fields and init(fromTextFile:) throws of Common/SyllableDetectorConfig.swift:11-45,
 //  :170-277; the text format is parsed by libsyldet (syldet_config_load_text) and ParseError keeps its
-//  four cases (:50-55).  Not compiled in this repository.
+//  four cases (:50-55).  `net` keeps the two members the rest of the project reads (inputs, outputs:
+//  Common/SyllableDetector.swift:53-59,70); the network itself lives in the library.
+//  Not compiled in this repository (no Swift toolchain in the build image).
 
 import Foundation
+
+/// Owns the C configuration syldet_config_load_text returned; freed with the last copy of the struct that refers to it.
+final class SyldetConfigBox {
+    let pointer: UnsafeMutablePointer<syldet_config_t>
+    init(_ p: UnsafeMutablePointer<syldet_config_t>) { pointer = p }
+    deinit { syldet_config_free(pointer) }
+}
 
 struct SyllableDetectorConfig {
     enum Scaling { case linear, log, db }
@@ -13,6 +22,11 @@ struct SyllableDetectorConfig {
         case missingValue(String)
         case invalidValue(String)
         case mismatchedLength(String)
+    }
+    /// What callers read of the reference's NeuralNet (Common/NeuralNet.swift:232-238)
+    struct Net {
+        let inputs: Int
+        let outputs: Int
     }
 
     let samplingRate: Double
@@ -23,7 +37,8 @@ struct SyllableDetectorConfig {
     let timeRange: Int
     let spectrogramScaling: Scaling
     let thresholds: [Double]
-    private let owned: UnsafeMutablePointer<syldet_config_t>     // freed by the owning class wrapper in real use
+    let net: Net
+    private let owned: SyldetConfigBox
 
     init(fromTextFile path: String) throws {
         var p: UnsafeMutablePointer<syldet_config_t>? = nil
@@ -37,7 +52,7 @@ struct SyllableDetectorConfig {
             default: throw ParseError.invalidValue(msg)
             }
         }
-        owned = c
+        owned = SyldetConfigBox(c)
         samplingRate = c.pointee.sampling_rate
         fourierLength = Int(c.pointee.fourier_length)
         windowLength = Int(c.pointee.window_length)
@@ -46,7 +61,9 @@ struct SyllableDetectorConfig {
         timeRange = Int(c.pointee.time_range)
         spectrogramScaling = [Scaling.linear, .log, .db][Int(c.pointee.scaling)]
         thresholds = Array(UnsafeBufferPointer(start: c.pointee.thresholds, count: Int(c.pointee.n_thresholds)))
+        let layers = UnsafeBufferPointer(start: c.pointee.layers, count: Int(c.pointee.n_layers))
+        net = Net(inputs: Int(layers.first?.inputs ?? 0), outputs: Int(layers.last?.outputs ?? 0))
     }
 
-    func withCStruct<R>(_ body: (UnsafePointer<syldet_config_t>) -> R) -> R { return body(UnsafePointer(owned)) }
+    func withCStruct<R>(_ body: (UnsafePointer<syldet_config_t>) -> R) -> R { return body(UnsafePointer(owned.pointer)) }
 }

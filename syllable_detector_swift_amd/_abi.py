@@ -123,6 +123,8 @@ SIGNATURES = {
     "syldet_resampler_destroy": (C.c_int, [Handle]),
     "syldet_resampler_count": (C.c_int64, [Handle, C.c_int64]),
     "syldet_resample_device": (C.c_int, [Handle, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, c_int64_p, C.c_void_p]),
+    "syldet_convert_rate_count": (C.c_int64, [C.c_int64, C.c_double, C.c_double]),
+    "syldet_convert_rate_device": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_double, C.c_double, C.c_void_p, C.c_int64, c_int64_p, C.c_void_p]),
     "syldet_resample": (C.c_int, [Handle, c_float_p, C.c_int64, C.c_int64, c_float_p, C.c_int64, c_int64_p]),
 }
 

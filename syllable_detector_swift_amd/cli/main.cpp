@@ -3,12 +3,12 @@
 //     channel,sample,seconds,out0[,out1...]
 // one per detection event (any output at or above its threshold, TrackDetector.swift:72-77; debounce
 // :80,:99), a line with the file name first when more than one file is given (main.swift:122-124).
-// All tracks of a file are one batch on the GPU: decode -> H2D -> de-interleave [-> ResamplerLinear when the
+// All tracks of a file are one batch on the GPU: decode -> H2D -> de-interleave [-> rate conversion when the
 // file's rate differs from the network's] -> fused STFT + network kernel -> flags/outputs -> host.
 //
 // Differences a user can see: the reference decodes anything AVFoundation can, this tool reads WAV; the
-// reference resamples through Core Audio, this tool through ResamplerLinear (Resampler.swift, the class the
-// reference's live path uses); events of different channels are interleaved buffer by buffer like the
+// reference has Core Audio deliver the network's rate (SyllableDetector.swift:19-23), this tool converts the decoded
+// file by linear interpolation with fp64 positions (syldet_convert_rate_device); events of different channels are interleaved buffer by buffer like the
 // reference's read loop (main.swift:126-130), with --chunk frames per buffer (AVAssetReader's buffer size is
 // not specified; 8192 is what it typically vends for linear PCM).
 
@@ -93,7 +93,6 @@ int process_file(const std::string &path, const syldet_config_t *cfg, int device
     const bool resample = info.rate != cfg->sampling_rate;
     int rc = 0;
     hipStream_t stream = nullptr;
-    syldet_resampler_t *rs = nullptr;
     std::vector<float> out;
     std::vector<uint8_t> flags;
     int64_t E = 0;
@@ -103,24 +102,27 @@ int process_file(const std::string &path, const syldet_config_t *cfg, int device
         DevBuf d_inter, d_planar, d_res, d_out, d_flags;
         if (!d_inter.alloc((size_t)n * C * sizeof(float))) { rc = 2; break; }
         if (hipMemcpyAsync(d_inter.p, frames.data(), (size_t)n * C * sizeof(float), hipMemcpyHostToDevice, stream) != hipSuccess) { rc = 2; break; }
-        int64_t S = n;
+        int64_t S = n, res_stride = 0;
+        int st = 0;
         if (resample) {
-            if (syldet_resampler_create(info.rate, cfg->sampling_rate, C, device, &rs)) { rc = 2; break; }
-            S = syldet_resampler_count(rs, n);
+            // The reference's tool has AVFoundation deliver every track at the network's rate (SyllableDetector.swift:19-23,
+            // TrackDetector.swift:35); here: linear interpolation of the whole decoded file with fp64 positions
+            // (syldet_convert_rate_device; ResamplerLinear is the live path's streaming object, not a file converter)
+            res_stride = syldet_convert_rate_count(n, info.rate, cfg->sampling_rate);
+            if (!d_planar.alloc((size_t)C * n * sizeof(float)) || !d_res.alloc((size_t)C * (res_stride > 0 ? res_stride : 1) * sizeof(float))) { rc = 2; break; }
+            st = syldet_deinterleave_device((const float *)d_inter.p, n, C, 0, C, (float *)d_planar.p, n, stream);
+            if (!st) st = syldet_convert_rate_device((const float *)d_planar.p, n, n, C, info.rate, cfg->sampling_rate, (float *)d_res.p, res_stride, &S, stream);
+            if (st) {
+                std::fprintf(stderr, "Unable to process %s: %s: %s\n", path.c_str(), syldet_strerror(st), syldet_last_error());
+                rc = 2;
+                break;
+            }
         }
         E = syldet_count_evals(h, S);
         if (E <= 0) break;                                  // shorter than one evaluation: no events
         if (!d_out.alloc((size_t)C * E * n_out * sizeof(float)) || !d_flags.alloc((size_t)C * E)) { rc = 2; break; }
-        int st;
-        if (!resample) {
-            st = syldet_run_interleaved_device(h, (const float *)d_inter.p, n, C, (float *)d_out.p, (uint8_t *)d_flags.p, stream);
-        } else {
-            int64_t got = 0;
-            if (!d_planar.alloc((size_t)C * n * sizeof(float)) || !d_res.alloc((size_t)C * S * sizeof(float))) { rc = 2; break; }
-            st = syldet_deinterleave_device((const float *)d_inter.p, n, C, 0, C, (float *)d_planar.p, n, stream);
-            if (!st) st = syldet_resample_device(rs, (const float *)d_planar.p, n, n, (float *)d_res.p, S, &got, stream);
-            if (!st) st = syldet_run_device(h, (const float *)d_res.p, S, S, (float *)d_out.p, (uint8_t *)d_flags.p, stream);
-        }
+        if (!resample) st = syldet_run_interleaved_device(h, (const float *)d_inter.p, n, C, (float *)d_out.p, (uint8_t *)d_flags.p, stream);
+        else st = syldet_run_device(h, (const float *)d_res.p, S, res_stride, (float *)d_out.p, (uint8_t *)d_flags.p, stream);
         if (st) {
             std::fprintf(stderr, "Unable to process %s: %s: %s\n", path.c_str(), syldet_strerror(st), syldet_last_error());
             rc = 2;
@@ -133,7 +135,6 @@ int process_file(const std::string &path, const syldet_config_t *cfg, int device
             hipStreamSynchronize(stream) != hipSuccess) { rc = 2; break; }
     } while (false);
     if (rc == 2 && hipPeekAtLastError() != hipSuccess) std::fprintf(stderr, "Unable to process %s: %s\n", path.c_str(), hipGetErrorString(hipGetLastError()));
-    if (rs) syldet_resampler_destroy(rs);
     if (stream) (void)hipStreamDestroy(stream);
     syldet_destroy(h);
     if (rc || E <= 0) return rc;

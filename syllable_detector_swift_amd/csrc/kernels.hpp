@@ -184,6 +184,9 @@ hipError_t launch_mlpx(const MlpxDesc &d, const float *columns, int C, int64_t J
 // ResamplerLinear (Common/Resampler.swift:36-69) for C channels at once; `last` is the per-channel carry on the device
 hipError_t launch_resample_linear(const float *in, int64_t n_in, int64_t in_stride, float *out, int64_t n_out,
                                   int64_t out_stride, int C, float step, float offset, float *last, hipStream_t stream);
+// whole-recording rate conversion, fp64 positions (offline input: no carry)
+hipError_t launch_convert_rate(const float *in, int64_t n_in, int64_t in_stride, float *out, int64_t n_out, int64_t out_stride,
+                               int C, double step, hipStream_t stream);
 // frame-major [n_frames][total] -> channel-major rows of channels first .. first+C-1
 hipError_t launch_deinterleave(const float *in, int64_t n_frames, int total, int first, int C, float *out,
                                int64_t out_stride, hipStream_t stream);

@@ -34,8 +34,9 @@ resample_linear_kernel(const float *__restrict__ in, int64_t n_in, int64_t in_st
     const bool across = offset < 0.0f;
     float b = offset + (float)i * step;
     if (i == 0 && across) b = 0.0f;
-    const int64_t k = (int64_t)floorf(b);
-    const float frac = b - (float)k;
+    int64_t k = (int64_t)floorf(b);
+    const float frac = b - (float)k;                // (of the unclamped position, as vDSP_vlint computes it)
+    k = k < n_in - 1 ? k : n_in - 1;                // a ramp rounded up to n_in must not read past the buffer
     const float a0 = a[k], a1 = (k + 1 < n_in) ? a[k + 1] : a0;
     float y = a0 + frac * (a1 - a0);
     if (i == 0) {
@@ -70,7 +71,35 @@ deinterleave_kernel(const float *__restrict__ in, int64_t n_frames, int total, i
         if (tid < nf) out[(int64_t)(c0 + ch) * out_stride + f0 + tid] = tile[tid][ch];
 }
 
+// Whole-recording rate conversion for offline input: output sample i reads position i * rate_in / rate_out, computed in
+// fp64 (an fp32 ramp loses half a sample after ~95 s at 44.1 kHz), linear interpolation between the two neighbours.
+// Stateless: no carry, no buffer seams.
+__global__ void __launch_bounds__(256)
+convert_rate_kernel(const float *__restrict__ in, int64_t n_in, int64_t in_stride, float *__restrict__ out, int64_t n_out,
+                    int64_t out_stride, double step)
+{
+    const int c = blockIdx.y;
+    const float *a = in + (int64_t)c * in_stride;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_out) return;
+    const double pos = (double)i * step;
+    int64_t k = (int64_t)pos;
+    k = k < n_in - 1 ? k : n_in - 1;
+    const double frac = pos - (double)k;
+    const double a0 = (double)a[k], a1 = (double)a[k + 1 < n_in ? k + 1 : k];
+    out[(int64_t)c * out_stride + i] = (float)(a0 + frac * (a1 - a0));
+}
+
 }  // namespace
+
+hipError_t launch_convert_rate(const float *in, int64_t n_in, int64_t in_stride, float *out, int64_t n_out, int64_t out_stride,
+                               int C, double step, hipStream_t stream)
+{
+    if (n_out <= 0 || C <= 0) return hipSuccess;
+    dim3 grid((unsigned)((n_out + 255) / 256), (unsigned)C);
+    hipLaunchKernelGGL(convert_rate_kernel, grid, dim3(256), 0, stream, in, n_in, in_stride, out, n_out, out_stride, step);
+    return hipGetLastError();
+}
 
 hipError_t launch_resample_linear(const float *in, int64_t n_in, int64_t in_stride, float *out, int64_t n_out,
                                   int64_t out_stride, int C, float step, float offset, float *last, hipStream_t stream)

@@ -140,6 +140,26 @@ int syldet_resample(syldet_resampler_t *r, const float *in, int64_t n_in, int64_
     return SYLDET_OK;
 }
 
+int64_t syldet_convert_rate_count(int64_t n_in, double rate_in, double rate_out)
+{
+    if (n_in <= 0 || !(rate_in > 0.0) || !(rate_out > 0.0)) return 0;
+    return (int64_t)((double)(n_in - 1) * rate_out / rate_in) + 1;       // positions i * rate_in / rate_out <= n_in - 1
+}
+
+int syldet_convert_rate_device(const float *d_in, int64_t n_in, int64_t in_stride, int32_t n_channels, double rate_in,
+                               double rate_out, float *d_out, int64_t out_stride, int64_t *n_out, void *hip_stream)
+{
+    if (n_out) *n_out = 0;
+    if (n_in < 0 || n_channels <= 0 || !(rate_in > 0.0) || !(rate_out > 0.0)) return fail(SYLDET_ERR_INVALID_ARGUMENT, "bad argument");
+    const int64_t n = syldet_convert_rate_count(n_in, rate_in, rate_out);
+    if (n <= 0) return SYLDET_OK;
+    if (!d_in || !d_out) return fail(SYLDET_ERR_INVALID_ARGUMENT, "NULL buffer");
+    if (n_channels > 1 && (in_stride < n_in || out_stride < n)) return fail(SYLDET_ERR_INVALID_ARGUMENT, "row strides must cover the rows");
+    SYLDET_HIP(launch_convert_rate(d_in, n_in, in_stride, d_out, n, out_stride, n_channels, rate_in / rate_out, (hipStream_t)hip_stream));
+    if (n_out) *n_out = n;
+    return SYLDET_OK;
+}
+
 int syldet_deinterleave_device(const float *d_interleaved, int64_t n_frames, int32_t total_channels, int32_t first_channel,
                                int32_t n_channels, float *d_out, int64_t out_stride, void *hip_stream)
 {

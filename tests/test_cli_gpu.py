@@ -97,20 +97,39 @@ def test_two_files_print_their_names(tmp_path, net):
     check_lines(lines[second + 1:], want[1])
 
 
-def test_other_sampling_rate_goes_through_resampler_linear(tmp_path, net):
+def convert_rate(x, rate_in, rate_out):
+    """What the tool does to a file at another rate: linear interpolation at positions i * rate_in / rate_out, in fp64."""
+    n = x.size
+    m = int((n - 1) * rate_out / rate_in) + 1
+    pos = np.arange(m, dtype=np.float64) * (rate_in / rate_out)
+    k = np.minimum(pos.astype(np.int64), n - 1)
+    return (x[k].astype(np.float64) + (pos - k) * (x[np.minimum(k + 1, n - 1)].astype(np.float64) - x[k])).astype(np.float32)
+
+
+def test_other_sampling_rate_is_converted_with_exact_positions(tmp_path, net):
     cfg, net_path = net
     x48 = synth.syllable_channel(4 * 48000, util.template(), seed=41, every=24000).astype(np.float32)
     p = str(tmp_path / "r48.wav")
     wavutil.write_wav(p, x48[:, None], 48000, "float32")
-    y = po.Resampler(48000.0, cfg.samplingRate).resample(x48)
-    ev, _ = expected_events(cfg, y)
+    ev, _ = expected_events(cfg, convert_rate(x48, 48000.0, cfg.samplingRate))
     check_lines(run("-n", net_path, "-a", p), [(0, s, t, o) for (s, t, o) in ev])
 
 
-def test_short_and_silent_files_print_nothing(tmp_path, net):
+def test_long_file_at_another_rate_against_fp64_interpolation(tmp_path, net):
+    """Six minutes at 48 kHz: read positions are computed in fp64, so the audio the detector sees is the linear interpolation of
+    the file from its first second to its last (an fp32 position ramp would be half a sample off after ~95 s), and so are
+    the detections: sample numbers exact, outputs to 1e-5."""
     cfg, net_path = net
-    p1, p2 = str(tmp_path / "short.wav"), str(tmp_path / "silent.wav")
-    wavutil.write_wav(p1, np.zeros((100, 1), np.int16), FS, "pcm16")
-    wavutil.write_wav(p2, np.zeros((FS, 2), np.int16), FS, "pcm16")
-    assert run("-n", net_path, "-a", p1) == []
-    assert run("-n", net_path, "-a", p2) == []                   # 0/0 in l2normalize: NaN never detects
+    n = 360 * 48000
+    x48 = np.zeros(n, np.float32)
+    from scipy.signal import resample_poly
+    seg = resample_poly(synth.syllable_channel(8 * FS, util.template(), seed=43).astype(np.float64), 160, 147).astype(np.float32)   # 44.1 -> 48 kHz
+    for at in (0, 100, 200, 352):                                # syllables at the start, in the middle and in the last seconds
+        x48[at * 48000:at * 48000 + seg.size] = seg
+    x48 += (0.003 * np.random.default_rng(7).standard_normal(n)).astype(np.float32)
+    p = str(tmp_path / "long48.wav")
+    wavutil.write_wav(p, x48[:, None], 48000, "float32")
+    lines = run("-n", net_path, "-a", p)
+    ev, o64 = expected_events(cfg, convert_rate(x48, 48000.0, cfg.samplingRate))
+    assert len(ev) >= 8 and ev[-1][0] > 340 * 44100, "fixture should fire in the last seconds too"
+    check_lines(lines, [(0, s, t, o) for (s, t, o) in ev])

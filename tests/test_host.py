@@ -218,3 +218,24 @@ def test_mfma_hazard_checker_sees_a_vector_write_in_front_of_a_hand_placed_mfma(
     waited = tmp_path / "waited.s"
     waited.write_text("\tv_mov_b32_e32 v21, v7\n\ts_nop 1\n" + mfma)
     assert chk.check(str(waited)) == (1, [])
+
+
+def test_header_is_plain_c_and_the_library_refuses_to_run_without_a_device(tmp_path):
+    """include/syldet.h compiles as strict C99 (-pedantic -Werror) and a C program links against libsyldet -- the way the
+    reference's bridging header binds its one C API (Common/Common-Bridging-Header.h:5).  Without a gfx950 device the
+    program must be told SYLDET_ERR_NO_DEVICE: there is no CPU path behind the ABI."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "syllable_detector_swift_amd", "lib")
+    exe = str(tmp_path / "header_is_c")
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(root, "include"),
+                    os.path.join(root, "tests", "c", "header_is_c.c"), "-o", exe, "-L" + lib, "-lsyldet",
+                    "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("the device run of this program is tests/test_parity_gpu.py::test_c_program_over_the_abi")
+    cfg = util.sample_net()
+    (tmp_path / "net.txt").write_text(cfg.toText())
+    np.zeros(4000, np.float32).tofile(str(tmp_path / "x.f32"))
+    r = subprocess.run([exe, str(tmp_path / "net.txt"), str(tmp_path / "x.f32")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip() == "no-device", (r.stdout, r.stderr)

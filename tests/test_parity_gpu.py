@@ -485,3 +485,24 @@ def test_a_nan_sample_poisons_exactly_the_windows_that_contain_it(oracle_lib, mo
     util.assert_outputs_close(out[ok], w64[ok])
     util.assert_flags_exact(fl[ok], w64[ok], cfg.thresholds, cfg.rule)
     assert not fl[~ok].any()
+
+
+def test_c_program_over_the_abi(oracle_lib, tmp_path):
+    """tests/c/header_is_c.c -- strict C99, plain C types only -- through load_text, create, run, detections, destroy."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(_abi.LIB_PATH), "header_is_c")
+    if not os.path.exists(exe):
+        pytest.skip("header_is_c not built (run __graft_entry__.build())")
+    cfg, x, gold = util.load_case("case_sample_syllables")
+    x = x[:60000]
+    (tmp_path / "net.txt").write_text(cfg.toText())
+    np.ascontiguousarray(x, np.float32).tofile(str(tmp_path / "x.f32"))
+    r = subprocess.run([exe, str(tmp_path / "net.txt"), str(tmp_path / "x.f32"), str(tmp_path / "out.f32")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    E, count, first = [int(v) for v in r.stdout.split()]
+    o = util.oracle_for(cfg)
+    _, wfl, w64 = o.run(x, po.F64)
+    idx = o.detections(wfl)
+    assert E == len(w64) and count == len(idx) and count > 0 and first == int(idx[0])
+    util.assert_outputs_close(np.fromfile(str(tmp_path / "out.f32"), np.float32).reshape(-1, 1), w64)
