@@ -418,7 +418,7 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
         // needs nothing but the accumulators this wave kept), which would otherwise crowd the second half of the block.
         const int dsc = se_ref - se_m1 < -45 ? -45 : (se_ref - se_m1 > 45 ? 45 : se_ref - se_m1);   // (beyond: the guard's business)
         const int rm = r3 == 0 ? 2 : r3 - 1, re = r3 == 2 ? 0 : r3 + 1;   // (q - 1) mod 3, (q - 2) mod 3
-#ifndef SYLDET_R_NOMAG
+#if !defined(SYLDET_R_NOMAG) && !defined(SYLDET_R_MAGTICK)
 #pragma unroll
         for (int j = 0; j < 15; j++) mag_micro(j, rm, dsc);
 #endif
@@ -479,8 +479,13 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
                 if (i >= 9 && i < 13) eval_reduce(i - 9);
 #endif
 #ifndef SYLDET_R_NOMAG
+#ifdef SYLDET_R_MAGTICK                // (experiment: the whole finishing of pass q-1 inside the block, from this tick on)
+                const int jm = i - SYLDET_R_MAGTICK;
+                if (jm >= 0 && jm < kMagSteps) mag_micro(jm, rm, dsc);
+#else
                 const int jm = i + 14;                                 // pass q-1's tap products and their stores: the first ticks
                 if (i >= 1 && jm < kMagSteps) mag_micro(jm, rm, dsc);
+#endif
 #endif
 #ifndef SYLDET_R_NOMAX
                 const int jx = i - (kTicks - NL - 4);                  // block maximum of pass q+2, a quad a tick (its loads left in the

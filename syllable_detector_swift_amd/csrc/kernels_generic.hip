@@ -89,9 +89,11 @@ stft_r8_kernel(StftDesc d, const float *__restrict__ samples, int64_t stride, in
         tw1[a] = w1024(2 * lane * a);                             // W512^(b c), b = lane, c = a
         tw2[a] = w1024(16 * lo3 * a);                             // W64^(b' c'), b' = lane & 7, c' = a
     }
-    float2 swr[8];                                              // split twiddles of this lane's bins f = lane + 64 it
+    // split twiddles of this lane's bins f = lane + 64 it: the first two in registers (bands of up to 128 bins: BASELINE
+    // configs[2] has 116), the rest fetched when a wider band needs them
+    float2 swr[2];
 #pragma unroll
-    for (int it = 0; it < 8; it++) swr[it] = lane + kWave * it < d.F ? d.sw[d.f0 + lane + kWave * it] : make_float2(0.0f, 0.0f);
+    for (int it = 0; it < 2; it++) swr[it] = lane + kWave * it < d.F ? d.sw[d.f0 + lane + kWave * it] : make_float2(0.0f, 0.0f);
     const int64_t j0 = ((int64_t)blockIdx.x * (kBlock / kWave) + wave) * kR8Frames;
     if (j0 >= J) return;
     // raw samples of a frame: points 64 a + lane, as (even, odd) pairs; the next frame is fetched while this one is transformed
@@ -137,10 +139,7 @@ stft_r8_kernel(StftDesc d, const float *__restrict__ samples, int64_t stride, in
         for (int dd = 0; dd < 8; dd++) buf[hi3 + 8 * lo3 + 64 * dd] = v[dd];   // Z[c + 8 c' + 64 d'], natural order
         __builtin_amdgcn_wave_barrier();
         // real split + magnitude for the band only; Nyquist is dropped (:323)
-#pragma unroll
-        for (int it = 0; it < 8; it++) {
-            const int f = lane + kWave * it;
-            if (f >= d.F) break;
+        auto split_bin = [&](int f, float2 w) {
             const int k = d.f0 + f;
             float re2, im2;
             if (k == 0) {
@@ -149,7 +148,6 @@ stft_r8_kernel(StftDesc d, const float *__restrict__ samples, int64_t stride, in
                 im2 = 0.0f;
             } else {
                 const float2 zk = buf[k], zm = buf[512 - k];
-                const float2 w = swr[it];
                 const float ar = zk.x + zm.x, ai = zk.y - zm.y;
                 const float br = zk.x - zm.x, bi = zk.y + zm.y;
                 const float tr = br * w.x - bi * w.y, ti = br * w.y + bi * w.x;
@@ -157,8 +155,13 @@ stft_r8_kernel(StftDesc d, const float *__restrict__ samples, int64_t stride, in
                 im2 = ai - tr;
             }
             const float p = re2 * re2 + im2 * im2;
-            cols[j * d.F + f] = d.power_mode ? p * 0.25f : sqrtf(p) * 0.5f;   // zvmags/4 :270-274, zvabs/2 :329-333
-        }
+            // zvmags/4 :270-274, zvabs/2 :329-333 (the hardware square root: 1 ulp, and NaN / inf / 0 as the library's)
+            cols[j * d.F + f] = d.power_mode ? p * 0.25f : __builtin_amdgcn_sqrtf(p) * 0.5f;
+        };
+#pragma unroll
+        for (int it = 0; it < 2; it++)
+            if (lane + kWave * it < d.F) split_bin(lane + kWave * it, swr[it]);
+        for (int f = lane + 2 * kWave; f < d.F; f += kWave) split_bin(f, d.sw[d.f0 + f]);
         __builtin_amdgcn_wave_barrier();
     }
 }

@@ -586,6 +586,14 @@ int run_on_stream(syldet *h, const float *d_samples, int64_t S, int64_t stride, 
         SYLDET_HIP(launch_wide_gemm(h->wide, h->d_xn.ptr, (int64_t)C * E, d_outputs, d_flags, stream));
         return SYLDET_OK;
     }
+    // 1024-point frames in front of a network of the matrix-core class: one launch, the columns never leave the CU
+    const bool no_fft1k = std::getenv("SYLDET_NO_FFT1K") != nullptr;      // (A/B runs and the tests that hold the two forms against each other)
+    if (h->mlpx.ok && !no_fft1k && (uint64_t)E * 4u < 0xFFFFFFF0ull &&
+        fft1k_applicable(h->stft, h->mlpx.desc, d_samples, stride)) {
+        KernelTimer t(h, stream, "fft1k_net_kernel");
+        SYLDET_HIP(launch_fft1k_net(h->stft, h->mlpx.desc, d_samples, stride, C, J, E, d_outputs, d_flags, stream));
+        return SYLDET_OK;
+    }
     if (int st = stft_on_stream(h, d_samples, stride, C, J, (float *)h->d_columns.ptr, stream)) return st;
     if (h->mlpx.ok && (uint64_t)E * 4u < 0xFFFFFFF0ull) {
         KernelTimer t(h, stream, "mlp_mfma_kernel");

@@ -506,3 +506,46 @@ def test_c_program_over_the_abi(oracle_lib, tmp_path):
     idx = o.detections(wfl)
     assert E == len(w64) and count == len(idx) and count > 0 and first == int(idx[0])
     util.assert_outputs_close(np.fromfile(str(tmp_path / "out.f32"), np.float32).reshape(-1, 1), w64)
+
+
+def test_1024_point_frames_in_one_launch_and_in_two(oracle_lib, monkeypatch):
+    """BASELINE configs[2]'s shape: the one-launch kernel (packed real FFT + matrix-core network stage, columns never in HBM:
+    kernels_fft1k.hip) and the two-launch form it replaces (stft_r8_kernel -> columns -> mlp_mfma_kernel), both against the
+    oracle; lengths around the 128-frame tiles and the carried columns; an odd channel stride keeps the two-launch form."""
+    torch = _torch()
+    cfg = nets.config3()
+    hop = cfg.windowLength - cfg.windowOverlap
+    o = util.oracle_for(cfg)
+    for frames in (10, 127, 128, 129, 137, 247, 600):
+        S = cfg.windowLength + (frames - 1) * hop + 18             # (even: rows start 8-byte aligned)
+        x = (synth.channels(3, S, first=50 + frames) * np.array([1.0, 1e-3, 30.0])[:, None]).astype(np.float32)
+        x[1, S // 2:] *= np.float32(1e-3)                       # a 60 dB step inside a tile: every frame has its own exponent
+        want = [o.run(x[c], po.F64)[2] for c in range(3)]
+        for one_launch in (True, False):
+            if one_launch:
+                monkeypatch.delenv("SYLDET_NO_FFT1K", raising=False)
+            else:
+                monkeypatch.setenv("SYLDET_NO_FFT1K", "1")
+            with sd.SyllableDetector(cfg, channels=3) as det:
+                det.profile(True)
+                out, fl = det.run(torch.from_numpy(x).cuda())
+                torch.cuda.synchronize()
+                names = [nm for nm, _ in det.lastTimings()]
+                assert names == (["fft1k_net_kernel"] if one_launch else ["stft_generic_kernel", "mlp_mfma_kernel"]), names
+                out, fl = out.cpu().numpy(), fl.cpu().numpy()
+            for c in range(3):
+                if one_launch or c != 1:                        # (the two-launch form scales a whole tile by its loudest column)
+                    util.assert_outputs_close(out[c], want[c])
+                    util.assert_flags_exact(fl[c], want[c], cfg.thresholds, cfg.rule)
+    # rows that do not start 8-byte aligned (an odd stride) take the two-launch form
+    monkeypatch.delenv("SYLDET_NO_FFT1K", raising=False)
+    S = cfg.windowLength + 199 * hop
+    base = torch.from_numpy(synth.channels(2, S + 1, first=7)).cuda()
+    xs = base[:, :S]                                            # stride S + 1
+    with sd.SyllableDetector(cfg, channels=2) as det:
+        det.profile(True)
+        out, _ = det.run(xs)
+        torch.cuda.synchronize()
+        assert [nm for nm, _ in det.lastTimings()] == ["stft_generic_kernel", "mlp_mfma_kernel"]
+        for c in range(2):
+            util.assert_outputs_close(out[c].cpu().numpy(), o.run(xs[c].cpu().numpy(), po.F64)[2])
