@@ -72,6 +72,7 @@ struct WideDesc {
     const double *thresholds;   // [n_out]
 };
 // columns [C][J][F] -> xn [C*E][kWideK] bf16 (scaling + input functions applied)
+bool wide_prep_is_chain(const NetDesc &n);   // which of the two preparation kernels launch_wide_prep picks (for timing labels)
 hipError_t launch_wide_prep(const NetDesc &n, int F, const float *columns, int C, int64_t J, int64_t E, void *xn, hipStream_t stream);
 // xn [NE][kWideK] -> outputs [NE][n_out], flags [NE]
 hipError_t launch_wide_gemm(const WideDesc &d, const void *xn, int64_t NE, float *outputs, uint8_t *flags, hipStream_t stream);

@@ -324,6 +324,13 @@ wide_gemm_kernel(WideDesc d, const uint4 *__restrict__ xn, int64_t NE, float *__
 
 }  // namespace
 
+// the input chains the training script writes -- [l2normalize,] one affine map -- take the chain-specialised kernel
+bool wide_prep_is_chain(const NetDesc &n)
+{
+    const bool affine_last = n.n_in_fns >= 1 && n.in_fns[n.n_in_fns - 1].kind >= 3;
+    return (n.n_in_fns == 2 && n.in_fns[0].kind == 0 && affine_last) || (n.n_in_fns == 1 && affine_last);
+}
+
 hipError_t launch_wide_prep(const NetDesc &n, int F, const float *columns, int C, int64_t J, int64_t E, void *xn, hipStream_t stream)
 {
     if (E <= 0 || C <= 0) return hipSuccess;

@@ -579,7 +579,7 @@ int run_on_stream(syldet *h, const float *d_samples, int64_t S, int64_t stride, 
         if (int st = h->d_xn.reserve((size_t)C * (size_t)E * (size_t)kWideK * 2)) return st;
         if (int st = stft_on_stream(h, d_samples, stride, C, J, (float *)h->d_columns.ptr, stream)) return st;
         {
-            KernelTimer t(h, stream, "wide_prep_kernel");
+            KernelTimer t(h, stream, wide_prep_is_chain(h->net) ? "wide_prep_chain_kernel" : "wide_prep_kernel");
             SYLDET_HIP(launch_wide_prep(h->net, h->geom.bins, (const float *)h->d_columns.ptr, C, J, E, h->d_xn.ptr, stream));
         }
         KernelTimer t(h, stream, "wide_gemm_kernel");
