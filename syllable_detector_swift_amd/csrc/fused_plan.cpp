@@ -318,6 +318,10 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
         };
         d.guard_se_abs_r = se_abs(phi_r);
         d.guard_se_abs_c = se_abs(phi_c);
+        // the spectrogram instantiation stores fp32 columns straight from the accumulators: the sample grid's floor alone, held
+        // against 1e-6 of the column's largest value (its norm / sqrt(F) at least) or 1e-6 absolute, whichever is larger
+        d.guard_spect = sq(std::sqrt((double)F) * phi_r / 1e-6);
+        d.guard_se_abs_s = (int)std::max(-200.0, std::min(200.0, std::ceil(std::log2(phi_r / 1e-6) + (double)d.col_shift)));
     }
     if (!d.classic_ok && !fused_r_applicable(d)) return no("LDS budget exceeded");
     p.koff.resize((size_t)KS * 4);
@@ -367,7 +371,7 @@ bool make_mlpx_plan(const syldet_config_t &c, const syldet_geometry_t &g, MlpxPl
     d.lds_p = take(kMlpxTile * d.p_stride * 4);
     d.lds_pq = take(kMlpxTile * 32 * 4);             // sums of squares per quad of column values (at most 32 quads a frame)
     d.lds_ss = take(2 * kMlpxTile * 4);              // per-frame sums of squares, two tiles (parity)
-    d.lds_red = take(64);
+    d.lds_red = take(2 * kMlpxTile * 4);             // per-frame scales 2^fe and their inverses
     d.lds_total = off;
     if (off > 160 * 1024) return no("LDS budget exceeded");
     // folded first layer (see make_fused_plan): W'_t[h][f] = W0[h][t*F+f] * a[t*F+f], scaled by 2^wexp, f16 hi + lo.

@@ -155,6 +155,8 @@ struct FusedDesc {
     float guard_rel_r, guard_rel_c;   // no normaliser: the per-column relative criterion (smallest column sum of squares of the
                                       // window) that joins the absolute one
     int guard_se_abs_r, guard_se_abs_c;   // no normaliser: passes scaled below this exponent are loud enough for the floor to matter
+    float guard_spect;          // spectrogram instantiation: a frame's column sum of squares (grid units) ...
+    int guard_se_abs_s;         //   ... in passes scaled below this exponent
     FixList fix;                // work list of evaluations to recompute (null counters: guard off)
     int ko;                     // diagnostic build only: knock-out mask (SYLDET_FUSED_KO)
     unsigned long long *stamps; // diagnostic build only: [workgroups][16] phase cycle sums, else null
@@ -217,6 +219,7 @@ int fused_taps_max(int T);
 // ---- exact recomputation of the evaluations the fused kernels reported (kernels_fixup.hip) ----
 struct FixDesc {
     int N, W, hop, gap, f0, F, T;
+    int power_mode;             // spectrogram items: 0 |X| (extractPower), 1 |X|^2 (extractMagnitude)
     const float *window;        // [W] the fp32 window table (WindowType.createWindow)
     const double2 *ctab;        // [N] (cos, sin)(2 pi m / N)
 };

@@ -79,7 +79,8 @@ fixup_kernel(const FixDesc fd, const NetDesc n, const float *__restrict__ sample
             }
             const float mag = (float)sqrt(re * re + im * im);
             cols[fr * F + b] = mag;
-            if (spect && columns) columns[((int64_t)c * J + first + fr) * F + b] = mag;
+            if (spect && columns)                                 // zvabs / 2 :329-333, or zvmags / 4 :270-274
+                columns[((int64_t)c * J + first + fr) * F + b] = fd.power_mode ? (float)(re * re + im * im) : mag;
         }
         __syncthreads();
         if (spect) continue;

@@ -244,7 +244,7 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
     // the window's sum of squares is kept for l2normalize and, for the precision guard, for linear columns without a normaliser
     const bool want_ss = norm == 1 || (norm == 0 && scaling == 0);
     bool badv = false;                  // this lane's evaluation of the pass failed the guard (kernels.hpp, FixItem)
-    const bool guard_on = !SPECT && d.fix.counters != nullptr;
+    const bool guard_on = d.fix.counters != nullptr;
     unsigned long long tsum[16] = {0}, tick[8] = {0};
     if (STAMP) tick[5] = __builtin_amdgcn_s_memtime();
     __syncthreads();
@@ -574,13 +574,34 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
             const float inv = pow2f(-se - 13);
             const int64_t jf = e_b + (int64_t)kPass * p + fl;
             const bool live = jf < e_e;
+            float gss = 0.0f;                                     // the frame's column sum of squares on the sample grid (guard)
 #pragma unroll
             for (int i = 0; i < 8; i++) {
-                const float re = acc[i >> 2][i & 3] * inv, im = acc[2 + (i >> 2)][i & 3] * inv;
+                // (the square root is taken on the accumulator's scale, |acc| < 2^41: a recording at 1e30 must not overflow in
+                // the squares of a magnitude that itself fits fp32)
+                const float re = acc[i >> 2][i & 3], im = acc[2 + (i >> 2)][i & 3];
                 const float pw = fmaf(re, re, im * im);
+                gss += pw;
+                const float mag = __builtin_amdgcn_sqrtf(pw) * inv;
                 const int bin = (i & 3) + 16 * (i >> 2) + 4 * g4;
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d.spect_power ? pw : __builtin_amdgcn_sqrtf(pw)), spc_rs,
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d.spect_power ? mag * mag : mag), spc_rs,
                                                       (live && bin < d.F) ? ((unsigned)jf * (unsigned)d.F + bin) * 4u : 0xFFFFFFFFu, 0, 0);
+            }
+            // Precision guard (kernels.hpp, FixItem): frames the pass's sample grid cannot hold -- an infinite sample in the
+            // pass, or a column within reach of the grid's floor in a pass loud enough for that floor to matter -- are
+            // recomputed from the samples.  16 frames of a wave are one work item.
+            if (guard_on) {
+                gss = xor32_sum(xor16_sum(gss)) * pow2f(2 * (-13 - d.col_shift));        // in column-grid units
+                const bool bad = live && (st == 2 || (st == 0 && se < d.guard_se_abs_s && !(gss >= d.guard_spect)));
+                if (__builtin_amdgcn_ballot_w64(bad) != 0ull) {
+                    int64_t lo = e_b + (int64_t)kPass * p + 16 * wave, hi = lo + 16;
+                    hi = hi > e_e ? e_e : hi;
+                    if (lane == 0 && hi > lo) {
+                        const unsigned slot = atomicAdd(d.fix.counters, 1u);
+                        if (slot < d.fix.capacity) d.fix.items[slot] = FixItem{c, (unsigned)lo, (int)(hi - lo), 1};
+                        else d.fix.counters[3] = 1u;
+                    }
+                }
             }
         } else if (!(kom & 64)) {
             // accumulators hold X * sx * 2^13.  Column scale (power of two; col_shift from the basis' largest row sum):

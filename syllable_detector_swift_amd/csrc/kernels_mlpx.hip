@@ -16,9 +16,10 @@
 // fewer MFMAs and 20x less LDS traffic.
 //
 // A tile = 128 frames of one channel (16 per wave): read once as coalesced quads (the next tile's are in flight meanwhile),
-// scaled by one power of two (the tile's largest value goes to [2^13, 2^14): block floating point), split into f16 hi + lo
-// in LDS; the l2normalize denominator comes from sums of squares taken per quad while the columns are split and added per
-// frame in a fixed order (no atomics: results do not depend on the order the threads arrive in); tap products go to LDS;
+// every frame scaled by its own power of two (its column norm goes to [2^12, 2^13): a quiet frame next to a loud one keeps 22
+// bits of its own level), split into f16 hi + lo in LDS; the l2normalize denominator comes from sums of squares taken per
+// quad and added per frame in a fixed order (no atomics: results do not depend on the order the threads arrive in); tap
+// products go back to true units by the frame's exponent and to LDS;
 // the tile's 128 - timeRange + 1 evaluations finish in registers, one thread each.
 //
 // gfx950 only.  wave = 64.
@@ -46,7 +47,8 @@ mlp_mfma_kernel(const MlpxDesc d, const float *__restrict__ columns, int64_t J, 
     float *pbuf = reinterpret_cast<float *>(smem + d.lds_p);
     float *pq = reinterpret_cast<float *>(smem + d.lds_pq);          // [frame][F / 4] sums of squares per quad
     float *ss0 = reinterpret_cast<float *>(smem + d.lds_ss);         // [2 tiles][128] sums of squares per frame
-    float *red = reinterpret_cast<float *>(smem + d.lds_red);
+    float *fup = reinterpret_cast<float *>(smem + d.lds_red);        // [128] per-frame scale 2^fe and, behind it, its inverse
+    float *fdn = fup + kTile;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -84,39 +86,43 @@ mlp_mfma_kernel(const MlpxDesc d, const float *__restrict__ columns, int64_t J, 
         const int64_t e0 = (int64_t)tile * step;      // first evaluation = first frame of the tile
         // (the sums alternate between two buffers: the previous tile's evaluations may still be reading theirs)
         float *ss = ss0 + parity * kTile;
-        float amax = 0.0f;
+        // ---- every frame gets its own power-of-two exponent (its column norm goes to [2^12, 2^13)): a quiet frame next to a
+        // loud one keeps 22 bits of its own level.  First the frame's sum of squares: per quad, then per frame in a fixed
+        // order (no atomics: results do not depend on the order the threads arrive in)
 #pragma unroll
         for (int k = 0; k < NQ; k++) {
-            const floatx4 q = as_floatx4(v[k]);
-            amax = absmax3(absmax3(amax, q[0], q[1]), q[2], q[3]);
+            const int q = tid + kBlock * k;
+            if (q < nq) {
+                const floatx4 x = as_floatx4(v[k]);
+                pq[q] = fmaf(x[0], x[0], fmaf(x[1], x[1], fmaf(x[2], x[2], x[3] * x[3])));
+            }
         }
-        amax = wave_max_nonneg(amax);
-        if (lane == 0) red[wave] = amax;
-        __syncthreads();          // partial maxima in
-        int se;
-        {
-            const floatx4 r0 = *reinterpret_cast<const floatx4 *>(red), r1 = *reinterpret_cast<const floatx4 *>(red + 4);
-            const float m = fmaxf(fmaxf(fmaxf(r0[0], r0[1]), fmaxf(r0[2], r0[3])), fmaxf(fmaxf(r1[0], r1[1]), fmaxf(r1[2], r1[3])));
-            int e = 13 - (int)((__float_as_uint(m) >> 23) & 0xffu) + 127;
-            e = m > 0.0f ? (e < -100 ? -100 : (e > 100 ? 100 : e)) : 0;
-            se = __builtin_amdgcn_readfirstlane(e);
+        __syncthreads();
+        if (tid < kTile) {
+            float sacc = 0.0f;
+            for (int i = 0; i < F / 4; i++) sacc += pq[tid * (F / 4) + i];
+            ss[tid] = sacc;
+            // t = floor(log2 sqrt(ss)) + 64, clamped; up = 2^(76 - t), down = 1 / up (see kernels_fused_r.hip, mag_micro)
+            unsigned tb = ((__float_as_uint(sacc) + 0x800000u) >> 1) & 0x7f800000u;
+            tb = (unsigned)min(max((int)tb, 16 << 23), 80 << 23);
+            fup[tid] = __uint_as_float((203u << 23) - tb);
+            fdn[tid] = __uint_as_float(tb + (51u << 23));
         }
-        const float sx = pow2f(se);
-        // ---- scale, split into f16 hi + lo, -> LDS [frame][bin]; the frame's sum of squares (of the scaled values)
+        __syncthreads();
+        // ---- scale, split into f16 hi + lo, -> LDS [frame][bin]
 #pragma unroll
         for (int k = 0; k < NQ; k++) {
             const int q = tid + kBlock * k;
             if (q < nq) {
                 const floatx4 x = as_floatx4(v[k]);
                 const int fr = F == 4 ? q : (int)__umulhi((unsigned)q, fmagic), bin = 4 * (q - fr * (F / 4));   // (the magic number of 1 does not fit 32 bits)
+                const float sx = fup[fr];
                 unsigned h0, l0, h1, l1;
                 split_pair_scaled(x[0], x[1], sx, h0, l0);
                 split_pair_scaled(x[2], x[3], sx, h1, l1);
                 uint32x2 uh = {h0, h1}, ul = {l0, l1};
                 *reinterpret_cast<uint32x2 *>(colh + fr * CS + bin) = uh;
                 *reinterpret_cast<uint32x2 *>(coll + fr * CS + bin) = ul;
-                const float a0 = x[0] * sx, a1 = x[1] * sx, a2 = x[2] * sx, a3 = x[3] * sx;
-                pq[q] = fmaf(a0, a0, fmaf(a1, a1, fmaf(a2, a2, a3 * a3)));              // summed per frame below, in a fixed order
             }
         }
         // the staging registers are free: the next tile's columns start their way from HBM
@@ -153,13 +159,9 @@ mlp_mfma_kernel(const MlpxDesc d, const float *__restrict__ columns, int64_t J, 
             }
             // result layout: column = frame f, register i of lane group g4 in tile m = row 16 m + 4 g4 + i = tap 4 m + g4,
             // unit i: four consecutive floats of the frame's row in pbuf
+            const float dn = fdn[fr];                 // back to true units by the frame's exponent
 #pragma unroll
-            for (int m = 0; m < 3; m++) *reinterpret_cast<floatx4 *>(pbuf + fr * PS + 4 * (4 * m + g4)) = acc[m];
-        }
-        if (tid < kTile) {                            // the frame's sum of squares: its F / 4 quads, in order
-            float s = 0.0f;
-            for (int i = 0; i < F / 4; i++) s += pq[tid * (F / 4) + i];
-            ss[tid] = s;
+            for (int m = 0; m < 3; m++) *reinterpret_cast<floatx4 *>(pbuf + fr * PS + 4 * (4 * m + g4)) = acc[m] * dn;
         }
         __syncthreads();
         // ---- evaluations e0 .. e0 + step - 1, one thread each: diagonal sum over the taps, l2normalize

@@ -382,6 +382,7 @@ int upload_fix(syldet *h)
     SYLDET_HIP(hipMemcpy(h->d_ctab.ptr, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
     FixDesc &f = h->fixd;
     f.N = N; f.W = c.window_length; f.hop = h->geom.hop; f.gap = h->geom.gap; f.f0 = h->geom.f0; f.F = h->geom.bins; f.T = c.time_range;
+    f.power_mode = c.spectrum == SYLDET_SPECTRUM_MAGNITUDE ? 1 : 0;
     f.window = (const float *)h->d_window.ptr;
     f.ctab = (const double2 *)h->d_ctab.ptr;
     h->has_fix = true;
@@ -500,10 +501,14 @@ int stft_on_stream(syldet *h, const float *d_samples, int64_t stride, int C, int
         fused_segmentation(d, J, C);
         d.spect_out = d_columns;
         d.stamps = nullptr;
-        d.fix = FixList{nullptr, nullptr, 0};
         d.ko = 0;
-        KernelTimer t(h, stream, "fused_kernel (spectrogram)");
-        SYLDET_HIP(launch_fused_spectrogram(d, d_samples, stride, C, J, stream));
+        // the precision guard's work list, and behind the kernel the exact recomputation of the frames it reports
+        if (int st = prepare_fix(h, C, J, (J + d.seg_evals - 1) / d.seg_evals, stream, d.fix)) return st;
+        {
+            KernelTimer t(h, stream, "fused_kernel (spectrogram)");
+            SYLDET_HIP(launch_fused_spectrogram(d, d_samples, stride, C, J, stream));
+        }
+        SYLDET_HIP(launch_fixup(h->fixd, h->net, d_samples, stride, J, 0, nullptr, nullptr, d_columns, d.fix, stream));
         return SYLDET_OK;
     }
     KernelTimer t(h, stream, "stft_generic_kernel");
@@ -685,7 +690,9 @@ int syldet_create(const syldet_config_t *cfg, int32_t n_channels, int32_t device
         }
     }
     if (engine != SYLDET_ENGINE_GENERIC) {
-        if (int st = build_dft_plan(h.get())) {
+        int st = build_dft_plan(h.get());
+        if (!st && h->has_dft && !h->has_fix) st = upload_fix(h.get());
+        if (st) {
             syldet_destroy(h.release());
             return st;
         }

@@ -65,3 +65,30 @@ def test_extreme_inputs(oracle_lib, monkeypatch, kernel, name):
     if name in ("one inf", "step 1e-12", "step 1e12"):
         assert items > 0
     assert over == 0
+
+
+@pytest.mark.parametrize("name", ["plain", "one NaN", "one inf", "x 1e30", "step 1e12", "step 1e-12", "clicks over quiet audio"])
+@pytest.mark.parametrize("spectrum", [0, 1])
+def test_extreme_inputs_spectrogram(oracle_lib, name, spectrum):
+    """The spectrogram API (the fused engine's DFT half) on the same inputs: every column to 1e-5 of its largest value, NaN
+    exactly in the frames that contain the offending sample."""
+    import torch
+    if spectrum and name == "x 1e30":
+        pytest.skip("|X|^2 of a recording at 1e30 does not fit fp32 (the reference's vDSP_zvmags overflows too)")
+    cfg = util.sample_net()
+    cfg.spectrum = spectrum
+    x = _cases()[name]
+    with sd.SyllableDetector(cfg, channels=1, engine=(1 if spectrum else 0)) as det:      # (|X|^2 columns: generic network engine)
+        det.profile(True)
+        cols = det.spectrogram(torch.from_numpy(x[None]).cuda())
+        torch.cuda.synchronize()
+        names = [nm for nm, _ in det.lastTimings()]
+        cols = cols.cpu().numpy()[0]
+        items, over = det.fixupStats()
+    o = util.oracle_for(cfg)
+    want = o.spectrogram(x, po.F64)
+    ok = np.isfinite(want).all(axis=1)
+    assert (np.isfinite(cols).all(axis=1) == ok).all()
+    util.assert_columns_close(cols[ok], want[ok])
+    if names == ["fused_kernel (spectrogram)"]:
+        assert over == 0 and (items > 0) == (name in ("one inf", "step 1e12"))
