@@ -25,7 +25,7 @@ namespace {
 using namespace generic_dev;
 
 constexpr int kBlock = 256;
-constexpr int kFixGrid = 512;
+constexpr int kFixGrid = 128;                   // (an empty list -- the ordinary case -- should cost a few microseconds, not a full grid)
 constexpr int kMaxFrames = kFixMaxCount + 11;      // frames behind one item: its evaluations' windows (timeRange <= 12)
 
 __global__ void __launch_bounds__(kBlock)

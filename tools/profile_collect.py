@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""Condenses what tools/profile_round.sh wrote under gpurun_out/prof_<round>/ into the small files that are committed under
+profiles/: per-kernel statistics (rocprofv3 --stats), HBM traffic per launch (FETCH_SIZE x 2 + WRITE_SIZE: the gfx950
+correction of MI355X_MICROARCH.md, HBM), utilisation counters per dispatch, and the bench lines of the profiled runs."""
+import collections, csv, glob, json, os, re, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = sys.argv[1] if len(sys.argv) > 1 else "r02"
+SRC = os.path.join(ROOT, "gpurun_out", "prof_" + R)
+DST = os.path.join(ROOT, "gpurun_out", "profiles_" + R)
+os.makedirs(DST, exist_ok=True)
+
+
+def kname(full):
+    """'void sd::(anonymous namespace)::fused_r_kernel<8, 12, 9, false, false>(sd::FusedDesc, ...)' -> 'fused_r_kernel'"""
+    m = re.search(r"(\w+_kernel)\b", full)
+    return m.group(1) if m else full[:40]
+
+
+def bench_line(log):
+    try:
+        for l in reversed(open(log).read().splitlines()):
+            if l.startswith("{"):
+                return json.loads(l)
+    except Exception:
+        pass
+    return None
+
+
+def kernel_stats(name):
+    f = glob.glob(os.path.join(SRC, "stats_" + name, "**", "*kernel_stats.csv"), recursive=True)
+    if not f:
+        return None
+    rows = list(csv.DictReader(open(f[0])))
+    keep = [r for r in rows if "sd::" in r["Name"]]
+    out = os.path.join(DST, "%s_%s_kernel_stats.csv" % (R, name))
+    with open(out, "w", newline="") as fh:
+        w = csv.DictWriter(fh, fieldnames=list(rows[0].keys()))
+        w.writeheader()
+        for r in keep:
+            w.writerow(r)
+    return {kname(r["Name"]): {"calls": int(r["Calls"]), "average_ms": float(r["AverageNs"]) / 1e6} for r in keep}
+
+
+def counters(name):
+    f = glob.glob(os.path.join(SRC, "pmc_" + name, "**", "*counter_collection.csv"), recursive=True)
+    if not f:
+        return {}
+    agg, cnt = collections.defaultdict(lambda: collections.defaultdict(float)), collections.Counter()
+    for row in csv.DictReader(open(f[0])):
+        if "sd::" not in row["Kernel_Name"]:
+            continue
+        k = kname(row["Kernel_Name"])
+        agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
+        cnt[(k, row["Counter_Name"])] += 1
+    return {k: {c: v / cnt[(k, c)] for c, v in d.items()} for k, d in agg.items()}
+
+
+summary = {"source": "tools/profile_round.sh %s (rocprofv3 --kernel-trace --stats; separate --kernel-trace --pmc passes), MI355X" % R}
+for wl, dom in (("sample", "fused_r_kernel"), ("config3", "fft1k_net_kernel"), ("config5", "wide_gemm_kernel")):
+    line = bench_line(os.path.join(SRC, "stats_%s.log" % wl))
+    ks = kernel_stats(wl)
+    if line:
+        json.dump(line, open(os.path.join(DST, "%s_%s_bench_under_rocprof.json" % (R, wl)), "w"), indent=1)
+    summary[wl] = {"kernel_stats": ks, "bench_kernel_ms": line["roofline"]["kernel_ms"] if line else None}
+    if wl == "config5":
+        continue
+    fetch, write = counters(wl + "_fetch"), counters(wl + "_write")
+    if dom in fetch and dom in write and line:
+        fk, wk = fetch[dom]["FETCH_SIZE"], write[dom]["WRITE_SIZE"]
+        hbm = 2.0 * fk * 1024.0 + wk * 1024.0
+        alg = line["roofline"]["algorithmic_bytes_per_launch"]
+        t = {"workload": {"channels_per_gpu": line["config"]["channels_per_gpu"], "samples_per_channel": line["config"]["samples_per_channel"],
+                          "hop": line["config"]["hop"], "engine": line["config"]["engine"]},
+             "kernel": dom,
+             "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, tools/profile_round.sh), python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-verify%s, per dispatch of %s" % ("" if wl == "sample" else " --workload " + wl, dom),
+             "FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk,
+             "correction": "gfx950 FETCH_SIZE counts 64 B per 128 B request on wide coalesced reads: x2 (MI355X_MICROARCH.md, HBM); WRITE_SIZE taken as is",
+             "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": alg, "ratio": hbm / alg}
+        json.dump(t, open(os.path.join(DST, "%s_%straffic.json" % (R, "" if wl == "sample" else wl + "_")), "w"), indent=1)
+        summary[wl]["traffic_ratio"] = hbm / alg
+    util = {}
+    for f in glob.glob(os.path.join(SRC, "pmc_%s_SQ*" % wl)):
+        if os.path.isdir(f):
+            for k, d in counters(os.path.basename(f)[4:]).items():
+                util.setdefault(k, {}).update(d)
+    if dom in util:
+        c = util[dom]
+        der = {}
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "SQ_BUSY_CU_CYCLES" in c:
+            der["mfma_pipe_busy_fraction (MFMA_BUSY / (4 SIMDs x BUSY_CU))"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * c["SQ_BUSY_CU_CYCLES"])
+        if "SQ_LDS_IDX_ACTIVE" in c and "SQ_BUSY_CU_CYCLES" in c:
+            der["lds_active_fraction (LDS_IDX_ACTIVE / BUSY_CU)"] = c["SQ_LDS_IDX_ACTIVE"] / c["SQ_BUSY_CU_CYCLES"]
+        if "SQ_LDS_BANK_CONFLICT" in c and "SQ_LDS_IDX_ACTIVE" in c:
+            der["lds_bank_conflict_fraction"] = c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"]
+        if "SQ_WAIT_ANY" in c and "SQ_WAVE_CYCLES" in c:
+            der["wait_any_fraction_of_wave_cycles"] = c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]
+        summary[wl]["utilisation"] = {"kernel": dom, "counters": c, "derived": der}
+json.dump(summary, open(os.path.join(DST, "%s_profile_summary.json" % R), "w"), indent=1)
+print(json.dumps({k: (v if k == "source" else {kk: vv for kk, vv in v.items() if kk != "utilisation"}) for k, v in summary.items()}, indent=1)[:3000])
