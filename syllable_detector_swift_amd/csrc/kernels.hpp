@@ -181,7 +181,7 @@ struct MlpxDesc {
     const double *thresholds;   // [1]
 };
 // ---- 1024-point frames: packed real FFT + the matrix-core network stage in one launch (kernels_fft1k.hip) ----
-constexpr int kFft1kBlock = 512;         // 8 waves: a frame per wave at a time, 16 frames of a 128-frame tile each
+constexpr int kFft1kBlock = 768;         // 12 waves (three per SIMD): a frame per wave at a time, 10 or 11 frames of a 128-frame tile each
 bool fft1k_applicable(const StftDesc &s, const MlpxDesc &d, const float *samples, int64_t stride);
 // outputs [C][E][1], flags [C][E] <- samples [C][stride]
 hipError_t launch_fft1k_net(const StftDesc &s, const MlpxDesc &d, const float *samples, int64_t stride, int C, int64_t J, int64_t E,

@@ -14,8 +14,8 @@
 //     radix-8 passes in registers with two transposes through a wave-private 4.5 KB of LDS, real split and |X| for the band;
 //   * the first layer with ALL taps as the rows of one GEMM on the matrix cores (kernels_mlpx.hip's formulation:
 //     P[(t, h), j] = W'_t[h, :] . c(j), f16 hi + lo operands, three products, fp32 accumulate), evaluations as diagonal sums.
-// Here a workgroup (8 waves) walks a contiguous run of 128-frame tiles of one channel: its waves transform the tile's new
-// frames (15 or 16 each), every frame's |X| column goes to LDS as f16 hi + lo under the frame's OWN power-of-two exponent (a quiet
+// Here a workgroup (12 waves) walks a contiguous run of 128-frame tiles of one channel: its waves transform the tile's new
+// frames (10 or 11 each), every frame's |X| column goes to LDS as f16 hi + lo under the frame's OWN power-of-two exponent (a quiet
 // frame next to a loud one keeps 22 bits of its own level), the tile's tap products come off the matrix cores, one thread per
 // evaluation finishes the network, and the last timeRange - 1 columns are carried to the front of the next tile.
 //
@@ -33,10 +33,13 @@ namespace {
 
 using namespace fused_dev;
 
-constexpr int kBlock = kFft1kBlock;            // 512 threads = 8 waves
+constexpr int kBlock = kFft1kBlock;            // 768 threads = 12 waves: the transform is a chain of LDS round trips, and three
+                                               // waves per SIMD hide more of it than two (3.08 ms against 3.28 on the BASELINE
+                                               // configs[2] batch; four, with the first layer's fragments read from memory to
+                                               // make room for their scratch, spill: 3.82 ms)
 constexpr int kWaves = kBlock / 64;
 constexpr int kTile = 128;                     // frames per tile
-constexpr int kScratch = 8 * 72;               // float2 per frame in flight: rows of 64 (+8) / 8 x 8 rows of 8 (+1) / 512 in natural order
+constexpr int kScratch = 8 * 80;               // float2 per frame in flight: rows of 64 (+8) / 8 x 8 rows of 8 (+1) / 512 in natural order, rows of 64 skewed to 80
 // Frames a wave transforms at a time.  Measured (BASELINE configs[2] batch): two frames in flight on 64-frame tiles (the LDS
 // budget of a second scratch set) 4.5 ms against 3.4 ms -- the transform is bound by LDS throughput (26 KB of transposes per
 // frame, stores at ~80 B/clk), not by the latency a second chain would hide.
@@ -72,20 +75,21 @@ __device__ __forceinline__ void dft8(f2 (&v)[8])
 }
 
 template <int KB>
-__global__ void __launch_bounds__(kBlock, 2)
+__global__ void __launch_bounds__(kBlock)
 fft1k_net_kernel(const StftDesc sd_, const MlpxDesc d, const float *__restrict__ samples, int64_t stride, int64_t J, int64_t E,
                  int tiles_per_channel, int tiles_per_run, float *__restrict__ outputs, uint8_t *__restrict__ flags)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // LDS: first-layer fragments | columns hi | columns lo | tap products | per-frame sums, exponents | transform scratch
+    // LDS: first-layer fragments | columns hi | columns lo | per-frame sums, exponents | transform scratch, whose first part
+    // holds the tap products once the tile's transforms are done (a barrier apart)
     const int CS = d.col_stride, PS = d.p_stride;
     uint32x4 *afr = reinterpret_cast<uint32x4 *>(smem);
     _Float16 *colh = reinterpret_cast<_Float16 *>(smem + 3 * KB * 2 * 1024);
     _Float16 *coll = colh + kTile * CS;
-    float *pbuf = reinterpret_cast<float *>(coll + kTile * CS);
-    float *ssf = pbuf + kTile * PS;                                  // [tile] per-frame sums of squares (true units)
+    float *ssf = reinterpret_cast<float *>(coll + kTile * CS);       // [tile] per-frame sums of squares (true units)
     float *fsc = ssf + kTile;                                        // [tile] 2^-fe: a frame's products back to true units
-    f2 *scratch = reinterpret_cast<f2 *>(fsc + kTile);               // [8 waves][kFly][kScratch]
+    f2 *scratch = reinterpret_cast<f2 *>(fsc + kTile);               // [waves][kFly][kScratch]
+    float *pbuf = reinterpret_cast<float *>(scratch);                // [tile][PS]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -125,6 +129,7 @@ fft1k_net_kernel(const StftDesc sd_, const MlpxDesc d, const float *__restrict__
         tw1[a] = w1024(2 * lane * a);                             // W512^(b c), b = lane, c = a
         tw2[a] = w1024(16 * lo3 * a);                             // W64^(b' c'), b' = lane & 7, c' = a
     }
+    auto nat = [](int k) { return (k & 63) + 2 * ((k >> 3) & 7) + 80 * (k >> 6); };   // where Z[k] sits in the skewed natural-order image
     f2 swr[2];
     int kbin[2];
 #pragma unroll
@@ -211,8 +216,10 @@ fft1k_net_kernel(const StftDesc sd_, const MlpxDesc d, const float *__restrict__
                 f2 *buf = buf0 + u * kScratch;
                 dft8(v[u]);                                       // over b' -> index d'
 #pragma unroll
-                for (int dd = 0; dd < 8; dd++)                    // Z[c + 8 c' + 64 d'], natural order
-                    if (need & (1u << dd)) buf[hi3 + 8 * lo3 + 64 * dd] = v[u][dd];
+                // Z[c + 8 c' + 64 d'] in natural order, every row of eight skewed by two elements (a lane group of 16 holds two
+                // values of c and all eight of c': without the skew the eight land on two sets of banks, a 4-way conflict)
+                for (int dd = 0; dd < 8; dd++)
+                    if (need & (1u << dd)) buf[hi3 + 10 * lo3 + 80 * dd] = v[u][dd];
             }
             __builtin_amdgcn_wave_barrier();
             // real split + |X| of this lane's bins (2X[k] = (Z[k] + conj Z[M-k]) - i e^{-2 pi i k/N} (Z[k] - conj Z[M-k]),
@@ -223,7 +230,7 @@ fft1k_net_kernel(const StftDesc sd_, const MlpxDesc d, const float *__restrict__
                 const f2 *buf = buf0 + u * kScratch;
 #pragma unroll
                 for (int it = 0; it < 2; it++) {
-                    const f2 zk = buf[kbin[it]], zm = buf[512 - kbin[it]];
+                    const f2 zk = buf[nat(kbin[it])], zm = buf[nat(512 - kbin[it])];
                     const float ar = zk.x + zm.x, ai = zk.y - zm.y, br = zk.x - zm.x, bi = zk.y + zm.y;
                     const float tre = br * swr[it].x - bi * swr[it].y, tim = br * swr[it].y + bi * swr[it].x;
                     const float re2 = ar + tim, im2 = ai - tre;
@@ -315,7 +322,7 @@ fft1k_net_kernel(const StftDesc sd_, const MlpxDesc d, const float *__restrict__
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y), out_rs, st ? (unsigned)e * 4u : 0xFFFFFFFFu, 0, 0);
             __builtin_amdgcn_raw_buffer_store_b8((unsigned char)((double)y >= thr ? 1 : 0), flg_rs, st ? (unsigned)e : 0xFFFFFFFFu, 0, 0);
         }
-        __syncthreads();
+        __syncthreads();                              // (the products are read: the scratch they sit in is free for the next tile's transforms)
         // ---- the last T - 1 frames are the next tile's first: their columns, sums and exponents move to the front
         if (tr + 1 < tiles_per_run) {
             const int words = (T - 1) * (CS / 2);     // 32-bit words per array
@@ -361,7 +368,8 @@ hipError_t launch_fft1k_net(const StftDesc &s, const MlpxDesc &d, const float *s
     auto kern = fft1k_net_kernel<4>;
     // LDS: the matrix-core stage's layout (fragments, columns, products, per-frame sums) with the transform's scratch where the
     // per-quad sums of the two-launch form were
-    const int lds = 3 * 4 * 2 * 1024 + 2 * kTile * d.col_stride * 2 + kTile * d.p_stride * 4 + 2 * kTile * 4 + (kBlock / 64) * kFly * kScratch * 8;
+    const int scratch = (kBlock / 64) * kFly * kScratch * 8, products = kTile * d.p_stride * 4;
+    const int lds = 3 * 4 * 2 * 1024 + 2 * kTile * d.col_stride * 2 + 2 * kTile * 4 + (scratch > products ? scratch : products);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     hipError_t st = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (st != hipSuccess) return st;
