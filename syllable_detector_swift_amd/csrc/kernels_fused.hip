@@ -342,10 +342,12 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
                     if (norm == 1) gthr = d.guard_c;
                     else if (norm == 0) gthr = cse_pp < d.guard_se_abs_c ? d.guard_rel_c : 0.0f;
                     else gthr = d.guard_c_range;
-                    if (norm == 2) {
+                    if (norm == 2) {                          // (min / max and mean / M2 are kept in true units: onto the grid)
                         float mn = INFINITY, mx = -INFINITY;
                         for (int t = 0; t < T; t++) { mn = fminf(mn, stat[wslot + t]); mx = fmaxf(mx, stat[PS + wslot + t]); }
-                        gstat = mx - mn;
+                        gstat = (mx - mn) * cs;
+                    } else if (norm == 3) {
+                        gstat = ssw * cs;
                     } else if (norm == 0) {                   // every column on its own: the quietest one of the window
                         float mn = INFINITY;
                         for (int t = 0; t < T; t++) mn = fminf(mn, stat[wslot + t]);

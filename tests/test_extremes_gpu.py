@@ -92,3 +92,33 @@ def test_extreme_inputs_spectrogram(oracle_lib, name, spectrum):
     util.assert_columns_close(cols[ok], want[ok])
     if names == ["fused_kernel (spectrogram)"]:
         assert over == 0 and (items > 0) == (name in ("one inf", "step 1e12"))
+
+
+@pytest.mark.parametrize("chain", [(), ("l2normalize",), ("l2normalize", "mapminmax"), ("normalize",), ("normalizestd", "mapstd"), ("mapstd", "mapminmax")])
+@pytest.mark.parametrize("level", [1.0, 1e-3])
+def test_guard_stays_quiet_on_ordinary_audio(oracle_lib, chain, level):
+    """The slow, exact path is for what the grid cannot hold.  Ordinary audio at an ordinary level -- any input chain, both
+    fused kernels (4 and 8 hidden units) -- must never reach it: a guard that cries wolf costs a factor of three in speed
+    without anyone noticing (results are right either way)."""
+    import torch
+    from syllable_detector_swift_amd import nets
+    base = util.sample_net()
+    rng = np.random.default_rng(12)
+    x = (synth.channels(2, 132 * 700 + 256, first=3) * level).astype(np.float32)
+    for H in (4, 8):
+        cfg = nets.variant(base, net=nets.random_net(rng, 290, (H,), 1, in_fns=chain))
+        with sd.SyllableDetector(cfg, channels=2) as det:
+            out, fl = det.run(torch.from_numpy(x).cuda())
+            torch.cuda.synchronize()
+            assert det.geometry.engine == 2
+            assert det.fixupStats() == (0, 0), (chain, H, det.fixupStats())
+            out = out.cpu().numpy()
+        o = util.oracle_for(cfg)
+        for c in range(2):
+            w32, _, w64 = o.run(x[c], po.F64)
+            own = float(np.abs(w32 - w64).max())
+            bar = np.full(w64.shape[0], max(util.TOL, 4 * own))
+            if not chain or chain[0] not in ("l2normalize", "normalize", "normalizestd"):
+                cols = o.spectrogram(x[c], po.F64)
+                bar = np.maximum(bar, util.TOL * np.array([cols[e:e + 10].max() for e in range(w64.shape[0])]))
+            util.assert_outputs_close(out[c], w64, bar)

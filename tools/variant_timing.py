@@ -31,9 +31,10 @@ for name, cfg in cases.items():
         fl = torch.empty((C, E), dtype=torch.uint8, device="cuda")
         det.profile(True)
         ms = []
-        for i in range(6):
+        for i in range(14):
             det.run(x, out, fl)
-            if i >= 2:
+            if i >= 4:
                 ms.append(det.lastTimings()[0][1])
         J = det.countFrames(S)
-        print("%-26s %.3f ms   %.3g frames/s" % (name, sum(ms) / len(ms), C * J / (sum(ms) / len(ms) * 1e-3)), flush=True)
+        torch.cuda.synchronize()
+        print("%-26s %-16s %.3f ms   %.3g frames/s   guard work items %d" % (name, det.lastTimings()[0][0], sum(ms) / len(ms), C * J / (sum(ms) / len(ms) * 1e-3), det.fixupStats()[0]), flush=True)
