@@ -74,6 +74,91 @@ __device__ __forceinline__ void dft8(f2 (&v)[8])
     dft4(b, v[1], v[3], v[5], v[7]);
 }
 
+// The two transposes between the radix-8 passes, in registers.  A wave holds a frame as 8 complex registers x 64 lanes; pass 2
+// wants register index <-> lane bits 3..5 exchanged, pass 3 register index <-> lane bits 0..2.  An 8 x 8 transpose is three
+// rounds of 2 x 2 block swaps (register bit s against one lane bit): for a register pair (a, b) the lanes whose bit is 1 take
+// the partner lane's b into a, the lanes whose bit is 0 take the partner's a into b.  gfx950 has the swap itself for lane bits
+// 4 and 5 (v_permlane16_swap / v_permlane32_swap: one instruction a pair), masked DPP row shifts do bits 2 and 3 (two
+// instructions a pair), bits 0 and 1 take a quad permute and a select.  ~110 vector instructions replace 16 KB of LDS traffic
+// and two LDS round trips per frame.
+template <int CTRL_A, int BANK_A, int CTRL_B, int BANK_B>
+__device__ __forceinline__ void swap_dpp_masked(float &a, float &b)
+{
+    const int na = __builtin_amdgcn_update_dpp((int)__float_as_uint(a), (int)__float_as_uint(b), CTRL_A, 0xF, BANK_A, false);
+    const int nb = __builtin_amdgcn_update_dpp((int)__float_as_uint(b), (int)__float_as_uint(a), CTRL_B, 0xF, BANK_B, false);
+    a = __uint_as_float((unsigned)na);
+    b = __uint_as_float((unsigned)nb);
+}
+template <int CTRL>
+__device__ __forceinline__ void swap_dpp_select(float &a, float &b, bool bit)
+{
+    const float pb = __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(b), CTRL, 0xF, 0xF, false));
+    const float pa = __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(a), CTRL, 0xF, 0xF, false));
+    a = bit ? pb : a;
+    b = bit ? b : pa;
+}
+__device__ __forceinline__ void transpose_hi(f2 (&v)[8])          // register bits 0, 1, 2 <-> lane bits 3, 4, 5
+{
+#pragma unroll
+    for (int r = 0; r < 8; r += 2) {                              // lane bit 3: l ^ 8 = row_ror:8; lanes 8-15 of a row are banks 2, 3
+        float ax = v[r].x, ay = v[r].y, bx = v[r + 1].x, by = v[r + 1].y;
+        swap_dpp_masked<0x128, 0xC, 0x128, 0x3>(ax, bx);
+        swap_dpp_masked<0x128, 0xC, 0x128, 0x3>(ay, by);
+        v[r] = f2{ax, ay};
+        v[r + 1] = f2{bx, by};
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {                                 // lane bit 4
+        const int r = (k & 1) + 4 * (k >> 1);
+        auto sx = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[r].x), __float_as_uint(v[r + 2].x), false, false);
+        auto sy = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[r].y), __float_as_uint(v[r + 2].y), false, false);
+        v[r] = f2{__uint_as_float(sx[0]), __uint_as_float(sy[0])};
+        v[r + 2] = f2{__uint_as_float(sx[1]), __uint_as_float(sy[1])};
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {                                 // lane bit 5
+        auto sx = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[r].x), __float_as_uint(v[r + 4].x), false, false);
+        auto sy = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[r].y), __float_as_uint(v[r + 4].y), false, false);
+        v[r] = f2{__uint_as_float(sx[0]), __uint_as_float(sy[0])};
+        v[r + 4] = f2{__uint_as_float(sx[1]), __uint_as_float(sy[1])};
+    }
+}
+__device__ __forceinline__ void transpose_lo(f2 (&v)[8], int lane)   // register bits 0, 1, 2 <-> lane bits 0, 1, 2
+{
+    const bool b0 = lane & 1, b1 = lane & 2;
+#pragma unroll
+    for (int r = 0; r < 8; r += 2) {                              // lane bit 0: quad_perm [1, 0, 3, 2]
+        float ax = v[r].x, ay = v[r].y, bx = v[r + 1].x, by = v[r + 1].y;
+        swap_dpp_select<0xB1>(ax, bx, b0);
+        swap_dpp_select<0xB1>(ay, by, b0);
+        v[r] = f2{ax, ay};
+        v[r + 1] = f2{bx, by};
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {                                 // lane bit 1: quad_perm [2, 3, 0, 1]
+        const int r = (k & 1) + 4 * (k >> 1);
+        float ax = v[r].x, ay = v[r].y, bx = v[r + 2].x, by = v[r + 2].y;
+        swap_dpp_select<0x4E>(ax, bx, b1);
+        swap_dpp_select<0x4E>(ay, by, b1);
+        v[r] = f2{ax, ay};
+        v[r + 2] = f2{bx, by};
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {                                 // lane bit 2: lanes 4-7, 12-15 (banks 1, 3) read l - 4 (row_shr:4), the others l + 4
+        float ax = v[r].x, ay = v[r].y, bx = v[r + 4].x, by = v[r + 4].y;
+        swap_dpp_masked<0x114, 0xA, 0x104, 0x5>(ax, bx);
+        swap_dpp_masked<0x114, 0xA, 0x104, 0x5>(ay, by);
+        v[r] = f2{ax, ay};
+        v[r + 4] = f2{bx, by};
+    }
+}
+
+// Which of the two goes through registers (A/B builds: -DSYLDET_FFT1K_T=0 both through LDS, 1 the first, 2 the second, 3 both)
+#ifndef SYLDET_FFT1K_T
+#define SYLDET_FFT1K_T 1
+#endif
+constexpr bool kRegT1 = (SYLDET_FFT1K_T & 1) != 0, kRegT2 = (SYLDET_FFT1K_T & 2) != 0;
+
 template <int KB>
 __global__ void __launch_bounds__(kBlock)
 fft1k_net_kernel(const StftDesc sd_, const MlpxDesc d, const float *__restrict__ samples, int64_t stride, int64_t J, int64_t E,
@@ -185,32 +270,48 @@ fft1k_net_kernel(const StftDesc sd_, const MlpxDesc d, const float *__restrict__
             for (int u = 0; u < kFly; u++) {
                 f2 *buf = buf0 + u * kScratch;
                 dft8(v[u]);                                       // over a -> index c
+                if (kRegT1) {
 #pragma unroll
-                for (int cc = 0; cc < 8; cc++) buf[cc * 72 + lane] = cc ? cmul(v[u][cc], tw1[cc]) : v[u][cc];
+                    for (int cc = 1; cc < 8; cc++) v[u][cc] = cmul(v[u][cc], tw1[cc]);
+                    transpose_hi(v[u]);                           // lane = (c, b'), registers a': y[c][8 a' + b']
+                } else {
+#pragma unroll
+                    for (int cc = 0; cc < 8; cc++) buf[cc * 72 + lane] = cc ? cmul(v[u][cc], tw1[cc]) : v[u][cc];
+                }
             }
-            __builtin_amdgcn_wave_barrier();
+            if (!kRegT1) {
+                __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int u = 0; u < kFly; u++) {
-                const f2 *buf = buf0 + u * kScratch;
+                for (int u = 0; u < kFly; u++) {
+                    const f2 *buf = buf0 + u * kScratch;
 #pragma unroll
-                for (int a = 0; a < 8; a++) v[u][a] = buf[hi3 * 72 + 8 * a + lo3];    // lane = (c, b'): y[c][8 a' + b']
+                    for (int a = 0; a < 8; a++) v[u][a] = buf[hi3 * 72 + 8 * a + lo3];    // lane = (c, b'): y[c][8 a' + b']
+                }
+                __builtin_amdgcn_wave_barrier();
             }
-            __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int u = 0; u < kFly; u++) {
                 f2 *buf = buf0 + u * kScratch;
                 dft8(v[u]);                                       // over a' -> index c'
+                if (kRegT2) {
 #pragma unroll
-                for (int cc = 0; cc < 8; cc++) buf[(hi3 * 8 + cc) * 9 + lo3] = cc ? cmul(v[u][cc], tw2[cc]) : v[u][cc];
+                    for (int cc = 1; cc < 8; cc++) v[u][cc] = cmul(v[u][cc], tw2[cc]);
+                    transpose_lo(v[u], lane);                     // lane = (c, c'), registers b': z[c][c'][b']
+                } else {
+#pragma unroll
+                    for (int cc = 0; cc < 8; cc++) buf[(hi3 * 8 + cc) * 9 + lo3] = cc ? cmul(v[u][cc], tw2[cc]) : v[u][cc];
+                }
             }
-            __builtin_amdgcn_wave_barrier();
+            if (!kRegT2) {
+                __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int u = 0; u < kFly; u++) {
-                const f2 *buf = buf0 + u * kScratch;
+                for (int u = 0; u < kFly; u++) {
+                    const f2 *buf = buf0 + u * kScratch;
 #pragma unroll
-                for (int a = 0; a < 8; a++) v[u][a] = buf[(hi3 * 8 + lo3) * 9 + a];   // lane = (c, c'): z[c][c'][b']
+                    for (int a = 0; a < 8; a++) v[u][a] = buf[(hi3 * 8 + lo3) * 9 + a];   // lane = (c, c'): z[c][c'][b']
+                }
+                __builtin_amdgcn_wave_barrier();
             }
-            __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int u = 0; u < kFly; u++) {
                 f2 *buf = buf0 + u * kScratch;

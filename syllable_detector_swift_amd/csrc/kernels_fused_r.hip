@@ -57,7 +57,7 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
                float *__restrict__ outputs, uint8_t *__restrict__ flags)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float *red = reinterpret_cast<float *>(smem + d.r_lds_red);      // [pass parity][4 waves] block-max partials
+    float *red = reinterpret_cast<float *>(smem + d.r_lds_red);      // [4 waves] block-max partials
     float *cst = reinterpret_cast<float *>(smem + d.r_lds_cst);
     const int T = d.T;                    // timeRange (taps past it are rows of zeros in the first-layer fragments)
 
@@ -119,7 +119,7 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
     auto pass_rsrc = [&](int p) {
         return tile_rsrc(row, (e_b + (int64_t)kPass * p) * d.hop + d.gap, p < runs ? s_eff : 0, d.r_nsmp);
     };
-    auto max_partial = [&](const uint32x4 (&v)[NL], int par) {
+    auto max_partial = [&](const uint32x4 (&v)[NL]) {
         float amax = 0.0f;
 #pragma unroll
         for (int k = 0; k < NL; k++) {
@@ -127,7 +127,7 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
             amax = absmax3(absmax3(amax, q[0], q[1]), q[2], q[3]);
         }
         amax = wave_max_nonneg(amax);
-        if (lane == 0) red[4 * par + wave] = amax;
+        if (lane == 0) red[wave] = amax;
     };
     // (status of the pass for the precision guard: 0 fine, 1 silent -- all samples zero, its columns are exact zeros --, 2 the
     // grid cannot hold it: an infinite sample, or a level above 2^113; a level below 2^-100 only loses headroom, which the
@@ -140,7 +140,7 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
         e = amax > 0.0f ? (e < -100 ? -100 : (e > 113 ? 113 : e)) : 0;       // (2^(-e - 13) must stay a normal number)
         return __builtin_amdgcn_readfirstlane(e);
     };
-    auto pass_scale = [&](int &status) { return scale_of(*reinterpret_cast<const floatx4 *>(red), status); };   // (pass 0)
+    auto pass_scale = [&](int &status) { return scale_of(*reinterpret_cast<const floatx4 *>(red), status); };
     // where this thread's quad k lands in a staged buffer (halves): 4 tid + 1024 k, with SKEW + 4 ((4 tid + 1024 k) >> 7)
     const int sbase = SKEW ? 4 * tid + 4 * (tid >> 5) : 4 * tid;
     constexpr int kinc = SKEW ? 4 * kBlock + 32 : 4 * kBlock;
@@ -155,8 +155,7 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
         const __amdgpu_buffer_rsrc_t rs1 = pass_rsrc(1);          // pass 1 follows at once: one exposed round trip, not two
 #pragma unroll
         for (int k = 0; k < NL; k++) v1[k] = __builtin_amdgcn_raw_buffer_load_b128(rs1, 16 * tid + 16 * kBlock * k, 0, 0);
-        max_partial(v0, 0);
-        max_partial(v1, 1);
+        max_partial(v0);
         __syncthreads();
         se_cur = pass_scale(st_cur);
         const float sx = pow2f(se_cur);
@@ -171,6 +170,8 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
             *reinterpret_cast<uint32x2 *>(ph) = uh;
             *reinterpret_cast<uint32x2 *>(ph + d.r_smp_stride) = ul;
         }
+        __syncthreads();                  // every wave has read the partial maxima of pass 0
+        max_partial(v1);
         __syncthreads();
     }
     // diagnostic instantiation only (SYLDET_FUSED_STAMPS=1): s_memtime at the phase boundaries of every pass
@@ -343,28 +344,25 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
     // segment's first pass (* 2^dsc, dsc = se(first) - se: a power of two), so that a window may straddle passes of
     // different scales.  Micro-steps j = 0 .. kMagSteps-1.
     constexpr int kMagSteps = 23;
-    floatx2 cv2[4];                       // sqrt(re^2 + im^2) of this lane's eight bins, still on the accumulators' scale
-    float mss = 0.0f, fs_ring = 1.0f;
-    floatx2 fsk2 = {1.0f, 1.0f};
+    float cval[8], mss = 0.0f, fs_up = 1.0f, fs_ring = 1.0f;
     unsigned bh[4], bl[4];
     floatx4 pt[3];
-    const float kmag = pow2f(-13 - d.col_shift), kmag2 = pow2f(2 * (-13 - d.col_shift));
-    // (inblock: called from the matrix block, where DFT MFMAs and other work sit between the steps; the drain calls the steps back to back)
-    auto mag_micro = [&](int j, int rm, int dsc, bool inblock) {
+    const float kmag = pow2f(-13 - d.col_shift);
+    auto mag_micro = [&](int j, int rm, int dsc) {
         // this frame's row in the ring; the ring's last T-1 frames are repeated in front of it (elsewhere: a spare spot)
         float *prow = pbuf + (kPLead + 64 * rm + fl) * kPStride;
         float *drow = (rm == 2 && fl >= kPass - (T - 1)) ? pbuf + (kPLead + fl - kPass) * kPStride : nullptr;
         float *spare = pbuf + (kPRows - 1) * kPStride;             // floats 0 .. 35 and 49 .. of the last row: where lanes with nothing to store store
-        if (j < 8) {                                              // |X| of one bin (the power of two kmag joins the sums below)
+        if (j < 8) {                                              // |X| of one bin
             const int i = j;
             float re = accP[i >> 2][i & 3], im = accP[2 + (i >> 2)][i & 3];
-            cv2[i >> 1][i & 1] = __builtin_amdgcn_sqrtf(fmaf(re, re, im * im));
+            cval[i] = __builtin_amdgcn_sqrtf(fmaf(re, re, im * im)) * kmag;
         } else if (j < 12) {                                      // the frame's sum of squares (l2normalize works from these)
-            const int i = j - 8;
+            const int i = 2 * (j - 8);
             if (j == 8) mss = 0.0f;
-            mss = fmaf(cv2[i][0], cv2[i][0], mss);
-            mss = fmaf(cv2[i][1], cv2[i][1], mss);
-            if (j == 11) mss = xor32_sum(xor16_sum(mss)) * kmag2;
+            mss = fmaf(cval[i], cval[i], mss);
+            mss = fmaf(cval[i + 1], cval[i + 1], mss);
+            if (j == 11) mss = xor32_sum(xor16_sum(mss));
         } else if (j == 12) {
             const float sr = mss * pow2f(2 * dsc);
             *(g4 == 0 ? prow + 48 : spare + 49) = sr;
@@ -375,23 +373,18 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
             // t = floor((ex + 1) / 2) = floor(log2 sqrt(mss)) + 64, clamped to [16, 80]: fs_up = 2^(76 - t).
             unsigned tb = ((__float_as_uint(mss) + 0x800000u) >> 1) & 0x7f800000u;    // t << 23
             tb = (unsigned)min(max((int)tb, 16 << 23), 80 << 23);                    // v_med3_i32 (NaN / inf: 80; zero: 16)
-            const float fsk = __uint_as_float((203u << 23) - tb) * kmag;      // fs_up * kmag: what takes cv2 to the split's scale
-            fsk2 = floatx2{fsk, fsk};
+            fs_up = __uint_as_float((203u << 23) - tb);
             fs_ring = __uint_as_float(tb + ((unsigned)(dsc + 51) << 23));
-        } else if (j < 15) {                                      // f16 hi + lo of four bins: half of the B operand pair (the
-            const int m = j - 13;                                 // staging's split: same bits as v_fma_mixlo/hi_f16, fewer slots)
-            floatx2 ta, tb2;
-            float ra, rb, rc, rd;
-            asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(ta) : "v"(cv2[2 * m]), "v"(fsk2));
-            asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(tb2) : "v"(cv2[2 * m + 1]), "v"(fsk2));
-            asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(bh[2 * m]) : "v"(ta[0]), "v"(ta[1]));
-            asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(bh[2 * m + 1]) : "v"(tb2[0]), "v"(tb2[1]));
-            asm volatile("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(ra) : "v"(cv2[2 * m][0]), "v"(fsk2[0]), "v"(bh[2 * m]));
-            asm volatile("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(rc) : "v"(cv2[2 * m + 1][0]), "v"(fsk2[0]), "v"(bh[2 * m + 1]));
-            asm volatile("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(rb) : "v"(cv2[2 * m][1]), "v"(fsk2[0]), "v"(bh[2 * m]));
-            asm volatile("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(rd) : "v"(cv2[2 * m + 1][1]), "v"(fsk2[0]), "v"(bh[2 * m + 1]));
-            asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(bl[2 * m]) : "v"(ra), "v"(rb));
-            asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(bl[2 * m + 1]) : "v"(rc), "v"(rd));
+        } else if (j < 15) {                                      // f16 hi + lo of four bins: half of the B operand pair
+            const int m = j - 13;
+            asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(bh[2 * m]) : "v"(cval[4 * m]), "v"(fs_up));
+            asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(bh[2 * m + 1]) : "v"(cval[4 * m + 2]), "v"(fs_up));
+            asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(bh[2 * m]) : "v"(cval[4 * m + 1]), "v"(fs_up));
+            asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(bh[2 * m + 1]) : "v"(cval[4 * m + 3]), "v"(fs_up));
+            asm volatile("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(bl[2 * m]) : "v"(cval[4 * m]), "v"(fs_up), "v"(bh[2 * m]));
+            asm volatile("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(bl[2 * m + 1]) : "v"(cval[4 * m + 2]), "v"(fs_up), "v"(bh[2 * m + 1]));
+            asm volatile("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(bl[2 * m]) : "v"(cval[4 * m + 1]), "v"(fs_up), "v"(bh[2 * m]));
+            asm volatile("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(bl[2 * m + 1]) : "v"(cval[4 * m + 3]), "v"(fs_up), "v"(bh[2 * m + 1]));
         } else if (j >= 16 && j < 19) {                           // tap products: hi*hi, hi*lo, lo*hi, one term of every row tile a step
             const uint32x4 vbh = {bh[0], bh[1], bh[2], bh[3]}, vbl = {bl[0], bl[1], bl[2], bl[3]};
 #pragma unroll
@@ -402,12 +395,7 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
             }
         } else if (j >= 20) {                                     // tile m: taps 4m + g4, units 0..3 of this frame -> its row
             const int m = j - 20;
-            // (eight wait states behind the last tap MFMA; in the block two ticks -- two DFT MFMAs, a load, two staging steps --
-            // lie between, the drain has nothing there)
-            if (m == 0) {
-                if (inblock) asm volatile("s_nop 3" : "+v"(pt[0]), "+v"(pt[1]), "+v"(pt[2]));
-                else asm volatile("s_nop 7" : "+v"(pt[0]), "+v"(pt[1]), "+v"(pt[2]));
-            }
+            if (m == 0) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(pt[0]), "+v"(pt[1]), "+v"(pt[2]));
             const floatx4 r = pt[m] * fs_ring;
             *reinterpret_cast<floatx4 *>(prow + 4 * (4 * m + g4)) = r;
             *reinterpret_cast<floatx4 *>((drow ? drow : spare) + 4 * (4 * m + g4) - (drow ? 0 : 4 * g4)) = r;
@@ -429,18 +417,14 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
         uint32x4 (&vl)[NL] = par ? v1 : v0;                           // pass q+2's samples: loaded in this block, maximum taken at its end
         const _Float16 *fph = smp0 + par * buf_halves + foff, *fpl = fph + d.r_smp_stride;
         half8 bh = lds_half8(fph + ko[0]), bl = lds_half8(fpl + ko[0]);   // first B fragments: all the first MFMA waits for
-        floatx4 r0 = *reinterpret_cast<const floatx4 *>(red + 4 * (par ^ 1));   // pass q+1's partial maxima
-        // pass q+2's go to the other quad (last read a block ago): this wave's slot starts from zero, and the cross-lane step
-        // of the maximum is an LDS atomic of all lanes on it (one issue slot instead of a six-step butterfly with its wait states)
-        unsigned *redw = reinterpret_cast<unsigned *>(red) + 4 * par + wave;
-        *redw = 0u;
+        floatx4 r0 = *reinterpret_cast<const floatx4 *>(red);             // pass q+1's partial maxima
         // In the shadow of those fetches: the vector half of finishing pass q-1 (magnitudes, sum of squares, f16 split; it
         // needs nothing but the accumulators this wave kept), which would otherwise crowd the second half of the block.
         const int dsc = se_ref - se_m1 < -45 ? -45 : (se_ref - se_m1 > 45 ? 45 : se_ref - se_m1);   // (beyond: the guard's business)
         const int rm = r3 == 0 ? 2 : r3 - 1, re = r3 == 2 ? 0 : r3 + 1;   // (q - 1) mod 3, (q - 2) mod 3
 #if !defined(SYLDET_R_NOMAG) && !defined(SYLDET_R_MAGTICK)
 #pragma unroll
-        for (int j = 0; j < 15; j++) mag_micro(j, rm, dsc, true);
+        for (int j = 0; j < 15; j++) mag_micro(j, rm, dsc);
 #endif
         SD_PIN(r0);
         int st_next;
@@ -463,33 +447,23 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
         {
             // the next pass's staging (scale, f16 hi/lo split, two LDS writes), one instruction per micro-step, one
             // micro-step a tick: v_fma_mix runs at half rate, one rides under an MFMA and a second one does not (tools/ubench)
-            // The split, priced on a lone wave (tools/ubench/valu_rates): a v_fma_mixlo/hi_f16 takes two issue slots and a
-            // partial write of a register another wait state; v_pk_mul_f32 (1.3 slots), v_cvt_pk_f16_f32 and v_fma_mix_f32 (one
-            // each) give the same bits -- x*s is exact (s a power of two), hi = RNE(x*s), x*s - hi is exact in fp32, lo = RNE of
-            // it -- for 5.3 slots a pair of samples instead of 9.
             unsigned mh0 = 0, ml0 = 0, mh1 = 0, ml1 = 0;
-            floatx2 t01 = {0.f, 0.f}, t23 = {0.f, 0.f};
-            float l0 = 0.f, l1 = 0.f, l2 = 0.f, l3 = 0.f;
-            const floatx2 sx2 = {sx_next, sx_next};
-            constexpr int kStageSteps = 12;
             auto stage_micro = [&](int i) {
-                const int k = i / kStageSteps, j = i % kStageSteps;
+                const int k = i / 10, j = i % 10;
                 if (k >= NL) return;
                 const floatx4 qv = as_floatx4(vs[k]);
-                const floatx2 q01 = {qv[0], qv[1]}, q23 = {qv[2], qv[3]};
-                if (j == 0) asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(t01) : "v"(q01), "v"(sx2));
-                if (j == 1) asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(t23) : "v"(q23), "v"(sx2));
-                if (j == 2) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(mh0) : "v"(t01[0]), "v"(t01[1]));
-                if (j == 3) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(mh1) : "v"(t23[0]), "v"(t23[1]));
-                if (j == 4) asm volatile("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l0) : "v"(qv[0]), "v"(sx_next), "v"(mh0));
-                if (j == 5) asm volatile("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l2) : "v"(qv[2]), "v"(sx_next), "v"(mh1));
-                if (j == 6) asm volatile("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(l1) : "v"(qv[1]), "v"(sx_next), "v"(mh0));
-                if (j == 7) asm volatile("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(l3) : "v"(qv[3]), "v"(sx_next), "v"(mh1));
-                if (j == 8) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(ml0) : "v"(l0), "v"(l1));
-                if (j == 9) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(ml1) : "v"(l2), "v"(l3));
+                // (lo / hi halves of one register are never written by neighbouring instructions: that costs a wait state)
+                if (j == 0) asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(mh0) : "v"(qv[0]), "v"(sx_next));
+                if (j == 1) asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(mh1) : "v"(qv[2]), "v"(sx_next));
+                if (j == 2) asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(mh0) : "v"(qv[1]), "v"(sx_next));
+                if (j == 3) asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(mh1) : "v"(qv[3]), "v"(sx_next));
+                if (j == 4) asm volatile("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(ml0) : "v"(qv[0]), "v"(sx_next), "v"(mh0));
+                if (j == 5) asm volatile("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(ml1) : "v"(qv[2]), "v"(sx_next), "v"(mh1));
+                if (j == 6) asm volatile("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(ml0) : "v"(qv[1]), "v"(sx_next), "v"(mh0));
+                if (j == 7) asm volatile("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(ml1) : "v"(qv[3]), "v"(sx_next), "v"(mh1));
                 _Float16 *ph = wh + sbase + kinc * k;
-                if (j == 10) { uint32x2 uh = {mh0, mh1}; *reinterpret_cast<uint32x2 *>(ph) = uh; }
-                if (j == 11) { uint32x2 ul = {ml0, ml1}; *reinterpret_cast<uint32x2 *>(ph + d.r_smp_stride) = ul; }
+                if (j == 8) { uint32x2 uh = {mh0, mh1}; *reinterpret_cast<uint32x2 *>(ph) = uh; }
+                if (j == 9) { uint32x2 ul = {ml0, ml1}; *reinterpret_cast<uint32x2 *>(ph + d.r_smp_stride) = ul; }
             };
             // tick i: what rides behind the i-th DFT MFMA.  The loads of pass q+2 leave in the first ticks (the other staging
             // set is free) and have the whole block to land before the block maximum reads them in the last ticks; staging
@@ -502,8 +476,7 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
                 // (SYLDET_R_NO*: diagnostic builds with one piece knocked out, tools/r_knockouts.sh; never the shipped library)
                 if (i < NL) vl[i] = __builtin_amdgcn_raw_buffer_load_b128(rs2, 16 * tid + 16 * kBlock * i, 0, 0);
 #ifndef SYLDET_R_NOSTAGE
-                stage_micro(i + i / 8);                                // 12 NL = 108 micro-steps over 96 ticks: nine every eight ticks
-                if (i % 8 == 7) stage_micro(i + i / 8 + 1);
+                stage_micro(i);
 #endif
 #ifndef SYLDET_R_NOEVAL
                 if (i % 4 == 0) eval_slot(i / 4, q - 2, re, thr_m2);
@@ -512,10 +485,10 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
 #ifndef SYLDET_R_NOMAG
 #ifdef SYLDET_R_MAGTICK                // (experiment: the whole finishing of pass q-1 inside the block, from this tick on)
                 const int jm = i - SYLDET_R_MAGTICK;
-                if (jm >= 0 && jm < kMagSteps) mag_micro(jm, rm, dsc, true);
+                if (jm >= 0 && jm < kMagSteps) mag_micro(jm, rm, dsc);
 #else
                 const int jm = i + 14;                                 // pass q-1's tap products and their stores: the first ticks
-                if (i >= 1 && jm < kMagSteps) mag_micro(jm, rm, dsc, true);
+                if (i >= 1 && jm < kMagSteps) mag_micro(jm, rm, dsc);
 #endif
 #endif
 #ifndef SYLDET_R_NOMAX
@@ -529,13 +502,11 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
                     amax_run = absmax3(amax_run, qv[0], qv[1]);
                     amax_b = absmax3(amax_b, qv[2], qv[3]);
                 }
-                if (jx == NL) amax_run = fmaxf(amax_run, amax_b);            // v_max3 drops NaNs: plain non-negative numbers,
-                // ordered like their bit patterns (written as the instruction: the compiler would turn an atomic on a
-                // wave-uniform address into a 64-step scalar loop over the lanes)
-                if (jx == NL + 1) asm volatile("ds_max_u32 %0, %1" : : "v"(lds_addr(redw)), "v"(__float_as_uint(amax_run)) : "memory");
+                if (jx == NL) amax_run = wave_max_nonneg(fmaxf(amax_run, amax_b));   // v_max3 drops NaNs: plain non-negative numbers
+                if (jx == NL + 2 && lane == 0) red[wave] = amax_run;
 #endif
             };
-            static_assert(kStageSteps * NL <= kTicks + kTicks / 8 && TMAX <= 12 && TMAX - 1 <= kPLead, "tick schedule");
+            static_assert(10 * NL <= kTicks && TMAX <= 12 && TMAX - 1 <= kPLead, "tick schedule");
             // The DFT's accumulators live in the accumulation registers (an MFMA whose C/D operands are architectural
             // registers takes 9.9 ns against 8.4: tools/ubench), which the basis alone would fill: its last four quads are
             // architectural instead.
@@ -572,8 +543,7 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
                 }
             }
 #undef SD_DFT_MFMA
-            // (eight wait states between an MFMA of this shape and a vector read of its result: what the compiler places there)
-            asm volatile("s_nop 7" : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3]));
+            asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3]));
 #pragma unroll
             for (int m = 0; m < 4; m++) accP[m] = acc[m];
         }
@@ -613,7 +583,7 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
         }
         push_bad(q - 2);
 #pragma unroll
-        for (int j = 0; j < kMagSteps; j++) mag_micro(j, rm, dsc, false);
+        for (int j = 0; j < kMagSteps; j++) mag_micro(j, rm, dsc);
         __syncthreads();
 #pragma unroll
         for (int sl = 0; sl < 12; sl++) {

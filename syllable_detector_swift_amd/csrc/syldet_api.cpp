@@ -552,7 +552,7 @@ int run_on_stream(syldet *h, const float *d_samples, int64_t S, int64_t stride, 
             double sum[16] = {0};
             for (size_t i = 0; i < n; i++) sum[i % 16] += (double)host[i];
             double tot = 0;
-            for (int i = 0; i < 8; i++) tot += sum[i];            // wave 0's phases add up to the pass; wave 7's are a second view
+            for (int i = 0; i < 6; i++) tot += sum[i];            // wave 0's phases add up to the pass; wave 7's are a second view
             const char *names[16] = {"DFT(p) || evaluate(p-1) || block max(p+1)", "barrier 1", "carry + mag + columns", "stage next pass + issue loads",
                                             "barrier 0", "-", "-", "-", "wave 7: DFT || evaluate || block max", "wave 7: barrier 1", "wave 7: carry + mag + columns",
                                             "wave 7: stage + issue loads", "wave 7: barrier 0", "-", "-", "-"};
@@ -565,7 +565,9 @@ int run_on_stream(syldet *h, const float *d_samples, int64_t S, int64_t stride, 
             }
             std::fprintf(stderr, "[syldet stamps] runs=%d workgroups=%zu cycles/pass=%.0f\n", d.runs, n / 16, tot / ((double)(n / 16) * d.runs));
             for (int i = 0; i < 16; i++)
-                if (sum[i] > 0) std::fprintf(stderr, "   %-32s %6.0f cycles/pass  %5.1f %%\n", names[i], sum[i] / ((double)(n / 16) * d.runs), 100.0 * sum[i] / tot);
+                if (sum[i] > 0 && i % 8 < 6) std::fprintf(stderr, "   %-32s %6.0f cycles/pass  %5.1f %%\n", names[i], sum[i] / ((double)(n / 16) * d.runs), 100.0 * sum[i] / tot);
+            if (sum[7] > 0)       // (the register-resident-basis kernel's stamped build: whole segments in both clocks)
+                std::fprintf(stderr, "   segment: %.0f shader clocks in %.2f us: %.3f GHz\n", sum[6] / (double)(n / 16), sum[7] / (double)(n / 16) * 0.01, sum[6] / (sum[7] * 10.0));
             return SYLDET_OK;
         }
         // the precision guard's work list, and behind the fused kernel the exact recomputation of what it reports
