@@ -343,15 +343,19 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
     // X * 2^(se + 13); |X| * 2^(se - col_shift) is what is split; products and sums of squares are stored relative to the
     // segment's first pass (* 2^dsc, dsc = se(first) - se: a power of two), so that a window may straddle passes of
     // different scales.  Micro-steps j = 0 .. kMagSteps-1.
-    constexpr int kMagSteps = 23;
+    constexpr int kMagSteps = 27;
     float cval[8], mss = 0.0f, fs_up = 1.0f, fs_ring = 1.0f;
     unsigned bh[4], bl[4];
     floatx4 pt[3];
     const float kmag = pow2f(-13 - d.col_shift);
-    auto mag_micro = [&](int j, int rm, int dsc) {
+    // (inblock: called from the matrix block, where DFT MFMAs and other work sit between the steps; the drain calls them back to back)
+    auto mag_micro = [&](int j, int rm, int dsc, bool inblock) {
         // this frame's row in the ring; the ring's last T-1 frames are repeated in front of it (elsewhere: a spare spot)
         float *prow = pbuf + (kPLead + 64 * rm + fl) * kPStride;
-        float *drow = (rm == 2 && fl >= kPass - (T - 1)) ? pbuf + (kPLead + fl - kPass) * kPStride : nullptr;
+        // (only frames of the pass's last wave, in every third pass: those stores sit behind a test -- a wave has one LDS
+        // write in flight at a time, 55 clocks for a b128, so a store that is not needed is not free)
+        const bool dupl = rm == 2 && fl >= kPass - (T - 1);
+        float *drow = pbuf + (kPLead + fl - kPass) * kPStride;
         float *spare = pbuf + (kPRows - 1) * kPStride;             // floats 0 .. 35 and 49 .. of the last row: where lanes with nothing to store store
         if (j < 8) {                                              // |X| of one bin
             const int i = j;
@@ -366,7 +370,7 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
         } else if (j == 12) {
             const float sr = mss * pow2f(2 * dsc);
             *(g4 == 0 ? prow + 48 : spare + 49) = sr;
-            *((g4 == 0 && drow) ? drow + 48 : spare + 50) = sr;
+            if (dupl && g4 == 0) drow[48] = sr;
             // The frame's own column exponent: its column is split into f16 hi + lo at the scale that puts its norm into
             // [2^12, 2^13) -- a quiet frame of a loud pass keeps 22 bits of its own level instead of the pass's f16 floor --
             // and the products come back through fs_ring = 2^dsc / fs_up.  With ex the biased exponent of mss,
@@ -375,16 +379,21 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
             tb = (unsigned)min(max((int)tb, 16 << 23), 80 << 23);                    // v_med3_i32 (NaN / inf: 80; zero: 16)
             fs_up = __uint_as_float((203u << 23) - tb);
             fs_ring = __uint_as_float(tb + ((unsigned)(dsc + 51) << 23));
-        } else if (j < 15) {                                      // f16 hi + lo of four bins: half of the B operand pair
-            const int m = j - 13;
-            asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(bh[2 * m]) : "v"(cval[4 * m]), "v"(fs_up));
-            asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(bh[2 * m + 1]) : "v"(cval[4 * m + 2]), "v"(fs_up));
-            asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(bh[2 * m]) : "v"(cval[4 * m + 1]), "v"(fs_up));
-            asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(bh[2 * m + 1]) : "v"(cval[4 * m + 3]), "v"(fs_up));
-            asm volatile("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(bl[2 * m]) : "v"(cval[4 * m]), "v"(fs_up), "v"(bh[2 * m]));
-            asm volatile("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(bl[2 * m + 1]) : "v"(cval[4 * m + 2]), "v"(fs_up), "v"(bh[2 * m + 1]));
-            asm volatile("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(bl[2 * m]) : "v"(cval[4 * m + 1]), "v"(fs_up), "v"(bh[2 * m]));
-            asm volatile("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(bl[2 * m + 1]) : "v"(cval[4 * m + 3]), "v"(fs_up), "v"(bh[2 * m + 1]));
+        } else if (j < 15) {                                      // f16 hi + lo of four bins: half of the B operand pair (the
+            const int m = j - 13;                                 // staging's split: one-slot instructions, the same bits)
+            float ta, tb2, tc, td, ra, rb, rc, rd;
+            asm volatile("v_mul_f32 %0, %1, %2" : "=v"(ta) : "v"(cval[4 * m]), "v"(fs_up));
+            asm volatile("v_mul_f32 %0, %1, %2" : "=v"(tb2) : "v"(cval[4 * m + 1]), "v"(fs_up));
+            asm volatile("v_mul_f32 %0, %1, %2" : "=v"(tc) : "v"(cval[4 * m + 2]), "v"(fs_up));
+            asm volatile("v_mul_f32 %0, %1, %2" : "=v"(td) : "v"(cval[4 * m + 3]), "v"(fs_up));
+            asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(bh[2 * m]) : "v"(ta), "v"(tb2));
+            asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(bh[2 * m + 1]) : "v"(tc), "v"(td));
+            asm volatile("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(ra) : "v"(cval[4 * m]), "v"(fs_up), "v"(bh[2 * m]));
+            asm volatile("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(rc) : "v"(cval[4 * m + 2]), "v"(fs_up), "v"(bh[2 * m + 1]));
+            asm volatile("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(rb) : "v"(cval[4 * m + 1]), "v"(fs_up), "v"(bh[2 * m]));
+            asm volatile("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(rd) : "v"(cval[4 * m + 3]), "v"(fs_up), "v"(bh[2 * m + 1]));
+            asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(bl[2 * m]) : "v"(ra), "v"(rb));
+            asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(bl[2 * m + 1]) : "v"(rc), "v"(rd));
         } else if (j >= 16 && j < 19) {                           // tap products: hi*hi, hi*lo, lo*hi, one term of every row tile a step
             const uint32x4 vbh = {bh[0], bh[1], bh[2], bh[3]}, vbl = {bl[0], bl[1], bl[2], bl[3]};
 #pragma unroll
@@ -393,12 +402,19 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
                 if (j == 17) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(pt[m]) : "v"(aft[m][0]), "v"(vbl));
                 if (j == 18) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(pt[m]) : "v"(aft[m][1]), "v"(vbh));
             }
-        } else if (j >= 20) {                                     // tile m: taps 4m + g4, units 0..3 of this frame -> its row
+        } else if (j >= 20 && j < 23) {                           // tile m: taps 4m + g4, units 0..3 of this frame -> its row
             const int m = j - 20;
-            if (m == 0) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(pt[0]), "+v"(pt[1]), "+v"(pt[2]));
-            const floatx4 r = pt[m] * fs_ring;
-            *reinterpret_cast<floatx4 *>(prow + 4 * (4 * m + g4)) = r;
-            *reinterpret_cast<floatx4 *>((drow ? drow : spare) + 4 * (4 * m + g4) - (drow ? 0 : 4 * g4)) = r;
+            // (eight wait states behind the last tap MFMA; in the block two ticks -- two DFT MFMAs, a load, staging steps --
+            // lie between, the drain has nothing there)
+            if (m == 0) {
+                if (inblock) asm volatile("s_nop 3" : "+v"(pt[0]), "+v"(pt[1]), "+v"(pt[2]));
+                else asm volatile("s_nop 7" : "+v"(pt[0]), "+v"(pt[1]), "+v"(pt[2]));
+            }
+            pt[m] = pt[m] * fs_ring;
+            *reinterpret_cast<floatx4 *>(prow + 4 * (4 * m + g4)) = pt[m];
+        } else if (j >= 24) {                                     // the ring's last T-1 frames once more in front of it
+            const int m = j - 24;
+            if (dupl) *reinterpret_cast<floatx4 *>(drow + 4 * (4 * m + g4)) = pt[m];
         }
     };
 
@@ -424,7 +440,7 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
         const int rm = r3 == 0 ? 2 : r3 - 1, re = r3 == 2 ? 0 : r3 + 1;   // (q - 1) mod 3, (q - 2) mod 3
 #if !defined(SYLDET_R_NOMAG) && !defined(SYLDET_R_MAGTICK)
 #pragma unroll
-        for (int j = 0; j < 15; j++) mag_micro(j, rm, dsc);
+        for (int j = 0; j < 15; j++) mag_micro(j, rm, dsc, true);
 #endif
         SD_PIN(r0);
         int st_next;
@@ -447,23 +463,34 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
         {
             // the next pass's staging (scale, f16 hi/lo split, two LDS writes), one instruction per micro-step, one
             // micro-step a tick: v_fma_mix runs at half rate, one rides under an MFMA and a second one does not (tools/ubench)
+            // The split, priced next to an MFMA on a lone wave (tools/ubench/tick_costs): two plain vector instructions ride
+            // free behind every MFMA, a third costs an issue slot; v_fma_mixlo/hi_f16 takes two slots, a packed fp32
+            // instruction waits for the matrix pipe (+17 clocks), and a wave has one LDS write in flight per ~32 clocks (b64;
+            // ~55 for b128).  Hence: v_mul_f32, v_cvt_pk_f16_f32, v_fma_mix_f32 (one slot each; the same bits -- x*s is
+            // exact, s being a power of two, hi = RNE(x*s), x*s - hi is exact in fp32, lo = RNE of it), 12 slots a quad instead
+            // of 16, and the quad's two LDS writes seven steps apart.
             unsigned mh0 = 0, ml0 = 0, mh1 = 0, ml1 = 0;
+            float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f, l0 = 0.f, l1 = 0.f, l2 = 0.f, l3 = 0.f;
+            constexpr int kStageSteps = 14;
             auto stage_micro = [&](int i) {
-                const int k = i / 10, j = i % 10;
+                const int k = i / kStageSteps, j = i % kStageSteps;
                 if (k >= NL) return;
                 const floatx4 qv = as_floatx4(vs[k]);
-                // (lo / hi halves of one register are never written by neighbouring instructions: that costs a wait state)
-                if (j == 0) asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(mh0) : "v"(qv[0]), "v"(sx_next));
-                if (j == 1) asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(mh1) : "v"(qv[2]), "v"(sx_next));
-                if (j == 2) asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(mh0) : "v"(qv[1]), "v"(sx_next));
-                if (j == 3) asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(mh1) : "v"(qv[3]), "v"(sx_next));
-                if (j == 4) asm volatile("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(ml0) : "v"(qv[0]), "v"(sx_next), "v"(mh0));
-                if (j == 5) asm volatile("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(ml1) : "v"(qv[2]), "v"(sx_next), "v"(mh1));
-                if (j == 6) asm volatile("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(ml0) : "v"(qv[1]), "v"(sx_next), "v"(mh0));
-                if (j == 7) asm volatile("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(ml1) : "v"(qv[3]), "v"(sx_next), "v"(mh1));
                 _Float16 *ph = wh + sbase + kinc * k;
-                if (j == 8) { uint32x2 uh = {mh0, mh1}; *reinterpret_cast<uint32x2 *>(ph) = uh; }
-                if (j == 9) { uint32x2 ul = {ml0, ml1}; *reinterpret_cast<uint32x2 *>(ph + d.r_smp_stride) = ul; }
+                if (j == 0) asm volatile("v_mul_f32 %0, %1, %2" : "=v"(t0) : "v"(qv[0]), "v"(sx_next));
+                if (j == 1) asm volatile("v_mul_f32 %0, %1, %2" : "=v"(t1) : "v"(qv[1]), "v"(sx_next));
+                if (j == 2) asm volatile("v_mul_f32 %0, %1, %2" : "=v"(t2) : "v"(qv[2]), "v"(sx_next));
+                if (j == 3) asm volatile("v_mul_f32 %0, %1, %2" : "=v"(t3) : "v"(qv[3]), "v"(sx_next));
+                if (j == 4) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(mh0) : "v"(t0), "v"(t1));
+                if (j == 5) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(mh1) : "v"(t2), "v"(t3));
+                if (j == 6) { uint32x2 uh = {mh0, mh1}; *reinterpret_cast<uint32x2 *>(ph) = uh; }
+                if (j == 7) asm volatile("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l0) : "v"(qv[0]), "v"(sx_next), "v"(mh0));
+                if (j == 8) asm volatile("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l2) : "v"(qv[2]), "v"(sx_next), "v"(mh1));
+                if (j == 9) asm volatile("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(l1) : "v"(qv[1]), "v"(sx_next), "v"(mh0));
+                if (j == 10) asm volatile("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(l3) : "v"(qv[3]), "v"(sx_next), "v"(mh1));
+                if (j == 11) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(ml0) : "v"(l0), "v"(l1));
+                if (j == 12) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(ml1) : "v"(l2), "v"(l3));
+                if (j == 13) { uint32x2 ul = {ml0, ml1}; *reinterpret_cast<uint32x2 *>(ph + d.r_smp_stride) = ul; }
             };
             // tick i: what rides behind the i-th DFT MFMA.  The loads of pass q+2 leave in the first ticks (the other staging
             // set is free) and have the whole block to land before the block maximum reads them in the last ticks; staging
@@ -476,7 +503,9 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
                 // (SYLDET_R_NO*: diagnostic builds with one piece knocked out, tools/r_knockouts.sh; never the shipped library)
                 if (i < NL) vl[i] = __builtin_amdgcn_raw_buffer_load_b128(rs2, 16 * tid + 16 * kBlock * i, 0, 0);
 #ifndef SYLDET_R_NOSTAGE
-                stage_micro(i);
+                // 14 NL = 126 micro-steps over the 96 ticks: 21 every 16 ticks
+#pragma unroll
+                for (int sm = i * (kStageSteps * NL) / kTicks; sm < (i + 1) * (kStageSteps * NL) / kTicks; sm++) stage_micro(sm);
 #endif
 #ifndef SYLDET_R_NOEVAL
                 if (i % 4 == 0) eval_slot(i / 4, q - 2, re, thr_m2);
@@ -485,10 +514,13 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
 #ifndef SYLDET_R_NOMAG
 #ifdef SYLDET_R_MAGTICK                // (experiment: the whole finishing of pass q-1 inside the block, from this tick on)
                 const int jm = i - SYLDET_R_MAGTICK;
-                if (jm >= 0 && jm < kMagSteps) mag_micro(jm, rm, dsc);
+                if (jm >= 0 && jm < kMagSteps) mag_micro(jm, rm, dsc, true);
 #else
-                const int jm = i + 14;                                 // pass q-1's tap products and their stores: the first ticks
-                if (i >= 1 && jm < kMagSteps) mag_micro(jm, rm, dsc);
+                // pass q-1's tap products in ticks 2-4, their stores four ticks apart (one b128 LDS write of a wave in
+                // flight at a time), the copies in front of the ring behind them
+                if (i >= 2 && i <= 4) mag_micro(i + 14, rm, dsc, true);
+                if (i == 6 || i == 10 || i == 14) mag_micro(20 + (i - 6) / 4, rm, dsc, true);
+                if (i == 18 || i == 22 || i == 26) mag_micro(24 + (i - 18) / 4, rm, dsc, true);
 #endif
 #endif
 #ifndef SYLDET_R_NOMAX
@@ -506,7 +538,7 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
                 if (jx == NL + 2 && lane == 0) red[wave] = amax_run;
 #endif
             };
-            static_assert(10 * NL <= kTicks && TMAX <= 12 && TMAX - 1 <= kPLead, "tick schedule");
+            static_assert(NL == 9 && KS == 8 && TMAX <= 12 && TMAX - 1 <= kPLead, "tick schedule");
             // The DFT's accumulators live in the accumulation registers (an MFMA whose C/D operands are architectural
             // registers takes 9.9 ns against 8.4: tools/ubench), which the basis alone would fill: its last four quads are
             // architectural instead.
@@ -543,7 +575,8 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
                 }
             }
 #undef SD_DFT_MFMA
-            asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3]));
+            // (eight wait states between an MFMA of this shape and a vector read of its result: what the compiler places there)
+            asm volatile("s_nop 7" : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3]));
 #pragma unroll
             for (int m = 0; m < 4; m++) accP[m] = acc[m];
         }
@@ -583,7 +616,7 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
         }
         push_bad(q - 2);
 #pragma unroll
-        for (int j = 0; j < kMagSteps; j++) mag_micro(j, rm, dsc);
+        for (int j = 0; j < kMagSteps; j++) mag_micro(j, rm, dsc, false);
         __syncthreads();
 #pragma unroll
         for (int sl = 0; sl < 12; sl++) {
