@@ -81,16 +81,20 @@ __device__ __forceinline__ floatx4 mfma(half8 a, half8 b, floatx4 c)
 }
 
 // x*sx -> f16 hi (round to nearest) and f16 lo = the exact remainder x*sx - hi rounded to f16, for two
-// values at once (packed words): hi + lo == x*sx to 2^-22 relative.  v_fma_mix computes in fp32 from
-// mixed-width sources and writes one half of the destination, so a pair costs 4 VALU instructions
-// and the scaling rides along for free.
+// values at once (packed words): hi + lo == x*sx to 2^-22 relative.  sx is a power of two at every call site, so x*sx
+// is exact; hi = RNE(x*sx); v_fma_mix_f32 gives x*sx - hi exactly in fp32 (mixed-width sources: hi is read as a half);
+// lo = RNE of it.  Six one-slot instructions a pair: v_fma_mixlo/hi_f16, which would do it in four, take two issue slots
+// each and a wait state between the halves of a register (tools/ubench/valu_rates, tick_costs).
 __device__ __forceinline__ void split_pair_scaled(float a, float b, float sx, unsigned &hi, unsigned &lo)
 {
     unsigned h, l;
-    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(a), "v"(sx));
-    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(b), "v"(sx));
-    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(a), "v"(sx), "v"(h));
-    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(b), "v"(sx), "v"(h));
+    float ta, tb, ra, rb;
+    asm("v_mul_f32 %0, %1, %2" : "=v"(ta) : "v"(a), "v"(sx));
+    asm("v_mul_f32 %0, %1, %2" : "=v"(tb) : "v"(b), "v"(sx));
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(ta), "v"(tb));
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(ra) : "v"(a), "v"(sx), "v"(h));
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(rb) : "v"(b), "v"(sx), "v"(h));
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(l) : "v"(ra), "v"(rb));
     hi = h;
     lo = l;
 }
