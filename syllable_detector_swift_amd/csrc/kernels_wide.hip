@@ -35,6 +35,10 @@ constexpr int kWave = 64;
 constexpr int kKSteps = kWideK / 16;          // 20 k-steps of 16
 constexpr int kChunkU4 = kWideChunkBytes / 16;     // 1320
 constexpr int kChunkU4Pad = 21 * 64;               // an LDS buffer holds whole 64-element spans (the DMA writes base + 16 lane)
+#ifndef SYLDET_WIDE_TW                              // (-DSYLDET_WIDE_TW=2: 19.15 ms against 18.27 on one box -- half the LDS bytes per
+#define SYLDET_WIDE_TW 1                            // flop do not pay for having two waves a SIMD instead of four)
+#endif
+constexpr int kWideTilesPerWave = SYLDET_WIDE_TW;
 
 __device__ __forceinline__ float wave_reduce_sum(float v)
 {
@@ -223,34 +227,44 @@ wide_prep_chain_kernel(NetDesc n, int F, const float *__restrict__ columns, int6
 // SIG: the hidden transfer function is TanSig or LogSig and the host has folded it into the tables -- weights and biases
 // pre-scaled so that the accumulator (initialised with the bias) is the exponent, second-layer weights and bias rewritten
 // so that  y += w1' / (2^acc + 1)  is all the epilogue does: exp2, add, rcp, fma per hidden value.
-template <int NOUT, bool SIG>
-__global__ void __launch_bounds__(kBlock, 1)
+// TW: evaluation tiles per wave (1 is what ships).  With two, a wave owns 64 evaluations (160 registers of B operands), the
+// workgroup has 8 waves instead of 16, and every A fragment fetched from LDS feeds two MFMAs: half the LDS bytes per flop.
+// Measured slower (below).
+template <int NOUT, bool SIG, int TW>
+__global__ void __launch_bounds__(kBlock / TW, 1)
 wide_gemm_kernel(WideDesc d, const uint4 *__restrict__ xn, int64_t NE, float *__restrict__ outputs, uint8_t *__restrict__ flags)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int kWaves = kBlock / 64 / TW;
     uint4 *buf0 = reinterpret_cast<uint4 *>(smem), *buf1 = buf0 + kChunkU4Pad;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, col = lane & 31;
-    const int64_t ev = (int64_t)blockIdx.x * kWideTile + wave * 32 + col;      // this lane's evaluation (both halves)
+    int64_t ev[TW];                                                           // this lane's evaluations (both halves)
+#pragma unroll
+    for (int t = 0; t < TW; t++) ev[t] = (int64_t)blockIdx.x * kWideTile + (wave * TW + t) * 32 + col;
 
-    // this wave's 32 evaluations as B operands, in registers for the whole kernel
-    bf16x8 B[kKSteps];
+    // this wave's evaluations as B operands, in registers for the whole kernel
+    bf16x8 B[TW][kKSteps];
 #pragma unroll
-    for (int ks = 0; ks < kKSteps; ks++) {
-        union { uint4 u; bf16x8 v; } b;
-        b.u = ev < NE ? xn[ev * (kWideK / 8) + 2 * ks + half] : uint4{0, 0, 0, 0};
-        B[ks] = b.v;
-    }
-    float ysum[NOUT];
+    for (int t = 0; t < TW; t++)
 #pragma unroll
-    for (int o = 0; o < NOUT; o++) ysum[o] = 0.0f;
+        for (int ks = 0; ks < kKSteps; ks++) {
+            union { uint4 u; bf16x8 v; } b;
+            b.u = ev[t] < NE ? xn[ev[t] * (kWideK / 8) + 2 * ks + half] : uint4{0, 0, 0, 0};
+            B[t][ks] = b.v;
+        }
+    float ysum[TW][NOUT];
+#pragma unroll
+    for (int t = 0; t < TW; t++)
+#pragma unroll
+        for (int o = 0; o < NOUT; o++) ysum[t][o] = 0.0f;
 
     // Weight chunks go global -> LDS without passing through registers (LDS-DMA: lane l of a wave lands at base + 16 l);
     // chunk c+1 is in flight while chunk c is multiplied.
     auto fetch_chunk = [&](int ch, uint4 *dst) {
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const int i0 = (wave + (kBlock / 64) * j) * 64;       // this wave's 64 consecutive 16-byte elements
+        for (int j = 0; j < 2 * TW; j++) {
+            const int i0 = (wave + kWaves * j) * 64;              // this wave's 64 consecutive 16-byte elements
             if (i0 < kChunkU4) {
                 const int i = i0 + lane < kChunkU4 ? i0 + lane : kChunkU4 - 1;   // the chunk ends inside the last span
                 __builtin_amdgcn_global_load_lds(d.wpack + (size_t)ch * kChunkU4 + i, dst + i0, 16, 0, 0);
@@ -264,19 +278,21 @@ wide_gemm_kernel(WideDesc d, const uint4 *__restrict__ xn, int64_t NE, float *__
         const uint4 *cur = (ch & 1) ? buf1 : buf0;
         if (ch + 1 < d.n_chunks) fetch_chunk(ch + 1, (ch & 1) ? buf0 : buf1);
         const float *cst = reinterpret_cast<const float *>(cur + kKSteps * 64);   // this chunk's constants follow its fragments
-        floatx16 acc = {0};
-        {                                                         // the accumulator starts at the bias: register i holds unit 8 (i/4) + 4 half + i%4
+        floatx16 acc[TW];
+        {                                                         // the accumulators start at the bias: register i holds unit 8 (i/4) + 4 half + i%4
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 const float4 b0 = *reinterpret_cast<const float4 *>(cst + 8 * g + 4 * half);
-                acc[4 * g] = b0.x; acc[4 * g + 1] = b0.y; acc[4 * g + 2] = b0.z; acc[4 * g + 3] = b0.w;
+#pragma unroll
+                for (int t = 0; t < TW; t++) { acc[t][4 * g] = b0.x; acc[t][4 * g + 1] = b0.y; acc[t][4 * g + 2] = b0.z; acc[t][4 * g + 3] = b0.w; }
             }
         }
 #pragma unroll
         for (int ks = 0; ks < kKSteps; ks++) {
             union { uint4 u; bf16x8 v; } a;
             a.u = cur[ks * 64 + lane];
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, B[ks], acc, 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < TW; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, B[t][ks], acc[t], 0, 0, 0);
         }
         // epilogue: transfer function, second-layer weights
 #pragma unroll
@@ -286,39 +302,44 @@ wide_gemm_kernel(WideDesc d, const uint4 *__restrict__ xn, int64_t NE, float *__
 #pragma unroll
             for (int o = 0; o < NOUT; o++) w1[o] = o < d.n_out ? *reinterpret_cast<const float4 *>(cst + 32 + 32 * o + u0) : float4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const float a0 = SIG ? __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(acc[4 * g + j]) + 1.0f)
-                                     : transfer_fast(d.tf0, acc[4 * g + j]);
+            for (int t = 0; t < TW; t++)
 #pragma unroll
-                for (int o = 0; o < NOUT; o++) {
-                    const float ww = j == 0 ? w1[o].x : (j == 1 ? w1[o].y : (j == 2 ? w1[o].z : w1[o].w));
-                    ysum[o] = fmaf(a0, ww, ysum[o]);
+                for (int j = 0; j < 4; j++) {
+                    const float a0 = SIG ? __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(acc[t][4 * g + j]) + 1.0f)
+                                         : transfer_fast(d.tf0, acc[t][4 * g + j]);
+#pragma unroll
+                    for (int o = 0; o < NOUT; o++) {
+                        const float ww = j == 0 ? w1[o].x : (j == 1 ? w1[o].y : (j == 2 ? w1[o].z : w1[o].w));
+                        ysum[t][o] = fmaf(a0, ww, ysum[t][o]);
+                    }
                 }
-            }
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);                       // the next chunk has landed (this wave's part)
         __syncthreads();
     }
     // the two lane halves hold disjoint units of the same evaluations
 #pragma unroll
-    for (int o = 0; o < NOUT; o++) {
-        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(ysum[o]), __float_as_uint(ysum[o]), false, false);
-        ysum[o] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-    }
-    if (half == 0 && ev < NE) {
-        bool hit = false;
+    for (int t = 0; t < TW; t++) {
 #pragma unroll
         for (int o = 0; o < NOUT; o++) {
-            if (o >= d.n_out) break;
-            float y = transfer_fast(d.tf1, ysum[o] + d.b1[o]);
-            for (int q = 0; q < d.n_out_fns; q++) {               // reverse maps, NeuralNet.swift:137-142 / :175-180
-                const float *op = d.out_params + q * (1 + 2 * d.n_out);
-                y = (y - op[0]) / op[1 + o] + op[1 + d.n_out + o];
-            }
-            if (outputs) outputs[ev * d.n_out + o] = y;
-            if (o == 0 || d.rule == 1) hit = hit || ((double)y >= d.thresholds[o]);
+            const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(ysum[t][o]), __float_as_uint(ysum[t][o]), false, false);
+            ysum[t][o] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
         }
-        if (flags) flags[ev] = hit ? 1 : 0;
+        if (half == 0 && ev[t] < NE) {
+            bool hit = false;
+#pragma unroll
+            for (int o = 0; o < NOUT; o++) {
+                if (o >= d.n_out) break;
+                float y = transfer_fast(d.tf1, ysum[t][o] + d.b1[o]);
+                for (int q = 0; q < d.n_out_fns; q++) {           // reverse maps, NeuralNet.swift:137-142 / :175-180
+                    const float *op = d.out_params + q * (1 + 2 * d.n_out);
+                    y = (y - op[0]) / op[1 + o] + op[1 + d.n_out + o];
+                }
+                if (outputs) outputs[ev[t] * d.n_out + o] = y;
+                if (o == 0 || d.rule == 1) hit = hit || ((double)y >= d.thresholds[o]);
+            }
+            if (flags) flags[ev[t]] = hit ? 1 : 0;
+        }
     }
 }
 
@@ -350,11 +371,14 @@ hipError_t launch_wide_gemm(const WideDesc &d, const void *xn, int64_t NE, float
 {
     if (NE <= 0) return hipSuccess;
     dim3 grid((unsigned)((NE + kWideTile - 1) / kWideTile));
-    auto kern = d.sig ? (d.n_out == 1 ? wide_gemm_kernel<1, true> : wide_gemm_kernel<4, true>)
-                      : (d.n_out == 1 ? wide_gemm_kernel<1, false> : wide_gemm_kernel<4, false>);
+    // (one output: two evaluation tiles a wave; with several outputs their running sums would spill -- one tile, 16 waves)
+    constexpr int TW = kWideTilesPerWave;
+    const bool one = d.n_out == 1;
+    auto kern = d.sig ? (one ? wide_gemm_kernel<1, true, TW> : wide_gemm_kernel<4, true, 1>)
+                      : (one ? wide_gemm_kernel<1, false, TW> : wide_gemm_kernel<4, false, 1>);
     hipError_t st = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kChunkU4Pad * 16);
     if (st != hipSuccess) return st;
-    hipLaunchKernelGGL(kern, grid, dim3(kBlock), 2 * kChunkU4Pad * 16, stream, d, (const uint4 *)xn, NE, outputs, flags);
+    hipLaunchKernelGGL(kern, grid, dim3(one ? kBlock / TW : kBlock), 2 * kChunkU4Pad * 16, stream, d, (const uint4 *)xn, NE, outputs, flags);
     return hipGetLastError();
 }
 
