@@ -339,7 +339,9 @@ bool make_mlpx_plan(const syldet_config_t &c, const syldet_geometry_t &g, MlpxPl
     p = MlpxPlan();
     auto no = [&p](const char *why) { p.reason = why; return false; };
     const int F = g.bins, T = c.time_range, I = g.inputs;
-    if (c.spectrum == SYLDET_SPECTRUM_MAGNITUDE || c.scaling != SYLDET_SCALING_LINEAR) return no("not linear |X| columns");
+    // (log / dB columns are fine here: the chain starts with l2normalize, so what the f16 hi + lo split loses -- 2^-22 of the
+    // frame's column norm -- is lost relative to the vector the network sees)
+    if (c.spectrum == SYLDET_SPECTRUM_MAGNITUDE) return no("not |X| columns");
     if (c.n_layers != 2 || g.outputs != 1) return no("not two layers with one output");
     const syldet_layer_t &L0 = c.layers[0], &L1 = c.layers[1];
     const int H = L0.outputs;
@@ -360,7 +362,7 @@ bool make_mlpx_plan(const syldet_config_t &c, const syldet_geometry_t &g, MlpxPl
     if (T > 12) return no("timeRange above 12");
     const int KB = F <= 64 ? 2 : 4;
     MlpxDesc &d = p.desc;
-    d.F = F; d.T = T; d.KB = KB; d.H = H; d.rule = c.rule;
+    d.F = F; d.T = T; d.KB = KB; d.H = H; d.rule = c.rule; d.scaling = c.scaling;
     d.col_stride = 32 * KB + 8;                      // 16-byte aligned rows that spread 16 consecutive rows over all banks
     d.p_stride = 48 + 4;                             // floats per frame of tap products: 12 taps x 4 units, padded likewise
     int off = 0;

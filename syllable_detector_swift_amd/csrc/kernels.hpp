@@ -172,6 +172,7 @@ constexpr int kMlpxTile = 128;           // frames per tile (its windows: 128 - 
 struct MlpxDesc {
     int F, T, KB, H;            // bins, timeRange, 32-bin blocks per tap (F <= 32 KB), hidden units
     int rule;
+    int scaling;                // SYLDET_SCALING_*: linear, ln x or 20 log10 x of the columns in front of the chain (SyllableDetector.swift:184-212)
     int col_stride;             // halves per column row in LDS: 32 KB + 8
     int p_stride;               // floats per frame row of tap products in LDS
     float w_unscale, b1, oa, og, ob;   // 1 / scale of the folded weights; second layer bias; output map (y - oa) / og + ob

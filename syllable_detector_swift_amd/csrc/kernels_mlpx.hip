@@ -81,9 +81,29 @@ mlp_mfma_kernel(const MlpxDesc d, const float *__restrict__ columns, int64_t J, 
 #pragma unroll
         for (int k = 0; k < NQ; k++) v[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * (tid + kBlock * k), 0, 0);
     }
+    // log / dB columns (SyllableDetector.swift:197-207 vvlogf, :185-195 vDSP_vdbcon with a zero reference of 1: 20 log10 x)
+    // through the hardware's base-2 logarithm (1 ulp; a denormal argument is lifted into its range first); ln 0 = -inf as
+    // in the reference, which has no guard either
+    const float lscale = d.scaling == 1 ? 0.6931471805599453f : 6.020599913279624f;
+    auto scaled = [&](float x) {
+        const bool tiny = x < 0x1p-96f;
+        const float l = __builtin_amdgcn_logf(tiny ? x * 0x1p64f : x) - (tiny ? 64.0f : 0.0f);
+        return l * lscale;
+    };
     int parity = 0;
     for (int tile = blockIdx.x; tile < tiles_per_channel; tile += gridDim.x, parity ^= 1) {
         const int64_t e0 = (int64_t)tile * step;      // first evaluation = first frame of the tile
+        if (d.scaling != 0) {
+#pragma unroll
+            for (int k = 0; k < NQ; k++) {
+                floatx4 x = as_floatx4(v[k]);
+#pragma unroll
+                for (int i = 0; i < 4; i++) x[i] = scaled(x[i]);
+                union { floatx4 f; uint32x4 u; } cv;
+                cv.f = x;
+                v[k] = cv.u;
+            }
+        }
         // (the sums alternate between two buffers: the previous tile's evaluations may still be reading theirs)
         float *ss = ss0 + parity * kTile;
         // ---- every frame gets its own power-of-two exponent (its column norm goes to [2^12, 2^13)): a quiet frame next to a
