@@ -348,7 +348,7 @@ bool make_mlpx_plan(const syldet_config_t &c, const syldet_geometry_t &g, MlpxPl
     if (H > 4 || L0.transfer != SYLDET_TF_TANSIG || L1.transfer != SYLDET_TF_PURELIN) return no("not <= 4 TanSig units and a linear output");
     if (c.n_input_fns < 1 || c.input_fns[0].kind != SYLDET_FN_L2NORMALIZE) return no("input chain does not start with l2normalize");
     if (c.n_output_fns > 1) return no("more than one output map");
-    if (F % 4 != 0 || F > 128) return no("bins not a multiple of 4 up to 128");
+    if (F > 128) return no("more than 128 bins");
     // affine tail of the input chain:  x = a o v' + b  (MapMinMax.apply NeuralNet.swift:127-131, MapStd.apply :162-169)
     std::vector<double> a((size_t)I, 1.0), b((size_t)I, 0.0);
     for (int k = 1; k < c.n_input_fns; k++) {

@@ -449,7 +449,7 @@ bool fft1k_applicable(const StftDesc &s, const MlpxDesc &d, const float *samples
     // (0, N/2) and at most 128 bins (two per lane)
     return s.N == 1024 && s.W == 1024 && (s.hop & 1) == 0 && (s.gap & 1) == 0 && (stride & 1) == 0 &&
            (reinterpret_cast<uintptr_t>(samples) & 7) == 0 && s.f0 >= 1 && s.f0 + s.F <= 511 && s.F <= 128 && s.power_mode == 0 &&
-           d.KB == 4 && d.F == s.F && d.scaling == 0;
+           d.KB == 4 && d.F == s.F && d.F % 4 == 0 && d.scaling == 0;
 }
 
 hipError_t launch_fft1k_net(const StftDesc &s, const MlpxDesc &d, const float *samples, int64_t stride, int C, int64_t J, int64_t E,

@@ -56,9 +56,13 @@ mlp_mfma_kernel(const MlpxDesc d, const float *__restrict__ columns, int64_t J, 
     const int c = blockIdx.y;
     const int F = d.F, T = d.T, CS = d.col_stride, PS = d.p_stride;
     const int step = kTile - (T - 1);                 // evaluations per tile = frames a tile advances by
-    const int nq = kTile * F / 4;                     // quads of column values per tile (F is a multiple of 4)
+    // a frame's bins as Fq quads; when F is not a multiple of 4 the last one reaches into the next frame's first bins (the
+    // columns buffer ends 16 bytes after its last value for that) and is masked after the load
+    const int Fq = (F + 3) / 4;
+    const int nq = kTile * Fq;                        // quads of column values per tile
     const float *chan = columns + (int64_t)c * J * F;
-    const unsigned fmagic = (unsigned)((0x100000000ull + (unsigned)(F / 4) - 1) / (unsigned)(F / 4));   // q / (F/4) == umulhi(q, fmagic), q < 2^16
+    const unsigned fmagic = (unsigned)((0x100000000ull + (unsigned)Fq - 1) / (unsigned)Fq);   // q / Fq == umulhi(q, fmagic), q < 2^16
+    auto frame_of = [&](int q) { return Fq == 1 ? q : (int)__umulhi((unsigned)q, fmagic); };    // (the magic number of 1 does not fit 32 bits)
 
     // once per workgroup: the folded first layer's fragments -> LDS
     for (int i = tid; i < 3 * KB * 2 * 64; i += kBlock) afr[i] = reinterpret_cast<const uint32x4 *>(d.afrag)[i];
@@ -73,14 +77,24 @@ mlp_mfma_kernel(const MlpxDesc d, const float *__restrict__ columns, int64_t J, 
         const int64_t e0 = (int64_t)tile * step;
         int64_t left = tile < tiles_per_channel ? (J - e0) * F : 0;    // floats from the tile's first column to the end of the channel
         left = left < 0 ? 0 : (left > (int64_t)kTile * F ? (int64_t)kTile * F : left);
+        if (left > 0) left += 4 * Fq - F;                              // (the last frame's last quad, whole)
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(chan + e0 * F), 0, (int)left * 4, 0x00020000);
     };
-    uint32x4 v[NQ];
-    {
-        const __amdgpu_buffer_rsrc_t rs = tile_rs(blockIdx.x);
+    // where this thread's quad k sits in the tile (bytes), and which of its four values are bins of its frame
+    int qoff[NQ], qlive[NQ];
 #pragma unroll
-        for (int k = 0; k < NQ; k++) v[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * (tid + kBlock * k), 0, 0);
+    for (int k = 0; k < NQ; k++) {
+        const int q = tid + kBlock * k, fr = frame_of(q), b4 = q - fr * Fq;
+        qoff[k] = q < nq ? 4 * (fr * F + 4 * b4) : 0x7fffff00;          // (past the tile: out of the descriptor's range, zeros)
+        qlive[k] = F - 4 * b4;                                          // values 0 .. qlive-1 of the quad are bins
     }
+    uint32x4 v[NQ];
+    auto load_tile = [&](int tile) {
+        const __amdgpu_buffer_rsrc_t rs = tile_rs(tile);
+#pragma unroll
+        for (int k = 0; k < NQ; k++) v[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, qoff[k], 0, 0);
+    };
+    load_tile(blockIdx.x);
     // log / dB columns (SyllableDetector.swift:197-207 vvlogf, :185-195 vDSP_vdbcon with a zero reference of 1: 20 log10 x)
     // through the hardware's base-2 logarithm (1 ulp; a denormal argument is lifted into its range first); ln 0 = -inf as
     // in the reference, which has no guard either
@@ -93,12 +107,15 @@ mlp_mfma_kernel(const MlpxDesc d, const float *__restrict__ columns, int64_t J, 
     int parity = 0;
     for (int tile = blockIdx.x; tile < tiles_per_channel; tile += gridDim.x, parity ^= 1) {
         const int64_t e0 = (int64_t)tile * step;      // first evaluation = first frame of the tile
-        if (d.scaling != 0) {
+        if (d.scaling != 0 || (F & 3) != 0) {
 #pragma unroll
             for (int k = 0; k < NQ; k++) {
                 floatx4 x = as_floatx4(v[k]);
 #pragma unroll
-                for (int i = 0; i < 4; i++) x[i] = scaled(x[i]);
+                for (int i = 0; i < 4; i++) {
+                    if (d.scaling != 0) x[i] = scaled(x[i]);
+                    x[i] = i < qlive[k] ? x[i] : 0.0f;                  // the next frame's bins behind this frame's last ones
+                }
                 union { floatx4 f; uint32x4 u; } cv;
                 cv.f = x;
                 v[k] = cv.u;
@@ -120,7 +137,7 @@ mlp_mfma_kernel(const MlpxDesc d, const float *__restrict__ columns, int64_t J, 
         __syncthreads();
         if (tid < kTile) {
             float sacc = 0.0f;
-            for (int i = 0; i < F / 4; i++) sacc += pq[tid * (F / 4) + i];
+            for (int i = 0; i < Fq; i++) sacc += pq[tid * Fq + i];
             ss[tid] = sacc;
             // t = floor(log2 sqrt(ss)) + 64, clamped; up = 2^(76 - t), down = 1 / up (see kernels_fused_r.hip, mag_micro)
             unsigned tb = ((__float_as_uint(sacc) + 0x800000u) >> 1) & 0x7f800000u;
@@ -135,7 +152,7 @@ mlp_mfma_kernel(const MlpxDesc d, const float *__restrict__ columns, int64_t J, 
             const int q = tid + kBlock * k;
             if (q < nq) {
                 const floatx4 x = as_floatx4(v[k]);
-                const int fr = F == 4 ? q : (int)__umulhi((unsigned)q, fmagic), bin = 4 * (q - fr * (F / 4));   // (the magic number of 1 does not fit 32 bits)
+                const int fr = frame_of(q), bin = 4 * (q - fr * Fq);
                 const float sx = fup[fr];
                 unsigned h0, l0, h1, l1;
                 split_pair_scaled(x[0], x[1], sx, h0, l0);
@@ -146,15 +163,11 @@ mlp_mfma_kernel(const MlpxDesc d, const float *__restrict__ columns, int64_t J, 
             }
         }
         // the staging registers are free: the next tile's columns start their way from HBM
-        {
-            const __amdgpu_buffer_rsrc_t rs = tile_rs(tile + (int)gridDim.x);
-#pragma unroll
-            for (int k = 0; k < NQ; k++) v[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * (tid + kBlock * k), 0, 0);
-        }
-        // bins F .. 32 KB - 1 of every row are read by the last k-block: zeros (the weights there are zero too, but
+        load_tile(tile + (int)gridDim.x);
+        // bins 4 Fq .. 32 KB - 1 of every row are read by the last k-block: zeros (the weights there are zero too, but
         // 0 * NaN from stale LDS is not)
-        for (int i = tid; i < kTile * ((32 * KB - F) / 4); i += kBlock) {
-            const int per = (32 * KB - F) / 4, fr = i / per, bin = F + 4 * (i - fr * per);
+        for (int i = tid; i < kTile * ((32 * KB - 4 * Fq) / 4); i += kBlock) {
+            const int per = (32 * KB - 4 * Fq) / 4, fr = i / per, bin = 4 * Fq + 4 * (i - fr * per);
             uint32x2 z = {0u, 0u};
             *reinterpret_cast<uint32x2 *>(colh + fr * CS + bin) = z;
             *reinterpret_cast<uint32x2 *>(coll + fr * CS + bin) = z;

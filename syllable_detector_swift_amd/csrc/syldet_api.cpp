@@ -581,7 +581,8 @@ int run_on_stream(syldet *h, const float *d_samples, int64_t S, int64_t stride, 
         SYLDET_HIP(launch_fixup(h->fixd, h->net, d_samples, stride, J, E, d_outputs, d_flags, nullptr, d.fix, stream));
         return SYLDET_OK;
     }
-    if (int st = h->d_columns.reserve((size_t)C * (size_t)J * (size_t)h->geom.bins * sizeof(float))) return st;
+    // (+ 16 bytes: the matrix-core network stage reads a frame's last bins as a whole quad)
+    if (int st = h->d_columns.reserve((size_t)C * (size_t)J * (size_t)h->geom.bins * sizeof(float) + 16)) return st;
     if (h->engine == SYLDET_ENGINE_WIDE_BF16) {
         if (int st = h->d_xn.reserve((size_t)C * (size_t)E * (size_t)kWideK * 2)) return st;
         if (int st = stft_on_stream(h, d_samples, stride, C, J, (float *)h->d_columns.ptr, stream)) return st;

@@ -426,11 +426,14 @@ def test_register_resident_kernel_is_only_taken_where_it_is_instantiated(oracle_
 @pytest.mark.parametrize("N,lo,hi,T,H,scaling", [(1024, 2000.0, 7000.0, 10, 4, "linear"), (512, 1000.0, 6150.0, 8, 3, "linear"),
                                                    (1024, 3000.0, 8500.0, 6, 1, "linear"), (256, 500.0, 7300.0, 12, 2, "linear"),
                                                    (1024, 2000.0, 7000.0, 10, 4, "db"), (512, 1000.0, 6150.0, 8, 3, "log"),
-                                                   (256, 500.0, 7300.0, 12, 2, "db")])
+                                                   (256, 500.0, 7300.0, 12, 2, "db"),
+                                                   # bins not a multiple of 4 (58, 115, 33): a frame's last quad reaches into the next frame
+                                                   (512, 2000.0, 7000.0, 10, 4, "linear"), (1024, 2000.0, 6950.0, 7, 3, "db"),
+                                                   (256, 1500.0, 7100.0, 5, 4, "log")])
 def test_network_stage_on_the_matrix_cores(oracle_lib, N, lo, hi, T, H, scaling):
     """Bands too wide / windows too long for the fused engine (BASELINE configs[2] first): under AUTO the generic engine's
     network stage is kernels_mlpx.hip's when the detector is of its class (l2normalize first, <= 4 TanSig units, one linear
-    output, bins a multiple of 4); a handle created for SYLDET_ENGINE_GENERIC keeps the interpretive kernels.  Both meet
+    output, up to 128 bins); a handle created for SYLDET_ENGINE_GENERIC keeps the interpretive kernels.  Both meet
     the oracle.  Ragged length (the last tile is partial), two channels, a level step, a stretch of silence (0/0 -> NaN;
     with log / dB columns -- SyllableDetector.swift:185-207, taken in the kernel -- ln 0 = -inf does the same)."""
     torch = _torch()
@@ -438,7 +441,7 @@ def test_network_stage_on_the_matrix_cores(oracle_lib, N, lo, hi, T, H, scaling)
     rng = np.random.default_rng(N + T)
     f0, f1 = frequencyIndexRange(N, 44100.0, lo, hi)
     F = f1 - f0
-    assert F % 4 == 0 and F > 32, F
+    assert F > 32, F
     net = nets.random_net(rng, F * T, (H,), 1, in_fns=("l2normalize", "mapminmax"), out_fns=("mapminmax",) if H != 3 else ())
     cfg = SyllableDetectorConfig(44100.0, N, N, N - N // 4, (lo, hi), T, scaling, [0.4], net)
     S = N + (N // 4) * 700 + 37
