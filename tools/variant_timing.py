@@ -24,8 +24,18 @@ cases = {
     "T=8, hop 100": nets.variant(base, timeRange=8, windowOverlap=156, net=nets.random_net(rng, 29 * 8, (4,), 1)),
     "hop 128": nets.variant(base, windowOverlap=128),
 }
+# shapes outside the fused engine (AUTO: generic FFT + whichever network stage applies)
+auto_cases = {
+    "N=512 hop 128, 58 bins": nets.variant(base, fourierLength=512, windowLength=512, windowOverlap=384, net=nets.random_net(rng, 58 * 10, (4,), 1, in_fns=("l2normalize", "mapminmax"))),
+    "N=512 hop 256, 58 bins, dB": nets.variant(base, fourierLength=512, windowLength=512, windowOverlap=256, spectrogramScaling="db", net=nets.random_net(rng, 58 * 10, (4,), 1, in_fns=("l2normalize", "mapminmax"))),
+    "N=128 hop 64, 15 bins": nets.variant(base, fourierLength=128, windowLength=128, windowOverlap=64, net=nets.random_net(rng, 15 * 10, (4,), 1, in_fns=("l2normalize", "mapminmax"))),
+    "sample.txt, dB": nets.variant(base, spectrogramScaling="db"),
+    "sample.txt, H=12": nets.variant(base, net=nets.random_net(rng, 290, (12,), 1, in_fns=("l2normalize", "mapminmax"))),
+}
+if "--auto" in sys.argv:
+    cases = auto_cases
 for name, cfg in cases.items():
-    with sd.SyllableDetector(cfg, channels=C, engine=_abi.ENGINE_FUSED) as det:
+    with sd.SyllableDetector(cfg, channels=C, engine=_abi.ENGINE_AUTO if "--auto" in sys.argv else _abi.ENGINE_FUSED) as det:
         E = det.countEvaluations(S)
         out = torch.empty((C, E, det.geometry.outputs), dtype=torch.float32, device="cuda")
         fl = torch.empty((C, E), dtype=torch.uint8, device="cuda")
@@ -37,4 +47,9 @@ for name, cfg in cases.items():
                 ms.append(det.lastTimings()[0][1])
         J = det.countFrames(S)
         torch.cuda.synchronize()
+        names = "+".join(n for n, _ in det.lastTimings())
+        if "--auto" in sys.argv:        # several kernels a step: the sum of the last step's
+            tot = sum(t for _, t in det.lastTimings())
+            print("%-28s %-44s %.3f ms   %.3g frames/s" % (name, names, tot, C * J / (tot * 1e-3)), flush=True)
+            continue
         print("%-26s %-16s %.3f ms   %.3g frames/s   guard work items %d" % (name, det.lastTimings()[0][0], sum(ms) / len(ms), C * J / (sum(ms) / len(ms) * 1e-3), det.fixupStats()[0]), flush=True)
