@@ -48,6 +48,9 @@ struct NetDesc {
 // columns [C][J][F] <- samples [C][stride]
 hipError_t launch_stft_generic(const StftDesc &d, const float *samples, int64_t stride, int C, int64_t J,
                                float *columns, hipStream_t stream);
+// the same for 128-, 256- and 512-point frames, butterflies across the lanes (kernels_stft_lanes.hip)
+bool stft_lanes_applicable(const StftDesc &d, const float *samples, int64_t stride);
+hipError_t launch_stft_lanes(const StftDesc &d, const float *samples, int64_t stride, int C, int64_t J, float *columns, hipStream_t stream);
 // outputs [C][E][n_out], flags [C][E] <- columns [C][J][F]; either output may be null
 hipError_t launch_mlp_generic(const NetDesc &n, int F, const float *columns, int C, int64_t J, int64_t E,
                               float *outputs, uint8_t *flags, hipStream_t stream);

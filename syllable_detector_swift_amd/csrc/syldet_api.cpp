@@ -511,6 +511,12 @@ int stft_on_stream(syldet *h, const float *d_samples, int64_t stride, int C, int
         SYLDET_HIP(launch_fixup(h->fixd, h->net, d_samples, stride, J, 0, nullptr, nullptr, d_columns, d.fix, stream));
         return SYLDET_OK;
     }
+    const bool no_lanes = std::getenv("SYLDET_NO_STFT_LANES") != nullptr;            // (A/B runs, and the tests that hold the two against each other)
+    if (!no_lanes && stft_lanes_applicable(h->stft, d_samples, stride)) {
+        KernelTimer t(h, stream, "stft_lanes_kernel");
+        SYLDET_HIP(launch_stft_lanes(h->stft, d_samples, stride, C, J, d_columns, stream));
+        return SYLDET_OK;
+    }
     KernelTimer t(h, stream, "stft_generic_kernel");
     SYLDET_HIP(launch_stft_generic(h->stft, d_samples, stride, C, J, d_columns, stream));
     return SYLDET_OK;

@@ -135,6 +135,40 @@ def test_every_fft_size(oracle_lib, N):
     util.assert_outputs_close(out, o.run(x, po.F64)[2])
 
 
+@pytest.mark.parametrize("N,W,ov,lo,hi,spectrum", [(128, 128, 64, 0.0, 3900.0, 0), (128, 96, 32, 500.0, 2500.0, 1), (256, 256, 124, 2000.0, 7000.0, 0),
+                                                    (256, 256, 128, 0.0, 3999.0, 1), (256, 200, 40, 300.0, 3000.0, 0), (512, 512, 384, 1000.0, 3500.0, 0),
+                                                    (512, 400, -24, 0.0, 2000.0, 0), (256, 256, 125, 2000.0, 7000.0, 0)])
+def test_short_frames_across_the_lanes(oracle_lib, monkeypatch, N, W, ov, lo, hi, spectrum):
+    """128-, 256- and 512-point frames on the generic engine: kernels_stft_lanes.hip (butterflies across the lanes) and the
+    LDS kernel it stands in for, both against the oracle -- whole and zero-padded windows, bands from bin 0 and up to the last
+    bin below Nyquist, |X| and |X|^2, a gap between frames; an odd hop (the last case) keeps the LDS kernel."""
+    torch = _torch()
+    fs = 8000.0 if hi < 4000.0 else 44100.0
+    rng = np.random.default_rng(N + W + ov)
+    f0, f1 = sd.frequencyIndexRange(N, fs, lo, hi)
+    cfg = sd.SyllableDetectorConfig(fs, N, W, ov, (lo, hi), 2, "linear", [0.0],
+                                    nets.random_net(rng, (f1 - f0) * 2, (3,), 1, in_fns=("l2normalize",), out_fns=()), spectrum=spectrum)
+    o = util.oracle_for(cfg)
+    hop = max(0, -ov) + W - max(0, ov)
+    x = synth.channels(3, 150 * hop + W + 12 + (hop & 1), first=2, fs=fs).astype(np.float32)      # (rows 8-byte aligned)
+    want = [o.spectrogram(x[c], po.F64) for c in range(3)]
+    for lanes in (True, False):
+        if lanes:
+            monkeypatch.delenv("SYLDET_NO_STFT_LANES", raising=False)
+        else:
+            monkeypatch.setenv("SYLDET_NO_STFT_LANES", "1")
+        with sd.SyllableDetector(cfg, channels=3, engine=_abi.ENGINE_GENERIC) as det:
+            det.profile(True)
+            out, _ = det.run(torch.from_numpy(x).cuda())
+            torch.cuda.synchronize()
+            assert det.lastTimings()[0][0] == ("stft_lanes_kernel" if lanes and hop % 2 == 0 else "stft_generic_kernel")
+            cols = det.spectrogram(torch.from_numpy(x).cuda()).cpu().numpy()
+            out = out.cpu().numpy()
+        for c in range(3):
+            util.assert_columns_close(cols[c], want[c])
+            util.assert_outputs_close(out[c], o.run(x[c], po.F64)[2])
+
+
 def test_detection_indices_and_debounce(oracle_lib):
     torch = _torch()
     cfg, x, gold = util.load_case("case_sample_syllables")

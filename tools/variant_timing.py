@@ -50,6 +50,6 @@ for name, cfg in cases.items():
         names = "+".join(n for n, _ in det.lastTimings())
         if "--auto" in sys.argv:        # several kernels a step: the sum of the last step's
             tot = sum(t for _, t in det.lastTimings())
-            print("%-28s %-44s %.3f ms   %.3g frames/s" % (name, names, tot, C * J / (tot * 1e-3)), flush=True)
+            print("%-28s %-60s %.3f ms   %.3g frames/s" % (name, " + ".join("%s %.2f" % (n, t) for n, t in det.lastTimings()), tot, C * J / (tot * 1e-3)), flush=True)
             continue
         print("%-26s %-16s %.3f ms   %.3g frames/s   guard work items %d" % (name, det.lastTimings()[0][0], sum(ms) / len(ms), C * J / (sum(ms) / len(ms) * 1e-3), det.fixupStats()[0]), flush=True)
