@@ -18,6 +18,8 @@
 //
 // gfx950 only.  wave = 64.
 
+#include <cstdlib>
+
 #include "kernels.hpp"
 
 namespace sd {
@@ -78,7 +80,14 @@ __device__ __forceinline__ float partner(float x)
 template <int S, bool TW>
 __device__ __forceinline__ void stage(f2 (&v)[8], float sgn, f2 tw)
 {
-    if (S == 16) {
+    if (S == 32) {                                              // (likewise with the wave's halves)
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const auto rx = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[c].x), __float_as_uint(v[c].x), false, false);
+            const auto ry = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[c].y), __float_as_uint(v[c].y), false, false);
+            v[c] = f2{fmaf(__uint_as_float(rx[1]), sgn, __uint_as_float(rx[0])), fmaf(__uint_as_float(ry[1]), sgn, __uint_as_float(ry[0]))};
+        }
+    } else if (S == 16) {
         // v_permlane16_swap(a, b): a's odd rows <-> b's even rows.  With a = b = x: r[0] holds the even rows' values in both
         // rows of a pair, r[1] the odd rows' -- the (lo, hi) of this stage in every lane
 #pragma unroll
@@ -108,7 +117,7 @@ __device__ __forceinline__ void stage(f2 (&v)[8], float sgn, f2 tw)
 // L = log2 P.  Frames per wave and round: 64 / P.  Every frame starts 8-byte aligned and the window is even (the launcher
 // checks): a lane's points come as (even, odd) sample pairs in one load.
 template <int L, bool PAD>
-__global__ void __launch_bounds__(kBlock, L == 5 ? 3 : 4)      // (512-point frames at four waves a SIMD spill 16 registers: 4.87 ms against 4.17)
+__global__ void __launch_bounds__(kBlock, L >= 5 ? 3 : 4)      // (512-point frames at four waves a SIMD spill 16 registers: 4.87 ms against 4.17)
 stft_lanes_kernel(StftDesc d, const float *__restrict__ samples, int64_t stride, int64_t J, float *__restrict__ columns)
 {
     constexpr int P = 1 << L, FW = kWave / P, M = 8 * P;
@@ -138,10 +147,10 @@ stft_lanes_kernel(StftDesc d, const float *__restrict__ samples, int64_t stride,
         moff[a] = (PAD && m >= d.W / 2) ? d.W / 2 - 1 : m;      // (no zero pad: P a + b, an immediate offset from one address)
         tw1[a] = wN(2 * b * a);                                 // W_M^(b c), c = a
     }
-    float sgn[5];
-    f2 tws[5];
+    float sgn[6];
+    f2 tws[6];
 #pragma unroll
-    for (int s = 0; s < 5; s++) {
+    for (int s = 0; s < 6; s++) {
         const int S = 1 << s;
         const bool up = (b & S) != 0;
         sgn[s] = up ? -1.0f : 1.0f;
@@ -190,6 +199,7 @@ stft_lanes_kernel(StftDesc d, const float *__restrict__ samples, int64_t stride,
 #pragma unroll
         for (int cc = 1; cc < 8; cc++) v[cc] = cmul(v[cc], tw1[cc]);
         // the P-point transforms over b, largest span first
+        if (L > 5) stage<32, true>(v, sgn[5], tws[5]);
         if (L > 4) stage<16, true>(v, sgn[4], tws[4]);
         if (L > 3) stage<8, true>(v, sgn[3], tws[3]);
         stage<4, true>(v, sgn[2], tws[2]);
@@ -226,7 +236,8 @@ stft_lanes_kernel(StftDesc d, const float *__restrict__ samples, int64_t stride,
 bool stft_lanes_applicable(const StftDesc &d, const float *samples, int64_t stride)
 {
     // 128-, 256- or 512-point frames; every frame 8-byte aligned and an even window (sample pairs in one load)
-    return (d.M == 64 || d.M == 128 || d.M == 256) && d.W <= 2 * d.M && d.W >= 2 && (d.W & 1) == 0 && (d.hop & 1) == 0 && (d.gap & 1) == 0 &&
+    static const bool with_1k = std::getenv("SYLDET_LANES_1K") != nullptr;      // (experiment: 1024-point frames too, instead of stft_r8_kernel)
+    return (d.M == 64 || d.M == 128 || d.M == 256 || (with_1k && d.M == 512)) && d.W <= 2 * d.M && d.W >= 2 && (d.W & 1) == 0 && (d.hop & 1) == 0 && (d.gap & 1) == 0 &&
            (stride & 1) == 0 && (reinterpret_cast<uintptr_t>(samples) & 7) == 0 && d.F >= 1 && d.f0 >= 0 && d.f0 + d.F <= d.M;
 }
 
@@ -241,7 +252,8 @@ hipError_t launch_stft_lanes(const StftDesc &d, const float *samples, int64_t st
     auto go = [&](auto kern) { hipLaunchKernelGGL(kern, grid, dim3(kBlock), 0, stream, d, samples, stride, J, columns); };
     if (d.M == 64) pad ? go(stft_lanes_kernel<3, true>) : go(stft_lanes_kernel<3, false>);
     else if (d.M == 128) pad ? go(stft_lanes_kernel<4, true>) : go(stft_lanes_kernel<4, false>);
-    else pad ? go(stft_lanes_kernel<5, true>) : go(stft_lanes_kernel<5, false>);
+    else if (d.M == 256) pad ? go(stft_lanes_kernel<5, true>) : go(stft_lanes_kernel<5, false>);
+    else pad ? go(stft_lanes_kernel<6, true>) : go(stft_lanes_kernel<6, false>);
     return hipGetLastError();
 }
 
