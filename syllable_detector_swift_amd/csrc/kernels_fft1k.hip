@@ -158,6 +158,14 @@ __device__ __forceinline__ void transpose_lo(f2 (&v)[8], int lane)   // register
 #define SYLDET_FFT1K_T 1
 #endif
 constexpr bool kRegT1 = (SYLDET_FFT1K_T & 1) != 0, kRegT2 = (SYLDET_FFT1K_T & 2) != 0;
+// Software pipeline (with the first transpose in registers; -DSYLDET_FFT1K_PIPE=1, an experiment): the next frame's first
+// pass -- window, radix-8, twiddles, the register transpose: vector work only -- is issued while this frame's two LDS round
+// trips are in flight (the counters have the waves of this kernel waiting 41 % of their cycles).  Measured slower: 3.18 ms
+// against 2.98 for the frame-at-a-time loop on one box (168 registers against 147, the same three waves a SIMD).
+#ifndef SYLDET_FFT1K_PIPE
+#define SYLDET_FFT1K_PIPE 0
+#endif
+constexpr bool kPipe = SYLDET_FFT1K_PIPE != 0 && kRegT1 && !kRegT2 && kFly == 1;
 
 template <int KB>
 __global__ void __launch_bounds__(kBlock)
@@ -251,6 +259,89 @@ fft1k_net_kernel(const StftDesc sd_, const MlpxDesc d, const float *__restrict__
                 raw[a] = f2{s.x, s.y};
             }
         };
+        if (kPipe) {
+            // p: the frame whose first pass is done; raw: the one behind it, on its way from memory
+            f2 p[8], raw[8];
+            auto first_pass = [&](f2 (&q)[8]) {                   // window (vDSP_vmul :311), even / odd packing (:314-316), over a -> c
+#pragma unroll
+                for (int a = 0; a < 8; a++) q[a] = raw[a] * win[a];
+            };
+            auto row_of = [&](int r) { return r < r1 ? r : (r1 > r0 ? r1 - 1 : r0); };
+            fetch(row_of(r0), raw);
+            first_pass(p);
+            fetch(row_of(r0 + 1), raw);
+            dft8(p);
+#pragma unroll
+            for (int cc = 1; cc < 8; cc++) p[cc] = cmul(p[cc], tw1[cc]);
+            transpose_hi(p);                                      // lane = (c, b'), registers a': y[c][8 a' + b']
+            for (int row = r0; row < r1; row++) {
+                f2 *buf = buf0;
+                f2 v[8], q[8];
+#pragma unroll
+                for (int a = 0; a < 8; a++) v[a] = p[a];
+                dft8(v);                                          // over a' -> index c'
+#pragma unroll
+                for (int cc = 0; cc < 8; cc++) buf[(hi3 * 8 + cc) * 9 + lo3] = cc ? cmul(v[cc], tw2[cc]) : v[cc];
+                // (in the shadow of that round trip: the next frame's window and radix-8)
+                first_pass(q);
+                fetch(row_of(row + 2), raw);
+                dft8(q);
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int a = 0; a < 8; a++) v[a] = buf[(hi3 * 8 + lo3) * 9 + a];   // lane = (c, c'): z[c][c'][b']
+                __builtin_amdgcn_wave_barrier();
+                dft8(v);                                          // over b' -> index d'
+#pragma unroll
+                for (int dd = 0; dd < 8; dd++)
+                    if (need & (1u << dd)) buf[hi3 + 10 * lo3 + 80 * dd] = v[dd];
+                // (and of this one: its twiddles and the register transpose)
+#pragma unroll
+                for (int cc = 1; cc < 8; cc++) q[cc] = cmul(q[cc], tw1[cc]);
+                transpose_hi(q);
+#pragma unroll
+                for (int a = 0; a < 8; a++) p[a] = q[a];
+                __builtin_amdgcn_wave_barrier();
+                float cv[2], ss;
+#pragma unroll
+                for (int it = 0; it < 2; it++) {
+                    const f2 zk = buf[nat(kbin[it])], zm = buf[nat(512 - kbin[it])];
+                    const float ar = zk.x + zm.x, ai = zk.y - zm.y, br = zk.x - zm.x, bi = zk.y + zm.y;
+                    const float tre = br * swr[it].x - bi * swr[it].y, tim = br * swr[it].y + bi * swr[it].x;
+                    const float re2 = ar + tim, im2 = ai - tre;
+                    const float m = __builtin_amdgcn_sqrtf(re2 * re2 + im2 * im2) * 0.5f;      // zvabs / 2, :329-333
+                    cv[it] = (lane + 64 * it < F) ? m : 0.0f;
+                }
+                ss = fmaf(cv[0], cv[0], cv[1] * cv[1]);
+                __builtin_amdgcn_wave_barrier();
+                {
+                    float t = xor32_sum(xor16_sum(ss));
+                    t += __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(t), 0xB1, 0xF, 0xF, false));
+                    t += __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(t), 0x4E, 0xF, 0xF, false));
+                    t += __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(t), 0x141, 0xF, 0xF, false));
+                    t += __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(t), 0x140, 0xF, 0xF, false));
+                    ss = t;
+                }
+                {
+                    unsigned tb = ((__float_as_uint(ss) + 0x800000u) >> 1) & 0x7f800000u;
+                    tb = (unsigned)min(max((int)tb, 16 << 23), 80 << 23);
+                    const float up = __uint_as_float((203u << 23) - tb), down = __uint_as_float(tb + (51u << 23));
+#pragma unroll
+                    for (int it = 0; it < 2; it++) {
+                        const int fb = lane + 64 * it;
+                        if (fb < F) {
+                            const float sc = cv[it] * up;
+                            const _Float16 hh = (_Float16)sc;
+                            colh[row * CS + fb] = hh;
+                            coll[row * CS + fb] = (_Float16)(sc - (float)hh);
+                        }
+                    }
+                    if (lane == 0) {
+                        ssf[row] = ss;
+                        fsc[row] = down;
+                    }
+                }
+            }
+        } else {
         // kFly frames at a time, stage by stage (rows past the share repeat its last row and are not stored)
         f2 nxt[kFly][8];
 #pragma unroll
@@ -375,6 +466,7 @@ fft1k_net_kernel(const StftDesc sd_, const MlpxDesc d, const float *__restrict__
                     }
                 }
             }
+        }
         }
         __syncthreads();
         // ---- phase 2: tap products of this wave's 16 frames, P[(t, h), j] for all taps at once (three row tiles), back to
