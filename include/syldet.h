@@ -214,6 +214,11 @@ int syldet_detections(syldet_t *h, const uint8_t *flags, int64_t n_evals, double
  * returns up to `capacity` kernel durations in milliseconds, in launch order, with their names.   */
 int syldet_profile(syldet_t *h, int enable);
 int syldet_last_timings(syldet_t *h, double *milliseconds, const char **names, int32_t capacity, int32_t *count);
+/* Keep the events of the last `calls` batch calls instead of one (waits for the handle's stream, drops what was recorded), so
+ * that a measurement loop need not wait for every call before making the next; syldet_timings reads the call made
+ * `calls_back` calls before the last one (0: the last), *count = 0 if that call is not held.                              */
+int syldet_profile_history(syldet_t *h, int32_t calls);
+int syldet_timings(syldet_t *h, int32_t calls_back, double *milliseconds, const char **names, int32_t capacity, int32_t *count);
 /* The fused kernels compute on a block-floating-point grid (one power-of-two scale per 64 / 128 frames).  Evaluations
  * whose windows that grid cannot hold to the 1e-5 contract -- a quiet stretch right behind a click, an infinite sample, a
  * level step of hundreds of dB -- are detected on the device and recomputed from the samples in fp64, so that results

@@ -104,6 +104,8 @@ SIGNATURES = {
     "syldet_detections": (C.c_int, [Handle, c_uint8_p, C.c_int64, C.c_double, c_int64_p, C.c_int64, c_int64_p]),
     "syldet_profile": (C.c_int, [Handle, C.c_int]),
     "syldet_last_timings": (C.c_int, [Handle, c_double_p, C.POINTER(C.c_char_p), C.c_int32, c_int32_p]),
+    "syldet_profile_history": (C.c_int, [Handle, C.c_int32]),
+    "syldet_timings": (C.c_int, [Handle, C.c_int32, c_double_p, C.POINTER(C.c_char_p), C.c_int32, c_int32_p]),
     "syldet_fixup_stats": (C.c_int, [Handle, c_int64_p, c_int32_p]),
     "syldet_segment_evals": (C.c_int64, [Handle, C.c_int64]),
     "syldet_append": (C.c_int, [Handle, C.c_int32, c_float_p, C.c_int64]),

@@ -160,9 +160,21 @@ struct syldet {
 
     // optional per-kernel timing (syldet_profile)
     bool profiling = false;
-    std::vector<hipEvent_t> events;          // 2 per kernel slot
-    std::vector<const char *> event_names;
-    int timed_kernels = 0;
+    // a ring of the last prof_depth batch calls: kMaxTimed kernel slots each, two events a slot
+    static constexpr int kMaxTimed = 8;
+    struct ProfCall { int count = 0; const char *names[kMaxTimed] = {}; };
+    std::vector<hipEvent_t> events;          // [prof_depth][kMaxTimed][2], created on first use
+    std::vector<ProfCall> prof_calls;        // [prof_depth]
+    int prof_depth = 1;
+    int64_t prof_seq = 0;                    // batch calls profiled so far
+    int prof_cur() const { return (int)((prof_seq > 0 ? prof_seq - 1 : 0) % prof_depth); }
+    void prof_begin()                        // a batch call starts
+    {
+        if (!profiling) return;
+        if ((int)prof_calls.size() != prof_depth) prof_calls.assign((size_t)prof_depth, ProfCall());
+        prof_seq++;
+        prof_calls[(size_t)prof_cur()].count = 0;
+    }
 };
 
 namespace {
@@ -471,21 +483,22 @@ struct KernelTimer {
     int slot = -1;
     KernelTimer(syldet *h_, hipStream_t s, const char *name) : h(h_), stream(s)
     {
-        if (!h->profiling) return;
-        slot = h->timed_kernels++;
-        while ((int)h->events.size() < 2 * (slot + 1)) {
-            hipEvent_t e = nullptr;
-            (void)hipEventCreate(&e);
-            h->events.push_back(e);
-        }
-        if ((int)h->event_names.size() <= slot) h->event_names.resize((size_t)slot + 1);
-        h->event_names[(size_t)slot] = name;
-        (void)hipEventRecord(h->events[(size_t)(2 * slot)], stream);
+        if (!h->profiling || h->prof_calls.empty()) return;
+        syldet::ProfCall &pc = h->prof_calls[(size_t)h->prof_cur()];
+        if (pc.count >= syldet::kMaxTimed) return;
+        slot = pc.count++;
+        pc.names[slot] = name;
+        base = (size_t)(h->prof_cur() * syldet::kMaxTimed + slot) * 2;
+        if (h->events.size() < (size_t)h->prof_depth * syldet::kMaxTimed * 2) h->events.resize((size_t)h->prof_depth * syldet::kMaxTimed * 2, nullptr);
+        for (int k = 0; k < 2; k++)
+            if (!h->events[base + (size_t)k]) (void)hipEventCreate(&h->events[base + (size_t)k]);
+        (void)hipEventRecord(h->events[base], stream);
     }
     ~KernelTimer()
     {
-        if (slot >= 0) (void)hipEventRecord(h->events[(size_t)(2 * slot + 1)], stream);
+        if (slot >= 0) (void)hipEventRecord(h->events[base + 1], stream);
     }
+    size_t base = 0;
 };
 
 // samples -> [C][J][F] columns: the fused engine's DFT half where its shape allows (and the handle was not created
@@ -528,7 +541,7 @@ int run_on_stream(syldet *h, const float *d_samples, int64_t S, int64_t stride, 
     const int64_t J = count_frames(h, S), E = count_evals(h, S);
     if (E <= 0) return SYLDET_OK;
     SYLDET_HIP(hipSetDevice(h->device));
-    h->timed_kernels = 0;
+    h->prof_begin();
     // the fused kernel addresses a channel's results with 32-bit byte offsets; longer rows take the generic engine
     if (h->engine == SYLDET_ENGINE_FUSED && (uint64_t)E * (uint64_t)h->geom.outputs * 4u < 0xFFFFFFF0ull) {
         FusedDesc d = h->fused.desc;
@@ -742,7 +755,8 @@ int syldet_destroy(syldet_t *h)
         (void)hipStreamSynchronize(h->stream);
         (void)hipStreamDestroy(h->stream);
     }
-    for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
+    for (hipEvent_t e : h->events)
+        if (e) (void)hipEventDestroy(e);
     for (DeviceBuffer *b : {&h->d_window, &h->d_tw, &h->d_sw, &h->d_params, &h->d_thr, &h->d_columns, &h->d_fused, &h->d_mlpx, &h->d_stamps, &h->d_fix, &h->d_ctab, &h->d_planar, &h->d_wide, &h->d_xn, &h->d_dft, &h->d_stage_in,
                             &h->d_stage_out, &h->d_stage_flags, &h->d_stage_idx, &h->d_stage_cnt})
         b->release();
@@ -765,23 +779,48 @@ int syldet_profile(syldet_t *h, int enable)
 {
     if (!h) return fail(SYLDET_ERR_INVALID_ARGUMENT, "NULL argument");
     h->profiling = enable != 0;
-    h->timed_kernels = 0;
+    h->prof_seq = 0;
+    h->prof_calls.clear();
+    return SYLDET_OK;
+}
+
+int syldet_profile_history(syldet_t *h, int32_t calls)
+{
+    if (!h || calls < 1 || calls > 65536) return fail(SYLDET_ERR_INVALID_ARGUMENT, "bad argument");
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (hipEvent_t e : h->events)
+        if (e) (void)hipEventDestroy(e);
+    h->events.clear();
+    h->prof_calls.clear();
+    h->prof_depth = calls;
+    h->prof_seq = 0;
+    return SYLDET_OK;
+}
+
+int syldet_timings(syldet_t *h, int32_t calls_back, double *milliseconds, const char **names, int32_t capacity, int32_t *count)
+{
+    if (!h || !count || capacity < 0 || (capacity > 0 && !milliseconds) || calls_back < 0)
+        return fail(SYLDET_ERR_INVALID_ARGUMENT, "bad argument");
+    *count = 0;
+    if (h->prof_calls.empty() || calls_back >= h->prof_depth || (int64_t)calls_back >= h->prof_seq) return SYLDET_OK;
+    const int idx = (int)((h->prof_seq - 1 - calls_back) % h->prof_depth);
+    const syldet::ProfCall &pc = h->prof_calls[(size_t)idx];
+    *count = pc.count;
+    for (int i = 0; i < pc.count && i < capacity; i++) {
+        const size_t base = (size_t)(idx * syldet::kMaxTimed + i) * 2;
+        SYLDET_HIP(hipEventSynchronize(h->events[base + 1]));
+        float ms = 0.0f;
+        SYLDET_HIP(hipEventElapsedTime(&ms, h->events[base], h->events[base + 1]));
+        milliseconds[i] = (double)ms;
+        if (names) names[i] = pc.names[i];
+    }
     return SYLDET_OK;
 }
 
 int syldet_last_timings(syldet_t *h, double *milliseconds, const char **names, int32_t capacity, int32_t *count)
 {
-    if (!h || !count || capacity < 0 || (capacity > 0 && !milliseconds))
-        return fail(SYLDET_ERR_INVALID_ARGUMENT, "bad argument");
-    *count = h->timed_kernels;
-    for (int i = 0; i < h->timed_kernels && i < capacity; i++) {
-        SYLDET_HIP(hipEventSynchronize(h->events[(size_t)(2 * i + 1)]));
-        float ms = 0.0f;
-        SYLDET_HIP(hipEventElapsedTime(&ms, h->events[(size_t)(2 * i)], h->events[(size_t)(2 * i + 1)]));
-        milliseconds[i] = (double)ms;
-        if (names) names[i] = h->event_names[(size_t)i];
-    }
-    return SYLDET_OK;
+    return syldet_timings(h, 0, milliseconds, names, capacity, count);
 }
 
 int syldet_fixup_stats(syldet_t *h, int64_t *items, int32_t *overflow)
@@ -825,7 +864,7 @@ int syldet_spectrogram_device(syldet_t *h, const float *d_samples, int64_t n_sam
     if (!d_columns) return fail(SYLDET_ERR_INVALID_ARGUMENT, "NULL argument");
     SYLDET_HIP(hipSetDevice(h->device));
     const int64_t J = count_frames(h, n_samples);
-    h->timed_kernels = 0;
+    h->prof_begin();
     return stft_on_stream(h, d_samples, channel_stride, h->channels, J, d_columns, (hipStream_t)hip_stream, false);
 }
 
@@ -930,7 +969,7 @@ int syldet_spectrogram(syldet_t *h, const float *samples, int64_t n_samples, int
     SYLDET_HIP(hipMemcpy2DAsync(h->d_stage_in.ptr, (size_t)n_samples * sizeof(float), samples,
                                 (size_t)channel_stride * sizeof(float), (size_t)n_samples * sizeof(float), (size_t)C,
                                 hipMemcpyHostToDevice, h->stream));
-    h->timed_kernels = 0;
+    h->prof_begin();
     if (int st = stft_on_stream(h, (const float *)h->d_stage_in.ptr, n_samples, C, J, (float *)h->d_columns.ptr, h->stream, false)) return st;
     SYLDET_HIP(hipMemcpyAsync(columns, h->d_columns.ptr, col_bytes, hipMemcpyDeviceToHost, h->stream));
     SYLDET_HIP(hipStreamSynchronize(h->stream));

@@ -200,8 +200,19 @@ class SyllableDetector:
         return idx, cnt
 
     # ---- measurement ------------------------------------------------------------------
-    def profile(self, enable: bool = True) -> None:
+    def profile(self, enable: bool = True, history: int = 1) -> None:
+        """Bracket every kernel of a batch call with HIP events; `history`: how many calls' events to keep (a timing loop
+        that reads them at its end need not wait for every call before making the next)."""
+        check(_abi.lib.syldet_profile_history(self._h, int(history)))
         check(_abi.lib.syldet_profile(self._h, 1 if enable else 0))
+
+    def timingsOf(self, calls_back: int = 0):
+        """[(kernel name, milliseconds)] of the batch call made `calls_back` calls before the last one."""
+        ms = (C.c_double * 8)()
+        names = (C.c_char_p * 8)()
+        n = C.c_int32()
+        check(_abi.lib.syldet_timings(self._h, int(calls_back), ms, names, 8, C.byref(n)))
+        return [(names[i].decode(), float(ms[i])) for i in range(min(n.value, 8))]
 
     def lastTimings(self):
         """[(kernel name, milliseconds)] of the last batch call (HIP events on its stream)."""

@@ -169,6 +169,26 @@ def test_short_frames_across_the_lanes(oracle_lib, monkeypatch, N, W, ov, lo, hi
             util.assert_outputs_close(out[c], o.run(x[c], po.F64)[2])
 
 
+def test_kernel_timings_of_the_last_calls():
+    """syldet_profile_history / syldet_timings: the events of the last few batch calls are kept, so a timing loop reads them
+    at its end instead of waiting for every call (bench.py)."""
+    torch = _torch()
+    cfg = util.sample_net()
+    x = torch.from_numpy(synth.channels(2, 40000, first=1)).cuda()
+    with sd.SyllableDetector(cfg, channels=2) as det:
+        det.profile(True, history=4)
+        assert det.timingsOf(0) == []                                  # nothing profiled yet
+        for _ in range(6):
+            det.run(x)
+        got = [det.timingsOf(back) for back in range(5)]
+        assert got[4] == [] and all(len(g) == 1 for g in got[:4])
+        assert got[0][0][0] == "fused_r_kernel" and all(ms > 0.0 for g in got[:4] for _, ms in g)
+        assert det.lastTimings() == got[0]
+        det.profile(True)                                              # back to one call
+        det.run(x)
+        assert len(det.timingsOf(0)) == 1 and det.timingsOf(1) == []
+
+
 def test_detection_indices_and_debounce(oracle_lib):
     torch = _torch()
     cfg, x, gold = util.load_case("case_sample_syllables")
