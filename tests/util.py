@@ -131,3 +131,32 @@ def band_condition(o: "po.Oracle", cfg, x: np.ndarray, cols64: np.ndarray = None
     with np.errstate(divide="ignore", invalid="ignore"):
         k = np.sqrt(num / den)
     return np.where(np.isfinite(k), k, 1.0)
+
+
+def log_condition(o: "po.Oracle", cfg, x: np.ndarray, cols64: np.ndarray, evals, trials: int = 6) -> np.ndarray:
+    """For log / dB columns: how far the anchor's own output moves when every bin's amplitude moves by +-2^-23 of the norm of
+    its frame's whole spectrum -- the error any fp32 transform leaves in a bin (band_condition's premise; a bin 60 dB under
+    the rest of its frame is known to 1e-4 of itself, and the logarithm turns that into an absolute error of the network's
+    input).  Per evaluation of `evals`: the largest move over a few random sign patterns, fp64 network on perturbed columns."""
+    W, N, T = cfg.windowLength, cfg.fourierLength, cfg.timeRange
+    gap = max(0, -cfg.windowOverlap)
+    hop = gap + W - max(0, cfg.windowOverlap)
+    J = cols64.shape[0]
+    w = o.window().astype(np.float64)
+    fr = np.lib.stride_tricks.sliding_window_view(x.astype(np.float64)[gap:], W)[::hop][:J]
+    delta = 2.0 ** -23 * np.sqrt(0.5 * N * ((fr * w[None, :]) ** 2).sum(axis=1))      # amplitude units of the columns
+    power = cols64.min() >= 0.0 and getattr(cfg, "spectrum", 0) == 1                    # |X|^2 columns
+    scale = (lambda c: np.log(c)) if cfg.spectrogramScaling == "log" else (lambda c: 20.0 * np.log10(c))
+    rng = np.random.default_rng(1)
+    moves = np.zeros(len(evals))
+    for n, e in enumerate(evals):
+        win = cols64[e:e + T]
+        amp = np.sqrt(win) if power else win
+        with np.errstate(divide="ignore", invalid="ignore"):
+            base = o.net_apply(scale(win).reshape(-1), po.F64)
+            for _ in range(trials):
+                a2 = np.maximum(amp + rng.choice([-1.0, 1.0], size=amp.shape) * delta[e:e + T, None], 1e-300)
+                out = o.net_apply(scale(a2 * a2 if power else a2).reshape(-1), po.F64)
+                d = np.abs(out - base) / np.maximum(1.0, np.abs(base))
+                moves[n] = max(moves[n], float(np.nan_to_num(d, nan=np.inf).max()))
+    return moves
