@@ -46,12 +46,12 @@ constexpr int kPLead = 11;                     // ring row 0 sits at row kPLead
 
 // KS: k-steps of 32 samples (the basis takes 32 KS registers); TMAX: largest timeRange; NL: staging quads per thread (all NL are
 // always loaded and staged: quads past the pass come back as zeros from the descriptor's bounds check and land in LDS
-// words no frame reads); SKEW: staged samples carry bank-spreading padding -- instantiated for hop 128 only, where the
+// words no frame reads); SKEW: staged samples carry bank-spreading padding -- instantiated for hops 16, 32, 64 and 128 (SKEW = the hop), where the
 // padding (4 halves after every 128 samples) is a matter of constants; STAMP: diagnostic phase timing.
 // GEN: the wider network class -- any transfer functions, with or without l2normalize in front -- as run-time facts; without
 // it the network class is the reference's example detector's (kernels_fused.hip's LEAN): l2normalize first, linear |X|
 // columns, two layers, TanSig hidden units (at most 4), one output, at most one output map.
-template <int KS, int TMAX, int NL, bool SKEW, bool STAMP, bool GEN>
+template <int KS, int TMAX, int NL, int SKEW, bool STAMP, bool GEN>
 __global__ void __launch_bounds__(kBlock, 1)
 fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t stride, int64_t s_eff, int64_t E,
                float *__restrict__ outputs, uint8_t *__restrict__ flags)
@@ -108,10 +108,14 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
     // this lane's frame in a staged buffer, and where k-step ks of lane group g4 starts inside it (see kernels_fused.hip)
     // SKEW (hop 128: every frame would start on the same LDS bank): sample i sits at i + 4 (i >> 7), so frame fl starts at
     // 132 fl and lane group g4's blocks at 64 g4 + 4 (g4 >> 1) inside it; a k-step's 8 ks < 64 never crosses a padding
-    const int foff = SKEW ? fl * 132 + 64 * g4 + 4 * (g4 >> 1) : fl * d.hop + 8 * KS * g4;
+    // (in general, with 4 halves of padding behind every hop staged samples -- a hop that is a multiple of 16 puts every
+    // frame of a tile on the same banks -- : sample i at i + 4 (i / hop); for a hop that is a power of two everything below
+    // is a matter of constants: frame fl starts at (hop + 4) fl, lane group g4's blocks at 8 KS g4 + 4 (8 KS g4 / hop) inside
+    // it, k-step ks at 8 ks + 4 (8 ks / hop) behind that -- 8 ks + the group's start never carries into the next padding)
+    const int foff = SKEW ? fl * (SKEW + 4) + 8 * KS * g4 + 4 * ((8 * KS * g4) / SKEW) : fl * d.hop + 8 * KS * g4;
     int ko[KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ks++) ko[ks] = 8 * ks;
+    for (int ks = 0; ks < KS; ks++) ko[ks] = 8 * ks + (SKEW ? 4 * ((8 * ks) / SKEW) : 0);
 
     // raw samples of one pass: quads 4*(tid + 256 k), k < NL, through a bounds-checked descriptor
     // two sets: pass q+1 (being staged during the matrix block of pass q) is in set (q+1)&1, pass q+2 arrives in set q&1
@@ -142,8 +146,8 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
     };
     auto pass_scale = [&](int &status) { return scale_of(*reinterpret_cast<const floatx4 *>(red), status); };
     // where this thread's quad k lands in a staged buffer (halves): 4 tid + 1024 k, with SKEW + 4 ((4 tid + 1024 k) >> 7)
-    const int sbase = SKEW ? 4 * tid + 4 * (tid >> 5) : 4 * tid;
-    constexpr int kinc = SKEW ? 4 * kBlock + 32 : 4 * kBlock;
+    const int sbase = SKEW ? 4 * tid + 4 * ((4 * tid) / SKEW) : 4 * tid;
+    constexpr int kinc = SKEW ? 4 * kBlock + 4 * ((4 * kBlock) / SKEW) : 4 * kBlock;
 
     // ---- prologue: pass 0 staged, pass 1 in the staging registers with its block maximum published
     int se_cur, se_m1 = 0;                // sample scale exponents of the pass in the matrix block and of the one before it
@@ -538,7 +542,7 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
                 if (jx == NL + 2 && lane == 0) red[wave] = amax_run;
 #endif
             };
-            static_assert(NL == 9 && KS == 8 && TMAX <= 12 && TMAX - 1 <= kPLead, "tick schedule");
+            static_assert(NL <= 9 && KS == 8 && TMAX <= 12 && TMAX - 1 <= kPLead, "tick schedule");
             // The DFT's accumulators live in the accumulation registers (an MFMA whose C/D operands are architectural
             // registers takes 9.9 ns against 8.4: tools/ubench), which the basis alone would fill: its last four quads are
             // architectural instead.
@@ -636,7 +640,7 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
 #undef SD_PIN
 }
 
-template <int KS, int TMAX, int NL, bool SKEW, bool STAMP = false, bool GEN = false>
+template <int KS, int TMAX, int NL, int SKEW, bool STAMP = false, bool GEN = false>
 hipError_t launch_one(const FusedDesc &d, const float *samples, int64_t stride, int C, int64_t s_eff, int64_t E,
                       float *outputs, uint8_t *flags, hipStream_t stream)
 {
@@ -654,8 +658,9 @@ hipError_t launch_one(const FusedDesc &d, const float *samples, int64_t stride, 
 // Shapes this kernel is instantiated for: the reference's example detector class (l2normalize first, linear |X| columns,
 // two layers, at most 4 TanSig hidden units, one output, at most one output map), windows of 132 .. 256 samples (8
 // k-steps), timeRange up to 12, at most 9 staging quads per thread (hop <= 140, the reference's 132 among them), no
-// bank-spreading padding except at hop 128 (a table-driven instantiation for any multiple of 16 spilled and measured 1.85 ms
-// against the 8-wave kernel's 1.47; at hop 128 the padding is a matter of constants).  Everything else stays on
+// bank-spreading padding except at hops 16, 32, 64 and 128 (a table-driven instantiation for any multiple of 16 spilled and
+// measured 1.85 ms against the 8-wave kernel's 1.47; at a power of two the padding is a matter of constants, and the three
+// short hops -- 75 % overlap and more -- stage 2, 3 and 5 quads a thread instead of 9).  Everything else stays on
 // kernels_fused.hip's kernel.
 bool fused_r_has_stamps()
 {
@@ -671,7 +676,8 @@ bool fused_r_applicable(const FusedDesc &d)
     // two layers with at most 4 hidden units and one output, linear |X| columns, no normaliser or l2normalize in front of the
     // affine maps, at most one output map (any transfer functions; the example detector's get the exact instantiation)
     const bool cls = (d.norm == 0 || d.norm == 1) && d.scaling == 0 && d.n_layers == 2 && d.n_out == 1 && d.H <= 4 && d.n_out_fns <= 1;
-    return d.r_ok && d.KS == 8 && d.T <= 12 && d.r_nload <= 9 && (d.skew == 0 || (d.skew == 4 && d.hop == 128)) && cls;
+    const bool pow2 = d.hop == 16 || d.hop == 32 || d.hop == 64 || d.hop == 128;
+    return d.r_ok && d.KS == 8 && d.T <= 12 && d.r_nload <= 9 && (d.skew == 0 || (d.skew == 4 && pow2)) && cls;
 }
 
 hipError_t launch_fused_r(const FusedDesc &d, const float *samples, int64_t stride, int C, int64_t S, int64_t J,
@@ -682,13 +688,17 @@ hipError_t launch_fused_r(const FusedDesc &d, const float *samples, int64_t stri
     if (!fused_r_applicable(d)) return hipErrorInvalidValue;
     const int64_t s_eff = (J - 1) * (int64_t)d.hop + d.gap + d.W;
 #ifdef SYLDET_R_STAMPS                // diagnostic builds only (-DSYLDET_R_STAMPS): the instantiation with phase timing
-    if (d.stamps && d.skew == 0) return launch_one<8, 12, 9, false, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
+    if (d.stamps && d.skew == 0) return launch_one<8, 12, 9, 0, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
 #endif
     const bool exact = d.norm == 1 && d.tf0 == 0 /* TanSig */ && d.tf1 == 2 /* PureLin */;     // the example detector's class
-    if (d.skew != 0) return exact ? launch_one<8, 12, 9, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream)
-                                  : launch_one<8, 12, 9, true, false, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
-    return exact ? launch_one<8, 12, 9, false>(d, samples, stride, C, s_eff, E, outputs, flags, stream)
-                 : launch_one<8, 12, 9, false, false, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
+    // (the short hops take the instantiation with the network class as run-time facts for the example class too)
+    if (d.skew != 0 && d.hop == 16) return launch_one<8, 12, 2, 16, false, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
+    if (d.skew != 0 && d.hop == 32) return launch_one<8, 12, 3, 32, false, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
+    if (d.skew != 0 && d.hop == 64) return launch_one<8, 12, 5, 64, false, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
+    if (d.skew != 0) return exact ? launch_one<8, 12, 9, 128>(d, samples, stride, C, s_eff, E, outputs, flags, stream)
+                                  : launch_one<8, 12, 9, 128, false, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
+    return exact ? launch_one<8, 12, 9, 0>(d, samples, stride, C, s_eff, E, outputs, flags, stream)
+                 : launch_one<8, 12, 9, 0, false, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
 }
 
 }  // namespace sd

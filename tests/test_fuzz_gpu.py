@@ -184,10 +184,10 @@ def test_random_configuration_streaming(oracle_lib, seed):
 
 def draw_example_class(rng):
     """The reference's example detector class, which runs on kernels_fused_r.hip: N = 256, windows of 192 or 256 samples,
-    any timeRange up to 12, hop a multiple of 4 up to 140 that is not a multiple of 16, or 128 (the other multiples of 16 take the 8-wave kernel), l2normalize
+    any timeRange up to 12, hop a multiple of 4 up to 140 that is not a multiple of 16, or 16, 32, 64, 128 (the other multiples of 16 take the 8-wave kernel), l2normalize
     first, <= 4 TanSig hidden units, one linear output, at most one output map; any band, window type, affine maps behind
     the normaliser, threshold, rule."""
-    hop = int(rng.choice([68, 84, 100, 116, 120, 124, 128, 128, 132, 132, 132, 136, 140]))
+    hop = int(rng.choice([16, 32, 64, 64, 68, 84, 100, 116, 120, 124, 128, 128, 132, 132, 132, 136, 140]))
     W = 256 if rng.random() < 0.75 else 192
     T = 10 if rng.random() < 0.4 else int(rng.integers(1, 13))
     f0 = int(rng.integers(0, 100))

@@ -32,6 +32,13 @@ auto_cases = {
     "sample.txt, dB": nets.variant(base, spectrogramScaling="db"),
     "sample.txt, H=12": nets.variant(base, net=nets.random_net(rng, 290, (12,), 1, in_fns=("l2normalize", "mapminmax"))),
 }
+if "--short" in sys.argv:            # short frames and hops (AUTO)
+    def short(N, ov, bins=15, T=10):
+        return nets.variant(base, fourierLength=N, windowLength=N, windowOverlap=ov, freqRange=(2000.0, 2000.0 + (bins - 0.6) * base.samplingRate / N),
+                            net=nets.random_net(rng, bins * T, (4,), 1, in_fns=("l2normalize", "mapminmax")))
+    auto_cases = {"N=128 hop 64": short(128, 64), "N=128 hop 68": short(128, 60), "N=128 hop 72": short(128, 56), "N=128 hop 96": short(128, 32),
+                  "N=256 hop 64": short(256, 192, 29), "N=256 hop 68": short(256, 188, 29), "N=256 hop 96": short(256, 160, 29), "N=64 hop 32": short(64, 32, 8)}
+    sys.argv.append("--auto")
 if "--auto" in sys.argv:
     cases = auto_cases
 for name, cfg in cases.items():
