@@ -155,7 +155,11 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
         const int rl = (rn / 4 + kFusedRBlock - 1) / kFusedRBlock;
         // every thread always stages all of its quads: room for 1024 rl samples (those past rn are zeros nobody reads)
         // (the instantiated kernel stages 9 quads a thread whatever the hop: room for those)
-        const int rn_p = (skewed(std::max(rn, 4 * kFusedRBlock * std::max(rl, 9)) + 16) + 15) / 8 * 8;
+        // (its own bank spreading: 4 halves behind every hop samples where the hop is a power of two, behind every 16
+        // samples for the other multiples of 16 -- kernels_fused_r.hip)
+        const bool pow2 = hop == 16 || hop == 32 || hop == 64 || hop == 128;
+        auto rskewed = [&](int i) { return skew == 0 ? i : (pow2 ? i + 4 * (i / hop) : i + 4 * (i / 16)); };
+        const int rn_p = (rskewed(std::max(rn, 4 * kFusedRBlock * std::max(rl, 9)) + 16) + 15) / 8 * 8;
         const int rps = kFusedRTileFrames + 2 * (T - 1);
         int roff = 0;
         auto rtake = [&roff](int bytes) { const int o = roff; roff += (bytes + 15) / 16 * 16; return o; };

@@ -112,10 +112,14 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
     // frame of a tile on the same banks -- : sample i at i + 4 (i / hop); for a hop that is a power of two everything below
     // is a matter of constants: frame fl starts at (hop + 4) fl, lane group g4's blocks at 8 KS g4 + 4 (8 KS g4 / hop) inside
     // it, k-step ks at 8 ks + 4 (8 ks / hop) behind that -- 8 ks + the group's start never carries into the next padding)
-    const int foff = SKEW ? fl * (SKEW + 4) + 8 * KS * g4 + 4 * ((8 * KS * g4) / SKEW) : fl * d.hop + 8 * KS * g4;
+    // SKEW == 1: the other multiples of 16 (48, 80, 96, 112): 4 halves behind every 16 samples -- frames then start 5/4 hop
+    // apart, which spreads them over the banks for every odd multiple of 16 and for 96, and everything is again a matter
+    // of constants, the same for all those hops: sample n of a frame at n + 4 (n >> 4)
+    const int foff = SKEW == 1 ? fl * (d.hop + d.hop / 4) + 10 * KS * g4
+                               : (SKEW ? fl * (SKEW + 4) + 8 * KS * g4 + 4 * ((8 * KS * g4) / SKEW) : fl * d.hop + 8 * KS * g4);
     int ko[KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ks++) ko[ks] = 8 * ks + (SKEW ? 4 * ((8 * ks) / SKEW) : 0);
+    for (int ks = 0; ks < KS; ks++) ko[ks] = 8 * ks + (SKEW == 1 ? 4 * (ks >> 1) : (SKEW ? 4 * ((8 * ks) / SKEW) : 0));
 
     // raw samples of one pass: quads 4*(tid + 256 k), k < NL, through a bounds-checked descriptor
     // two sets: pass q+1 (being staged during the matrix block of pass q) is in set (q+1)&1, pass q+2 arrives in set q&1
@@ -146,8 +150,8 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
     };
     auto pass_scale = [&](int &status) { return scale_of(*reinterpret_cast<const floatx4 *>(red), status); };
     // where this thread's quad k lands in a staged buffer (halves): 4 tid + 1024 k, with SKEW + 4 ((4 tid + 1024 k) >> 7)
-    const int sbase = SKEW ? 4 * tid + 4 * ((4 * tid) / SKEW) : 4 * tid;
-    constexpr int kinc = SKEW ? 4 * kBlock + 4 * ((4 * kBlock) / SKEW) : 4 * kBlock;
+    const int sbase = SKEW == 1 ? 4 * tid + 4 * (tid >> 2) : (SKEW ? 4 * tid + 4 * ((4 * tid) / SKEW) : 4 * tid);
+    constexpr int kinc = SKEW == 1 ? 5 * kBlock : (SKEW ? 4 * kBlock + 4 * ((4 * kBlock) / SKEW) : 4 * kBlock);
 
     // ---- prologue: pass 0 staged, pass 1 in the staging registers with its block maximum published
     int se_cur, se_m1 = 0;                // sample scale exponents of the pass in the matrix block and of the one before it
@@ -542,7 +546,7 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
                 if (jx == NL + 2 && lane == 0) red[wave] = amax_run;
 #endif
             };
-            static_assert(NL <= 9 && KS == 8 && TMAX <= 12 && TMAX - 1 <= kPLead, "tick schedule");
+            static_assert(NL <= 9 && (KS == 8 || KS == 4) && TMAX <= 12 && TMAX - 1 <= kPLead, "tick schedule");
             // The DFT's accumulators live in the accumulation registers (an MFMA whose C/D operands are architectural
             // registers takes 9.9 ns against 8.4: tools/ubench), which the basis alone would fill: its last four quads are
             // architectural instead.
@@ -657,7 +661,7 @@ hipError_t launch_one(const FusedDesc &d, const float *samples, int64_t stride, 
 
 // Shapes this kernel is instantiated for: the reference's example detector class (l2normalize first, linear |X| columns,
 // two layers, at most 4 TanSig hidden units, one output, at most one output map), windows of 132 .. 256 samples (8
-// k-steps), timeRange up to 12, at most 9 staging quads per thread (hop <= 140, the reference's 132 among them), no
+// k-steps) or up to 128 (4), timeRange up to 12, at most 9 staging quads per thread (hop <= 140, the reference's 132 among them), no
 // bank-spreading padding except at hops 16, 32, 64 and 128 (a table-driven instantiation for any multiple of 16 spilled and
 // measured 1.85 ms against the 8-wave kernel's 1.47; at a power of two the padding is a matter of constants, and the three
 // short hops -- 75 % overlap and more -- stage 2, 3 and 5 quads a thread instead of 9).  Everything else stays on
@@ -676,8 +680,7 @@ bool fused_r_applicable(const FusedDesc &d)
     // two layers with at most 4 hidden units and one output, linear |X| columns, no normaliser or l2normalize in front of the
     // affine maps, at most one output map (any transfer functions; the example detector's get the exact instantiation)
     const bool cls = (d.norm == 0 || d.norm == 1) && d.scaling == 0 && d.n_layers == 2 && d.n_out == 1 && d.H <= 4 && d.n_out_fns <= 1;
-    const bool pow2 = d.hop == 16 || d.hop == 32 || d.hop == 64 || d.hop == 128;
-    return d.r_ok && d.KS == 8 && d.T <= 12 && d.r_nload <= 9 && (d.skew == 0 || (d.skew == 4 && pow2)) && cls;
+    return d.r_ok && (d.KS == 8 || d.KS == 4) && d.T <= 12 && d.r_nload <= 9 && (d.skew == 0 || d.skew == 4) && cls;
 }
 
 hipError_t launch_fused_r(const FusedDesc &d, const float *samples, int64_t stride, int C, int64_t S, int64_t J,
@@ -691,14 +694,26 @@ hipError_t launch_fused_r(const FusedDesc &d, const float *samples, int64_t stri
     if (d.stamps && d.skew == 0) return launch_one<8, 12, 9, 0, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
 #endif
     const bool exact = d.norm == 1 && d.tf0 == 0 /* TanSig */ && d.tf1 == 2 /* PureLin */;     // the example detector's class
-    // (the short hops take the instantiation with the network class as run-time facts for the example class too)
-    if (d.skew != 0 && d.hop == 16) return launch_one<8, 12, 2, 16, false, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
-    if (d.skew != 0 && d.hop == 32) return launch_one<8, 12, 3, 32, false, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
-    if (d.skew != 0 && d.hop == 64) return launch_one<8, 12, 5, 64, false, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
-    if (d.skew != 0) return exact ? launch_one<8, 12, 9, 128>(d, samples, stride, C, s_eff, E, outputs, flags, stream)
-                                  : launch_one<8, 12, 9, 128, false, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
-    return exact ? launch_one<8, 12, 9, 0>(d, samples, stride, C, s_eff, E, outputs, flags, stream)
-                 : launch_one<8, 12, 9, 0, false, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
+    // (the short hops, and windows of up to 128 samples -- four k-steps --, take the instantiation with the network class as
+    // run-time facts for the example class too)
+#define SD_R_GO(KS_, NL_, SKEW_, GEN_) return launch_one<KS_, 12, NL_, SKEW_, false, GEN_>(d, samples, stride, C, s_eff, E, outputs, flags, stream)
+    const bool pad16 = d.skew != 0 && d.hop != 16 && d.hop != 32 && d.hop != 64 && d.hop != 128;      // 48, 80, 96, 112
+    if (d.KS == 4) {
+        if (pad16) { if (d.r_nload <= 6) SD_R_GO(4, 6, 1, true); SD_R_GO(4, 9, 1, true); }
+        if (d.skew != 0 && d.hop == 16) SD_R_GO(4, 2, 16, true);
+        if (d.skew != 0 && d.hop == 32) SD_R_GO(4, 3, 32, true);
+        if (d.skew != 0 && d.hop == 64) SD_R_GO(4, 5, 64, true);
+        if (d.skew != 0) SD_R_GO(4, 9, 128, true);
+        SD_R_GO(4, 9, 0, true);
+    }
+    if (pad16) { if (d.r_nload <= 6) SD_R_GO(8, 6, 1, true); SD_R_GO(8, 9, 1, true); }
+    if (d.skew != 0 && d.hop == 16) SD_R_GO(8, 2, 16, true);
+    if (d.skew != 0 && d.hop == 32) SD_R_GO(8, 3, 32, true);
+    if (d.skew != 0 && d.hop == 64) SD_R_GO(8, 5, 64, true);
+    if (d.skew != 0) { if (exact) SD_R_GO(8, 9, 128, false); SD_R_GO(8, 9, 128, true); }
+    if (exact) SD_R_GO(8, 9, 0, false);
+    SD_R_GO(8, 9, 0, true);
+#undef SD_R_GO
 }
 
 }  // namespace sd

@@ -183,22 +183,27 @@ def test_random_configuration_streaming(oracle_lib, seed):
 
 
 def draw_example_class(rng):
-    """The reference's example detector class, which runs on kernels_fused_r.hip: N = 256, windows of 192 or 256 samples,
-    any timeRange up to 12, hop a multiple of 4 up to 140 that is not a multiple of 16, or 16, 32, 64, 128 (the other multiples of 16 take the 8-wave kernel), l2normalize
+    """The reference's example detector class, which runs on kernels_fused_r.hip: N = 256, windows of 192 or 256 samples (or N = 128, windows of 96 or 128),
+    any timeRange up to 12, hop a multiple of 4 up to 140, l2normalize
     first, <= 4 TanSig hidden units, one linear output, at most one output map; any band, window type, affine maps behind
     the normaliser, threshold, rule."""
-    hop = int(rng.choice([16, 32, 64, 64, 68, 84, 100, 116, 120, 124, 128, 128, 132, 132, 132, 136, 140]))
+    hop = int(rng.choice([16, 32, 48, 64, 64, 68, 80, 84, 96, 100, 112, 116, 120, 124, 128, 128, 132, 132, 132, 136, 140]))
+    N = 256
     W = 256 if rng.random() < 0.75 else 192
+    if rng.random() < 0.25:              # 128-point frames, windows of up to 128 samples: the kernel's four-k-step instantiations
+        N = 128
+        W = 128 if rng.random() < 0.7 else 96
+        hop = int(rng.choice([16, 32, 32, 48, 64, 64, 36, 44, 60, 68, 80, 96, 100, 112, 128]))
     T = 10 if rng.random() < 0.4 else int(rng.integers(1, 13))
-    f0 = int(rng.integers(0, 100))
+    f0 = int(rng.integers(0, N // 2 - 28))
     F = int(rng.integers(1, 30))
-    lo, hi = max((f0 - 0.4) * FS / 256, 0.0), (f0 + F - 1 + 0.4) * FS / 256
-    r = frequencyIndexRange(256, FS, lo, hi)
+    lo, hi = max((f0 - 0.4) * FS / N, 0.0), (f0 + F - 1 + 0.4) * FS / N
+    r = frequencyIndexRange(N, FS, lo, hi)
     F = r[1] - r[0]
     chain = [("l2normalize",), ("l2normalize", "mapminmax"), ("l2normalize", "mapstd"), ("l2normalize", "mapstd", "mapminmax")][int(rng.integers(0, 4))]
     net = nets.random_net(rng, F * T, (int(rng.integers(1, 5)),), 1, transfer=("TanSig", "PureLin"), in_fns=chain,
                           out_fns=[(), ("mapminmax",), ("mapstd",)][int(rng.integers(0, 3))])
-    return SyllableDetectorConfig(FS, 256, W, W - hop, (lo, hi), T, "linear", [float(rng.uniform(-0.5, 0.8))], net,
+    return SyllableDetectorConfig(FS, N, W, W - hop, (lo, hi), T, "linear", [float(rng.uniform(-0.5, 0.8))], net,
                                   window=int(rng.integers(0, 4)), spectrum=_abi.SPECTRUM_POWER, rule=int(rng.integers(0, 2)))
 
 
