@@ -38,6 +38,9 @@ if "--short" in sys.argv:            # short frames and hops (AUTO)
                             net=nets.random_net(rng, bins * T, (4,), 1, in_fns=("l2normalize", "mapminmax")))
     auto_cases = {"N=128 hop 64": short(128, 64), "N=128 hop 68": short(128, 60), "N=128 hop 72": short(128, 56), "N=128 hop 96": short(128, 32),
                   "N=256 hop 64": short(256, 192, 29), "N=256 hop 68": short(256, 188, 29), "N=256 hop 96": short(256, 160, 29), "N=64 hop 32": short(64, 32, 8)}
+    if "--long" in sys.argv:         # long hops: little or no overlap, gaps between frames
+        auto_cases = {"N=256 hop 144": short(256, 112, 29), "N=256 hop 160": short(256, 96, 29), "N=256 hop 192": short(256, 64, 29), "N=256 hop 256": short(256, 0, 29),
+                      "N=256 hop 320 (gap 64)": short(256, -64, 29), "N=128 hop 128": short(128, 0), "N=128 hop 192 (gap 64)": short(128, -64)}
     sys.argv.append("--auto")
 if "--auto" in sys.argv:
     cases = auto_cases
