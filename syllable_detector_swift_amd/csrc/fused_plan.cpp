@@ -364,7 +364,7 @@ bool make_mlpx_plan(const syldet_config_t &c, const syldet_geometry_t &g, MlpxPl
         }
     }
     if (T > 12) return no("timeRange above 12");
-    const int KB = F <= 64 ? 2 : 4;
+    const int KB = F <= 32 ? 1 : (F <= 64 ? 2 : 4);
     MlpxDesc &d = p.desc;
     d.F = F; d.T = T; d.KB = KB; d.H = H; d.rule = c.rule; d.scaling = c.scaling;
     d.col_stride = 32 * KB + 8;                      // 16-byte aligned rows that spread 16 consecutive rows over all banks

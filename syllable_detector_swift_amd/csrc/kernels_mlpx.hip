@@ -244,6 +244,7 @@ hipError_t launch_mlpx(const MlpxDesc &d, const float *columns, int C, int64_t J
         hipLaunchKernelGGL(kern, grid, dim3(kBlock), (size_t)d.lds_total, stream, d, columns, J, E, (int)tiles, outputs, flags);
         return hipGetLastError();
     };
+    if (d.KB == 1) return launch(mlp_mfma_kernel<1>);
     if (d.KB == 2) return launch(mlp_mfma_kernel<2>);
     if (d.KB == 4) return launch(mlp_mfma_kernel<4>);
     return hipErrorInvalidValue;
