@@ -691,7 +691,7 @@ hipError_t launch_fused_r(const FusedDesc &d, const float *samples, int64_t stri
     if (!fused_r_applicable(d)) return hipErrorInvalidValue;
     const int64_t s_eff = (J - 1) * (int64_t)d.hop + d.gap + d.W;
 #ifdef SYLDET_R_STAMPS                // diagnostic builds only (-DSYLDET_R_STAMPS): the instantiation with phase timing
-    if (d.stamps && d.skew == 0) return launch_one<8, 12, 9, 0, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
+    if (d.stamps && d.skew == 0 && d.KS == 8) return launch_one<8, 12, 9, 0, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
 #endif
     const bool exact = d.norm == 1 && d.tf0 == 0 /* TanSig */ && d.tf1 == 2 /* PureLin */;     // the example detector's class
     // (the short hops, and windows of up to 128 samples -- four k-steps --, take the instantiation with the network class as
