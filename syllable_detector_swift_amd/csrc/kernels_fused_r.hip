@@ -72,7 +72,7 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
     const int64_t e_e = (e_b + d.r_seg_evals < E) ? e_b + d.r_seg_evals : E;
     const float *row = samples + (int64_t)c * stride;
     const int H = d.H;
-    constexpr int n_out = 1;
+    const int n_out = GEN ? d.n_out : 1;              // (GEN: up to four outputs, each finished by its own lane group)
     const int fl = 16 * wave + f;     // this lane's frame / evaluation slot inside the pass
     const int runs = d.r_runs;
 
@@ -97,13 +97,16 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
 #pragma unroll
         for (int p = 0; p < 2; p++) aft[m][p] = as_half8(reinterpret_cast<const uint32x4 *>(d.afrag_t)[(m * 2 + p) * 64 + lane]);
     for (int i = tid; i < kPRows * kPStride / 4; i += kBlock) reinterpret_cast<floatx4 *>(pbuf)[i] = floatx4{0.f, 0.f, 0.f, 0.f};
-    const float c_b1 = d.b1[0];
+    const float c_b1 = GEN ? (g4 < n_out ? d.b1[g4] : 0.0f) : d.b1[0];   // (GEN: this lane group's output)
 
     const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(
         outputs ? outputs + (int64_t)c * E * n_out : nullptr, 0, outputs ? (int)(E * n_out * 4) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t flg_rs = __builtin_amdgcn_make_buffer_rsrc(flags ? flags + (int64_t)c * E : nullptr, 0, flags ? (int)E : 0, 0x00020000);
     float lean_oa = 0.0f, lean_og = 1.0f, lean_ob = 0.0f;
-    if (d.n_out_fns == 1) { lean_oa = d.out_params[0]; lean_og = d.out_params[1]; lean_ob = d.out_params[2]; }
+    if (d.n_out_fns == 1) {                       // reverse map (y - y0) / gain + xoff of this lane group's output: [y0 | gains | xoffs]
+        const int o = (GEN && g4 < n_out) ? g4 : 0;
+        lean_oa = d.out_params[0]; lean_og = d.out_params[1 + o]; lean_ob = d.out_params[1 + n_out + o];
+    }
 
     // this lane's frame in a staged buffer, and where k-step ks of lane group g4 starts inside it (see kernels_fused.hip)
     // SKEW (hop 128: every frame would start on the same LDS bank): sample i sits at i + 4 (i >> 7), so frame fl starts at
@@ -253,6 +256,12 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
     // ONE hidden unit (its own) through the transfer function instead of all four.  One step a tick (ticks 9 .. 12).
     float s01 = 0.0f, s23 = 0.0f, zt = 0.0f;
     const float b0g = g4 < H ? d.bias0[g4] : 0.0f, w1g = g4 < H ? d.w1[g4] : 0.0f;   // this lane group's hidden unit
+    float w1o[4];                                     // (GEN, several outputs: its weight in every output, w1 is [output][unit])
+#pragma unroll
+    for (int o = 0; o < 4; o++) w1o[o] = (GEN && g4 < H && o < n_out) ? d.w1[o * H + g4] : 0.0f;
+    const bool multi = GEN && n_out > 1;
+    const double thr_g = d.thresholds[(GEN && g4 < n_out) ? g4 : 0];
+    const bool counts = !GEN || n_out == 1 ? true : (g4 < n_out && (g4 == 0 || d.rule == 1));    // lastDetected: output 0; CLI rule: any
     auto eval_reduce = [&](int k) {
         if (k == 0) {
             const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(zp[0]), __float_as_uint(zp[1]), false, false);
@@ -276,7 +285,7 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
     };
     // the rest of the network (NeuralNet.swift:47-59 L2Normalize on the folded first layer, :189-194 TanSig, :366-377 second
     // layer, :137-142 / :175-180 reverse output map; SyllableDetector.swift:27-31 threshold), one step a slot
-    float ypart = 0.0f;
+    float ypart = 0.0f, yp[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     const int seg_len = (int)(e_e - e_b);
     const unsigned e_b32 = (unsigned)e_b;
     // (GEN: without a normaliser the products, kept relative to the segment's first pass, go back to true units by a constant)
@@ -286,19 +295,44 @@ fused_r_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
     auto eval_tail = [&](int k, int pp, unsigned thr) {
         if (k == 0) {                                             // this group's unit: z and the sums of squares are both relative
             const float alpha = norm == 1 ? d.w_unscale * __builtin_amdgcn_rsqf(ssw) : alpha0;   // L2Normalize, NeuralNet.swift:47-59
-            ypart = w1g * transfer_fn(tf0, fmaf(alpha, zt, b0g));
+            const float act = transfer_fn(tf0, fmaf(alpha, zt, b0g));
+            ypart = w1g * act;
+            if (multi) {
+#pragma unroll
+                for (int o = 0; o < 4; o++) yp[o] = w1o[o] * act;
+            }
         } else if (k == 1) {
-            float y = transfer_fn(tf1, xor32_sum(xor16_sum(ypart)) + c_b1);
+            float ysum;
+            if (multi) {
+                // the halving butterfly of eval_reduce again: the sum over the lane groups (hidden units) of yp[o] lands in lane
+                // group o, which finishes output o
+                auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(yp[0]), __float_as_uint(yp[1]), false, false);
+                const float a01 = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+                r = __builtin_amdgcn_permlane16_swap(__float_as_uint(yp[2]), __float_as_uint(yp[3]), false, false);
+                const float a23 = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+                r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a01), __float_as_uint(a23), false, false);
+                ysum = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+            } else {
+                ysum = xor32_sum(xor16_sum(ypart));
+            }
+            float y = transfer_fn(tf1, ysum + c_b1);
             y = (y - lean_oa) / lean_og + lean_ob;
             yv = y;
-            hit = (double)y >= reinterpret_cast<const double *>(cst + kCstThr)[0];
+            hit = counts && (double)y >= thr_g;
+            if (multi) {                                          // one flag an evaluation: any counting output over its threshold
+                unsigned hb = hit ? 1u : 0u;
+                auto r = __builtin_amdgcn_permlane16_swap(hb, hb, false, false);
+                hb = r[0] | r[1];
+                r = __builtin_amdgcn_permlane32_swap(hb, hb, false, false);
+                hit = (r[0] | r[1]) != 0u;
+            }
         } else if (k == 2) {                                      // stores, through the bounds-checked descriptors of this channel's rows
             const int er = kPass * pp - (T - 1) + fl;             // evaluation index inside the segment (32-bit arithmetic)
             const bool vld = pp >= 0 && er >= 0 && er < seg_len;
-            const bool st = vld && g4 == 0;
+            const bool st = vld && g4 == 0, sto = vld && g4 < n_out;      // flags: lane group 0; outputs: a lane group each
             badv = vld && !(ssw >= __uint_as_float(thr));         // the guard: too close to the grid's floor (or NaN) -> work list
             const unsigned off = e_b32 + (unsigned)er;            // E * 4 < 2^32 is checked by the launcher
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(yv), out_rs, st ? off * 4u : 0xFFFFFFFFu, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(yv), out_rs, sto ? (off * (unsigned)n_out + (unsigned)g4) * 4u : 0xFFFFFFFFu, 0, 0);
             __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(hit ? 1 : 0), flg_rs, st ? off : 0xFFFFFFFFu, 0, 0);
         }
     };
@@ -679,7 +713,7 @@ bool fused_r_applicable(const FusedDesc &d)
 {
     // two layers with at most 4 hidden units and one output, linear |X| columns, no normaliser or l2normalize in front of the
     // affine maps, at most one output map (any transfer functions; the example detector's get the exact instantiation)
-    const bool cls = (d.norm == 0 || d.norm == 1) && d.scaling == 0 && d.n_layers == 2 && d.n_out == 1 && d.H <= 4 && d.n_out_fns <= 1;
+    const bool cls = (d.norm == 0 || d.norm == 1) && d.scaling == 0 && d.n_layers == 2 && d.n_out >= 1 && d.n_out <= 4 && d.H <= 4 && d.n_out_fns <= 1;
     return d.r_ok && (d.KS == 8 || d.KS == 4) && d.T <= 12 && d.r_nload <= 9 && (d.skew == 0 || d.skew == 4) && cls;
 }
 
@@ -693,7 +727,7 @@ hipError_t launch_fused_r(const FusedDesc &d, const float *samples, int64_t stri
 #ifdef SYLDET_R_STAMPS                // diagnostic builds only (-DSYLDET_R_STAMPS): the instantiation with phase timing
     if (d.stamps && d.skew == 0 && d.KS == 8) return launch_one<8, 12, 9, 0, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
 #endif
-    const bool exact = d.norm == 1 && d.tf0 == 0 /* TanSig */ && d.tf1 == 2 /* PureLin */;     // the example detector's class
+    const bool exact = d.norm == 1 && d.tf0 == 0 /* TanSig */ && d.tf1 == 2 /* PureLin */ && d.n_out == 1;     // the example detector's class
     // (the short hops, and windows of up to 128 samples -- four k-steps --, take the instantiation with the network class as
     // run-time facts for the example class too)
 #define SD_R_GO(KS_, NL_, SKEW_, GEN_) return launch_one<KS_, 12, NL_, SKEW_, false, GEN_>(d, samples, stride, C, s_eff, E, outputs, flags, stream)

@@ -185,7 +185,7 @@ def test_random_configuration_streaming(oracle_lib, seed):
 def draw_example_class(rng):
     """The reference's example detector class, which runs on kernels_fused_r.hip: N = 256, windows of 192 or 256 samples (or N = 128, windows of 96 or 128),
     any timeRange up to 12, hop a multiple of 4 up to 140, l2normalize
-    first, <= 4 TanSig hidden units, one linear output, at most one output map; any band, window type, affine maps behind
+    first, <= 4 TanSig hidden units, one to four linear outputs, at most one output map; any band, window type, affine maps behind
     the normaliser, threshold, rule."""
     hop = int(rng.choice([16, 32, 48, 64, 64, 68, 80, 84, 96, 100, 112, 116, 120, 124, 128, 128, 132, 132, 132, 136, 140]))
     N = 256
@@ -201,9 +201,10 @@ def draw_example_class(rng):
     r = frequencyIndexRange(N, FS, lo, hi)
     F = r[1] - r[0]
     chain = [("l2normalize",), ("l2normalize", "mapminmax"), ("l2normalize", "mapstd"), ("l2normalize", "mapstd", "mapminmax")][int(rng.integers(0, 4))]
-    net = nets.random_net(rng, F * T, (int(rng.integers(1, 5)),), 1, transfer=("TanSig", "PureLin"), in_fns=chain,
+    n_out = 1 if rng.random() < 0.7 else int(rng.integers(2, 5))       # several syllables: an output and a threshold each
+    net = nets.random_net(rng, F * T, (int(rng.integers(1, 5)),), n_out, transfer=("TanSig", "PureLin"), in_fns=chain,
                           out_fns=[(), ("mapminmax",), ("mapstd",)][int(rng.integers(0, 3))])
-    return SyllableDetectorConfig(FS, N, W, W - hop, (lo, hi), T, "linear", [float(rng.uniform(-0.5, 0.8))], net,
+    return SyllableDetectorConfig(FS, N, W, W - hop, (lo, hi), T, "linear", [float(t) for t in rng.uniform(-0.5, 0.8, n_out)], net,
                                   window=int(rng.integers(0, 4)), spectrum=_abi.SPECTRUM_POWER, rule=int(rng.integers(0, 2)))
 
 

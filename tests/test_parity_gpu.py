@@ -189,6 +189,45 @@ def test_kernel_timings_of_the_last_calls():
         assert len(det.timingsOf(0)) == 1 and det.timingsOf(1) == []
 
 
+@pytest.mark.parametrize("n_out,H,rule,hop,maps", [(2, 4, 0, 132, ("mapminmax",)), (3, 3, 1, 132, ()), (4, 4, 1, 64, ("mapstd",)), (4, 2, 0, 96, ("mapminmax",)),
+                                                   (2, 1, 1, 100, ())])
+def test_several_outputs_on_the_register_resident_kernel(oracle_lib, n_out, H, rule, hop, maps):
+    """Up to four outputs (several syllables, one threshold each: SyllableDetector.swift:27-31 looks at output 0, the CLI at
+    any -- TrackDetector.swift:72-77) on kernels_fused_r.hip: every output is finished by its own lane group.  Values, flags
+    under both rules, planted syllables so that flags fire."""
+    torch = _torch()
+    rng = np.random.default_rng(100 * n_out + H)
+    base = util.sample_net()
+    net = nets.random_net(rng, 290, (H,), n_out, in_fns=("l2normalize", "mapminmax"), out_fns=maps)
+    cfg = nets.variant(base, net=net, thresholds=[float(t) for t in rng.uniform(-0.2, 0.3, n_out)], windowOverlap=256 - hop, rule=rule)
+    x = np.stack([synth.syllable_channel(64 * hop * 3 + 999, util.template(), seed=4 + c) for c in range(2)]).astype(np.float32)
+    # thresholds inside the range of each output (2e-5 clear of every value, so that every flag is decided), so that some fire
+    w = util.oracle_for(cfg).run(x[0], po.F64, rule)[2]
+    thr = []
+    for k in range(n_out):
+        v = np.sort(w[:, k])
+        gaps = np.diff(v)
+        lo, hi = (len(v) // 4, 3 * len(v) // 4) if rule == 0 else (17 * len(v) // 20, 19 * len(v) // 20)   # (rule "any": rarer hits, or every evaluation fires)
+        i = int(np.argmax(gaps[lo:hi])) + lo
+        thr.append(float(0.5 * (v[i] + v[i + 1])))
+    cfg = nets.variant(cfg, thresholds=thr)
+    o = util.oracle_for(cfg)
+    with sd.SyllableDetector(cfg, channels=2) as det:
+        det.profile(True)
+        out, fl = det.run(torch.from_numpy(x).cuda())
+        torch.cuda.synchronize()
+        assert [nm for nm, _ in det.lastTimings()] == ["fused_r_kernel"]
+        out, fl = out.cpu().numpy(), fl.cpu().numpy()
+    fired = 0
+    for c in range(2):
+        _, wfl, w64 = o.run(x[c], po.F64, rule)
+        assert out[c].shape == w64.shape == (o.count_evals(x.shape[1]), n_out)
+        util.assert_outputs_close(out[c], w64)
+        util.assert_flags_exact(fl[c], w64, cfg.thresholds, rule)
+        fired += int(fl[c].sum())
+    assert 0 < fired < out.shape[0] * out.shape[1]
+
+
 def test_detection_indices_and_debounce(oracle_lib):
     torch = _torch()
     cfg, x, gold = util.load_case("case_sample_syllables")
@@ -460,13 +499,13 @@ def test_both_fused_kernels_against_the_oracle_and_each_other(oracle_lib, monkey
 
 
 def test_register_resident_kernel_is_only_taken_where_it_is_instantiated(oracle_lib):
-    """A wider hidden layer, two outputs, a short window: kernels_fused.hip's kernel."""
+    """A wider hidden layer, a normaliser other than l2normalize: kernels_fused.hip's kernel."""
     torch = _torch()
     base = nets.from_npz()
     rng = np.random.default_rng(5)
     x = synth.channel(30000, 3)[None].astype(np.float32)
     xd = torch.from_numpy(x).cuda()
-    for cfg in (nets.variant(base, net=nets.random_net(rng, 290, (4,), 2), thresholds=[0.5, 0.5]),
+    for cfg in (nets.variant(base, net=nets.random_net(rng, 290, (4,), 1, in_fns=("normalizestd", "mapstd"))),
                 nets.variant(base, net=nets.random_net(rng, 290, (8,), 1))):
         with sd.SyllableDetector(cfg, channels=1, engine=_abi.ENGINE_FUSED) as det:
             det.profile(True)

@@ -23,6 +23,10 @@ cases = {
     "T=4": nets.variant(base, timeRange=4, net=nets.random_net(rng, 29 * 4, (4,), 1)),
     "T=8, hop 100": nets.variant(base, timeRange=8, windowOverlap=156, net=nets.random_net(rng, 29 * 8, (4,), 1)),
     "hop 128": nets.variant(base, windowOverlap=128),
+    "H=4, 2 outputs": nets.variant(base, net=nets.random_net(rng, 290, (4,), 2), thresholds=[0.5] * 2),
+    "H=4, 4 outputs": nets.variant(base, net=nets.random_net(rng, 290, (4,), 4), thresholds=[0.5] * 4),
+    "H=4, normalizestd chain": nets.variant(base, net=nets.random_net(rng, 290, (4,), 1, in_fns=("normalizestd", "mapstd"))),
+    "H=6, 1 output": nets.variant(base, net=nets.random_net(rng, 290, (6,), 1)),
 }
 # shapes outside the fused engine (AUTO: generic FFT + whichever network stage applies)
 auto_cases = {
