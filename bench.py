@@ -276,7 +276,8 @@ def main():
                     hdet.runHost(hx)
                 line["host_buffers"] = {"value": 3 * hc * hdet.countFrames(hs) / (time.perf_counter() - t1), "unit": "frames/s",
                                         "sample": "%d channels x %d samples through syldet_run (pageable host memory, PCIe both ways)" % (hc, hs)}
-            n_cpu = min(S, 1 << 22)
+            # (the 4096-unit network costs the CPU 2.4 MFLOP an evaluation: a sixteenth of the sample keeps five passes in the budget)
+            n_cpu = min(S, 1 << (18 if g.engine == 3 else 22))
             host = x[:min(C, 8), :n_cpu].cpu().numpy()
             # the reference runs every detector on one serial queue (Processor.swift:82,128; main.swift:126-130): 1 thread
             line["cpu_baseline"] = cpu_baseline(cfg, host, threads=1)
