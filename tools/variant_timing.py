@@ -27,6 +27,10 @@ cases = {
     "H=4, 4 outputs": nets.variant(base, net=nets.random_net(rng, 290, (4,), 4), thresholds=[0.5] * 4),
     "H=4, normalizestd chain": nets.variant(base, net=nets.random_net(rng, 290, (4,), 1, in_fns=("normalizestd", "mapstd"))),
     "H=6, 1 output": nets.variant(base, net=nets.random_net(rng, 290, (6,), 1)),
+    "H=8, hop 64": nets.variant(base, windowOverlap=192, net=nets.random_net(rng, 290, (8,), 1)),
+    "H=8, hop 68": nets.variant(base, windowOverlap=188, net=nets.random_net(rng, 290, (8,), 1)),
+    "H=8, hop 128": nets.variant(base, windowOverlap=128, net=nets.random_net(rng, 290, (8,), 1)),
+    "H=8, hop 96": nets.variant(base, windowOverlap=160, net=nets.random_net(rng, 290, (8,), 1)),
 }
 # shapes outside the fused engine (AUTO: generic FFT + whichever network stage applies)
 auto_cases = {
