@@ -114,8 +114,9 @@ __device__ __forceinline__ void stage(f2 (&v)[8], float sgn, f2 tw)
     }
 }
 
-// L = log2 P.  Frames per wave and round: 64 / P.  Every frame starts 8-byte aligned and the window is even (the launcher
-// checks): a lane's points come as (even, odd) sample pairs in one load.
+// L = log2 P.  Frames per wave and round: 64 / P.  PAD = false: every frame starts 8-byte aligned and the window fills the
+// frame (the launcher checks) -- a lane's points come as (even, odd) sample pairs in one load; PAD = true: any alignment and
+// any window up to N (zero pad :110), two loads a point, clamped into the window (what they fetch past it meets a zero).
 template <int L, bool PAD>
 __global__ void __launch_bounds__(kBlock, L >= 5 ? 3 : 4)      // (512-point frames at four waves a SIMD spill 16 registers: 4.87 ms against 4.17)
 stft_lanes_kernel(StftDesc d, const float *__restrict__ samples, int64_t stride, int64_t J, float *__restrict__ columns)
@@ -144,7 +145,7 @@ stft_lanes_kernel(StftDesc d, const float *__restrict__ samples, int64_t stride,
     for (int a = 0; a < 8; a++) {
         const int m = P * a + b, n0 = 2 * m;
         win[a] = f2{n0 < d.W ? d.window[n0] : 0.0f, n0 + 1 < d.W ? d.window[n0 + 1] : 0.0f};
-        moff[a] = (PAD && m >= d.W / 2) ? d.W / 2 - 1 : m;      // (no zero pad: P a + b, an immediate offset from one address)
+        moff[a] = PAD ? (n0 < d.W ? n0 : d.W - 1) : m;          // (PAD: the even sample's index, clamped into the window)
         tw1[a] = wN(2 * b * a);                                 // W_M^(b c), c = a
     }
     float sgn[6];
@@ -179,11 +180,17 @@ stft_lanes_kernel(StftDesc d, const float *__restrict__ samples, int64_t stride,
     if (j0 >= J) return;
     auto fetch = [&](int64_t j, f2 (&raw)[8]) {
         j = j < J ? j : J - 1;                                  // frames past the end repeat the last one and are not stored
-        const float2 *x = reinterpret_cast<const float2 *>(chan + j * d.hop);
+        const float *xf = chan + j * d.hop;
+        const float2 *x = reinterpret_cast<const float2 *>(xf);
 #pragma unroll
         for (int a = 0; a < 8; a++) {
-            const float2 s2 = PAD ? x[moff[a]] : x[P * a + b];
-            raw[a] = f2{s2.x, s2.y};
+            if (PAD) {                                          // any alignment, any window up to N: two loads a point
+                const int i1 = moff[a] + 1 < d.W ? moff[a] + 1 : d.W - 1;
+                raw[a] = f2{xf[moff[a]], xf[i1]};
+            } else {
+                const float2 s2 = x[P * a + b];
+                raw[a] = f2{s2.x, s2.y};
+            }
         }
     };
     f2 nxt[8];
@@ -235,10 +242,10 @@ stft_lanes_kernel(StftDesc d, const float *__restrict__ samples, int64_t stride,
 
 bool stft_lanes_applicable(const StftDesc &d, const float *samples, int64_t stride)
 {
-    // 128-, 256- or 512-point frames; every frame 8-byte aligned and an even window (sample pairs in one load)
+    // 128-, 256- or 512-point frames
+    (void)samples; (void)stride;
     static const bool with_1k = std::getenv("SYLDET_LANES_1K") != nullptr;      // (experiment: 1024-point frames too, instead of stft_r8_kernel)
-    return (d.M == 64 || d.M == 128 || d.M == 256 || (with_1k && d.M == 512)) && d.W <= 2 * d.M && d.W >= 2 && (d.W & 1) == 0 && (d.hop & 1) == 0 && (d.gap & 1) == 0 &&
-           (stride & 1) == 0 && (reinterpret_cast<uintptr_t>(samples) & 7) == 0 && d.F >= 1 && d.f0 >= 0 && d.f0 + d.F <= d.M;
+    return (d.M == 64 || d.M == 128 || d.M == 256 || (with_1k && d.M == 512)) && d.W <= 2 * d.M && d.W >= 1 && d.F >= 1 && d.f0 >= 0 && d.f0 + d.F <= d.M;
 }
 
 hipError_t launch_stft_lanes(const StftDesc &d, const float *samples, int64_t stride, int C, int64_t J, float *columns, hipStream_t stream)
@@ -248,7 +255,8 @@ hipError_t launch_stft_lanes(const StftDesc &d, const float *samples, int64_t st
     const int P = d.M / 8;
     const int64_t per_block = (int64_t)(kBlock / kWave) * kRounds * (kWave / P);
     dim3 grid((unsigned)((J + per_block - 1) / per_block), (unsigned)C);
-    const bool pad = d.W < 2 * d.M;
+    // sample pairs in one load where every frame is 8-byte aligned and the window fills it
+    const bool pad = d.W < 2 * d.M || (d.hop & 1) != 0 || (d.gap & 1) != 0 || (stride & 1) != 0 || (reinterpret_cast<uintptr_t>(samples) & 7) != 0;
     auto go = [&](auto kern) { hipLaunchKernelGGL(kern, grid, dim3(kBlock), 0, stream, d, samples, stride, J, columns); };
     if (d.M == 64) pad ? go(stft_lanes_kernel<3, true>) : go(stft_lanes_kernel<3, false>);
     else if (d.M == 128) pad ? go(stft_lanes_kernel<4, true>) : go(stft_lanes_kernel<4, false>);
