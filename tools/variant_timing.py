@@ -27,6 +27,9 @@ cases = {
     "H=4, 4 outputs": nets.variant(base, net=nets.random_net(rng, 290, (4,), 4), thresholds=[0.5] * 4),
     "H=4, normalizestd chain": nets.variant(base, net=nets.random_net(rng, 290, (4,), 1, in_fns=("normalizestd", "mapstd"))),
     "H=6, 1 output": nets.variant(base, net=nets.random_net(rng, 290, (6,), 1)),
+    "H=8, T=8": nets.variant(base, timeRange=8, net=nets.random_net(rng, 29 * 8, (8,), 1)),
+    "H=8, T=12": nets.variant(base, timeRange=12, net=nets.random_net(rng, 29 * 12, (8,), 1)),
+    "H=8, T=10, hop 120": nets.variant(base, windowOverlap=136, net=nets.random_net(rng, 290, (8,), 1)),
     "H=8, hop 64": nets.variant(base, windowOverlap=192, net=nets.random_net(rng, 290, (8,), 1)),
     "H=8, hop 68": nets.variant(base, windowOverlap=188, net=nets.random_net(rng, 290, (8,), 1)),
     "H=8, hop 128": nets.variant(base, windowOverlap=128, net=nets.random_net(rng, 290, (8,), 1)),
