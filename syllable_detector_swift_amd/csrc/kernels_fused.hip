@@ -137,12 +137,19 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
     for (int i = tid; i < (SPECT ? 0 : d.n_out_fns * (1 + 2 * n_out)); i += kBlock) cst[kCstOut + i] = d.out_params[i];
     // first-layer fragments, one (hi, lo) pair per tap: A operand, lane l holds row l&15 (hidden unit, or the
     // statistic row), k = 8*(l>>4) + j (bin)
-    half8 afr[TMAX][2];
+    // (In registers, 8 a tap -- except in the exact-size instantiation with bank-spread staging and the network as run-time
+    // facts, which spills 91 registers that way and 40 when it fetches a tap's pair when it is due, three taps ahead, from the
+    // table in memory (every workgroup reads the same few KB, which stay in the caches): 8 hidden units at hop 128 1.98 ms
+    // against 3.30.  Measured the other way round elsewhere: without the padding 1.86 against 1.81, and the instantiations
+    // with run-time sizes -- which spill 70 - 146 registers either way -- 7.4 ms against 4.1 at timeRange 12.)
+    constexpr bool kAfrRegs = LEAN || SPECT || !(EXACT && SKEW);
+    half8 afr[kAfrRegs ? TMAX : 1][2];
+    const uint32x4 *afr_mem = reinterpret_cast<const uint32x4 *>(d.afrag) + lane;
 #pragma unroll
-    for (int t = 0; t < TMAX; t++)
+    for (int t = 0; t < (kAfrRegs ? TMAX : 1); t++)
 #pragma unroll
         for (int p = 0; p < 2; p++)
-            afr[t][p] = SPECT ? half8{} : as_half8(reinterpret_cast<const uint32x4 *>(d.afrag)[((t < T ? t : 0) * 2 + p) * 64 + lane]);
+            afr[t][p] = (SPECT || !kAfrRegs) ? half8{} : as_half8(afr_mem[((t < T ? t : 0) * 2 + p) * 64]);
     // evaluation-phase constants of the 4 hidden units this lane group owns (rows 4*g4 + j of a result)
     float c_b0[4], c_rv[4], c_w1[4][4];
 #pragma unroll
@@ -221,7 +228,9 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
             if (k < nload && !(kom & 2)) {
                 const floatx4 q = as_floatx4(v[k]);
                 const int i = 4 * (tid + kBlock * k);
-                if (k + 1 < nload || i < d.nsmp) {             // only the last quad set can reach past the pass
+                // (quads past the pass are not staged: with exact sizes the nine quads of a thread are loaded whatever the hop,
+                // and those past the pass came back as zeros from the descriptor's bounds check)
+                if (EXACT ? i < d.nsmp : (k + 1 < nload || i < d.nsmp)) {
                     unsigned h0, l0, h1, l1;
                     split_pair_scaled(q[0], q[1], sx, h0, l0);
                     split_pair_scaled(q[2], q[3], sx, h1, l1);
@@ -259,6 +268,7 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
     bool hit = false;
     constexpr int kAhead = 3;                                 // column fragments are fetched this many taps ahead
     uint32x4 bh_q[kAhead], bl_q[kAhead];
+    uint32x4 ah_q[kAhead], al_q[kAhead];                     // (first-layer fragments of the taps ahead, where they are not resident)
     // Evaluation slot q < T-1 straddles two passes: its window is the transition strip [T-1 carried columns | copies of
     // this pass's first T-1 columns], kept at a scale both passes fit in; every other window reads the pass's own
     // columns at the pass's own scale.  Either way the window is T consecutive slots starting at `wslot`.
@@ -269,13 +279,23 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
         for (int t = 0; t < TMAX; t++) {
             if (t >= t0 && t < t1 && t < T && !(kom & 16)) {
                 const half8 h0 = as_half8(bh_q[t % kAhead]), l0 = as_half8(bl_q[t % kAhead]);
+                const half8 a0 = kAfrRegs ? afr[kAfrRegs ? t : 0][0] : as_half8(ah_q[t % kAhead]);
+                const half8 a1 = kAfrRegs ? afr[kAfrRegs ? t : 0][1] : as_half8(al_q[t % kAhead]);
                 if (t + kAhead < T) {
                     bh_q[t % kAhead] = *reinterpret_cast<const uint32x4 *>(bph + (t + kAhead) * kColStride);
                     bl_q[t % kAhead] = *reinterpret_cast<const uint32x4 *>(bpl + (t + kAhead) * kColStride);
+                    if (!kAfrRegs) {
+                        // (the address goes through an opaque statement here: left alone the compiler hoists the fetches of
+                        // all taps to the top of the evaluation and the fragments are resident again)
+                        const uint32x4 *pm = afr_mem + ((t + kAhead) * 2) * 64;
+                        asm volatile("" : "+v"(pm));
+                        ah_q[t % kAhead] = pm[0];
+                        al_q[t % kAhead] = pm[64];
+                    }
                 }
-                z = mfma(afr[t][0], h0, z);                   // two accumulation chains: hi*hi on one,
-                z2 = mfma(afr[t][0], l0, z2);                 // the cross terms on the other
-                z2 = mfma(afr[t][1], h0, z2);
+                z = mfma(a0, h0, z);                          // two accumulation chains: hi*hi on one,
+                z2 = mfma(a0, l0, z2);                        // the cross terms on the other
+                z2 = mfma(a1, h0, z2);
             }
         }
     };
@@ -291,6 +311,10 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
                 if (t < T && !(kom & 16)) {
                     bh_q[t] = *reinterpret_cast<const uint32x4 *>(bph + t * kColStride);
                     bl_q[t] = *reinterpret_cast<const uint32x4 *>(bpl + t * kColStride);
+                    if (!kAfrRegs) {
+                        ah_q[t] = afr_mem[(t * 2 + 0) * 64];
+                        al_q[t] = afr_mem[(t * 2 + 1) * 64];
+                    }
                 }
             gemm0_taps(0, n0);
         } else if (step == 1) {
@@ -765,13 +789,22 @@ hipError_t launch_fused(const FusedDesc &d, const float *samples, int64_t stride
     const int64_t s_eff = (J - 1) * (int64_t)d.hop + d.gap + d.W;
     const bool skew = d.skew != 0;
     // the reference's example shape (W = 256, hop 132, timeRange 10) gets an instantiation with exact sizes
-    if (d.KS == 8 && d.T == 10 && d.nload == 9 && skew) {      // the same shape at hop 128 (bank-spread staging)
+    // (timeRange 8 and 12 at any hop up to 140, with the network as run-time facts: exact sizes too)
+    if (d.KS == 8 && d.T == 8 && d.nload <= 9) {
+        if (skew) return launch_one<8, 8, 9, true, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
+        return launch_one<8, 8, 9, true, false>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
+    }
+    if (d.KS == 8 && d.T == 12 && d.nload <= 9) {
+        if (skew) return launch_one<8, 12, 9, true, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
+        return launch_one<8, 12, 9, true, false>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
+    }
+    if (d.KS == 8 && d.T == 10 && d.nload <= 9 && skew) {      // the same shape at hop 128 (bank-spread staging)
         const bool lean = d.norm == 1 && d.scaling == 0 && d.n_layers == 2 && d.tf0 == 0 /* TanSig */ && d.tf1 == 2 /* PureLin */ &&
                           d.n_out == 1 && d.H <= 4 && d.n_out_fns <= 1;
         if (lean) return launch_one<8, 10, 9, true, true, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
         return launch_one<8, 10, 9, true, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
     }
-    if (d.KS == 8 && d.T == 10 && d.nload == 9 && !skew) {
+    if (d.KS == 8 && d.T == 10 && d.nload <= 9 && !skew) {
         const bool lean = d.norm == 1 && d.scaling == 0 && d.n_layers == 2 && d.tf0 == 0 /* TanSig */ && d.tf1 == 2 /* PureLin */ &&
                           d.n_out == 1 && d.H <= 4 && d.n_out_fns <= 1;
 #ifdef SYLDET_KNOCKOUTS

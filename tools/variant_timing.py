@@ -55,6 +55,9 @@ if "--short" in sys.argv:            # short frames and hops (AUTO)
     sys.argv.append("--auto")
 if "--auto" in sys.argv:
     cases = auto_cases
+if "--only" in sys.argv:
+    key = sys.argv[sys.argv.index("--only") + 1]
+    cases = {k: v for k, v in cases.items() if key in k}
 for name, cfg in cases.items():
     with sd.SyllableDetector(cfg, channels=C, engine=_abi.ENGINE_AUTO if "--auto" in sys.argv else _abi.ENGINE_FUSED) as det:
         E = det.countEvaluations(S)
