@@ -559,7 +559,7 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
             const int src = (XS + kPass - (T - 1)) * (kColStride / 2);
             // all reads first, then all writes: one LDS round trip instead of one per 64 words (this wave is the
             // last one through the phase, so its latency is the workgroup's)
-            constexpr int kIt = (2 * (TMAX - 1) * (kColStride / 2) + 63) / 64;
+            constexpr int kIt = TMAX > 1 ? (2 * (TMAX - 1) * (kColStride / 2) + 63) / 64 : 1;    // (timeRange 1: nothing is carried)
             unsigned u[kIt];
 #pragma unroll
             for (int k = 0; k < kIt; k++) {
@@ -789,15 +789,19 @@ hipError_t launch_fused(const FusedDesc &d, const float *samples, int64_t stride
     const int64_t s_eff = (J - 1) * (int64_t)d.hop + d.gap + d.W;
     const bool skew = d.skew != 0;
     // the reference's example shape (W = 256, hop 132, timeRange 10) gets an instantiation with exact sizes
-    // (timeRange 8 and 12 at any hop up to 140, with the network as run-time facts: exact sizes too)
-    if (d.KS == 8 && d.T == 8 && d.nload <= 9) {
-        if (skew) return launch_one<8, 8, 9, true, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
-        return launch_one<8, 8, 9, true, false>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
+    // (every other timeRange at any hop up to 140, with the network as run-time facts: exact sizes too -- the instantiations
+    // with run-time sizes spill 70 - 146 registers and run at half the speed)
+#define SD_EXACT(KS_, T_)                                                                                                    \
+    if (d.KS == KS_ && d.T == T_ && d.nload <= 9 && !(KS_ == 8 && T_ == 10)) {                                               \
+        if (skew) return launch_one<KS_, T_, 9, true, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);        \
+        return launch_one<KS_, T_, 9, true, false>(d, samples, stride, C, s_eff, E, outputs, flags, stream);                 \
     }
-    if (d.KS == 8 && d.T == 12 && d.nload <= 9) {
-        if (skew) return launch_one<8, 12, 9, true, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
-        return launch_one<8, 12, 9, true, false>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
-    }
+#define SD_EXACT_ALL(KS_) SD_EXACT(KS_, 1) SD_EXACT(KS_, 2) SD_EXACT(KS_, 3) SD_EXACT(KS_, 4) SD_EXACT(KS_, 5) SD_EXACT(KS_, 6) \
+    SD_EXACT(KS_, 7) SD_EXACT(KS_, 8) SD_EXACT(KS_, 9) SD_EXACT(KS_, 10) SD_EXACT(KS_, 11) SD_EXACT(KS_, 12)
+    SD_EXACT_ALL(8)
+    SD_EXACT_ALL(4)
+#undef SD_EXACT_ALL
+#undef SD_EXACT
     if (d.KS == 8 && d.T == 10 && d.nload <= 9 && skew) {      // the same shape at hop 128 (bank-spread staging)
         const bool lean = d.norm == 1 && d.scaling == 0 && d.n_layers == 2 && d.tf0 == 0 /* TanSig */ && d.tf1 == 2 /* PureLin */ &&
                           d.n_out == 1 && d.H <= 4 && d.n_out_fns <= 1;

@@ -30,6 +30,9 @@ cases = {
     "H=8, T=8": nets.variant(base, timeRange=8, net=nets.random_net(rng, 29 * 8, (8,), 1)),
     "H=8, T=12": nets.variant(base, timeRange=12, net=nets.random_net(rng, 29 * 12, (8,), 1)),
     "H=8, T=10, hop 120": nets.variant(base, windowOverlap=136, net=nets.random_net(rng, 290, (8,), 1)),
+    "H=8, T=5": nets.variant(base, timeRange=5, net=nets.random_net(rng, 29 * 5, (8,), 1)),
+    "H=8, T=11": nets.variant(base, timeRange=11, net=nets.random_net(rng, 29 * 11, (8,), 1)),
+    "H=8, N=128 hop 64": nets.variant(base, fourierLength=128, windowLength=128, windowOverlap=64, freqRange=(2000.0, 6900.0), net=nets.random_net(rng, 15 * 10, (8,), 1)),
     "H=8, hop 64": nets.variant(base, windowOverlap=192, net=nets.random_net(rng, 290, (8,), 1)),
     "H=8, hop 68": nets.variant(base, windowOverlap=188, net=nets.random_net(rng, 290, (8,), 1)),
     "H=8, hop 128": nets.variant(base, windowOverlap=128, net=nets.random_net(rng, 290, (8,), 1)),
