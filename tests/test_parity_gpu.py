@@ -544,7 +544,9 @@ def test_network_stage_on_the_matrix_cores(oracle_lib, N, lo, hi, T, H, scaling)
     x[1, 20000:20000 + 40 * N] = 0.0
     xd = torch.from_numpy(x).cuda()
     o = util.oracle_for(cfg)
-    for engine, kernel in ((_abi.ENGINE_AUTO, "mlp_mfma_kernel"), (_abi.ENGINE_GENERIC, "mlp_generic_kernel")):
+    # (1024-point frames in front of a network of this class: the one-launch kernel where its shape applies)
+    one_launch = N == 1024 and scaling == "linear" and F % 4 == 0
+    for engine, kernel in ((_abi.ENGINE_AUTO, "fft1k_net_kernel" if one_launch else "mlp_mfma_kernel"), (_abi.ENGINE_GENERIC, "mlp_generic_kernel")):
         with sd.SyllableDetector(cfg, channels=2, engine=engine) as det:
             det.profile(True)
             out, fl = det.run(xd)
@@ -612,7 +614,8 @@ def test_c_program_over_the_abi(oracle_lib, tmp_path):
 def test_1024_point_frames_in_one_launch_and_in_two(oracle_lib, monkeypatch):
     """BASELINE configs[2]'s shape: the one-launch kernel (packed real FFT + matrix-core network stage, columns never in HBM:
     kernels_fft1k.hip) and the two-launch form it replaces (stft_r8_kernel -> columns -> mlp_mfma_kernel), both against the
-    oracle; lengths around the 128-frame tiles and the carried columns; an odd channel stride keeps the two-launch form."""
+    oracle; lengths around the 128-frame tiles and the carried columns; rows that do not start 8-byte aligned (an odd channel
+    stride) take the one-launch kernel too, with two loads a point."""
     torch = _torch()
     cfg = nets.config3()
     hop = cfg.windowLength - cfg.windowOverlap
@@ -637,7 +640,7 @@ def test_1024_point_frames_in_one_launch_and_in_two(oracle_lib, monkeypatch):
             for c in range(3):
                 util.assert_outputs_close(out[c], want[c])
                 util.assert_flags_exact(fl[c], want[c], cfg.thresholds, cfg.rule)
-    # rows that do not start 8-byte aligned (an odd stride) take the two-launch form
+    # rows that do not start 8-byte aligned (an odd stride): the same kernel, two loads a point
     monkeypatch.delenv("SYLDET_NO_FFT1K", raising=False)
     S = cfg.windowLength + 199 * hop
     base = torch.from_numpy(synth.channels(2, S + 1, first=7)).cuda()
@@ -646,6 +649,6 @@ def test_1024_point_frames_in_one_launch_and_in_two(oracle_lib, monkeypatch):
         det.profile(True)
         out, _ = det.run(xs)
         torch.cuda.synchronize()
-        assert [nm for nm, _ in det.lastTimings()] == ["stft_generic_kernel", "mlp_mfma_kernel"]
+        assert [nm for nm, _ in det.lastTimings()] == ["fft1k_net_kernel"]
         for c in range(2):
             util.assert_outputs_close(out[c].cpu().numpy(), o.run(xs[c].cpu().numpy(), po.F64)[2])
