@@ -50,12 +50,17 @@ class SyllableDetector: NSObject, AVCaptureAudioDataOutputSampleBufferDelegate {
     private let bank: SyllableDetectorBank
     private let channel: Int32
 
-    // the reference's reader settings, unchanged: Float32, non-interleaved, at the network's rate (:19-23; used by
-    // TrackDetector.swift:35 and ViewControllerSimulator.swift:176)
+    /// What a reader must deliver to this detector (the role of Common/SyllableDetector.swift:19-23; read by
+    /// TrackDetector.swift:35 and ViewControllerSimulator.swift:176): packed 32-bit float PCM, one plane per channel,
+    /// already at the network's sampling rate -- libsyldet's rings take exactly that layout.
     var audioSettings: [String: AnyObject] {
-        get {
-            return [AVFormatIDKey: NSNumber(value: kAudioFormatLinearPCM), AVLinearPCMBitDepthKey: NSNumber(value: 32), AVLinearPCMIsFloatKey: true as AnyObject, AVLinearPCMIsNonInterleaved: true as AnyObject, AVSampleRateKey: NSNumber(value: config.samplingRate)]
-        }
+        var wanted = [String: AnyObject]()
+        wanted[AVFormatIDKey] = NSNumber(value: kAudioFormatLinearPCM)
+        wanted[AVSampleRateKey] = NSNumber(value: config.samplingRate)
+        wanted[AVLinearPCMBitDepthKey] = NSNumber(value: MemoryLayout<Float>.size * 8)
+        wanted[AVLinearPCMIsFloatKey] = NSNumber(value: true)
+        wanted[AVLinearPCMIsNonInterleaved] = NSNumber(value: true)
+        return wanted
     }
 
     var lastOutputs: [Float] {
@@ -85,30 +90,31 @@ class SyllableDetector: NSObject, AVCaptureAudioDataOutputSampleBufferDelegate {
         }
     }
 
-    /// Common/SyllableDetector.swift:81-119: the same format checks, then the samples go to this channel's ring
-    /// (callers: TrackDetector.swift:62, ViewControllerSimulator.swift:292)
+    /// The role of Common/SyllableDetector.swift:81-119 (callers: TrackDetector.swift:62, ViewControllerSimulator.swift:292):
+    /// refuse anything but planar 32-bit float PCM the way the reference does (fatalError), then hand the buffer's samples to
+    /// this channel's ring.  Written against the audio buffer list rather than the raw block buffer: a sample buffer whose
+    /// block is not contiguous is still delivered whole.
     func processSampleBuffer(_ sampleBuffer: CMSampleBuffer) {
-        let numSamples = CMSampleBufferGetNumSamples(sampleBuffer)
-        guard 0 < numSamples else { return }
-        guard let format = CMSampleBufferGetFormatDescription(sampleBuffer) else { return }
-        let audioDescription = CMAudioFormatDescriptionGetStreamBasicDescription(format)
-        let isInterleaved = 1 < (audioDescription?[0].mChannelsPerFrame)! && 0 == ((audioDescription?[0].mFormatFlags)! & kAudioFormatFlagIsNonInterleaved)
-        let isFloat = 0 < ((audioDescription?[0].mFormatFlags)! & kAudioFormatFlagIsFloat)
-        guard audioDescription?[0].mFormatID == kAudioFormatLinearPCM && isFloat && !isInterleaved && audioDescription?[0].mBitsPerChannel == 32 else {
-            fatalError("Invalid audio format.")
-        }
-        guard let audioBuffer = CMSampleBufferGetDataBuffer(sampleBuffer) else { return }
-        var lengthAtOffset: Int = 0, totalLength: Int = 0
-        var inSamples: UnsafeMutablePointer<Int8>? = nil
-        CMBlockBufferGetDataPointer(audioBuffer, 0, &lengthAtOffset, &totalLength, &inSamples)
-        inSamples!.withMemoryRebound(to: Float.self, capacity: numSamples) {
-            appendAudioData($0, withSamples: numSamples)
-        }
+        let frames = CMSampleBufferGetNumSamples(sampleBuffer)
+        if frames <= 0 { return }
+        guard let desc = CMSampleBufferGetFormatDescription(sampleBuffer),
+              let asbd = CMAudioFormatDescriptionGetStreamBasicDescription(desc)?.pointee else { return }
+        let planar = asbd.mChannelsPerFrame <= 1 || (asbd.mFormatFlags & kAudioFormatFlagIsNonInterleaved) != 0
+        let float32 = asbd.mFormatID == kAudioFormatLinearPCM && (asbd.mFormatFlags & kAudioFormatFlagIsFloat) != 0 && asbd.mBitsPerChannel == 32
+        if !(planar && float32) { fatalError("Invalid audio format.") }             // :100-102
+        var list = AudioBufferList()
+        var block: CMBlockBuffer? = nil
+        let st = CMSampleBufferGetAudioBufferListWithRetainedBlockBuffer(sampleBuffer, nil, &list, MemoryLayout<AudioBufferList>.size, nil, nil,
+                                                                         kCMSampleBufferFlag_AudioBufferList_Assure16ByteAlignment, &block)
+        guard st == noErr, let bytes = list.mBuffers.mData else { return }
+        let n = min(frames, Int(list.mBuffers.mDataByteSize) / MemoryLayout<Float>.size)
+        appendAudioData(bytes.assumingMemoryBound(to: Float.self), withSamples: n)
     }
 
-    /// :121-124 (AVCaptureAudioDataOutputSampleBufferDelegate)
+    /// :121-127 (AVCaptureAudioDataOutputSampleBufferDelegate): ingest, then drain every evaluation that became available
     func captureOutput(_ captureOutput: AVCaptureOutput, didOutput sampleBuffer: CMSampleBuffer, from connection: AVCaptureConnection) {
         processSampleBuffer(sampleBuffer)
+        while processNewValue() {}
     }
 
     func processNewValue() -> Bool { return syldet_process_new_value(bank.handle, channel) == 1 }

@@ -161,6 +161,7 @@ struct FusedDesc {
     float guard_spect;          // spectrogram instantiation: a frame's column sum of squares (grid units) ...
     int guard_se_abs_s;         //   ... in passes scaled below this exponent
     FixList fix;                // work list of evaluations to recompute (null counters: guard off)
+    int force_classic;          // the handle was created under SYLDET_FUSED_CLASSIC=1: the 8-wave kernel where both take the shape
     int ko;                     // diagnostic build only: knock-out mask (SYLDET_FUSED_KO)
     unsigned long long *stamps; // diagnostic build only: [workgroups][16] phase cycle sums, else null
 };

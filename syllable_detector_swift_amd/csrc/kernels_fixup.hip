@@ -83,7 +83,7 @@ fixup_kernel(const FixDesc fd, const NetDesc n, const float *__restrict__ sample
                 columns[((int64_t)c * J + first + fr) * F + b] = fd.power_mode ? (float)(re * re + im * im) : mag;
         }
         __syncthreads();
-        if (spect) continue;
+        if (spect || (!outputs && !flags)) continue;    // (no network buffers were allocated for a launch without result arrays)
         // the item's evaluations, one wave each a round; every wave makes the same number of rounds (workgroup barriers inside)
         float *bufA = nbuf + (size_t)wave * 2 * n.max_width, *bufB = bufA + n.max_width;
         for (int r = 0; r < (kFixMaxCount + kBlock / kWave - 1) / (kBlock / kWave); r++) {
@@ -116,8 +116,11 @@ hipError_t launch_fixup(const FixDesc &fd, const NetDesc &n, const float *sample
                         float *outputs, uint8_t *flags, float *columns, const FixList &list, hipStream_t stream)
 {
     if (!list.counters) return hipSuccess;
+    // (the network's buffers only where evaluations are recomputed: behind the spectrogram kernels -- outputs and flags null,
+    // frame items only -- a wide network in front of the generic / wide engines must not count against the 160 KB)
+    const bool evals = outputs != nullptr || flags != nullptr;
     const size_t lds = (size_t)fd.N * sizeof(double2) + ((size_t)(kMaxFrames - 1) * fd.hop + 2 * (size_t)fd.W + (size_t)kMaxFrames * fd.F) * sizeof(float) +
-                       (size_t)(kBlock / kWave) * 2 * (size_t)n.max_width * sizeof(float);
+                       (evals ? (size_t)(kBlock / kWave) * 2 * (size_t)n.max_width * sizeof(float) : 0);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (lds > 64 * 1024) {
         hipError_t st = hipFuncSetAttribute((const void *)fixup_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

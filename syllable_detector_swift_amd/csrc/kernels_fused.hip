@@ -780,9 +780,9 @@ hipError_t launch_fused(const FusedDesc &d, const float *samples, int64_t stride
                         int64_t E, float *outputs, uint8_t *flags, hipStream_t stream)
 {
     if (E <= 0 || C <= 0) return hipSuccess;
-    // the register-resident-basis kernel where it is instantiated (SYLDET_FUSED_CLASSIC=1 keeps this file's kernel: A/B
-    // runs and the tests that hold the two against each other; read per call so that one process can do both)
-    const bool classic = std::getenv("SYLDET_FUSED_CLASSIC") != nullptr;
+    // the register-resident-basis kernel where it is instantiated (a handle created under SYLDET_FUSED_CLASSIC=1 keeps this
+    // file's kernel: A/B runs and the tests that hold the two against each other)
+    const bool classic = d.force_classic != 0;
     if ((!classic || !d.classic_ok) && !d.ko && fused_r_applicable(d) && (!d.stamps || fused_r_has_stamps() || !d.classic_ok)) return launch_fused_r(d, samples, stride, C, S, J, E, outputs, flags, stream);
     if (!d.classic_ok) return hipErrorInvalidValue;
     // one past the last sample an existing frame reads: frame J-1 covers [(J-1)*hop + gap, ... + W)

@@ -119,6 +119,28 @@ struct syldet {
     int device = 0;
     int engine = SYLDET_ENGINE_GENERIC;
 
+    // Diagnostic switches (A/B runs, and the tests that hold two forms of a kernel against each other): read from the
+    // environment ONCE, when the handle is created -- never on the launch path, and a handle keeps the form it was created for.
+    struct Switches {
+        bool fused_classic = false;   // SYLDET_FUSED_CLASSIC: the 8-wave fused kernel where both fused kernels take the shape
+        bool no_fft1k = false;        // SYLDET_NO_FFT1K: 1024-point frames as two launches
+        bool no_stft_lanes = false;   // SYLDET_NO_STFT_LANES: the LDS Stockham FFT instead of the lane-butterfly one
+        bool no_guard = false;        // SYLDET_NO_GUARD: the precision guard off
+        bool no_mlpx = false;         // SYLDET_NO_MLPX: the interpretive network kernels under AUTO
+        bool fused_stamps = false;    // SYLDET_FUSED_STAMPS: the stamped diagnostic instantiation
+        int fused_ko = 0;             // SYLDET_FUSED_KO=<mask>: knock-out instantiation
+        void read()
+        {
+            fused_classic = std::getenv("SYLDET_FUSED_CLASSIC") != nullptr;
+            no_fft1k = std::getenv("SYLDET_NO_FFT1K") != nullptr;
+            no_stft_lanes = std::getenv("SYLDET_NO_STFT_LANES") != nullptr;
+            no_guard = std::getenv("SYLDET_NO_GUARD") != nullptr;
+            no_mlpx = std::getenv("SYLDET_NO_MLPX") != nullptr;
+            fused_stamps = std::getenv("SYLDET_FUSED_STAMPS") != nullptr;
+            fused_ko = std::getenv("SYLDET_FUSED_KO") ? std::atoi(std::getenv("SYLDET_FUSED_KO")) : 0;
+        }
+    } sw;
+
     // device tables
     DeviceBuffer d_window, d_tw, d_sw, d_params, d_thr;
     StftDesc stft{};
@@ -407,8 +429,7 @@ int upload_fix(syldet *h)
 int prepare_fix(syldet *h, int C, int64_t units, int64_t segments, hipStream_t stream, FixList &out)
 {
     out = FixList{nullptr, nullptr, 0};
-    static const bool no_guard = std::getenv("SYLDET_NO_GUARD") != nullptr;
-    if (!h->has_fix || no_guard) return SYLDET_OK;
+    if (!h->has_fix || h->sw.no_guard) return SYLDET_OK;
     const uint64_t cap = (uint64_t)C * (uint64_t)((units + 15) / 16 + 8 * segments + 16);
     if (cap > 0x7fffffffull) return SYLDET_OK;              // (rows this long take the generic engine anyway)
     const size_t bytes = 16 + (size_t)cap * sizeof(FixItem);
@@ -524,8 +545,7 @@ int stft_on_stream(syldet *h, const float *d_samples, int64_t stride, int C, int
         SYLDET_HIP(launch_fixup(h->fixd, h->net, d_samples, stride, J, 0, nullptr, nullptr, d_columns, d.fix, stream));
         return SYLDET_OK;
     }
-    const bool no_lanes = std::getenv("SYLDET_NO_STFT_LANES") != nullptr;            // (A/B runs, and the tests that hold the two against each other)
-    if (!no_lanes && stft_lanes_applicable(h->stft, d_samples, stride)) {
+    if (!h->sw.no_stft_lanes && stft_lanes_applicable(h->stft, d_samples, stride)) {
         KernelTimer t(h, stream, "stft_lanes_kernel");
         SYLDET_HIP(launch_stft_lanes(h->stft, d_samples, stride, C, J, d_columns, stream));
         return SYLDET_OK;
@@ -549,13 +569,12 @@ int run_on_stream(syldet *h, const float *d_samples, int64_t S, int64_t stride, 
         d.stamps = nullptr;
         d.fix = FixList{nullptr, nullptr, 0};
         // diagnostic only: SYLDET_FUSED_KO=<mask> runs an instantiation with parts of the kernel knocked out
-        static const int want_ko = std::getenv("SYLDET_FUSED_KO") ? std::atoi(std::getenv("SYLDET_FUSED_KO")) : 0;
-        d.ko = want_ko;
+        d.ko = h->sw.fused_ko;
+        d.force_classic = h->sw.fused_classic ? 1 : 0;
         // diagnostic only: SYLDET_FUSED_STAMPS=1 runs the stamped instantiation and prints where a
         // workgroup pass spends its cycles (never set in tests or the benchmark)
-        static const bool want_stamps = std::getenv("SYLDET_FUSED_STAMPS") != nullptr;
-        if (want_stamps) {
-            const bool rk = fused_r_applicable(d) && fused_r_has_stamps() && !std::getenv("SYLDET_FUSED_CLASSIC");   // which kernel the launcher picks
+        if (h->sw.fused_stamps) {
+            const bool rk = fused_r_applicable(d) && fused_r_has_stamps() && !h->sw.fused_classic;   // which kernel the launcher picks
             const int64_t seg = rk ? d.r_seg_evals : d.seg_evals;
             const size_t n = (size_t)((E + seg - 1) / seg) * (size_t)C * 16;
             if (int st = h->d_stamps.reserve(n * sizeof(unsigned long long))) return st;
@@ -594,7 +613,7 @@ int run_on_stream(syldet *h, const float *d_samples, int64_t S, int64_t stride, 
         if (int st = prepare_fix(h, C, E, segs, stream, d.fix)) return st;
         {
             // (the launcher picks the register-resident-basis kernel where it is instantiated: named for what runs)
-            KernelTimer t(h, stream, (fused_r_applicable(d) && (!std::getenv("SYLDET_FUSED_CLASSIC") || !d.classic_ok) && !d.ko) ? "fused_r_kernel" : "fused_kernel");
+            KernelTimer t(h, stream, (fused_r_applicable(d) && (!h->sw.fused_classic || !d.classic_ok) && !d.ko) ? "fused_r_kernel" : "fused_kernel");
             SYLDET_HIP(launch_fused(d, d_samples, stride, C, S, J, E, d_outputs, d_flags, stream));
         }
         SYLDET_HIP(launch_fixup(h->fixd, h->net, d_samples, stride, J, E, d_outputs, d_flags, nullptr, d.fix, stream));
@@ -614,8 +633,7 @@ int run_on_stream(syldet *h, const float *d_samples, int64_t S, int64_t stride, 
         return SYLDET_OK;
     }
     // 1024-point frames in front of a network of the matrix-core class: one launch, the columns never leave the CU
-    const bool no_fft1k = std::getenv("SYLDET_NO_FFT1K") != nullptr;      // (A/B runs and the tests that hold the two forms against each other)
-    if (h->mlpx.ok && !no_fft1k && (uint64_t)E * 4u < 0xFFFFFFF0ull &&
+    if (h->mlpx.ok && !h->sw.no_fft1k && (uint64_t)E * 4u < 0xFFFFFFF0ull &&
         fft1k_applicable(h->stft, h->mlpx.desc, d_samples, stride)) {
         KernelTimer t(h, stream, "fft1k_net_kernel");
         SYLDET_HIP(launch_fft1k_net(h->stft, h->mlpx.desc, d_samples, stride, C, J, E, d_outputs, d_flags, stream));
@@ -661,6 +679,7 @@ int syldet_create(const syldet_config_t *cfg, int32_t n_channels, int32_t device
     if (!h) return fail(SYLDET_ERR_OUT_OF_MEMORY, "out of memory");
     if (int st = h->cfg.assign(*cfg)) return st;
     if (int st = compute_geometry(h->cfg.view, &h->geom)) return st;
+    h->sw.read();
 
     int n_dev = 0;
     hipError_t e = hipGetDeviceCount(&n_dev);
@@ -704,8 +723,7 @@ int syldet_create(const syldet_config_t *cfg, int32_t n_channels, int32_t device
     }
     // AUTO on the generic engine: the network stage goes to the matrix cores where the configuration is of that kernel's
     // class (a handle created for SYLDET_ENGINE_GENERIC keeps the reference's operation order throughout)
-    static const bool no_mlpx = std::getenv("SYLDET_NO_MLPX") != nullptr;
-    if (engine == SYLDET_ENGINE_AUTO && h->engine == SYLDET_ENGINE_GENERIC && !no_mlpx && make_mlpx_plan(h->cfg.view, h->geom, h->mlpx)) {
+    if (engine == SYLDET_ENGINE_AUTO && h->engine == SYLDET_ENGINE_GENERIC && !h->sw.no_mlpx && make_mlpx_plan(h->cfg.view, h->geom, h->mlpx)) {
         if (int st = upload_mlpx(h.get())) {
             syldet_destroy(h.release());
             return st;
@@ -843,7 +861,7 @@ int64_t syldet_segment_evals(const syldet_t *h, int64_t n_samples)
     if (E <= 0) return 0;
     FusedDesc d = h->fused.desc;
     fused_segmentation(d, E, h->channels);
-    const bool r = fused_r_applicable(d) && (!std::getenv("SYLDET_FUSED_CLASSIC") || !d.classic_ok);
+    const bool r = fused_r_applicable(d) && (!h->sw.fused_classic || !d.classic_ok);
     return r ? d.r_seg_evals : d.seg_evals;
 }
 

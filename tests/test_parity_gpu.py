@@ -390,6 +390,70 @@ def test_benchmark_size_against_the_oracle(oracle_lib, monkeypatch, C, log2S, ke
         assert torch.isfinite(out).all()
 
 
+@pytest.mark.parametrize("workload", ["config3", "config5"])
+def test_other_baseline_workloads_at_full_size(oracle_lib, workload):
+    """BASELINE configs[2] (1024-point frames, hop 256, 512 channels x 2^21 samples: `fft1k_net_kernel`, 1e-5) and configs[4]
+    (sample.txt front end, 290 -> 4096 -> 1 as a bf16 MFMA GEMM, 64 channels x 2^24 samples: 1e-2, bf16's separately stated
+    bar) at the sizes bench.py's `also` records are quoted on, against the oracle's fp64 anchor: head and tail of the first,
+    a middle and the last channel, and stretches across the 128-frame tile / 512-evaluation tile seams in the middle."""
+    import spotcheck
+    torch = _torch()
+    if workload == "config3":
+        cfg, C, S, engine, tol, kernels = nets.config3(), 512, 1 << 21, _abi.ENGINE_AUTO, util.TOL, ["fft1k_net_kernel"]
+    else:
+        cfg, C, S, engine, tol = nets.wide_mlp(nets.from_npz()), 64, 1 << 24, _abi.ENGINE_WIDE_BF16, 1e-2
+        kernels = ["fused_kernel (spectrogram)", "wide_prep_chain_kernel", "wide_gemm_kernel"]
+    x = synth.channels_on_device(C, S, "cuda", fs=cfg.samplingRate)
+    chans = [0, C // 2 - 1, C - 1]
+    with sd.SyllableDetector(cfg, channels=C, engine=engine) as det:
+        g = det.geometry
+        E = det.countEvaluations(S)
+        det.profile(True)
+        out, fl = det.run(x)
+        torch.cuda.synchronize()
+        assert [nm for nm, _ in det.lastTimings()] == kernels
+        assert torch.isfinite(out).all()
+        res = spotcheck.check(det, cfg, x, out, fl, chans, width=96 if workload == "config3" else 160, tol=tol)
+        # + the middle of each checked channel: seams of the kernels' own tiles (128 frames; 512 evaluations)
+        o = util.oracle_for(cfg)
+        worst = res["max_error"]
+        for c in chans:
+            for e0 in (E // 2 - 70, (E // 3 // 512) * 512 - 40):
+                e1 = e0 + (96 if workload == "config3" else 160)
+                xs = x[c, e0 * g.hop:(e1 - 1 + cfg.timeRange - 1) * g.hop + g.gap + cfg.windowLength].cpu().numpy()
+                _, _, w64 = o.run(xs, po.F64, cfg.rule)
+                got = out[c, e0:e1].cpu().numpy()
+                util.assert_outputs_close(got, w64, tol)
+                util.assert_flags_exact(fl[c, e0:e1].cpu().numpy(), w64, cfg.thresholds, cfg.rule, tol)
+                worst = max(worst, float(np.abs(got - w64).max()))
+        assert res["evaluations_checked"] >= 3 * 2 * 96
+        if workload == "config5":
+            assert worst > 1e-7, "bf16 rounding should be visible: is the wide engine really running?"
+
+
+def test_wide_hidden_layer_on_auto_keeps_its_spectrogram_front(oracle_lib):
+    """A 290 -> 5000 -> 1 network under AUTO runs on the generic engine behind the fused DFT front half; the exact
+    recomputation behind that front half handles frames only and must not count the network's LDS buffers (4 waves x 2 x
+    5000 floats on top of its tables would pass 160 KB and fail every call)."""
+    torch = _torch()
+    base = util.sample_net()
+    rng = np.random.default_rng(5)
+    cfg = nets.variant(base, net=nets.random_net(rng, 290, (5000,), 1, in_fns=("l2normalize", "mapminmax"), out_fns=()), thresholds=[0.5])
+    x = synth.channels(2, 20000, first=7, fs=cfg.samplingRate)
+    with sd.SyllableDetector(cfg, channels=2) as det:
+        assert det.geometry.engine == _abi.ENGINE_GENERIC
+        det.profile(True)
+        out, fl = det.run(torch.from_numpy(x).cuda())
+        cols = det.spectrogram(torch.from_numpy(x).cuda())
+        torch.cuda.synchronize()
+        assert det.lastTimings()[0][0] == "fused_kernel (spectrogram)"
+    o = util.oracle_for(cfg)
+    for c in range(2):
+        _, _, w64 = o.run(x[c], po.F64, cfg.rule)
+        util.assert_outputs_close(out[c].cpu().numpy(), w64)
+        util.assert_columns_close(cols[c].cpu().numpy(), o.spectrogram(x[c], po.F64))
+
+
 def test_cpp_mirror_of_the_swift_surface(oracle_lib, tmp_path):
     """include/syldet.hpp (SyllableDetectorConfig(fromTextFile:), SyllableDetector.appendAudioData /
     processNewValue / lastOutputs / lastDetected, bank.run, detections) driven from a C++ program."""
