@@ -198,6 +198,74 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
                     p.dfrag[((((size_t)ks * 4 + m) * 2 + 1) * 64 + l) * 8 + j] = lo;
                 }
 
+
+    // ---- the symmetric-fold kernel (kernels_fused_s.hip): geometry, LDS layout per wave, folded basis.
+    // Applicable when the window is symmetric about its centre, w[n] == w[W - n] (every window of WindowType.createWindow,
+    // CircularShortTimeFourierTransform.swift:19-28, is: checked on the table itself), W is 64, 128, 192 or 256, the gap keeps
+    // frames 16-byte aligned, and a tile's samples leave room in the wave's share of the LDS.
+    {
+        d.s_ok = 0;
+        bool sym = (W % 64 == 0) && (g.gap % 4 == 0);
+        // (to an ulp of the fp32 table: the two sides are averaged below, which moves a coefficient by 2^-25 of itself at most)
+        for (int nn = 1; nn < W && sym; nn++) sym = std::fabs((double)win[(size_t)nn] - (double)win[(size_t)(W - nn)]) <= 2.4e-7 * std::fabs((double)win[(size_t)nn]) + 1e-30;
+        const int TP = (T + 1) / 2 * 2;                          // taps stored per frame row (even: the row stride 4 TP + 4 then spreads 16 rows over the banks)
+        const int PSs = 4 * TP + 4;
+        const int row_bytes = ((T - 1 + kFusedSTileFrames) * PSs + 8) * 4;
+        const int per_wave = 160 * 1024 / (kFusedSBlock / 64);
+        const int RC = (per_wave - (row_bytes + 15) / 16 * 16) / 1024 - 1;     // ring chunks of 256 samples, one more for the mirror
+        const int span = (kFusedSTileFrames - 1) * hop + W;
+        if (sym && H <= 4 && RC >= (span + 255) / 256 + 1 && kFusedSTileFrames * hop <= RC * 256) {
+            d.s_ok = 1;
+            d.s_perm = (hop / 4) % 2 == 1 ? 1 : 0;               // (the slot permutation spreads the frames over the banks when hop / 4 is odd)
+            d.s_ring_chunks = RC; d.s_pstride = PSs; d.s_tp = TP;
+            d.s_lds_wave = per_wave;
+            const int K2 = W / 64, c0 = W / 2;
+            // A operands, lane l: row l & 15 of its tile, k = 8 (l >> 4) + j -> folded position m = 32 ks + k.
+            // s rows (real part): w[c0 + m] cos(2 pi k m / N), half of it at m = 0 (s[0] = 2 x[c0]);
+            // d rows (imaginary part): -w[c0 + m] sin(2 pi k m / N); slot m = 0 takes the frame's first sample: +w[0] sin(2 pi k (W/2) / N).
+            p.sfrag.assign((size_t)K2 * 2 * 2 * 2 * 64 * 8, 0);
+            for (int ks = 0; ks < K2; ks++)
+                for (int which = 0; which < 2; which++)
+                    for (int m2 = 0; m2 < 2; m2++)
+                        for (int l = 0; l < 64; l++)
+                            for (int j = 0; j < 8; j++) {
+                                const int r = 16 * m2 + (l & 15), m = 32 * ks + 8 * (l >> 4) + j;
+                                double v = 0.0;
+                                if (r < F) {
+                                    const int k = g.f0 + r;
+                                    const int kn = (int)(((int64_t)k * m) % N);
+                                    const double ang = two_pi * (double)kn / (double)N;
+                                    const double wm = 0.5 * ((double)win[(size_t)(c0 + m)] + (double)win[(size_t)(c0 - m)]);
+                                    if (which == 0) {
+                                        v = wm * std::cos(ang) * (m == 0 ? 0.5 : 1.0);
+                                    } else if (m == 0) {
+                                        const int kh = (int)(((int64_t)k * (W / 2)) % N);
+                                        v = (double)win[0] * std::sin(two_pi * (double)kh / (double)N);
+                                    } else {
+                                        v = -wm * std::sin(ang);
+                                    }
+                                    if (which == 1 && k == 0) v = 0.0;            // DC is real (:323 drops the packed Nyquist)
+                                    v *= 8192.0;
+                                }
+                                uint16_t hi, lo;
+                                split_half(v, hi, lo);
+                                const size_t base = (((((size_t)ks * 2 + which) * 2 + m2) * 2) * 64 + l) * 8 + j;
+                                p.sfrag[base] = hi;
+                                p.sfrag[base + 64 * 8] = lo;
+                            }
+            // the first sample's real part for the bins a lane holds in a result: 4 g + i (i < 4), 16 + 4 g + i - 4
+            p.slone.assign(64 * 8, 0.0f);
+            for (int l = 0; l < 64; l++)
+                for (int i = 0; i < 8; i++) {
+                    const int r = i < 4 ? 4 * (l >> 4) + i : 16 + 4 * (l >> 4) + (i - 4);
+                    if (r < F) {
+                        const int kh = (int)(((int64_t)(g.f0 + r) * (W / 2)) % N);
+                        p.slone[(size_t)l * 8 + i] = (float)((double)win[0] * std::cos(two_pi * (double)kh / (double)N) * 8192.0);
+                    }
+                }
+        }
+    }
+
     // |X[k]| <= (sum_n |D[k][n]|) * max|x|: with samples scaled below 2^14 the column shift keeps |X| * 2^(cse-shift) < 2^13
     {
         double rowsum_max = 1.0;
@@ -327,7 +395,7 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
         d.guard_spect = sq(std::sqrt((double)F) * phi_r / 1e-6);
         d.guard_se_abs_s = (int)std::max(-200.0, std::min(200.0, std::ceil(std::log2(phi_r / 1e-6) + (double)d.col_shift)));
     }
-    if (!d.classic_ok && !fused_r_applicable(d)) return no("LDS budget exceeded");
+    if (!d.classic_ok && !fused_r_applicable(d) && !fused_s_applicable(d)) return no("LDS budget exceeded");
     p.koff.resize((size_t)KS * 4);
     for (int ks = 0; ks < KS; ks++)
         for (int h = 0; h < 4; h++) {
@@ -448,6 +516,30 @@ void fused_segmentation(FusedDesc &d, int64_t E, int C)
     };
     segment(kFusedTileFrames, 64, d.runs, d.seg_evals);
     segment(kFusedRTileFrames, 128, d.r_runs, d.r_seg_evals);
+    // The symmetric-fold kernel: a segment belongs to a WAVE (eight to a workgroup, a workgroup per CU).  A wave pays its
+    // prologue (the basis from L2, the first tile's samples) once and T - 1 frames of lead-in, so segments are as long as the
+    // batch allows: their number is the smallest multiple of 2048 / gcd(C, 2048) per channel that keeps every wave slot of the
+    // 256 CUs busy in whole rounds (64 channels: 32 segments of ~249 tiles for the benchmark batch); short batches get what
+    // fills the chip.
+    {
+        const int64_t max_tiles = 512;
+        const int64_t max_evals = max_tiles * kFusedSTileFrames - (d.T - 1);
+        int64_t segs = std::max<int64_t>(1, (E + max_evals - 1) / max_evals);
+        const int64_t slots = 256 * (kFusedSBlock / 64);
+        if ((int64_t)C * segs >= slots) {
+            int gg = C, m = (int)slots;
+            while (gg) { const int t = m % gg; m = gg; gg = t; }
+            const int64_t mult = slots / m;
+            segs = (segs + mult - 1) / mult * mult;
+        } else {
+            segs = std::max<int64_t>(segs, std::min<int64_t>((slots + C - 1) / C, (frames + 4 * kFusedSTileFrames - 1) / (4 * kFusedSTileFrames)));
+        }
+        segs = (segs + 7) / 8 * 8;                               // whole workgroups per channel
+        int64_t per = (E + segs - 1) / segs;
+        int64_t tl = (per + (d.T - 1) + kFusedSTileFrames - 1) / kFusedSTileFrames;
+        tl = std::max<int64_t>(1, tl);
+        d.s_seg_evals = (int)(tl * kFusedSTileFrames - (d.T - 1));
+    }
 }
 
 }  // namespace sd

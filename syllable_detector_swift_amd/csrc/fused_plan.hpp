@@ -16,6 +16,8 @@ struct FusedPlan {
     FusedDesc desc{};                // device pointers are filled in by the owner after upload
     std::vector<uint16_t> dfrag;     // f16 bit patterns
     std::vector<uint16_t> afrag, afrag_t;
+    std::vector<uint16_t> sfrag;     // the folded basis of the symmetric-fold kernel
+    std::vector<float> slone;
     std::vector<int> koff;
     std::vector<float> bias0, rvec, w1, b1, out_params;
 };

@@ -93,6 +93,8 @@ constexpr int kFusedRBlock = 256;       // register-resident-basis kernel (kerne
 constexpr int kFusedRTileFrames = 64;   //   16 frames per wave and pass
 constexpr int kFusedRMaxLoads = 10;     //   float4 loads per thread per pass
 constexpr int kFusedRPRows = 11 + 3 * 64 + 2;   //   rows of its tap-product ring in LDS (52 floats each)
+constexpr int kFusedSBlock = 512;       // symmetric-fold kernel (kernels_fused_s.hip): 8 waves, two per SIMD, each a stream of its own
+constexpr int kFusedSTileFrames = 16;   //   frames per wave and tile
 constexpr int kFusedColStride = 40;     // halves per column row in LDS: 32 bins + 8 of padding (80 B rows: 16-byte
                                         // aligned, and 16 consecutive rows cover all 64 banks once for ds_read_b128)
 
@@ -138,6 +140,12 @@ struct FusedDesc {
     int classic_ok;             // the 8-wave kernel's LDS layout fits (else only the register-resident-basis kernel can run the plan)
     int r_ok, r_nsmp, r_nload, r_ps, r_smp_stride, r_runs, r_seg_evals;
     int r_lds_smp, r_lds_p, r_lds_red, r_lds_cst, r_lds_total;   // second sample buffer: r_lds_smp + 4 r_smp_stride
+    // layout of the symmetric-fold kernel (kernels_fused_s.hip): per wave a ring of s_ring_chunks x 256 samples + a mirror chunk,
+    // rows of s_pstride floats of tap products (4 s_tp products, the frame's sum of squares, its floor weight); s_ok = 0 when the
+    // shape does not fit it
+    int s_ok, s_perm, s_ring_chunks, s_pstride, s_tp, s_lds_wave, s_seg_evals;
+    const uint4 *sfrag;         // [W/64 k-steps][s, d][bins 0-15, 16-31][hi,lo][64 lanes] A-operand fragments of the folded basis
+    const float *slone;         // [64 lanes][8] the frame's first sample's real coefficients for the lane's bins
     const uint4 *dfrag;         // [KS][re 0-15, re 16-31, im 0-15, im 16-31][hi,lo][64 lanes] A-operand fragments of the DFT basis
     const uint4 *afrag;         // [T][hi,lo][64 lanes] A-operand fragments of the folded first layer (16x16x32)
     const uint4 *afrag_t;       // [3 row tiles][hi,lo][64 lanes] the same layer with all taps as rows (row 4 t + h), K in the
@@ -162,6 +170,7 @@ struct FusedDesc {
     int guard_se_abs_s;         //   ... in passes scaled below this exponent
     FixList fix;                // work list of evaluations to recompute (null counters: guard off)
     int force_classic;          // the handle was created under SYLDET_FUSED_CLASSIC=1: the 8-wave kernel where both take the shape
+    int no_fold;                // the handle was created under SYLDET_FUSED_NOFOLD=1: not the symmetric-fold kernel
     int ko;                     // diagnostic build only: knock-out mask (SYLDET_FUSED_KO)
     unsigned long long *stamps; // diagnostic build only: [workgroups][16] phase cycle sums, else null
 };
@@ -211,12 +220,17 @@ hipError_t launch_unpack_flags(const uint8_t *bits, int64_t rows, int64_t row_le
 
 hipError_t launch_fused(const FusedDesc &d, const float *samples, int64_t stride, int C, int64_t S, int64_t J,
                         int64_t E, float *outputs, uint8_t *flags, hipStream_t stream);
+int fused_choice(const FusedDesc &d, int64_t J);    // 0 the 8-wave kernel, 1 the register-resident-basis kernel, 2 the symmetric-fold kernel
 // the DFT front half alone: samples -> [C][J][F] columns; d: a plan for timeRange 1 with spect_out / spect_power set
 hipError_t launch_fused_spectrogram(const FusedDesc &d, const float *samples, int64_t stride, int C, int64_t J, hipStream_t stream);
 // the same contract on the register-resident-basis kernel; only called when d.r_ok and fused_r_applicable(d)
 bool fused_r_applicable(const FusedDesc &d);
 bool fused_r_has_stamps();      // built with -DSYLDET_R_STAMPS (phase timing, SYLDET_FUSED_STAMPS=1)
 hipError_t launch_fused_r(const FusedDesc &d, const float *samples, int64_t stride, int C, int64_t S, int64_t J,
+                          int64_t E, float *outputs, uint8_t *flags, hipStream_t stream);
+// the same contract on the symmetric-fold kernel; only called when fused_s_applicable(d)
+bool fused_s_applicable(const FusedDesc &d);
+hipError_t launch_fused_s(const FusedDesc &d, const float *samples, int64_t stride, int C, int64_t S, int64_t J,
                           int64_t E, float *outputs, uint8_t *flags, hipStream_t stream);
 // taps the register-resident first-layer fragments are instantiated for (0: timeRange too long)
 int fused_taps_max(int T);

@@ -776,14 +776,26 @@ hipError_t launch_one(const FusedDesc &d, const float *samples, int64_t stride, 
 
 int fused_taps_max(int T) { return T <= 12 ? 12 : 0; }
 
+// Which of the three fused kernels runs a plan: 2 the symmetric-fold kernel (kernels_fused_s.hip) where the shape is of its
+// class, 1 the register-resident-basis kernel (kernels_fused_r.hip), 0 this file's 8-wave kernel.  A handle created under
+// SYLDET_FUSED_NOFOLD=1 / SYLDET_FUSED_CLASSIC=1 keeps the older kernels (A/B runs, and the tests that hold them against
+// each other); the diagnostic instantiations (stamps, knock-outs) exist for the older two only.
+int fused_choice(const FusedDesc &d, int64_t J)
+{
+    const bool classic = d.force_classic != 0;
+    const int64_t s_eff = (J - 1) * (int64_t)d.hop + d.gap + d.W;
+    if (!classic && !d.no_fold && !d.ko && !d.stamps && fused_s_applicable(d) && s_eff * 4 < 0x7fffffffll) return 2;
+    if ((!classic || !d.classic_ok) && !d.ko && fused_r_applicable(d) && (!d.stamps || fused_r_has_stamps() || !d.classic_ok)) return 1;
+    return 0;
+}
+
 hipError_t launch_fused(const FusedDesc &d, const float *samples, int64_t stride, int C, int64_t S, int64_t J,
                         int64_t E, float *outputs, uint8_t *flags, hipStream_t stream)
 {
     if (E <= 0 || C <= 0) return hipSuccess;
-    // the register-resident-basis kernel where it is instantiated (a handle created under SYLDET_FUSED_CLASSIC=1 keeps this
-    // file's kernel: A/B runs and the tests that hold the two against each other)
-    const bool classic = d.force_classic != 0;
-    if ((!classic || !d.classic_ok) && !d.ko && fused_r_applicable(d) && (!d.stamps || fused_r_has_stamps() || !d.classic_ok)) return launch_fused_r(d, samples, stride, C, S, J, E, outputs, flags, stream);
+    const int choice = fused_choice(d, J);
+    if (choice == 2) return launch_fused_s(d, samples, stride, C, S, J, E, outputs, flags, stream);
+    if (choice == 1) return launch_fused_r(d, samples, stride, C, S, J, E, outputs, flags, stream);
     if (!d.classic_ok) return hipErrorInvalidValue;
     // one past the last sample an existing frame reads: frame J-1 covers [(J-1)*hop + gap, ... + W)
     const int64_t s_eff = (J - 1) * (int64_t)d.hop + d.gap + d.W;

@@ -1,0 +1,502 @@
+// kernels_fused_s.hip -- the fused engine on the window's symmetry: half the DFT's matrix work, two waves a SIMD, no barriers.
+//
+// Same path as kernels_fused.hip / kernels_fused_r.hip (reference, root relative:
+//   extractPower          Common/CircularShortTimeFourierTransform.swift:280-337
+//   processFourierData    Common/SyllableDetector.swift:134-151
+//   processNewValue       Common/SyllableDetector.swift:153-217
+//   NeuralNet.apply       Common/NeuralNet.swift:294-326, :366-377
+//   lastDetected          Common/SyllableDetector.swift:27-31),
+// built on what round 3 measured about the part (profiles/r03_energy_probe.txt): under these kernels the chip sits on its
+// power limit, so a launch takes what its energy takes, and a v_mfma_f32_16x16x32_f16 costs 8.3 nJ against 1.2 nJ for a
+// vector instruction of a wave.  The DFT's 96 matrix instructions per 16 frames were two thirds of the kernel's energy.
+//
+//   * Every window the reference offers (WindowType.createWindow, CircularShortTimeFourierTransform.swift:19-28: periodic
+//     Hamming, Hann, Blackman, rectangular) satisfies w[n] = w[W - n].  Only |X[k]| leaves the transform (:329-333), so the
+//     phase reference may sit at the window's centre c = W/2: with m = n - c,
+//         Re' X[k] =  sum_{m=0}^{W/2-1} w[c+m] cos(2 pi k m / N) s[m]  +  w[0] cos(pi k W / N) x[0]
+//         Im' X[k] = -sum_{m=1}^{W/2-1} w[c+m] sin(2 pi k m / N) d[m]  +  w[0] sin(pi k W / N) x[0]
+//     with s[m] = x[c+m] + x[c-m], d[m] = x[c+m] - x[c-m] (s[0] = 2 x[c] against half the coefficient; the frame's first
+//     sample x[0] has no partner: its imaginary part rides in the d-GEMM's free slot 0, its real part is 8 multiply-adds).
+//     Two GEMMs of K = W/2 instead of one of K = W: 48 matrix instructions per 16 frames instead of 96, a basis of 128
+//     registers instead of 256.  The price is vector work: a frame's folded samples are its own (overlapping frames share
+//     samples, not sums), so every frame is folded and split into f16 hi + lo by the lanes that own it: ~14 vector
+//     instructions a frame instead of ~6.
+//   * A basis of 128 registers leaves room for TWO waves per SIMD (256 registers each), which doubles the rate at which
+//     the vector instructions issue (tools/ubench/valu_rates: 2.2 clocks against 4.45 for a lone wave) and lets one wave's
+//     matrix instructions run under the other's vector work without any hand-placed interleaving.
+//   * A wave is a stream processor of its own: it walks a contiguous run of 16-frame tiles of one channel, its samples arrive
+//     in a wave-private LDS ring by LDS-DMA (buffer_load ... lds, non-temporal: 7 % less energy per byte and 13 % more bytes per
+//     second than plain loads), its tap products live in wave-private LDS rows.  Nothing crosses waves: no workgroup
+//     barrier anywhere.
+//   * Every FRAME is scaled by its own power of two before the split (its loudest sample goes to [2^13, 2^14)): a result
+//     depends on the frame's samples alone, not on what shares a tile or a pass with it.  A click over a quiet cage no longer
+//     drags its neighbours to the f16 floor (bench.py's `clicks` record: 500 000 work items on the pass-scaled kernels), and
+//     the same samples give the same bits however they are tiled -- streaming and batch results are identical.
+//
+// Lane (n, g) of a wave: column n of every B operand and result (a frame; slots are permuted so that even frames sit in the
+// lanes the LDS serves together with the odd frames of the other lane group: conflict-free ds_read_b128 at hops = 4 mod 8),
+// k block 8 g .. 8 g + 7 of an operand, rows 4 g .. 4 g + 3 of a result.
+//
+// gfx950 only.  wave = 64.
+
+#include "fused_common.hpp"
+
+namespace sd {
+
+namespace {
+
+using namespace fused_dev;
+
+constexpr int kBlock = kFusedSBlock;           // 512 threads = 8 waves, two per SIMD
+constexpr int kWaves = kBlock / 64;
+constexpr int kTile = kFusedSTileFrames;       // 16 frames per wave and tile
+
+typedef __attribute__((address_space(3))) void lds_void;
+
+// a * 1 - (the half `hi` or `lo` of h) in fp32: the remainder of a value behind its f16 rounding, exact
+__device__ __forceinline__ float rem_lo(float a, unsigned h)
+{
+    float r;
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(r) : "v"(a), "v"(h));
+    return r;
+}
+__device__ __forceinline__ float rem_hi(float a, unsigned h)
+{
+    float r;
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(a), "v"(h));
+    return r;
+}
+__device__ __forceinline__ unsigned cvt_pk(float a, float b)
+{
+    unsigned r;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// two values -> f16 hi pair and f16 lo pair (hi + lo == the value to 2^-22 relative)
+__device__ __forceinline__ void split2(float a, float b, unsigned &hi, unsigned &lo)
+{
+    hi = cvt_pk(a, b);
+    lo = cvt_pk(rem_lo(a, hi), rem_hi(b, hi));
+}
+
+// K2: k-steps of 32 folded positions (W = 64 K2).  GEN: the network class as run-time facts (any transfer functions, with or
+// without l2normalize, up to four outputs); without it the reference's example class (l2normalize, TanSig, one linear output).
+template <int K2, bool GEN>
+__global__ void __launch_bounds__(kBlock, 1)
+fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t stride, int64_t s_eff, int64_t E,
+               float *__restrict__ outputs, uint8_t *__restrict__ flags)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, g = lane >> 4;
+    const int c = blockIdx.y;
+    const int T = d.T, H = d.H, hop = d.hop;
+    constexpr int W = 64 * K2;
+    const int n_out = GEN ? d.n_out : 1;
+    // this wave's segment of the channel
+    const int64_t e_b = ((int64_t)blockIdx.x * kWaves + wave) * d.s_seg_evals;
+    if (e_b >= E) return;
+    const int64_t e_e = (e_b + d.s_seg_evals < E) ? e_b + d.s_seg_evals : E;
+    const int seg_len = (int)(e_e - e_b);
+    const int tiles = (seg_len + (T - 1) + kTile - 1) / kTile;
+    const unsigned e_b32 = (unsigned)e_b;
+
+    // frame of slot n (see the header): slots {0-3, 12-15} take the even frames, {4-11} the odd ones
+    const int fr = d.s_perm ? (n < 4 ? 2 * n : (n >= 12 ? 2 * (n - 8) : 2 * (n - 4) + 1)) : n;
+
+    // ---- wave-private LDS: sample ring (RC chunks of 256 floats + one mirror chunk), tap products, a zero quad
+    unsigned char *wbase = smem + (size_t)wave * d.s_lds_wave;
+    const int RC = d.s_ring_chunks, R = RC * 256;
+    float *ring = reinterpret_cast<float *>(wbase);
+    const int PS = d.s_pstride, TP = d.s_tp;          // floats per frame row: 4 TP tap products, sum of squares, floor weight, padding
+    float *rows = reinterpret_cast<float *>(wbase + (size_t)(RC + 1) * 1024);       // [T - 1 + 16][PS]
+    float *zquad = rows + (T - 1 + kTile) * PS;       // 8 floats: a zero quad, and a quad for stores that have no place
+    {
+        const int nz = ((T - 1 + kTile) * PS + 8) / 4;
+        for (int i = lane; i < nz; i += 64) reinterpret_cast<floatx4 *>(rows)[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    // ---- constants in registers: the folded basis (A operands; s: real rows against the sums, d: imaginary rows against
+    // the differences), the first layer with all taps as rows, the lone sample's real coefficients
+    half8 as_[K2][2][2], ad_[K2][2][2];               // [k-step][row tile: bins 0-15, 16-31][hi, lo]
+#pragma unroll
+    for (int ks = 0; ks < K2; ks++)
+#pragma unroll
+        for (int m = 0; m < 2; m++)
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+                as_[ks][m][p] = as_half8(reinterpret_cast<const uint32x4 *>(d.sfrag)[(((ks * 2 + 0) * 2 + m) * 2 + p) * 64 + lane]);
+                ad_[ks][m][p] = as_half8(reinterpret_cast<const uint32x4 *>(d.sfrag)[(((ks * 2 + 1) * 2 + m) * 2 + p) * 64 + lane]);
+            }
+    half8 aft[3][2];
+#pragma unroll
+    for (int m = 0; m < 3; m++)
+#pragma unroll
+        for (int p = 0; p < 2; p++) aft[m][p] = as_half8(reinterpret_cast<const uint32x4 *>(d.afrag_t)[(m * 2 + p) * 64 + lane]);
+    float cre[8];                                     // w[0] cos(pi k W / N) 2^13 for this lane's bins 4 g + i, 16 + 4 g + i
+#pragma unroll
+    for (int i = 0; i < 8; i++) cre[i] = d.slone[lane * 8 + i];
+
+    const float *row = samples + (int64_t)c * stride;
+    const __amdgpu_buffer_rsrc_t in_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(row), 0, (int)(s_eff * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(
+        outputs ? outputs + (int64_t)c * E * n_out : nullptr, 0, outputs ? (int)(E * n_out * 4) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t flg_rs = __builtin_amdgcn_make_buffer_rsrc(flags ? flags + (int64_t)c * E : nullptr, 0, flags ? (int)E : 0, 0x00020000);
+
+    // ---- the sample stream: chunk q holds samples [256 q, 256 q + 256) behind the segment's first one, in ring slot q mod RC;
+    // slot 0's chunks are written a second time behind the ring (the mirror), so that a frame's reads never wrap.
+    // A chunk may be issued once the chunk it replaces is dead: while tile t is read, chunks up to RC - 1 + floor(16 hop t / 256).
+    const unsigned org = (unsigned)((e_b * hop + d.gap) * 4);            // byte offset of the segment's first sample in its row (row < 4 GB: launcher)
+    int cn = 0, slot = 0;                                                // next chunk, its ring slot
+    auto issue_upto = [&](int last) {
+        while (cn <= last) {
+            const unsigned voff = org + (unsigned)cn * 1024u + (unsigned)lane * 16u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rs, (lds_void *)(wbase + slot * 1024), 16, voff, 0, 0, 2 /* nt */);
+            if (slot == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rs, (lds_void *)(wbase + RC * 1024), 16, voff, 0, 0, 2);
+            cn++;
+            slot = slot + 1 == RC ? 0 : slot + 1;
+        }
+    };
+    const int span = (kTile - 1) * hop + W;                              // samples under one tile
+    auto need = [&](int t) { return (kTile * hop * t + span - 1) >> 8; };
+    auto allowed = [&](int t) { return RC - 1 + ((kTile * hop * t) >> 8); };
+
+    // ---- per-lane LDS places.  fo: this lane's frame inside the ring (floats), advanced by 16 hop a tile.
+    unsigned fo = (unsigned)(hop * fr);                                  // < R (launcher: 16 hop <= R)
+    float *prow = rows + (T - 1 + fr) * PS;                              // this frame's row of tap products
+    const float *erow = rows + n * PS;                                   // evaluation n: rows n .. n + T - 1
+    const float *pv_p[3], *sv_p[3];
+#pragma unroll
+    for (int tt = 0; tt < 3; tt++) {
+        const int t = g + 4 * tt;
+        // (taps past timeRange: their products are 0 * column, which is NaN for a column with a NaN in it -- read zeros)
+        pv_p[tt] = t < T ? erow + t * PS + 4 * t : zquad;
+        sv_p[tt] = t < T ? erow + t * PS + 4 * TP : zquad;
+    }
+    // tile m of the tap products holds tap 4 m + g of this frame: taps past TP have no place in the row
+    float *pt_p[3];
+#pragma unroll
+    for (int m = 0; m < 3; m++) pt_p[m] = 4 * m + g < TP ? prow + 4 * (4 * m + g) : zquad + 4;
+
+    const float c_b1 = GEN ? (g < n_out ? d.b1[g] : 0.0f) : d.b1[0];
+    float lean_oa = 0.0f, lean_og = 1.0f, lean_ob = 0.0f;
+    if (d.n_out_fns == 1) {
+        const int o = (GEN && g < n_out) ? g : 0;
+        lean_oa = d.out_params[0]; lean_og = d.out_params[1 + o]; lean_ob = d.out_params[1 + n_out + o];
+    }
+    const float b0g = g < H ? d.bias0[g] : 0.0f, w1g = g < H ? d.w1[g] : 0.0f;       // this lane group's hidden unit
+    float w1o[4];
+#pragma unroll
+    for (int o = 0; o < 4; o++) w1o[o] = (GEN && g < H && o < n_out) ? d.w1[o * H + g] : 0.0f;
+    const bool multi = GEN && n_out > 1;
+    const double thr_g = d.thresholds[(GEN && g < n_out) ? g : 0];
+    const bool counts = !GEN || n_out == 1 ? true : (g < n_out && (g == 0 || d.rule == 1));
+    const int tf0 = GEN ? d.tf0 : 0, tf1 = GEN ? d.tf1 : 2, norm = GEN ? d.norm : 1;
+    const float kmag = pow2f(-13 - d.col_shift);
+    const bool guard_on = d.fix.counters != nullptr;
+    const float guard_k = norm == 1 ? d.guard_r : d.guard_rel_r;
+
+    // ---- prologue: tile 0's samples
+    issue_upto(need(0) < allowed(0) ? need(0) : allowed(0));
+    int se_ref = 0;                                   // products are stored relative to the segment's first frame that has a level
+
+    for (int t = 0; t < tiles; t++) {
+        // tile t's chunks have landed (behind them in the queue: nothing but the two result stores of tile t - 1)
+        if (t == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        const float *fp = ring + fo;                  // this lane's frame: W samples from here (the mirror makes them contiguous)
+
+        // ---- the frame's own scale from its loudest sample (this lane looks at a quarter of the frame)
+        float amax;
+        {
+            float m0 = 0.0f, m1 = 0.0f;
+            const floatx4 *q0 = reinterpret_cast<const floatx4 *>(fp + (W / 4) * g);
+#pragma unroll
+            for (int q = 0; q < W / 16; q++) {
+                const floatx4 v = q0[q];
+                m0 = absmax3(m0, v[0], v[1]);
+                m1 = absmax3(m1, v[2], v[3]);
+            }
+            amax = fmaxf(m0, m1);                      // (v_max3 drops NaNs: plain non-negative numbers from here on)
+            auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(amax), __float_as_uint(amax), false, false);
+            amax = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+            r = __builtin_amdgcn_permlane32_swap(__float_as_uint(amax), __float_as_uint(amax), false, false);
+            amax = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+        }
+        // status of the frame for the precision guard: 0 fine, 1 silent (its column is exact zeros), 2 the grid cannot hold it
+        // (an infinite sample, or a level above 2^113)
+        const int ex = (int)((__float_as_uint(amax) >> 23) & 0xffu);
+        int se = 140 - ex;                            // 2^se puts the loudest sample into [2^13, 2^14)
+        const int fst = amax > 0.0f ? ((ex == 255 || se < -100) ? 2 : 0) : 1;
+        se = amax > 0.0f ? (se < -100 ? -100 : (se > 113 ? 113 : se)) : 0;
+        const float sx = pow2f(se);
+        if (t == 0) {                                 // the segment's reference exponent: the loudest frame of its first tile
+            const float tm = wave_max_nonneg(amax);
+            const int exr = (int)((__float_as_uint(tm) >> 23) & 0xffu);
+            int r0 = 140 - exr;
+            r0 = tm > 0.0f ? (r0 < -100 ? -100 : (r0 > 113 ? 113 : r0)) : 0;
+            se_ref = __builtin_amdgcn_readfirstlane(r0);
+        }
+
+        // the next tile's samples, as far as the ring has room while this tile is read
+        if (t + 1 < tiles) issue_upto(need(t + 1) < allowed(t) ? need(t + 1) : allowed(t));
+
+        // ---- the folded DFT: per k-step this lane folds, scales and splits 8 positions of its frame, then 12 MFMAs
+        const float xl = fp[0] * sx;                  // the frame's first sample (no partner)
+        floatx4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // re 0-15, re 16-31, im 0-15, im 16-31
+        const float *xpb = fp + W / 2 + 8 * g, *xmb = fp + W / 2 - 8 * g;
+#pragma unroll
+        for (int ks = 0; ks < K2; ks++) {
+            // x[c + m0 + i], i = 0..7, and x[c - m0 - i]: words c-m0-8 .. c-m0-1 as two quads, and the word c - m0
+            const floatx4 p0 = *reinterpret_cast<const floatx4 *>(xpb + 32 * ks), p1 = *reinterpret_cast<const floatx4 *>(xpb + 32 * ks + 4);
+            const floatx4 q1 = *reinterpret_cast<const floatx4 *>(xmb - 32 * ks - 8), q2 = *reinterpret_cast<const floatx4 *>(xmb - 32 * ks - 4);
+            const float q0 = xmb[-32 * ks];
+            const float xp[8] = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
+            const float xm[8] = {q0, q2[3], q2[2], q2[1], q2[0], q1[3], q1[2], q1[1]};
+            float s[8], dd[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const float tm = xm[i] * sx;
+                s[i] = fmaf(xp[i], sx, tm);
+                dd[i] = fmaf(xp[i], sx, -tm);
+            }
+            if (ks == 0) dd[0] = g == 0 ? xl : dd[0];  // slot 0 of the differences carries the lone sample
+            uint32x4 sh, sl, dh, dl;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                unsigned h, l;
+                split2(s[2 * j], s[2 * j + 1], h, l);
+                sh[j] = h; sl[j] = l;
+                split2(dd[2 * j], dd[2 * j + 1], h, l);
+                dh[j] = h; dl[j] = l;
+            }
+            const half8 bsh = as_half8(sh), bsl = as_half8(sl), bdh = as_half8(dh), bdl = as_half8(dl);
+#pragma unroll
+            for (int m = 0; m < 2; m++) acc[m] = mfma(as_[ks][m][0], bsh, acc[m]);
+#pragma unroll
+            for (int m = 0; m < 2; m++) acc[2 + m] = mfma(ad_[ks][m][0], bdh, acc[2 + m]);
+#pragma unroll
+            for (int m = 0; m < 2; m++) acc[m] = mfma(as_[ks][m][0], bsl, acc[m]);
+#pragma unroll
+            for (int m = 0; m < 2; m++) acc[2 + m] = mfma(ad_[ks][m][0], bdl, acc[2 + m]);
+#pragma unroll
+            for (int m = 0; m < 2; m++) acc[m] = mfma(as_[ks][m][1], bsh, acc[m]);
+#pragma unroll
+            for (int m = 0; m < 2; m++) acc[2 + m] = mfma(ad_[ks][m][1], bdh, acc[2 + m]);
+        }
+        // the raw samples of this tile are dead (every read of them has returned): the rest of the next tile's chunks
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (t + 1 < tiles) issue_upto(need(t + 1));
+
+        // ---- |X| (zvabs / 2, CircularShortTimeFourierTransform.swift:329-333) of this lane's 8 bins, the frame's sum of squares,
+        // the f16 hi + lo split of the column under the frame's own column exponent, the tap products of the first layer.
+        // acc holds X 2^(se + 13); cval = |X| 2^(se - col_shift).
+        float cval[8], mss = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const float re = fmaf(cre[i], xl, acc[i >> 2][i & 3]), im = acc[2 + (i >> 2)][i & 3];
+            cval[i] = __builtin_amdgcn_sqrtf(fmaf(re, re, im * im)) * kmag;
+            mss = fmaf(cval[i], cval[i], mss);
+        }
+        mss = xor32_sum(xor16_sum(mss));
+        // products and sums of squares are stored relative to the segment's reference exponent (* 2^dsc, * 4^dsc): a window
+        // straddles frames of different scales.  Frames 2^45 away from it, and frames the grid cannot hold, condemn their windows.
+        int dsc = se_ref - se;
+        const bool far = dsc > 45 || dsc < -45 || fst == 2;
+        dsc = dsc < -45 ? -45 : (dsc > 45 ? 45 : dsc);
+        // The frame's own column exponent: its column is split at the scale that puts its norm into [2^12, 2^13); with ex the
+        // biased exponent of mss, tb = floor((ex + 1) / 2) = floor(log2 sqrt(mss)) + 64, clamped to [16, 80]: fs_up = 2^(76 - tb).
+        unsigned tb = ((__float_as_uint(mss) + 0x800000u) >> 1) & 0x7f800000u;
+        tb = (unsigned)min(max((int)tb, 16 << 23), 80 << 23);
+        const float fs_up = __uint_as_float((203u << 23) - tb);
+        const float fs_ring = __uint_as_float(tb + ((unsigned)(dsc + 51) << 23));
+        uint32x4 bh, bl;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            unsigned h, l;
+            split2(cval[2 * j] * fs_up, cval[2 * j + 1] * fs_up, h, l);
+            bh[j] = h; bl[j] = l;
+        }
+        const half8 vbh = as_half8(bh), vbl = as_half8(bl);
+        floatx4 pt[3];
+#pragma unroll
+        for (int m = 0; m < 3; m++) {
+            pt[m] = mfma(aft[m][0], vbh, floatx4{0.f, 0.f, 0.f, 0.f});
+            pt[m] = mfma(aft[m][0], vbl, pt[m]);
+            pt[m] = mfma(aft[m][1], vbh, pt[m]);
+        }
+#pragma unroll
+        for (int m = 0; m < 3; m++) *reinterpret_cast<floatx4 *>(pt_p[m]) = pt[m] * fs_ring;
+        {
+            // the frame's sum of squares relative to the reference, and the weight of its grid floor there: 4^dsc (0 for a
+            // silent frame: exact zeros; +inf for a frame the grid cannot hold)
+            const float sr = mss * pow2f(2 * dsc);
+            const float fw = far ? INFINITY : (fst == 1 ? 0.0f : pow2f(2 * dsc));
+            if (g == 0) *reinterpret_cast<floatx2 *>(prow + 4 * TP) = floatx2{sr, fw};
+        }
+
+        // ---- the tile's 16 evaluations: evaluation n ends on frame n of the tile; its taps are rows n .. n + T - 1.  Lane
+        // group g takes taps g, g + 4, g + 8 and, after the halving butterfly, hidden unit g.
+        floatx4 zp;
+        float ssp, fwp;
+        {
+            const floatx4 pv0 = *reinterpret_cast<const floatx4 *>(pv_p[0]), pv1 = *reinterpret_cast<const floatx4 *>(pv_p[1]),
+                          pv2 = *reinterpret_cast<const floatx4 *>(pv_p[2]);
+            const floatx2 s0 = *reinterpret_cast<const floatx2 *>(sv_p[0]), s1 = *reinterpret_cast<const floatx2 *>(sv_p[1]),
+                          s2 = *reinterpret_cast<const floatx2 *>(sv_p[2]);
+            zp = pv0 + pv1 + pv2;
+            if (GEN && norm == 0)                     // no normaliser: the guard wants the quietest column of the window
+                ssp = fminf(fminf(g < T ? s0[0] : INFINITY, g + 4 < T ? s1[0] : INFINITY), g + 8 < T ? s2[0] : INFINITY);
+            else
+                ssp = s0[0] + s1[0] + s2[0];
+            fwp = fmaxf(fmaxf(s0[1], s1[1]), s2[1]);
+        }
+        float zt, ssw, fww;
+        {
+            auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(zp[0]), __float_as_uint(zp[1]), false, false);
+            const float s01 = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+            r = __builtin_amdgcn_permlane16_swap(__float_as_uint(zp[2]), __float_as_uint(zp[3]), false, false);
+            const float s23 = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+            r = __builtin_amdgcn_permlane32_swap(__float_as_uint(s01), __float_as_uint(s23), false, false);
+            zt = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+            if (GEN && norm == 0) {
+                r = __builtin_amdgcn_permlane16_swap(__float_as_uint(ssp), __float_as_uint(ssp), false, false);
+                const float m = fminf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+                r = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+                ssw = fminf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+            } else {
+                ssw = xor32_sum(xor16_sum(ssp));
+            }
+            r = __builtin_amdgcn_permlane16_swap(__float_as_uint(fwp), __float_as_uint(fwp), false, false);
+            const float m = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+            r = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+            fww = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+        }
+        // the rest of the network (NeuralNet.swift:47-59 L2Normalize on the folded first layer, :189-194 TanSig, :366-377 second
+        // layer, :137-142 / :175-180 reverse output map; SyllableDetector.swift:27-31 threshold)
+        float yv;
+        bool hit;
+        {
+            const int ush = d.col_shift - se_ref;
+            const float alpha0 = d.w_unscale * pow2f(ush < -120 ? -120 : (ush > 120 ? 120 : ush));
+            const float alpha = norm == 1 ? d.w_unscale * __builtin_amdgcn_rsqf(ssw) : alpha0;
+            const float act = transfer_fn(tf0, fmaf(alpha, zt, b0g));
+            float ysum;
+            if (multi) {
+                float yp[4];
+#pragma unroll
+                for (int o = 0; o < 4; o++) yp[o] = w1o[o] * act;
+                auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(yp[0]), __float_as_uint(yp[1]), false, false);
+                const float a01 = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+                r = __builtin_amdgcn_permlane16_swap(__float_as_uint(yp[2]), __float_as_uint(yp[3]), false, false);
+                const float a23 = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+                r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a01), __float_as_uint(a23), false, false);
+                ysum = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+            } else {
+                ysum = xor32_sum(xor16_sum(w1g * act));
+            }
+            float y = transfer_fn(tf1, ysum + c_b1);
+            y = (y - lean_oa) / lean_og + lean_ob;
+            yv = y;
+            hit = counts && (double)y >= thr_g;
+            if (multi) {
+                unsigned hb = hit ? 1u : 0u;
+                auto r = __builtin_amdgcn_permlane16_swap(hb, hb, false, false);
+                hb = r[0] | r[1];
+                r = __builtin_amdgcn_permlane32_swap(hb, hb, false, false);
+                hit = (r[0] | r[1]) != 0u;
+            }
+        }
+        const int er = kTile * t - (T - 1) + n;       // evaluation index inside the segment
+        const bool vld = er >= 0 && er < seg_len;
+        {
+            const bool st = vld && g == 0, sto = vld && g < n_out;
+            const unsigned off = e_b32 + (unsigned)er;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(yv), out_rs, sto ? (off * (unsigned)n_out + (unsigned)g) * 4u : 0xFFFFFFFFu, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(hit ? 1 : 0), flg_rs, st ? off : 0xFFFFFFFFu, 0, 0);
+        }
+        // ---- the precision guard (kernels.hpp, FixItem): the window statistic against the loudest grid floor among its frames
+        if (guard_on) {
+            // (all frames silent: exact zeros, the fused result is the reference's 0/0; a frame the grid cannot hold: +inf, nothing passes)
+            bool bad = vld && !(fww == 0.0f) && !(ssw >= guard_k * fww);
+            if (GEN && norm != 1 && fww != INFINITY && fww != 0.0f) {
+                // no normaliser: loud enough for the floor not to matter?  (the floor in true units against the network's sensitivity)
+                // fww = 4^(se_ref - se_min): se_min = se_ref - log2(fww) / 2
+                const int lg = (int)((__float_as_uint(fww) >> 23) & 0xffu) - 127;
+                if (se_ref - lg / 2 >= d.guard_se_abs_r) bad = false;
+            }
+            if (__builtin_amdgcn_ballot_w64(bad) != 0ull) {
+                const int er0 = kTile * t - (T - 1);
+                const int lo = er0 < 0 ? 0 : er0, hi = er0 + kTile < seg_len ? er0 + kTile : seg_len;
+                if (lane == 0 && hi > lo) {
+                    const unsigned sl = atomicAdd(d.fix.counters, 1u);
+                    if (sl < d.fix.capacity) d.fix.items[sl] = FixItem{c, e_b32 + (unsigned)lo, hi - lo, 0};
+                    else d.fix.counters[3] = 1u;
+                }
+            }
+        }
+        // ---- the last T - 1 frames' rows go to the front for the next tile (a wave's LDS operations execute in order)
+        {
+            const floatx4 *src = reinterpret_cast<const floatx4 *>(rows + kTile * PS);
+            floatx4 *dst = reinterpret_cast<floatx4 *>(rows);
+            const int nq = (T - 1) * PS / 4;
+            floatx4 h0 = {0.f, 0.f, 0.f, 0.f}, h1 = h0, h2 = h0;
+            if (lane < nq) h0 = src[lane];
+            if (lane + 64 < nq) h1 = src[lane + 64];
+            if (lane + 128 < nq) h2 = src[lane + 128];
+            if (lane < nq) dst[lane] = h0;
+            if (lane + 64 < nq) dst[lane + 64] = h1;
+            if (lane + 128 < nq) dst[lane + 128] = h2;
+        }
+        fo += (unsigned)(kTile * hop);
+        fo = fo >= (unsigned)R ? fo - (unsigned)R : fo;
+    }
+}
+
+template <int K2, bool GEN>
+hipError_t launch_one(const FusedDesc &d, const float *samples, int64_t stride, int C, int64_t s_eff, int64_t E,
+                      float *outputs, uint8_t *flags, hipStream_t stream)
+{
+    auto kern = fused_s_kernel<K2, GEN>;
+    const int lds = d.s_lds_wave * kWaves;
+    hipError_t st = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (st != hipSuccess) return st;
+    const int64_t segs = (E + d.s_seg_evals - 1) / d.s_seg_evals;         // wave segments per channel
+    dim3 grid((unsigned)((segs + kWaves - 1) / kWaves), (unsigned)C);
+    hipLaunchKernelGGL(kern, grid, dim3(kBlock), (size_t)lds, stream, d, samples, stride, s_eff, E, outputs, flags);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+// The class fused_r_kernel takes (two layers, at most 4 hidden units, at most 4 outputs, linear |X| columns, no normaliser
+// or l2normalize in front of the affine maps, at most one output map), for windows of 64, 128, 192 or 256 samples that are
+// symmetric (all of the reference's are), any timeRange up to 12, hops that are multiples of 4 and leave room for the ring.
+bool fused_s_applicable(const FusedDesc &d)
+{
+    const bool cls = (d.norm == 0 || d.norm == 1) && d.scaling == 0 && d.n_layers == 2 && d.n_out >= 1 && d.n_out <= 4 && d.H <= 4 && d.n_out_fns <= 1;
+    return d.s_ok && d.T <= 12 && cls;
+}
+
+hipError_t launch_fused_s(const FusedDesc &d, const float *samples, int64_t stride, int C, int64_t S, int64_t J,
+                          int64_t E, float *outputs, uint8_t *flags, hipStream_t stream)
+{
+    (void)S;
+    if (E <= 0 || C <= 0) return hipSuccess;
+    if (!fused_s_applicable(d)) return hipErrorInvalidValue;
+    const int64_t s_eff = (J - 1) * (int64_t)d.hop + d.gap + d.W;
+    if (s_eff * 4 >= 0x7fffffffll) return hipErrorInvalidValue;           // (the launcher's caller keeps such rows on the other kernels)
+    const bool exact = d.norm == 1 && d.tf0 == 0 /* TanSig */ && d.tf1 == 2 /* PureLin */ && d.n_out == 1;
+#define SD_S_GO(K2_)                                                                                                  \
+    if (d.W == 64 * K2_) {                                                                                            \
+        if (exact) return launch_one<K2_, false>(d, samples, stride, C, s_eff, E, outputs, flags, stream);            \
+        return launch_one<K2_, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);                        \
+    }
+    SD_S_GO(4) SD_S_GO(2) SD_S_GO(1) SD_S_GO(3)
+#undef SD_S_GO
+    return hipErrorInvalidValue;
+}
+
+}  // namespace sd

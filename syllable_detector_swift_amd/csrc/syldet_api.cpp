@@ -127,6 +127,7 @@ struct syldet {
         bool no_stft_lanes = false;   // SYLDET_NO_STFT_LANES: the LDS Stockham FFT instead of the lane-butterfly one
         bool no_guard = false;        // SYLDET_NO_GUARD: the precision guard off
         bool no_mlpx = false;         // SYLDET_NO_MLPX: the interpretive network kernels under AUTO
+        bool fused_nofold = false;    // SYLDET_FUSED_NOFOLD: not the symmetric-fold kernel (the register-resident-basis / 8-wave kernels)
         bool fused_stamps = false;    // SYLDET_FUSED_STAMPS: the stamped diagnostic instantiation
         int fused_ko = 0;             // SYLDET_FUSED_KO=<mask>: knock-out instantiation
         void read()
@@ -136,6 +137,7 @@ struct syldet {
             no_stft_lanes = std::getenv("SYLDET_NO_STFT_LANES") != nullptr;
             no_guard = std::getenv("SYLDET_NO_GUARD") != nullptr;
             no_mlpx = std::getenv("SYLDET_NO_MLPX") != nullptr;
+            fused_nofold = std::getenv("SYLDET_FUSED_NOFOLD") != nullptr;
             fused_stamps = std::getenv("SYLDET_FUSED_STAMPS") != nullptr;
             fused_ko = std::getenv("SYLDET_FUSED_KO") ? std::atoi(std::getenv("SYLDET_FUSED_KO")) : 0;
         }
@@ -381,6 +383,7 @@ int upload_plan(syldet *h, FusedPlan &p, DeviceBuffer &buf)
     const size_t o_r = put(p.rvec.data(), p.rvec.size() * 4), o_w1 = put(p.w1.data(), p.w1.size() * 4);
     const size_t o_b1 = put(p.b1.data(), p.b1.size() * 4), o_op = put(p.out_params.data(), p.out_params.size() * 4);
     const size_t o_wt = put(p.afrag_t.data(), p.afrag_t.size() * 2);
+    const size_t o_sf = put(p.sfrag.data(), p.sfrag.size() * 2), o_sl = put(p.slone.data(), p.slone.size() * 4);
     if (int st = buf.reserve(blob.size())) return st;
     SYLDET_HIP(hipMemcpy(buf.ptr, blob.data(), blob.size(), hipMemcpyHostToDevice));
     unsigned char *base = (unsigned char *)buf.ptr;
@@ -388,6 +391,8 @@ int upload_plan(syldet *h, FusedPlan &p, DeviceBuffer &buf)
     d.dfrag = (const uint4 *)(base + o_d);
     d.afrag = (const uint4 *)(base + o_w);
     d.afrag_t = (const uint4 *)(base + o_wt);
+    d.sfrag = (const uint4 *)(base + o_sf);
+    d.slone = (const float *)(base + o_sl);
     d.koff = (const int *)(base + o_k);
     d.bias0 = (const float *)(base + o_b);
     d.rvec = (const float *)(base + o_r);
@@ -571,6 +576,7 @@ int run_on_stream(syldet *h, const float *d_samples, int64_t S, int64_t stride, 
         // diagnostic only: SYLDET_FUSED_KO=<mask> runs an instantiation with parts of the kernel knocked out
         d.ko = h->sw.fused_ko;
         d.force_classic = h->sw.fused_classic ? 1 : 0;
+        d.no_fold = h->sw.fused_nofold ? 1 : 0;
         // diagnostic only: SYLDET_FUSED_STAMPS=1 runs the stamped instantiation and prints where a
         // workgroup pass spends its cycles (never set in tests or the benchmark)
         if (h->sw.fused_stamps) {
@@ -609,11 +615,13 @@ int run_on_stream(syldet *h, const float *d_samples, int64_t S, int64_t stride, 
             return SYLDET_OK;
         }
         // the precision guard's work list, and behind the fused kernel the exact recomputation of what it reports
-        const int64_t segs = (E + d.r_seg_evals - 1) / d.r_seg_evals + (E + d.seg_evals - 1) / d.seg_evals;
+        const int64_t segs = (E + d.r_seg_evals - 1) / d.r_seg_evals + (E + d.seg_evals - 1) / d.seg_evals +
+                             (d.s_seg_evals > 0 ? (E + d.s_seg_evals - 1) / d.s_seg_evals : 0);
         if (int st = prepare_fix(h, C, E, segs, stream, d.fix)) return st;
         {
             // (the launcher picks the register-resident-basis kernel where it is instantiated: named for what runs)
-            KernelTimer t(h, stream, (fused_r_applicable(d) && (!h->sw.fused_classic || !d.classic_ok) && !d.ko) ? "fused_r_kernel" : "fused_kernel");
+            static const char *const names[3] = {"fused_kernel", "fused_r_kernel", "fused_s_kernel"};
+            KernelTimer t(h, stream, names[fused_choice(d, J)]);
             SYLDET_HIP(launch_fused(d, d_samples, stride, C, S, J, E, d_outputs, d_flags, stream));
         }
         SYLDET_HIP(launch_fixup(h->fixd, h->net, d_samples, stride, J, E, d_outputs, d_flags, nullptr, d.fix, stream));
@@ -861,8 +869,12 @@ int64_t syldet_segment_evals(const syldet_t *h, int64_t n_samples)
     if (E <= 0) return 0;
     FusedDesc d = h->fused.desc;
     fused_segmentation(d, E, h->channels);
-    const bool r = fused_r_applicable(d) && (!h->sw.fused_classic || !d.classic_ok);
-    return r ? d.r_seg_evals : d.seg_evals;
+    d.force_classic = h->sw.fused_classic ? 1 : 0;
+    d.no_fold = h->sw.fused_nofold ? 1 : 0;
+    d.ko = h->sw.fused_ko;
+    d.stamps = nullptr;
+    const int choice = fused_choice(d, count_frames(h, n_samples));
+    return choice == 2 ? d.s_seg_evals : (choice == 1 ? d.r_seg_evals : d.seg_evals);
 }
 
 int64_t syldet_count_frames(const syldet_t *h, int64_t n_samples) { return h ? count_frames(h, n_samples) : -1; }
