@@ -183,20 +183,22 @@ def test_kernel_timings_of_the_last_calls():
             det.run(x)
         got = [det.timingsOf(back) for back in range(5)]
         assert got[4] == [] and all(len(g) == 1 for g in got[:4])
-        assert got[0][0][0] == "fused_r_kernel" and all(ms > 0.0 for g in got[:4] for _, ms in g)
+        assert got[0][0][0] == "fused_s_kernel" and all(ms > 0.0 for g in got[:4] for _, ms in g)
         assert det.lastTimings() == got[0]
         det.profile(True)                                              # back to one call
         det.run(x)
         assert len(det.timingsOf(0)) == 1 and det.timingsOf(1) == []
 
 
+@pytest.mark.parametrize("kernel", ["fused_s_kernel", "fused_r_kernel"])
 @pytest.mark.parametrize("n_out,H,rule,hop,maps", [(2, 4, 0, 132, ("mapminmax",)), (3, 3, 1, 132, ()), (4, 4, 1, 64, ("mapstd",)), (4, 2, 0, 96, ("mapminmax",)),
                                                    (2, 1, 1, 100, ())])
-def test_several_outputs_on_the_register_resident_kernel(oracle_lib, n_out, H, rule, hop, maps):
+def test_several_outputs_on_the_register_resident_kernel(oracle_lib, monkeypatch, kernel, n_out, H, rule, hop, maps):
     """Up to four outputs (several syllables, one threshold each: SyllableDetector.swift:27-31 looks at output 0, the CLI at
     any -- TrackDetector.swift:72-77) on kernels_fused_r.hip: every output is finished by its own lane group.  Values, flags
     under both rules, planted syllables so that flags fire."""
     torch = _torch()
+    util.select_fused(monkeypatch, kernel)
     rng = np.random.default_rng(100 * n_out + H)
     base = util.sample_net()
     net = nets.random_net(rng, 290, (H,), n_out, in_fns=("l2normalize", "mapminmax"), out_fns=maps)
@@ -217,7 +219,7 @@ def test_several_outputs_on_the_register_resident_kernel(oracle_lib, n_out, H, r
         det.profile(True)
         out, fl = det.run(torch.from_numpy(x).cuda())
         torch.cuda.synchronize()
-        assert [nm for nm, _ in det.lastTimings()] == ["fused_r_kernel"]
+        assert [nm for nm, _ in det.lastTimings()] == [kernel]
         out, fl = out.cpu().numpy(), fl.cpu().numpy()
     fired = 0
     for c in range(2):
@@ -355,7 +357,8 @@ def test_full_size_properties():
         assert torch.equal(out4, out[perm])
 
 
-@pytest.mark.parametrize("C,log2S,kernel", [(64, 24, "fused_r_kernel"), (64, 24, "fused_kernel"), (512, 21, "fused_r_kernel")])
+@pytest.mark.parametrize("C,log2S,kernel", [(64, 24, "fused_s_kernel"), (64, 24, "fused_r_kernel"), (64, 24, "fused_kernel"), (512, 21, "fused_s_kernel"),
+                                            (512, 21, "fused_r_kernel")])
 def test_benchmark_size_against_the_oracle(oracle_lib, monkeypatch, C, log2S, kernel):
     """The sizes the headline is quoted on -- BASELINE configs[1] (64 channels x 2^24 samples) and the per-GPU shape of
     configs[3] (512 x 2^21) -- against the oracle where a tiling bug would show (tests/spotcheck.py): head and tail of the
@@ -363,10 +366,7 @@ def test_benchmark_size_against_the_oracle(oracle_lib, monkeypatch, C, log2S, ke
     checked stretches, so flags fire there (the BASELINE audio model alone never triggers the example network)."""
     import spotcheck
     torch = _torch()
-    if kernel == "fused_kernel":
-        monkeypatch.setenv("SYLDET_FUSED_CLASSIC", "1")
-    else:
-        monkeypatch.delenv("SYLDET_FUSED_CLASSIC", raising=False)
+    util.select_fused(monkeypatch, kernel)
     cfg = util.sample_net()
     S = 1 << log2S
     x = synth.channels_on_device(C, S, "cuda")
@@ -542,11 +542,8 @@ def test_both_fused_kernels_against_the_oracle_and_each_other(oracle_lib, monkey
     xd = torch.from_numpy(x).cuda()
     o = util.oracle_for(cfg)
     got = {}
-    for kernel in ("fused_r_kernel", "fused_kernel"):
-        if kernel == "fused_kernel":
-            monkeypatch.setenv("SYLDET_FUSED_CLASSIC", "1")
-        else:
-            monkeypatch.delenv("SYLDET_FUSED_CLASSIC", raising=False)
+    for kernel in util.FUSED_KERNELS:
+        util.select_fused(monkeypatch, kernel)
         with sd.SyllableDetector(cfg, channels=channels, engine=_abi.ENGINE_FUSED) as det:
             det.profile(True)
             out, fl = det.run(xd)
@@ -558,9 +555,10 @@ def test_both_fused_kernels_against_the_oracle_and_each_other(oracle_lib, monkey
             _, _, w64 = o.run(x[c], po.F64)
             util.assert_outputs_close(out[c], w64)
             util.assert_flags_exact(fl[c], w64, cfg.thresholds, cfg.rule)
-    both = np.isfinite(got["fused_kernel"]) & np.isfinite(got["fused_r_kernel"])
-    assert (np.isfinite(got["fused_kernel"]) == np.isfinite(got["fused_r_kernel"])).all()
-    assert np.abs(got["fused_kernel"][both] - got["fused_r_kernel"][both]).max() <= 5e-6
+    for other in ("fused_r_kernel", "fused_s_kernel"):
+        both = np.isfinite(got["fused_kernel"]) & np.isfinite(got[other])
+        assert (np.isfinite(got["fused_kernel"]) == np.isfinite(got[other])).all()
+        assert np.abs(got["fused_kernel"][both] - got[other][both]).max() <= 5e-6
 
 
 def test_register_resident_kernel_is_only_taken_where_it_is_instantiated(oracle_lib):
@@ -627,16 +625,13 @@ def test_network_stage_on_the_matrix_cores(oracle_lib, N, lo, hi, T, H, scaling)
             assert not fl[c][~ok].any()
 
 
-@pytest.mark.parametrize("classic", [False, True])
-def test_a_nan_sample_poisons_exactly_the_windows_that_contain_it(oracle_lib, monkeypatch, classic):
+@pytest.mark.parametrize("kernel", util.FUSED_KERNELS)
+def test_a_nan_sample_poisons_exactly_the_windows_that_contain_it(oracle_lib, monkeypatch, kernel):
     """The reference propagates a NaN sample into the frames that cover it and from there into the timeRange evaluations
     whose windows contain those frames -- no more (rows of zero weights in a GEMM still turn a NaN column into NaN
     products: the register-resident-basis kernel reads zeros for the taps past timeRange instead).  Both fused kernels."""
     torch = _torch()
-    if classic:
-        monkeypatch.setenv("SYLDET_FUSED_CLASSIC", "1")
-    else:
-        monkeypatch.delenv("SYLDET_FUSED_CLASSIC", raising=False)
+    util.select_fused(monkeypatch, kernel)
     cfg = util.sample_net()
     x = synth.syllable_channel(64 * 132 * 5 + 700, util.template(), seed=8).astype(np.float32)
     x[25000] = np.nan

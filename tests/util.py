@@ -160,3 +160,20 @@ def log_condition(o: "po.Oracle", cfg, x: np.ndarray, cols64: np.ndarray, evals,
                 d = np.abs(out - base) / np.maximum(1.0, np.abs(base))
                 moves[n] = max(moves[n], float(np.nan_to_num(d, nan=np.inf).max()))
     return moves
+
+
+FUSED_KERNELS = ["fused_s_kernel", "fused_r_kernel", "fused_kernel"]
+
+
+def select_fused(monkeypatch, kernel):
+    """The environment under which a handle created next runs `kernel` where several fused kernels take the shape (the switches
+    are read once, at syldet_create): the symmetric-fold kernel by default, the register-resident-basis kernel under
+    SYLDET_FUSED_NOFOLD=1, the 8-wave kernel under SYLDET_FUSED_CLASSIC=1."""
+    monkeypatch.delenv("SYLDET_FUSED_CLASSIC", raising=False)
+    monkeypatch.delenv("SYLDET_FUSED_NOFOLD", raising=False)
+    if kernel == "fused_r_kernel":
+        monkeypatch.setenv("SYLDET_FUSED_NOFOLD", "1")
+    elif kernel == "fused_kernel":
+        monkeypatch.setenv("SYLDET_FUSED_CLASSIC", "1")
+    else:
+        assert kernel == "fused_s_kernel"
