@@ -194,6 +194,11 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
     const double thr_g = d.thresholds[(GEN && g < n_out) ? g : 0];
     const bool counts = !GEN || n_out == 1 ? true : (g < n_out && (g == 0 || d.rule == 1));
     const int tf0 = GEN ? d.tf0 : 0, tf1 = GEN ? d.tf1 : 2, norm = GEN ? d.norm : 1;
+    const int scaling = GEN ? d.scaling : 0;          // linear |X|, or ln / 20 log10 of it in front of the chain (SyllableDetector.swift:184-212)
+    const float klog = scaling == 1 ? 0.6931471805599453f : 6.020599913279624f;      // ln 2, 20 log10 2
+    bool binv[8];                                     // which of this lane's 8 bins are band bins (rows past F are zeros: log 0)
+#pragma unroll
+    for (int i = 0; i < 8; i++) binv[i] = (i < 4 ? 4 * g + i : 16 + 4 * g + (i - 4)) < d.F;
     const float kmag = pow2f(-13 - d.col_shift);
     const bool guard_on = d.fix.counters != nullptr;
     const float guard_k = norm == 1 ? d.guard_r : d.guard_rel_r;
@@ -210,6 +215,9 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
 
         // ---- the frame's own scale from its loudest sample (this lane looks at a quarter of the frame)
         float amax;
+#ifdef SYLDET_S_NOMAX                // (diagnostic knock-outs, tools/s_knockouts.sh: wrong results by construction, never the shipped library)
+        amax = 1.0f;
+#else
         {
             float m0 = 0.0f, m1 = 0.0f;
             const floatx4 *q0 = reinterpret_cast<const floatx4 *>(fp + (W / 4) * g);
@@ -225,6 +233,7 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
             r = __builtin_amdgcn_permlane32_swap(__float_as_uint(amax), __float_as_uint(amax), false, false);
             amax = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
         }
+#endif
         // status of the frame for the precision guard: 0 fine, 1 silent (its column is exact zeros), 2 the grid cannot hold it
         // (an infinite sample, or a level above 2^113)
         const int ex = (int)((__float_as_uint(amax) >> 23) & 0xffu);
@@ -247,6 +256,7 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
         const float xl = fp[0] * sx;                  // the frame's first sample (no partner)
         floatx4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // re 0-15, re 16-31, im 0-15, im 16-31
         const float *xpb = fp + W / 2 + 8 * g, *xmb = fp + W / 2 - 8 * g;
+#ifndef SYLDET_S_NODFT
 #pragma unroll
         for (int ks = 0; ks < K2; ks++) {
             // x[c + m0 + i], i = 0..7, and x[c - m0 - i]: words c-m0-8 .. c-m0-1 as two quads, and the word c - m0
@@ -286,6 +296,9 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
 #pragma unroll
             for (int m = 0; m < 2; m++) acc[2 + m] = mfma(ad_[ks][m][1], bdh, acc[2 + m]);
         }
+#else
+        acc[0][0] = xpb[0]; acc[1][1] = xmb[0];
+#endif
         // the raw samples of this tile are dead (every read of them has returned): the rest of the next tile's chunks
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (t + 1 < tiles) issue_upto(need(t + 1));
@@ -298,12 +311,20 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
         for (int i = 0; i < 8; i++) {
             const float re = fmaf(cre[i], xl, acc[i >> 2][i & 3]), im = acc[2 + (i >> 2)][i & 3];
             cval[i] = __builtin_amdgcn_sqrtf(fmaf(re, re, im * im)) * kmag;
-            mss = fmaf(cval[i], cval[i], mss);
         }
+        if (GEN && scaling != 0) {
+            // log / dB columns: |X| = cval 2^(col_shift - se) in true units; v_log_f32 is log2; ln 0 = -inf as in the reference
+            const float off = (float)(d.col_shift - se) * klog;
+#pragma unroll
+            for (int i = 0; i < 8; i++) cval[i] = binv[i] ? fmaf(__builtin_amdgcn_logf(cval[i]), klog, off) : 0.0f;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) mss = fmaf(cval[i], cval[i], mss);
         mss = xor32_sum(xor16_sum(mss));
         // products and sums of squares are stored relative to the segment's reference exponent (* 2^dsc, * 4^dsc): a window
         // straddles frames of different scales.  Frames 2^45 away from it, and frames the grid cannot hold, condemn their windows.
-        int dsc = se_ref - se;
+        // (log / dB columns are absolute numbers: no relative scale, and no grid floor to guard beyond what no grid can hold)
+        int dsc = (GEN && scaling != 0) ? 0 : se_ref - se;
         const bool far = dsc > 45 || dsc < -45 || fst == 2;
         dsc = dsc < -45 ? -45 : (dsc > 45 ? 45 : dsc);
         // The frame's own column exponent: its column is split at the scale that puts its norm into [2^12, 2^13); with ex the
@@ -333,7 +354,7 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
             // the frame's sum of squares relative to the reference, and the weight of its grid floor there: 4^dsc (0 for a
             // silent frame: exact zeros; +inf for a frame the grid cannot hold)
             const float sr = mss * pow2f(2 * dsc);
-            const float fw = far ? INFINITY : (fst == 1 ? 0.0f : pow2f(2 * dsc));
+            const float fw = far ? INFINITY : ((fst == 1 || (GEN && scaling != 0)) ? 0.0f : pow2f(2 * dsc));
             if (g == 0) *reinterpret_cast<floatx2 *>(prow + 4 * TP) = floatx2{sr, fw};
         }
 
@@ -379,7 +400,7 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
         float yv;
         bool hit;
         {
-            const int ush = d.col_shift - se_ref;
+            const int ush = (GEN && scaling != 0) ? 0 : d.col_shift - se_ref;
             const float alpha0 = d.w_unscale * pow2f(ush < -120 ? -120 : (ush > 120 ? 120 : ush));
             const float alpha = norm == 1 ? d.w_unscale * __builtin_amdgcn_rsqf(ssw) : alpha0;
             const float act = transfer_fn(tf0, fmaf(alpha, zt, b0g));
@@ -476,7 +497,9 @@ hipError_t launch_one(const FusedDesc &d, const float *samples, int64_t stride, 
 // symmetric (all of the reference's are), any timeRange up to 12, hops that are multiples of 4 and leave room for the ring.
 bool fused_s_applicable(const FusedDesc &d)
 {
-    const bool cls = (d.norm == 0 || d.norm == 1) && d.scaling == 0 && d.n_layers == 2 && d.n_out >= 1 && d.n_out <= 4 && d.H <= 4 && d.n_out_fns <= 1;
+    // (log / dB columns too: every frame is transformed at its own scale, so a bin's error is relative to its frame, as an fp32
+    // FFT's is -- what the logarithm makes of that is the same for both)
+    const bool cls = (d.norm == 0 || d.norm == 1) && d.n_layers == 2 && d.n_out >= 1 && d.n_out <= 4 && d.H <= 4 && d.n_out_fns <= 1;
     return d.s_ok && d.T <= 12 && cls;
 }
 
@@ -488,7 +511,7 @@ hipError_t launch_fused_s(const FusedDesc &d, const float *samples, int64_t stri
     if (!fused_s_applicable(d)) return hipErrorInvalidValue;
     const int64_t s_eff = (J - 1) * (int64_t)d.hop + d.gap + d.W;
     if (s_eff * 4 >= 0x7fffffffll) return hipErrorInvalidValue;           // (the launcher's caller keeps such rows on the other kernels)
-    const bool exact = d.norm == 1 && d.tf0 == 0 /* TanSig */ && d.tf1 == 2 /* PureLin */ && d.n_out == 1;
+    const bool exact = d.norm == 1 && d.scaling == 0 && d.tf0 == 0 /* TanSig */ && d.tf1 == 2 /* PureLin */ && d.n_out == 1;
 #define SD_S_GO(K2_)                                                                                                  \
     if (d.W == 64 * K2_) {                                                                                            \
         if (exact) return launch_one<K2_, false>(d, samples, stride, C, s_eff, E, outputs, flags, stream);            \

@@ -706,9 +706,18 @@ int syldet_create(const syldet_config_t *cfg, int32_t n_channels, int32_t device
         // The fused engine hands columns to the first layer as f16 hi + lo pairs.  For linear |X| columns that is below
         // fp32 noise; log / dB values (magnitude up to ~100, 2^-22 relative = a few 1e-5 absolute) can leave the 1e-5
         // parity bar.  AUTO therefore keeps those scalings on the generic engine; the fused one stays available on request.
+        // Round 3: the symmetric-fold kernel transforms every frame at its own scale -- a bin's error is relative to its frame,
+        // as the generic FFT's is -- so behind l2normalize (what the split of the logarithms loses is lost relative to the vector
+        // the network sees, as in the generic engine's matrix-core network stage) AUTO takes it for log / dB columns too.
         const bool strict_ok = h->cfg.view.scaling == SYLDET_SCALING_LINEAR;
         if (engine == SYLDET_ENGINE_AUTO && !strict_ok) {
-            h->fused.reason = "log/dB scaling: AUTO keeps the generic engine for 1e-5 parity";
+            if (make_fused_plan(h->cfg.view, h->geom, h->fused) && fused_s_applicable(h->fused.desc) && h->fused.desc.norm == 1 &&
+                !h->sw.fused_nofold && !h->sw.fused_classic) {
+                h->engine = SYLDET_ENGINE_FUSED;
+            } else {
+                h->fused = FusedPlan();
+                h->fused.reason = "log/dB scaling: AUTO keeps the generic engine for 1e-5 parity";
+            }
         } else if (make_fused_plan(h->cfg.view, h->geom, h->fused)) {
             h->engine = SYLDET_ENGINE_FUSED;
         } else if (engine == SYLDET_ENGINE_FUSED) {

@@ -454,6 +454,37 @@ def test_wide_hidden_layer_on_auto_keeps_its_spectrogram_front(oracle_lib):
         util.assert_columns_close(cols[c].cpu().numpy(), o.spectrogram(x[c], po.F64))
 
 
+@pytest.mark.parametrize("scaling", ["log", "db"])
+@pytest.mark.parametrize("chain", [("l2normalize", "mapminmax"), ("l2normalize",)])
+def test_log_and_db_columns_on_the_fold_kernel(oracle_lib, scaling, chain):
+    """SyllableDetector.swift:184-212: ln / 20 log10 of the |X| columns in front of the network.  The symmetric-fold kernel
+    transforms every frame at its own scale (a bin's error is relative to its frame, as an fp32 FFT's), so AUTO takes it for
+    these columns when the chain starts with l2normalize; one launch instead of FFT + network stage.  The bar is the one the
+    log / dB sweeps use everywhere: 1e-4, or 30x the fp32 port's own distance from the anchor."""
+    torch = _torch()
+    base = util.sample_net()
+    rng = np.random.default_rng(17)
+    net = nets.random_net(rng, 290, (4,), 1, in_fns=chain, out_fns=("mapminmax",))
+    cfg = nets.variant(base, net=net, spectrogramScaling=scaling, thresholds=[0.1])
+    x = np.stack([synth.syllable_channel(90000, util.template(), seed=31), synth.channel(90000, 5)]).astype(np.float32)
+    x[1, 40000:] *= np.float32(0.003)                      # a level step: frames are scaled one by one
+    with sd.SyllableDetector(cfg, channels=2) as det:
+        assert det.geometry.engine == _abi.ENGINE_FUSED
+        det.profile(True)
+        out, fl = det.run(torch.from_numpy(x).cuda())
+        torch.cuda.synchronize()
+        assert [nm for nm, _ in det.lastTimings()] == ["fused_s_kernel"]
+        assert det.fixupStats() == (0, 0)
+        out, fl = out.cpu().numpy(), fl.cpu().numpy()
+    o = util.oracle_for(cfg)
+    for c in range(2):
+        w32, _, w64 = o.run(x[c], po.F64, cfg.rule)
+        own = float(np.abs(w32 - w64).max())
+        tol = max(1e-4, 30.0 * own)
+        util.assert_outputs_close(out[c], w64, tol)
+        util.assert_flags_exact(fl[c], w64, cfg.thresholds, cfg.rule, tol)
+
+
 def test_cpp_mirror_of_the_swift_surface(oracle_lib, tmp_path):
     """include/syldet.hpp (SyllableDetectorConfig(fromTextFile:), SyllableDetector.appendAudioData /
     processNewValue / lastOutputs / lastDetected, bank.run, detections) driven from a C++ program."""

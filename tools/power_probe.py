@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic: socket power and shader clock (rocm-smi, sampled from a side thread) while the benchmark batch's kernel -- or,
 for comparison, a plain streaming read of the same 4.3 GB (torch's sum) -- runs back to back for a few seconds.
-    python tools/power_probe.py [seconds] [fused|read|classic|config3|config5]"""
+    python tools/power_probe.py [seconds] [fused|fusedr|read|classic|config3|config5]     (fused: the symmetric-fold kernel; fusedr: fused_r_kernel)"""
 import os, re, subprocess, sys, threading, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -13,6 +13,8 @@ secs = float(sys.argv[1]) if len(sys.argv) > 1 else 6.0
 mode = sys.argv[2] if len(sys.argv) > 2 else "fused"
 if mode == "classic":
     os.environ["SYLDET_FUSED_CLASSIC"] = "1"
+if mode == "fusedr":
+    os.environ["SYLDET_FUSED_NOFOLD"] = "1"
 samples, stop = [], False
 def sampler():
     while not stop:

@@ -159,6 +159,47 @@ __global__ void __launch_bounds__(256) rd(const floatx4r *__restrict__ p, size_t
     }
     if (acc[0] + acc[1] + acc[2] + acc[3] == 12345.678f) sink[0] = acc[0];
 }
+// the same read through a buffer descriptor with a cache-policy operand: aux bit 0 sc0, bit 1 nt, bit 4 sc1
+template <int AUX>
+__global__ void __launch_bounds__(256) rdaux(const floatx4r *__restrict__ p, size_t n, size_t per_wg, float *sink)
+{
+    floatx4r acc = {0, 0, 0, 0};
+    const size_t b = (size_t)blockIdx.x * per_wg, e = b + per_wg < n ? b + per_wg : n;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<floatx4r *>(p + b), 0, (int)((e - b) * 16), 0x00020000);
+    for (size_t i = threadIdx.x; i < e - b; i += 256 * 8) {
+        uint32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)((i + 256 * u) * 16), 0, AUX);
+#pragma unroll
+        for (int u = 0; u < 8; u++) { acc[0] += __uint_as_float(v[u][0]); acc[1] += __uint_as_float(v[u][1]); acc[2] += __uint_as_float(v[u][2]); acc[3] += __uint_as_float(v[u][3]); }
+    }
+    if (acc[0] + acc[1] + acc[2] + acc[3] == 12345.678f) sink[0] = acc[0];
+}
+template <int AUX>
+void run_hbm_aux(const char *name, double secs)
+{
+    const size_t n = (size_t)1 << 28;
+    floatx4r *p; float *sink;
+    CK(hipMalloc(&p, n * 16));
+    CK(hipMalloc(&sink, 4));
+    hipLaunchKernelGGL(fill, dim3(4096), dim3(256), 0, 0, reinterpret_cast<uint32x4 *>(p), n);
+    CK(hipDeviceSynchronize());
+    const int grid = 2048;
+    const size_t per_wg = (n + grid - 1) / grid;
+    const auto t0 = std::chrono::steady_clock::now();
+    long launches = 0;
+    double el = 0;
+    while (el < secs) {
+        for (int i = 0; i < 50; i++) hipLaunchKernelGGL(rdaux<AUX>, dim3(grid), dim3(256), 0, 0, p, n, per_wg, sink);
+        CK(hipDeviceSynchronize());
+        launches += 50;
+        el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    printf("%s: %.3f ms per 4 GiB launch = %.2f TB/s, %.4e wave-instructions/s over the chip (1 KiB each)\n", name, el / launches * 1e3,
+           (double)launches * n * 16 / el / 1e12, (double)launches * n * 16 / 1024 / el);
+    CK(hipFree(p)); CK(hipFree(sink));
+}
+
 template <bool NT>
 void run_hbm(const char *name, double secs)
 {
@@ -227,6 +268,14 @@ int main(int argc, char **argv)
     else if (!strcmp(mode, "ldsr")) run<LDSR>(mode, 8, secs, 16, 60000);
     else if (!strcmp(mode, "hbm")) run_hbm<false>(mode, secs);
     else if (!strcmp(mode, "hbmnt")) run_hbm<true>(mode, secs);
+    else if (!strcmp(mode, "aux0")) run_hbm_aux<0>(mode, secs);
+    else if (!strcmp(mode, "aux1")) run_hbm_aux<1>(mode, secs);
+    else if (!strcmp(mode, "aux2")) run_hbm_aux<2>(mode, secs);
+    else if (!strcmp(mode, "aux3")) run_hbm_aux<3>(mode, secs);
+    else if (!strcmp(mode, "aux16")) run_hbm_aux<16>(mode, secs);
+    else if (!strcmp(mode, "aux17")) run_hbm_aux<17>(mode, secs);
+    else if (!strcmp(mode, "aux18")) run_hbm_aux<18>(mode, secs);
+    else if (!strcmp(mode, "aux19")) run_hbm_aux<19>(mode, secs);
     else if (!strcmp(mode, "m16fma")) run<M16FMA>(mode, 8, secs, 8, 30000);
     else { printf("unknown mode %s\n", mode); return 1; }
     return 0;
