@@ -219,11 +219,15 @@ int syldet_last_timings(syldet_t *h, double *milliseconds, const char **names, i
  * `calls_back` calls before the last one (0: the last), *count = 0 if that call is not held.                              */
 int syldet_profile_history(syldet_t *h, int32_t calls);
 int syldet_timings(syldet_t *h, int32_t calls_back, double *milliseconds, const char **names, int32_t capacity, int32_t *count);
-/* The fused kernels compute on a block-floating-point grid (one power-of-two scale per 64 / 128 frames).  Evaluations
- * whose windows that grid cannot hold to the 1e-5 contract -- a quiet stretch right behind a click, an infinite sample, a
- * level step of hundreds of dB -- are detected on the device and recomputed from the samples in fp64, so that results
- * (and NaN, which the reference yields exactly for the windows that contain the offending sample: NeuralNet.swift:47-59)
- * never depend on the tiling.  *items = 16-evaluation work items the last completed batch call of this handle recomputed
+/* The fused kernels compute on a block-floating-point grid.  The symmetric-fold kernel (the reference's example class: at
+ * most 4 hidden units, no normaliser or l2normalize, windows of 64 / 128 / 192 / 256 samples) gives every FRAME its own
+ * power-of-two scale: its results are a function of the samples under the window alone -- the same bits whether the audio
+ * arrives through the streaming calls or a batch call, however it is tiled -- and only what no grid can hold (an infinite
+ * sample, levels 2^45 apart inside one window) is recomputed.  The two older kernels (wider networks, normalize /
+ * normalizestd chains) scale per 64 / 128-frame pass: evaluations whose windows that grid cannot hold to the 1e-5 contract --
+ * a quiet stretch right behind a click, a level step of hundreds of dB -- are detected on the device and recomputed from
+ * the samples in fp64 (and NaN, which the reference yields exactly for the windows that contain the offending sample:
+ * NeuralNet.swift:47-59, appears exactly there); between two tilings of the same audio their results agree to a few 1e-7.  *items = 16-evaluation work items the last completed batch call of this handle recomputed
  * (0 for ordinary audio), *overflow = 1 if a work list was ever too small (never, by construction).  Blocks; call it after
  * the stream the batch call ran on has been synchronised.  No reference counterpart (diagnostic).                       */
 int syldet_fixup_stats(syldet_t *h, int64_t *items, int32_t *overflow);

@@ -279,11 +279,18 @@ def test_streaming_api_equals_batch(oracle_lib, name):
         assert not det.processNewValue(0)                       # channel 0 saw no audio
         got = np.array(got).reshape(-1, o.n_out)
         util.assert_outputs_close(got, w64)
+        det.profile(True)
         batch, _ = det.runHost(np.stack([x, x]))
-        # streaming results are the batch engine's: identical on the generic engine; the fused engine
-        # picks its block-floating-point scale per 128-frame tile, so a different tiling of the same
-        # audio moves results by a few 1e-7
-        util.assert_outputs_close(batch[1], got, tol=2e-6)
+        kernels = [nm for nm, _ in det.lastTimings()]
+        # Streaming results are the batch engine's.  Identical bits on the generic engine and on the symmetric-fold kernel,
+        # which scales every FRAME by itself: a result depends on the samples under its window, not on how the audio is cut
+        # into calls, tiles or segments (the reference is chunking-invariant too: SyllableDetector.swift:153-217).  The two
+        # pass-scaled kernels (wider networks, normalize / normalizestd chains) pick a block scale per 64 / 128-frame pass, so a
+        # different tiling moves their results by a few 1e-7.
+        if det.geometry.engine != _abi.ENGINE_FUSED or kernels == ["fused_s_kernel"]:
+            assert np.array_equal(batch[1].astype(np.float32), got.astype(np.float32)), float(np.abs(batch[1] - got).max())
+        else:
+            util.assert_outputs_close(batch[1], got, tol=2e-6)
 
 
 def test_streaming_seen_syllable_and_overflow(oracle_lib):

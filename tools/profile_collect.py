@@ -57,8 +57,10 @@ def counters(name):
 
 
 summary = {"source": "tools/profile_round.sh %s (rocprofv3 --kernel-trace --stats; separate --kernel-trace --pmc passes), MI355X" % R}
-for wl, dom in (("sample", "fused_r_kernel"), ("config3", "fft1k_net_kernel"), ("config5", "wide_gemm_kernel")):
+for wl, dom in (("sample", "fused_s_kernel"), ("config3", "fft1k_net_kernel"), ("config5", "wide_gemm_kernel")):
     line = bench_line(os.path.join(SRC, "stats_%s.log" % wl))
+    if line and line.get("roofline", {}).get("kernel"):
+        dom = line["roofline"]["kernel"]                 # what the run says its dominant kernel was
     ks = kernel_stats(wl)
     if line:
         json.dump(line, open(os.path.join(DST, "%s_%s_bench_under_rocprof.json" % (R, wl)), "w"), indent=1)

@@ -4,19 +4,19 @@
 #   usage: tools/profile_round.sh r02
 # Counters are collected in passes of their own (--kernel-trace + --pmc only), the program right behind "--".
 set -u
-R=${1:-r02}
+R=${1:-r03}
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/prof_$R
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 run_stats() {   # name, bench args
   name=$1; shift
-  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$name -- python3 $ROOT/bench.py --no-cpu-baseline "$@" > $OUT/stats_$name.log 2>&1
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$name -- python3 $ROOT/bench.py --no-cpu-baseline --no-also "$@" > $OUT/stats_$name.log 2>&1
   echo "stats $name rc=$?"
 }
 run_pmc() {     # name, counters, bench args
   name=$1; ctrs=$2; shift 2
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $OUT/pmc_$name -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-verify "$@" > $OUT/pmc_$name.log 2>&1
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $OUT/pmc_$name -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-verify --no-also "$@" > $OUT/pmc_$name.log 2>&1
   echo "pmc $name rc=$?"
 }
 run_stats sample
