@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "fused_plan.hpp"
@@ -208,14 +209,21 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
         bool sym = (W % 64 == 0) && (g.gap % 4 == 0);
         // (to an ulp of the fp32 table: the two sides are averaged below, which moves a coefficient by 2^-25 of itself at most)
         for (int nn = 1; nn < W && sym; nn++) sym = std::fabs((double)win[(size_t)nn] - (double)win[(size_t)(W - nn)]) <= 2.4e-7 * std::fabs((double)win[(size_t)nn]) + 1e-30;
-        const int TP = (T + 1) / 2 * 2;                          // taps stored per frame row (even: the row stride 4 TP + 4 then spreads 16 rows over the banks)
-        const int PSs = 4 * TP + 4;
-        const int row_bytes = ((T - 1 + kFusedSTileFrames) * PSs + 8) * 4;
-        const int per_wave = 160 * 1024 / (kFusedSBlock / 64);
-        const int RC = (per_wave - (row_bytes + 15) / 16 * 16) / 1024 - 1;     // ring chunks of 256 samples, one more for the mirror
+        const int TP = (T + 1) / 2 * 2;                          // taps stored per frame row (even: the row stride then spreads 16 rows over the banks)
+        const int HQ = (H + 3) / 4;                              // quads of hidden units: one -> 8 waves a workgroup, more -> 4 (kernels_fused_s.hip)
+        const int PSs = 4 * HQ * TP + 4;
+        const int row_bytes = ((T - 1 + kFusedSTileFrames) * PSs + 8 * HQ + 128) * 4;   // rows, the zero quad and the dump quad, lane-group constants
         const int span = (kFusedSTileFrames - 1) * hop + W;
-        if (sym && H <= 4 && RC >= (span + 255) / 256 + 1 && kFusedSTileFrames * hop <= RC * 256) {
+        auto ring_chunks = [&](int waves) { return std::min(30, (160 * 1024 / waves - (row_bytes + 15) / 16 * 16) / 1024 - 1); };
+        auto fits = [&](int rc) { return rc >= (span + 255) / 256 + 1 && kFusedSTileFrames * hop <= rc * 256; };
+        // two waves a SIMD where the rows of tap products leave room for the ring in a 20 KB share of the LDS (one or two quads of units)
+        // (one quad: always -- it is instantiated for 8 waves only)
+        const int s_waves = (HQ == 1 || (HQ == 2 && fits(ring_chunks(kFusedSBlock / 64)))) ? kFusedSBlock / 64 : kFusedSBlock / 128;
+        const int per_wave = 160 * 1024 / s_waves;
+        const int RC = ring_chunks(s_waves);
+        if (sym && H <= 16 && c.n_layers == 2 && fits(RC)) {
             d.s_ok = 1;
+            d.s_waves = s_waves;
             d.s_perm = (hop / 4) % 2 == 1 ? 1 : 0;               // (the slot permutation spreads the frames over the banks when hop / 4 is odd)
             d.s_ring_chunks = RC; d.s_pstride = PSs; d.s_tp = TP;
             d.s_lds_wave = per_wave;
@@ -318,6 +326,25 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
                     p.afrag_t[(((size_t)m * 2 + 0) * 64 + l) * 8 + j] = hi;
                     p.afrag_t[(((size_t)m * 2 + 1) * 64 + l) * 8 + j] = lo;
                 }
+    // ... and for 5 .. 16 hidden units (kernels_fused_s.hip, HQ = ceil(H / 4) quads): row tile (m, q), row 4 g + i of it = tap
+    // 4 m + g, unit 4 q + i -- lane group g of a result then holds tap 4 m + g for every quad, as with one quad
+    {
+        const int HQ = (H + 3) / 4;
+        p.afrag_w.assign((size_t)3 * HQ * 2 * 64 * 8, 0);
+        if (HQ > 1)
+            for (int m = 0; m < 3; m++)
+                for (int q = 0; q < HQ; q++)
+                    for (int l = 0; l < 64; l++)
+                        for (int j = 0; j < 8; j++) {
+                            const int r = l & 15, t = 4 * m + r / 4, h = 4 * q + r % 4, gq = l >> 4, bin = j < 4 ? 4 * gq + j : 16 + 4 * gq + (j - 4);
+                            double v = 0.0;
+                            if (t < T && h < H && bin < F) v = (double)L0.weights[(size_t)h * I + t * F + bin] * a[(size_t)(t * F + bin)] * wscale;
+                            uint16_t hi, lo;
+                            split_half(v, hi, lo);
+                            p.afrag_w[((((size_t)m * HQ + q) * 2 + 0) * 64 + l) * 8 + j] = hi;
+                            p.afrag_w[((((size_t)m * HQ + q) * 2 + 1) * 64 + l) * 8 + j] = lo;
+                        }
+    }
     p.bias0.resize((size_t)H);
     p.rvec.resize((size_t)H);
     for (int h = 0; h < H; h++) {
@@ -379,6 +406,7 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
         d.guard_r = sq(lip * sqI * phi_r / eps_out);
         d.guard_c = sq(lip * sqI * phi_c / eps_out);
         d.guard_c_range = (float)std::min((norm == 2 ? 4.0 : 2.0) * lip * sqI * phi_c / eps_out, 1e30);
+        d.guard_range_r = (float)std::min((norm == 2 ? 4.0 : 2.0) * lip * sqI * phi_r / eps_out, 1e30);
         // no normaliser: every column has to stand on its own (the reference's error is relative to the frame, and nothing
         // divides a quiet column's error by a loud neighbour's norm): the smallest column sum of squares of the window
         d.guard_rel_r = sq(std::sqrt((double)F) * phi_r / rel);
@@ -525,7 +553,8 @@ void fused_segmentation(FusedDesc &d, int64_t E, int C)
         const int64_t max_tiles = 512;
         const int64_t max_evals = max_tiles * kFusedSTileFrames - (d.T - 1);
         int64_t segs = std::max<int64_t>(1, (E + max_evals - 1) / max_evals);
-        const int64_t slots = 256 * (kFusedSBlock / 64);
+        const int sw = d.s_waves > 0 ? d.s_waves : kFusedSBlock / 64;
+        const int64_t slots = 256 * sw;
         if ((int64_t)C * segs >= slots) {
             int gg = C, m = (int)slots;
             while (gg) { const int t = m % gg; m = gg; gg = t; }
@@ -534,7 +563,7 @@ void fused_segmentation(FusedDesc &d, int64_t E, int C)
         } else {
             segs = std::max<int64_t>(segs, std::min<int64_t>((slots + C - 1) / C, (frames + 4 * kFusedSTileFrames - 1) / (4 * kFusedSTileFrames)));
         }
-        segs = (segs + 7) / 8 * 8;                               // whole workgroups per channel
+        segs = (segs + sw - 1) / sw * sw;                        // whole workgroups per channel
         int64_t per = (E + segs - 1) / segs;
         int64_t tl = (per + (d.T - 1) + kFusedSTileFrames - 1) / kFusedSTileFrames;
         tl = std::max<int64_t>(1, tl);

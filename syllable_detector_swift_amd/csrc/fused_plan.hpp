@@ -15,7 +15,7 @@ struct FusedPlan {
     std::string reason;              // why the configuration does not fit, when !ok
     FusedDesc desc{};                // device pointers are filled in by the owner after upload
     std::vector<uint16_t> dfrag;     // f16 bit patterns
-    std::vector<uint16_t> afrag, afrag_t;
+    std::vector<uint16_t> afrag, afrag_t, afrag_w;
     std::vector<uint16_t> sfrag;     // the folded basis of the symmetric-fold kernel
     std::vector<float> slone;
     std::vector<int> koff;

@@ -143,8 +143,9 @@ struct FusedDesc {
     // layout of the symmetric-fold kernel (kernels_fused_s.hip): per wave a ring of s_ring_chunks x 256 samples + a mirror chunk,
     // rows of s_pstride floats of tap products (4 s_tp products, the frame's sum of squares, its floor weight); s_ok = 0 when the
     // shape does not fit it
-    int s_ok, s_perm, s_ring_chunks, s_pstride, s_tp, s_lds_wave, s_seg_evals;
+    int s_ok, s_waves, s_perm, s_ring_chunks, s_pstride, s_tp, s_lds_wave, s_seg_evals;
     const uint4 *sfrag;         // [W/64 k-steps][s, d][bins 0-15, 16-31][hi,lo][64 lanes] A-operand fragments of the folded basis
+    const uint4 *afrag_w;       // [3][HQ quads of hidden units][hi,lo][64 lanes] the first layer with all taps as rows for 5 .. 16 units
     const float *slone;         // [64 lanes][8] the frame's first sample's real coefficients for the lane's bins
     const uint4 *dfrag;         // [KS][re 0-15, re 16-31, im 0-15, im 16-31][hi,lo][64 lanes] A-operand fragments of the DFT basis
     const uint4 *afrag;         // [T][hi,lo][64 lanes] A-operand fragments of the folded first layer (16x16x32)
@@ -163,6 +164,7 @@ struct FusedDesc {
     float guard_r;              // register-resident-basis kernel: window sum of squares, times 4^(se_ref - se_min)
     float guard_c;              // 8-wave kernel, l2normalize / no normaliser: window sum of squares
     float guard_c_range;        //   normalize: window range;  normalizestd: window sigma
+    float guard_range_r;        // symmetric-fold kernel, normalize: window range; normalizestd: window sigma (relative to the loudest frame's floor)
     float guard_rel_r, guard_rel_c;   // no normaliser: the per-column relative criterion (smallest column sum of squares of the
                                       // window) that joins the absolute one
     int guard_se_abs_r, guard_se_abs_c;   // no normaliser: passes scaled below this exponent are loud enough for the floor to matter

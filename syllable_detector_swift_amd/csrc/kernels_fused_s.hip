@@ -47,8 +47,6 @@ namespace {
 
 using namespace fused_dev;
 
-constexpr int kBlock = kFusedSBlock;           // 512 threads = 8 waves, two per SIMD
-constexpr int kWaves = kBlock / 64;
 constexpr int kTile = kFusedSTileFrames;       // 16 frames per wave and tile
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -80,9 +78,12 @@ __device__ __forceinline__ void split2(float a, float b, unsigned &hi, unsigned 
 }
 
 // K2: k-steps of 32 folded positions (W = 64 K2).  GEN: the network class as run-time facts (any transfer functions, with or
-// without l2normalize, up to four outputs); without it the reference's example class (l2normalize, TanSig, one linear output).
-template <int K2, bool GEN>
-__global__ void __launch_bounds__(kBlock, 1)
+// without l2normalize, up to four outputs, log / dB columns); without it the reference's example class (l2normalize, TanSig, one
+// linear output).  HQ: quads of hidden units (H <= 4 HQ).  One quad: 8 waves a workgroup, two per SIMD, 256 registers each.
+// Wider hidden layers (5 .. 16 units) multiply the first layer's rows -- 9 HQ tap MFMAs a tile, 24 HQ fragment registers, rows
+// of 4 HQ T products -- and take 4 waves a workgroup, one per SIMD, with twice the registers and twice the LDS each.
+template <int K2, bool GEN, int HQ, int NW>
+__global__ void __launch_bounds__(64 * NW, 1)
 fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t stride, int64_t s_eff, int64_t E,
                float *__restrict__ outputs, uint8_t *__restrict__ flags)
 {
@@ -91,6 +92,7 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, g = lane >> 4;
+    constexpr int kWaves = NW;
     const int c = blockIdx.y;
     const int T = d.T, H = d.H, hop = d.hop;
     constexpr int W = 64 * K2;
@@ -112,9 +114,14 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
     float *ring = reinterpret_cast<float *>(wbase);
     const int PS = d.s_pstride, TP = d.s_tp;          // floats per frame row: 4 TP tap products, sum of squares, floor weight, padding
     float *rows = reinterpret_cast<float *>(wbase + (size_t)(RC + 1) * 1024);       // [T - 1 + 16][PS]
-    float *zquad = rows + (T - 1 + kTile) * PS;       // 8 floats: a zero quad, and a quad for stores that have no place
+    float *zquad = rows + (T - 1 + kTile) * PS;       // 8 HQ floats: HQ zero quads (what taps past timeRange read), HQ quads for stores that have no place
+    // Two quads of units at two waves a SIMD: 256 registers hold the basis, 48 registers of first-layer fragments and the
+    // loop's working set only if the constants that depend on the lane group alone wait in LDS (4 groups x 20 floats behind the
+    // zero quad) and are fetched where they are used -- otherwise 28 registers go to scratch.
+    constexpr bool kTbl = HQ == 2 && NW == 8;
+    float *gtab = zquad + 8 * HQ + 32 * g;
     {
-        const int nz = ((T - 1 + kTile) * PS + 8) / 4;
+        const int nz = ((T - 1 + kTile) * PS + 8 * HQ + 128) / 4;          // (+ the table of lane-group constants, where there is one)
         for (int i = lane; i < nz; i += 64) reinterpret_cast<floatx4 *>(rows)[i] = floatx4{0.f, 0.f, 0.f, 0.f};
     }
 
@@ -130,14 +137,22 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
                 as_[ks][m][p] = as_half8(reinterpret_cast<const uint32x4 *>(d.sfrag)[(((ks * 2 + 0) * 2 + m) * 2 + p) * 64 + lane]);
                 ad_[ks][m][p] = as_half8(reinterpret_cast<const uint32x4 *>(d.sfrag)[(((ks * 2 + 1) * 2 + m) * 2 + p) * 64 + lane]);
             }
-    half8 aft[3][2];
+    // (row tile 3 q + m... in table order [m][q]: tap 4 m + g, units 4 q .. 4 q + 3 for lane group g of its result)
+    half8 aft[3][HQ][2];
 #pragma unroll
     for (int m = 0; m < 3; m++)
 #pragma unroll
-        for (int p = 0; p < 2; p++) aft[m][p] = as_half8(reinterpret_cast<const uint32x4 *>(d.afrag_t)[(m * 2 + p) * 64 + lane]);
+        for (int q = 0; q < HQ; q++)
+#pragma unroll
+            for (int p = 0; p < 2; p++)
+                aft[m][q][p] = as_half8(reinterpret_cast<const uint32x4 *>(HQ == 1 ? d.afrag_t : d.afrag_w)[((m * HQ + q) * 2 + p) * 64 + lane]);
     float cre[8];                                     // w[0] cos(pi k W / N) 2^13 for this lane's bins 4 g + i, 16 + 4 g + i
 #pragma unroll
     for (int i = 0; i < 8; i++) cre[i] = d.slone[lane * 8 + i];
+    if (kTbl && n == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) gtab[i] = cre[i];
+    }
 
     const float *row = samples + (int64_t)c * stride;
     const __amdgpu_buffer_rsrc_t in_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(row), 0, (int)(s_eff * 4), 0x00020000);
@@ -172,13 +187,13 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
     for (int tt = 0; tt < 3; tt++) {
         const int t = g + 4 * tt;
         // (taps past timeRange: their products are 0 * column, which is NaN for a column with a NaN in it -- read zeros)
-        pv_p[tt] = t < T ? erow + t * PS + 4 * t : zquad;
-        sv_p[tt] = t < T ? erow + t * PS + 4 * TP : zquad;
+        pv_p[tt] = t < T ? erow + t * PS + 4 * HQ * t : zquad;
+        sv_p[tt] = t < T ? erow + t * PS + 4 * HQ * TP : zquad;
     }
     // tile m of the tap products holds tap 4 m + g of this frame: taps past TP have no place in the row
     float *pt_p[3];
 #pragma unroll
-    for (int m = 0; m < 3; m++) pt_p[m] = 4 * m + g < TP ? prow + 4 * (4 * m + g) : zquad + 4;
+    for (int m = 0; m < 3; m++) pt_p[m] = 4 * m + g < TP ? prow + 4 * HQ * (4 * m + g) : zquad + 4 * HQ;
 
     const float c_b1 = GEN ? (g < n_out ? d.b1[g] : 0.0f) : d.b1[0];
     float lean_oa = 0.0f, lean_og = 1.0f, lean_ob = 0.0f;
@@ -186,12 +201,33 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
         const int o = (GEN && g < n_out) ? g : 0;
         lean_oa = d.out_params[0]; lean_og = d.out_params[1 + o]; lean_ob = d.out_params[1 + n_out + o];
     }
-    const float b0g = g < H ? d.bias0[g] : 0.0f, w1g = g < H ? d.w1[g] : 0.0f;       // this lane group's hidden unit
-    float w1o[4];
+    // this lane group's hidden units: 4 q + g
+    float b0g[HQ], w1g[HQ], w1o[4][HQ], rvg[HQ];      // (rvg: (W0 o a) . 1, what the normalisers' offset meets)
 #pragma unroll
-    for (int o = 0; o < 4; o++) w1o[o] = (GEN && g < H && o < n_out) ? d.w1[o * H + g] : 0.0f;
+    for (int q = 0; q < HQ; q++) {
+        const int u = 4 * q + g;
+        rvg[q] = (GEN && u < H) ? d.rvec[u] : 0.0f;
+        b0g[q] = u < H ? d.bias0[u] : 0.0f;
+        w1g[q] = u < H ? d.w1[u] : 0.0f;
+#pragma unroll
+        for (int o = 0; o < 4; o++) w1o[o][q] = (GEN && u < H && o < n_out) ? d.w1[o * H + u] : 0.0f;
+    }
+    if (kTbl && n == 0) {
+#pragma unroll
+        for (int q = 0; q < HQ; q++) {
+            gtab[8 + q] = b0g[q];
+            gtab[8 + HQ + q] = w1g[q];
+            gtab[8 + 6 * HQ + q] = rvg[q];
+#pragma unroll
+            for (int o = 0; o < 4; o++) gtab[8 + 2 * HQ + o * HQ + q] = w1o[o][q];
+        }
+    }
     const bool multi = GEN && n_out > 1;
     const double thr_g = d.thresholds[(GEN && g < n_out) ? g : 0];
+    if (kTbl && n == 0) {                              // (the output stage's constants wait in the table too)
+        gtab[22] = c_b1; gtab[23] = lean_oa; gtab[24] = lean_og; gtab[25] = lean_ob;
+        *reinterpret_cast<double *>(gtab + 26) = thr_g;
+    }
     const bool counts = !GEN || n_out == 1 ? true : (g < n_out && (g == 0 || d.rule == 1));
     const int tf0 = GEN ? d.tf0 : 0, tf1 = GEN ? d.tf1 : 2, norm = GEN ? d.norm : 1;
     const int scaling = GEN ? d.scaling : 0;          // linear |X|, or ln / 20 log10 of it in front of the chain (SyllableDetector.swift:184-212)
@@ -201,7 +237,7 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
     for (int i = 0; i < 8; i++) binv[i] = (i < 4 ? 4 * g + i : 16 + 4 * g + (i - 4)) < d.F;
     const float kmag = pow2f(-13 - d.col_shift);
     const bool guard_on = d.fix.counters != nullptr;
-    const float guard_k = norm == 1 ? d.guard_r : d.guard_rel_r;
+    const float guard_k = norm == 1 ? d.guard_r : (norm == 0 ? d.guard_rel_r : d.guard_range_r);
 
     // ---- prologue: tile 0's samples
     issue_upto(need(0) < allowed(0) ? need(0) : allowed(0));
@@ -307,9 +343,20 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
         // the f16 hi + lo split of the column under the frame's own column exponent, the tap products of the first layer.
         // acc holds X 2^(se + 13); cval = |X| 2^(se - col_shift).
         float cval[8], mss = 0.0f;
+        float cre_l[8];
+        if (kTbl) {                                   // (the address passes through an opaque statement: the fetch stays in the loop)
+            const float *tp = gtab;
+            asm volatile("" : "+v"(tp));
+            const floatx4 c0 = *reinterpret_cast<const floatx4 *>(tp), c1 = *reinterpret_cast<const floatx4 *>(tp + 4);
+#pragma unroll
+            for (int i = 0; i < 4; i++) { cre_l[i] = c0[i]; cre_l[4 + i] = c1[i]; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; i++) cre_l[i] = cre[i];
+        }
 #pragma unroll
         for (int i = 0; i < 8; i++) {
-            const float re = fmaf(cre[i], xl, acc[i >> 2][i & 3]), im = acc[2 + (i >> 2)][i & 3];
+            const float re = fmaf(cre_l[i], xl, acc[i >> 2][i & 3]), im = acc[2 + (i >> 2)][i & 3];
             cval[i] = __builtin_amdgcn_sqrtf(fmaf(re, re, im * im)) * kmag;
         }
         if (GEN && scaling != 0) {
@@ -341,54 +388,120 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
             bh[j] = h; bl[j] = l;
         }
         const half8 vbh = as_half8(bh), vbl = as_half8(bl);
-        floatx4 pt[3];
+        floatx4 pt[3][HQ];
 #pragma unroll
-        for (int m = 0; m < 3; m++) {
-            pt[m] = mfma(aft[m][0], vbh, floatx4{0.f, 0.f, 0.f, 0.f});
-            pt[m] = mfma(aft[m][0], vbl, pt[m]);
-            pt[m] = mfma(aft[m][1], vbh, pt[m]);
-        }
+        for (int m = 0; m < 3; m++)
 #pragma unroll
-        for (int m = 0; m < 3; m++) *reinterpret_cast<floatx4 *>(pt_p[m]) = pt[m] * fs_ring;
+            for (int q = 0; q < HQ; q++) {
+                pt[m][q] = mfma(aft[m][q][0], vbh, floatx4{0.f, 0.f, 0.f, 0.f});
+                pt[m][q] = mfma(aft[m][q][0], vbl, pt[m][q]);
+                pt[m][q] = mfma(aft[m][q][1], vbh, pt[m][q]);
+            }
+#pragma unroll
+        for (int m = 0; m < 3; m++)
+#pragma unroll
+            for (int q = 0; q < HQ; q++) *reinterpret_cast<floatx4 *>(pt_p[m] + 4 * q) = pt[m][q] * fs_ring;
         {
             // the frame's sum of squares relative to the reference, and the weight of its grid floor there: 4^dsc (0 for a
             // silent frame: exact zeros; +inf for a frame the grid cannot hold)
-            const float sr = mss * pow2f(2 * dsc);
+            float st0 = mss * pow2f(2 * dsc), st1 = 0.0f;
+            if (GEN && norm == 2) {                   // Normalize (NeuralNet.swift:69-96): the frame's smallest and largest band bin
+                float mn = INFINITY, mx = -INFINITY;
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    mn = binv[i] ? fminf(mn, cval[i]) : mn;
+                    mx = binv[i] ? fmaxf(mx, cval[i]) : mx;
+                }
+                auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(mn), __float_as_uint(mn), false, false);
+                mn = fminf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+                r = __builtin_amdgcn_permlane32_swap(__float_as_uint(mn), __float_as_uint(mn), false, false);
+                mn = fminf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+                r = __builtin_amdgcn_permlane16_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+                mx = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+                r = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+                mx = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+                st0 = mn * pow2f(dsc);
+                st1 = mx * pow2f(dsc);
+            } else if (GEN && norm == 3) {            // NormalizeStd (:105-108): the frame's mean and sum of squared deviations
+                float sm = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 8; i++) sm += binv[i] ? cval[i] : 0.0f;
+                sm = xor32_sum(xor16_sum(sm));
+                const float mean = sm / (float)d.F;
+                float m2 = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const float dl = cval[i] - mean;
+                    m2 = binv[i] ? fmaf(dl, dl, m2) : m2;
+                }
+                m2 = xor32_sum(xor16_sum(m2));
+                st0 = mean * pow2f(dsc);
+                st1 = m2 * pow2f(2 * dsc);
+            }
             const float fw = far ? INFINITY : ((fst == 1 || (GEN && scaling != 0)) ? 0.0f : pow2f(2 * dsc));
-            if (g == 0) *reinterpret_cast<floatx2 *>(prow + 4 * TP) = floatx2{sr, fw};
+            if (g == 0) *reinterpret_cast<floatx4 *>(prow + 4 * HQ * TP) = floatx4{st0, fw, st1, 0.0f};
         }
 
         // ---- the tile's 16 evaluations: evaluation n ends on frame n of the tile; its taps are rows n .. n + T - 1.  Lane
         // group g takes taps g, g + 4, g + 8 and, after the halving butterfly, hidden unit g.
-        floatx4 zp;
-        float ssp, fwp;
+        floatx4 zp[HQ];
+        float ssp, fwp, st1p = 0.0f;                  // this lane group's share of the window's statistics (its taps g, g + 4, g + 8)
+        float sq0[3];                                 // (normalizestd: the frames' means once more)
         {
-            const floatx4 pv0 = *reinterpret_cast<const floatx4 *>(pv_p[0]), pv1 = *reinterpret_cast<const floatx4 *>(pv_p[1]),
-                          pv2 = *reinterpret_cast<const floatx4 *>(pv_p[2]);
-            const floatx2 s0 = *reinterpret_cast<const floatx2 *>(sv_p[0]), s1 = *reinterpret_cast<const floatx2 *>(sv_p[1]),
-                          s2 = *reinterpret_cast<const floatx2 *>(sv_p[2]);
-            zp = pv0 + pv1 + pv2;
-            if (GEN && norm == 0)                     // no normaliser: the guard wants the quietest column of the window
+            floatx4 pv[3][HQ];
+#pragma unroll
+            for (int tt = 0; tt < 3; tt++)
+#pragma unroll
+                for (int q = 0; q < HQ; q++) pv[tt][q] = *reinterpret_cast<const floatx4 *>(pv_p[tt] + 4 * q);
+            const floatx4 s0 = *reinterpret_cast<const floatx4 *>(sv_p[0]), s1 = *reinterpret_cast<const floatx4 *>(sv_p[1]),
+                          s2 = *reinterpret_cast<const floatx4 *>(sv_p[2]);
+            sq0[0] = s0[0]; sq0[1] = s1[0]; sq0[2] = s2[0];
+#pragma unroll
+            for (int q = 0; q < HQ; q++) zp[q] = pv[0][q] + pv[1][q] + pv[2][q];
+            if (GEN && (norm == 0 || norm == 2)) {    // no normaliser: the guard wants the quietest column of the window; Normalize: the window's minimum
                 ssp = fminf(fminf(g < T ? s0[0] : INFINITY, g + 4 < T ? s1[0] : INFINITY), g + 8 < T ? s2[0] : INFINITY);
-            else
+                st1p = fmaxf(fmaxf(g < T ? s0[2] : -INFINITY, g + 4 < T ? s1[2] : -INFINITY), g + 8 < T ? s2[2] : -INFINITY);
+            } else {                                  // sums (rows of taps past timeRange read zeros)
                 ssp = s0[0] + s1[0] + s2[0];
+                st1p = s0[2] + s1[2] + s2[2];
+            }
             fwp = fmaxf(fmaxf(s0[1], s1[1]), s2[1]);
         }
-        float zt, ssw, fww;
+        float zt[HQ], ssw, fww, st1w = 0.0f;
         {
-            auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(zp[0]), __float_as_uint(zp[1]), false, false);
-            const float s01 = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-            r = __builtin_amdgcn_permlane16_swap(__float_as_uint(zp[2]), __float_as_uint(zp[3]), false, false);
-            const float s23 = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-            r = __builtin_amdgcn_permlane32_swap(__float_as_uint(s01), __float_as_uint(s23), false, false);
-            zt = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-            if (GEN && norm == 0) {
-                r = __builtin_amdgcn_permlane16_swap(__float_as_uint(ssp), __float_as_uint(ssp), false, false);
+#pragma unroll
+            for (int q = 0; q < HQ; q++) {
+                auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(zp[q][0]), __float_as_uint(zp[q][1]), false, false);
+                const float s01 = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+                r = __builtin_amdgcn_permlane16_swap(__float_as_uint(zp[q][2]), __float_as_uint(zp[q][3]), false, false);
+                const float s23 = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+                r = __builtin_amdgcn_permlane32_swap(__float_as_uint(s01), __float_as_uint(s23), false, false);
+                zt[q] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+            }
+            auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(ssp), __float_as_uint(ssp), false, false);
+            if (GEN && (norm == 0 || norm == 2)) {
                 const float m = fminf(__uint_as_float(r[0]), __uint_as_float(r[1]));
                 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
                 ssw = fminf(__uint_as_float(r[0]), __uint_as_float(r[1]));
             } else {
-                ssw = xor32_sum(xor16_sum(ssp));
+                ssw = xor32_sum(__uint_as_float(r[0]) + __uint_as_float(r[1]));
+            }
+            if (GEN && norm == 2) {                   // the window's maximum
+                r = __builtin_amdgcn_permlane16_swap(__float_as_uint(st1p), __float_as_uint(st1p), false, false);
+                const float m = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+                r = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+                st1w = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+            } else if (GEN && norm == 3) {
+                // mean and M2 of the window from its frames' (equal counts F): M2 = sum M2_t + F sum (mean_t - mean)^2
+                const float mean = ssw / (float)T;
+                float dv = 0.0f;
+#pragma unroll
+                for (int tt = 0; tt < 3; tt++) {
+                    const float dl = sq0[tt] - mean;
+                    dv = g + 4 * tt < T ? fmaf(dl, dl, dv) : dv;
+                }
+                st1w = xor32_sum(xor16_sum(st1p)) + (float)d.F * xor32_sum(xor16_sum(dv));
+                ssw = mean;
             }
             r = __builtin_amdgcn_permlane16_swap(__float_as_uint(fwp), __float_as_uint(fwp), false, false);
             const float m = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
@@ -397,18 +510,58 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
         }
         // the rest of the network (NeuralNet.swift:47-59 L2Normalize on the folded first layer, :189-194 TanSig, :366-377 second
         // layer, :137-142 / :175-180 reverse output map; SyllableDetector.swift:27-31 threshold)
-        float yv;
+        float yv, gstat = ssw;                       // (gstat: what the guard holds against the grid's floor)
         bool hit;
         {
             const int ush = (GEN && scaling != 0) ? 0 : d.col_shift - se_ref;
             const float alpha0 = d.w_unscale * pow2f(ush < -120 ? -120 : (ush > 120 ? 120 : ush));
-            const float alpha = norm == 1 ? d.w_unscale * __builtin_amdgcn_rsqf(ssw) : alpha0;
-            const float act = transfer_fn(tf0, fmaf(alpha, zt, b0g));
+            float alpha = norm == 1 ? d.w_unscale * __builtin_amdgcn_rsqf(ssw) : alpha0, beta = 0.0f;
+            if (GEN && norm == 2) {                   // Normalize: 2 (v - mn) / (mx - mn) - 1, all -1 when mx == mn
+                const float range = st1w - ssw;
+                gstat = range;
+                if (range == 0.0f) { alpha = 0.0f; beta = -1.0f; }
+                else { alpha = d.w_unscale * 2.0f / range; beta = (0.0f - ssw - st1w) / range; }
+            } else if (GEN && norm == 3) {            // NormalizeStd: (v - mean) / sigma, population sigma
+                const float sdv = sqrtf(st1w / (float)d.I);
+                gstat = sdv;
+                alpha = d.w_unscale / sdv;
+                beta = -ssw / sdv;
+            }
+            float b0_l[HQ], w1_l[HQ], w1o_l[4][HQ], rv_l[HQ];
+            if (kTbl) {
+                const float *tp = gtab + 8;
+                asm volatile("" : "+v"(tp));
+#pragma unroll
+                for (int q = 0; q < HQ; q++) {
+                    b0_l[q] = tp[q];
+                    w1_l[q] = tp[HQ + q];
+                    rv_l[q] = norm >= 2 ? tp[6 * HQ + q] : 0.0f;
+#pragma unroll
+                    for (int o = 0; o < 4; o++) w1o_l[o][q] = multi ? tp[2 * HQ + o * HQ + q] : 0.0f;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < HQ; q++) {
+                    b0_l[q] = b0g[q];
+                    w1_l[q] = w1g[q];
+                    rv_l[q] = rvg[q];
+#pragma unroll
+                    for (int o = 0; o < 4; o++) w1o_l[o][q] = w1o[o][q];
+                }
+            }
+            float act[HQ];
+#pragma unroll
+            for (int q = 0; q < HQ; q++)
+                act[q] = transfer_fn(tf0, (GEN && norm >= 2) ? fmaf(alpha, zt[q], fmaf(beta, rv_l[q], b0_l[q])) : fmaf(alpha, zt[q], b0_l[q]));
             float ysum;
             if (multi) {
                 float yp[4];
 #pragma unroll
-                for (int o = 0; o < 4; o++) yp[o] = w1o[o] * act;
+                for (int o = 0; o < 4; o++) {
+                    yp[o] = w1o_l[o][0] * act[0];
+#pragma unroll
+                    for (int q = 1; q < HQ; q++) yp[o] = fmaf(w1o_l[o][q], act[q], yp[o]);
+                }
                 auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(yp[0]), __float_as_uint(yp[1]), false, false);
                 const float a01 = __uint_as_float(r[0]) + __uint_as_float(r[1]);
                 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(yp[2]), __float_as_uint(yp[3]), false, false);
@@ -416,12 +569,25 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
                 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a01), __float_as_uint(a23), false, false);
                 ysum = __uint_as_float(r[0]) + __uint_as_float(r[1]);
             } else {
-                ysum = xor32_sum(xor16_sum(w1g * act));
+                float yq = w1_l[0] * act[0];
+#pragma unroll
+                for (int q = 1; q < HQ; q++) yq = fmaf(w1_l[q], act[q], yq);
+                ysum = xor32_sum(xor16_sum(yq));
             }
-            float y = transfer_fn(tf1, ysum + c_b1);
-            y = (y - lean_oa) / lean_og + lean_ob;
+            float ob1 = c_b1, ooa = lean_oa, oog = lean_og, oob = lean_ob;
+            double othr = thr_g;
+            if (kTbl) {
+                const float *tp = gtab + 22;
+                asm volatile("" : "+v"(tp));
+                const floatx4 ov = *reinterpret_cast<const floatx4 *>(tp - 2);      // [.., .., b1, oa]
+                ob1 = ov[2]; ooa = ov[3];
+                oog = tp[2]; oob = tp[3];
+                othr = *reinterpret_cast<const double *>(tp + 4);
+            }
+            float y = transfer_fn(tf1, ysum + ob1);
+            y = (y - ooa) / oog + oob;
             yv = y;
-            hit = counts && (double)y >= thr_g;
+            hit = counts && (double)y >= othr;
             if (multi) {
                 unsigned hb = hit ? 1u : 0u;
                 auto r = __builtin_amdgcn_permlane16_swap(hb, hb, false, false);
@@ -441,8 +607,8 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
         // ---- the precision guard (kernels.hpp, FixItem): the window statistic against the loudest grid floor among its frames
         if (guard_on) {
             // (all frames silent: exact zeros, the fused result is the reference's 0/0; a frame the grid cannot hold: +inf, nothing passes)
-            bool bad = vld && !(fww == 0.0f) && !(ssw >= guard_k * fww);
-            if (GEN && norm != 1 && fww != INFINITY && fww != 0.0f) {
+            bool bad = vld && !(fww == 0.0f) && !(gstat >= guard_k * ((GEN && norm >= 2) ? sqrtf(fww) : fww));
+            if (GEN && norm == 0 && fww != INFINITY && fww != 0.0f) {
                 // no normaliser: loud enough for the floor not to matter?  (the floor in true units against the network's sensitivity)
                 // fww = 4^(se_ref - se_min): se_min = se_ref - log2(fww) / 2
                 const int lg = (int)((__float_as_uint(fww) >> 23) & 0xffu) - 127;
@@ -462,31 +628,36 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
         {
             const floatx4 *src = reinterpret_cast<const floatx4 *>(rows + kTile * PS);
             floatx4 *dst = reinterpret_cast<floatx4 *>(rows);
-            const int nq = (T - 1) * PS / 4;
-            floatx4 h0 = {0.f, 0.f, 0.f, 0.f}, h1 = h0, h2 = h0;
-            if (lane < nq) h0 = src[lane];
-            if (lane + 64 < nq) h1 = src[lane + 64];
-            if (lane + 128 < nq) h2 = src[lane + 128];
-            if (lane < nq) dst[lane] = h0;
-            if (lane + 64 < nq) dst[lane + 64] = h1;
-            if (lane + 128 < nq) dst[lane + 128] = h2;
+            const int nq = (T - 1) * PS / 4;               // (source rows 16 .. and destination rows 0 .. T - 2 never overlap: T - 1 < 16)
+            if (HQ == 1) {                                 // at most 143 quads
+                floatx4 h0 = {0.f, 0.f, 0.f, 0.f}, h1 = h0, h2 = h0;
+                if (lane < nq) h0 = src[lane];
+                if (lane + 64 < nq) h1 = src[lane + 64];
+                if (lane + 128 < nq) h2 = src[lane + 128];
+                if (lane < nq) dst[lane] = h0;
+                if (lane + 64 < nq) dst[lane + 64] = h1;
+                if (lane + 128 < nq) dst[lane + 128] = h2;
+            } else {
+                for (int i = lane; i < nq; i += 64) dst[i] = src[i];
+            }
         }
         fo += (unsigned)(kTile * hop);
         fo = fo >= (unsigned)R ? fo - (unsigned)R : fo;
     }
 }
 
-template <int K2, bool GEN>
+template <int K2, bool GEN, int HQ, int NW>
 hipError_t launch_one(const FusedDesc &d, const float *samples, int64_t stride, int C, int64_t s_eff, int64_t E,
                       float *outputs, uint8_t *flags, hipStream_t stream)
 {
-    auto kern = fused_s_kernel<K2, GEN>;
+    auto kern = fused_s_kernel<K2, GEN, HQ, NW>;
+    constexpr int kWaves = NW;
     const int lds = d.s_lds_wave * kWaves;
     hipError_t st = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (st != hipSuccess) return st;
     const int64_t segs = (E + d.s_seg_evals - 1) / d.s_seg_evals;         // wave segments per channel
     dim3 grid((unsigned)((segs + kWaves - 1) / kWaves), (unsigned)C);
-    hipLaunchKernelGGL(kern, grid, dim3(kBlock), (size_t)lds, stream, d, samples, stride, s_eff, E, outputs, flags);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * kWaves), (size_t)lds, stream, d, samples, stride, s_eff, E, outputs, flags);
     return hipGetLastError();
 }
 
@@ -499,7 +670,7 @@ bool fused_s_applicable(const FusedDesc &d)
 {
     // (log / dB columns too: every frame is transformed at its own scale, so a bin's error is relative to its frame, as an fp32
     // FFT's is -- what the logarithm makes of that is the same for both)
-    const bool cls = (d.norm == 0 || d.norm == 1) && d.n_layers == 2 && d.n_out >= 1 && d.n_out <= 4 && d.H <= 4 && d.n_out_fns <= 1;
+    const bool cls = d.norm >= 0 && d.norm <= 3 && d.n_layers == 2 && d.n_out >= 1 && d.n_out <= 4 && d.H <= 16 && d.n_out_fns <= 1;
     return d.s_ok && d.T <= 12 && cls;
 }
 
@@ -514,8 +685,12 @@ hipError_t launch_fused_s(const FusedDesc &d, const float *samples, int64_t stri
     const bool exact = d.norm == 1 && d.scaling == 0 && d.tf0 == 0 /* TanSig */ && d.tf1 == 2 /* PureLin */ && d.n_out == 1;
 #define SD_S_GO(K2_)                                                                                                  \
     if (d.W == 64 * K2_) {                                                                                            \
-        if (exact) return launch_one<K2_, false>(d, samples, stride, C, s_eff, E, outputs, flags, stream);            \
-        return launch_one<K2_, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);                        \
+        if (d.H > 12) return launch_one<K2_, true, 4, 4>(d, samples, stride, C, s_eff, E, outputs, flags, stream);    \
+        if (d.H > 8) return launch_one<K2_, true, 3, 4>(d, samples, stride, C, s_eff, E, outputs, flags, stream);     \
+        if (d.H > 4 && d.s_waves == 8) return launch_one<K2_, true, 2, 8>(d, samples, stride, C, s_eff, E, outputs, flags, stream); \
+        if (d.H > 4) return launch_one<K2_, true, 2, 4>(d, samples, stride, C, s_eff, E, outputs, flags, stream);     \
+        if (exact) return launch_one<K2_, false, 1, 8>(d, samples, stride, C, s_eff, E, outputs, flags, stream);      \
+        return launch_one<K2_, true, 1, 8>(d, samples, stride, C, s_eff, E, outputs, flags, stream);                  \
     }
     SD_S_GO(4) SD_S_GO(2) SD_S_GO(1) SD_S_GO(3)
 #undef SD_S_GO

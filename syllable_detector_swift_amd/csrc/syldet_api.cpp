@@ -384,6 +384,7 @@ int upload_plan(syldet *h, FusedPlan &p, DeviceBuffer &buf)
     const size_t o_b1 = put(p.b1.data(), p.b1.size() * 4), o_op = put(p.out_params.data(), p.out_params.size() * 4);
     const size_t o_wt = put(p.afrag_t.data(), p.afrag_t.size() * 2);
     const size_t o_sf = put(p.sfrag.data(), p.sfrag.size() * 2), o_sl = put(p.slone.data(), p.slone.size() * 4);
+    const size_t o_ww = put(p.afrag_w.data(), p.afrag_w.size() * 2);
     if (int st = buf.reserve(blob.size())) return st;
     SYLDET_HIP(hipMemcpy(buf.ptr, blob.data(), blob.size(), hipMemcpyHostToDevice));
     unsigned char *base = (unsigned char *)buf.ptr;
@@ -393,6 +394,7 @@ int upload_plan(syldet *h, FusedPlan &p, DeviceBuffer &buf)
     d.afrag_t = (const uint4 *)(base + o_wt);
     d.sfrag = (const uint4 *)(base + o_sf);
     d.slone = (const float *)(base + o_sl);
+    d.afrag_w = (const uint4 *)(base + o_ww);
     d.koff = (const int *)(base + o_k);
     d.bias0 = (const float *)(base + o_b);
     d.rvec = (const float *)(base + o_r);

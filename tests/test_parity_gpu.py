@@ -599,15 +599,19 @@ def test_both_fused_kernels_against_the_oracle_and_each_other(oracle_lib, monkey
         assert np.abs(got["fused_kernel"][both] - got[other][both]).max() <= 5e-6
 
 
-def test_register_resident_kernel_is_only_taken_where_it_is_instantiated(oracle_lib):
-    """A wider hidden layer, a normaliser other than l2normalize: kernels_fused.hip's kernel."""
+def test_older_fused_kernels_keep_what_the_fold_kernel_does_not_take(oracle_lib, monkeypatch):
+    """With the symmetric-fold kernel switched off, a normaliser other than l2normalize and a wider hidden layer run on
+    kernels_fused.hip's kernel (with it on, both stay on it: the tests around this one); a window that is not a multiple of
+    64 samples runs there either way."""
     torch = _torch()
     base = nets.from_npz()
     rng = np.random.default_rng(5)
     x = synth.channel(30000, 3)[None].astype(np.float32)
     xd = torch.from_numpy(x).cuda()
-    for cfg in (nets.variant(base, net=nets.random_net(rng, 290, (4,), 1, in_fns=("normalizestd", "mapstd"))),
-                nets.variant(base, net=nets.random_net(rng, 290, (8,), 1))):
+    for nofold, cfg in ((True, nets.variant(base, net=nets.random_net(rng, 290, (4,), 1, in_fns=("normalizestd", "mapstd")))),
+                        (True, nets.variant(base, net=nets.random_net(rng, 290, (8,), 1))),
+                        (False, nets.variant(base, windowLength=200, windowOverlap=100, net=nets.random_net(rng, 290, (6,), 1)))):
+        util.select_fused(monkeypatch, "fused_r_kernel" if nofold else "fused_s_kernel")
         with sd.SyllableDetector(cfg, channels=1, engine=_abi.ENGINE_FUSED) as det:
             det.profile(True)
             out, fl = det.run(xd)
@@ -615,6 +619,75 @@ def test_register_resident_kernel_is_only_taken_where_it_is_instantiated(oracle_
             assert [nm for nm, _ in det.lastTimings()] == ["fused_kernel"]
         _, _, w64 = util.oracle_for(cfg).run(x[0], po.F64)
         util.assert_outputs_close(out.cpu().numpy()[0], w64)
+
+
+@pytest.mark.parametrize("chain", [("normalize",), ("normalize", "mapminmax"), ("normalizestd",), ("normalizestd", "mapstd")])
+@pytest.mark.parametrize("H", [3, 8])
+def test_normalize_and_normalizestd_chains_on_the_fold_kernel(oracle_lib, chain, H):
+    """NeuralNet.swift:63-109: Normalize (window minimum and maximum) and NormalizeStd (window mean and population sigma)
+    in front of the affine maps, from per-frame statistics kept next to the tap products.  A level step inside the
+    recording (frames are scaled one by one), a stretch of silence (Normalize of a constant window: all -1, :74-77;
+    NormalizeStd: 0/0)."""
+    torch = _torch()
+    rng = np.random.default_rng(300 + H)
+    base = util.sample_net()
+    cfg = nets.variant(base, net=nets.random_net(rng, 290, (H,), 1, in_fns=chain, out_fns=("mapminmax",)), thresholds=[0.2])
+    S = 132 * 400 + 300
+    x = np.stack([synth.syllable_channel(S, util.template(), seed=9), synth.channel(S, 2)]).astype(np.float32)
+    x[1, S // 3:] *= np.float32(0.01)
+    x[0, 20000:20000 + 12 * 132 + 256] = 0.0
+    with sd.SyllableDetector(cfg, channels=2) as det:
+        det.profile(True)
+        out, fl = det.run(torch.from_numpy(x).cuda())
+        torch.cuda.synchronize()
+        assert [nm for nm, _ in det.lastTimings()] == ["fused_s_kernel"]
+        out, fl = out.cpu().numpy(), fl.cpu().numpy()
+    o = util.oracle_for(cfg)
+    for c in range(2):
+        w32, _, w64 = o.run(x[c], po.F64, cfg.rule)
+        ok = np.isfinite(w64).all(axis=1)
+        assert (np.isfinite(out[c]).all(axis=1) == ok).all()
+        own = float((np.abs(w32[ok] - w64[ok]) / np.maximum(1.0, np.abs(w64[ok]))).max())
+        tol = max(util.TOL, 4.0 * own)
+        util.assert_outputs_close(out[c][ok], w64[ok], tol)
+        util.assert_flags_exact(fl[c][ok], w64[ok], cfg.thresholds, cfg.rule, tol)
+
+
+@pytest.mark.parametrize("H,n_out,T,hop,chain,tf", [(8, 1, 10, 132, ("l2normalize", "mapminmax"), ("TanSig", "PureLin")), (5, 2, 7, 100, ("l2normalize",), ("LogSig", "PureLin")),
+                                                    (12, 1, 12, 132, ("l2normalize", "mapstd"), ("TanSig", "PureLin")), (16, 4, 10, 64, (), ("TanSig", "TanSig")),
+                                                    (9, 3, 4, 140, ("mapminmax",), ("SatLin", "PureLin")), (16, 1, 1, 132, ("l2normalize", "mapminmax"), ("TanSig", "PureLin"))])
+def test_wider_hidden_layers_on_the_fold_kernel(oracle_lib, H, n_out, T, hop, chain, tf):
+    """5 .. 16 hidden units on kernels_fused_s.hip: the first layer's rows multiply (one row tile per tap group and quad of
+    units), a workgroup is 4 waves with one per SIMD instead of 8 with two.  Values, flags under both rules, a level step, a
+    stretch of silence (0/0 -> NaN in l2normalize, as in the reference), planted syllables."""
+    torch = _torch()
+    rng = np.random.default_rng(1000 * H + T)
+    base = util.sample_net()
+    net = nets.random_net(rng, 29 * T, (H,), n_out, transfer=tf, in_fns=chain, out_fns=("mapminmax",) if H % 2 == 0 else ())
+    cfg = nets.variant(base, net=net, timeRange=T, thresholds=[float(t) for t in rng.uniform(-0.2, 0.3, n_out)], windowOverlap=256 - hop, rule=H % 2)
+    S = 16 * hop * 9 + 777
+    x = np.stack([synth.syllable_channel(S, util.template(), seed=4 + c, hop=hop) for c in range(2)]).astype(np.float32)
+    x[1, S // 2:] *= np.float32(0.004)
+    x[0, 5000:5000 + 3 * 256] = 0.0
+    with sd.SyllableDetector(cfg, channels=2) as det:
+        det.profile(True)
+        out, fl = det.run(torch.from_numpy(x).cuda())
+        torch.cuda.synchronize()
+        assert [nm for nm, _ in det.lastTimings()] == ["fused_s_kernel"]
+        out, fl = out.cpu().numpy(), fl.cpu().numpy()
+    o = util.oracle_for(cfg)
+    for c in range(2):
+        w32, _, w64 = o.run(x[c], po.F64, cfg.rule)
+        ok = np.isfinite(w64).all(axis=1)
+        assert (np.isfinite(out[c]).all(axis=1) == ok).all()
+        own = float((np.abs(w32[ok] - w64[ok]) / np.maximum(1.0, np.abs(w64[ok]))).max())
+        tol = max(util.TOL, 4.0 * own)
+        if "l2normalize" not in chain:                  # (no normaliser: the bar follows the level of the columns, as in the sweeps)
+            cols = o.spectrogram(x[c], po.F64)
+            cmax = np.array([cols[e:e + T].max() for e in range(w64.shape[0])])
+            tol = np.maximum(tol, util.TOL * cmax)[ok]
+        util.assert_outputs_close(out[c][ok], w64[ok], tol)
+        util.assert_flags_exact(fl[c][ok], w64[ok], cfg.thresholds, cfg.rule, tol)
 
 
 @pytest.mark.parametrize("N,lo,hi,T,H,scaling", [(1024, 2000.0, 7000.0, 10, 4, "linear"), (512, 1000.0, 6150.0, 8, 3, "linear"),
