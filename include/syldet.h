@@ -26,7 +26,10 @@
  *     TPCircularBuffer.h:14 guarantees in the reference (append never locks; it allocates
  *     once, on a channel's first samples); the host-pointer batch calls and the streaming
  *     consumers of one handle serialise on its staging buffers; the *_device batch calls are
- *     not re-entrant on one handle; distinct handles are independent.
+ *     not re-entrant on one handle, and two of them must not be in flight at once on different
+ *     streams either (a handle owns one scratch set and one work list of the precision guard:
+ *     enqueue a handle's calls on one stream, or use a handle per stream); distinct handles are
+ *     independent.
  *   - there is NO CPU fallback: without a gfx950 device create fails with
  *     SYLDET_ERR_NO_DEVICE.
  */

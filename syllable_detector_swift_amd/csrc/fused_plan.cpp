@@ -121,7 +121,7 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
     const int hop = g.hop;
     const int nsmp = (kFusedTileFrames - 1) * hop + KS * 32;    // samples one pass's frames read
     const int nload = (nsmp / 4 + kFusedBlock - 1) / kFusedBlock;
-    if (nload > kFusedMaxLoads) return no("hop too large for the staging registers");
+    const bool classic_hop_ok = nload <= kFusedMaxLoads;   // (else only the symmetric-fold kernel, with its own ring geometry, may take the shape)
     // LDS bank spreading: a lane reads 8 consecutive f16 samples of its frame with two ds_read_b64; the 16
     // frames of a tile are hop/2 dwords apart, which spreads over the 64 banks unless hop is a multiple of 16
     // (hop = 128: every frame on the same bank).  Then 4 halves of padding follow every hop staged samples;
@@ -150,7 +150,7 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
     d.lds_red = take(64);
     d.lds_cst = take((32 + kMaxFns * 33) * 4);       // thresholds + output maps (kCst* in kernels_fused.hip)
     d.lds_total = off;
-    d.classic_ok = off <= 160 * 1024 ? 1 : 0;        // (the register-resident-basis kernel has its own, smaller layout: decided below)
+    d.classic_ok = (off <= 160 * 1024 && classic_hop_ok) ? 1 : 0;        // (the register-resident-basis kernel has its own, smaller layout: decided below)
     {   // the register-resident-basis kernel's own pass geometry and LDS layout
         const int rn = (kFusedRTileFrames - 1) * hop + KS * 32;
         const int rl = (rn / 4 + kFusedRBlock - 1) / kFusedRBlock;
@@ -423,7 +423,7 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
         d.guard_spect = sq(std::sqrt((double)F) * phi_r / 1e-6);
         d.guard_se_abs_s = (int)std::max(-200.0, std::min(200.0, std::ceil(std::log2(phi_r / 1e-6) + (double)d.col_shift)));
     }
-    if (!d.classic_ok && !fused_r_applicable(d) && !fused_s_applicable(d)) return no("LDS budget exceeded");
+    if (!d.classic_ok && !fused_r_applicable(d) && !fused_s_applicable(d)) return no(classic_hop_ok ? "LDS budget exceeded" : "hop too large for the staging registers / the sample ring");
     p.koff.resize((size_t)KS * 4);
     for (int ks = 0; ks < KS; ks++)
         for (int h = 0; h < 4; h++) {
@@ -460,7 +460,9 @@ bool make_mlpx_plan(const syldet_config_t &c, const syldet_geometry_t &g, MlpxPl
         }
     }
     if (T > 12) return no("timeRange above 12");
-    const int KB = F <= 32 ? 1 : (F <= 64 ? 2 : 4);
+    // (1024-point frames: four blocks whatever the band, which is what the one-launch kernel of kernels_fft1k.hip is
+    // instantiated for -- a narrow band then pays a few idle MFMAs instead of a second launch and the columns' trip through HBM)
+    const int KB = (c.fourier_length == 1024 && c.window_length == 1024 && F % 4 == 0) ? 4 : (F <= 32 ? 1 : (F <= 64 ? 2 : 4));
     MlpxDesc &d = p.desc;
     d.F = F; d.T = T; d.KB = KB; d.H = H; d.rule = c.rule; d.scaling = c.scaling;
     d.col_stride = 32 * KB + 8;                      // 16-byte aligned rows that spread 16 consecutive rows over all banks

@@ -437,8 +437,11 @@ int prepare_fix(syldet *h, int C, int64_t units, int64_t segments, hipStream_t s
 {
     out = FixList{nullptr, nullptr, 0};
     if (!h->has_fix || h->sw.no_guard) return SYLDET_OK;
-    const uint64_t cap = (uint64_t)C * (uint64_t)((units + 15) / 16 + 8 * segments + 16);
-    if (cap > 0x7fffffffull) return SYLDET_OK;              // (rows this long take the generic engine anyway)
+    // (a list for every tile of every segment cannot overflow; past 2^26 items -- a gigabyte of list, batches of 10^9
+    // evaluations -- it is bounded instead, and a kernel that finds it full raises the sticky overflow flag that
+    // syldet_fixup_stats reports: the guard is never silently off)
+    uint64_t cap = (uint64_t)C * (uint64_t)((units + 15) / 16 + 8 * segments + 16);
+    if (cap > (1ull << 26)) cap = 1ull << 26;
     const size_t bytes = 16 + (size_t)cap * sizeof(FixItem);
     if (bytes > h->d_fix.cap) {
         if (int st = h->d_fix.reserve(bytes + bytes / 4)) return st;
@@ -485,6 +488,7 @@ int build_dft_plan(syldet *h)
     syldet_geometry_t sg = h->geom;
     sg.inputs = F; sg.outputs = 1;
     if (!make_fused_plan(sc, sg, h->dft)) return SYLDET_OK;          // not applicable: the generic FFT stays
+    if (!h->dft.desc.classic_ok) return SYLDET_OK;                   // (the spectrogram instantiation is the 8-wave kernel's: its shapes only)
     if (int st = upload_plan(h, h->dft, h->d_dft)) return st;
     h->dft.desc.spect_power = c.spectrum == SYLDET_SPECTRUM_MAGNITUDE ? 1 : 0;
     h->has_dft = true;

@@ -35,3 +35,19 @@ def oracle_lib():
     import pyoracle
     pyoracle.build()
     return pyoracle.lib()
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """The random sweeps' bookkeeping (tests/util.py::sweep_record) as a JSON summary: how many draws needed a bar wider than
+    the flat one and why, the worst error ratios -- the evidence behind "N draws green" (copied into profiles/ per round)."""
+    try:
+        import json
+        import util
+        if not util.SWEEP_LOG:
+            return
+        out = os.environ.get("SYLDET_SWEEP_SUMMARY", os.path.join(ROOT, "gpurun_out", "sweep_summary.json"))
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        json.dump({"exitstatus": int(exitstatus), "draws_env": os.environ.get("SYLDET_FUZZ_DRAWS", "default"),
+                   "summary": util.sweep_summary()}, open(out, "w"), indent=1)
+    except Exception as e:                                        # bookkeeping must never fail a run
+        print("sweep summary not written:", e)

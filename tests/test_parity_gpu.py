@@ -219,7 +219,8 @@ def test_several_outputs_on_the_register_resident_kernel(oracle_lib, monkeypatch
         det.profile(True)
         out, fl = det.run(torch.from_numpy(x).cuda())
         torch.cuda.synchronize()
-        assert [nm for nm, _ in det.lastTimings()] == [kernel]
+        # (hops that are multiples of 64 stay on the register-resident-basis kernel for long windows: its padded staging)
+        assert [nm for nm, _ in det.lastTimings()] == ["fused_r_kernel" if hop % 64 == 0 else kernel]
         out, fl = out.cpu().numpy(), fl.cpu().numpy()
     fired = 0
     for c in range(2):

@@ -177,3 +177,33 @@ def select_fused(monkeypatch, kernel):
         monkeypatch.setenv("SYLDET_FUSED_CLASSIC", "1")
     else:
         assert kernel == "fused_s_kernel"
+
+
+# ---- sweep bookkeeping: what every random draw needed, written as JSON when the session ends (tests/conftest.py) ---------
+SWEEP_LOG = []
+
+
+def sweep_record(sweep, seed, kernel, err, own, flat_bar, bar_used, reason):
+    """One (draw, channel) of a random sweep: the worst output error relative to max(1, |anchor|), the fp32 port's own
+    distance from the anchor, the flat bar (1e-5 or 4x own; 1e-4 or 30x own for log / dB), the worst ratio of error to the
+    bar that was applied, and why a wider bar was applied, if one was ("" | "kappa" | "column level" | "log condition")."""
+    SWEEP_LOG.append({"sweep": sweep, "seed": int(seed), "kernel": kernel, "err": float(err), "own": float(own),
+                      "flat_bar": float(flat_bar), "err_over_bar": float(bar_used), "wider_bar": reason})
+
+
+def sweep_summary():
+    out = {}
+    for r in SWEEP_LOG:
+        d = out.setdefault(r["sweep"], {"records": 0, "needed_wider_bar": {}, "worst_err": 0.0, "worst_err_over_own": 0.0,
+                                         "worst_err_over_bar": 0.0, "worst_err_over_flat_bar": 0.0, "kernels": {}})
+        d["records"] += 1
+        d["kernels"][r["kernel"]] = d["kernels"].get(r["kernel"], 0) + 1
+        d["worst_err"] = max(d["worst_err"], r["err"])
+        if r["own"] > 0:
+            d["worst_err_over_own"] = max(d["worst_err_over_own"], r["err"] / r["own"])
+        d["worst_err_over_bar"] = max(d["worst_err_over_bar"], r["err_over_bar"])
+        d["worst_err_over_flat_bar"] = max(d["worst_err_over_flat_bar"], r["err"] / r["flat_bar"])
+        if r["err"] > r["flat_bar"]:
+            k = r["wider_bar"] or "none (failed)"
+            d["needed_wider_bar"][k] = d["needed_wider_bar"].get(k, 0) + 1
+    return out
