@@ -519,6 +519,82 @@ bool make_mlpx_plan(const syldet_config_t &c, const syldet_geometry_t &g, MlpxPl
     return true;
 }
 
+bool make_bdft_plan(const syldet_config_t &c, const syldet_geometry_t &g, const MlpxPlan &mx, BdftPlan &p)
+{
+    p = BdftPlan();
+    const int N = c.fourier_length, W = c.window_length, hop = g.hop, F = g.bins, T = c.time_range, I = g.inputs;
+    // the matrix-core network stage's class with 128-bin columns, |X| columns, linear scaling
+    if (!mx.ok || mx.desc.KB != 4 || c.scaling != SYLDET_SCALING_LINEAR || c.spectrum == SYLDET_SPECTRUM_MAGNITUDE) return false;
+    // frames of four whole blocks, no gap, no zero padding; 2 or 4 k-steps of 32 folded positions a block
+    if (W != N || g.gap != 0 || 4 * hop != N || (hop != 128 && hop != 256)) return false;
+    // the window as a short cosine sum (WindowType.createWindow, CircularShortTimeFourierTransform.swift:19-28; Blackman's five taps
+    // along the bins are not built)
+    double a0, a1;
+    if (c.window == SYLDET_WINDOW_HAMMING) { a0 = 0.54; a1 = -0.46; }
+    else if (c.window == SYLDET_WINDOW_HANNING) { a0 = 0.5; a1 = -0.5; }
+    else if (c.window == SYLDET_WINDOW_NONE) { a0 = 1.0; a1 = 0.0; }
+    else return false;
+    if (g.f0 < 1 || T > 12) return false;
+    const int kb0 = (g.f0 - 1) / 4 * 4;                          // the bin under the band is a neighbour of its first one
+    if (g.f0 + F + 1 > kb0 + 128 || kb0 + 128 > N / 2) return false;
+    const int KS = hop / 64, c0 = hop / 2;
+    const double two_pi = 6.283185307179586476925286766559, theta = two_pi * (double)c0 / (double)N;
+    BdftDesc &d = p.desc;
+    d.hop = hop; d.kb0 = kb0; d.f0 = g.f0;
+    d.a0 = (float)a0; d.a1c = (float)(0.5 * a1 * std::cos(theta)); d.a1s = (float)(0.5 * a1 * std::sin(theta));
+    // A operands, lane l: row l & 15 of its tile (bin kb0 + 16 w + row), k = 8 (l >> 4) + j -> folded position m = 32 ks + k.
+    // cosine rows: cos(2 pi k m / N), half of it at m = 0 (s[0] = 2 x[c]); sine rows: -sin(2 pi k m / N), slot m = 0 takes the
+    // block's first sample: +sin(theta k).  Scaled by 2^13.
+    p.basis.assign((size_t)8 * 2 * KS * 2 * 64 * 8, 0);
+    for (int w = 0; w < 8; w++)
+        for (int which = 0; which < 2; which++)
+            for (int ks = 0; ks < KS; ks++)
+                for (int l = 0; l < 64; l++)
+                    for (int j = 0; j < 8; j++) {
+                        const int k = kb0 + 16 * w + (l & 15), m = 32 * ks + 8 * (l >> 4) + j;
+                        const int km = (int)(((int64_t)k * m) % N), kc = (int)(((int64_t)k * c0) % N);
+                        const double ang = two_pi * (double)km / (double)N;
+                        double v;
+                        if (which == 0) v = std::cos(ang) * (m == 0 ? 0.5 : 1.0);
+                        else v = m == 0 ? std::sin(two_pi * (double)kc / (double)N) : -std::sin(ang);
+                        v *= 8192.0;
+                        uint16_t hi, lo;
+                        split_half(v, hi, lo);
+                        const size_t base = (((((size_t)w * 2 + which) * KS + ks) * 2) * 64 + l) * 8 + j;
+                        p.basis[base] = hi;
+                        p.basis[base + 64 * 8] = lo;
+                    }
+    p.cre.assign((size_t)8 * 64 * 4, 0.0f);
+    for (int w = 0; w < 8; w++)
+        for (int l = 0; l < 64; l++)
+            for (int i = 0; i < 4; i++) {
+                const int k = kb0 + 16 * w + 4 * (l >> 4) + i, kc = (int)(((int64_t)k * c0) % N);
+                p.cre[((size_t)w * 64 + l) * 4 + i] = (float)(std::cos(two_pi * (double)kc / (double)N) * 8192.0);
+            }
+    // the first layer with all taps as rows (make_mlpx_plan's table) with K = bin - kb0: zero weights outside the band
+    std::vector<double> a((size_t)I, 1.0);
+    for (int k = 1; k < c.n_input_fns; k++)
+        for (int i = 0; i < I; i++) a[(size_t)i] *= (double)c.input_fns[k].gains[i];
+    const syldet_layer_t &L0 = c.layers[0];
+    const int H = L0.outputs;
+    const double wscale = 1.0 / (double)mx.desc.w_unscale;
+    p.afrag.assign((size_t)3 * 4 * 2 * 64 * 8, 0);
+    for (int m = 0; m < 3; m++)
+        for (int kb = 0; kb < 4; kb++)
+            for (int l = 0; l < 64; l++)
+                for (int j = 0; j < 8; j++) {
+                    const int r = 16 * m + (l & 15), t = r / 4, h = r % 4, bin = kb0 + 32 * kb + 8 * (l >> 4) + j - g.f0;
+                    double v = 0.0;
+                    if (t < T && h < H && bin >= 0 && bin < F) v = (double)L0.weights[(size_t)h * I + t * F + bin] * a[(size_t)(t * F + bin)] * wscale;
+                    uint16_t hi, lo;
+                    split_half(v, hi, lo);
+                    p.afrag[((((size_t)m * 4 + kb) * 2 + 0) * 64 + l) * 8 + j] = hi;
+                    p.afrag[((((size_t)m * 4 + kb) * 2 + 1) * 64 + l) * 8 + j] = lo;
+                }
+    p.ok = true;
+    return true;
+}
+
 void fused_segmentation(FusedDesc &d, int64_t E, int C)
 {
     // A workgroup segment = `runs` consecutive passes of one channel, emitting pass * runs - (T-1) evaluations.  Both kernels

@@ -29,6 +29,15 @@ struct MlpxPlan {
     std::vector<uint16_t> afrag;
     std::vector<float> bias0, w1;
 };
+struct BdftPlan {
+    bool ok = false;
+    BdftDesc desc{};
+    std::vector<uint16_t> basis, afrag;
+    std::vector<float> cre;
+};
+// frames of four hops on the block-transform kernel (kernels_bdft.hip), when the configuration is of the matrix-core network
+// stage's class, W = N = 4 hop with hop 128 or 256, and the window is rectangular, Hann or Hamming
+bool make_bdft_plan(const syldet_config_t &cfg, const syldet_geometry_t &geom, const MlpxPlan &mlpx, BdftPlan &plan);
 // the matrix-core network stage of the generic engine (kernels_mlpx.hip), when the configuration is of its class
 bool make_mlpx_plan(const syldet_config_t &cfg, const syldet_geometry_t &geom, MlpxPlan &plan);
 

@@ -196,6 +196,19 @@ struct MlpxDesc {
     const float *bias0, *w1;    // [4] folded first-layer biases, second-layer weights (zero padded)
     const double *thresholds;   // [1]
 };
+// ---- frames of four hops (W = N = 4 hop): every block of `hop` samples transformed once on the matrix cores, frames as sliding
+// sums of four blocks, the window as three taps along the bins, then the matrix-core network stage -- one launch (kernels_bdft.hip)
+constexpr int kBdftBlock = 512;          // 8 waves, two per SIMD; wave w owns bins kb0 + 16 w .. + 15
+struct BdftDesc {
+    int hop, kb0, f0;           // hop = N / 4 (128 or 256); first of the 128 bins transformed (a multiple of 4, <= f0 - 1); the band's first bin
+    float a0, a1c, a1s;         // the window as a cosine sum: a_0, (a_1 / 2) cos(pi hop / N), (a_1 / 2) sin(pi hop / N)
+    const uint4 *basis;         // [8 waves][cosine rows, sine rows][hop / 64 k-steps][hi,lo][64 lanes] A-operand fragments of the folded block basis
+    const float *cre;           // [8 waves][64 lanes][4] the block's first sample's real coefficients for the lane's bins
+    const uint4 *afrag;         // [3 row tiles][4][hi,lo][64 lanes] first layer, all taps as rows, K = bin - kb0
+};
+// outputs [C][E][1], flags [C][E] <- samples [C][stride]; S: samples per channel
+hipError_t launch_bdft_net(const MlpxDesc &d, const BdftDesc &bd, const float *samples, int64_t stride, int C, int64_t S, int64_t J, int64_t E,
+                           float *outputs, uint8_t *flags, hipStream_t stream);
 // ---- 1024-point frames: packed real FFT + the matrix-core network stage in one launch (kernels_fft1k.hip) ----
 constexpr int kFft1kBlock = 768;         // 12 waves (three per SIMD): a frame per wave at a time, 10 or 11 frames of a 128-frame tile each
 bool fft1k_applicable(const StftDesc &s, const MlpxDesc &d, const float *samples, int64_t stride);

@@ -1,0 +1,450 @@
+// kernels_bdft.hip -- long frames whose hop divides them (BASELINE configs[2]: 1024-point frames, hop 256): samples in HBM ->
+// network outputs + detection flags in HBM in ONE kernel, with the transform on the matrix cores and every sample
+// transformed ONCE, not once per frame that covers it.
+//
+// Reference path being replaced, per frame and per evaluation (reference root relative):
+//   extractPower          Common/CircularShortTimeFourierTransform.swift:280-337   (window, packed real FFT, |X|)
+//   processFourierData    Common/SyllableDetector.swift:134-151                    (slice to [f0, f1))
+//   processNewValue       Common/SyllableDetector.swift:153-217                    (timeRange-column window)
+//   NeuralNet.apply       Common/NeuralNet.swift:294-326, :366-377                 (l2normalize, affine maps, TanSig, linear)
+//   lastDetected          Common/SyllableDetector.swift:27-31
+//
+// With W = N = R hop a frame is R consecutive blocks of `hop` samples, and its DFT under a rectangular window is
+//     Y_j[k] = sum_{q < R} w_R^{k q} B_{j+q}[k],   w_R = e^{-2 pi i / R},   B_b[k] = sum_{n < hop} x[b hop + n] e^{-2 pi i k n / N}
+// -- a block's band-limited partial transform is shared by the R frames that contain it, and for R = 4 the factors are
+// 1, -i, -1, i: a sum of four with swaps and signs.  The reference's windows are short cosine sums, w[n] = sum_p a_p
+// cos(2 pi p n / N) (Hamming 0.54, -0.46; Hann 0.5, -0.5; rectangular 1), so the window is three taps along the bins AFTER the
+// transform:  X_j[k] = a_0 Y_j[k] + (a_1 / 2) (Y_j[k-1] + Y_j[k+1]).  B_b itself is kernels_fused_s.hip's symmetric fold (a block
+// under no window is symmetric about its centre c = hop / 2): with s[m] = x[c+m] + x[c-m], d[m] = x[c+m] - x[c-m],
+//     B'_b[k] = e^{+i theta k} B_b[k] = sum_m s[m] cos(2 pi k m / N) - i sum_m d[m] sin(2 pi k m / N) + x[0] e^{+i theta k},  theta = 2 pi c / N,
+// two GEMMs of K = hop / 2 on the matrix cores (f16 hi + lo operands, three products, fp32 accumulation).  The common phase
+// e^{i theta k} drops out of |X| once the window's taps carry e^{+-i theta}.
+// Per frame: 12 matrix instructions instead of the FFT kernel's ~280 vector instructions and 18 KB of LDS transposes.
+//
+// A workgroup of 8 waves (two per SIMD) walks a contiguous run of one channel.  Wave w owns bins kb0 + 16 w .. + 15: their
+// cosine rows and sine rows are 64 registers, resident.  The run advances in sub-tiles of 16 blocks with ONE barrier each:
+//     iteration u:  barrier  |  load the raw samples of sub-tile u+2 into registers (each of 512 threads: 8 positions of one block)
+//                            |  fold, scale (the block's own power of two), split sub-tile u+1 -> B fragments in LDS (the other buffer)
+//                            |  24 MFMAs on sub-tile u's fragments, the first sample's rank-1 term, back to true units,
+//                               the sliding sum over the last R blocks (DPP row shifts; the previous sub-tile's last columns carry)
+//                            |  the lane groups' edge bins of sub-tile u -> LDS
+//                            |  window taps, |X|, f16 hi + lo columns of sub-tile u-1 (its neighbours' edge bins arrived with the barrier)
+//                            |  block maxima of sub-tile u+2 (LDS atomic max)
+// Six sub-tiles (96 new frames) make a tile; then kernels_fft1k.hip's back half: all taps of the first layer as the rows of one
+// GEMM over the tile's columns, one thread per evaluation for the rest of the network, the last timeRange - 1 columns carried.
+//
+// gfx950 only.  wave = 64.
+
+#include "fused_common.hpp"
+
+namespace sd {
+
+namespace {
+
+using namespace fused_dev;
+
+constexpr int kBlock = kBdftBlock;             // 512 threads = 8 waves, two per SIMD
+constexpr int kWaves = kBlock / 64;
+constexpr int kTile = 128;                     // column rows of a tile: timeRange - 1 carried + 96 new
+constexpr int kSubs = 6;                       // sub-tiles of 16 blocks per tile
+constexpr int kNew = 16 * kSubs;               // new frames (= evaluations) per tile
+
+__device__ __forceinline__ float rem_lo(float a, unsigned h)
+{
+    float r;
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(r) : "v"(a), "v"(h));
+    return r;
+}
+__device__ __forceinline__ float rem_hi(float a, unsigned h)
+{
+    float r;
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(a), "v"(h));
+    return r;
+}
+__device__ __forceinline__ unsigned cvt_pk(float a, float b)
+{
+    unsigned r;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ void split2(float a, float b, unsigned &hi, unsigned &lo)
+{
+    hi = cvt_pk(a, b);
+    lo = cvt_pk(rem_lo(a, hi), rem_hi(b, hi));
+}
+// the value of lane n - Q of this 16-lane row (0 where there is none) / of lane n + 16 - Q of `prev` (0 elsewhere)
+template <int Q>
+__device__ __forceinline__ float shr_cur(float v)
+{
+    return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x110 + Q, 0xF, 0xF, true));   // row_shr:Q
+}
+template <int Q>
+__device__ __forceinline__ float shl_prev(float v)
+{
+    return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x100 + (16 - Q), 0xF, 0xF, true));   // row_shl:16-Q
+}
+template <int Q>
+__device__ __forceinline__ float back(float cur, float prev) { return shr_cur<Q>(cur) + shl_prev<Q>(prev); }   // column n - Q of the stream
+
+// KS: k-steps of 32 folded positions per block (hop = 64 KS).  Frames of R = 4 blocks.
+template <int KS>
+__global__ void __launch_bounds__(kBlock, 1)
+bdft_net_kernel(const MlpxDesc d, const BdftDesc bd, const float *__restrict__ samples, int64_t stride, int64_t S, int64_t J, int64_t E,
+                int64_t evals_per_run, float *__restrict__ outputs, uint8_t *__restrict__ flags)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int KB = 4, R = 4, HOP = 64 * KS;
+    // LDS: first-layer fragments | columns hi | columns lo | per-frame sums, exponents | B fragments (two buffers) | edge bins |
+    // per-wave partial sums | block maxima;  the tap products of a tile sit where the second fragment buffer and the edge bins are
+    const int CS = d.col_stride, PS = d.p_stride;
+    uint32x4 *afr = reinterpret_cast<uint32x4 *>(smem);
+    _Float16 *colh = reinterpret_cast<_Float16 *>(smem + 3 * KB * 2 * 1024);
+    _Float16 *coll = colh + kTile * CS;
+    float *ssf = reinterpret_cast<float *>(coll + kTile * CS);       // [tile] per-frame sums of squares (true units)
+    float *fsc = ssf + kTile;                                        // [tile] a frame's products back to true units
+    unsigned char *scr = reinterpret_cast<unsigned char *>(fsc + kTile);
+    constexpr int kFragBytes = 4 * KS * 1024;                        // s hi, s lo, d hi, d lo: KS fragments each
+    uint32x2 *bfr0 = reinterpret_cast<uint32x2 *>(scr), *bfr1 = reinterpret_cast<uint32x2 *>(scr + kFragBytes);
+    floatx4 *edges = reinterpret_cast<floatx4 *>(scr + 2 * kFragBytes);                  // [2 parities][16 frames][32 lane groups] (re0, im0, re3, im3)
+    float *pbuf = reinterpret_cast<float *>(scr + kFragBytes);                           // [tile][PS] over buffer 1 and the edges
+    float *ssf8 = reinterpret_cast<float *>(scr + 2 * kFragBytes + 2 * 16 * 32 * 16);   // [tile][8 waves]
+    unsigned *bmax = reinterpret_cast<unsigned *>(ssf8 + kTile * kWaves);                 // [4][16] block maxima (bit patterns of |x|), by sub-tile & 3
+    float *x0buf = reinterpret_cast<float *>(bmax + 64);                                  // [4][16] the blocks' first samples
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, g = lane >> 4;
+    const int c = blockIdx.y;
+    const int F = d.F, T = d.T;
+    const int64_t E0 = (int64_t)blockIdx.x * evals_per_run;
+    if (E0 >= E) return;
+    const int64_t E1 = E0 + evals_per_run < E ? E0 + evals_per_run : E;
+    const int64_t fbase = E0 - 16;                                   // the run's first (discarded) frame: a sub-tile of lead-in
+    const int tiles = (int)((E1 - E0 + 16 + (T - 1) + kNew - 1) / kNew);
+
+    // ---- once per workgroup: first-layer fragments, zero columns (rows the run never writes must not hold NaNs), maxima
+    for (int i = tid; i < 3 * KB * 2 * 64; i += kBlock) afr[i] = reinterpret_cast<const uint32x4 *>(bd.afrag)[i];
+    for (int i = tid; i < kTile * CS / 2; i += kBlock) {
+        reinterpret_cast<unsigned *>(colh)[i] = 0u;
+        reinterpret_cast<unsigned *>(coll)[i] = 0u;
+    }
+    if (tid < kTile) { ssf[tid] = 0.0f; fsc[tid] = 0.0f; }
+    for (int i = tid; i < kTile * kWaves; i += kBlock) ssf8[i] = 0.0f;
+    if (tid < 64) bmax[tid] = 0u;
+    const float b0[4] = {d.bias0[0], d.bias0[1], d.bias0[2], d.bias0[3]}, w1[4] = {d.w1[0], d.w1[1], d.w1[2], d.w1[3]};
+    const double thr = d.thresholds[0];
+    const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(outputs ? outputs + (int64_t)c * E : nullptr, 0, outputs ? (int)(E * 4) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t flg_rs = __builtin_amdgcn_make_buffer_rsrc(flags ? flags + (int64_t)c * E : nullptr, 0, flags ? (int)E : 0, 0x00020000);
+    const float *chan = samples + (int64_t)c * stride;
+    const __amdgpu_buffer_rsrc_t in_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(chan), 0, (int)(S * 4), 0x00020000);
+
+    // ---- this wave's basis: cosine rows and sine rows of its 16 bins, [k-step][hi, lo]; the first sample's real coefficients
+    half8 ac[KS][2], as_[KS][2];
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++)
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            ac[ks][p] = as_half8(reinterpret_cast<const uint32x4 *>(bd.basis)[(((wave * 2 + 0) * KS + ks) * 2 + p) * 64 + lane]);
+            as_[ks][p] = as_half8(reinterpret_cast<const uint32x4 *>(bd.basis)[(((wave * 2 + 1) * KS + ks) * 2 + p) * 64 + lane]);
+        }
+    float cre[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) cre[i] = bd.cre[(wave * 64 + lane) * 4 + i];
+    const float wa0 = bd.a0, wc = bd.a1c, wsn = bd.a1s;               // a_0, (a_1 / 2) cos theta, (a_1 / 2) sin theta
+    const int fb0 = bd.kb0 + 16 * wave + 4 * g - bd.f0;              // band index of this lane's first bin (the band is [0, F))
+
+    // ---- the fold's thread layout: block n of the sub-tile, positions m = 32 ks + 8 gf + 4 half + j (j < 4)
+    const int f_ks = wave % KS, f_half = (wave / KS) & 1;
+    const bool folder = wave < 2 * KS;
+    const int f_m = 32 * f_ks + 8 * g + 4 * f_half;
+    // raw samples of one block's share: x[c + m .. c + m + 3], x[c - m - 4 .. c - m - 1], x[c - m], and the block's first sample
+    struct Raw { floatx4 p, q; float z, x0; };
+    auto load_raw = [&](int64_t blk0) {                              // blk0: first block of the sub-tile
+        Raw r;
+        const int64_t blk = blk0 + n;
+        const int64_t base = blk * HOP;                               // (in samples)
+        const bool ok = blk >= 0 && folder;
+        const unsigned o = ok ? (unsigned)((base + HOP / 2) * 4) : 0xFFFFFFF0u;
+        r.p = as_floatx4(__builtin_amdgcn_raw_buffer_load_b128(in_rs, ok ? o + (unsigned)f_m * 4u : 0xFFFFFFF0u, 0, 0));
+        r.q = as_floatx4(__builtin_amdgcn_raw_buffer_load_b128(in_rs, ok ? o - (unsigned)(f_m + 4) * 4u : 0xFFFFFFF0u, 0, 0));
+        r.z = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(in_rs, ok ? o - (unsigned)f_m * 4u : 0xFFFFFFF0u, 0, 0));
+        r.x0 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(in_rs, (ok && wave == 0) ? (unsigned)(base * 4) : 0xFFFFFFF0u, 0, 0));
+        return r;
+    };
+    auto raw_max = [&](const Raw &r, unsigned *slot) {               // this thread's share of its block's loudest sample
+        float m = absmax3(absmax3(0.0f, r.p[0], r.p[1]), r.p[2], r.p[3]);
+        m = absmax3(absmax3(m, r.q[0], r.q[1]), r.q[2], r.q[3]);
+        m = absmax3(m, r.z, r.x0);
+        if (folder) atomicMax(slot + n, __float_as_uint(m));         // (v_max3 drops NaNs: non-negative numbers compare as their bits)
+    };
+    auto scale_exp = [](unsigned bits) {                             // 2^e puts the block's loudest sample into [2^13, 2^14)
+        const int ex = (int)((bits >> 23) & 0xffu);
+        int e = 140 - ex;
+        e = bits != 0u ? (e < -100 ? -100 : (e > 113 ? 113 : e)) : 0;
+        return e;
+    };
+    auto fold_store = [&](const Raw &r, int slt, uint32x2 *bf) {     // slt: the sub-tile's slot (its index & 3)
+        if (!folder) return;
+        const unsigned *slot = bmax + 16 * slt;
+        if (wave == 0 && g == 0) x0buf[16 * slt + n] = r.x0;
+        const float sx = pow2f(scale_exp(slot[n]));
+        const float xp[4] = {r.p[0], r.p[1], r.p[2], r.p[3]};
+        const float xm[4] = {r.z, r.q[3], r.q[2], r.q[1]};           // x[c - m - j]
+        float s[4], dd[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float tm = xm[j] * sx;
+            s[j] = fmaf(xp[j], sx, tm);
+            dd[j] = fmaf(xp[j], sx, -tm);
+        }
+        if (f_m == 0) dd[0] = r.x0 * sx;                             // slot 0 of the differences carries the block's first sample
+        uint32x2 sh, sl, dh, dl;
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            unsigned h, l;
+            split2(s[2 * j], s[2 * j + 1], h, l);
+            sh[j] = h; sl[j] = l;
+            split2(dd[2 * j], dd[2 * j + 1], h, l);
+            dh[j] = h; dl[j] = l;
+        }
+        // fragment [which][k-step][lane (n, g)]: 8 halves; this thread's four are its half of them
+        uint32x2 *at = bf + ((f_ks * 64 + 16 * g + n) * 2 + f_half);
+        at[0 * KS * 128] = sh;
+        at[1 * KS * 128] = sl;
+        at[2 * KS * 128] = dh;
+        at[3 * KS * 128] = dl;
+    };
+
+    // ---- the stream's state
+    floatx4 yre_prev = {0.f, 0.f, 0.f, 0.f}, yim_prev = yre_prev;   // sub-tile u-1: Y' of this lane's four bins for the frame ending at block n
+    floatx4 bre_prev = yre_prev, bim_prev = yre_prev;               // sub-tile u-1: the blocks' own partial transforms (true units), for the carry
+    int eb_prev = 0x7fff;                                            // ... and the blocks' scale exponents (0x7fff: a silent block does not count)
+    float up_prev = 0.0f, dn_prev = 0.0f;                            // ... and the frames' column scales
+    int64_t u = 0;                                                   // sub-tile counter of the run
+    auto blk_of = [&](int64_t uu) { return fbase + 16 * uu + (R - 1); };   // first block of sub-tile uu (frames end on their last block)
+
+    // prologue: sub-tiles 0 and 1 loaded, their maxima taken, sub-tile 0 folded
+    Raw r1 = load_raw(blk_of(0)), r2 = load_raw(blk_of(1));
+    __syncthreads();                                                 // (the zeroed maxima)
+    raw_max(r1, bmax + 0);
+    raw_max(r2, bmax + 16);
+    __syncthreads();
+    fold_store(r1, 0, bfr0);
+    r1 = r2;
+
+    for (int tr = 0; tr < tiles; tr++) {
+#pragma unroll
+        for (int s = 0; s <= kSubs; s++) {
+            // bfr[u & 1] holds sub-tile u's fragments, bmax[(u + 1) % 3] sub-tile u + 1's maxima, edges[(u - 1) & 1] sub-tile u - 1's edge bins
+            __syncthreads();
+            const bool last_tile = tr + 1 == tiles;
+            const bool mm = s < kSubs;                               // a sub-tile to multiply in this iteration
+            Raw r3;
+            floatx4 yre = yre_prev, yim = yim_prev;
+            float upc = 0.0f, dnc = 0.0f;
+            if (mm) {
+                const int par = (int)(u & 1);
+                const bool more = !(last_tile && s == kSubs - 1);   // a sub-tile u + 1 follows
+                if (tid < 16) bmax[((u + 3) & 3) * 16 + tid] = 0u;   // (sub-tile u - 1's slot: read for the last time before this barrier)
+                r3 = load_raw(blk_of(u + 2));                        // (past the recording: zeros from the descriptor's bounds check)
+                (void)more;
+                fold_store(r1, (int)((u + 1) & 3), par ? bfr0 : bfr1);
+                // ---- B'_n[k] for this wave's bins: cosine rows against the sums, sine rows against the differences
+                const uint32x4 *bf = reinterpret_cast<const uint32x4 *>(par ? bfr1 : bfr0);
+                floatx4 are = {0.f, 0.f, 0.f, 0.f}, aim = are;
+#pragma unroll
+                for (int ks = 0; ks < KS; ks++) {
+                    const half8 bsh = as_half8(bf[(0 * KS + ks) * 64 + lane]), bsl = as_half8(bf[(1 * KS + ks) * 64 + lane]);
+                    const half8 bdh = as_half8(bf[(2 * KS + ks) * 64 + lane]), bdl = as_half8(bf[(3 * KS + ks) * 64 + lane]);
+                    are = mfma(ac[ks][0], bsh, are);
+                    aim = mfma(as_[ks][0], bdh, aim);
+                    are = mfma(ac[ks][0], bsl, are);
+                    aim = mfma(as_[ks][0], bdl, aim);
+                    are = mfma(ac[ks][1], bsh, are);
+                    aim = mfma(as_[ks][1], bdh, aim);
+                }
+                // the block's first sample (its real part; the imaginary part rode in slot 0), then back to true units
+                const unsigned mb = bmax[(u & 3) * 16 + n];
+                const int eb = scale_exp(mb);
+                const float x0s = x0buf[(u & 3) * 16 + n] * pow2f(eb);
+                const float un = pow2f(-eb - 13);
+                floatx4 bre, bim;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    bre[i] = fmaf(cre[i], x0s, are[i]) * un;
+                    bim[i] = aim[i] * un;
+                }
+                // ---- frames end on their last block: Y'_n = sum_{q' < 4} (-i)^{k (3 - q')} B'_{n - q'}, k = i (mod 4)
+                //      i = 0: 1, 1, 1, 1   i = 1: i, -1, -i, 1   i = 2: -1, 1, -1, 1   i = 3: -i, -1, i, 1   (q' = 0 .. 3)
+                {
+                    const float r0a = back<1>(bre[0], bre_prev[0]), r0b = back<2>(bre[0], bre_prev[0]), r0c = back<3>(bre[0], bre_prev[0]);
+                    const float i0a = back<1>(bim[0], bim_prev[0]), i0b = back<2>(bim[0], bim_prev[0]), i0c = back<3>(bim[0], bim_prev[0]);
+                    yre[0] = bre[0] + r0a + r0b + r0c;
+                    yim[0] = bim[0] + i0a + i0b + i0c;
+                    const float r1a = back<1>(bre[1], bre_prev[1]), r1b = back<2>(bre[1], bre_prev[1]), r1c = back<3>(bre[1], bre_prev[1]);
+                    const float i1a = back<1>(bim[1], bim_prev[1]), i1b = back<2>(bim[1], bim_prev[1]), i1c = back<3>(bim[1], bim_prev[1]);
+                    yre[1] = -bim[1] - r1a + i1b + r1c;              // i z = (-b, a); -z; -i z = (b, -a); z
+                    yim[1] = bre[1] - i1a - r1b + i1c;
+                    const float r2a = back<1>(bre[2], bre_prev[2]), r2b = back<2>(bre[2], bre_prev[2]), r2c = back<3>(bre[2], bre_prev[2]);
+                    const float i2a = back<1>(bim[2], bim_prev[2]), i2b = back<2>(bim[2], bim_prev[2]), i2c = back<3>(bim[2], bim_prev[2]);
+                    yre[2] = -bre[2] + r2a - r2b + r2c;
+                    yim[2] = -bim[2] + i2a - i2b + i2c;
+                    const float r3a = back<1>(bre[3], bre_prev[3]), r3b = back<2>(bre[3], bre_prev[3]), r3c = back<3>(bre[3], bre_prev[3]);
+                    const float i3a = back<1>(bim[3], bim_prev[3]), i3b = back<2>(bim[3], bim_prev[3]), i3c = back<3>(bim[3], bim_prev[3]);
+                    yre[3] = bim[3] - r3a - i3b + r3c;               // -i z = (b, -a); -z; i z = (-b, a); z
+                    yim[3] = -bre[3] - i3a + r3b + i3c;
+                }
+                // the frame's column scale from its loudest block (a power of two that every wave derives alike: |X| 2^(e - 10) < 2^14)
+                const int ebq = mb != 0u ? eb : 0x7fff;
+                int ef = min(ebq, min((int)__builtin_amdgcn_update_dpp(0x7fff, ebq, 0x111, 0xF, 0xF, false), min((int)__builtin_amdgcn_update_dpp(0x7fff, ebq, 0x112, 0xF, 0xF, false),
+                                                                                                              (int)__builtin_amdgcn_update_dpp(0x7fff, ebq, 0x113, 0xF, 0xF, false))));
+                // (columns n < 3 reach into the previous sub-tile's last blocks)
+                ef = min(ef, min((int)__builtin_amdgcn_update_dpp(0x7fff, eb_prev, 0x10F, 0xF, 0xF, false), min((int)__builtin_amdgcn_update_dpp(0x7fff, eb_prev, 0x10E, 0xF, 0xF, false),
+                                                                                                           (int)__builtin_amdgcn_update_dpp(0x7fff, eb_prev, 0x10D, 0xF, 0xF, false))));
+                ef = ef == 0x7fff ? 0 : ef;
+                const int eu = ef - 10 < -120 ? -120 : (ef - 10 > 120 ? 120 : ef - 10);
+                upc = pow2f(eu);
+                dnc = pow2f(-eu);
+                // this lane group's edge bins -> LDS for its neighbours
+                edges[(par * 16 + n) * 32 + 4 * wave + g] = floatx4{yre[0], yim[0], yre[3], yim[3]};
+                bre_prev = bre; bim_prev = bim; eb_prev = ebq;
+            }
+            if (s >= 1) {
+                // ---- sub-tile u - 1 (or, in the drain iteration, the tile's last): window taps, |X|, columns.  Row of frame n:
+                const int sp = s - 1;
+                const int pe = (int)((u - 1) & 1);                   // (u: this iteration's sub-tile, or one past the tile's last in the drain iteration)
+                const int G = 4 * wave + g;
+                const floatx4 eL = G > 0 ? edges[(pe * 16 + n) * 32 + G - 1] : floatx4{0.f, 0.f, 0.f, 0.f};
+                const floatx4 eR = G < 31 ? edges[(pe * 16 + n) * 32 + G + 1] : floatx4{0.f, 0.f, 0.f, 0.f};
+                const float reL[4] = {eL[2], yre_prev[0], yre_prev[1], yre_prev[2]}, imL[4] = {eL[3], yim_prev[0], yim_prev[1], yim_prev[2]};
+                const float reR[4] = {yre_prev[1], yre_prev[2], yre_prev[3], eR[0]}, imR[4] = {yim_prev[1], yim_prev[2], yim_prev[3], eR[1]};
+                float cv[4], ssq = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const float xr = fmaf(wa0, yre_prev[i], fmaf(wc, reL[i] + reR[i], -wsn * (imL[i] - imR[i])));
+                    const float xi = fmaf(wa0, yim_prev[i], fmaf(wsn, reL[i] - reR[i], wc * (imL[i] + imR[i])));
+                    cv[i] = __builtin_amdgcn_sqrtf(fmaf(xr, xr, xi * xi));        // zvabs / 2, :329-333 (Y is the DFT itself, not twice it)
+                    const bool inb = (unsigned)(fb0 + i) < (unsigned)F;
+                    ssq = inb ? fmaf(cv[i], cv[i], ssq) : ssq;
+                }
+                ssq = xor32_sum(xor16_sum(ssq));
+                const int rw = (T - 1) + 16 * sp + n;
+                unsigned h0, l0, h1, l1;
+                split2(cv[0] * up_prev, cv[1] * up_prev, h0, l0);
+                split2(cv[2] * up_prev, cv[3] * up_prev, h1, l1);
+                const int cb = 16 * wave + 4 * g;                    // column index = bin - kb0 (the first layer's fragments are in that order)
+                *reinterpret_cast<uint32x2 *>(colh + rw * CS + cb) = uint32x2{h0, h1};
+                *reinterpret_cast<uint32x2 *>(coll + rw * CS + cb) = uint32x2{l0, l1};
+                if (g == 0) ssf8[rw * kWaves + wave] = ssq;
+                if (wave == 0 && g == 0) fsc[rw] = dn_prev;
+            }
+            if (mm) {
+                // ---- sub-tile u + 2's block maxima; the stream moves on
+                raw_max(r3, bmax + ((u + 2) & 3) * 16);
+                yre_prev = yre; yim_prev = yim; up_prev = upc; dn_prev = dnc;
+                r1 = r3;
+                u++;
+            }
+        }
+        __syncthreads();
+        // ---- the frames' sums of squares from the waves' partial sums, in a fixed order
+        if (tid < kTile) {
+            float a = 0.0f;
+#pragma unroll
+            for (int w = 0; w < kWaves; w++) a += ssf8[tid * kWaves + w];
+            if (tid >= T - 1) ssf[tid] = a;                          // (rows 0 .. T-2 were carried)
+        }
+        // ---- tap products of this wave's 16 rows, P[(t, h), j] for all taps at once (three row tiles), back to true units
+        {
+            const int fr = 16 * wave + n;
+            const _Float16 *bph = colh + fr * CS + 8 * g, *bpl = coll + fr * CS + 8 * g;
+            floatx4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int kb = 0; kb < KB; kb++) {
+                const half8 bh = as_half8(*reinterpret_cast<const uint32x4 *>(bph + 32 * kb));
+                const half8 bl = as_half8(*reinterpret_cast<const uint32x4 *>(bpl + 32 * kb));
+#pragma unroll
+                for (int m = 0; m < 3; m++) {
+                    const half8 ah = as_half8(afr[((m * KB + kb) * 2 + 0) * 64 + lane]), al = as_half8(afr[((m * KB + kb) * 2 + 1) * 64 + lane]);
+                    acc[m] = mfma(ah, bh, acc[m]);
+                    acc[m] = mfma(ah, bl, acc[m]);
+                    acc[m] = mfma(al, bh, acc[m]);
+                }
+            }
+            const float dn = fsc[fr];
+#pragma unroll
+            for (int m = 0; m < 3; m++) *reinterpret_cast<floatx4 *>(pbuf + fr * PS + 4 * (4 * m + g)) = acc[m] * dn;
+        }
+        __syncthreads();
+        // ---- evaluations, one thread each: row r starts the window of evaluation fbase + kNew tr + r - (T - 1) ... r + T - 1
+        if (tid < kNew) {
+            floatx4 z = {0.f, 0.f, 0.f, 0.f};
+            float ssw = 0.0f;
+            for (int t = 0; t < T; t++) {
+                z += *reinterpret_cast<const floatx4 *>(pbuf + (tid + t) * PS + 4 * t);
+                ssw += ssf[tid + t];
+            }
+            const float alpha = d.w_unscale * __builtin_amdgcn_rsqf(ssw);
+            float y = d.b1;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {             // TanSig hidden units (rows past H meet zero weights), linear output
+                const float a = fmaf(alpha, z[j], b0[j]);
+                const float th = fmaf(-2.0f, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(a * 2.885390081777927f) + 1.0f), 1.0f);
+                y = fmaf(w1[j], th, y);
+            }
+            y = (y - d.oa) / d.og + d.ob;
+            const int64_t e = fbase + (int64_t)kNew * tr + tid;      // row tid is frame fbase + kNew tr + tid - (T - 1): the window's first
+            const int64_t ev = e - (T - 1);
+            const bool st = ev >= E0 && ev < E1;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y), out_rs, st ? (unsigned)ev * 4u : 0xFFFFFFFFu, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b8((unsigned char)((double)y >= thr ? 1 : 0), flg_rs, st ? (unsigned)ev : 0xFFFFFFFFu, 0, 0);
+        }
+        __syncthreads();                              // (the products are read: the second fragment buffer and the edges are free again)
+        // ---- the last T - 1 frames are the next tile's first: their columns, sums and exponents move to the front
+        if (tr + 1 < tiles) {
+            const int words = (T - 1) * (CS / 2);     // 32-bit words per array
+            for (int i = tid; i < 2 * words; i += kBlock) {
+                unsigned *arr = reinterpret_cast<unsigned *>(i < words ? colh : coll);
+                const int w = i < words ? i : i - words;
+                arr[w] = arr[kNew * (CS / 2) + w];
+            }
+            if (tid < T - 1) {
+                ssf[tid] = ssf[kNew + tid];
+                fsc[tid] = fsc[kNew + tid];
+            }
+        }
+    }
+}
+
+}  // namespace
+
+hipError_t launch_bdft_net(const MlpxDesc &d, const BdftDesc &bd, const float *samples, int64_t stride, int C, int64_t S, int64_t J, int64_t E,
+                           float *outputs, uint8_t *flags, hipStream_t stream)
+{
+    if (E <= 0 || C <= 0) return hipSuccess;
+    if ((uint64_t)E * 4u >= 0xFFFFFFF0ull || (uint64_t)S * 4u >= 0x7fffffffull) return hipErrorInvalidValue;
+    // a workgroup walks a contiguous run of one channel; runs as long as still leaves two rounds of workgroups on the 256 CUs
+    int64_t runs_per_channel = (512 + C - 1) / C;
+    const int64_t min_run = 4 * kNew;
+    runs_per_channel = std::max<int64_t>(1, std::min<int64_t>(runs_per_channel, (E + min_run - 1) / min_run));
+    const int64_t evals_per_run = (E + runs_per_channel - 1) / runs_per_channel;
+    const int64_t runs = (E + evals_per_run - 1) / evals_per_run;
+    dim3 grid((unsigned)runs, (unsigned)C);
+    const int KS = bd.hop / 64;
+    const int frag = 4 * KS * 1024;
+    const int lds = 3 * 4 * 2 * 1024 + 2 * kTile * d.col_stride * 2 + 2 * kTile * 4 + 2 * frag + 2 * 16 * 32 * 16 + kTile * kWaves * 4 + 2 * 4 * 16 * 4;
+    if (lds > 160 * 1024 || kTile * d.p_stride * 4 > frag + 2 * 16 * 32 * 16) return hipErrorInvalidValue;
+#define SD_BDFT_GO(KS_)                                                                                                        \
+    if (KS == KS_) {                                                                                                           \
+        auto kern = bdft_net_kernel<KS_>;                                                                                      \
+        hipError_t st = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);              \
+        if (st != hipSuccess) return st;                                                                                       \
+        hipLaunchKernelGGL(kern, grid, dim3(kBlock), (size_t)lds, stream, d, bd, samples, stride, S, J, E, evals_per_run, outputs, flags); \
+        return hipGetLastError();                                                                                              \
+    }
+    SD_BDFT_GO(4) SD_BDFT_GO(2)
+#undef SD_BDFT_GO
+    return hipErrorInvalidValue;
+}
+
+}  // namespace sd

@@ -124,6 +124,7 @@ struct syldet {
     struct Switches {
         bool fused_classic = false;   // SYLDET_FUSED_CLASSIC: the 8-wave fused kernel where both fused kernels take the shape
         bool no_fft1k = false;        // SYLDET_NO_FFT1K: 1024-point frames as two launches
+        bool no_bdft = false;         // SYLDET_NO_BDFT: frames of four hops on the FFT kernels, not the block-transform kernel
         bool no_stft_lanes = false;   // SYLDET_NO_STFT_LANES: the LDS Stockham FFT instead of the lane-butterfly one
         bool no_guard = false;        // SYLDET_NO_GUARD: the precision guard off
         bool no_mlpx = false;         // SYLDET_NO_MLPX: the interpretive network kernels under AUTO
@@ -134,6 +135,7 @@ struct syldet {
         {
             fused_classic = std::getenv("SYLDET_FUSED_CLASSIC") != nullptr;
             no_fft1k = std::getenv("SYLDET_NO_FFT1K") != nullptr;
+            no_bdft = std::getenv("SYLDET_NO_BDFT") != nullptr;
             no_stft_lanes = std::getenv("SYLDET_NO_STFT_LANES") != nullptr;
             no_guard = std::getenv("SYLDET_NO_GUARD") != nullptr;
             no_mlpx = std::getenv("SYLDET_NO_MLPX") != nullptr;
@@ -171,6 +173,9 @@ struct syldet {
     // the generic engine's network stage on the matrix cores, where the configuration is of its class (kernels_mlpx.hip)
     MlpxPlan mlpx;
     DeviceBuffer d_mlpx;              // afrag | bias0 | w1
+    // ... with the block-transform front (kernels_bdft.hip) where frames are four hops long
+    BdftPlan bdft;
+    DeviceBuffer d_bdft;              // basis | cre | afrag
 
     // wide-network engine (SYLDET_ENGINE_WIDE_BF16)
     WideDesc wide{};
@@ -471,6 +476,24 @@ int upload_mlpx(syldet *h)
     return SYLDET_OK;
 }
 
+int upload_bdft(syldet *h)
+{
+    BdftPlan &p = h->bdft;
+    auto pad = [](size_t b) { return (b + 255) / 256 * 256; };
+    const size_t b_bytes = pad(p.basis.size() * 2), c_bytes = pad(p.cre.size() * 4), a_bytes = pad(p.afrag.size() * 2);
+    std::vector<unsigned char> blob(b_bytes + c_bytes + a_bytes);
+    std::memcpy(blob.data(), p.basis.data(), p.basis.size() * 2);
+    std::memcpy(blob.data() + b_bytes, p.cre.data(), p.cre.size() * 4);
+    std::memcpy(blob.data() + b_bytes + c_bytes, p.afrag.data(), p.afrag.size() * 2);
+    if (int st = h->d_bdft.reserve(blob.size())) return st;
+    SYLDET_HIP(hipMemcpy(h->d_bdft.ptr, blob.data(), blob.size(), hipMemcpyHostToDevice));
+    unsigned char *base = (unsigned char *)h->d_bdft.ptr;
+    p.desc.basis = (const uint4 *)base;
+    p.desc.cre = (const float *)(base + b_bytes);
+    p.desc.afrag = (const uint4 *)(base + b_bytes + c_bytes);
+    return SYLDET_OK;
+}
+
 // A plan for the DFT front half alone: the real STFT geometry with a one-frame, one-unit stand-in network (the
 // spectrogram instantiation never touches the network tables).
 int build_dft_plan(syldet *h)
@@ -647,6 +670,12 @@ int run_on_stream(syldet *h, const float *d_samples, int64_t S, int64_t stride, 
         return SYLDET_OK;
     }
     // 1024-point frames in front of a network of the matrix-core class: one launch, the columns never leave the CU
+    // frames of four hops: every block transformed once on the matrix cores, then the same network stage -- one launch
+    if (h->bdft.ok && !h->sw.no_bdft && (uint64_t)E * 4u < 0xFFFFFFF0ull && (uint64_t)S * 4u < 0x7fffffffull) {
+        KernelTimer t(h, stream, "bdft_net_kernel");
+        SYLDET_HIP(launch_bdft_net(h->mlpx.desc, h->bdft.desc, d_samples, stride, C, S, J, E, d_outputs, d_flags, stream));
+        return SYLDET_OK;
+    }
     if (h->mlpx.ok && !h->sw.no_fft1k && (uint64_t)E * 4u < 0xFFFFFFF0ull &&
         fft1k_applicable(h->stft, h->mlpx.desc, d_samples, stride)) {
         KernelTimer t(h, stream, "fft1k_net_kernel");
@@ -750,6 +779,12 @@ int syldet_create(const syldet_config_t *cfg, int32_t n_channels, int32_t device
         if (int st = upload_mlpx(h.get())) {
             syldet_destroy(h.release());
             return st;
+        }
+        if (make_bdft_plan(h->cfg.view, h->geom, h->mlpx, h->bdft)) {
+            if (int st = upload_bdft(h.get())) {
+                syldet_destroy(h.release());
+                return st;
+            }
         }
     }
     if (engine != SYLDET_ENGINE_GENERIC) {

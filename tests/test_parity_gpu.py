@@ -407,7 +407,7 @@ def test_other_baseline_workloads_at_full_size(oracle_lib, workload):
     import spotcheck
     torch = _torch()
     if workload == "config3":
-        cfg, C, S, engine, tol, kernels = nets.config3(), 512, 1 << 21, _abi.ENGINE_AUTO, util.TOL, ["fft1k_net_kernel"]
+        cfg, C, S, engine, tol, kernels = nets.config3(), 512, 1 << 21, _abi.ENGINE_AUTO, util.TOL, ["bdft_net_kernel"]
     else:
         cfg, C, S, engine, tol = nets.wide_mlp(nets.from_npz()), 64, 1 << 24, _abi.ENGINE_WIDE_BF16, 1e-2
         kernels = ["fused_kernel (spectrogram)", "wide_prep_chain_kernel", "wide_gemm_kernel"]
@@ -796,23 +796,28 @@ def test_1024_point_frames_in_one_launch_and_in_two(oracle_lib, monkeypatch):
         x = (synth.channels(3, S, first=50 + frames) * np.array([1.0, 1e-3, 30.0])[:, None]).astype(np.float32)
         x[1, S // 2:] *= np.float32(1e-3)                       # a 60 dB step inside a tile: every frame has its own exponent
         want = [o.run(x[c], po.F64)[2] for c in range(3)]
-        for one_launch in (True, False):
-            if one_launch:
-                monkeypatch.delenv("SYLDET_NO_FFT1K", raising=False)
-            else:
+        # three forms: every block transformed once on the matrix cores (kernels_bdft.hip: the hop is a quarter of the frame),
+        # the FFT kernel, the two launches it replaced
+        for form, expect in (("bdft", ["bdft_net_kernel"]), ("fft1k", ["fft1k_net_kernel"]), ("two", ["stft_generic_kernel", "mlp_mfma_kernel"])):
+            monkeypatch.delenv("SYLDET_NO_FFT1K", raising=False)
+            monkeypatch.delenv("SYLDET_NO_BDFT", raising=False)
+            if form != "bdft":
+                monkeypatch.setenv("SYLDET_NO_BDFT", "1")
+            if form == "two":
                 monkeypatch.setenv("SYLDET_NO_FFT1K", "1")
             with sd.SyllableDetector(cfg, channels=3) as det:
                 det.profile(True)
                 out, fl = det.run(torch.from_numpy(x).cuda())
                 torch.cuda.synchronize()
                 names = [nm for nm, _ in det.lastTimings()]
-                assert names == (["fft1k_net_kernel"] if one_launch else ["stft_generic_kernel", "mlp_mfma_kernel"]), names
+                assert names == expect, names
                 out, fl = out.cpu().numpy(), fl.cpu().numpy()
             for c in range(3):
                 util.assert_outputs_close(out[c], want[c])
                 util.assert_flags_exact(fl[c], want[c], cfg.thresholds, cfg.rule)
-    # rows that do not start 8-byte aligned (an odd stride): the same kernel, two loads a point
+    # rows that do not start 8-byte aligned (an odd stride): the FFT kernel with two loads a point; the block-transform kernel as it is
     monkeypatch.delenv("SYLDET_NO_FFT1K", raising=False)
+    monkeypatch.setenv("SYLDET_NO_BDFT", "1")
     S = cfg.windowLength + 199 * hop
     base = torch.from_numpy(synth.channels(2, S + 1, first=7)).cuda()
     xs = base[:, :S]                                            # stride S + 1
@@ -821,5 +826,13 @@ def test_1024_point_frames_in_one_launch_and_in_two(oracle_lib, monkeypatch):
         out, _ = det.run(xs)
         torch.cuda.synchronize()
         assert [nm for nm, _ in det.lastTimings()] == ["fft1k_net_kernel"]
+        for c in range(2):
+            util.assert_outputs_close(out[c].cpu().numpy(), o.run(xs[c].cpu().numpy(), po.F64)[2])
+    monkeypatch.delenv("SYLDET_NO_BDFT", raising=False)
+    with sd.SyllableDetector(cfg, channels=2) as det:
+        det.profile(True)
+        out, _ = det.run(xs)
+        torch.cuda.synchronize()
+        assert [nm for nm, _ in det.lastTimings()] == ["bdft_net_kernel"]
         for c in range(2):
             util.assert_outputs_close(out[c].cpu().numpy(), o.run(xs[c].cpu().numpy(), po.F64)[2])
