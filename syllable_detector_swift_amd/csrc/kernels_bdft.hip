@@ -35,9 +35,16 @@
 //
 // gfx950 only.  wave = 64.
 
+#include <algorithm>
+#include <cstdio>
+
 #include "fused_common.hpp"
 
 namespace sd {
+
+#ifdef SYLDET_B_STAMPS                  // diagnostic build only (tools/knockouts.sh): cycles per stage, summed over workgroups, printed by the launcher
+__device__ unsigned long long g_bdft_stamps[16];
+#endif
 
 namespace {
 
@@ -223,130 +230,177 @@ bdft_net_kernel(const MlpxDesc d, const BdftDesc bd, const float *__restrict__ s
     int64_t u = 0;                                                   // sub-tile counter of the run
     auto blk_of = [&](int64_t uu) { return fbase + 16 * uu + (R - 1); };   // first block of sub-tile uu (frames end on their last block)
 
-    // prologue: sub-tiles 0 and 1 loaded, their maxima taken, sub-tile 0 folded
+    // prologue: sub-tiles 0, 1 and 2 loaded, the maxima of the first two taken, sub-tile 0 folded.  In the loop a sub-tile's
+    // samples are loaded three iterations ahead of its MFMAs, its maxima taken two ahead, its fragments made one ahead: nothing
+    // waits for memory inside an iteration.
     Raw r1 = load_raw(blk_of(0)), r2 = load_raw(blk_of(1));
+    Raw r3 = load_raw(blk_of(2));
     __syncthreads();                                                 // (the zeroed maxima)
     raw_max(r1, bmax + 0);
     raw_max(r2, bmax + 16);
     __syncthreads();
     fold_store(r1, 0, bfr0);
-    r1 = r2;
+    r1 = r2;                                                         // r1: sub-tile u + 1 (to fold), r2: sub-tile u + 2 (to take the maxima of)
+    r2 = r3;
 
+    // ---- the stages of an iteration.  They are independent of each other (each works on a different sub-tile), so the two
+    // waves of a SIMD -- w and w + 4 -- take them in opposite orders: one multiplies while the other folds and finishes columns.
+    floatx4 yre, yim;
+    float upc = 0.0f, dnc = 0.0f;
+    auto stage_load_fold = [&]() {                                   // raw samples of sub-tile u + 3; fragments of sub-tile u + 1
+        if (tid < 16) bmax[((u + 3) & 3) * 16 + tid] = 0u;           // (sub-tile u - 1's slot: read for the last time before this barrier)
+#ifdef SYLDET_B_NOLOAD
+        r3 = load_raw(-100000);
+#else
+        r3 = load_raw(blk_of(u + 3));                                // (past the recording: zeros from the descriptor's bounds check)
+#endif
+#ifndef SYLDET_B_NOFOLD
+        fold_store(r1, (int)((u + 1) & 3), (u & 1) ? bfr0 : bfr1);
+#endif
+    };
+    auto stage_mfma = [&]() {                                        // sub-tile u: B', the sliding sum, the edge bins
+        const int par = (int)(u & 1);
+        // ---- B'_n[k] for this wave's bins: cosine rows against the sums, sine rows against the differences
+        const uint32x4 *bf = reinterpret_cast<const uint32x4 *>(par ? bfr1 : bfr0);
+        floatx4 are = {0.f, 0.f, 0.f, 0.f}, aim = are;
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            const half8 bsh = as_half8(bf[(0 * KS + ks) * 64 + lane]), bsl = as_half8(bf[(1 * KS + ks) * 64 + lane]);
+            const half8 bdh = as_half8(bf[(2 * KS + ks) * 64 + lane]), bdl = as_half8(bf[(3 * KS + ks) * 64 + lane]);
+            are = mfma(ac[ks][0], bsh, are);
+            aim = mfma(as_[ks][0], bdh, aim);
+            are = mfma(ac[ks][0], bsl, are);
+            aim = mfma(as_[ks][0], bdl, aim);
+            are = mfma(ac[ks][1], bsh, are);
+            aim = mfma(as_[ks][1], bdh, aim);
+        }
+        // the block's first sample (its real part; the imaginary part rode in slot 0), then back to true units
+        const unsigned mb = bmax[(u & 3) * 16 + n];
+        const int eb = scale_exp(mb);
+        const float x0s = x0buf[(u & 3) * 16 + n] * pow2f(eb);
+        const float un = pow2f(-eb - 13);
+        floatx4 bre, bim;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            bre[i] = fmaf(cre[i], x0s, are[i]) * un;
+            bim[i] = aim[i] * un;
+        }
+        // ---- frames end on their last block: Y'_n = sum_{q' < 4} (-i)^{k (3 - q')} B'_{n - q'}, k = i (mod 4)
+        //      i = 0: 1, 1, 1, 1   i = 1: i, -1, -i, 1   i = 2: -1, 1, -1, 1   i = 3: -i, -1, i, 1   (q' = 0 .. 3)
+        {
+            const float r0a = back<1>(bre[0], bre_prev[0]), r0b = back<2>(bre[0], bre_prev[0]), r0c = back<3>(bre[0], bre_prev[0]);
+            const float i0a = back<1>(bim[0], bim_prev[0]), i0b = back<2>(bim[0], bim_prev[0]), i0c = back<3>(bim[0], bim_prev[0]);
+            yre[0] = bre[0] + r0a + r0b + r0c;
+            yim[0] = bim[0] + i0a + i0b + i0c;
+            const float r1a = back<1>(bre[1], bre_prev[1]), r1b = back<2>(bre[1], bre_prev[1]), r1c = back<3>(bre[1], bre_prev[1]);
+            const float i1a = back<1>(bim[1], bim_prev[1]), i1b = back<2>(bim[1], bim_prev[1]), i1c = back<3>(bim[1], bim_prev[1]);
+            yre[1] = -bim[1] - r1a + i1b + r1c;                      // i z = (-b, a); -z; -i z = (b, -a); z
+            yim[1] = bre[1] - i1a - r1b + i1c;
+            const float r2a = back<1>(bre[2], bre_prev[2]), r2b = back<2>(bre[2], bre_prev[2]), r2c = back<3>(bre[2], bre_prev[2]);
+            const float i2a = back<1>(bim[2], bim_prev[2]), i2b = back<2>(bim[2], bim_prev[2]), i2c = back<3>(bim[2], bim_prev[2]);
+            yre[2] = -bre[2] + r2a - r2b + r2c;
+            yim[2] = -bim[2] + i2a - i2b + i2c;
+            const float r3a = back<1>(bre[3], bre_prev[3]), r3b = back<2>(bre[3], bre_prev[3]), r3c = back<3>(bre[3], bre_prev[3]);
+            const float i3a = back<1>(bim[3], bim_prev[3]), i3b = back<2>(bim[3], bim_prev[3]), i3c = back<3>(bim[3], bim_prev[3]);
+            yre[3] = bim[3] - r3a - i3b + r3c;                       // -i z = (b, -a); -z; i z = (-b, a); z
+            yim[3] = -bre[3] - i3a + r3b + i3c;
+        }
+        // the frame's column scale from its loudest block (a power of two that every wave derives alike: |X| 2^(e - 10) < 2^14)
+        const int ebq = mb != 0u ? eb : 0x7fff;
+        int ef = min(ebq, min((int)__builtin_amdgcn_update_dpp(0x7fff, ebq, 0x111, 0xF, 0xF, false), min((int)__builtin_amdgcn_update_dpp(0x7fff, ebq, 0x112, 0xF, 0xF, false),
+                                                                                                      (int)__builtin_amdgcn_update_dpp(0x7fff, ebq, 0x113, 0xF, 0xF, false))));
+        // (columns n < 3 reach into the previous sub-tile's last blocks)
+        ef = min(ef, min((int)__builtin_amdgcn_update_dpp(0x7fff, eb_prev, 0x10F, 0xF, 0xF, false), min((int)__builtin_amdgcn_update_dpp(0x7fff, eb_prev, 0x10E, 0xF, 0xF, false),
+                                                                                                   (int)__builtin_amdgcn_update_dpp(0x7fff, eb_prev, 0x10D, 0xF, 0xF, false))));
+        ef = ef == 0x7fff ? 0 : ef;
+        const int eu = ef - 10 < -120 ? -120 : (ef - 10 > 120 ? 120 : ef - 10);
+        upc = pow2f(eu);
+        dnc = pow2f(-eu);
+        // this lane group's edge bins -> LDS for its neighbours
+        edges[(par * 32 + 4 * wave + g) * 16 + n] = floatx4{yre[0], yim[0], yre[3], yim[3]};
+        bre_prev = bre; bim_prev = bim; eb_prev = ebq;
+    };
+    auto stage_window = [&](int sp) {                                // sub-tile u - 1 (row block sp of the tile): window taps, |X|, columns
+        const int pe = (int)((u - 1) & 1);                           // (u: this iteration's sub-tile, or one past the tile's last in the drain iteration)
+        const int G = 4 * wave + g;
+        const floatx4 eL = G > 0 ? edges[(pe * 32 + G - 1) * 16 + n] : floatx4{0.f, 0.f, 0.f, 0.f};
+        const floatx4 eR = G < 31 ? edges[(pe * 32 + G + 1) * 16 + n] : floatx4{0.f, 0.f, 0.f, 0.f};
+        const float reL[4] = {eL[2], yre_prev[0], yre_prev[1], yre_prev[2]}, imL[4] = {eL[3], yim_prev[0], yim_prev[1], yim_prev[2]};
+        const float reR[4] = {yre_prev[1], yre_prev[2], yre_prev[3], eR[0]}, imR[4] = {yim_prev[1], yim_prev[2], yim_prev[3], eR[1]};
+        float cv[4], ssq = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const float xr = fmaf(wa0, yre_prev[i], fmaf(wc, reL[i] + reR[i], -wsn * (imL[i] - imR[i])));
+            const float xi = fmaf(wa0, yim_prev[i], fmaf(wsn, reL[i] - reR[i], wc * (imL[i] + imR[i])));
+            cv[i] = __builtin_amdgcn_sqrtf(fmaf(xr, xr, xi * xi));        // zvabs / 2, :329-333 (Y is the DFT itself, not twice it)
+            const bool inb = (unsigned)(fb0 + i) < (unsigned)F;
+            ssq = inb ? fmaf(cv[i], cv[i], ssq) : ssq;
+        }
+        ssq = xor32_sum(xor16_sum(ssq));
+        const int rw = (T - 1) + 16 * sp + n;
+        unsigned h0, l0, h1, l1;
+        split2(cv[0] * up_prev, cv[1] * up_prev, h0, l0);
+        split2(cv[2] * up_prev, cv[3] * up_prev, h1, l1);
+        const int cb = 16 * wave + 4 * g;                            // column index = bin - kb0 (the first layer's fragments are in that order)
+        *reinterpret_cast<uint32x2 *>(colh + rw * CS + cb) = uint32x2{h0, h1};
+        *reinterpret_cast<uint32x2 *>(coll + rw * CS + cb) = uint32x2{l0, l1};
+        if (g == 0) ssf8[rw * kWaves + wave] = ssq;
+        if (wave == 0 && g == 0) fsc[rw] = dn_prev;
+    };
+
+    const bool first_half = wave < kWaves / 2;
+#ifdef SYLDET_B_STAMPS
+    unsigned long long tsum[8] = {0}, tk = 0;
+#define SD_BT(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long now = __builtin_amdgcn_s_memtime(); tsum[i] += now - tk; tk = now; __builtin_amdgcn_sched_barrier(0); }
+    tk = __builtin_amdgcn_s_memtime();
+#else
+#define SD_BT(i)
+#endif
     for (int tr = 0; tr < tiles; tr++) {
-#pragma unroll
         for (int s = 0; s <= kSubs; s++) {
-            // bfr[u & 1] holds sub-tile u's fragments, bmax[(u + 1) % 3] sub-tile u + 1's maxima, edges[(u - 1) & 1] sub-tile u - 1's edge bins
+            // bfr[u & 1] holds sub-tile u's fragments, bmax[(u + 1) & 3] sub-tile u + 1's maxima, edges[(u - 1) & 1] sub-tile u - 1's edge bins
+            SD_BT(0)
             __syncthreads();
-            const bool last_tile = tr + 1 == tiles;
+            SD_BT(1)
             const bool mm = s < kSubs;                               // a sub-tile to multiply in this iteration
-            Raw r3;
-            floatx4 yre = yre_prev, yim = yim_prev;
-            float upc = 0.0f, dnc = 0.0f;
-            if (mm) {
-                const int par = (int)(u & 1);
-                const bool more = !(last_tile && s == kSubs - 1);   // a sub-tile u + 1 follows
-                if (tid < 16) bmax[((u + 3) & 3) * 16 + tid] = 0u;   // (sub-tile u - 1's slot: read for the last time before this barrier)
-                r3 = load_raw(blk_of(u + 2));                        // (past the recording: zeros from the descriptor's bounds check)
-                (void)more;
-                fold_store(r1, (int)((u + 1) & 3), par ? bfr0 : bfr1);
-                // ---- B'_n[k] for this wave's bins: cosine rows against the sums, sine rows against the differences
-                const uint32x4 *bf = reinterpret_cast<const uint32x4 *>(par ? bfr1 : bfr0);
-                floatx4 are = {0.f, 0.f, 0.f, 0.f}, aim = are;
-#pragma unroll
-                for (int ks = 0; ks < KS; ks++) {
-                    const half8 bsh = as_half8(bf[(0 * KS + ks) * 64 + lane]), bsl = as_half8(bf[(1 * KS + ks) * 64 + lane]);
-                    const half8 bdh = as_half8(bf[(2 * KS + ks) * 64 + lane]), bdl = as_half8(bf[(3 * KS + ks) * 64 + lane]);
-                    are = mfma(ac[ks][0], bsh, are);
-                    aim = mfma(as_[ks][0], bdh, aim);
-                    are = mfma(ac[ks][0], bsl, are);
-                    aim = mfma(as_[ks][0], bdl, aim);
-                    are = mfma(ac[ks][1], bsh, are);
-                    aim = mfma(as_[ks][1], bdh, aim);
-                }
-                // the block's first sample (its real part; the imaginary part rode in slot 0), then back to true units
-                const unsigned mb = bmax[(u & 3) * 16 + n];
-                const int eb = scale_exp(mb);
-                const float x0s = x0buf[(u & 3) * 16 + n] * pow2f(eb);
-                const float un = pow2f(-eb - 13);
-                floatx4 bre, bim;
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    bre[i] = fmaf(cre[i], x0s, are[i]) * un;
-                    bim[i] = aim[i] * un;
-                }
-                // ---- frames end on their last block: Y'_n = sum_{q' < 4} (-i)^{k (3 - q')} B'_{n - q'}, k = i (mod 4)
-                //      i = 0: 1, 1, 1, 1   i = 1: i, -1, -i, 1   i = 2: -1, 1, -1, 1   i = 3: -i, -1, i, 1   (q' = 0 .. 3)
-                {
-                    const float r0a = back<1>(bre[0], bre_prev[0]), r0b = back<2>(bre[0], bre_prev[0]), r0c = back<3>(bre[0], bre_prev[0]);
-                    const float i0a = back<1>(bim[0], bim_prev[0]), i0b = back<2>(bim[0], bim_prev[0]), i0c = back<3>(bim[0], bim_prev[0]);
-                    yre[0] = bre[0] + r0a + r0b + r0c;
-                    yim[0] = bim[0] + i0a + i0b + i0c;
-                    const float r1a = back<1>(bre[1], bre_prev[1]), r1b = back<2>(bre[1], bre_prev[1]), r1c = back<3>(bre[1], bre_prev[1]);
-                    const float i1a = back<1>(bim[1], bim_prev[1]), i1b = back<2>(bim[1], bim_prev[1]), i1c = back<3>(bim[1], bim_prev[1]);
-                    yre[1] = -bim[1] - r1a + i1b + r1c;              // i z = (-b, a); -z; -i z = (b, -a); z
-                    yim[1] = bre[1] - i1a - r1b + i1c;
-                    const float r2a = back<1>(bre[2], bre_prev[2]), r2b = back<2>(bre[2], bre_prev[2]), r2c = back<3>(bre[2], bre_prev[2]);
-                    const float i2a = back<1>(bim[2], bim_prev[2]), i2b = back<2>(bim[2], bim_prev[2]), i2c = back<3>(bim[2], bim_prev[2]);
-                    yre[2] = -bre[2] + r2a - r2b + r2c;
-                    yim[2] = -bim[2] + i2a - i2b + i2c;
-                    const float r3a = back<1>(bre[3], bre_prev[3]), r3b = back<2>(bre[3], bre_prev[3]), r3c = back<3>(bre[3], bre_prev[3]);
-                    const float i3a = back<1>(bim[3], bim_prev[3]), i3b = back<2>(bim[3], bim_prev[3]), i3c = back<3>(bim[3], bim_prev[3]);
-                    yre[3] = bim[3] - r3a - i3b + r3c;               // -i z = (b, -a); -z; i z = (-b, a); z
-                    yim[3] = -bre[3] - i3a + r3b + i3c;
-                }
-                // the frame's column scale from its loudest block (a power of two that every wave derives alike: |X| 2^(e - 10) < 2^14)
-                const int ebq = mb != 0u ? eb : 0x7fff;
-                int ef = min(ebq, min((int)__builtin_amdgcn_update_dpp(0x7fff, ebq, 0x111, 0xF, 0xF, false), min((int)__builtin_amdgcn_update_dpp(0x7fff, ebq, 0x112, 0xF, 0xF, false),
-                                                                                                              (int)__builtin_amdgcn_update_dpp(0x7fff, ebq, 0x113, 0xF, 0xF, false))));
-                // (columns n < 3 reach into the previous sub-tile's last blocks)
-                ef = min(ef, min((int)__builtin_amdgcn_update_dpp(0x7fff, eb_prev, 0x10F, 0xF, 0xF, false), min((int)__builtin_amdgcn_update_dpp(0x7fff, eb_prev, 0x10E, 0xF, 0xF, false),
-                                                                                                           (int)__builtin_amdgcn_update_dpp(0x7fff, eb_prev, 0x10D, 0xF, 0xF, false))));
-                ef = ef == 0x7fff ? 0 : ef;
-                const int eu = ef - 10 < -120 ? -120 : (ef - 10 > 120 ? 120 : ef - 10);
-                upc = pow2f(eu);
-                dnc = pow2f(-eu);
-                // this lane group's edge bins -> LDS for its neighbours
-                edges[(par * 16 + n) * 32 + 4 * wave + g] = floatx4{yre[0], yim[0], yre[3], yim[3]};
-                bre_prev = bre; bim_prev = bim; eb_prev = ebq;
-            }
-            if (s >= 1) {
-                // ---- sub-tile u - 1 (or, in the drain iteration, the tile's last): window taps, |X|, columns.  Row of frame n:
-                const int sp = s - 1;
-                const int pe = (int)((u - 1) & 1);                   // (u: this iteration's sub-tile, or one past the tile's last in the drain iteration)
-                const int G = 4 * wave + g;
-                const floatx4 eL = G > 0 ? edges[(pe * 16 + n) * 32 + G - 1] : floatx4{0.f, 0.f, 0.f, 0.f};
-                const floatx4 eR = G < 31 ? edges[(pe * 16 + n) * 32 + G + 1] : floatx4{0.f, 0.f, 0.f, 0.f};
-                const float reL[4] = {eL[2], yre_prev[0], yre_prev[1], yre_prev[2]}, imL[4] = {eL[3], yim_prev[0], yim_prev[1], yim_prev[2]};
-                const float reR[4] = {yre_prev[1], yre_prev[2], yre_prev[3], eR[0]}, imR[4] = {yim_prev[1], yim_prev[2], yim_prev[3], eR[1]};
-                float cv[4], ssq = 0.0f;
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const float xr = fmaf(wa0, yre_prev[i], fmaf(wc, reL[i] + reR[i], -wsn * (imL[i] - imR[i])));
-                    const float xi = fmaf(wa0, yim_prev[i], fmaf(wsn, reL[i] - reR[i], wc * (imL[i] + imR[i])));
-                    cv[i] = __builtin_amdgcn_sqrtf(fmaf(xr, xr, xi * xi));        // zvabs / 2, :329-333 (Y is the DFT itself, not twice it)
-                    const bool inb = (unsigned)(fb0 + i) < (unsigned)F;
-                    ssq = inb ? fmaf(cv[i], cv[i], ssq) : ssq;
-                }
-                ssq = xor32_sum(xor16_sum(ssq));
-                const int rw = (T - 1) + 16 * sp + n;
-                unsigned h0, l0, h1, l1;
-                split2(cv[0] * up_prev, cv[1] * up_prev, h0, l0);
-                split2(cv[2] * up_prev, cv[3] * up_prev, h1, l1);
-                const int cb = 16 * wave + 4 * g;                    // column index = bin - kb0 (the first layer's fragments are in that order)
-                *reinterpret_cast<uint32x2 *>(colh + rw * CS + cb) = uint32x2{h0, h1};
-                *reinterpret_cast<uint32x2 *>(coll + rw * CS + cb) = uint32x2{l0, l1};
-                if (g == 0) ssf8[rw * kWaves + wave] = ssq;
-                if (wave == 0 && g == 0) fsc[rw] = dn_prev;
+            // (SYLDET_B_NO*: diagnostic builds with one stage knocked out, tools/knockouts.sh; never the shipped library)
+#if defined(SYLDET_B_NOMFMA) || defined(SYLDET_B_NOMW)
+            const bool do_m = false;
+#else
+            const bool do_m = mm;
+#endif
+#if defined(SYLDET_B_NOWINDOW) || defined(SYLDET_B_NOMW)
+            const bool do_w = false;
+#else
+            const bool do_w = s >= 1;
+#endif
+            if (first_half) {
+                if (do_m) stage_mfma();
+                SD_BT(2)
+                if (mm) stage_load_fold();
+                SD_BT(3)
+                if (do_w) stage_window(s - 1);
+                SD_BT(4)
+            } else {
+                if (mm) stage_load_fold();
+                SD_BT(3)
+                if (do_w) stage_window(s - 1);
+                SD_BT(4)
+                if (do_m) stage_mfma();
+                SD_BT(2)
             }
             if (mm) {
-                // ---- sub-tile u + 2's block maxima; the stream moves on
-                raw_max(r3, bmax + ((u + 2) & 3) * 16);
+                // ---- sub-tile u + 2's block maxima (its samples were loaded an iteration ago); the stream moves on
+                raw_max(r2, bmax + ((u + 2) & 3) * 16);
                 yre_prev = yre; yim_prev = yim; up_prev = upc; dn_prev = dnc;
-                r1 = r3;
+                r1 = r2;
+                r2 = r3;
                 u++;
             }
         }
+        SD_BT(0)
         __syncthreads();
+        SD_BT(1)
         // ---- the frames' sums of squares from the waves' partial sums, in a fixed order
         if (tid < kTile) {
             float a = 0.0f;
@@ -355,6 +409,7 @@ bdft_net_kernel(const MlpxDesc d, const BdftDesc bd, const float *__restrict__ s
             if (tid >= T - 1) ssf[tid] = a;                          // (rows 0 .. T-2 were carried)
         }
         // ---- tap products of this wave's 16 rows, P[(t, h), j] for all taps at once (three row tiles), back to true units
+#ifndef SYLDET_B_NOTAPS
         {
             const int fr = 16 * wave + n;
             const _Float16 *bph = colh + fr * CS + 8 * g, *bpl = coll + fr * CS + 8 * g;
@@ -375,30 +430,51 @@ bdft_net_kernel(const MlpxDesc d, const BdftDesc bd, const float *__restrict__ s
 #pragma unroll
             for (int m = 0; m < 3; m++) *reinterpret_cast<floatx4 *>(pbuf + fr * PS + 4 * (4 * m + g)) = acc[m] * dn;
         }
+#endif
         __syncthreads();
-        // ---- evaluations, one thread each: row r starts the window of evaluation fbase + kNew tr + r - (T - 1) ... r + T - 1
-        if (tid < kNew) {
+#ifndef SYLDET_B_NOEVAL
+        // ---- evaluations, four threads each: row r starts the window of evaluation fbase + kNew tr + r - (T - 1); thread j of the
+        // four takes taps j, j + 4, j + 8 and then hidden unit j (quad permutes carry the sums)
+        if (tid < 4 * kNew) {
+            const int r = tid >> 2, j = tid & 3;
             floatx4 z = {0.f, 0.f, 0.f, 0.f};
             float ssw = 0.0f;
-            for (int t = 0; t < T; t++) {
-                z += *reinterpret_cast<const floatx4 *>(pbuf + (tid + t) * PS + 4 * t);
-                ssw += ssf[tid + t];
+#pragma unroll
+            for (int tt = 0; tt < 3; tt++) {
+                const int t = j + 4 * tt;
+                if (t < T) {
+                    z += *reinterpret_cast<const floatx4 *>(pbuf + (r + t) * PS + 4 * t);
+                    ssw += ssf[r + t];
+                }
             }
+            auto quad_sum = [](float v) {
+                v += __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+                v += __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+                return v;
+            };
+            ssw = quad_sum(ssw);
+            float zs[4];
+#pragma unroll
+            for (int h = 0; h < 4; h++) zs[h] = quad_sum(z[h]);
             const float alpha = d.w_unscale * __builtin_amdgcn_rsqf(ssw);
+            // TanSig hidden unit j (rows past H meet zero weights), linear output
+            const float zu = j == 0 ? zs[0] : (j == 1 ? zs[1] : (j == 2 ? zs[2] : zs[3]));
+            const float a = fmaf(alpha, zu, b0[j == 0 ? 0 : (j == 1 ? 1 : (j == 2 ? 2 : 3))]);
+            const float th = fmaf(-2.0f, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(a * 2.885390081777927f) + 1.0f), 1.0f);
+            // the second layer in the reference's order of units: y = b1 + w1[0] th0 + w1[1] th1 + ... (every lane of the four forms it alike)
+            float thq[4];
+#pragma unroll
+            for (int h = 0; h < 4; h++) thq[h] = quad_sum(j == h ? th : 0.0f);
             float y = d.b1;
 #pragma unroll
-            for (int j = 0; j < 4; j++) {             // TanSig hidden units (rows past H meet zero weights), linear output
-                const float a = fmaf(alpha, z[j], b0[j]);
-                const float th = fmaf(-2.0f, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(a * 2.885390081777927f) + 1.0f), 1.0f);
-                y = fmaf(w1[j], th, y);
-            }
+            for (int h = 0; h < 4; h++) y = fmaf(w1[h], thq[h], y);
             y = (y - d.oa) / d.og + d.ob;
-            const int64_t e = fbase + (int64_t)kNew * tr + tid;      // row tid is frame fbase + kNew tr + tid - (T - 1): the window's first
-            const int64_t ev = e - (T - 1);
-            const bool st = ev >= E0 && ev < E1;
+            const int64_t ev = fbase + (int64_t)kNew * tr + r - (T - 1);
+            const bool st = j == 0 && ev >= E0 && ev < E1;
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y), out_rs, st ? (unsigned)ev * 4u : 0xFFFFFFFFu, 0, 0);
             __builtin_amdgcn_raw_buffer_store_b8((unsigned char)((double)y >= thr ? 1 : 0), flg_rs, st ? (unsigned)ev : 0xFFFFFFFFu, 0, 0);
         }
+#endif
         __syncthreads();                              // (the products are read: the second fragment buffer and the edges are free again)
         // ---- the last T - 1 frames are the next tile's first: their columns, sums and exponents move to the front
         if (tr + 1 < tiles) {
@@ -413,7 +489,13 @@ bdft_net_kernel(const MlpxDesc d, const BdftDesc bd, const float *__restrict__ s
                 fsc[tid] = fsc[kNew + tid];
             }
         }
+        SD_BT(5)
     }
+#ifdef SYLDET_B_STAMPS
+    if (lane == 0 && (wave == 0 || wave == 4))
+        for (int i = 0; i < 8; i++) atomicAdd(&g_bdft_stamps[(wave ? 8 : 0) + i], tsum[i]);
+#endif
+#undef SD_BT
 }
 
 }  // namespace
@@ -434,12 +516,29 @@ hipError_t launch_bdft_net(const MlpxDesc &d, const BdftDesc &bd, const float *s
     const int frag = 4 * KS * 1024;
     const int lds = 3 * 4 * 2 * 1024 + 2 * kTile * d.col_stride * 2 + 2 * kTile * 4 + 2 * frag + 2 * 16 * 32 * 16 + kTile * kWaves * 4 + 2 * 4 * 16 * 4;
     if (lds > 160 * 1024 || kTile * d.p_stride * 4 > frag + 2 * 16 * 32 * 16) return hipErrorInvalidValue;
+#ifdef SYLDET_B_STAMPS
+#define SD_BDFT_STAMP_REPORT                                                                                                   \
+    {                                                                                                                          \
+        unsigned long long hs[16];                                                                                             \
+        hipStreamSynchronize(stream);                                                                                          \
+        hipMemcpyFromSymbol(hs, HIP_SYMBOL(g_bdft_stamps), sizeof(hs));                                                        \
+        const double wg = (double)runs * C;                                                                                    \
+        static const char *nm[8] = {"work before the barrier -> arrival", "barrier wait", "MFMA + sliding sum + edges", "load + fold", "window + columns", "tile end (sums, taps, evaluation, carry)", "-", "-"}; \
+        for (int w = 0; w < 2; w++)                                                                                            \
+            for (int i = 0; i < 6; i++) std::fprintf(stderr, "[bdft stamps] wave %d  %-42s %10.0f cycles per workgroup\n", 4 * w, nm[i], (double)hs[8 * w + i] / wg); \
+        unsigned long long z[16] = {0};                                                                                        \
+        hipMemcpyToSymbol(HIP_SYMBOL(g_bdft_stamps), z, sizeof(z));                                                            \
+    }
+#else
+#define SD_BDFT_STAMP_REPORT
+#endif
 #define SD_BDFT_GO(KS_)                                                                                                        \
     if (KS == KS_) {                                                                                                           \
         auto kern = bdft_net_kernel<KS_>;                                                                                      \
         hipError_t st = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);              \
         if (st != hipSuccess) return st;                                                                                       \
         hipLaunchKernelGGL(kern, grid, dim3(kBlock), (size_t)lds, stream, d, bd, samples, stride, S, J, E, evals_per_run, outputs, flags); \
+        SD_BDFT_STAMP_REPORT                                                                                                   \
         return hipGetLastError();                                                                                              \
     }
     SD_BDFT_GO(4) SD_BDFT_GO(2)
