@@ -32,6 +32,7 @@ struct MlpxPlan {
 struct BdftPlan {
     bool ok = false;
     BdftDesc desc{};
+    MlpxDesc md{};                   // the network stage's descriptor with 128-bin columns (filled in by the owner after upload)
     std::vector<uint16_t> basis, afrag;
     std::vector<float> cre;
 };

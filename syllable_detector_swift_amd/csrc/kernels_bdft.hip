@@ -110,13 +110,14 @@ bdft_net_kernel(const MlpxDesc d, const BdftDesc bd, const float *__restrict__ s
     float *ssf = reinterpret_cast<float *>(coll + kTile * CS);       // [tile] per-frame sums of squares (true units)
     float *fsc = ssf + kTile;                                        // [tile] a frame's products back to true units
     unsigned char *scr = reinterpret_cast<unsigned char *>(fsc + kTile);
-    constexpr int kFragBytes = 4 * KS * 1024;                        // s hi, s lo, d hi, d lo: KS fragments each
+    constexpr int kFragBytes = 4 * KS * 1024 < 16384 ? 16384 : 4 * KS * 1024;   // s hi, s lo, d hi, d lo: KS fragments each (and room for the products)
     uint32x2 *bfr0 = reinterpret_cast<uint32x2 *>(scr), *bfr1 = reinterpret_cast<uint32x2 *>(scr + kFragBytes);
     floatx4 *edges = reinterpret_cast<floatx4 *>(scr + 2 * kFragBytes);                  // [2 parities][16 frames][32 lane groups] (re0, im0, re3, im3)
     float *pbuf = reinterpret_cast<float *>(scr + kFragBytes);                           // [tile][PS] over buffer 1 and the edges
     float *ssf8 = reinterpret_cast<float *>(scr + 2 * kFragBytes + 2 * 16 * 32 * 16);   // [tile][8 waves]
     unsigned *bmax = reinterpret_cast<unsigned *>(ssf8 + kTile * kWaves);                 // [4][16] block maxima (bit patterns of |x|), by sub-tile & 3
     float *x0buf = reinterpret_cast<float *>(bmax + 64);                                  // [4][16] the blocks' first samples
+    int *efb = reinterpret_cast<int *>(x0buf + 64);                                       // [4][16] the frames' scale exponents (their loudest block's)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -182,7 +183,13 @@ bdft_net_kernel(const MlpxDesc d, const BdftDesc bd, const float *__restrict__ s
         float m = absmax3(absmax3(0.0f, r.p[0], r.p[1]), r.p[2], r.p[3]);
         m = absmax3(absmax3(m, r.q[0], r.q[1]), r.q[2], r.q[3]);
         m = absmax3(m, r.z, r.x0);
-        if (folder) atomicMax(slot + n, __float_as_uint(m));         // (v_max3 drops NaNs: non-negative numbers compare as their bits)
+        // the four lanes of this wave that share a block first (two swaps), then one LDS atomic a block and wave instead of four
+        unsigned mu = __float_as_uint(m);                            // (v_max3 drops NaNs: non-negative numbers compare as their bits)
+        auto rr = __builtin_amdgcn_permlane16_swap(mu, mu, false, false);
+        mu = max(rr[0], rr[1]);
+        rr = __builtin_amdgcn_permlane32_swap(mu, mu, false, false);
+        mu = max(rr[0], rr[1]);
+        if (folder && g == 0) atomicMax(slot + n, mu);
     };
     auto scale_exp = [](unsigned bits) {                             // 2^e puts the block's loudest sample into [2^13, 2^14)
         const int ex = (int)((bits >> 23) & 0xffu);
@@ -194,6 +201,16 @@ bdft_net_kernel(const MlpxDesc d, const BdftDesc bd, const float *__restrict__ s
         if (!folder) return;
         const unsigned *slot = bmax + 16 * slt;
         if (wave == 0 && g == 0) x0buf[16 * slt + n] = r.x0;
+        if (wave == 1 && g == 0) {                                   // the frame ending on block n: the loudest of its four blocks (silent ones do not count)
+            const unsigned *prevs = bmax + 16 * ((slt + 3) & 3);      // (the sub-tile before this one)
+            int e = 0x7fff;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const unsigned mbq = n - q >= 0 ? slot[n - q] : prevs[16 + n - q];
+                e = mbq != 0u ? min(e, scale_exp(mbq)) : e;
+            }
+            efb[16 * slt + n] = e == 0x7fff ? 0 : e;
+        }
         const float sx = pow2f(scale_exp(slot[n]));
         const float xp[4] = {r.p[0], r.p[1], r.p[2], r.p[3]};
         const float xm[4] = {r.z, r.q[3], r.q[2], r.q[1]};           // x[c - m - j]
@@ -225,9 +242,10 @@ bdft_net_kernel(const MlpxDesc d, const BdftDesc bd, const float *__restrict__ s
     // ---- the stream's state
     floatx4 yre_prev = {0.f, 0.f, 0.f, 0.f}, yim_prev = yre_prev;   // sub-tile u-1: Y' of this lane's four bins for the frame ending at block n
     floatx4 bre_prev = yre_prev, bim_prev = yre_prev;               // sub-tile u-1: the blocks' own partial transforms (true units), for the carry
-    int eb_prev = 0x7fff;                                            // ... and the blocks' scale exponents (0x7fff: a silent block does not count)
+    floatx4 vre_prev = yre_prev, vim_prev = yre_prev;               // ... and the first level of the sliding sum
     float up_prev = 0.0f, dn_prev = 0.0f;                            // ... and the frames' column scales
     int64_t u = 0;                                                   // sub-tile counter of the run
+    int rbase = 0;                                                   // the tile's first (carried) row in the ring of 128 column rows: no copying between tiles
     auto blk_of = [&](int64_t uu) { return fbase + 16 * uu + (R - 1); };   // first block of sub-tile uu (frames end on their last block)
 
     // prologue: sub-tiles 0, 1 and 2 loaded, the maxima of the first two taken, sub-tile 0 folded.  In the loop a sub-tile's
@@ -285,40 +303,26 @@ bdft_net_kernel(const MlpxDesc d, const BdftDesc bd, const float *__restrict__ s
             bre[i] = fmaf(cre[i], x0s, are[i]) * un;
             bim[i] = aim[i] * un;
         }
-        // ---- frames end on their last block: Y'_n = sum_{q' < 4} (-i)^{k (3 - q')} B'_{n - q'}, k = i (mod 4)
-        //      i = 0: 1, 1, 1, 1   i = 1: i, -1, -i, 1   i = 2: -1, 1, -1, 1   i = 3: -i, -1, i, 1   (q' = 0 .. 3)
-        {
-            const float r0a = back<1>(bre[0], bre_prev[0]), r0b = back<2>(bre[0], bre_prev[0]), r0c = back<3>(bre[0], bre_prev[0]);
-            const float i0a = back<1>(bim[0], bim_prev[0]), i0b = back<2>(bim[0], bim_prev[0]), i0c = back<3>(bim[0], bim_prev[0]);
-            yre[0] = bre[0] + r0a + r0b + r0c;
-            yim[0] = bim[0] + i0a + i0b + i0c;
-            const float r1a = back<1>(bre[1], bre_prev[1]), r1b = back<2>(bre[1], bre_prev[1]), r1c = back<3>(bre[1], bre_prev[1]);
-            const float i1a = back<1>(bim[1], bim_prev[1]), i1b = back<2>(bim[1], bim_prev[1]), i1c = back<3>(bim[1], bim_prev[1]);
-            yre[1] = -bim[1] - r1a + i1b + r1c;                      // i z = (-b, a); -z; -i z = (b, -a); z
-            yim[1] = bre[1] - i1a - r1b + i1c;
-            const float r2a = back<1>(bre[2], bre_prev[2]), r2b = back<2>(bre[2], bre_prev[2]), r2c = back<3>(bre[2], bre_prev[2]);
-            const float i2a = back<1>(bim[2], bim_prev[2]), i2b = back<2>(bim[2], bim_prev[2]), i2c = back<3>(bim[2], bim_prev[2]);
-            yre[2] = -bre[2] + r2a - r2b + r2c;
-            yim[2] = -bim[2] + i2a - i2b + i2c;
-            const float r3a = back<1>(bre[3], bre_prev[3]), r3b = back<2>(bre[3], bre_prev[3]), r3c = back<3>(bre[3], bre_prev[3]);
-            const float i3a = back<1>(bim[3], bim_prev[3]), i3b = back<2>(bim[3], bim_prev[3]), i3c = back<3>(bim[3], bim_prev[3]);
-            yre[3] = bim[3] - r3a - i3b + r3c;                       // -i z = (b, -a); -z; i z = (-b, a); z
-            yim[3] = -bre[3] - i3a + r3b + i3c;
-        }
-        // the frame's column scale from its loudest block (a power of two that every wave derives alike: |X| 2^(e - 10) < 2^14)
-        const int ebq = mb != 0u ? eb : 0x7fff;
-        int ef = min(ebq, min((int)__builtin_amdgcn_update_dpp(0x7fff, ebq, 0x111, 0xF, 0xF, false), min((int)__builtin_amdgcn_update_dpp(0x7fff, ebq, 0x112, 0xF, 0xF, false),
-                                                                                                      (int)__builtin_amdgcn_update_dpp(0x7fff, ebq, 0x113, 0xF, 0xF, false))));
-        // (columns n < 3 reach into the previous sub-tile's last blocks)
-        ef = min(ef, min((int)__builtin_amdgcn_update_dpp(0x7fff, eb_prev, 0x10F, 0xF, 0xF, false), min((int)__builtin_amdgcn_update_dpp(0x7fff, eb_prev, 0x10E, 0xF, 0xF, false),
-                                                                                                   (int)__builtin_amdgcn_update_dpp(0x7fff, eb_prev, 0x10D, 0xF, 0xF, false))));
-        ef = ef == 0x7fff ? 0 : ef;
+        // ---- frames end on their last block: Y'_n = sum_{q' < 4} rho^(3 - q') B'_{n - q'} with rho = (-i)^k, k = i (mod 4):
+        // 1, -i, -1, i for i = 0 .. 3.  In two levels: V_n = rho B'_n + B'_{n-1}, Y'_n = rho^2 V_n + V_{n-2} -- two shifts a value
+        // instead of three (the previous sub-tile's last columns carry: B' for the first level, V for the second).
+        floatx4 vre, vim;
+        vre[0] = bre[0] + back<1>(bre[0], bre_prev[0]);   vim[0] = bim[0] + back<1>(bim[0], bim_prev[0]);      // rho = 1
+        vre[1] = bim[1] + back<1>(bre[1], bre_prev[1]);   vim[1] = -bre[1] + back<1>(bim[1], bim_prev[1]);     // -i z = (b, -a)
+        vre[2] = -bre[2] + back<1>(bre[2], bre_prev[2]);  vim[2] = -bim[2] + back<1>(bim[2], bim_prev[2]);     // -z
+        vre[3] = -bim[3] + back<1>(bre[3], bre_prev[3]);  vim[3] = bre[3] + back<1>(bim[3], bim_prev[3]);      // i z = (-b, a)
+        yre[0] = vre[0] + back<2>(vre[0], vre_prev[0]);   yim[0] = vim[0] + back<2>(vim[0], vim_prev[0]);      // rho^2 = 1
+        yre[1] = -vre[1] + back<2>(vre[1], vre_prev[1]);  yim[1] = -vim[1] + back<2>(vim[1], vim_prev[1]);     // -1
+        yre[2] = vre[2] + back<2>(vre[2], vre_prev[2]);   yim[2] = vim[2] + back<2>(vim[2], vim_prev[2]);      // 1
+        yre[3] = -vre[3] + back<2>(vre[3], vre_prev[3]);  yim[3] = -vim[3] + back<2>(vim[3], vim_prev[3]);     // -1
+        // the frame's column scale from its loudest block (every wave reads the same power of two: |X| 2^(e - 10) < 2^14)
+        const int ef = efb[(u & 3) * 16 + n];
         const int eu = ef - 10 < -120 ? -120 : (ef - 10 > 120 ? 120 : ef - 10);
         upc = pow2f(eu);
         dnc = pow2f(-eu);
         // this lane group's edge bins -> LDS for its neighbours
         edges[(par * 32 + 4 * wave + g) * 16 + n] = floatx4{yre[0], yim[0], yre[3], yim[3]};
-        bre_prev = bre; bim_prev = bim; eb_prev = ebq;
+        bre_prev = bre; bim_prev = bim; vre_prev = vre; vim_prev = vim;
     };
     auto stage_window = [&](int sp) {                                // sub-tile u - 1 (row block sp of the tile): window taps, |X|, columns
         const int pe = (int)((u - 1) & 1);                           // (u: this iteration's sub-tile, or one past the tile's last in the drain iteration)
@@ -337,7 +341,7 @@ bdft_net_kernel(const MlpxDesc d, const BdftDesc bd, const float *__restrict__ s
             ssq = inb ? fmaf(cv[i], cv[i], ssq) : ssq;
         }
         ssq = xor32_sum(xor16_sum(ssq));
-        const int rw = (T - 1) + 16 * sp + n;
+        const int rw = (rbase + (T - 1) + 16 * sp + n) & (kTile - 1);
         unsigned h0, l0, h1, l1;
         split2(cv[0] * up_prev, cv[1] * up_prev, h0, l0);
         split2(cv[2] * up_prev, cv[3] * up_prev, h1, l1);
@@ -349,6 +353,9 @@ bdft_net_kernel(const MlpxDesc d, const BdftDesc bd, const float *__restrict__ s
     };
 
     const bool first_half = wave < kWaves / 2;
+#ifdef SYLDET_B_PRIO                  // (experiment: the younger wave of a SIMD loses every arbitration and finishes ~600 cycles behind its partner)
+    if (!first_half) __builtin_amdgcn_s_setprio(1);
+#endif
 #ifdef SYLDET_B_STAMPS
     unsigned long long tsum[8] = {0}, tk = 0;
 #define SD_BT(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long now = __builtin_amdgcn_s_memtime(); tsum[i] += now - tk; tk = now; __builtin_amdgcn_sched_barrier(0); }
@@ -406,7 +413,7 @@ bdft_net_kernel(const MlpxDesc d, const BdftDesc bd, const float *__restrict__ s
             float a = 0.0f;
 #pragma unroll
             for (int w = 0; w < kWaves; w++) a += ssf8[tid * kWaves + w];
-            if (tid >= T - 1) ssf[tid] = a;                          // (rows 0 .. T-2 were carried)
+            ssf[tid] = a;                                            // (a carried row's partial sums are still in place: the same sum again)
         }
         // ---- tap products of this wave's 16 rows, P[(t, h), j] for all taps at once (three row tiles), back to true units
 #ifndef SYLDET_B_NOTAPS
@@ -443,8 +450,9 @@ bdft_net_kernel(const MlpxDesc d, const BdftDesc bd, const float *__restrict__ s
             for (int tt = 0; tt < 3; tt++) {
                 const int t = j + 4 * tt;
                 if (t < T) {
-                    z += *reinterpret_cast<const floatx4 *>(pbuf + (r + t) * PS + 4 * t);
-                    ssw += ssf[r + t];
+                    const int rr = (rbase + r + t) & (kTile - 1);
+                    z += *reinterpret_cast<const floatx4 *>(pbuf + rr * PS + 4 * t);
+                    ssw += ssf[rr];
                 }
             }
             auto quad_sum = [](float v) {
@@ -475,20 +483,8 @@ bdft_net_kernel(const MlpxDesc d, const BdftDesc bd, const float *__restrict__ s
             __builtin_amdgcn_raw_buffer_store_b8((unsigned char)((double)y >= thr ? 1 : 0), flg_rs, st ? (unsigned)ev : 0xFFFFFFFFu, 0, 0);
         }
 #endif
-        __syncthreads();                              // (the products are read: the second fragment buffer and the edges are free again)
-        // ---- the last T - 1 frames are the next tile's first: their columns, sums and exponents move to the front
-        if (tr + 1 < tiles) {
-            const int words = (T - 1) * (CS / 2);     // 32-bit words per array
-            for (int i = tid; i < 2 * words; i += kBlock) {
-                unsigned *arr = reinterpret_cast<unsigned *>(i < words ? colh : coll);
-                const int w = i < words ? i : i - words;
-                arr[w] = arr[kNew * (CS / 2) + w];
-            }
-            if (tid < T - 1) {
-                ssf[tid] = ssf[kNew + tid];
-                fsc[tid] = fsc[kNew + tid];
-            }
-        }
+        rbase = (rbase + kNew) & (kTile - 1);          // the last T - 1 rows are the next tile's first: the ring moves on, nothing is copied
+        // (the next iteration's barrier also says that the products are read: the second fragment buffer and the edges are free again)
         SD_BT(5)
     }
 #ifdef SYLDET_B_STAMPS
@@ -513,8 +509,8 @@ hipError_t launch_bdft_net(const MlpxDesc &d, const BdftDesc &bd, const float *s
     const int64_t runs = (E + evals_per_run - 1) / evals_per_run;
     dim3 grid((unsigned)runs, (unsigned)C);
     const int KS = bd.hop / 64;
-    const int frag = 4 * KS * 1024;
-    const int lds = 3 * 4 * 2 * 1024 + 2 * kTile * d.col_stride * 2 + 2 * kTile * 4 + 2 * frag + 2 * 16 * 32 * 16 + kTile * kWaves * 4 + 2 * 4 * 16 * 4;
+    const int frag = 4 * KS * 1024 < 16384 ? 16384 : 4 * KS * 1024;
+    const int lds = 3 * 4 * 2 * 1024 + 2 * kTile * d.col_stride * 2 + 2 * kTile * 4 + 2 * frag + 2 * 16 * 32 * 16 + kTile * kWaves * 4 + 3 * 4 * 16 * 4;
     if (lds > 160 * 1024 || kTile * d.p_stride * 4 > frag + 2 * 16 * 32 * 16) return hipErrorInvalidValue;
 #ifdef SYLDET_B_STAMPS
 #define SD_BDFT_STAMP_REPORT                                                                                                   \

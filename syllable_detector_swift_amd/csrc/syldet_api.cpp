@@ -491,6 +491,9 @@ int upload_bdft(syldet *h)
     p.desc.basis = (const uint4 *)base;
     p.desc.cre = (const float *)(base + b_bytes);
     p.desc.afrag = (const uint4 *)(base + b_bytes + c_bytes);
+    p.md = h->mlpx.desc;                 // (its device pointers are in place: upload_mlpx ran first)
+    p.md.KB = 4;
+    p.md.col_stride = 32 * 4 + 8;
     return SYLDET_OK;
 }
 
@@ -673,7 +676,7 @@ int run_on_stream(syldet *h, const float *d_samples, int64_t S, int64_t stride, 
     // frames of four hops: every block transformed once on the matrix cores, then the same network stage -- one launch
     if (h->bdft.ok && !h->sw.no_bdft && (uint64_t)E * 4u < 0xFFFFFFF0ull && (uint64_t)S * 4u < 0x7fffffffull) {
         KernelTimer t(h, stream, "bdft_net_kernel");
-        SYLDET_HIP(launch_bdft_net(h->mlpx.desc, h->bdft.desc, d_samples, stride, C, S, J, E, d_outputs, d_flags, stream));
+        SYLDET_HIP(launch_bdft_net(h->bdft.md, h->bdft.desc, d_samples, stride, C, S, J, E, d_outputs, d_flags, stream));
         return SYLDET_OK;
     }
     if (h->mlpx.ok && !h->sw.no_fft1k && (uint64_t)E * 4u < 0xFFFFFFF0ull &&

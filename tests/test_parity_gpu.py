@@ -720,7 +720,11 @@ def test_network_stage_on_the_matrix_cores(oracle_lib, N, lo, hi, T, H, scaling)
     o = util.oracle_for(cfg)
     # (1024-point frames in front of a network of this class: the one-launch kernel where its shape applies)
     one_launch = N == 1024 and scaling == "linear" and F % 4 == 0
-    for engine, kernel in ((_abi.ENGINE_AUTO, "fft1k_net_kernel" if one_launch else "mlp_mfma_kernel"), (_abi.ENGINE_GENERIC, "mlp_generic_kernel")):
+    # (frames of four hops -- these are -- with 512 or 1024 points and a band that fits 128 bins with its two neighbours: every
+    # block transformed once on the matrix cores, kernels_bdft.hip)
+    blocks = scaling == "linear" and N in (512, 1024) and f0 >= 1 and f0 + F + 1 <= (f0 - 1) // 4 * 4 + 128
+    auto_kernel = "bdft_net_kernel" if blocks else ("fft1k_net_kernel" if one_launch else "mlp_mfma_kernel")
+    for engine, kernel in ((_abi.ENGINE_AUTO, auto_kernel), (_abi.ENGINE_GENERIC, "mlp_generic_kernel")):
         with sd.SyllableDetector(cfg, channels=2, engine=engine) as det:
             det.profile(True)
             out, fl = det.run(xd)
@@ -735,6 +739,46 @@ def test_network_stage_on_the_matrix_cores(oracle_lib, N, lo, hi, T, H, scaling)
             util.assert_outputs_close(out[c][ok], w64[ok])
             util.assert_flags_exact(fl[c][ok], w64[ok], cfg.thresholds, cfg.rule)
             assert not fl[c][~ok].any()
+
+
+@pytest.mark.parametrize("N,window,lo,hi,T,H", [(1024, _abi.WINDOW_HANNING, 2000.0, 7000.0, 10, 4), (1024, _abi.WINDOW_NONE, 1000.0, 6000.0, 7, 3),
+                                                (512, _abi.WINDOW_HAMMING, 2000.0, 7000.0, 10, 4), (512, _abi.WINDOW_HANNING, 300.0, 10000.0, 12, 2),
+                                                (1024, _abi.WINDOW_BLACKMAN, 2000.0, 7000.0, 10, 4)])
+def test_frames_of_four_hops_on_the_block_transform_kernel(oracle_lib, N, window, lo, hi, T, H):
+    """kernels_bdft.hip: W = N = 4 hop, every block of `hop` samples transformed once on the matrix cores, frames as sliding
+    sums of four blocks, the window (WindowType.createWindow, CircularShortTimeFourierTransform.swift:19-28) as three taps
+    along the bins.  Hann, Hamming and rectangular windows, 512- and 1024-point frames, bands up to 113 bins; a Blackman window
+    (five taps) keeps the FFT kernels.  Several runs per channel, a ragged tail, a 70 dB level step (every block has its own
+    scale), a stretch of silence (0/0 in l2normalize -> NaN, as in the reference), a NaN sample (exactly the frames that
+    contain it, NeuralNet.swift:47-59)."""
+    torch = _torch()
+    from syllable_detector_swift_amd.config import SyllableDetectorConfig, frequencyIndexRange
+    rng = np.random.default_rng(N + T + window)
+    f0, f1 = frequencyIndexRange(N, 44100.0, lo, hi)
+    F = f1 - f0
+    net = nets.random_net(rng, F * T, (H,), 1, in_fns=("l2normalize", "mapminmax"), out_fns=("mapminmax",) if H != 3 else ())
+    cfg = SyllableDetectorConfig(44100.0, N, N, N - N // 4, (lo, hi), T, "linear", [0.4], net, window=window)
+    S = N + (N // 4) * 1500 + 101
+    x = synth.channels(3, S, first=13).astype(np.float32)
+    x[0, S // 2:] *= np.float32(0.0003)
+    x[1, 30000:30000 + 30 * N] = 0.0
+    x[2, 77777] = np.nan
+    with sd.SyllableDetector(cfg, channels=3) as det:
+        det.profile(True)
+        out, fl = det.run(torch.from_numpy(x).cuda())
+        torch.cuda.synchronize()
+        names = [nm for nm, _ in det.lastTimings()]
+        assert names[-1] == ("bdft_net_kernel" if window != _abi.WINDOW_BLACKMAN else ("fft1k_net_kernel" if N == 1024 and F % 4 == 0 else "mlp_mfma_kernel")), names
+        out, fl = out.cpu().numpy(), fl.cpu().numpy()
+    o = util.oracle_for(cfg)
+    for c in range(3):
+        _, _, w64 = o.run(x[c], po.F64)
+        ok = np.isfinite(w64).all(axis=1)
+        assert (np.isfinite(out[c]).all(axis=1) == ok).all(), "NaN evaluations must coincide"
+        assert c == 0 or (~ok).any()
+        util.assert_outputs_close(out[c][ok], w64[ok])
+        util.assert_flags_exact(fl[c][ok], w64[ok], cfg.thresholds, cfg.rule)
+        assert not fl[c][~ok].any()
 
 
 @pytest.mark.parametrize("kernel", util.FUSED_KERNELS)
