@@ -268,3 +268,54 @@ def test_random_example_class_detector_on_the_register_resident_kernel(oracle_li
             util.assert_outputs_close(out[c][ok], w64[ok], tol)
             util.assert_flags_exact(fl[c][ok], w64[ok], cfg.thresholds, cfg.rule, tol)
         assert not fl[c][~ok].any()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SYLDET_FUZZ_DRAWS_BLOCKS", "16"))))
+def test_random_frames_of_four_hops(oracle_lib, seed):
+    """kernels_bdft.hip (every block of hop samples transformed once, frames as sliding sums, the window as taps along the bins)
+    on random bands, windows, timeRanges, networks, lengths around its sub-tiles of 16 blocks and tiles of 96 frames, level steps
+    of up to 100 dB (every block has its own scale)."""
+    import torch
+    from syllable_detector_swift_amd.config import SyllableDetectorConfig
+    rng = np.random.default_rng(31000 + seed)
+    N = int(rng.choice([512, 1024]))
+    hop = N // 4
+    window = int(rng.choice([_abi.WINDOW_NONE, _abi.WINDOW_HAMMING, _abi.WINDOW_HAMMING, _abi.WINDOW_HANNING]))
+    f0 = int(rng.integers(1, N // 2 - 130))
+    F = int(rng.integers(33, 122))
+    lo, hi = (f0 - 0.4) * FS / N, (f0 + F - 1 + 0.4) * FS / N
+    r = frequencyIndexRange(N, FS, lo, hi)
+    F = r[1] - r[0]
+    T = int(rng.integers(1, 13))
+    net = nets.random_net(rng, F * T, (int(rng.integers(1, 5)),), 1, transfer=("TanSig", "PureLin"),
+                          in_fns=[("l2normalize",), ("l2normalize", "mapminmax"), ("l2normalize", "mapstd")][int(rng.integers(0, 3))],
+                          out_fns=[(), ("mapminmax",)][int(rng.integers(0, 2))])
+    cfg = SyllableDetectorConfig(FS, N, N, N - hop, (lo, hi), T, "linear", [float(rng.uniform(-0.5, 0.8))], net, window=window)
+    edges = [T, 15, 16, 17, 95, 96, 97, 105, 111, 112, 113, 192, 200, 700, 1300, 2100]
+    frames = max(T, int(edges[seed % len(edges)]))
+    S = N + (frames - 1) * hop + int(rng.integers(0, hop))
+    C = int(rng.integers(1, 4))
+    x = synth.channels(C, S, first=seed * 3, fs=FS) * float(10.0 ** rng.uniform(-3, 1))
+    env = np.ones(S)
+    for _ in range(int(rng.integers(0, 3))):
+        env[int(rng.integers(0, S)):] *= float(10.0 ** rng.uniform(-2.5, 2.5))
+    x = (x * np.clip(env, 1e-5, 1e3)[None, :]).astype(np.float32)
+    o = util.oracle_for(cfg)
+    with sd.SyllableDetector(cfg, channels=C) as det:
+        det.profile(True)
+        out, fl = det.run(torch.from_numpy(x).cuda())
+        torch.cuda.synchronize()
+        assert [nm for nm, _ in det.lastTimings()] == ["bdft_net_kernel"]
+        out, fl = out.cpu().numpy(), fl.cpu().numpy()
+    for c in range(C):
+        w32, _, w64 = o.run(x[c], po.F64, cfg.rule)
+        ok = np.isfinite(w64).all(axis=1)
+        own = float((np.abs(w32[ok] - w64[ok]) / np.maximum(1.0, np.abs(w64[ok]))).max()) if ok.any() else 0.0
+        assert (np.isfinite(out[c]).all(axis=1) == ok).all(), "NaN/inf evaluations must coincide"
+        flat = max(util.TOL, 4.0 * own)
+        tol = np.maximum(flat, 2.0 ** -21 * util.band_condition(o, cfg, x[c]))[ok]
+        if ok.any():
+            err = (np.abs(out[c][ok] - w64[ok]) / np.maximum(1.0, np.abs(w64[ok]))).max(axis=1)
+            util.sweep_record("frames of four hops", seed, "bdft_net_kernel", err.max(), own, flat, (err / tol).max(), "kappa" if (err > flat).any() else "")
+            util.assert_outputs_close(out[c][ok], w64[ok], tol)
+            util.assert_flags_exact(fl[c][ok], w64[ok], cfg.thresholds, cfg.rule, tol)
