@@ -69,6 +69,7 @@ struct WideDesc {
     int H, n_chunks;            // first-layer outputs, chunks of 32 of them (zero padded)
     int n_out, tf0, tf1, rule, n_out_fns;
     int sig;                    // TanSig / LogSig hidden layer folded into the tables (see wide_gemm_kernel)
+    int shape16;                // the chunks are packed for v_mfma_f32_16x16x32_bf16 ([k-step of 32][unit tile of 16]): wide_gemm16_kernel
     const uint4 *wpack;         // [n_chunks][kWideChunkBytes / 16]
     const float *b1;            // [n_out]
     const float *out_params;    // per output fn: y, gain[n_out], xoff[n_out]

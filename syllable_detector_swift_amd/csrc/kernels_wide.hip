@@ -343,6 +343,131 @@ wide_gemm_kernel(WideDesc d, const uint4 *__restrict__ xn, int64_t NE, float *__
     }
 }
 
+
+// ------------------------------------------------------------------------------------
+// The same GEMM on v_mfma_f32_16x16x32_bf16 (round 3).  tools/energy_probe.py prices the 32x32x16 shape at 12 % more energy per
+// flop and a 16 % lower clock under load than the 16x16x32 one (profiles/r03_energy_probe.txt), and this kernel runs on the
+// power limit.  Same data flow: a wave owns 32 evaluations as B operands in registers (two column tiles of 16 x ten k-steps of
+// 32: the same 80 registers), a chunk of 32 hidden units is two row tiles, every A fragment feeds two MFMAs.
+//   A [16 units x 32 k]:   lane l holds unit l % 16 of its tile, k = 8 (l / 16) + 0..7   (from LDS, host-packed: [k-step][tile])
+//   B [32 k x 16 evals]:   lane l holds evaluation l % 16 of its tile, k = 8 (l / 16) + 0..7
+//   D [16 units x 16 evals]: lane l holds evaluation l % 16; register i holds unit 4 (l / 16) + i
+// ------------------------------------------------------------------------------------
+typedef float floatx4w __attribute__((ext_vector_type(4)));
+template <int NOUT, bool SIG>
+__global__ void __launch_bounds__(kBlock, 1)
+wide_gemm16_kernel(WideDesc d, const uint4 *__restrict__ xn, int64_t NE, float *__restrict__ outputs, uint8_t *__restrict__ flags)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int kWaves = kBlock / 64, kK2 = kWideK / 32;
+    uint4 *buf0 = reinterpret_cast<uint4 *>(smem), *buf1 = buf0 + kChunkU4Pad;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    int64_t ev[2];
+#pragma unroll
+    for (int t = 0; t < 2; t++) ev[t] = (int64_t)blockIdx.x * kWideTile + wave * 32 + 16 * t + n;
+    bf16x8 B[2][kK2];
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int ks = 0; ks < kK2; ks++) {
+            union { uint4 u; bf16x8 v; } b;
+            b.u = ev[t] < NE ? xn[ev[t] * (kWideK / 8) + 4 * ks + g] : uint4{0, 0, 0, 0};
+            B[t][ks] = b.v;
+        }
+    float ysum[2][NOUT];
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int o = 0; o < NOUT; o++) ysum[t][o] = 0.0f;
+    auto fetch_chunk = [&](int ch, uint4 *dst) {
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int i0 = (wave + kWaves * j) * 64;
+            if (i0 < kChunkU4) {
+                const int i = i0 + lane < kChunkU4 ? i0 + lane : kChunkU4 - 1;
+                __builtin_amdgcn_global_load_lds(d.wpack + (size_t)ch * kChunkU4 + i, dst + i0, 16, 0, 0);
+            }
+        }
+    };
+    fetch_chunk(0, buf0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+    for (int ch = 0; ch < d.n_chunks; ch++) {
+        const uint4 *cur = (ch & 1) ? buf1 : buf0;
+        if (ch + 1 < d.n_chunks) fetch_chunk(ch + 1, (ch & 1) ? buf0 : buf1);
+        const float *cst = reinterpret_cast<const float *>(cur + kKSteps * 64);
+        floatx4w acc[2][2];                                       // [unit tile][evaluation tile]: register i = unit 16 ut + 4 g + i
+#pragma unroll
+        for (int ut = 0; ut < 2; ut++) {
+            const float4 b0 = *reinterpret_cast<const float4 *>(cst + 16 * ut + 4 * g);
+#pragma unroll
+            for (int t = 0; t < 2; t++) acc[ut][t] = floatx4w{b0.x, b0.y, b0.z, b0.w};
+        }
+#pragma unroll
+        for (int ks = 0; ks < kK2; ks++) {
+            union { uint4 u; bf16x8 v; } a0, a1;
+            a0.u = cur[(2 * ks + 0) * 64 + lane];
+            a1.u = cur[(2 * ks + 1) * 64 + lane];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0.v, B[0][ks], acc[0][0], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1.v, B[0][ks], acc[1][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0.v, B[1][ks], acc[0][1], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1.v, B[1][ks], acc[1][1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int ut = 0; ut < 2; ut++) {
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    acc[ut][t][j] = SIG ? __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(acc[ut][t][j]) + 1.0f) : transfer_fast(d.tf0, acc[ut][t][j]);
+#pragma unroll
+            for (int o = 0; o < NOUT; o++) {                      // (rows of unused outputs are zero in the table)
+                const float4 w1 = *reinterpret_cast<const float4 *>(cst + 32 + 32 * o + 16 * ut + 4 * g);
+#pragma unroll
+                for (int t = 0; t < 2; t++) {
+                    ysum[t][o] = fmaf(acc[ut][t][0], w1.x, ysum[t][o]);
+                    ysum[t][o] = fmaf(acc[ut][t][1], w1.y, ysum[t][o]);
+                    ysum[t][o] = fmaf(acc[ut][t][2], w1.z, ysum[t][o]);
+                    ysum[t][o] = fmaf(acc[ut][t][3], w1.w, ysum[t][o]);
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();
+    }
+    // the four lane groups hold disjoint units of the same evaluations
+    int tid2 = threadIdx.x;
+    asm volatile("" : "+v"(tid2));                                // (recomputed: held across the loop they cost two spilled pairs)
+#pragma unroll
+    for (int t = 0; t < 2; t++) ev[t] = (int64_t)blockIdx.x * kWideTile + (tid2 >> 6) * 32 + 16 * t + (tid2 & 15);
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+#pragma unroll
+        for (int o = 0; o < NOUT; o++) {
+            auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(ysum[t][o]), __float_as_uint(ysum[t][o]), false, false);
+            float v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+            r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+            ysum[t][o] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+        }
+        if (g == 0 && ev[t] < NE) {
+            bool hit = false;
+#pragma unroll
+            for (int o = 0; o < NOUT; o++) {
+                if (o >= d.n_out) break;
+                float y = transfer_fast(d.tf1, ysum[t][o] + d.b1[o]);
+                for (int q = 0; q < d.n_out_fns; q++) {
+                    const float *op = d.out_params + q * (1 + 2 * d.n_out);
+                    y = (y - op[0]) / op[1 + o] + op[1 + d.n_out + o];
+                }
+                if (outputs) outputs[ev[t] * d.n_out + o] = y;
+                if (o == 0 || d.rule == 1) hit = hit || ((double)y >= d.thresholds[o]);
+            }
+            if (flags) flags[ev[t]] = hit ? 1 : 0;
+        }
+    }
+}
+
 }  // namespace
 
 // the input chains the training script writes -- [l2normalize,] one affine map -- take the chain-specialised kernel
@@ -371,6 +496,14 @@ hipError_t launch_wide_gemm(const WideDesc &d, const void *xn, int64_t NE, float
 {
     if (NE <= 0) return hipSuccess;
     dim3 grid((unsigned)((NE + kWideTile - 1) / kWideTile));
+    if (d.shape16) {                      // the 16x16x32 shape (what ships; the other one under SYLDET_WIDE_SHAPE32=1, with its own packing)
+        const bool one16 = d.n_out == 1;
+        auto k16 = d.sig ? (one16 ? wide_gemm16_kernel<1, true> : wide_gemm16_kernel<4, true>) : (one16 ? wide_gemm16_kernel<1, false> : wide_gemm16_kernel<4, false>);
+        hipError_t st16 = hipFuncSetAttribute((const void *)k16, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kChunkU4Pad * 16);
+        if (st16 != hipSuccess) return st16;
+        hipLaunchKernelGGL(k16, grid, dim3(kBlock), 2 * kChunkU4Pad * 16, stream, d, (const uint4 *)xn, NE, outputs, flags);
+        return hipGetLastError();
+    }
     // (one output: two evaluation tiles a wave; with several outputs their running sums would spill -- one tile, 16 waves)
     constexpr int TW = kWideTilesPerWave;
     const bool one = d.n_out == 1;

@@ -124,6 +124,7 @@ struct syldet {
     struct Switches {
         bool fused_classic = false;   // SYLDET_FUSED_CLASSIC: the 8-wave fused kernel where both fused kernels take the shape
         bool no_fft1k = false;        // SYLDET_NO_FFT1K: 1024-point frames as two launches
+        bool wide_shape32 = false;    // SYLDET_WIDE_SHAPE32: the wide engine's GEMM on the 32x32x16 MFMA shape (rounds 1-2), not 16x16x32
         bool no_bdft = false;         // SYLDET_NO_BDFT: frames of four hops on the FFT kernels, not the block-transform kernel
         bool no_stft_lanes = false;   // SYLDET_NO_STFT_LANES: the LDS Stockham FFT instead of the lane-butterfly one
         bool no_guard = false;        // SYLDET_NO_GUARD: the precision guard off
@@ -136,6 +137,7 @@ struct syldet {
             fused_classic = std::getenv("SYLDET_FUSED_CLASSIC") != nullptr;
             no_fft1k = std::getenv("SYLDET_NO_FFT1K") != nullptr;
             no_bdft = std::getenv("SYLDET_NO_BDFT") != nullptr;
+            wide_shape32 = std::getenv("SYLDET_WIDE_SHAPE32") != nullptr;
             no_stft_lanes = std::getenv("SYLDET_NO_STFT_LANES") != nullptr;
             no_guard = std::getenv("SYLDET_NO_GUARD") != nullptr;
             no_mlpx = std::getenv("SYLDET_NO_MLPX") != nullptr;
@@ -330,12 +332,16 @@ int upload_wide(syldet *h, std::string &why)
     const bool sig = L0.transfer == SYLDET_TF_TANSIG || L0.transfer == SYLDET_TF_LOGSIG;
     const double sc = !sig ? 1.0 : (L0.transfer == SYLDET_TF_TANSIG ? 2.8853900817779268 : -1.4426950408889634);
     const double w1s = (sig && L0.transfer == SYLDET_TF_TANSIG) ? -2.0 : 1.0;
+    const bool shape16 = !h->sw.wide_shape32;
     for (int ch = 0; ch < n_chunks; ch++) {
         uint16_t *frag = pack.data() + (size_t)ch * chunk_u16;
         for (int ks = 0; ks < kWideK / 16; ks++)
             for (int l = 0; l < 64; l++)
                 for (int j = 0; j < 8; j++) {
-                    const int unit = 32 * ch + (l & 31), k = 16 * ks + 8 * (l >> 5) + j;
+                    // 32x32x16: fragment ks = k-step of 16, lane l = unit l % 32, k = 8 (l / 32) + j
+                    // 16x16x32: fragment ks = (k-step of 32, unit tile of 16), lane l = unit l % 16 of its tile, k = 8 (l / 16) + j
+                    const int unit = shape16 ? 32 * ch + 16 * (ks & 1) + (l & 15) : 32 * ch + (l & 31);
+                    const int k = shape16 ? 32 * (ks >> 1) + 8 * (l >> 4) + j : 16 * ks + 8 * (l >> 5) + j;
                     const float v = (unit < H && k < I) ? (float)(sc * (double)L0.weights[(size_t)unit * I + k]) : 0.0f;
                     frag[((size_t)ks * 64 + l) * 8 + j] = to_bf16(v);
                 }
@@ -367,6 +373,7 @@ int upload_wide(syldet *h, std::string &why)
     d.H = H; d.n_chunks = n_chunks; d.n_out = n_out; d.tf0 = L0.transfer; d.tf1 = L1.transfer; d.rule = c.rule;
     d.n_out_fns = c.n_output_fns;
     d.sig = sig ? 1 : 0;
+    d.shape16 = shape16 ? 1 : 0;
     d.wpack = (const uint4 *)h->d_wide.ptr;
     d.b1 = (const float *)((const char *)h->d_wide.ptr + pack_bytes);
     d.out_params = d.b1 + n_out;
@@ -668,7 +675,7 @@ int run_on_stream(syldet *h, const float *d_samples, int64_t S, int64_t stride, 
             KernelTimer t(h, stream, wide_prep_is_chain(h->net) ? "wide_prep_chain_kernel" : "wide_prep_kernel");
             SYLDET_HIP(launch_wide_prep(h->net, h->geom.bins, (const float *)h->d_columns.ptr, C, J, E, h->d_xn.ptr, stream));
         }
-        KernelTimer t(h, stream, "wide_gemm_kernel");
+        KernelTimer t(h, stream, h->wide.shape16 ? "wide_gemm16_kernel" : "wide_gemm_kernel");
         SYLDET_HIP(launch_wide_gemm(h->wide, h->d_xn.ptr, (int64_t)C * E, d_outputs, d_flags, stream));
         return SYLDET_OK;
     }
