@@ -230,7 +230,7 @@ def main():
     if args.total_channels is not None:                  # strong scaling: a fixed bank sharded over the ranks
         scaling, total = "strong", args.total_channels
         first, C = shard_channels(total, world, rank)
-        assert C > 0, "fewer channels than ranks"
+        assert C > 0, "fewer channels than ranks: dist.ShardedSyllableDetector shards the time axis then; this benchmark does not"
 
     det = sd.SyllableDetector(cfg, channels=C, device=local_rank, engine=args.engine)
     g = det.geometry

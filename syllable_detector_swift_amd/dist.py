@@ -4,6 +4,11 @@ data path needs no collective.  The only exchange is ONE gather of the per-chann
 flags per batch (RCCL over xGMI on GPUs; `gloo` in the CPU tests): a few MB, latency-bound,
 so it is issued once per run, never per frame.
 
+With fewer channels than ranks the TIME axis is sharded instead: a channel's evaluations are cut into contiguous
+ranges, one per rank of that channel, and each rank reads its range's samples plus a halo of (T - 1) hop + W - hop samples --
+the frames its last evaluations' windows reach into (SyllableDetector.swift:153-217: evaluation e is frames e .. e + T - 1,
+frame j is samples [j hop + gap, j hop + gap + W)).  Still no collective on the data path; the one gather concatenates along time.
+
 One process per GPU (torch.distributed; backend "nccl" is RCCL on ROCm).
 """
 from __future__ import annotations
@@ -19,6 +24,64 @@ def shard_channels(total_channels: int, world_size: int, rank: int) -> Tuple[int
     base, extra = divmod(total_channels, world_size)
     first = rank * base + min(rank, extra)
     return first, base + (1 if rank < extra else 0)
+
+
+def shard_plane(total_channels: int, world_size: int, rank: int) -> Tuple[int, int, int, int]:
+    """(first channel, channel count, part, parts) of `rank`.  With at least as many channels as ranks this is
+    shard_channels() with one part; with fewer, every channel is shared by world // channels ranks (the first
+    world % channels channels by one more) and `part` of `parts` is this rank's place along the channel's time axis."""
+    if total_channels < 1 or world_size < 1 or not (0 <= rank < world_size):
+        raise ValueError("bad sharding arguments")
+    if total_channels >= world_size:
+        first, count = shard_channels(total_channels, world_size, rank)
+        return first, count, 0, 1
+    base, extra = divmod(world_size, total_channels)
+    r = rank
+    for ch in range(total_channels):
+        parts = base + (1 if ch < extra else 0)
+        if r < parts:
+            return ch, 1, r, parts
+        r -= parts
+    raise AssertionError("unreachable")
+
+
+def shard_evaluations(evaluations: int, parts: int, part: int) -> Tuple[int, int]:
+    """Contiguous range of a channel's evaluations owned by `part`: (first, count); the first evaluations % parts
+    parts take one more."""
+    if evaluations < 0 or parts < 1 or not (0 <= part < parts):
+        raise ValueError("bad sharding arguments")
+    base, extra = divmod(evaluations, parts)
+    return part * base + min(part, extra), base + (1 if part < extra else 0)
+
+
+def time_shard_samples(hop: int, gap: int, window: int, time_range: int, first_eval: int, count: int) -> Tuple[int, int]:
+    """Samples [s0, s1) a rank reads for evaluations [first_eval, first_eval + count): from its first frame's hop to the end
+    of its last evaluation's last frame.  Neighbouring ranges overlap by the halo (time_range - 1) hop + window - hop
+    (+ gap); a run over the slice yields exactly `count` evaluations, the same numbers the unsharded run gives them."""
+    if count <= 0:
+        return first_eval * hop, first_eval * hop
+    return first_eval * hop, (first_eval + count + time_range - 2) * hop + gap + window
+
+
+def gather_time_shards(local_flags, total_channels: int, evaluations: int, group=None):
+    """The time-sharded counterpart of gather_flags: this rank holds [1, n] flags of its range of its channel; every rank
+    receives [total_channels, evaluations].  Ranges are ragged by at most one evaluation: one padded all-gather."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    plan = [shard_plane(total_channels, world, r) for r in range(world)]
+    spans = [shard_evaluations(evaluations, parts, part) for (_, _, part, parts) in plan]
+    assert tuple(local_flags.shape) == (1, spans[rank][1]), "local flags do not match shard_plane() / shard_evaluations()"
+    biggest = max(n for _, n in spans)
+    padded = torch.zeros((biggest,), dtype=local_flags.dtype, device=local_flags.device)
+    padded[: spans[rank][1]] = local_flags[0]
+    buf = torch.empty((world * biggest,), dtype=local_flags.dtype, device=local_flags.device)
+    dist.all_gather_into_tensor(buf, padded, group=group)
+    out = torch.empty((total_channels, evaluations), dtype=local_flags.dtype, device=local_flags.device)
+    for r, ((ch, _, _, _), (e0, n)) in enumerate(zip(plan, spans)):
+        out[ch, e0: e0 + n] = buf[r * biggest: r * biggest + n]
+    return out
 
 
 def pack_flags(flags, out=None):
@@ -136,7 +199,8 @@ class PipelinedFlagGather:
 
 
 class ShardedSyllableDetector:
-    """This rank's share of a `total_channels`-wide bank on its own GPU."""
+    """This rank's share of a `total_channels`-wide bank on its own GPU: a block of channels, or -- with fewer channels than
+    ranks -- a stretch of one channel's time axis (`time_sharded`; see the module docstring)."""
 
     def __init__(self, config, total_channels: int, device: Optional[int] = None, group=None, engine: int = 0):
         import torch.distributed as dist
@@ -145,9 +209,8 @@ class ShardedSyllableDetector:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.total_channels = int(total_channels)
-        self.first, self.count = shard_channels(self.total_channels, self.world, self.rank)
-        if self.count == 0:
-            raise ValueError("fewer channels than ranks: shard by time with a (T-1)*hop + W - hop halo instead")
+        self.first, self.count, self.part, self.parts = shard_plane(self.total_channels, self.world, self.rank)
+        self.time_sharded = self.parts > 1
         if device is None:
             # one process per GPU: under torch.distributed.run every rank sees every GPU and owns the one of its LOCAL_RANK
             import os
@@ -155,11 +218,31 @@ class ShardedSyllableDetector:
             device = int(os.environ["LOCAL_RANK"]) if "LOCAL_RANK" in os.environ else torch.cuda.current_device()
         self.device = int(device)
         self.detector = SyllableDetector(config, channels=self.count, device=self.device, engine=engine)
+        self._time_range = int(config.timeRange)
+        self._window = int(config.windowLength)
 
-    def run(self, local_samples, gather: bool = True):
-        """local_samples: this rank's [count, S] block.  Returns (outputs_local, flags) where flags is
-        the gathered [total_channels, E] tensor when `gather`, else the local one."""
+    def sample_range(self, n_samples: int) -> Tuple[int, int]:
+        """[s0, s1) of a recording of n_samples per channel that this rank reads (all of it unless time-sharded)."""
+        if not self.time_sharded:
+            return 0, int(n_samples)
+        g = self.detector.geometry
+        e0, n = shard_evaluations(self.detector.countEvaluations(n_samples), self.parts, self.part)
+        return time_shard_samples(g.hop, g.gap, self._window, self._time_range, e0, n)
+
+    def run(self, local_samples, gather: bool = True, n_samples: Optional[int] = None):
+        """local_samples: this rank's [count, S] block -- when time-sharded, its [1, s1 - s0] slice of a recording of
+        `n_samples` (sample_range()).  Returns (outputs_local, flags) where flags is the gathered [total_channels, E]
+        tensor when `gather`, else the local one."""
         outputs, flags = self.detector.run(local_samples)
+        if self.time_sharded:
+            if n_samples is None:
+                raise ValueError("a time-sharded run needs the recording's length (n_samples)")
+            E = self.detector.countEvaluations(n_samples)
+            if int(flags.shape[1]) != shard_evaluations(E, self.parts, self.part)[1]:
+                raise ValueError("local samples are not this rank's sample_range() of the recording")
+            if gather and self.world > 1:
+                flags = gather_time_shards(flags, self.total_channels, E, self.group)
+            return outputs, flags
         if gather and self.world > 1:
             flags = gather_flags(flags, self.total_channels, self.group)
         return outputs, flags

@@ -396,3 +396,29 @@ def test_sharded_detector_over_rccl_single_rank(tmp_path):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29594", HSA_ENABLE_IPC_MODE_LEGACY="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload", ["sample", "config3"])
+def test_time_sharded_parts_equal_the_whole_run(workload):
+    """Fewer channels than ranks: a channel's evaluations cut into contiguous ranges, each run from its own
+    slice of the samples (range + halo, dist.time_shard_samples) as a rank would -- here one after another on the one GPU --
+    give the unsharded run's outputs and flags bit for bit: results do not depend on where a run starts."""
+    import torch
+    from syllable_detector_swift_amd.dist import shard_evaluations, time_shard_samples
+    cfg = util.sample_net() if workload == "sample" else nets.config3()
+    S = 300007
+    x = synth.channels_on_device(1, S, "cuda", fs=cfg.samplingRate)
+    with sd.SyllableDetector(cfg, channels=1) as det:
+        g = det.geometry
+        E = det.countEvaluations(S)
+        out, fl = det.run(x)
+        for parts in (2, 3, 8):
+            outs, fls = [], []
+            for part in range(parts):
+                e0, n = shard_evaluations(E, parts, part)
+                s0, s1 = time_shard_samples(g.hop, g.gap, cfg.windowLength, cfg.timeRange, e0, n)
+                o, f = det.run(x[:, s0:s1].contiguous())
+                assert o.shape[1] == n
+                outs.append(o.clone()); fls.append(f.clone())
+            assert torch.equal(torch.cat(outs, dim=1), out) and torch.equal(torch.cat(fls, dim=1), fl)
