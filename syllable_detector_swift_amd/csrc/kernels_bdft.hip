@@ -37,6 +37,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <type_traits>
 
 #include "fused_common.hpp"
 
@@ -116,8 +117,9 @@ bdft_net_kernel(const MlpxDesc d, const BdftDesc bd, const float *__restrict__ s
     float *pbuf = reinterpret_cast<float *>(scr + kFragBytes);                           // [tile][PS] over buffer 1 and the edges
     float *ssf8 = reinterpret_cast<float *>(scr + 2 * kFragBytes + 2 * 16 * 32 * 16);   // [tile][8 waves]
     unsigned *bmax = reinterpret_cast<unsigned *>(ssf8 + kTile * kWaves);                 // [4][16] block maxima (bit patterns of |x|), by sub-tile & 3
-    float *x0buf = reinterpret_cast<float *>(bmax + 64);                                  // [4][16] the blocks' first samples
-    int *efb = reinterpret_cast<int *>(x0buf + 64);                                       // [4][16] the frames' scale exponents (their loudest block's)
+    // [4][16] what the multiplying waves need of a block and of the frame ending on it, made once by the fold:
+    // (x[0] 2^e, 2^(-e-13): the block's first sample in the fragments' units and the way back; the frame's column scale up, down)
+    floatx4 *recs = reinterpret_cast<floatx4 *>(bmax + 64);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -169,14 +171,13 @@ bdft_net_kernel(const MlpxDesc d, const BdftDesc bd, const float *__restrict__ s
     struct Raw { floatx4 p, q; float z, x0; };
     auto load_raw = [&](int64_t blk0) {                              // blk0: first block of the sub-tile
         Raw r;
-        const int64_t blk = blk0 + n;
-        const int64_t base = blk * HOP;                               // (in samples)
-        const bool ok = blk >= 0 && folder;
-        const unsigned o = ok ? (unsigned)((base + HOP / 2) * 4) : 0xFFFFFFF0u;
+        const int base = (int)(blk0 + n) * HOP;                       // (in samples; S 4 < 2^31, negative in the lead-in)
+        const bool ok = base >= 0 && folder;
+        const unsigned o = (unsigned)(base + HOP / 2) * 4u;
         r.p = as_floatx4(__builtin_amdgcn_raw_buffer_load_b128(in_rs, ok ? o + (unsigned)f_m * 4u : 0xFFFFFFF0u, 0, 0));
         r.q = as_floatx4(__builtin_amdgcn_raw_buffer_load_b128(in_rs, ok ? o - (unsigned)(f_m + 4) * 4u : 0xFFFFFFF0u, 0, 0));
         r.z = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(in_rs, ok ? o - (unsigned)f_m * 4u : 0xFFFFFFF0u, 0, 0));
-        r.x0 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(in_rs, (ok && wave == 0) ? (unsigned)(base * 4) : 0xFFFFFFF0u, 0, 0));
+        r.x0 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(in_rs, (ok && wave == 0) ? (unsigned)base * 4u : 0xFFFFFFF0u, 0, 0));
         return r;
     };
     auto raw_max = [&](const Raw &r, unsigned *slot) {               // this thread's share of its block's loudest sample
@@ -197,11 +198,13 @@ bdft_net_kernel(const MlpxDesc d, const BdftDesc bd, const float *__restrict__ s
         e = bits != 0u ? (e < -100 ? -100 : (e > 113 ? 113 : e)) : 0;
         return e;
     };
-    auto fold_store = [&](const Raw &r, int slt, uint32x2 *bf) {     // slt: the sub-tile's slot (its index & 3)
+    auto fold_store = [&](const Raw &r, int slt, uint32x2 *bf, bool writers) {   // slt: the sub-tile's slot (its index & 3); writers: waves 0 and 1 may be here
         if (!folder) return;
         const unsigned *slot = bmax + 16 * slt;
-        if (wave == 0 && g == 0) x0buf[16 * slt + n] = r.x0;
-        if (wave == 1 && g == 0) {                                   // the frame ending on block n: the loudest of its four blocks (silent ones do not count)
+        const int eb = scale_exp(slot[n]);
+        const float sx = pow2f(eb);
+        if (writers && wave == 0 && g == 0) *reinterpret_cast<floatx2 *>(recs + 16 * slt + n) = floatx2{r.x0 * sx, pow2f(-eb - 13)};
+        if (writers && wave == 1 && g == 0) {                        // the frame ending on block n: the loudest of its four blocks (silent ones do not count)
             const unsigned *prevs = bmax + 16 * ((slt + 3) & 3);      // (the sub-tile before this one)
             int e = 0x7fff;
 #pragma unroll
@@ -209,9 +212,11 @@ bdft_net_kernel(const MlpxDesc d, const BdftDesc bd, const float *__restrict__ s
                 const unsigned mbq = n - q >= 0 ? slot[n - q] : prevs[16 + n - q];
                 e = mbq != 0u ? min(e, scale_exp(mbq)) : e;
             }
-            efb[16 * slt + n] = e == 0x7fff ? 0 : e;
+            // the frame's column scale (every wave reads the same power of two: |X| 2^(e - 10) < 2^14)
+            const int ef = e == 0x7fff ? 0 : e;
+            const int eu = ef - 10 < -120 ? -120 : (ef - 10 > 120 ? 120 : ef - 10);
+            *(reinterpret_cast<floatx2 *>(recs + 16 * slt + n) + 1) = floatx2{pow2f(eu), pow2f(-eu)};
         }
-        const float sx = pow2f(scale_exp(slot[n]));
         const float xp[4] = {r.p[0], r.p[1], r.p[2], r.p[3]};
         const float xm[4] = {r.z, r.q[3], r.q[2], r.q[1]};           // x[c - m - j]
         float s[4], dd[4];
@@ -240,10 +245,10 @@ bdft_net_kernel(const MlpxDesc d, const BdftDesc bd, const float *__restrict__ s
     };
 
     // ---- the stream's state
-    floatx4 yre_prev = {0.f, 0.f, 0.f, 0.f}, yim_prev = yre_prev;   // sub-tile u-1: Y' of this lane's four bins for the frame ending at block n
-    floatx4 bre_prev = yre_prev, bim_prev = yre_prev;               // sub-tile u-1: the blocks' own partial transforms (true units), for the carry
-    floatx4 vre_prev = yre_prev, vim_prev = yre_prev;               // ... and the first level of the sliding sum
-    float up_prev = 0.0f, dn_prev = 0.0f;                            // ... and the frames' column scales
+    floatx4 yre = {0.f, 0.f, 0.f, 0.f}, yim = yre;                   // the last multiplied sub-tile: Y' of this lane's four bins for the frame ending at block n
+    floatx4 bre_prev = yre, bim_prev = yre;                          // ... the blocks' own partial transforms (true units), for the carry
+    floatx4 vre_prev = yre, vim_prev = yre;                          // ... and the first level of the sliding sum
+    float upc = 0.0f, dnc = 0.0f;                                    // ... and the frames' column scales
     int64_t u = 0;                                                   // sub-tile counter of the run
     int rbase = 0;                                                   // the tile's first (carried) row in the ring of 128 column rows: no copying between tiles
     auto blk_of = [&](int64_t uu) { return fbase + 16 * uu + (R - 1); };   // first block of sub-tile uu (frames end on their last block)
@@ -257,46 +262,54 @@ bdft_net_kernel(const MlpxDesc d, const BdftDesc bd, const float *__restrict__ s
     raw_max(r1, bmax + 0);
     raw_max(r2, bmax + 16);
     __syncthreads();
-    fold_store(r1, 0, bfr0);
+    fold_store(r1, 0, bfr0, true);
     r1 = r2;                                                         // r1: sub-tile u + 1 (to fold), r2: sub-tile u + 2 (to take the maxima of)
     r2 = r3;
 
     // ---- the stages of an iteration.  They are independent of each other (each works on a different sub-tile), so the two
-    // waves of a SIMD -- w and w + 4 -- take them in opposite orders: one multiplies while the other folds and finishes columns.
-    floatx4 yre, yim;
-    float upc = 0.0f, dnc = 0.0f;
-    auto stage_load_fold = [&]() {                                   // raw samples of sub-tile u + 3; fragments of sub-tile u + 1
-        if (tid < 16) bmax[((u + 3) & 3) * 16 + tid] = 0u;           // (sub-tile u - 1's slot: read for the last time before this barrier)
+    // waves of a SIMD -- w and w + 4 -- take them in different orders: one multiplies while the other folds or finishes columns.
+    // The window stage comes before the multiplication in both: it reads what the last multiplication left in registers.
+    auto stage_load_fold = [&](bool fh) {                            // raw samples of sub-tile u + 3; fragments of sub-tile u + 1 (fh: a wave of the first half)
+        if (fh && tid < 16) bmax[((u + 3) & 3) * 16 + tid] = 0u;           // (sub-tile u - 1's slot: read for the last time before this barrier)
 #ifdef SYLDET_B_NOLOAD
         r3 = load_raw(-100000);
 #else
         r3 = load_raw(blk_of(u + 3));                                // (past the recording: zeros from the descriptor's bounds check)
 #endif
 #ifndef SYLDET_B_NOFOLD
-        fold_store(r1, (int)((u + 1) & 3), (u & 1) ? bfr0 : bfr1);
+        fold_store(r1, (int)((u + 1) & 3), (u & 1) ? bfr0 : bfr1, fh);
 #endif
     };
     auto stage_mfma = [&]() {                                        // sub-tile u: B', the sliding sum, the edge bins
         const int par = (int)(u & 1);
         // ---- B'_n[k] for this wave's bins: cosine rows against the sums, sine rows against the differences
-        const uint32x4 *bf = reinterpret_cast<const uint32x4 *>(par ? bfr1 : bfr0);
+        const uint32x4 *bf = reinterpret_cast<const uint32x4 *>(par ? bfr1 : bfr0) + lane;
+        const floatx4 rec = recs[(u & 3) * 16 + n];
         floatx4 are = {0.f, 0.f, 0.f, 0.f}, aim = are;
+        uint32x4 fr[2][4];                                           // fragments two k-steps ahead of their MFMAs
+#pragma unroll
+        for (int w = 0; w < 4; w++) fr[0][w] = bf[(w * KS + 0) * 64];
+        if (KS > 1) {
+#pragma unroll
+            for (int w = 0; w < 4; w++) fr[1][w] = bf[(w * KS + 1) * 64];
+        }
 #pragma unroll
         for (int ks = 0; ks < KS; ks++) {
-            const half8 bsh = as_half8(bf[(0 * KS + ks) * 64 + lane]), bsl = as_half8(bf[(1 * KS + ks) * 64 + lane]);
-            const half8 bdh = as_half8(bf[(2 * KS + ks) * 64 + lane]), bdl = as_half8(bf[(3 * KS + ks) * 64 + lane]);
+            const half8 bsh = as_half8(fr[ks & 1][0]), bsl = as_half8(fr[ks & 1][1]);
+            const half8 bdh = as_half8(fr[ks & 1][2]), bdl = as_half8(fr[ks & 1][3]);
             are = mfma(ac[ks][0], bsh, are);
             aim = mfma(as_[ks][0], bdh, aim);
             are = mfma(ac[ks][0], bsl, are);
             aim = mfma(as_[ks][0], bdl, aim);
             are = mfma(ac[ks][1], bsh, are);
             aim = mfma(as_[ks][1], bdh, aim);
+            if (ks + 2 < KS) {
+#pragma unroll
+                for (int w = 0; w < 4; w++) fr[ks & 1][w] = bf[(w * KS + ks + 2) * 64];
+            }
         }
         // the block's first sample (its real part; the imaginary part rode in slot 0), then back to true units
-        const unsigned mb = bmax[(u & 3) * 16 + n];
-        const int eb = scale_exp(mb);
-        const float x0s = x0buf[(u & 3) * 16 + n] * pow2f(eb);
-        const float un = pow2f(-eb - 13);
+        const float x0s = rec[0], un = rec[1];
         floatx4 bre, bim;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
@@ -315,27 +328,24 @@ bdft_net_kernel(const MlpxDesc d, const BdftDesc bd, const float *__restrict__ s
         yre[1] = -vre[1] + back<2>(vre[1], vre_prev[1]);  yim[1] = -vim[1] + back<2>(vim[1], vim_prev[1]);     // -1
         yre[2] = vre[2] + back<2>(vre[2], vre_prev[2]);   yim[2] = vim[2] + back<2>(vim[2], vim_prev[2]);      // 1
         yre[3] = -vre[3] + back<2>(vre[3], vre_prev[3]);  yim[3] = -vim[3] + back<2>(vim[3], vim_prev[3]);     // -1
-        // the frame's column scale from its loudest block (every wave reads the same power of two: |X| 2^(e - 10) < 2^14)
-        const int ef = efb[(u & 3) * 16 + n];
-        const int eu = ef - 10 < -120 ? -120 : (ef - 10 > 120 ? 120 : ef - 10);
-        upc = pow2f(eu);
-        dnc = pow2f(-eu);
+        upc = rec[2];
+        dnc = rec[3];
         // this lane group's edge bins -> LDS for its neighbours
         edges[(par * 32 + 4 * wave + g) * 16 + n] = floatx4{yre[0], yim[0], yre[3], yim[3]};
         bre_prev = bre; bim_prev = bim; vre_prev = vre; vim_prev = vim;
     };
-    auto stage_window = [&](int sp) {                                // sub-tile u - 1 (row block sp of the tile): window taps, |X|, columns
+    auto stage_window = [&](int sp, bool fh) {                                // sub-tile u - 1 (row block sp of the tile): window taps, |X|, columns
         const int pe = (int)((u - 1) & 1);                           // (u: this iteration's sub-tile, or one past the tile's last in the drain iteration)
         const int G = 4 * wave + g;
         const floatx4 eL = G > 0 ? edges[(pe * 32 + G - 1) * 16 + n] : floatx4{0.f, 0.f, 0.f, 0.f};
         const floatx4 eR = G < 31 ? edges[(pe * 32 + G + 1) * 16 + n] : floatx4{0.f, 0.f, 0.f, 0.f};
-        const float reL[4] = {eL[2], yre_prev[0], yre_prev[1], yre_prev[2]}, imL[4] = {eL[3], yim_prev[0], yim_prev[1], yim_prev[2]};
-        const float reR[4] = {yre_prev[1], yre_prev[2], yre_prev[3], eR[0]}, imR[4] = {yim_prev[1], yim_prev[2], yim_prev[3], eR[1]};
+        const float reL[4] = {eL[2], yre[0], yre[1], yre[2]}, imL[4] = {eL[3], yim[0], yim[1], yim[2]};
+        const float reR[4] = {yre[1], yre[2], yre[3], eR[0]}, imR[4] = {yim[1], yim[2], yim[3], eR[1]};
         float cv[4], ssq = 0.0f;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const float xr = fmaf(wa0, yre_prev[i], fmaf(wc, reL[i] + reR[i], -wsn * (imL[i] - imR[i])));
-            const float xi = fmaf(wa0, yim_prev[i], fmaf(wsn, reL[i] - reR[i], wc * (imL[i] + imR[i])));
+            const float xr = fmaf(wa0, yre[i], fmaf(wc, reL[i] + reR[i], -wsn * (imL[i] - imR[i])));
+            const float xi = fmaf(wa0, yim[i], fmaf(wsn, reL[i] - reR[i], wc * (imL[i] + imR[i])));
             cv[i] = __builtin_amdgcn_sqrtf(fmaf(xr, xr, xi * xi));        // zvabs / 2, :329-333 (Y is the DFT itself, not twice it)
             const bool inb = (unsigned)(fb0 + i) < (unsigned)F;
             ssq = inb ? fmaf(cv[i], cv[i], ssq) : ssq;
@@ -343,19 +353,16 @@ bdft_net_kernel(const MlpxDesc d, const BdftDesc bd, const float *__restrict__ s
         ssq = xor32_sum(xor16_sum(ssq));
         const int rw = (rbase + (T - 1) + 16 * sp + n) & (kTile - 1);
         unsigned h0, l0, h1, l1;
-        split2(cv[0] * up_prev, cv[1] * up_prev, h0, l0);
-        split2(cv[2] * up_prev, cv[3] * up_prev, h1, l1);
+        split2(cv[0] * upc, cv[1] * upc, h0, l0);
+        split2(cv[2] * upc, cv[3] * upc, h1, l1);
         const int cb = 16 * wave + 4 * g;                            // column index = bin - kb0 (the first layer's fragments are in that order)
         *reinterpret_cast<uint32x2 *>(colh + rw * CS + cb) = uint32x2{h0, h1};
         *reinterpret_cast<uint32x2 *>(coll + rw * CS + cb) = uint32x2{l0, l1};
         if (g == 0) ssf8[rw * kWaves + wave] = ssq;
-        if (wave == 0 && g == 0) fsc[rw] = dn_prev;
+        if (fh && wave == 0 && g == 0) fsc[rw] = dnc;
     };
 
     const bool first_half = wave < kWaves / 2;
-#ifdef SYLDET_B_PRIO                  // (experiment: the younger wave of a SIMD loses every arbitration and finishes ~600 cycles behind its partner)
-    if (!first_half) __builtin_amdgcn_s_setprio(1);
-#endif
 #ifdef SYLDET_B_STAMPS
     unsigned long long tsum[8] = {0}, tk = 0;
 #define SD_BT(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long now = __builtin_amdgcn_s_memtime(); tsum[i] += now - tk; tk = now; __builtin_amdgcn_sched_barrier(0); }
@@ -363,48 +370,55 @@ bdft_net_kernel(const MlpxDesc d, const BdftDesc bd, const float *__restrict__ s
 #else
 #define SD_BT(i)
 #endif
-    for (int tr = 0; tr < tiles; tr++) {
-        for (int s = 0; s <= kSubs; s++) {
-            // bfr[u & 1] holds sub-tile u's fragments, bmax[(u + 1) & 3] sub-tile u + 1's maxima, edges[(u - 1) & 1] sub-tile u - 1's edge bins
-            SD_BT(0)
-            __syncthreads();
-            SD_BT(1)
-            const bool mm = s < kSubs;                               // a sub-tile to multiply in this iteration
-            // (SYLDET_B_NO*: diagnostic builds with one stage knocked out, tools/knockouts.sh; never the shipped library)
+    // (SYLDET_B_NO*: diagnostic builds with one stage knocked out, tools/knockouts.sh; never the shipped library)
 #if defined(SYLDET_B_NOMFMA) || defined(SYLDET_B_NOMW)
-            const bool do_m = false;
+    constexpr bool kDoM = false;
 #else
-            const bool do_m = mm;
+    constexpr bool kDoM = true;
 #endif
 #if defined(SYLDET_B_NOWINDOW) || defined(SYLDET_B_NOMW)
-            const bool do_w = false;
+    constexpr bool kDoW = false;
 #else
-            const bool do_w = s >= 1;
+    constexpr bool kDoW = true;
 #endif
-            if (first_half) {
-                if (do_m) stage_mfma();
-                SD_BT(2)
-                if (mm) stage_load_fold();
-                SD_BT(3)
-                if (do_w) stage_window(s - 1);
-                SD_BT(4)
-            } else {
-                if (mm) stage_load_fold();
-                SD_BT(3)
-                if (do_w) stage_window(s - 1);
-                SD_BT(4)
-                if (do_m) stage_mfma();
-                SD_BT(2)
-            }
-            if (mm) {
-                // ---- sub-tile u + 2's block maxima (its samples were loaded an iteration ago); the stream moves on
-                raw_max(r2, bmax + ((u + 2) & 3) * 16);
-                yre_prev = yre; yim_prev = yim; up_prev = upc; dn_prev = dnc;
-                r1 = r2;
-                r2 = r3;
-                u++;
-            }
+    // One iteration: a barrier, then this wave's stages.  MM: there is a sub-tile to multiply (and to load and fold for);
+    // WW: there is one to finish columns of -- the tile's first iteration has none (the last tile's drain took it), its
+    // drain iteration nothing else.  Three straight-line bodies, no per-stage conditions in the loop.
+    // bfr[u & 1] holds sub-tile u's fragments, bmax[(u + 1) & 3] sub-tile u + 1's maxima, edges[(u - 1) & 1] sub-tile u - 1's edge bins
+    auto iteration = [&](auto mm_, auto ww_, int sp) {
+        constexpr bool MM = decltype(mm_)::value, WW = decltype(ww_)::value;
+        SD_BT(0)
+        __syncthreads();
+        SD_BT(1)
+        if (first_half) {
+            if (WW && kDoW) stage_window(sp, true);
+            SD_BT(4)
+            if (MM && kDoM) stage_mfma();
+            SD_BT(2)
+            if (MM) stage_load_fold(true);
+            SD_BT(3)
+        } else {
+            if (MM) stage_load_fold(false);
+            SD_BT(3)
+            if (WW && kDoW) stage_window(sp, false);
+            SD_BT(4)
+            if (MM && kDoM) stage_mfma();
+            SD_BT(2)
         }
+        if (MM) {
+            // ---- sub-tile u + 2's block maxima (its samples were loaded an iteration ago); the stream moves on
+            raw_max(r2, bmax + ((u + 2) & 3) * 16);
+            r1 = r2;
+            r2 = r3;
+            u++;
+        }
+    };
+    using yes = std::integral_constant<bool, true>;
+    using no = std::integral_constant<bool, false>;
+    for (int tr = 0; tr < tiles; tr++) {
+        iteration(yes{}, no{}, 0);
+        for (int s = 1; s < kSubs; s++) iteration(yes{}, yes{}, s - 1);
+        iteration(no{}, yes{}, kSubs - 1);
         SD_BT(0)
         __syncthreads();
         SD_BT(1)
@@ -510,7 +524,7 @@ hipError_t launch_bdft_net(const MlpxDesc &d, const BdftDesc &bd, const float *s
     dim3 grid((unsigned)runs, (unsigned)C);
     const int KS = bd.hop / 64;
     const int frag = 4 * KS * 1024 < 16384 ? 16384 : 4 * KS * 1024;
-    const int lds = 3 * 4 * 2 * 1024 + 2 * kTile * d.col_stride * 2 + 2 * kTile * 4 + 2 * frag + 2 * 16 * 32 * 16 + kTile * kWaves * 4 + 3 * 4 * 16 * 4;
+    const int lds = 3 * 4 * 2 * 1024 + 2 * kTile * d.col_stride * 2 + 2 * kTile * 4 + 2 * frag + 2 * 16 * 32 * 16 + kTile * kWaves * 4 + 4 * 16 * 4 + 4 * 16 * 16;
     if (lds > 160 * 1024 || kTile * d.p_stride * 4 > frag + 2 * 16 * 32 * 16) return hipErrorInvalidValue;
 #ifdef SYLDET_B_STAMPS
 #define SD_BDFT_STAMP_REPORT                                                                                                   \
