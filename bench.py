@@ -15,6 +15,10 @@ scaling.  Channels are independent detectors (Processor.swift:57-59, main.swift:
 the timed step ends with ONE RCCL all-gather of the per-channel detection flags, as bits.  `--total-channels 4096` fixes
 the total instead and shards it over the ranks (strong scaling, dist.shard_channels).
 
+Before the W warmup steps the same step runs `--preroll` more times untimed (default 150, about 0.15 s; `preroll_steps` in the
+line): from an idle device the clock governor needs 30-50 ms of launches to reach the state it then holds for seconds
+(profiles/r03_clock_ramp.txt), and W + K = 25 launches would otherwise be timed inside that ramp.  The timed region is K steps.
+
 Rank 0 prints one JSON line.  `roofline` is computed from HIP-event timings of the dominant kernel taken inside the timed
 region on the launch stream.  After the timed region the last step's results are spot-checked against the CPU oracle
 (tests/spotcheck.py: head, tail and segment seams of the first, a middle and the last channel) -> `verified`.
@@ -92,7 +96,7 @@ def measured_traffic(C, S, hop, engine, kernel=None):
     return None, None
 
 
-def side_record(workload, local_rank, steps=10, warmup=2, verify=True):
+def side_record(workload, local_rank, steps=10, warmup=2, verify=True, preroll_s=0.15):
     """One sub-record of the `also` object: another single-GPU BASELINE workload (configs[2] "config3": 1024-point frames;
     configs[4] "config5": the 4096-hidden network as a bf16 MFMA GEMM) or the headline workload on adversarial audio
     ("clicks": a full-scale click every 64 frames over a cage at -80 dBFS, which the precision guard legitimately sends to
@@ -119,6 +123,11 @@ def side_record(workload, local_rank, steps=10, warmup=2, verify=True):
         outputs = torch.empty((C, E, g.outputs), dtype=torch.float32, device=dev)
         flags = torch.empty((C, E), dtype=torch.uint8, device=dev)
         det.profile(True, history=steps)
+        tp = time.perf_counter()                                     # (the clock ramp: see the headline's pre-roll)
+        while time.perf_counter() - tp < preroll_s:
+            for _ in range(5):
+                det.run(x, outputs, flags)
+            torch.cuda.synchronize()
         for _ in range(warmup):
             det.run(x, outputs, flags)
         torch.cuda.synchronize()
@@ -133,7 +142,7 @@ def side_record(workload, local_rank, steps=10, warmup=2, verify=True):
                 kernel_ms.setdefault(nm, []).append(ms)
         means = {k: sum(v) / len(v) for k, v in kernel_ms.items()}
         fixups, overflow = det.fixupStats()
-        rec = {"workload": workload, "value": C * J * steps / elapsed, "unit": "frames/s", "steps": steps,
+        rec = {"workload": workload, "value": C * J * steps / elapsed, "unit": "frames/s", "steps": steps, "warmup": warmup, "preroll_s": preroll_s,
                "ms_per_step": 1e3 * elapsed / steps, "channels": C, "samples_per_channel": S, "frames_per_channel": J,
                "fixups": {"work_items_last_step": fixups, "overflow": overflow}}
         if engine == 3:
@@ -149,6 +158,8 @@ def side_record(workload, local_rank, steps=10, warmup=2, verify=True):
             gbs = C * J * b_frame / (means[dom] * 1e-3) / 1e9
             rec["roofline"] = {"bound": "hbm", "kernel": dom, "kernel_ms": means[dom], "achieved": gbs, "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "all_kernels_ms": means}
+        wk_or_dom = rec["roofline"]["kernel"]
+        rec["roofline"]["kernel_ms_per_step"] = [round(v, 4) for v in reversed(kernel_ms[wk_or_dom])]   # (in launch order)
         if verify:
             import spotcheck
             try:
@@ -169,6 +180,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--preroll", type=int, default=None,
+                    help="untimed launches of the step before the warmup steps, to bring an idle device's clocks to their sustained state (default 150; 0: from cold)")
     ap.add_argument("--channels", type=int, default=None, help="channels per GPU (default: 64 at one GPU, 512 at several)")
     ap.add_argument("--log2-samples", type=int, default=None, help="samples per channel = 2^k (default: 24 at one GPU, 21 at several)")
     ap.add_argument("--total-channels", type=int, default=None, help="strong scaling: this many channels sharded over the ranks")
@@ -255,6 +268,14 @@ def main():
         elif exchange:
             gathered = gather_flags(flags, total)        # ragged shards: the padded form, on the compute stream
 
+    # From an idle device the clock governor takes 30-50 ms of back-to-back launches to reach the state it then holds for
+    # seconds (tools/ramp_probe.py, profiles/r03_clock_ramp.txt: 1.42, 1.17, 1.04, 0.977 ms a launch over the first 50 launches of
+    # this batch, 0.973-0.975 from there to 6 s) -- W + K = 25 launches would be timed inside that ramp.  A pre-roll of the same
+    # step (the same count on every rank: the step may hold a collective) brings the device there first; the W warmup steps
+    # and the K timed steps follow unchanged.  --preroll 0 times from cold.
+    preroll = args.preroll if args.preroll is not None else (150 if args.engine != 3 and args.workload != "config5" else 10)
+    for _ in range(preroll):
+        step()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -297,7 +318,7 @@ def main():
             "metric": {"sample": "audio frames/sec (256-pt STFT + 2-layer MLP), whole job",
                        "config3": "audio frames/sec (1024-pt STFT + 2-layer MLP), whole job",
                        "config5": "audio frames/sec (256-pt STFT + 4096-hidden MLP as bf16 MFMA GEMM), whole job"}[args.workload],
-            "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "preroll_steps": preroll,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None,
             # what the path computes in: fp32 in and out, fp32 accumulation; the DFT and first-layer products run on the matrix
