@@ -42,6 +42,23 @@ def kernel_stats(name):
     return {kname(r["Name"]): {"calls": int(r["Calls"]), "average_ms": float(r["AverageNs"]) / 1e6} for r in keep}
 
 
+def timed_region_ms(name, kernel, steps):
+    """rocprofv3's own timestamps of the LAST `steps` full-size dispatches of `kernel` -- the bench's timed region (the
+    dispatches before them are its pre-roll and warmup steps; `--stats` averages over all of them, the clock ramp included)."""
+    f = glob.glob(os.path.join(SRC, "stats_" + name, "**", "*kernel_trace.csv"), recursive=True)
+    if not f or not steps:
+        return None
+    rows = [r for r in csv.DictReader(open(f[0])) if kernel in r["Kernel_Name"]]
+    if not rows:
+        return None
+    grid = collections.Counter((r["Grid_Size_X"], r["Grid_Size_Y"]) for r in rows).most_common(1)[0][0]
+    rows = [r for r in rows if (r["Grid_Size_X"], r["Grid_Size_Y"]) == grid]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    last = rows[-steps:]
+    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in last]
+    return {"dispatches": len(d), "average_ms": sum(d) / len(d), "min_ms": min(d), "max_ms": max(d), "of_full_size_dispatches": len(rows)}
+
+
 def counters(name):
     f = glob.glob(os.path.join(SRC, "pmc_" + name, "**", "*counter_collection.csv"), recursive=True)
     if not f:
@@ -64,7 +81,9 @@ for wl, dom in (("sample", "fused_s_kernel"), ("config3", "fft1k_net_kernel"), (
     ks = kernel_stats(wl)
     if line:
         json.dump(line, open(os.path.join(DST, "%s_%s_bench_under_rocprof.json" % (R, wl)), "w"), indent=1)
-    summary[wl] = {"kernel_stats": ks, "bench_kernel_ms": line["roofline"]["kernel_ms"] if line else None}
+    summary[wl] = {"kernel_stats": ks, "bench_kernel_ms": line["roofline"]["kernel_ms"] if line else None,
+                   "bench_steps": line.get("steps") if line else None, "bench_preroll_steps": line.get("preroll_steps") if line else None,
+                   "timed_region_from_the_trace": timed_region_ms(wl, dom, line.get("steps") if line else 0)}
     if wl == "config5":
         continue
     fetch, write = counters(wl + "_fetch"), counters(wl + "_write")

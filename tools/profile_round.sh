@@ -16,12 +16,14 @@ run_stats() {   # name, bench args
 }
 run_pmc() {     # name, counters, bench args
   name=$1; ctrs=$2; shift 2
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $OUT/pmc_$name -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-verify --no-also "$@" > $OUT/pmc_$name.log 2>&1
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $OUT/pmc_$name -- python3 $ROOT/bench.py --steps 3 --warmup 1 --preroll 0 --no-cpu-baseline --no-verify --no-also "$@" > $OUT/pmc_$name.log 2>&1
   echo "pmc $name rc=$?"
 }
-run_stats sample
-run_stats config3 --workload config3
-run_stats config5 --workload config5 --steps 5 --warmup 2
+# (--stats averages over every dispatch, pre-roll and warmup included: enough timed steps that the ramp's 25 launches weigh
+# under 1 %; tools/profile_collect.py also reads the timed region's dispatches out of the trace by themselves)
+run_stats sample --steps 500 --warmup 5
+run_stats config3 --workload config3 --steps 300 --warmup 5
+run_stats config5 --workload config5 --steps 20 --warmup 2
 run_pmc sample_fetch FETCH_SIZE
 run_pmc sample_write WRITE_SIZE
 run_pmc config3_fetch FETCH_SIZE --workload config3
