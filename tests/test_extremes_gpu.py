@@ -66,14 +66,14 @@ def test_extreme_inputs(oracle_lib, monkeypatch, kernel, name):
     assert over == 0
 
 
-@pytest.mark.parametrize("name", ["plain", "one NaN", "one inf", "x 1e30", "step 1e12", "step 1e-12", "clicks over quiet audio"])
-@pytest.mark.parametrize("spectrum", [0, 1])
+# (|X|^2 of a recording at 1e30 is not a case: it does not fit fp32 -- the reference's vDSP_zvmags overflows too)
+@pytest.mark.parametrize("name,spectrum", [(name, spectrum) for spectrum in (0, 1)
+                                           for name in ("plain", "one NaN", "one inf", "x 1e30", "step 1e12", "step 1e-12", "clicks over quiet audio")
+                                           if not (spectrum and name == "x 1e30")])
 def test_extreme_inputs_spectrogram(oracle_lib, name, spectrum):
     """The spectrogram API (the fused engine's DFT half) on the same inputs: every column to 1e-5 of its largest value, NaN
     exactly in the frames that contain the offending sample."""
     import torch
-    if spectrum and name == "x 1e30":
-        pytest.skip("|X|^2 of a recording at 1e30 does not fit fp32 (the reference's vDSP_zvmags overflows too)")
     cfg = util.sample_net()
     cfg.spectrum = spectrum
     x = _cases()[name]

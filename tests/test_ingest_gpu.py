@@ -2,6 +2,8 @@
 ResamplerLinear (bit-identical to the oracle's restatement of Resampler.swift:36-69, call after call),
 interleaved -> channel-major (exact), the interleaved batch entry points, and the wide network of
 BASELINE configs[4] on the generic engine."""
+import os
+
 import numpy as np
 import pytest
 
@@ -122,11 +124,16 @@ def test_wide_network_config5_on_the_generic_engine(oracle_lib):
 WIDE_TOL = 1e-2      # bf16 inputs and first-layer weights (8-bit significands), fp32 accumulate: BASELINE configs[4]'s own bar
 
 
-@pytest.mark.parametrize("shape", ["config5", "H96_3out_logsig", "H40_normalize"])
-def test_wide_network_bf16_mfma_engine(oracle_lib, shape):
+@pytest.mark.parametrize("shape", ["config5", "H96_3out_logsig", "H40_normalize", "H72_2out_satlin", "config5_shape32"])
+def test_wide_network_bf16_mfma_engine(oracle_lib, shape, monkeypatch):
     """The opt-in wide engine (first layer as a bf16 MFMA GEMM over thousands of evaluations) against the fp64 anchor,
-    to bf16's bar; flags wherever the anchor is farther than that from the threshold."""
+    to bf16's bar; flags wherever the anchor is farther than that from the threshold.  The four instantiations of the
+    16x16x32 GEMM (one / several outputs x folded sigmoid / any other transfer function), and the 32x32x16 form of rounds
+    1-2 behind its switch (read when the detector is created)."""
     torch = _torch()
+    if shape == "config5_shape32":
+        monkeypatch.setenv("SYLDET_WIDE_SHAPE32", "1")
+        shape = "config5"
     base = nets.from_npz()
     rng = np.random.default_rng(3)
     if shape == "config5":
@@ -134,6 +141,8 @@ def test_wide_network_bf16_mfma_engine(oracle_lib, shape):
     elif shape == "H96_3out_logsig":
         cfg = nets.variant(base, net=nets.random_net(rng, 290, (96,), 3, transfer=("LogSig", "TanSig")), thresholds=[0.1, 0.2, 0.3],
                            rule=_abi.RULE_ANY)
+    elif shape == "H72_2out_satlin":
+        cfg = nets.variant(base, net=nets.random_net(rng, 290, (72,), 2, transfer=("SatLin", "TanSig")), thresholds=[0.1, 0.2])
     else:
         cfg = nets.variant(base, net=nets.random_net(rng, 290, (40,), 1, transfer=("SatLin", "PureLin"), in_fns=("normalize",), out_fns=()))
     C, S = 3, 70000                                      # 3 x 521 evaluations: several 512-evaluation tiles, ragged end
@@ -141,9 +150,12 @@ def test_wide_network_bf16_mfma_engine(oracle_lib, shape):
     o = po.Oracle(po.from_config(cfg))
     with sd.SyllableDetector(cfg, channels=C, engine=_abi.ENGINE_WIDE_BF16) as det:
         assert det.geometry.engine == _abi.ENGINE_WIDE_BF16
+        det.profile(True)
         out, fl = det.run(torch.from_numpy(x).cuda())
         torch.cuda.synchronize()
         out, fl = out.cpu().numpy(), fl.cpu().numpy()
+        gemm = [k for k, _ in det.lastTimings() if k.startswith("wide_gemm")]
+        assert gemm == (["wide_gemm_kernel"] if "SYLDET_WIDE_SHAPE32" in os.environ else ["wide_gemm16_kernel"])
     worst = 0.0
     for c in range(C):
         _, _, w64 = o.run(x[c], po.F64, cfg.rule)
