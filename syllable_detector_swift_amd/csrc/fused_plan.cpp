@@ -206,6 +206,7 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
     // frames 16-byte aligned, and a tile's samples leave room in the wave's share of the LDS.
     {
         d.s_ok = 0;
+        d.s_padp = 0;
         bool sym = (W % 64 == 0) && (g.gap % 4 == 0);
         // (to an ulp of the fp32 table: the two sides are averaged below, which moves a coefficient by 2^-25 of itself at most)
         for (int nn = 1; nn < W && sym; nn++) sym = std::fabs((double)win[(size_t)nn] - (double)win[(size_t)(W - nn)]) <= 2.4e-7 * std::fabs((double)win[(size_t)nn]) + 1e-30;
@@ -214,17 +215,39 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
         const int PSs = 4 * HQ * TP + 4;
         const int row_bytes = ((T - 1 + kFusedSTileFrames) * PSs + 8 * HQ + 128) * 4;   // rows, the zero quad and the dump quad, lane-group constants
         const int span = (kFusedSTileFrames - 1) * hop + W;
-        auto ring_chunks = [&](int waves) { return std::min(30, (160 * 1024 / waves - (row_bytes + 15) / 16 * 16) / 1024 - 1); };
+        // hops that are multiples of 64 floats put every frame of a tile on the same LDS banks: under a 256-sample window the ring
+        // is then padded by a quad after every `padp` floats (the power of two that divides the hop; one DMA instruction per
+        // padded piece of a chunk).  Instantiated for one quad of units (two would spill a register or three).  Not for
+        // 128-sample windows: there the pieces' DMA instructions cost more than the conflicts (1.65 against 1.47 ms at hop 64,
+        // profiles/r03_padded_ring_ab.txt)
+        int padp = 0;
+        if (hop % 64 == 0 && W == 256 && HQ == 1) padp = (hop % 128 == 0) ? 128 : 64;
+        if (padp > W / 2) padp = 0;
+#ifdef SYLDET_PLAN_NOPAD                 // (diagnostic builds, tools/knockouts.sh fused_plan.cpp ...: never the shipped library)
+        padp = 0;
+#endif
+        int chunk_bytes = 1024 + (padp ? 16 * (256 / padp) : 0);
+        auto ring_chunks = [&](int waves) { return std::min(30, (160 * 1024 / waves - (row_bytes + 15) / 16 * 16) / chunk_bytes - 1); };
         auto fits = [&](int rc) { return rc >= (span + 255) / 256 + 1 && kFusedSTileFrames * hop <= rc * 256; };
         // two waves a SIMD where the rows of tap products leave room for the ring in a 20 KB share of the LDS (one or two quads of units)
         // (one quad: always -- it is instantiated for 8 waves only)
+        if (padp && !fits(ring_chunks(kFusedSBlock / 64))) {     // (the padding costs a chunk: hop 192 under a 256-sample window keeps the plain ring)
+            padp = 0;
+            chunk_bytes = 1024;
+        }
         const int s_waves = (HQ == 1 || (HQ == 2 && fits(ring_chunks(kFusedSBlock / 64)))) ? kFusedSBlock / 64 : kFusedSBlock / 128;
         const int per_wave = 160 * 1024 / s_waves;
         const int RC = ring_chunks(s_waves);
         if (sym && H <= 16 && c.n_layers == 2 && fits(RC)) {
             d.s_ok = 1;
             d.s_waves = s_waves;
-            d.s_perm = (hop / 4) % 2 == 1 ? 1 : 0;               // (the slot permutation spreads the frames over the banks when hop / 4 is odd)
+            d.s_padp = (padp && s_waves == kFusedSBlock / 64) ? padp : 0;
+            // (the slot permutation spreads the frames over the banks when a frame's start moves on by an odd number of quads --
+            // the padding counts)
+            d.s_perm = (hop / 4 + (d.s_padp ? hop / d.s_padp : 0)) % 2 == 1 ? 1 : 0;
+#ifdef SYLDET_PLAN_NOPERM
+            d.s_perm = (hop / 4) % 2 == 1 ? 1 : 0;
+#endif
             d.s_ring_chunks = RC; d.s_pstride = PSs; d.s_tp = TP;
             d.s_lds_wave = per_wave;
             const int K2 = W / 64, c0 = W / 2;

@@ -145,6 +145,7 @@ struct FusedDesc {
     // rows of s_pstride floats of tap products (4 s_tp products, the frame's sum of squares, its floor weight); s_ok = 0 when the
     // shape does not fit it
     int s_ok, s_waves, s_perm, s_ring_chunks, s_pstride, s_tp, s_lds_wave, s_seg_evals;
+    int s_padp;                 // 0, or the padding period (floats) of the fold kernel's sample ring: hops that are multiples of 64 (fused_plan.cpp)
     const uint4 *sfrag;         // [W/64 k-steps][s, d][bins 0-15, 16-31][hi,lo][64 lanes] A-operand fragments of the folded basis
     const uint4 *afrag_w;       // [3][HQ quads of hidden units][hi,lo][64 lanes] the first layer with all taps as rows for 5 .. 16 units
     const float *slone;         // [64 lanes][8] the frame's first sample's real coefficients for the lane's bins

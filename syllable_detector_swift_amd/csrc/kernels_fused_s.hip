@@ -82,7 +82,10 @@ __device__ __forceinline__ void split2(float a, float b, unsigned &hi, unsigned 
 // linear output).  HQ: quads of hidden units (H <= 4 HQ).  One quad: 8 waves a workgroup, two per SIMD, 256 registers each.
 // Wider hidden layers (5 .. 16 units) multiply the first layer's rows -- 9 HQ tap MFMAs a tile, 24 HQ fragment registers, rows
 // of 4 HQ T products -- and take 4 waves a workgroup, one per SIMD, with twice the registers and twice the LDS each.
-template <int K2, bool GEN, int HQ, int NW>
+// PADP: 0, or the power of two that divides the hop when the hop is a multiple of 64 floats: the frames of a tile would then
+// all start on the same LDS banks, so the ring is laid out with one quad of padding after every PADP floats -- a frame's
+// start moves on by one bank group per frame, and inside a frame the padding is a compile-time offset per access.
+template <int K2, bool GEN, int HQ, int NW, int PADP = 0>
 __global__ void __launch_bounds__(64 * NW, 1)
 fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t stride, int64_t s_eff, int64_t E,
                float *__restrict__ outputs, uint8_t *__restrict__ flags)
@@ -111,9 +114,12 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
     // ---- wave-private LDS: sample ring (RC chunks of 256 floats + one mirror chunk), tap products, a zero quad
     unsigned char *wbase = smem + (size_t)wave * d.s_lds_wave;
     const int RC = d.s_ring_chunks, R = RC * 256;
+    constexpr int kSub = PADP ? 256 / PADP : 1;       // padded pieces of a chunk of 256 floats
+    constexpr int kChunkB = 1024 + (PADP ? 16 * kSub : 0);
+    auto sk = [](int i) { return PADP ? 4 * (i / (PADP ? PADP : 1)) : 0; };   // padding (floats) in front of position i of a frame / of the ring
     float *ring = reinterpret_cast<float *>(wbase);
     const int PS = d.s_pstride, TP = d.s_tp;          // floats per frame row: 4 TP tap products, sum of squares, floor weight, padding
-    float *rows = reinterpret_cast<float *>(wbase + (size_t)(RC + 1) * 1024);       // [T - 1 + 16][PS]
+    float *rows = reinterpret_cast<float *>(wbase + (size_t)(RC + 1) * kChunkB);    // [T - 1 + 16][PS]
     float *zquad = rows + (T - 1 + kTile) * PS;       // 8 HQ floats: HQ zero quads (what taps past timeRange read), HQ quads for stores that have no place
     // Two quads of units at two waves a SIMD: 256 registers hold the basis, 48 registers of first-layer fragments and the
     // loop's working set only if the constants that depend on the lane group alone wait in LDS (4 groups x 20 floats behind the
@@ -168,8 +174,18 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
     auto issue_upto = [&](int last) {
         while (cn <= last) {
             const unsigned voff = org + (unsigned)cn * 1024u + (unsigned)lane * 16u;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rs, (lds_void *)(wbase + slot * 1024), 16, voff, 0, 0, 2 /* nt */);
-            if (slot == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rs, (lds_void *)(wbase + RC * 1024), 16, voff, 0, 0, 2);
+            if (PADP == 0) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rs, (lds_void *)(wbase + slot * 1024), 16, voff, 0, 0, 2 /* nt */);
+                if (slot == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rs, (lds_void *)(wbase + RC * 1024), 16, voff, 0, 0, 2);
+            } else {
+                // (the DMA writes base + 16 lane: one instruction per padded piece, its lanes only, the base moved on by the padding)
+#pragma unroll
+                for (int k = 0; k < kSub; k++)
+                    if (lane / (64 / kSub) == k) {
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rs, (lds_void *)(wbase + slot * kChunkB + 16 * k), 16, voff, 0, 0, 2);
+                        if (slot == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rs, (lds_void *)(wbase + RC * kChunkB + 16 * k), 16, voff, 0, 0, 2);
+                    }
+            }
             cn++;
             slot = slot + 1 == RC ? 0 : slot + 1;
         }
@@ -247,7 +263,7 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
         // tile t's chunks have landed (behind them in the queue: nothing but the two result stores of tile t - 1)
         if (t == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        const float *fp = ring + fo;                  // this lane's frame: W samples from here (the mirror makes them contiguous)
+        const float *fp = ring + fo + sk((int)fo);    // this lane's frame: W samples from here (the mirror makes them contiguous)
 
         // ---- the frame's own scale from its loudest sample (this lane looks at a quarter of the frame)
         float amax;
@@ -256,7 +272,7 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
 #else
         {
             float m0 = 0.0f, m1 = 0.0f;
-            const floatx4 *q0 = reinterpret_cast<const floatx4 *>(fp + (W / 4) * g);
+            const floatx4 *q0 = reinterpret_cast<const floatx4 *>(fp + (W / 4) * g + sk((W / 4) * g));   // (a quarter never crosses a padding)
 #pragma unroll
             for (int q = 0; q < W / 16; q++) {
                 const floatx4 v = q0[q];
@@ -292,13 +308,15 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
         const float xl = fp[0] * sx;                  // the frame's first sample (no partner)
         floatx4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // re 0-15, re 16-31, im 0-15, im 16-31
         const float *xpb = fp + W / 2 + 8 * g, *xmb = fp + W / 2 - 8 * g;
+        const float *xmz = xmb + ((PADP && g == 0) ? 4 : 0);     // (the word c - m0 of lane group 0 sits on a piece's first position)
 #ifndef SYLDET_S_NODFT
 #pragma unroll
         for (int ks = 0; ks < K2; ks++) {
             // x[c + m0 + i], i = 0..7, and x[c - m0 - i]: words c-m0-8 .. c-m0-1 as two quads, and the word c - m0
-            const floatx4 p0 = *reinterpret_cast<const floatx4 *>(xpb + 32 * ks), p1 = *reinterpret_cast<const floatx4 *>(xpb + 32 * ks + 4);
-            const floatx4 q1 = *reinterpret_cast<const floatx4 *>(xmb - 32 * ks - 8), q2 = *reinterpret_cast<const floatx4 *>(xmb - 32 * ks - 4);
-            const float q0 = xmb[-32 * ks];
+            const int skp = sk(W / 2 + 32 * ks), skm = sk(W / 2 - 32 * ks - 32), skw = sk(W / 2 - 32 * ks);   // (constants once unrolled)
+            const floatx4 p0 = *reinterpret_cast<const floatx4 *>(xpb + 32 * ks + skp), p1 = *reinterpret_cast<const floatx4 *>(xpb + 32 * ks + 4 + skp);
+            const floatx4 q1 = *reinterpret_cast<const floatx4 *>(xmb - 32 * ks - 8 + skm), q2 = *reinterpret_cast<const floatx4 *>(xmb - 32 * ks - 4 + skm);
+            const float q0 = (skw != skm ? xmz : xmb)[-32 * ks + skm];
             const float xp[8] = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
             const float xm[8] = {q0, q2[3], q2[2], q2[1], q2[0], q1[3], q1[2], q1[1]};
             float s[8], dd[8];
@@ -646,11 +664,11 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
     }
 }
 
-template <int K2, bool GEN, int HQ, int NW>
+template <int K2, bool GEN, int HQ, int NW, int PADP = 0>
 hipError_t launch_one(const FusedDesc &d, const float *samples, int64_t stride, int C, int64_t s_eff, int64_t E,
                       float *outputs, uint8_t *flags, hipStream_t stream)
 {
-    auto kern = fused_s_kernel<K2, GEN, HQ, NW>;
+    auto kern = fused_s_kernel<K2, GEN, HQ, NW, PADP>;
     constexpr int kWaves = NW;
     const int lds = d.s_lds_wave * kWaves;
     hipError_t st = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -692,6 +710,18 @@ hipError_t launch_fused_s(const FusedDesc &d, const float *samples, int64_t stri
         if (exact) return launch_one<K2_, false, 1, 8>(d, samples, stride, C, s_eff, E, outputs, flags, stream);      \
         return launch_one<K2_, true, 1, 8>(d, samples, stride, C, s_eff, E, outputs, flags, stream);                  \
     }
+    // hops that are multiples of 64: the padded ring (256-sample windows, up to 4 hidden units: fused_plan.cpp)
+#define SD_S_PAD(K2_, P_)                                                                                              \
+    if (d.W == 64 * K2_ && d.s_padp == P_) {                                                                           \
+        if (d.H > 4) return hipErrorInvalidValue;                                                                      \
+        if (exact) return launch_one<K2_, false, 1, 8, P_>(d, samples, stride, C, s_eff, E, outputs, flags, stream);   \
+        return launch_one<K2_, true, 1, 8, P_>(d, samples, stride, C, s_eff, E, outputs, flags, stream);               \
+    }
+    if (d.s_padp) {
+        SD_S_PAD(4, 64) SD_S_PAD(4, 128)
+        return hipErrorInvalidValue;
+    }
+#undef SD_S_PAD
     SD_S_GO(4) SD_S_GO(2) SD_S_GO(1) SD_S_GO(3)
 #undef SD_S_GO
     return hipErrorInvalidValue;

@@ -228,8 +228,9 @@ def test_random_example_class_detector_on_the_register_resident_kernel(oracle_li
     rng = np.random.default_rng(77000 + seed)
     cfg = draw_example_class(rng)
     hop_ = cfg.windowLength - cfg.windowOverlap
-    if kernel == "fused_s_kernel" and (cfg.windowLength % 64 != 0 or (hop_ % 64 == 0 and cfg.windowLength > 128)):
-        kernel = "fused_r_kernel"      # (windows of 96 samples; hops of 64 / 128 under long windows: the other kernel's padded staging)
+    padded = cfg.windowLength == 256 and cfg.net.layers[0].outputs <= 4          # (the fold kernel's padded ring)
+    if kernel == "fused_s_kernel" and (cfg.windowLength % 64 != 0 or (hop_ % 64 == 0 and cfg.windowLength > 128 and not padded)):
+        kernel = "fused_r_kernel"      # (windows of 96 samples; hops of 64 / 128 under 192-sample windows or wider layers: the other kernel's padded staging)
     hop = cfg.windowLength - cfg.windowOverlap
     edges = [10, 11, 63, 64, 65, 73, 74, 127, 128, 129, 137, 192, 201, 2047, 2048, 2049, 2057, 2058, 4100]
     frames = max(cfg.timeRange, int(edges[seed % len(edges)] if seed < len(edges) else rng.integers(10, 6000)))

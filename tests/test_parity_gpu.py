@@ -219,8 +219,9 @@ def test_several_outputs_on_the_register_resident_kernel(oracle_lib, monkeypatch
         det.profile(True)
         out, fl = det.run(torch.from_numpy(x).cuda())
         torch.cuda.synchronize()
-        # (hops that are multiples of 64 stay on the register-resident-basis kernel for long windows: its padded staging)
-        assert [nm for nm, _ in det.lastTimings()] == ["fused_r_kernel" if hop % 64 == 0 else kernel]
+        # (hops that are multiples of 64: the fold kernel's padded ring is instantiated for up to four hidden units; wider
+        # layers stay on the register-resident-basis kernel and its padded staging)
+        assert [nm for nm, _ in det.lastTimings()] == ["fused_r_kernel" if (hop % 64 == 0 and H > 4) else kernel]
         out, fl = out.cpu().numpy(), fl.cpu().numpy()
     fired = 0
     for c in range(2):
@@ -880,3 +881,32 @@ def test_1024_point_frames_in_one_launch_and_in_two(oracle_lib, monkeypatch):
         assert [nm for nm, _ in det.lastTimings()] == ["bdft_net_kernel"]
         for c in range(2):
             util.assert_outputs_close(out[c].cpu().numpy(), o.run(xs[c].cpu().numpy(), po.F64)[2])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("W,hop,H", [(256, 64, 4), (256, 128, 4), (256, 192, 3), (128, 64, 4), (256, 128, 2)])   # (hop 192: no room for the padding, the plain ring)
+def test_hops_that_are_multiples_of_64_on_the_fold_kernel(oracle_lib, W, hop, H):
+    """Frames that start a multiple of 64 floats apart would all read the same LDS banks: the fold kernel lays its sample ring
+    out with a quad of padding per power-of-two piece of the hop.  Same numbers as any other hop (values to 1e-5 of the fp64
+    anchor, flags exact), over recordings long enough for the ring to wrap many times, ragged ends, several channels."""
+    torch = _torch()
+    rng = np.random.default_rng(640 + W + hop + H)
+    base = util.sample_net()
+    F = 29 if W == 256 else 15
+    net = nets.random_net(rng, F * 10, (H,), 1, in_fns=("l2normalize", "mapminmax"), out_fns=("mapminmax",))
+    cfg = nets.variant(base, fourierLength=W, windowLength=W, windowOverlap=W - hop, net=net, thresholds=[0.1])
+    C = 3
+    for S in (W + 9 * hop, 70000 + 13, 300000 + 77):
+        x = synth.channels(C, S, first=7, fs=cfg.samplingRate)
+        o = util.oracle_for(cfg)
+        with sd.SyllableDetector(cfg, channels=C) as det:
+            det.profile(True)
+            out, fl = det.run(torch.from_numpy(x).cuda())
+            torch.cuda.synchronize()
+            assert [nm for nm, _ in det.lastTimings()] == ["fused_s_kernel"]
+            assert det.fixupStats() == (0, 0)
+            out, fl = out.cpu().numpy(), fl.cpu().numpy()
+        for c in range(C):
+            _, _, w64 = o.run(x[c], po.F64, cfg.rule)
+            util.assert_outputs_close(out[c], w64)
+            util.assert_flags_exact(fl[c], w64, cfg.thresholds, cfg.rule)
