@@ -70,16 +70,24 @@ struct WideDesc {
     int n_out, tf0, tf1, rule, n_out_fns;
     int sig;                    // TanSig / LogSig hidden layer folded into the tables (see wide_gemm_kernel)
     int shape16;                // the chunks are packed for v_mfma_f32_16x16x32_bf16 ([k-step of 32][unit tile of 16]): wide_gemm16_kernel
+    // front = 1: the GEMM kernel reads the |X| columns itself (an evaluation's inputs are I consecutive floats of [C][J][F]) --
+    // the input chain is [l2normalize,] affine maps on linear columns, the affine part folded into the first layer by the host,
+    // so the B operands are bf16(v / |v|) (l2 = 1) or bf16(v): no [evaluations][320] image in HBM, no preparation kernel
+    int front, l2, I, F;
     const uint4 *wpack;         // [n_chunks][kWideChunkBytes / 16]
     const float *b1;            // [n_out]
     const float *out_params;    // per output fn: y, gain[n_out], xoff[n_out]
     const double *thresholds;   // [n_out]
 };
 // columns [C][J][F] -> xn [C*E][kWideK] bf16 (scaling + input functions applied)
+int wide_front_stage_floats(int F, int I);
+bool wide_front_fits(int F, int I);        // WideDesc::front needs the columns under 512 evaluations in LDS
 bool wide_prep_is_chain(const NetDesc &n);   // which of the two preparation kernels launch_wide_prep picks (for timing labels)
 hipError_t launch_wide_prep(const NetDesc &n, int F, const float *columns, int C, int64_t J, int64_t E, void *xn, hipStream_t stream);
 // xn [NE][kWideK] -> outputs [NE][n_out], flags [NE]
-hipError_t launch_wide_gemm(const WideDesc &d, const void *xn, int64_t NE, float *outputs, uint8_t *flags, hipStream_t stream);
+// (front: columns [C][J][F], E evaluations per channel, NE = C E; xn unused)
+hipError_t launch_wide_gemm(const WideDesc &d, const void *xn, const float *columns, int64_t J, int64_t E, int64_t NE, float *outputs,
+                            uint8_t *flags, hipStream_t stream);
 
 // ---- fused engine (kernels_fused.hip) ----------------------------------------------------
 // One kernel: samples -> outputs + flags.  The band-limited windowed DFT of 32 frames at a

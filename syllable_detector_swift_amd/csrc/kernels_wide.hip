@@ -354,27 +354,89 @@ wide_gemm_kernel(WideDesc d, const uint4 *__restrict__ xn, int64_t NE, float *__
 //   D [16 units x 16 evals]: lane l holds evaluation l % 16; register i holds unit 4 (l / 16) + i
 // ------------------------------------------------------------------------------------
 typedef float floatx4w __attribute__((ext_vector_type(4)));
-template <int NOUT, bool SIG>
+// FRONT: the B operands are made here from the |X| columns (WideDesc::front) instead of being read from the prepared image.
+template <int NOUT, bool SIG, bool FRONT>
 __global__ void __launch_bounds__(kBlock, 1)
-wide_gemm16_kernel(WideDesc d, const uint4 *__restrict__ xn, int64_t NE, float *__restrict__ outputs, uint8_t *__restrict__ flags)
+wide_gemm16_kernel(WideDesc d, const uint4 *__restrict__ xn, const float *__restrict__ columns, int64_t J, int64_t E, int64_t NE,
+                   float *__restrict__ outputs, uint8_t *__restrict__ flags)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int kWaves = kBlock / 64, kK2 = kWideK / 32;
     uint4 *buf0 = reinterpret_cast<uint4 *>(smem), *buf1 = buf0 + kChunkU4Pad;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g = lane >> 4;
+    // FRONT: a workgroup's 512 evaluations are consecutive ones of ONE channel (grid y), so the columns under them are one
+    // stretch of 511 F + I floats, staged through LDS once; otherwise evaluations are numbered through all channels
+    const int64_t e_blk = (int64_t)blockIdx.x * kWideTile;        // (FRONT: within channel blockIdx.y)
     int64_t ev[2];
+    bool ev_ok[2];
 #pragma unroll
-    for (int t = 0; t < 2; t++) ev[t] = (int64_t)blockIdx.x * kWideTile + wave * 32 + 16 * t + n;
+    for (int t = 0; t < 2; t++) {
+        const int64_t el = e_blk + wave * 32 + 16 * t + n;
+        ev[t] = FRONT ? (int64_t)blockIdx.y * E + el : el;
+        ev_ok[t] = FRONT ? el < E : el < NE;
+    }
     bf16x8 B[2][kK2];
+    if (!FRONT) {
 #pragma unroll
-    for (int t = 0; t < 2; t++)
+        for (int t = 0; t < 2; t++)
 #pragma unroll
-        for (int ks = 0; ks < kK2; ks++) {
-            union { uint4 u; bf16x8 v; } b;
-            b.u = ev[t] < NE ? xn[ev[t] * (kWideK / 8) + 4 * ks + g] : uint4{0, 0, 0, 0};
-            B[t][ks] = b.v;
+            for (int ks = 0; ks < kK2; ks++) {
+                union { uint4 u; bf16x8 v; } b;
+                b.u = ev_ok[t] ? xn[ev[t] * (kWideK / 8) + 4 * ks + g] : uint4{0, 0, 0, 0};
+                B[t][ks] = b.v;
+            }
+    } else {
+        // evaluation e of channel c: frames e .. e + T - 1 = I consecutive floats of the channel's [J][F] columns
+        // (SyllableDetector.swift:158-181); this lane holds inputs 32 ks + 8 g + 0..7 of it.  The stretch under the workgroup's
+        // evaluations goes through LDS (behind the two chunk buffers): coalesced loads once, then every lane picks its own
+        float *stage = reinterpret_cast<float *>(smem + 2 * kChunkU4Pad * 16);
+        const int F = d.F, I = d.I;
+        const int span = (kWideTile - 1) * F + I;                 // (wide_front_stage_floats - 1)
+        const float *chan = columns + (int64_t)blockIdx.y * J * F;
+        const int64_t first = e_blk * F, limit = J * (int64_t)F;
+        for (int i = tid; i < span; i += kBlock) stage[i] = first + i < limit ? chan[first + i] : 0.0f;
+        float *css = stage + span + 32;                           // [frames under the workgroup] a column's sum of squares (32 floats of slack: reads past I stay inside)
+        __syncthreads();
+        const int T = I / F;                                      // (I = F timeRange: SyllableDetector.swift:52-55)
+        if (d.l2) {
+            for (int f = tid; f < kWideTile + T - 1; f += kBlock) {
+                float a = 0.0f;
+                for (int b = 0; b < F; b++) a = fmaf(stage[f * F + b], stage[f * F + b], a);
+                css[f] = a;
+            }
+            __syncthreads();
         }
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const int el = wave * 32 + 16 * t + n;
+            int off = el * F + 8 * g;
+            const int lim = I - 8 * g;
+            float rinv = 1.0f;
+            if (d.l2) {                                           // L2Normalize, NeuralNet.swift:47-59: the window's sum of squares from its columns'
+                float ss = 0.0f;
+                for (int tt = 0; tt < T; tt++) ss += css[el + tt];
+                rinv = 1.0f / sqrtf(ss);                          // (silence: 0 * inf = NaN, as the reference's 0 / 0)
+            }
+            asm volatile("" : "+v"(off), "+v"(rinv));             // (the reads below stay below: hoisted, their 80 values would wait in scratch)
+            const float *src = stage + off;
+#pragma unroll
+            for (int ks = 0; ks < kK2; ks++) {
+                bf16x8 b;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const float x = src[32 * ks + j];             // (always read; inputs past I are the next frames' values: zeroed)
+                    b[j] = (__bf16)((32 * ks + j < lim ? x : 0.0f) * rinv);
+                }
+                union { bf16x8 v; uint4 u; } pk;                  // (finished here, four registers, before the next k-step's reads: left to
+                pk.v = b;                                         // itself the compiler reads all 80 values first and parks them in scratch)
+                asm volatile("" : "+v"(pk.u.x), "+v"(pk.u.y), "+v"(pk.u.z), "+v"(pk.u.w));
+                B[t][ks] = pk.v;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();                                          // (nothing else uses the stage; the chunk buffers are next)
+    }
     float ysum[2][NOUT];
 #pragma unroll
     for (int t = 0; t < 2; t++)
@@ -440,7 +502,11 @@ wide_gemm16_kernel(WideDesc d, const uint4 *__restrict__ xn, int64_t NE, float *
     int tid2 = threadIdx.x;
     asm volatile("" : "+v"(tid2));                                // (recomputed: held across the loop they cost two spilled pairs)
 #pragma unroll
-    for (int t = 0; t < 2; t++) ev[t] = (int64_t)blockIdx.x * kWideTile + (tid2 >> 6) * 32 + 16 * t + (tid2 & 15);
+    for (int t = 0; t < 2; t++) {
+        const int64_t el = (int64_t)blockIdx.x * kWideTile + (tid2 >> 6) * 32 + 16 * t + (tid2 & 15);
+        ev[t] = FRONT ? (int64_t)blockIdx.y * E + el : el;
+        ev_ok[t] = FRONT ? el < E : el < NE;
+    }
 #pragma unroll
     for (int t = 0; t < 2; t++) {
 #pragma unroll
@@ -450,7 +516,7 @@ wide_gemm16_kernel(WideDesc d, const uint4 *__restrict__ xn, int64_t NE, float *
             r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
             ysum[t][o] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
         }
-        if (g == 0 && ev[t] < NE) {
+        if (g == 0 && ev_ok[t]) {
             bool hit = false;
 #pragma unroll
             for (int o = 0; o < NOUT; o++) {
@@ -471,6 +537,10 @@ wide_gemm16_kernel(WideDesc d, const uint4 *__restrict__ xn, int64_t NE, float *
 }  // namespace
 
 // the input chains the training script writes -- [l2normalize,] one affine map -- take the chain-specialised kernel
+// floats of |X| columns under one workgroup's 512 consecutive evaluations (WideDesc::front), and whether they fit behind the chunk buffers
+int wide_front_stage_floats(int F, int I) { return (kWideTile - 1) * F + I + 32 + kWideTile + I / (F > 0 ? F : 1); }   // (+ slack, + the columns' sums of squares)
+bool wide_front_fits(int F, int I) { return (size_t)wide_front_stage_floats(F, I) * 4 + 2 * kChunkU4Pad * 16 <= 150 * 1024; }
+
 bool wide_prep_is_chain(const NetDesc &n)
 {
     const bool affine_last = n.n_in_fns >= 1 && n.in_fns[n.n_in_fns - 1].kind >= 3;
@@ -492,18 +562,30 @@ hipError_t launch_wide_prep(const NetDesc &n, int F, const float *columns, int C
     return hipGetLastError();
 }
 
-hipError_t launch_wide_gemm(const WideDesc &d, const void *xn, int64_t NE, float *outputs, uint8_t *flags, hipStream_t stream)
+hipError_t launch_wide_gemm(const WideDesc &d, const void *xn, const float *columns, int64_t J, int64_t E, int64_t NE, float *outputs,
+                            uint8_t *flags, hipStream_t stream)
 {
     if (NE <= 0) return hipSuccess;
     dim3 grid((unsigned)((NE + kWideTile - 1) / kWideTile));
     if (d.shape16) {                      // the 16x16x32 shape (what ships; the other one under SYLDET_WIDE_SHAPE32=1, with its own packing)
         const bool one16 = d.n_out == 1;
-        auto k16 = d.sig ? (one16 ? wide_gemm16_kernel<1, true> : wide_gemm16_kernel<4, true>) : (one16 ? wide_gemm16_kernel<1, false> : wide_gemm16_kernel<4, false>);
-        hipError_t st16 = hipFuncSetAttribute((const void *)k16, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kChunkU4Pad * 16);
+        auto k16 = d.front ? (d.sig ? (one16 ? wide_gemm16_kernel<1, true, true> : wide_gemm16_kernel<4, true, true>)
+                                    : (one16 ? wide_gemm16_kernel<1, false, true> : wide_gemm16_kernel<4, false, true>))
+                           : (d.sig ? (one16 ? wide_gemm16_kernel<1, true, false> : wide_gemm16_kernel<4, true, false>)
+                                    : (one16 ? wide_gemm16_kernel<1, false, false> : wide_gemm16_kernel<4, false, false>));
+        size_t lds16 = 2 * kChunkU4Pad * 16;
+        dim3 grid16 = grid;
+        if (d.front) {                    // one channel per grid row; the columns under a workgroup's evaluations behind the chunk buffers
+            if (E <= 0 || NE % E != 0) return hipErrorInvalidValue;
+            lds16 += (size_t)wide_front_stage_floats(d.F, d.I) * 4;
+            grid16 = dim3((unsigned)((E + kWideTile - 1) / kWideTile), (unsigned)(NE / E));
+        }
+        hipError_t st16 = hipFuncSetAttribute((const void *)k16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);
         if (st16 != hipSuccess) return st16;
-        hipLaunchKernelGGL(k16, grid, dim3(kBlock), 2 * kChunkU4Pad * 16, stream, d, (const uint4 *)xn, NE, outputs, flags);
+        hipLaunchKernelGGL(k16, grid16, dim3(kBlock), lds16, stream, d, (const uint4 *)xn, columns, J, E, NE, outputs, flags);
         return hipGetLastError();
     }
+    if (d.front) return hipErrorInvalidValue;
     // (one output: two evaluation tiles a wave; with several outputs their running sums would spill -- one tile, 16 waves)
     constexpr int TW = kWideTilesPerWave;
     const bool one = d.n_out == 1;

@@ -124,6 +124,7 @@ struct syldet {
     struct Switches {
         bool fused_classic = false;   // SYLDET_FUSED_CLASSIC: the 8-wave fused kernel where both fused kernels take the shape
         bool no_fft1k = false;        // SYLDET_NO_FFT1K: 1024-point frames as two launches
+        bool wide_no_front = false;   // SYLDET_WIDE_NO_FRONT: the wide engine's inputs through the preparation kernel and the bf16 image in HBM (rounds 1-2)
         bool wide_shape32 = false;    // SYLDET_WIDE_SHAPE32: the wide engine's GEMM on the 32x32x16 MFMA shape (rounds 1-2), not 16x16x32
         bool no_bdft = false;         // SYLDET_NO_BDFT: frames of four hops on the FFT kernels, not the block-transform kernel
         bool no_stft_lanes = false;   // SYLDET_NO_STFT_LANES: the LDS Stockham FFT instead of the lane-butterfly one
@@ -138,6 +139,7 @@ struct syldet {
             no_fft1k = std::getenv("SYLDET_NO_FFT1K") != nullptr;
             no_bdft = std::getenv("SYLDET_NO_BDFT") != nullptr;
             wide_shape32 = std::getenv("SYLDET_WIDE_SHAPE32") != nullptr;
+            wide_no_front = std::getenv("SYLDET_WIDE_NO_FRONT") != nullptr;
             no_stft_lanes = std::getenv("SYLDET_NO_STFT_LANES") != nullptr;
             no_guard = std::getenv("SYLDET_NO_GUARD") != nullptr;
             no_mlpx = std::getenv("SYLDET_NO_MLPX") != nullptr;
@@ -333,6 +335,22 @@ int upload_wide(syldet *h, std::string &why)
     const double sc = !sig ? 1.0 : (L0.transfer == SYLDET_TF_TANSIG ? 2.8853900817779268 : -1.4426950408889634);
     const double w1s = (sig && L0.transfer == SYLDET_TF_TANSIG) ? -2.0 : 1.0;
     const bool shape16 = !h->sw.wide_shape32;
+    // The input chain the training script writes -- [l2normalize,] affine maps, on linear columns -- needs no preparation pass:
+    // u_i = a_i (v_i r) + o_i with r = 1 / |v| (or 1), so W0 u + b0 = (W0 diag a) (v r) + (W0 o + b0): the affine part goes
+    // into the first layer here, and the GEMM kernel makes its operands bf16(v r) from the columns themselves.  (Also the
+    // better numbers: bf16 keeps 8 bits of v r instead of 8 bits of a value that sits next to -1.)
+    bool front = shape16 && !h->sw.wide_no_front && c.scaling == SYLDET_SCALING_LINEAR && wide_front_fits(h->geom.bins, I);
+    int l2 = 0;
+    std::vector<double> fa((size_t)I, 1.0), fo((size_t)I, 0.0);
+    for (int k = 0; k < c.n_input_fns && front; k++) {
+        const syldet_fn_t &f = c.input_fns[k];
+        if (f.kind == SYLDET_FN_L2NORMALIZE && k == 0) { l2 = 1; continue; }
+        if (f.kind != SYLDET_FN_MAPMINMAX && f.kind != SYLDET_FN_MAPSTD) { front = false; break; }
+        for (int i = 0; i < I; i++) {                              // MapMinMax.apply :127-131, MapStd.apply :162-169
+            fo[(size_t)i] = (fo[(size_t)i] - (double)f.x_offsets[i]) * (double)f.gains[i] + (double)f.y;
+            fa[(size_t)i] *= (double)f.gains[i];
+        }
+    }
     for (int ch = 0; ch < n_chunks; ch++) {
         uint16_t *frag = pack.data() + (size_t)ch * chunk_u16;
         for (int ks = 0; ks < kWideK / 16; ks++)
@@ -342,13 +360,16 @@ int upload_wide(syldet *h, std::string &why)
                     // 16x16x32: fragment ks = (k-step of 32, unit tile of 16), lane l = unit l % 16 of its tile, k = 8 (l / 16) + j
                     const int unit = shape16 ? 32 * ch + 16 * (ks & 1) + (l & 15) : 32 * ch + (l & 31);
                     const int k = shape16 ? 32 * (ks >> 1) + 8 * (l >> 4) + j : 16 * ks + 8 * (l >> 5) + j;
-                    const float v = (unit < H && k < I) ? (float)(sc * (double)L0.weights[(size_t)unit * I + k]) : 0.0f;
+                    const float v = (unit < H && k < I) ? (float)(sc * (double)L0.weights[(size_t)unit * I + k] * (front ? fa[(size_t)k] : 1.0)) : 0.0f;
                     frag[((size_t)ks * 64 + l) * 8 + j] = to_bf16(v);
                 }
         float *cst = reinterpret_cast<float *>(frag + (size_t)(kWideK / 16) * 64 * 8);
         for (int u = 0; u < 32; u++) {
             const int unit = 32 * ch + u;
-            cst[u] = unit < H ? (float)(sc * (double)L0.biases[unit]) : 0.0f;
+            double b0f = unit < H ? (double)L0.biases[unit] : 0.0;
+            if (front && unit < H)
+                for (int i = 0; i < I; i++) b0f += (double)L0.weights[(size_t)unit * I + i] * fo[(size_t)i];
+            cst[u] = unit < H ? (float)(sc * b0f) : 0.0f;
             for (int o = 0; o < 4; o++) cst[32 + 32 * o + u] = (unit < H && o < n_out) ? (float)(w1s * (double)L1.weights[(size_t)o * H + unit]) : 0.0f;
         }
     }
@@ -374,6 +395,7 @@ int upload_wide(syldet *h, std::string &why)
     d.n_out_fns = c.n_output_fns;
     d.sig = sig ? 1 : 0;
     d.shape16 = shape16 ? 1 : 0;
+    d.front = front ? 1 : 0; d.l2 = l2; d.I = I; d.F = h->geom.bins;
     d.wpack = (const uint4 *)h->d_wide.ptr;
     d.b1 = (const float *)((const char *)h->d_wide.ptr + pack_bytes);
     d.out_params = d.b1 + n_out;
@@ -669,14 +691,15 @@ int run_on_stream(syldet *h, const float *d_samples, int64_t S, int64_t stride, 
     // (+ 16 bytes: the matrix-core network stage reads a frame's last bins as a whole quad)
     if (int st = h->d_columns.reserve((size_t)C * (size_t)J * (size_t)h->geom.bins * sizeof(float) + 16)) return st;
     if (h->engine == SYLDET_ENGINE_WIDE_BF16) {
-        if (int st = h->d_xn.reserve((size_t)C * (size_t)E * (size_t)kWideK * 2)) return st;
+        if (!h->wide.front)
+            if (int st = h->d_xn.reserve((size_t)C * (size_t)E * (size_t)kWideK * 2)) return st;
         if (int st = stft_on_stream(h, d_samples, stride, C, J, (float *)h->d_columns.ptr, stream)) return st;
-        {
+        if (!h->wide.front) {
             KernelTimer t(h, stream, wide_prep_is_chain(h->net) ? "wide_prep_chain_kernel" : "wide_prep_kernel");
             SYLDET_HIP(launch_wide_prep(h->net, h->geom.bins, (const float *)h->d_columns.ptr, C, J, E, h->d_xn.ptr, stream));
         }
         KernelTimer t(h, stream, h->wide.shape16 ? "wide_gemm16_kernel" : "wide_gemm_kernel");
-        SYLDET_HIP(launch_wide_gemm(h->wide, h->d_xn.ptr, (int64_t)C * E, d_outputs, d_flags, stream));
+        SYLDET_HIP(launch_wide_gemm(h->wide, h->d_xn.ptr, (const float *)h->d_columns.ptr, J, E, (int64_t)C * E, d_outputs, d_flags, stream));
         return SYLDET_OK;
     }
     // 1024-point frames in front of a network of the matrix-core class: one launch, the columns never leave the CU

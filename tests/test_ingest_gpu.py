@@ -124,7 +124,7 @@ def test_wide_network_config5_on_the_generic_engine(oracle_lib):
 WIDE_TOL = 1e-2      # bf16 inputs and first-layer weights (8-bit significands), fp32 accumulate: BASELINE configs[4]'s own bar
 
 
-@pytest.mark.parametrize("shape", ["config5", "H96_3out_logsig", "H40_normalize", "H72_2out_satlin", "config5_shape32"])
+@pytest.mark.parametrize("shape", ["config5", "H96_3out_logsig", "H40_normalize", "H72_2out_satlin", "config5_shape32", "config5_prepared"])
 def test_wide_network_bf16_mfma_engine(oracle_lib, shape, monkeypatch):
     """The opt-in wide engine (first layer as a bf16 MFMA GEMM over thousands of evaluations) against the fp64 anchor,
     to bf16's bar; flags wherever the anchor is farther than that from the threshold.  The four instantiations of the
@@ -133,6 +133,9 @@ def test_wide_network_bf16_mfma_engine(oracle_lib, shape, monkeypatch):
     torch = _torch()
     if shape == "config5_shape32":
         monkeypatch.setenv("SYLDET_WIDE_SHAPE32", "1")
+        shape = "config5"
+    if shape == "config5_prepared":                      # (the inputs as a bf16 image made by the preparation kernel, as in rounds 1-2)
+        monkeypatch.setenv("SYLDET_WIDE_NO_FRONT", "1")
         shape = "config5"
     base = nets.from_npz()
     rng = np.random.default_rng(3)
@@ -154,8 +157,14 @@ def test_wide_network_bf16_mfma_engine(oracle_lib, shape, monkeypatch):
         out, fl = det.run(torch.from_numpy(x).cuda())
         torch.cuda.synchronize()
         out, fl = out.cpu().numpy(), fl.cpu().numpy()
-        gemm = [k for k, _ in det.lastTimings() if k.startswith("wide_gemm")]
+        names = [k for k, _ in det.lastTimings()]
+        gemm = [k for k in names if k.startswith("wide_gemm")]
         assert gemm == (["wide_gemm_kernel"] if "SYLDET_WIDE_SHAPE32" in os.environ else ["wide_gemm16_kernel"])
+        # [l2normalize,] affine maps on linear columns: the GEMM reads the columns itself; other chains (and the old shape,
+        # and the switch) go through a preparation kernel
+        prepared = [k for k in names if k.startswith("wide_prep")]
+        direct = shape != "H40_normalize" and "SYLDET_WIDE_SHAPE32" not in os.environ and "SYLDET_WIDE_NO_FRONT" not in os.environ
+        assert (prepared == []) == direct
     worst = 0.0
     for c in range(C):
         _, _, w64 = o.run(x[c], po.F64, cfg.rule)
