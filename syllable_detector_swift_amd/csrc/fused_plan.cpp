@@ -546,9 +546,9 @@ bool make_bdft_plan(const syldet_config_t &c, const syldet_geometry_t &g, const 
 {
     p = BdftPlan();
     const int N = c.fourier_length, W = c.window_length, hop = g.hop, F = g.bins, T = c.time_range, I = g.inputs;
-    // the matrix-core network stage's class with 128-bin columns, |X| columns, linear scaling
+    // the matrix-core network stage's class with 128-bin columns, |X| columns (linear, ln or dB of them)
     // (its columns are 128 bins wide whatever the band: the owner gives it a copy of the stage's descriptor with those strides)
-    if (!mx.ok || c.scaling != SYLDET_SCALING_LINEAR || c.spectrum == SYLDET_SPECTRUM_MAGNITUDE) return false;
+    if (!mx.ok || c.spectrum == SYLDET_SPECTRUM_MAGNITUDE) return false;
     // frames of four whole blocks, no gap, no zero padding; 2 or 4 k-steps of 32 folded positions a block
     if (W != N || g.gap != 0 || 4 * hop != N || (hop != 128 && hop != 256)) return false;
     // the window as a short cosine sum (WindowType.createWindow, CircularShortTimeFourierTransform.swift:19-28; Blackman's five taps

@@ -94,8 +94,8 @@ __device__ __forceinline__ float shl_prev(float v)
 template <int Q>
 __device__ __forceinline__ float back(float cur, float prev) { return shr_cur<Q>(cur) + shl_prev<Q>(prev); }   // column n - Q of the stream
 
-// KS: k-steps of 32 folded positions per block (hop = 64 KS).  Frames of R = 4 blocks.
-template <int KS>
+// KS: k-steps of 32 folded positions per block (hop = 64 KS).  Frames of R = 4 blocks.  SC: log / dB columns.
+template <int KS, bool SC>
 __global__ void __launch_bounds__(kBlock, 1)
 bdft_net_kernel(const MlpxDesc d, const BdftDesc bd, const float *__restrict__ samples, int64_t stride, int64_t S, int64_t J, int64_t E,
                 int64_t evals_per_run, float *__restrict__ outputs, uint8_t *__restrict__ flags)
@@ -126,6 +126,8 @@ bdft_net_kernel(const MlpxDesc d, const BdftDesc bd, const float *__restrict__ s
     const int n = lane & 15, g = lane >> 4;
     const int c = blockIdx.y;
     const int F = d.F, T = d.T;
+    const int scaling = SC ? d.scaling : 0;                          // SYLDET_SCALING_*: linear |X|, ln |X| or 20 log10 |X| columns
+    const float lscale = scaling == 1 ? 0.6931471805599453f : 6.020599913279624f;      // ln 2, 20 log10 2
     const int64_t E0 = (int64_t)blockIdx.x * evals_per_run;
     if (E0 >= E) return;
     const int64_t E1 = E0 + evals_per_run < E ? E0 + evals_per_run : E;
@@ -348,18 +350,27 @@ bdft_net_kernel(const MlpxDesc d, const BdftDesc bd, const float *__restrict__ s
             const float xi = fmaf(wa0, yim[i], fmaf(wsn, reL[i] - reR[i], wc * (imL[i] + imR[i])));
             cv[i] = __builtin_amdgcn_sqrtf(fmaf(xr, xr, xi * xi));        // zvabs / 2, :329-333 (Y is the DFT itself, not twice it)
             const bool inb = (unsigned)(fb0 + i) < (unsigned)F;
+            if (scaling != 0) {
+                // ln x / 20 log10 x of the band's columns (SyllableDetector.swift:185-207) through the hardware's base-2
+                // logarithm (a denormal argument is lifted into its range first); ln 0 = -inf as in the reference.  Bins
+                // outside the band meet zero weights: zeros, not logarithms of whatever is there
+                const bool tiny = cv[i] < 0x1p-96f;
+                const float l = __builtin_amdgcn_logf(tiny ? cv[i] * 0x1p64f : cv[i]) - (tiny ? 64.0f : 0.0f);
+                cv[i] = inb ? l * lscale : 0.0f;
+            }
             ssq = inb ? fmaf(cv[i], cv[i], ssq) : ssq;
         }
         ssq = xor32_sum(xor16_sum(ssq));
         const int rw = (rbase + (T - 1) + 16 * sp + n) & (kTile - 1);
         unsigned h0, l0, h1, l1;
-        split2(cv[0] * upc, cv[1] * upc, h0, l0);
-        split2(cv[2] * upc, cv[3] * upc, h1, l1);
+        const float upw = scaling != 0 ? 16.0f : upc;               // (logarithms are within +-800: a fixed scale keeps them under f16's 65504)
+        split2(cv[0] * upw, cv[1] * upw, h0, l0);
+        split2(cv[2] * upw, cv[3] * upw, h1, l1);
         const int cb = 16 * wave + 4 * g;                            // column index = bin - kb0 (the first layer's fragments are in that order)
         *reinterpret_cast<uint32x2 *>(colh + rw * CS + cb) = uint32x2{h0, h1};
         *reinterpret_cast<uint32x2 *>(coll + rw * CS + cb) = uint32x2{l0, l1};
         if (g == 0) ssf8[rw * kWaves + wave] = ssq;
-        if (fh && wave == 0 && g == 0) fsc[rw] = dnc;
+        if (fh && wave == 0 && g == 0) fsc[rw] = scaling != 0 ? 0.0625f : dnc;
     };
 
     const bool first_half = wave < kWaves / 2;
@@ -544,7 +555,7 @@ hipError_t launch_bdft_net(const MlpxDesc &d, const BdftDesc &bd, const float *s
 #endif
 #define SD_BDFT_GO(KS_)                                                                                                        \
     if (KS == KS_) {                                                                                                           \
-        auto kern = bdft_net_kernel<KS_>;                                                                                      \
+        auto kern = d.scaling != 0 ? bdft_net_kernel<KS_, true> : bdft_net_kernel<KS_, false>;                                 \
         hipError_t st = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);              \
         if (st != hipSuccess) return st;                                                                                       \
         hipLaunchKernelGGL(kern, grid, dim3(kBlock), (size_t)lds, stream, d, bd, samples, stride, S, J, E, evals_per_run, outputs, flags); \

@@ -723,7 +723,7 @@ def test_network_stage_on_the_matrix_cores(oracle_lib, N, lo, hi, T, H, scaling)
     one_launch = N == 1024 and scaling == "linear" and F % 4 == 0
     # (frames of four hops -- these are -- with 512 or 1024 points and a band that fits 128 bins with its two neighbours: every
     # block transformed once on the matrix cores, kernels_bdft.hip)
-    blocks = scaling == "linear" and N in (512, 1024) and f0 >= 1 and f0 + F + 1 <= (f0 - 1) // 4 * 4 + 128
+    blocks = N in (512, 1024) and f0 >= 1 and f0 + F + 1 <= (f0 - 1) // 4 * 4 + 128                 # (linear, log and dB columns alike)
     auto_kernel = "bdft_net_kernel" if blocks else ("fft1k_net_kernel" if one_launch else "mlp_mfma_kernel")
     for engine, kernel in ((_abi.ENGINE_AUTO, auto_kernel), (_abi.ENGINE_GENERIC, "mlp_generic_kernel")):
         with sd.SyllableDetector(cfg, channels=2, engine=engine) as det:
@@ -742,14 +742,15 @@ def test_network_stage_on_the_matrix_cores(oracle_lib, N, lo, hi, T, H, scaling)
             assert not fl[c][~ok].any()
 
 
-@pytest.mark.parametrize("N,window,lo,hi,T,H", [(1024, _abi.WINDOW_HANNING, 2000.0, 7000.0, 10, 4), (1024, _abi.WINDOW_NONE, 1000.0, 6000.0, 7, 3),
-                                                (512, _abi.WINDOW_HAMMING, 2000.0, 7000.0, 10, 4), (512, _abi.WINDOW_HANNING, 300.0, 10000.0, 12, 2),
-                                                (1024, _abi.WINDOW_BLACKMAN, 2000.0, 7000.0, 10, 4)])
-def test_frames_of_four_hops_on_the_block_transform_kernel(oracle_lib, N, window, lo, hi, T, H):
+@pytest.mark.parametrize("N,window,lo,hi,T,H,scaling", [(1024, _abi.WINDOW_HANNING, 2000.0, 7000.0, 10, 4, "linear"), (1024, _abi.WINDOW_NONE, 1000.0, 6000.0, 7, 3, "linear"),
+                                                        (512, _abi.WINDOW_HAMMING, 2000.0, 7000.0, 10, 4, "linear"), (512, _abi.WINDOW_HANNING, 300.0, 10000.0, 12, 2, "linear"),
+                                                        (1024, _abi.WINDOW_BLACKMAN, 2000.0, 7000.0, 10, 4, "linear"),
+                                                        (1024, _abi.WINDOW_HAMMING, 2000.0, 7000.0, 10, 4, "db"), (512, _abi.WINDOW_HANNING, 1000.0, 6150.0, 8, 3, "log")])
+def test_frames_of_four_hops_on_the_block_transform_kernel(oracle_lib, N, window, lo, hi, T, H, scaling):
     """kernels_bdft.hip: W = N = 4 hop, every block of `hop` samples transformed once on the matrix cores, frames as sliding
     sums of four blocks, the window (WindowType.createWindow, CircularShortTimeFourierTransform.swift:19-28) as three taps
-    along the bins.  Hann, Hamming and rectangular windows, 512- and 1024-point frames, bands up to 113 bins; a Blackman window
-    (five taps) keeps the FFT kernels.  Several runs per channel, a ragged tail, a 70 dB level step (every block has its own
+    along the bins.  Hann, Hamming and rectangular windows, 512- and 1024-point frames, bands up to 113 bins, linear, log and dB
+    columns (SyllableDetector.swift:184-212); a Blackman window (five taps) keeps the FFT kernels.  Several runs per channel, a ragged tail, a 70 dB level step (every block has its own
     scale), a stretch of silence (0/0 in l2normalize -> NaN, as in the reference), a NaN sample (exactly the frames that
     contain it, NeuralNet.swift:47-59)."""
     torch = _torch()
@@ -758,7 +759,7 @@ def test_frames_of_four_hops_on_the_block_transform_kernel(oracle_lib, N, window
     f0, f1 = frequencyIndexRange(N, 44100.0, lo, hi)
     F = f1 - f0
     net = nets.random_net(rng, F * T, (H,), 1, in_fns=("l2normalize", "mapminmax"), out_fns=("mapminmax",) if H != 3 else ())
-    cfg = SyllableDetectorConfig(44100.0, N, N, N - N // 4, (lo, hi), T, "linear", [0.4], net, window=window)
+    cfg = SyllableDetectorConfig(44100.0, N, N, N - N // 4, (lo, hi), T, scaling, [0.4], net, window=window)
     S = N + (N // 4) * 1500 + 101
     x = synth.channels(3, S, first=13).astype(np.float32)
     x[0, S // 2:] *= np.float32(0.0003)
