@@ -549,8 +549,10 @@ bool make_bdft_plan(const syldet_config_t &c, const syldet_geometry_t &g, const 
     // the matrix-core network stage's class with 128-bin columns, |X| columns (linear, ln or dB of them)
     // (its columns are 128 bins wide whatever the band: the owner gives it a copy of the stage's descriptor with those strides)
     if (!mx.ok || c.spectrum == SYLDET_SPECTRUM_MAGNITUDE) return false;
-    // frames of four whole blocks, no gap, no zero padding; 2 or 4 k-steps of 32 folded positions a block
-    if (W != N || g.gap != 0 || 4 * hop != N || (hop != 128 && hop != 256)) return false;
+    // frames of four or two whole blocks (75 % or 50 % overlap), no gap, no zero padding; 2 or 4 k-steps of 32 folded positions a
+    // block; 512 points and up (a frame costs this kernel the same whatever its length, the FFT kernels less the shorter it is:
+    // 256-point frames at hop 256 take 1.89 ms here against 1.36 as two launches, 512-point ones at hop 256 2.02 against 2.66)
+    if (W != N || g.gap != 0 || N < 512 || (hop != 128 && hop != 256) || (4 * hop != N && 2 * hop != N)) return false;
     // the window as a short cosine sum (WindowType.createWindow, CircularShortTimeFourierTransform.swift:19-28; Blackman's five taps
     // along the bins are not built)
     double a0, a1;
@@ -559,12 +561,13 @@ bool make_bdft_plan(const syldet_config_t &c, const syldet_geometry_t &g, const 
     else if (c.window == SYLDET_WINDOW_NONE) { a0 = 1.0; a1 = 0.0; }
     else return false;
     if (g.f0 < 1 || T > 12) return false;
-    const int kb0 = (g.f0 - 1) / 4 * 4;                          // the bin under the band is a neighbour of its first one
+    // the bin under the band is a neighbour of its first one; 128 bins from a multiple of 4 (where the spectrum has no more, from 0)
+    const int kb0 = std::min((g.f0 - 1) / 4 * 4, std::max(0, N / 2 - 128));
     if (g.f0 + F + 1 > kb0 + 128 || kb0 + 128 > N / 2) return false;
     const int KS = hop / 64, c0 = hop / 2;
     const double two_pi = 6.283185307179586476925286766559, theta = two_pi * (double)c0 / (double)N;
     BdftDesc &d = p.desc;
-    d.hop = hop; d.kb0 = kb0; d.f0 = g.f0;
+    d.hop = hop; d.kb0 = kb0; d.f0 = g.f0; d.R = N / hop;
     d.a0 = (float)a0; d.a1c = (float)(0.5 * a1 * std::cos(theta)); d.a1s = (float)(0.5 * a1 * std::sin(theta));
     // A operands, lane l: row l & 15 of its tile (bin kb0 + 16 w + row), k = 8 (l >> 4) + j -> folded position m = 32 ks + k.
     // cosine rows: cos(2 pi k m / N), half of it at m = 0 (s[0] = 2 x[c]); sine rows: -sin(2 pi k m / N), slot m = 0 takes the

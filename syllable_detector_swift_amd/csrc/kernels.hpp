@@ -206,11 +206,12 @@ struct MlpxDesc {
     const float *bias0, *w1;    // [4] folded first-layer biases, second-layer weights (zero padded)
     const double *thresholds;   // [1]
 };
-// ---- frames of four hops (W = N = 4 hop): every block of `hop` samples transformed once on the matrix cores, frames as sliding
-// sums of four blocks, the window as three taps along the bins, then the matrix-core network stage -- one launch (kernels_bdft.hip)
+// ---- frames of whole hops (W = N = R hop, R = 4, 2 or 1): every block of `hop` samples transformed once on the matrix cores, frames as sliding
+// sums of R blocks, the window as three taps along the bins, then the matrix-core network stage -- one launch (kernels_bdft.hip)
 constexpr int kBdftBlock = 512;          // 8 waves, two per SIMD; wave w owns bins kb0 + 16 w .. + 15
 struct BdftDesc {
-    int hop, kb0, f0;           // hop = N / 4 (128 or 256); first of the 128 bins transformed (a multiple of 4, <= f0 - 1); the band's first bin
+    int hop, kb0, f0;           // hop = N / R (128 or 256); first of the 128 bins transformed (a multiple of 4, <= f0 - 1); the band's first bin
+    int R;                      // blocks per frame: 4, 2 or 1 (75 %, 50 %, no overlap)
     float a0, a1c, a1s;         // the window as a cosine sum: a_0, (a_1 / 2) cos(pi hop / N), (a_1 / 2) sin(pi hop / N)
     const uint4 *basis;         // [8 waves][cosine rows, sine rows][hop / 64 k-steps][hi,lo][64 lanes] A-operand fragments of the folded block basis
     const float *cre;           // [8 waves][64 lanes][4] the block's first sample's real coefficients for the lane's bins

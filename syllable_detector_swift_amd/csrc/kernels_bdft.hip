@@ -94,14 +94,14 @@ __device__ __forceinline__ float shl_prev(float v)
 template <int Q>
 __device__ __forceinline__ float back(float cur, float prev) { return shr_cur<Q>(cur) + shl_prev<Q>(prev); }   // column n - Q of the stream
 
-// KS: k-steps of 32 folded positions per block (hop = 64 KS).  Frames of R = 4 blocks.  SC: log / dB columns.
-template <int KS, bool SC>
+// KS: k-steps of 32 folded positions per block (hop = 64 KS).  RR: blocks per frame (4, 2, 1).  SC: log / dB columns.
+template <int KS, bool SC, int RR>
 __global__ void __launch_bounds__(kBlock, 1)
 bdft_net_kernel(const MlpxDesc d, const BdftDesc bd, const float *__restrict__ samples, int64_t stride, int64_t S, int64_t J, int64_t E,
                 int64_t evals_per_run, float *__restrict__ outputs, uint8_t *__restrict__ flags)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int KB = 4, R = 4, HOP = 64 * KS;
+    constexpr int KB = 4, R = RR, HOP = 64 * KS;
     // LDS: first-layer fragments | columns hi | columns lo | per-frame sums, exponents | B fragments (two buffers) | edge bins |
     // per-wave partial sums | block maxima;  the tap products of a tile sit where the second fragment buffer and the edge bins are
     const int CS = d.col_stride, PS = d.p_stride;
@@ -210,7 +210,7 @@ bdft_net_kernel(const MlpxDesc d, const BdftDesc bd, const float *__restrict__ s
             const unsigned *prevs = bmax + 16 * ((slt + 3) & 3);      // (the sub-tile before this one)
             int e = 0x7fff;
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
+            for (int q = 0; q < R; q++) {
                 const unsigned mbq = n - q >= 0 ? slot[n - q] : prevs[16 + n - q];
                 e = mbq != 0u ? min(e, scale_exp(mbq)) : e;
             }
@@ -318,18 +318,29 @@ bdft_net_kernel(const MlpxDesc d, const BdftDesc bd, const float *__restrict__ s
             bre[i] = fmaf(cre[i], x0s, are[i]) * un;
             bim[i] = aim[i] * un;
         }
-        // ---- frames end on their last block: Y'_n = sum_{q' < 4} rho^(3 - q') B'_{n - q'} with rho = (-i)^k, k = i (mod 4):
+        // ---- frames end on their last block.  Four blocks a frame: Y'_n = sum_{q' < 4} rho^(3 - q') B'_{n - q'} with rho = (-i)^k, k = i (mod 4):
         // 1, -i, -1, i for i = 0 .. 3.  In two levels: V_n = rho B'_n + B'_{n-1}, Y'_n = rho^2 V_n + V_{n-2} -- two shifts a value
         // instead of three (the previous sub-tile's last columns carry: B' for the first level, V for the second).
-        floatx4 vre, vim;
-        vre[0] = bre[0] + back<1>(bre[0], bre_prev[0]);   vim[0] = bim[0] + back<1>(bim[0], bim_prev[0]);      // rho = 1
-        vre[1] = bim[1] + back<1>(bre[1], bre_prev[1]);   vim[1] = -bre[1] + back<1>(bim[1], bim_prev[1]);     // -i z = (b, -a)
-        vre[2] = -bre[2] + back<1>(bre[2], bre_prev[2]);  vim[2] = -bim[2] + back<1>(bim[2], bim_prev[2]);     // -z
-        vre[3] = -bim[3] + back<1>(bre[3], bre_prev[3]);  vim[3] = bre[3] + back<1>(bim[3], bim_prev[3]);      // i z = (-b, a)
-        yre[0] = vre[0] + back<2>(vre[0], vre_prev[0]);   yim[0] = vim[0] + back<2>(vim[0], vim_prev[0]);      // rho^2 = 1
-        yre[1] = -vre[1] + back<2>(vre[1], vre_prev[1]);  yim[1] = -vim[1] + back<2>(vim[1], vim_prev[1]);     // -1
-        yre[2] = vre[2] + back<2>(vre[2], vre_prev[2]);   yim[2] = vim[2] + back<2>(vim[2], vim_prev[2]);      // 1
-        yre[3] = -vre[3] + back<2>(vre[3], vre_prev[3]);  yim[3] = -vim[3] + back<2>(vim[3], vim_prev[3]);     // -1
+        floatx4 vre = bre, vim = bim;
+        if (R == 4) {
+            vre[0] = bre[0] + back<1>(bre[0], bre_prev[0]);   vim[0] = bim[0] + back<1>(bim[0], bim_prev[0]);      // rho = 1
+            vre[1] = bim[1] + back<1>(bre[1], bre_prev[1]);   vim[1] = -bre[1] + back<1>(bim[1], bim_prev[1]);     // -i z = (b, -a)
+            vre[2] = -bre[2] + back<1>(bre[2], bre_prev[2]);  vim[2] = -bim[2] + back<1>(bim[2], bim_prev[2]);     // -z
+            vre[3] = -bim[3] + back<1>(bre[3], bre_prev[3]);  vim[3] = bre[3] + back<1>(bim[3], bim_prev[3]);      // i z = (-b, a)
+            yre[0] = vre[0] + back<2>(vre[0], vre_prev[0]);   yim[0] = vim[0] + back<2>(vim[0], vim_prev[0]);      // rho^2 = 1
+            yre[1] = -vre[1] + back<2>(vre[1], vre_prev[1]);  yim[1] = -vim[1] + back<2>(vim[1], vim_prev[1]);     // -1
+            yre[2] = vre[2] + back<2>(vre[2], vre_prev[2]);   yim[2] = vim[2] + back<2>(vim[2], vim_prev[2]);      // 1
+            yre[3] = -vre[3] + back<2>(vre[3], vre_prev[3]);  yim[3] = -vim[3] + back<2>(vim[3], vim_prev[3]);     // -1
+        } else if (R == 2) {
+            // two blocks a frame: Y'_n = rho B'_n + B'_{n-1} with rho = (-1)^k
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                yre[i] = ((i & 1) ? -bre[i] : bre[i]) + back<1>(bre[i], bre_prev[i]);
+                yim[i] = ((i & 1) ? -bim[i] : bim[i]) + back<1>(bim[i], bim_prev[i]);
+            }
+        } else {
+            yre = bre; yim = bim;                                    // (a frame is its block: not instantiated -- the FFT kernels are faster there)
+        }
         upc = rec[2];
         dnc = rec[3];
         // this lane group's edge bins -> LDS for its neighbours
@@ -525,7 +536,7 @@ hipError_t launch_bdft_net(const MlpxDesc &d, const BdftDesc &bd, const float *s
                            float *outputs, uint8_t *flags, hipStream_t stream)
 {
     if (E <= 0 || C <= 0) return hipSuccess;
-    if ((uint64_t)E * 4u >= 0xFFFFFFF0ull || (uint64_t)S * 4u >= 0x7fffffffull) return hipErrorInvalidValue;
+    if ((uint64_t)E * 4u >= 0xFFFFFFF0ull || (uint64_t)S * 4u >= 0x7fffffffull || (bd.R != 4 && bd.R != 2)) return hipErrorInvalidValue;
     // a workgroup walks a contiguous run of one channel; runs as long as still leaves two rounds of workgroups on the 256 CUs
     int64_t runs_per_channel = (512 + C - 1) / C;
     const int64_t min_run = 4 * kNew;
@@ -555,7 +566,8 @@ hipError_t launch_bdft_net(const MlpxDesc &d, const BdftDesc &bd, const float *s
 #endif
 #define SD_BDFT_GO(KS_)                                                                                                        \
     if (KS == KS_) {                                                                                                           \
-        auto kern = d.scaling != 0 ? bdft_net_kernel<KS_, true> : bdft_net_kernel<KS_, false>;                                 \
+        auto kern = bd.R == 4 ? (d.scaling != 0 ? bdft_net_kernel<KS_, true, 4> : bdft_net_kernel<KS_, false, 4>)                      \
+                              : (d.scaling != 0 ? bdft_net_kernel<KS_, true, 2> : bdft_net_kernel<KS_, false, 2>);                     \
         hipError_t st = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);              \
         if (st != hipSuccess) return st;                                                                                       \
         hipLaunchKernelGGL(kern, grid, dim3(kBlock), (size_t)lds, stream, d, bd, samples, stride, S, J, E, evals_per_run, outputs, flags); \

@@ -783,6 +783,44 @@ def test_frames_of_four_hops_on_the_block_transform_kernel(oracle_lib, N, window
         assert not fl[c][~ok].any()
 
 
+@pytest.mark.parametrize("N,hop,window,lo,hi,T,H,scaling", [(512, 256, _abi.WINDOW_HAMMING, 2000.0, 7000.0, 10, 4, "linear"),
+                                                            (512, 256, _abi.WINDOW_NONE, 400.0, 9000.0, 6, 2, "linear"),
+                                                            (512, 256, _abi.WINDOW_HANNING, 1000.0, 6150.0, 8, 4, "db"),
+                                                            (256, 128, _abi.WINDOW_HANNING, 500.0, 7300.0, 8, 3, "linear")])
+def test_frames_of_two_hops_on_the_block_transform_kernel(oracle_lib, N, hop, window, lo, hi, T, H, scaling):
+    """kernels_bdft.hip with 50 % overlap (a frame is two blocks: Y'_n = (-1)^k B'_n + B'_{n-1}): the same fold, taps and network
+    stage, for 512-point frames (256-point ones stay on the FFT kernels: faster there).  Bands of 40 to 100 bins, level step,
+    silence, a NaN sample, ragged lengths."""
+    torch = _torch()
+    from syllable_detector_swift_amd.config import SyllableDetectorConfig, frequencyIndexRange
+    rng = np.random.default_rng(N + hop + T)
+    f0, f1 = frequencyIndexRange(N, 44100.0, lo, hi)
+    F = f1 - f0
+    assert F > 32
+    net = nets.random_net(rng, F * T, (H,), 1, in_fns=("l2normalize", "mapminmax"), out_fns=("mapminmax",) if H != 3 else ())
+    cfg = SyllableDetectorConfig(44100.0, N, N, N - hop, (lo, hi), T, scaling, [0.4], net, window=window)
+    S = N + hop * 1100 + 77
+    x = synth.channels(3, S, first=21).astype(np.float32)
+    x[0, S // 2:] *= np.float32(0.0003 if scaling == "linear" else 0.003)
+    x[1, 30000:30000 + 30 * N] = 0.0
+    x[2, 77777] = np.nan
+    with sd.SyllableDetector(cfg, channels=3) as det:
+        det.profile(True)
+        out, fl = det.run(torch.from_numpy(x).cuda())
+        torch.cuda.synchronize()
+        assert [nm for nm, _ in det.lastTimings()] == (["bdft_net_kernel"] if N >= 512 else ["stft_lanes_kernel", "mlp_mfma_kernel"])
+        out, fl = out.cpu().numpy(), fl.cpu().numpy()
+    o = util.oracle_for(cfg)
+    for c in range(3):
+        _, _, w64 = o.run(x[c], po.F64)
+        ok = np.isfinite(w64).all(axis=1)
+        assert (np.isfinite(out[c]).all(axis=1) == ok).all(), "NaN evaluations must coincide"
+        assert c == 0 or (~ok).any()
+        util.assert_outputs_close(out[c][ok], w64[ok])
+        util.assert_flags_exact(fl[c][ok], w64[ok], cfg.thresholds, cfg.rule)
+        assert not fl[c][~ok].any()
+
+
 @pytest.mark.parametrize("kernel", util.FUSED_KERNELS)
 def test_a_nan_sample_poisons_exactly_the_windows_that_contain_it(oracle_lib, monkeypatch, kernel):
     """The reference propagates a NaN sample into the frames that cover it and from there into the timeRange evaluations
