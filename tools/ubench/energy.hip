@@ -23,6 +23,7 @@
 #include <vector>
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef float floatx2 __attribute__((ext_vector_type(2)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef unsigned int uint32x4 __attribute__((ext_vector_type(4)));
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
@@ -34,7 +35,7 @@ __device__ __forceinline__ unsigned hash(unsigned x)
 }
 __device__ __forceinline__ float rnd(unsigned s) { return (float)(hash(s) & 0xffffu) / 32768.0f - 1.0f; }   // [-1, 1)
 
-enum { IDLE, MFMA16, MFMA32, FMA, SPLIT, LDSR, M16FMA };
+enum { IDLE, MFMA16, MFMA32, FMA, SPLIT, LDSR, M16FMA, PKFMA, TRANS, DPPMOV };
 
 template <int MODE>
 __global__ void __launch_bounds__(512) k(int iters, unsigned long long *clk, float *sink)
@@ -89,6 +90,34 @@ __global__ void __launch_bounds__(512) k(int iters, unsigned long long *clk, flo
         for (int it = 0; it < iters; it++) {
 #pragma unroll
             for (int q = 0; q < 32; q++) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f[q & 15]) : "v"(m), "v"(c));
+        }
+        for (int i = 0; i < 16; i++) s += f[i];
+    } else if (MODE == PKFMA) {                       // packed fp32: two multiply-adds a lane and instruction
+        floatx2 f[16];
+        for (int i = 0; i < 16; i++) f[i] = floatx2{rnd(seed * 64 + i), rnd(seed * 64 + 32 + i)};
+        const floatx2 m = {-0.99993f, -0.99991f}, c = {0.37f * rnd(seed), 0.21f * rnd(seed + 9)};
+        for (int it = 0; it < iters; it++) {
+#pragma unroll
+            for (int q = 0; q < 32; q++) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(f[q & 15]) : "v"(m), "v"(c));
+        }
+        for (int i = 0; i < 16; i++) s += f[i][0] + f[i][1];
+    } else if (MODE == TRANS) {                       // the transcendental unit: exp2 and rcp alternating (the wide engine's epilogue pair)
+        float f[16];
+        for (int i = 0; i < 16; i++) f[i] = rnd(seed * 64 + i);
+        for (int it = 0; it < iters; it++) {
+#pragma unroll
+            for (int q = 0; q < 32; q++) {
+                if (q & 1) asm volatile("v_rcp_f32 %0, %0" : "+v"(f[q & 15]));
+                else asm volatile("v_exp_f32 %0, %0" : "+v"(f[q & 15]));
+            }
+        }
+        for (int i = 0; i < 16; i++) s += f[i];
+    } else if (MODE == DPPMOV) {                      // a DPP row shift into a fresh register (the block-transform kernel's sliding sums)
+        float f[16];
+        for (int i = 0; i < 16; i++) f[i] = rnd(seed * 64 + i);
+        for (int it = 0; it < iters; it++) {
+#pragma unroll
+            for (int q = 0; q < 32; q++) asm volatile("v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(f[q & 15]) : "v"(f[(q + 5) & 15]));
         }
         for (int i = 0; i < 16; i++) s += f[i];
     } else if (MODE == SPLIT) {
@@ -277,6 +306,9 @@ int main(int argc, char **argv)
     else if (!strcmp(mode, "aux18")) run_hbm_aux<18>(mode, secs);
     else if (!strcmp(mode, "aux19")) run_hbm_aux<19>(mode, secs);
     else if (!strcmp(mode, "m16fma")) run<M16FMA>(mode, 8, secs, 8, 30000);
+    else if (!strcmp(mode, "pkfma")) run<PKFMA>(mode, 8, secs, 32, 60000);
+    else if (!strcmp(mode, "trans")) run<TRANS>(mode, 8, secs, 32, 30000);
+    else if (!strcmp(mode, "dppmov")) run<DPPMOV>(mode, 8, secs, 32, 60000);
     else { printf("unknown mode %s\n", mode); return 1; }
     return 0;
 }
