@@ -25,9 +25,9 @@ with sd.SyllableDetector(base, channels=C, engine=_abi.ENGINE_FUSED) as det:
     det.profile(True)
     ms = []
     stamped = "SYLDET_FUSED_STAMPS" in os.environ      # (a -DSYLDET_R_STAMPS build: its phase table goes to stderr)
-    for i in range(4 if stamped else 40):
+    for i in range(4 if stamped else 300):             # (the first 100 launches: the clock governor's ramp, MEASUREMENTS R3.8)
         det.run(x, out, fl)
-        if i >= (2 if stamped else 10):
+        if i >= (2 if stamped else 100):
             ms.append(det.lastTimings()[0][1])
     torch.cuda.synchronize()
     ms.sort()
