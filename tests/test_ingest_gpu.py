@@ -448,3 +448,29 @@ def test_time_sharded_parts_equal_the_whole_run(workload):
                 assert o.shape[1] == n
                 outs.append(o.clone()); fls.append(f.clone())
             assert torch.equal(torch.cat(outs, dim=1), out) and torch.equal(torch.cat(fls, dim=1), fl)
+
+
+@pytest.mark.gpu
+def test_wide_engine_keeps_nan_and_silence_where_the_reference_has_them(oracle_lib):
+    """The wide engine's direct front (operands made from the |X| columns inside the GEMM kernel): a NaN sample makes exactly the
+    evaluations whose windows contain it NaN, a stretch of silence the ones whose whole window is silent (0 / 0 in L2Normalize,
+    NeuralNet.swift:47-59); every other evaluation within bf16's bar, also right next to them."""
+    torch = _torch()
+    cfg = nets.wide_mlp(nets.from_npz())
+    S = 90000
+    x = synth.channels(2, S, first=5, fs=cfg.samplingRate).astype(np.float32)
+    x[0, 41234] = np.nan
+    x[1, 30000:30000 + 40 * 256] = 0.0
+    o = po.Oracle(po.from_config(cfg))
+    with sd.SyllableDetector(cfg, channels=2, engine=_abi.ENGINE_WIDE_BF16) as det:
+        out, fl = det.run(torch.from_numpy(x).cuda())
+        torch.cuda.synchronize()
+        out, fl = out.cpu().numpy(), fl.cpu().numpy()
+    for c in range(2):
+        _, _, w64 = o.run(x[c], po.F64, cfg.rule)
+        ok = np.isfinite(w64).all(axis=1)
+        assert (~ok).any() and ok.any()
+        assert (np.isfinite(out[c]).all(axis=1) == ok).all(), "NaN evaluations must coincide"
+        util.assert_outputs_close(out[c][ok], w64[ok], WIDE_TOL)
+        util.assert_flags_exact(fl[c][ok], w64[ok], cfg.thresholds, cfg.rule, WIDE_TOL)
+        assert not fl[c][~ok].any()
