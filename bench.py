@@ -100,7 +100,8 @@ def side_record(workload, local_rank, steps=10, warmup=2, verify=True, preroll_s
     """One sub-record of the `also` object: another single-GPU BASELINE workload (configs[2] "config3": 1024-point frames;
     configs[4] "config5": the 4096-hidden network as a bf16 MFMA GEMM) or the headline workload on adversarial audio
     ("clicks": a full-scale click every 64 frames over a cage at -80 dBFS, which the precision guard legitimately sends to
-    the exact fp64 recomputation), measured in this process after the headline's timed region: the same launch loop, the
+    the exact fp64 recomputation; "hop128": the same network on 256-point frames at hop 128, BASELINE configs[0]'s framing --
+    SURVEY 8(d) names the variant -- where every frame starts on the same LDS banks), measured in this process after the headline's timed region: the same launch loop, the
     kernels' own HIP events, the oracle spot-check of the last step."""
     import torch
     import syllable_detector_swift_amd as sd
@@ -113,6 +114,8 @@ def side_record(workload, local_rank, steps=10, warmup=2, verify=True, preroll_s
         cfg, C, S, engine = nets.wide_mlp(nets.from_npz()), 64, 1 << 24, 3
     else:
         cfg, C, S = nets.from_npz(), 64, 1 << 24
+        if workload == "hop128":                                     # BASELINE configs[0]'s framing (256-point frames, hop 128) at configs[1]'s size
+            cfg = nets.variant(cfg, windowOverlap=128)
     with sd.SyllableDetector(cfg, channels=C, device=local_rank, engine=engine) as det:
         g = det.geometry
         J, E = det.countFrames(S), det.countEvaluations(S)
@@ -397,7 +400,7 @@ def main():
             del x, outputs, flags
             torch.cuda.empty_cache()
             line["also"] = {}
-            for wl in ("config3", "config5", "clicks"):
+            for wl in ("config3", "config5", "clicks", "hop128"):
                 try:
                     line["also"][wl] = side_record(wl, local_rank, verify=not args.no_verify)
                 except Exception as e:                       # a side record must never cost the headline its line
