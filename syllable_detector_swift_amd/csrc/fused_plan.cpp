@@ -655,7 +655,10 @@ void fused_segmentation(FusedDesc &d, int64_t E, int C)
     // 256 CUs busy in whole rounds (64 channels: 32 segments of ~249 tiles for the benchmark batch); short batches get what
     // fills the chip.
     {
-        const int64_t max_tiles = 512;
+#ifndef SYLDET_S_MAXTILES                // (diagnostic builds: shorter wave segments = more rounds of workgroups; measured no faster, MEASUREMENTS R3.3)
+#define SYLDET_S_MAXTILES 512
+#endif
+        const int64_t max_tiles = SYLDET_S_MAXTILES;
         const int64_t max_evals = max_tiles * kFusedSTileFrames - (d.T - 1);
         int64_t segs = std::max<int64_t>(1, (E + max_evals - 1) / max_evals);
         const int sw = d.s_waves > 0 ? d.s_waves : kFusedSBlock / 64;
