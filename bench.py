@@ -19,6 +19,15 @@ Before the W warmup steps the same step runs `--preroll` more times untimed (def
 line): from an idle device the clock governor needs 30-50 ms of launches to reach the state it then holds for seconds
 (profiles/r03_clock_ramp.txt), and W + K = 25 launches would otherwise be timed inside that ramp.  The timed region is K steps.
 
+`from_idle` in the line is the same K-step measurement taken FIRST, before any pre-roll (W warmup launches from an idle device,
+then K timed steps): both regimes are in the record.
+
+`python bench.py --gpus N` WITHOUT a torch.distributed launcher (no WORLD_SIZE in the environment), or with
+`--single-process`, drives all N GPUs from ONE process through the library's sharded bank (syldet_create_sharded: a sub-bank and a
+stream per device, every shard launched before any is waited for, one ncclAllGather of the bit-packed flags inside the
+library's own RCCL group) -- the shape of the reference, which is one process that owns every channel
+(Processor.swift:57-59,128-141) -- and prints the same line with `rccl_ranks` = N and `launcher` = "single-process".
+
 Rank 0 prints one JSON line.  `roofline` is computed from HIP-event timings of the dominant kernel taken inside the timed
 region on the launch stream.  After the timed region the last step's results are spot-checked against the CPU oracle
 (tests/spotcheck.py: head, tail and segment seams of the first, a middle and the last channel) -> `verified`.
@@ -178,6 +187,205 @@ def side_record(workload, local_rank, steps=10, warmup=2, verify=True, preroll_s
     return rec
 
 
+def live_record(local_rank, channels=64, verify=True):
+    """The reference's real use (N4): an audio callback appends a few frames per channel (32-frame buffers:
+    AudioInterface.swift:342,474; 512 for comparison), the consumer drains every detector (Processor.swift:102-149).  Here:
+    syldet_append_interleaved + syldet_process_all (one staged copy, one launch, one copy back for all channels) + the
+    per-channel hand-out; wall time per callback, and the outputs of three channels against the oracle's streaming form."""
+    import numpy as np
+    import syllable_detector_swift_amd as sd
+    from syllable_detector_swift_amd import nets, synth
+    import pyoracle as po
+    import util
+    cfg = nets.from_npz()
+    rec = {"channels": channels, "path": "syldet_append_interleaved -> syldet_process_all -> syldet_process_new_value / syldet_last_outputs per channel"}
+    for n, rounds in ((32, 3000), (512, 600)):
+        S = n * rounds
+        x = np.stack([synth.channel(S, 1000 + c) for c in range(channels)])
+        got = {c: [] for c in (0, channels // 2, channels - 1)}
+        with sd.SyllableDetector(cfg, channels=channels, device=local_rank) as det:
+            t_cb, evals = [], 0
+            t_start = time.perf_counter()
+            for r in range(rounds):
+                blk = np.ascontiguousarray(x[:, r * n:(r + 1) * n].T)
+                t0 = time.perf_counter()
+                det.appendInterleavedData(blk)
+                det.processAll()
+                for c in range(channels):
+                    while det.processNewValue(c):
+                        evals += 1
+                        if c in got:
+                            got[c].append(det.lastOutputsFor(c))
+                t_cb.append(time.perf_counter() - t0)
+            wall = time.perf_counter() - t_start
+        w = rounds // 10
+        t = np.array(t_cb[w:])
+        hop = cfg.windowLength - cfg.windowOverlap
+        r_ = {"frames_per_callback": n, "callbacks": rounds, "audio_us_per_callback": 1e6 * n / cfg.samplingRate,
+              "callback_us_median": 1e6 * float(np.median(t)), "callback_us_p99": 1e6 * float(np.percentile(t, 99)),
+              "evaluations": evals, "sustained_frames_per_s": channels * (S // hop) / wall,
+              "real_time_factor": (S / cfg.samplingRate) / wall}
+        if verify:
+            o = util.oracle_for(cfg)
+            worst = 0.0
+            for c, rows in got.items():
+                want, _ = o.stream_run(x[c], po.F64, chunk=n)
+                a = np.array(rows, np.float32).reshape(-1, want.shape[1])
+                assert a.shape == want.shape, (a.shape, want.shape)
+                worst = max(worst, float(np.abs(a.astype(np.float64) - want).max()))
+            r_["verified"] = bool(worst <= 1e-5)
+            r_["max_error_vs_oracle_streaming_form"] = worst
+        rec["callbacks_of_%d" % n] = r_
+    return rec
+
+
+def host_record(cfg, det_engine, local_rank, x):
+    """The boundary on host buffers (syldet_run: H2D, kernel, D2H pipelined along time inside the library) on a bounded sample,
+    ordinary and page-locked memory, beside the box's own page-locked H2D rate: PCIe, not the kernel, bounds this form."""
+    import numpy as np
+    import torch
+    import syllable_detector_swift_amd as sd
+    from syllable_detector_swift_amd.bank import PinnedArray
+    hc, hs = 16, 1 << 23                                           # 512 MiB of input: two stages of the pipeline
+    hx = x[:hc, :hs].cpu().numpy()
+    rec = {"unit": "frames/s", "sample": "%d channels x %d samples through syldet_run (PCIe both ways; staged along time in 256 MiB stages)" % (hc, hs)}
+    with sd.SyllableDetector(cfg, channels=hc, device=local_rank, engine=det_engine) as hdet:
+        J, E = hdet.countFrames(hs), hdet.countEvaluations(hs)
+        b_frame = 4 * hdet.geometry.hop + 4 * hdet.geometry.outputs + 1
+        out = np.zeros((hc, E, hdet.geometry.outputs), np.float32)
+        fl = np.zeros((hc, E), np.uint8)
+        hdet.runHost(hx, out, fl)
+        t1 = time.perf_counter()
+        for _ in range(3):
+            hdet.runHost(hx, out, fl)
+        rec["value"] = 3 * hc * J / (time.perf_counter() - t1)
+        px, po_, pf = PinnedArray(hx.shape, np.float32), PinnedArray(out.shape, np.float32), PinnedArray(fl.shape, np.uint8)
+        px.array[:] = hx
+        hdet.runHost(px.array, po_.array, pf.array)
+        t1 = time.perf_counter()
+        for _ in range(3):
+            hdet.runHost(px.array, po_.array, pf.array)
+        rec["page_locked_buffers"] = 3 * hc * J / (time.perf_counter() - t1)
+        rec["results_equal_pageable"] = bool(np.array_equal(po_.array, out) and np.array_equal(pf.array, fl))
+        # the box's page-locked H2D rate on the same bytes (one plain copy), and what it allows at B_frame bytes a frame
+        d = torch.empty(hx.shape, dtype=torch.float32, device=torch.device("cuda", local_rank))
+        src = torch.from_numpy(px.array)
+        d.copy_(src, non_blocking=True)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            d.copy_(src, non_blocking=True)
+        torch.cuda.synchronize()
+        h2d = 3 * hx.nbytes / (time.perf_counter() - t1)
+        rec["h2d_page_locked_GBps"] = h2d / 1e9
+        rec["pcie_bound_frames_per_s"] = h2d / (4 * hdet.geometry.hop)
+        rec["fraction_of_pcie_bound"] = {"pageable": rec["value"] / rec["pcie_bound_frames_per_s"],
+                                         "page_locked": rec["page_locked_buffers"] / rec["pcie_bound_frames_per_s"]}
+        rec["algorithmic_bytes_per_frame"] = b_frame
+        for p_ in (px, po_, pf):
+            p_.free()
+    return rec
+
+
+def single_process(args):
+    """All N GPUs from ONE process through the sharded bank (BASELINE configs[3]'s shape per GPU; weak scaling)."""
+    import numpy as np
+    import torch
+    import syllable_detector_swift_amd as sd
+    from syllable_detector_swift_amd import nets, synth
+    from syllable_detector_swift_amd.bank import ShardedSyllableDetectorBank
+    N = args.gpus
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    cfg = nets.from_npz()
+    if args.overlap is not None:
+        cfg = nets.variant(cfg, windowOverlap=args.overlap)
+    Cg = args.channels or 512
+    S = 1 << (args.log2_samples or 21)
+    total = args.total_channels if args.total_channels is not None else N * Cg
+    scaling = "strong" if args.total_channels is not None else "weak"
+    devices = list(range(N))
+    bank = ShardedSyllableDetectorBank(cfg, total, devices, engine=args.engine)
+    g = bank.geometry
+    J, E = bank.countFrames(S), bank.countEvaluations(S)
+    blocks, outs, fls, alls = [], [], [], []
+    for i, sh in enumerate(bank.shards):
+        dev = torch.device("cuda", sh.device)
+        blocks.append(synth.channels_on_device(sh.channels, S, dev, first=sh.first_channel, fs=cfg.samplingRate))
+        outs.append(torch.empty((sh.channels, E, g.outputs), dtype=torch.float32, device=dev))
+        fls.append(torch.empty((sh.channels, E), dtype=torch.uint8, device=dev))
+        alls.append(torch.empty((total, E), dtype=torch.uint8, device=dev))
+    dets = [sd.SyllableDetector.borrowed(bank, i) for i in range(N)]
+    for d in dets:
+        d.profile(True, history=max(args.steps, 1))
+
+    def step():
+        bank.run(blocks, S, gather=True, outputs=outs, flags=fls, flags_all=alls)
+
+    preroll = args.preroll if args.preroll is not None else 150
+    for _ in range(preroll + args.warmup):
+        step()
+    bank.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    bank.synchronize()
+    elapsed = time.perf_counter() - t0
+    b_frame = 4 * g.hop + 4 * g.outputs + 1
+    per_dev = []
+    for d in dets:
+        km = {}
+        for back in range(args.steps):
+            for nm, ms in d.timingsOf(back):
+                km.setdefault(nm, []).append(ms)
+        per_dev.append({k: sum(v) / len(v) for k, v in km.items()})
+    dom = max(per_dev[0], key=per_dev[0].get)
+    worst_ms = max(m[dom] for m in per_dev)
+    C0 = bank.shards[0].channels
+    achieved = C0 * J * b_frame / (per_dev[0][dom] * 1e-3) / 1e9
+    value = total * J * args.steps / elapsed
+    line = {"metric": "audio frames/sec (256-pt STFT + 2-layer MLP), whole job", "value": value, "unit": "frames/s", "n_gpus": N,
+            "steps": args.steps, "warmup": args.warmup, "preroll_steps": preroll, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+            "dtype": "f32 (I/O and accumulate; products as f16 hi/lo split x3 on MFMA)" if g.engine == 2 else "f32", "data": "synthetic",
+            "per_gpu": value / N, "launcher": "single-process",
+            "config": {"workload": "BASELINE configs[3]: sample.txt network, %d channels sharded across %d MI355X (%d x 2^%d samples per GPU), RCCL gather of detection flags"
+                                   % (total, N, Cg, S.bit_length() - 1),
+                       "channels_per_gpu": [sh.channels for sh in bank.shards], "total_channels": total, "samples_per_channel": S, "frames_per_channel": J,
+                       "evaluations_per_channel": E, "fourier_length": cfg.fourierLength, "hop": g.hop, "bins": [g.f0, g.f1], "time_range": cfg.timeRange,
+                       "engine": {1: "generic", 2: "fused", 3: "wide_bf16"}.get(g.engine, str(g.engine)),
+                       "sharding": "one process, one handle (syldet_create_sharded): a sub-bank and a stream per device, contiguous channel blocks, no data-path "
+                                   "collective; one ncclAllGather of the bit-packed flags per step inside the library's own RCCL group (ncclCommInitAll)"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "traffic_source": None, "algorithmic_bytes_per_launch": C0 * J * b_frame, "algorithmic_bytes_per_frame": b_frame,
+                         "kernel_ms": per_dev[0], "kernel_ms_per_device": [m[dom] for m in per_dev], "slowest_device_kernel_ms": worst_ms,
+                         "note": "per device: device 0's launch"},
+            "rccl_ranks": bank.rcclRanks, "gathered_flags_shape": [total, E],
+            "gathered_bytes_per_rank_per_step": max(sh.channels for sh in bank.shards) * ((E + 7) // 8)}
+    if not args.no_verify:
+        # every device holds every channel's flags: all copies equal device 0's, whose own rows equal its local flags; and the
+        # last step's outputs of the first and last shard against the oracle
+        import spotcheck
+        same = all(bool(torch.equal(alls[i].cpu(), alls[0].cpu())) for i in range(1, N))
+        own = all(bool(torch.equal(alls[i][sh.first_channel: sh.first_channel + sh.channels], fls[i])) for i, sh in enumerate(bank.shards))
+        line["gathered_flags_identical_on_every_device"] = bool(same and own)
+        try:
+            checks = {}
+            for i in sorted({0, N - 1}):
+                sh = bank.shards[i]
+                torch.cuda.set_device(sh.device)
+                checks["shard%d" % i] = spotcheck.check(dets[i], cfg, blocks[i], outs[i], fls[i], sorted({0, sh.channels - 1}), tol=1e-5)
+            line["verify"] = checks
+            line["verified"] = bool(same and own)
+        except AssertionError as e:
+            line["verified"] = False
+            line["verify"] = {"error": str(e)[:400]}
+    sys.stdout.flush()
+    os.write(json_fd, (json.dumps(line) + "\n").encode())
+    bank.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -195,7 +403,11 @@ def main():
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the `also` sub-records (configs[2], configs[4], clicks over quiet audio)")
     ap.add_argument("--force-gather", action="store_true", help="run the flag exchange even with one rank (rehearsal of the multi-GPU step)")
+    ap.add_argument("--single-process", action="store_true",
+                    help="drive all --gpus devices from this one process through the library's sharded bank (the default when --gpus > 1 and no torch.distributed launcher set WORLD_SIZE)")
     args = ap.parse_args()
+    if args.single_process or (args.gpus > 1 and "WORLD_SIZE" not in os.environ):
+        return single_process(args)
 
     import numpy as np
     import torch
@@ -282,6 +494,29 @@ def main():
     # step (the same count on every rank: the step may hold a collective) brings the device there first; the W warmup steps
     # and the K timed steps follow unchanged.  --preroll 0 times from cold.
     preroll = args.preroll if args.preroll is not None else (150 if args.engine != 3 and args.workload != "config5" else 10)
+    # ... and BEFORE it, the from-idle regime for the record: W warmup launches on the idle device, then K timed steps
+    # (what `--preroll 0` measures), with the same barriers; the pre-rolled measurement below is the headline.
+    from_idle = None
+    if preroll > 0:
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ti = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        idle_elapsed = time.perf_counter() - ti
+        idle_ms = {}
+        for back in range(args.steps):
+            for nm, ms in det.timingsOf(back):
+                idle_ms.setdefault(nm, []).append(ms)
+        from_idle = (idle_elapsed, {k: sum(v) / len(v) for k, v in idle_ms.items()})
     for _ in range(preroll):
         step()
     for _ in range(args.warmup):
@@ -346,7 +581,15 @@ def main():
             "fixups": {"work_items_last_step": fixups, "overflow": fix_overflow,
                        "note": "16-evaluation items the precision guard sent to the exact fp64 recomputation (0 for ordinary audio)"},
         }
+        if from_idle is not None:
+            idle_elapsed, idle_means = from_idle
+            idom = max(idle_means, key=idle_means.get)
+            line["from_idle"] = {"ms_per_step": 1e3 * idle_elapsed / args.steps, "kernel": idom, "kernel_ms": idle_means[idom],
+                                 "frac": C * J * b_frame / (idle_means[idom] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                 "value_local": C * J * args.steps / idle_elapsed,
+                                 "note": "the same K steps timed first, after W warmup launches on an idle device and before the pre-roll (rank 0's clock)"}
         if exchange:
+            line["launcher"] = "torch.distributed.run, one process per GPU"
             line["rccl_ranks"] = dist.get_world_size()
             line["gathered_flags_shape"] = [total, E]
             line["gathered_bytes_per_rank_per_step"] = C * ((E + 7) // 8) if gather is not None else C * E
@@ -372,17 +615,12 @@ def main():
                 line["verified"] = False
                 line["verify"] = {"error": str(e)[:400]}
         if world == 1 and not args.no_cpu_baseline:
-            # the boundary also takes host buffers (syldet_run): H2D + kernel + D2H, pageable memory, bounded sample.
+            # the boundary also takes host buffers (syldet_run): H2D + kernel + D2H pipelined along time, bounded sample.
             # Reported beside the headline, never as `value`.
-            hc, hs = min(C, 8), min(S, 1 << 22)
-            with sd.SyllableDetector(cfg, channels=hc, device=local_rank, engine=args.engine) as hdet:
-                hx = x[:hc, :hs].cpu().numpy()
-                hdet.runHost(hx)
-                t1 = time.perf_counter()
-                for _ in range(3):
-                    hdet.runHost(hx)
-                line["host_buffers"] = {"value": 3 * hc * hdet.countFrames(hs) / (time.perf_counter() - t1), "unit": "frames/s",
-                                        "sample": "%d channels x %d samples through syldet_run (pageable host memory, PCIe both ways)" % (hc, hs)}
+            try:
+                line["host_buffers"] = host_record(cfg, args.engine, local_rank, x)
+            except Exception as e:
+                line["host_buffers"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
             # (the 4096-unit network costs the CPU 2.4 MFLOP an evaluation: a sixteenth of the sample keeps five passes in the budget)
             n_cpu = min(S, 1 << (18 if g.engine == 3 else 22))
             host = x[:min(C, 8), :n_cpu].cpu().numpy()
@@ -405,6 +643,10 @@ def main():
                     line["also"][wl] = side_record(wl, local_rank, verify=not args.no_verify)
                 except Exception as e:                       # a side record must never cost the headline its line
                     line["also"][wl] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+            try:
+                line["also"]["live"] = live_record(local_rank, verify=not args.no_verify)
+            except Exception as e:
+                line["also"]["live"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
             if "roofline" in line["also"].get("clicks", {}):
                 line["also"]["clicks"]["slowdown_vs_headline"] = line["also"]["clicks"]["ms_per_step"] / line["ms_per_step"]
         sys.stdout.flush()

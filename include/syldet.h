@@ -193,6 +193,14 @@ int syldet_run_device(syldet_t *h, const float *d_samples, int64_t n_samples, in
 int syldet_run(syldet_t *h, const float *samples, int64_t n_samples, int64_t channel_stride,
                float *outputs, uint8_t *flags);
 
+/* syldet_run cuts a long recording along time into stages of about 256 MiB of input and overlaps the H2D copy of the next
+ * stage with the kernel of this one and the D2H copy of the last (device staging: two stages, whatever the length).
+ * The copies read and write the caller's rows in place: buffers from syldet_host_alloc are page-locked, their copies
+ * truly asynchronous; ordinary buffers work too (the runtime pins the pages of each copy as it goes).  TPCircularBufferInit (TPCircularBuffer.c:43-124) is the reference's
+ * allocation of the buffer audio is produced into; this is its counterpart for a host that feeds a GPU.                 */
+int syldet_host_alloc(size_t bytes, void **out);
+int syldet_host_free(void *p);
+
 /* the spectrogram columns the detector feeds its network, [C][J][bins] fp32
  * (processFourierData, SyllableDetector.swift:134-151; linear values, before scaling)    */
 int syldet_spectrogram_device(syldet_t *h, const float *d_samples, int64_t n_samples, int64_t channel_stride,
@@ -290,6 +298,73 @@ int syldet_run_interleaved(syldet_t *h, const float *interleaved, int64_t n_fram
  * `hip_stream`; rows <= 65535.                                                                            */
 int syldet_pack_flags_device(const uint8_t *d_flags, int64_t rows, int64_t row_len, uint8_t *d_bits, void *hip_stream);
 int syldet_unpack_flags_device(const uint8_t *d_bits, int64_t rows, int64_t row_len, uint8_t *d_flags, void *hip_stream);
+
+/* ---- one bank over several GPUs, ONE process ----
+ * The reference is one process that owns every channel: Processor.swift:57-59 builds one SyllableDetector per channel and
+ * one serial queue drains them all (:82, :128-141); main.swift:86-89 builds one TrackDetector per track and one loop runs
+ * them (:126-130).  A sharded bank keeps that shape for a host with several MI355X: one handle, one call per batch; the
+ * library places a sub-bank and a stream on every listed device, splits the channels into contiguous blocks (the first
+ * n_channels % n_devices devices take one more), and -- with fewer channels than devices -- splits a channel's TIME axis
+ * instead: a shard then computes a contiguous range of one channel's evaluations from its samples plus a halo of
+ * (timeRange - 1) hop + window - hop (+ gap) samples (evaluation e is frames e .. e + timeRange - 1, frame j is samples
+ * [j hop + gap, j hop + gap + window): SyllableDetector.swift:153-217, CircularShortTimeFourierTransform.swift:286-302).
+ * Every kernel scales per frame or per hop-aligned block, so a shard's results are the unsharded bank's bit for bit.
+ * The data path has no collective.  The one exchange -- every device receives every channel's detection flags -- is ONE
+ * all-gather of the bit-packed rows per batch, on RCCL communicators the library makes itself (ncclCommInitAll, one
+ * process; librccl is loaded on first use, so hosts with one GPU never pay for it).                                   */
+typedef struct syldet_sharded syldet_sharded_t;
+
+typedef struct {
+    int32_t device;              /* HIP device of the shard                                                */
+    int32_t first_channel;       /* the shard owns channels [first_channel, first_channel + channels)      */
+    int32_t channels;
+    int32_t part, parts;         /* its place along the time axis of its channel (0 of 1 unless n_channels < n_devices) */
+} syldet_shard_t;
+
+/* how the flags travel between the devices of a sharded bank */
+typedef enum {
+    SYLDET_EXCHANGE_RCCL = 0,        /* one ncclAllGather per device inside one ncclGroupStart/End (xGMI)            */
+    SYLDET_EXCHANGE_PEER_COPY = 1    /* hipMemcpyPeerAsync of every shard's packed rows to every device: no RCCL in
+                                        the process; also what a bank with one device listed twice uses (a rehearsal
+                                        of the shard logic on a one-GPU box: RCCL refuses duplicate devices)        */
+} syldet_exchange_t;
+
+/* The shard table alone (host arithmetic, no device): out[i] for i < n_shards, device = i. */
+int syldet_shard_table(int32_t n_channels, int32_t n_shards, syldet_shard_t *out);
+/* Evaluations [*first, *first + *count) of a channel with n_evals evaluations that part `part` of `parts` computes, and the
+ * samples [*s0, *s1) of the recording it reads for them (cfg gives hop, gap, window, timeRange).                         */
+int syldet_shard_evaluations(int64_t n_evals, int32_t parts, int32_t part, int64_t *first, int64_t *count);
+int syldet_shard_samples(const syldet_config_t *cfg, int64_t first_eval, int64_t count, int64_t *s0, int64_t *s1);
+
+int syldet_create_sharded(const syldet_config_t *cfg, int32_t n_channels, const int32_t *devices, int32_t n_devices,
+                          int32_t engine, int32_t exchange, syldet_sharded_t **out);
+int syldet_sharded_destroy(syldet_sharded_t *b);
+int32_t syldet_sharded_channels(const syldet_sharded_t *b);
+int32_t syldet_sharded_shards(const syldet_sharded_t *b);
+int syldet_sharded_shard(const syldet_sharded_t *b, int32_t shard, syldet_shard_t *out);
+/* the shard's own bank (borrowed: destroyed with the sharded bank) and the stream its work is queued on */
+syldet_t *syldet_sharded_bank(syldet_sharded_t *b, int32_t shard);
+void *syldet_sharded_stream(syldet_sharded_t *b, int32_t shard);
+/* For a recording of n_samples per channel: the samples [*s0, *s1) shard `shard` reads of each of its channels (all of them
+ * unless time-sharded) and the evaluations [*e0, *e0 + *count) it computes.  Any output pointer may be NULL.            */
+int syldet_sharded_ranges(const syldet_sharded_t *b, int32_t shard, int64_t n_samples, int64_t *s0, int64_t *s1,
+                          int64_t *e0, int64_t *count);
+/* Host buffers, the whole bank in one call: samples [C][channel_stride] -> outputs [C][E][outputs], flags [C][E], as
+ * syldet_run.  Every shard's copies and kernels are queued before any is waited for (one pipelined H2D / kernel / D2H
+ * chain per device); results land in the caller's rows directly, so this form needs no collective.  Blocks.              */
+int syldet_sharded_run(syldet_sharded_t *b, const float *samples, int64_t n_samples, int64_t channel_stride,
+                       float *outputs, uint8_t *flags);
+/* Device buffers: d_samples[i] is shard i's block on its device -- [channels_i][strides[i]] rows holding the shard's
+ * sample range (syldet_sharded_ranges) of a recording of n_samples per channel; d_outputs[i] [channels_i][count_i][outputs]
+ * and d_flags[i] [channels_i][count_i] receive its own results (either array, or any entry, may be NULL);
+ * d_flags_all[i], when the array is given, receives EVERY channel's flags [C][E] on device i (8-byte aligned) through the
+ * one exchange.  Asynchronous: every shard's kernel is launched before the exchange is queued; results are complete after
+ * syldet_sharded_synchronize (or after synchronising syldet_sharded_stream(b, i) for shard i's own results).             */
+int syldet_sharded_run_device(syldet_sharded_t *b, const float *const *d_samples, int64_t n_samples, const int64_t *strides,
+                              float *const *d_outputs, uint8_t *const *d_flags, uint8_t *const *d_flags_all);
+int syldet_sharded_synchronize(syldet_sharded_t *b);
+/* RCCL ranks behind the exchange (0 under SYLDET_EXCHANGE_PEER_COPY) */
+int32_t syldet_sharded_rccl_ranks(const syldet_sharded_t *b);
 
 /* ResamplerLinear, Common/Resampler.swift:20-76 (used when the device rate differs from the
  * network's: Processor.swift:116-121, ViewControllerProcessor.swift:247-250), for n_channels

@@ -9,9 +9,11 @@ from . import _abi
 from .config import (InvalidValue, MismatchedLength, MissingValue, NeuralNet, NeuralNetLayer, ParseError,
                      ProcessingFunction, SyllableDetectorConfig, SyllableDetectorError, UnableToOpenPath,
                      createWindow, frequencyIndexRange)
+from .bank import PinnedArray, ShardedSyllableDetectorBank, shard_table
 from .detector import SyllableDetector
 from .resampler import ResamplerLinear, deinterleave
 
 __all__ = ["SyllableDetector", "SyllableDetectorConfig", "NeuralNet", "NeuralNetLayer", "ProcessingFunction",
            "ParseError", "UnableToOpenPath", "MissingValue", "InvalidValue", "MismatchedLength",
-           "SyllableDetectorError", "frequencyIndexRange", "createWindow", "ResamplerLinear", "deinterleave"]
+           "SyllableDetectorError", "frequencyIndexRange", "createWindow", "ResamplerLinear", "deinterleave",
+           "ShardedSyllableDetectorBank", "PinnedArray", "shard_table"]

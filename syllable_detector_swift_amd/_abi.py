@@ -77,8 +77,16 @@ class Geometry(C.Structure):
                 ("engine", C.c_int32)]
 
 
+class Shard(C.Structure):
+    _fields_ = [("device", C.c_int32), ("first_channel", C.c_int32), ("channels", C.c_int32),
+                ("part", C.c_int32), ("parts", C.c_int32)]
+
+
+EXCHANGE_RCCL, EXCHANGE_PEER_COPY = 0, 1
+
 Handle = C.c_void_p
 Config_p = C.POINTER(Config)
+c_void_pp = C.POINTER(C.c_void_p)
 
 # every symbol include/syldet.h declares: name -> (restype, argtypes)
 SIGNATURES = {
@@ -128,6 +136,23 @@ SIGNATURES = {
     "syldet_convert_rate_count": (C.c_int64, [C.c_int64, C.c_double, C.c_double]),
     "syldet_convert_rate_device": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_double, C.c_double, C.c_void_p, C.c_int64, c_int64_p, C.c_void_p]),
     "syldet_resample": (C.c_int, [Handle, c_float_p, C.c_int64, C.c_int64, c_float_p, C.c_int64, c_int64_p]),
+    "syldet_host_alloc": (C.c_int, [C.c_size_t, c_void_pp]),
+    "syldet_host_free": (C.c_int, [C.c_void_p]),
+    "syldet_shard_table": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(Shard)]),
+    "syldet_shard_evaluations": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, c_int64_p, c_int64_p]),
+    "syldet_shard_samples": (C.c_int, [Config_p, C.c_int64, C.c_int64, c_int64_p, c_int64_p]),
+    "syldet_create_sharded": (C.c_int, [Config_p, C.c_int32, c_int32_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Handle)]),
+    "syldet_sharded_destroy": (C.c_int, [Handle]),
+    "syldet_sharded_channels": (C.c_int32, [Handle]),
+    "syldet_sharded_shards": (C.c_int32, [Handle]),
+    "syldet_sharded_shard": (C.c_int, [Handle, C.c_int32, C.POINTER(Shard)]),
+    "syldet_sharded_bank": (Handle, [Handle, C.c_int32]),
+    "syldet_sharded_stream": (C.c_void_p, [Handle, C.c_int32]),
+    "syldet_sharded_ranges": (C.c_int, [Handle, C.c_int32, C.c_int64, c_int64_p, c_int64_p, c_int64_p, c_int64_p]),
+    "syldet_sharded_run": (C.c_int, [Handle, c_float_p, C.c_int64, C.c_int64, c_float_p, c_uint8_p]),
+    "syldet_sharded_run_device": (C.c_int, [Handle, c_void_pp, C.c_int64, c_int64_p, c_void_pp, c_void_pp, c_void_pp]),
+    "syldet_sharded_synchronize": (C.c_int, [Handle]),
+    "syldet_sharded_rccl_ranks": (C.c_int32, [Handle]),
 }
 
 

@@ -33,12 +33,13 @@ constexpr int kExUsage = 64;   // EX_USAGE, main.swift:40
 void usage(FILE *to)
 {
     std::fprintf(to,
-                 "Usage: syllable-detector-cli -n <net> [-a <audio>]... [-d <seconds>] [--device <k>] [--chunk <frames>] [--probe]\n"
+                 "Usage: syllable-detector-cli -n <net> [-a <audio>]... [-d <seconds>] [--device <k>] [--chunk <frames>] [--format <shortest|swift4>] [--probe]\n"
                  "  -n, --net <net>:\n      Path to trained network file.\n"
                  "  -a, --audio <audio>:\n      Path to the audio file to process.\n"
                  "  -d, --debounce <seconds>:\n      Number of seconds to debounce triggers.\n"
                  "      --device <k>:\n      HIP device to run on (default 0).\n"
                  "      --chunk <frames>:\n      Frames per decode buffer when interleaving events of several channels (default 8192; 0: channel by channel).\n"
+                 "      --format <shortest|swift4>:\n      How numbers are printed: the shortest digits that round-trip (Swift 4.2 and later; default) or 15 / 6 significant digits (Swift 4.0, the toolchain the project declares: the example line below).\n"
                  "      --probe:\n      Only print what the audio files contain; does not touch the GPU.\n"
                  "The command line will write a comma-separated list of detection events (when the network has at least one output above threshold) to standard out. For example, it might output:\n"
                  "\n\t0,1593298,36.1292063492063,0.918557\n\n"
@@ -59,6 +60,24 @@ std::string swift_number(F v)
     if (s.find_first_of(".en") == std::string::npos) s += ".0";   // "2" -> "2.0"; leaves "1e+16", "inf", "nan"
     return s;
 }
+
+// The same under Swift 4.0 / 4.1, the toolchain the project declares (SWIFT_VERSION = 4.0, project.pbxproj:593): before
+// Swift 4.2 `description` printed "%0.*g" with digits10 significant digits -- 15 for Double, 6 for Float -- and appended ".0" when
+// the text held neither '.', 'e' nor a letter.  The one output line the reference holds, in its help text (main.swift:33),
+// "0,1593298,36.1292063492063,0.918557", is in this form: 15 and 6 digits.
+template <typename F>
+std::string swift4_number(F v)
+{
+    char buf[64];
+    std::snprintf(buf, sizeof buf, "%0.*g", sizeof(F) == 8 ? 15 : 6, (double)v);
+    std::string s(buf);
+    if (s.find_first_of(".eEn") == std::string::npos) s += ".0";          // ("inf", "nan" keep their letters)
+    return s;
+}
+
+bool g_swift4 = false;                                     // --format swift4
+template <typename F>
+std::string number(F v) { return g_swift4 ? swift4_number(v) : swift_number(v); }
 
 struct DevBuf {
     void *p = nullptr;
@@ -160,8 +179,8 @@ int process_file(const std::string &path, const syldet_config_t *cfg, int device
     });
     for (const Event &ev : events) {
         std::string line = std::to_string(ev.channel) + "," + std::to_string(ev.sample) + "," +
-                           swift_number((double)ev.sample / cfg->sampling_rate);
-        for (int o = 0; o < n_out; o++) line += "," + swift_number(out[((size_t)ev.channel * E + ev.eval) * n_out + o]);
+                           number((double)ev.sample / cfg->sampling_rate);
+        for (int o = 0; o < n_out; o++) line += "," + number(out[((size_t)ev.channel * E + ev.eval) * n_out + o]);
         std::puts(line.c_str());
     }
     return 0;
@@ -197,7 +216,20 @@ int main(int argc, char **argv)
         } else if (a == "--device") device = std::atoi(value(i, "--device"));
         else if (a == "--chunk") chunk = std::atoll(value(i, "--chunk"));
         else if (a == "--probe") probe = true;
-        else {                                              // -h, --help and anything unknown: usage text, EX_USAGE (main.swift:27-41)
+        else if (a == "--format") {
+            const std::string f = value(i, "--format");
+            if (f != "shortest" && f != "swift4") { usage(stdout); return kExUsage; }
+            g_swift4 = f == "swift4";
+        } else if (a == "--format-line") {
+            // formats one event line from its parts (channel sample rate out0 [out1 ...]; the outputs as fp32) exactly as the
+            // event loop does: the known-answer test of the number formats, no audio and no GPU involved
+            if (i + 3 >= argc) { usage(stdout); return kExUsage; }
+            const long long smp = std::atoll(argv[i + 2]);
+            std::string line = std::string(argv[i + 1]) + "," + std::to_string(smp) + "," + number((double)smp / std::strtod(argv[i + 3], nullptr));
+            for (int k = i + 4; k < argc; k++) line += "," + number(std::strtof(argv[k], nullptr));
+            std::puts(line.c_str());
+            return 0;
+        } else {                                              // -h, --help and anything unknown: usage text, EX_USAGE (main.swift:27-41)
             usage(stdout);
             return kExUsage;
         }

@@ -243,6 +243,8 @@ hipError_t launch_deinterleave(const float *in, int64_t n_frames, int total, int
 // detection flags <-> bits (bit b of byte t of a row = flag 8 t + b), rows padded to whole bytes
 hipError_t launch_pack_flags(const uint8_t *flags, int64_t rows, int64_t row_len, uint8_t *bits, hipStream_t stream);
 hipError_t launch_unpack_flags(const uint8_t *bits, int64_t rows, int64_t row_len, uint8_t *flags, hipStream_t stream);
+hipError_t launch_unpack_flags_gathered(const uint8_t *bits, int64_t rows, int64_t row_len, int64_t shards, int64_t padded,
+                                        uint8_t *flags, hipStream_t stream);
 
 hipError_t launch_fused(const FusedDesc &d, const float *samples, int64_t stride, int C, int64_t S, int64_t J,
                         int64_t E, float *outputs, uint8_t *flags, hipStream_t stream);

@@ -129,8 +129,21 @@ pack_flags_kernel(const uint8_t *__restrict__ flags, int64_t row_len, int64_t ro
     bits[(int64_t)blockIdx.y * row_bytes + t] = (uint8_t)b;
 }
 
+// Source row of output row r when the bit rows arrive as `shards` padded blocks of `padded` rows each (the all-gather of
+// ragged contiguous channel blocks: the first `extra` blocks hold base + 1 rows, the rest base; padded >= base + 1).  With
+// extra == 0 and padded == base the map is the identity.
+__device__ __forceinline__ int64_t gathered_row(int64_t r, int64_t padded, int64_t base, int64_t extra)
+{
+    const int64_t big = extra * (base + 1);
+    if (r < big) return (r / (base + 1)) * padded + r % (base + 1);
+    const int64_t q = r - big;
+    return (extra + q / base) * padded + q % base;
+}
+
+template <bool MAPPED>
 __global__ void __launch_bounds__(256)
-unpack_flags_kernel(const uint8_t *__restrict__ bits, int64_t rows, int64_t row_len, int64_t row_bytes, uint8_t *__restrict__ flags)
+unpack_flags_kernel(const uint8_t *__restrict__ bits, int64_t rows, int64_t row_len, int64_t row_bytes, uint8_t *__restrict__ flags,
+                    int64_t padded, int64_t base, int64_t extra)
 {
     // one aligned 8-byte store per thread over the flat [rows * row_len] output; a thread's eight flags may straddle two rows
     const int64_t q = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8, total = rows * row_len;
@@ -140,7 +153,8 @@ unpack_flags_kernel(const uint8_t *__restrict__ bits, int64_t rows, int64_t row_
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         if (q + k < total) {
-            const unsigned b = bits[row * row_bytes + (i >> 3)];
+            const int64_t src = MAPPED ? gathered_row(row, padded, base, extra) : row;
+            const unsigned b = bits[src * row_bytes + (i >> 3)];
             out |= (uint64_t)((b >> (i & 7)) & 1u) << (8 * k);
             if (++i == row_len) { i = 0; row++; }
         }
@@ -169,7 +183,23 @@ hipError_t launch_unpack_flags(const uint8_t *bits, int64_t rows, int64_t row_le
     const bool aligned = (reinterpret_cast<uintptr_t>(flags) & 7) == 0;
     if (!aligned || threads > 0x7fffffffLL * 256) return hipErrorInvalidValue;
     dim3 grid((unsigned)((threads + 255) / 256));
-    hipLaunchKernelGGL(unpack_flags_kernel, grid, dim3(256), 0, stream, bits, rows, row_len, row_bytes, flags);
+    hipLaunchKernelGGL(unpack_flags_kernel<false>, grid, dim3(256), 0, stream, bits, rows, row_len, row_bytes, flags, (int64_t)0, (int64_t)1, (int64_t)0);
+    return hipGetLastError();
+}
+
+// The gathered form: `shards` blocks of `padded` bit rows each, of which block s holds rows/shards (+ 1 for the first
+// rows % shards blocks) real rows -- dist.shard_channels' table -- unpacked into the contiguous [rows][row_len] flags.
+hipError_t launch_unpack_flags_gathered(const uint8_t *bits, int64_t rows, int64_t row_len, int64_t shards, int64_t padded,
+                                        uint8_t *flags, hipStream_t stream)
+{
+    if (rows <= 0 || row_len <= 0) return hipSuccess;
+    if (shards <= 0 || rows < shards || padded < (rows + shards - 1) / shards) return hipErrorInvalidValue;
+    const int64_t row_bytes = (row_len + 7) / 8;
+    const int64_t threads = (rows * row_len + 7) / 8;
+    const bool aligned = (reinterpret_cast<uintptr_t>(flags) & 7) == 0;
+    if (!aligned || threads > 0x7fffffffLL * 256) return hipErrorInvalidValue;
+    dim3 grid((unsigned)((threads + 255) / 256));
+    hipLaunchKernelGGL(unpack_flags_kernel<true>, grid, dim3(256), 0, stream, bits, rows, row_len, row_bytes, flags, padded, rows / shards, rows % shards);
     return hipGetLastError();
 }
 

@@ -133,8 +133,10 @@ struct syldet {
         bool fused_nofold = false;    // SYLDET_FUSED_NOFOLD: not the symmetric-fold kernel (the register-resident-basis / 8-wave kernels)
         bool fused_stamps = false;    // SYLDET_FUSED_STAMPS: the stamped diagnostic instantiation
         int fused_ko = 0;             // SYLDET_FUSED_KO=<mask>: knock-out instantiation
+        long long host_chunk = 0;     // SYLDET_HOST_CHUNK_BYTES=<n>: bytes of input per stage of the host-pointer pipeline (tests force seams with it)
         void read()
         {
+            host_chunk = std::getenv("SYLDET_HOST_CHUNK_BYTES") ? std::atoll(std::getenv("SYLDET_HOST_CHUNK_BYTES")) : 0;
             fused_classic = std::getenv("SYLDET_FUSED_CLASSIC") != nullptr;
             no_fft1k = std::getenv("SYLDET_NO_FFT1K") != nullptr;
             no_bdft = std::getenv("SYLDET_NO_BDFT") != nullptr;
@@ -190,6 +192,16 @@ struct syldet {
     std::vector<std::unique_ptr<ChannelStream>> streams;
     std::mutex pump_mu;               // the staging buffers and the stream below belong to one pump at a time
     PinnedBuffer p_stage_in, p_stage_out;
+
+    // the host-pointer batch call as a pipeline along time (syldet_run): two sets of device buffers, a copy-in and a copy-out
+    // stream beside the compute stream, one event of each kind per set
+    struct Pipe {
+        hipStream_t s_in = nullptr, s_out = nullptr;
+        DeviceBuffer d_in[2], d_out[2], d_fl[2];
+        hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_k[2] = {nullptr, nullptr}, ev_d2h[2] = {nullptr, nullptr};
+        bool up = false;
+    } pipe;
+    size_t host_chunk_bytes = (size_t)256 << 20;   // SYLDET_HOST_CHUNK_BYTES (read at create): device staging per set
 
     // optional per-kernel timing (syldet_profile)
     bool profiling = false;
@@ -756,6 +768,7 @@ int syldet_create(const syldet_config_t *cfg, int32_t n_channels, int32_t device
     if (int st = h->cfg.assign(*cfg)) return st;
     if (int st = compute_geometry(h->cfg.view, &h->geom)) return st;
     h->sw.read();
+    if (h->sw.host_chunk > 0) h->host_chunk_bytes = (size_t)h->sw.host_chunk;
 
     int n_dev = 0;
     hipError_t e = hipGetDeviceCount(&n_dev);
@@ -871,6 +884,13 @@ int syldet_destroy(syldet_t *h)
         b->release();
     h->p_stage_in.release();
     h->p_stage_out.release();
+    for (int b = 0; b < 2; b++) {
+        h->pipe.d_in[b].release(); h->pipe.d_out[b].release(); h->pipe.d_fl[b].release();
+        for (hipEvent_t e : {h->pipe.ev_h2d[b], h->pipe.ev_k[b], h->pipe.ev_d2h[b]})
+            if (e) (void)hipEventDestroy(e);
+    }
+    if (h->pipe.s_in) (void)hipStreamDestroy(h->pipe.s_in);
+    if (h->pipe.s_out) (void)hipStreamDestroy(h->pipe.s_out);
     delete h;
     return SYLDET_OK;
 }
@@ -995,29 +1015,107 @@ int syldet_detections_device(syldet_t *h, const uint8_t *d_flags, int64_t n_eval
 
 // ---- host-pointer conveniences: stage, run, copy back, block ----
 
+static int pipe_bring_up(syldet *h)
+{
+    syldet::Pipe &p = h->pipe;
+    if (p.up) return SYLDET_OK;
+    if (!p.s_in) SYLDET_HIP(hipStreamCreateWithFlags(&p.s_in, hipStreamNonBlocking));
+    if (!p.s_out) SYLDET_HIP(hipStreamCreateWithFlags(&p.s_out, hipStreamNonBlocking));
+    for (int b = 0; b < 2; b++)
+        for (hipEvent_t *e : {&p.ev_h2d[b], &p.ev_k[b], &p.ev_d2h[b]})
+            if (!*e) SYLDET_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    p.up = true;
+    return SYLDET_OK;
+}
+
+// The batch call on host buffers: TrackDetector's loop reads a recording buffer by buffer and runs the detector on each
+// (TrackDetector.swift:45-105); here the recording is cut along time into stages of about host_chunk_bytes of input, each
+// stage the evaluations [e0, e0 + n) of every channel with the samples they reach ((n + T - 2) hop + gap + W: the halo of
+// (T - 1) hop + W - hop samples is read by both neighbours), and the stages flow through two sets of device buffers: the H2D
+// copy of stage k + 1 (copy-in stream) runs under the kernel of stage k (the handle's stream) and the D2H copy of stage k - 1
+// (copy-out stream).  Device staging is bounded by two stages, whatever the recording's length.  Kernels whose scales
+// are per frame or per hop-aligned block (the fold kernel, the FFT and block-transform engines) give a stage's evaluations
+// the bits the one-shot call gives them; the pass-scaled kernels agree to a few 1e-7, as between any two tilings (syldet.h,
+// syldet_fixup_stats).  The copies read and write the caller's rows in place: page-locked memory (syldet_host_alloc) is
+// truly asynchronous; for ordinary memory the runtime pins the pages of each copy on the fly and the copy call returns when
+// its bytes have moved -- the kernel of the stage before runs meanwhile all the same (measured: within a few per cent of
+// the PCIe rate either way, and a staging copy through a pinned buffer of our own was half as fast).
 int syldet_run(syldet_t *h, const float *samples, int64_t n_samples, int64_t channel_stride, float *outputs, uint8_t *flags)
 {
     if (int st = check_batch_args(h, samples, n_samples, channel_stride)) return st;
     std::lock_guard<std::mutex> staging(h->pump_mu);   // the staging buffers and h->stream: one user at a time
     SYLDET_HIP(hipSetDevice(h->device));
-    const int C = h->channels;
-    const int64_t E = count_evals(h, n_samples);
-    const size_t in_bytes = (size_t)C * (size_t)n_samples * sizeof(float);
-    const size_t out_bytes = (size_t)C * (size_t)E * (size_t)h->geom.outputs * sizeof(float);
-    const size_t fl_bytes = (size_t)C * (size_t)E;
+    const int C = h->channels, n_out = h->geom.outputs, T = h->cfg.view.time_range;
+    const int64_t E = count_evals(h, n_samples), hop = h->geom.hop, frame = (int64_t)h->geom.gap + h->cfg.view.window_length;
     if (E <= 0) return SYLDET_OK;
-    if (int st = h->d_stage_in.reserve(in_bytes)) return st;
-    if (int st = h->d_stage_out.reserve(out_bytes)) return st;
-    if (int st = h->d_stage_flags.reserve(fl_bytes)) return st;
-    SYLDET_HIP(hipMemcpy2DAsync(h->d_stage_in.ptr, (size_t)n_samples * sizeof(float), samples,
-                                (size_t)channel_stride * sizeof(float), (size_t)n_samples * sizeof(float), (size_t)C,
-                                hipMemcpyHostToDevice, h->stream));
-    if (int st = run_on_stream(h, (const float *)h->d_stage_in.ptr, n_samples, n_samples, C, (float *)h->d_stage_out.ptr,
-                               (uint8_t *)h->d_stage_flags.ptr, h->stream))
-        return st;
-    if (outputs) SYLDET_HIP(hipMemcpyAsync(outputs, h->d_stage_out.ptr, out_bytes, hipMemcpyDeviceToHost, h->stream));
-    if (flags) SYLDET_HIP(hipMemcpyAsync(flags, h->d_stage_flags.ptr, fl_bytes, hipMemcpyDeviceToHost, h->stream));
-    SYLDET_HIP(hipStreamSynchronize(h->stream));
+    if (int st = pipe_bring_up(h)) return st;
+    syldet::Pipe &p = h->pipe;
+
+    // evaluations per stage: about host_chunk_bytes of input, the stages of equal size
+    const int64_t fixed = (int64_t)C * ((T - 2) * hop + frame) * 4, per_eval = (int64_t)C * hop * 4;
+    int64_t n_c = ((int64_t)h->host_chunk_bytes - fixed) / per_eval;
+    if (n_c < 1) n_c = 1;
+    const int64_t n_stages = (E + n_c - 1) / n_c;
+    n_c = (E + n_stages - 1) / n_stages;
+    const int64_t S_max = (n_c + T - 2) * hop + frame;
+    for (int b = 0; b < (n_stages > 1 ? 2 : 1); b++) {
+        if (int st = p.d_in[b].reserve((size_t)C * (size_t)S_max * 4)) return st;
+        if (int st = p.d_out[b].reserve((size_t)C * (size_t)n_c * (size_t)n_out * 4)) return st;
+        if (int st = p.d_fl[b].reserve((size_t)C * (size_t)n_c)) return st;
+    }
+    // whatever happens, nothing of this call is in flight when it returns
+    struct Drain {
+        syldet *h;
+        ~Drain()
+        {
+            (void)hipStreamSynchronize(h->pipe.s_in);
+            (void)hipStreamSynchronize(h->stream);
+            (void)hipStreamSynchronize(h->pipe.s_out);
+        }
+    } drain{h};
+
+    for (int64_t k = 0; k < n_stages; k++) {
+        const int b = (int)(k & 1);
+        const int64_t e0 = k * n_c, n = std::min(n_c, E - e0), s0 = e0 * hop, Sc = (n + T - 2) * hop + frame;
+        if (k >= 2) SYLDET_HIP(hipStreamWaitEvent(p.s_in, p.ev_k[b], 0));      // the kernel of stage k - 2 has read this device buffer
+        SYLDET_HIP(hipMemcpy2DAsync(p.d_in[b].ptr, (size_t)Sc * 4, samples + s0, (size_t)channel_stride * 4, (size_t)Sc * 4, (size_t)C,
+                                    hipMemcpyHostToDevice, p.s_in));
+        SYLDET_HIP(hipEventRecord(p.ev_h2d[b], p.s_in));
+        SYLDET_HIP(hipStreamWaitEvent(h->stream, p.ev_h2d[b], 0));
+        if (k >= 2) SYLDET_HIP(hipStreamWaitEvent(h->stream, p.ev_d2h[b], 0)); // stage k - 2's results have left the device buffers
+        if (int st = run_on_stream(h, (const float *)p.d_in[b].ptr, Sc, Sc, C, (float *)p.d_out[b].ptr, (uint8_t *)p.d_fl[b].ptr, h->stream)) return st;
+        SYLDET_HIP(hipEventRecord(p.ev_k[b], h->stream));
+        SYLDET_HIP(hipStreamWaitEvent(p.s_out, p.ev_k[b], 0));
+        if (outputs)
+            SYLDET_HIP(hipMemcpy2DAsync(outputs + (size_t)e0 * n_out, (size_t)E * n_out * 4, p.d_out[b].ptr, (size_t)n * n_out * 4,
+                                        (size_t)n * n_out * 4, (size_t)C, hipMemcpyDeviceToHost, p.s_out));
+        if (flags)
+            SYLDET_HIP(hipMemcpy2DAsync(flags + e0, (size_t)E, p.d_fl[b].ptr, (size_t)n, (size_t)n, (size_t)C, hipMemcpyDeviceToHost, p.s_out));
+        SYLDET_HIP(hipEventRecord(p.ev_d2h[b], p.s_out));
+    }
+    SYLDET_HIP(hipStreamSynchronize(p.s_out));
+    return SYLDET_OK;
+}
+
+// Host memory for audio and results that the device reads and writes in place (page-locked): what the reference's ring
+// allocation (TPCircularBufferInit, TPCircularBuffer.c:43-124: the buffer the audio thread produces into) becomes for a
+// host that feeds a GPU.  Buffers from here make syldet_run skip its staging copies.
+int syldet_host_alloc(size_t bytes, void **out)
+{
+    if (!out) return fail(SYLDET_ERR_INVALID_ARGUMENT, "NULL argument");
+    *out = nullptr;
+    hipError_t e = hipHostMalloc(out, bytes > 0 ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        *out = nullptr;
+        return fail(e == hipErrorOutOfMemory ? SYLDET_ERR_OUT_OF_MEMORY : SYLDET_ERR_DEVICE, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+    }
+    return SYLDET_OK;
+}
+
+int syldet_host_free(void *p)
+{
+    if (!p) return SYLDET_OK;
+    SYLDET_HIP(hipHostFree(p));
     return SYLDET_OK;
 }
 

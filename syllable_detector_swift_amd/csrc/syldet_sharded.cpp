@@ -1,0 +1,498 @@
+// syldet_sharded.cpp -- one detector bank over several GPUs in ONE process, behind the C ABI.
+//
+// The reference is one process that owns every channel (Processor.swift:57-59,82,128-141; main.swift:86-89,126-130).  This
+// file keeps that shape on a host with several MI355X: a sub-bank (an ordinary syldet_t) and a stream per listed device,
+// channels split into contiguous blocks (time-axis ranges when there are fewer channels than devices), every shard's work
+// queued before any is waited for, and ONE exchange per batch: the all-gather of the bit-packed detection flags, on RCCL
+// communicators made here with ncclCommInitAll.  It is written over the public ABI (syldet_create, syldet_run_device,
+// syldet_run, syldet_pack_flags_device) plus the HIP runtime; librccl is loaded when the first bank asks for it.
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>      // types and prototypes only: the library itself is dlopen'ed (573 MB; one-GPU hosts never load it)
+
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "kernels.hpp"
+#include "syldet_internal.hpp"
+
+using namespace sd;
+
+#define SYLDET_HIP(expr)                                                                         \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess)                                                                    \
+            return fail(SYLDET_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e));  \
+    } while (0)
+
+namespace {
+
+// ---- librccl, on demand ------------------------------------------------------------------------------------------
+struct Rccl {
+    void *lib = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    std::string why;
+};
+
+Rccl *rccl()
+{
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        // the copy a host process already holds (a torch process carries one under the same soname) is the one we get
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (r.lib) break;
+            r.why = dlerror() ? dlerror() : "dlopen failed";
+        }
+        if (!r.lib) return;
+        auto sym = [&](const char *n) {
+            void *p = dlsym(r.lib, n);
+            if (!p) r.why = std::string("librccl lacks ") + n;
+            return p;
+        };
+        r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+        r.CommInitAll = (decltype(r.CommInitAll))sym("ncclCommInitAll");
+        r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+        r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
+        r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
+        r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
+        if (!r.GetErrorString || !r.CommInitAll || !r.CommDestroy || !r.AllGather || !r.GroupStart || !r.GroupEnd) {
+            dlclose(r.lib);
+            r.lib = nullptr;
+        }
+    });
+    return &r;
+}
+
+#define SYLDET_NCCL(expr)                                                                                      \
+    do {                                                                                                       \
+        ncclResult_t _r = (expr);                                                                              \
+        if (_r != ncclSuccess) return fail(SYLDET_ERR_DEVICE, std::string(#expr) + ": " + rccl()->GetErrorString(_r)); \
+    } while (0)
+
+struct DevMem {
+    void *ptr = nullptr;
+    size_t cap = 0;
+    int device = 0;
+    int reserve(size_t bytes)                                     // (the caller has made `device` current)
+    {
+        if (bytes <= cap) return SYLDET_OK;
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+        hipError_t e = hipMalloc(&ptr, bytes);
+        if (e != hipSuccess) {
+            ptr = nullptr;
+            return fail(e == hipErrorOutOfMemory ? SYLDET_ERR_OUT_OF_MEMORY : SYLDET_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e));
+        }
+        cap = bytes;
+        return SYLDET_OK;
+    }
+    void release()
+    {
+        if (ptr) {
+            (void)hipSetDevice(device);
+            (void)hipFree(ptr);
+        }
+        ptr = nullptr;
+        cap = 0;
+    }
+};
+
+// dist.shard_channels / dist.shard_plane (the table the process-per-GPU path uses): contiguous channel blocks, the first
+// C % G shards one channel longer; with C < G every channel is shared by G / C shards (the first G % C channels by one more).
+int shard_table(int32_t C, int32_t G, syldet_shard_t *out)
+{
+    if (C < 1 || G < 1 || !out) return fail(SYLDET_ERR_INVALID_ARGUMENT, "n_channels and n_shards must be positive");
+    if (C >= G) {
+        const int32_t base = C / G, extra = C % G;
+        for (int32_t r = 0; r < G; r++) out[r] = syldet_shard_t{r, r * base + std::min(r, extra), base + (r < extra ? 1 : 0), 0, 1};
+        return SYLDET_OK;
+    }
+    const int32_t base = G / C, extra = G % C;
+    int32_t r = 0;
+    for (int32_t ch = 0; ch < C; ch++) {
+        const int32_t parts = base + (ch < extra ? 1 : 0);
+        for (int32_t part = 0; part < parts; part++, r++) out[r] = syldet_shard_t{r, ch, 1, part, parts};
+    }
+    return SYLDET_OK;
+}
+
+// the calling thread's current device, put back when a call that visits several devices returns
+struct DeviceGuard {
+    int prev = -1;
+    DeviceGuard() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+void shard_evals(int64_t E, int32_t parts, int32_t part, int64_t *first, int64_t *count)
+{
+    const int64_t base = E / parts, extra = E % parts;
+    *first = part * base + std::min<int64_t>(part, extra);
+    *count = base + (part < extra ? 1 : 0);
+}
+
+}  // namespace
+
+struct syldet_sharded {
+    struct Shard {
+        syldet_shard_t info{};
+        syldet_t *bank = nullptr;
+        hipStream_t stream = nullptr;
+        hipEvent_t packed = nullptr;          // this shard's rows are in its send buffer
+        hipEvent_t pulled = nullptr;          // (copy exchange) this device has read every shard's send buffer
+        DevMem flags, send, recv;             // own flags when the caller keeps none | packed rows | every shard's packed rows
+        ncclComm_t comm = nullptr;
+    };
+    std::vector<Shard> shards;
+    syldet_geometry_t geom{};
+    int32_t channels = 0, time_range = 0, window = 0;
+    int exchange = SYLDET_EXCHANGE_RCCL;
+    bool time_mode = false;                   // fewer channels than shards: ranges of evaluations, raw bytes in the exchange
+    bool comms_up = false;
+    std::mutex mu;                            // one batch call at a time
+};
+
+namespace {
+
+void ranges_of(const syldet_sharded *b, const syldet_sharded::Shard &s, int64_t S, int64_t *s0, int64_t *s1, int64_t *e0, int64_t *count)
+{
+    const int64_t E = syldet_count_evals(s.bank, S);
+    int64_t f = 0, n = E > 0 ? E : 0, a = 0, z = S;
+    if (s.info.parts > 1) {
+        shard_evals(n, s.info.parts, s.info.part, &f, &n);
+        // dist.time_shard_samples: from the first frame's hop to the end of the last evaluation's last frame
+        a = f * b->geom.hop;
+        z = n > 0 ? (f + n + b->time_range - 2) * b->geom.hop + b->geom.gap + b->window : a;
+    }
+    if (s0) *s0 = a;
+    if (s1) *s1 = z;
+    if (e0) *e0 = f;
+    if (count) *count = n;
+}
+
+int bring_up_comms(syldet_sharded *b)
+{
+    if (b->comms_up || b->exchange != SYLDET_EXCHANGE_RCCL) return SYLDET_OK;
+    Rccl *r = rccl();
+    if (!r->lib) return fail(SYLDET_ERR_DEVICE, "librccl could not be loaded (" + r->why + "); create the bank with SYLDET_EXCHANGE_PEER_COPY to do without it");
+    const int n = (int)b->shards.size();
+    std::vector<int> devs((size_t)n);
+    std::vector<ncclComm_t> comms((size_t)n, nullptr);
+    for (int i = 0; i < n; i++) devs[(size_t)i] = b->shards[(size_t)i].info.device;
+    SYLDET_NCCL(r->CommInitAll(comms.data(), n, devs.data()));
+    for (int i = 0; i < n; i++) b->shards[(size_t)i].comm = comms[(size_t)i];
+    b->comms_up = true;
+    return SYLDET_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int syldet_shard_table(int32_t n_channels, int32_t n_shards, syldet_shard_t *out) { return shard_table(n_channels, n_shards, out); }
+
+int syldet_shard_evaluations(int64_t n_evals, int32_t parts, int32_t part, int64_t *first, int64_t *count)
+{
+    if (n_evals < 0 || parts < 1 || part < 0 || part >= parts || !first || !count) return fail(SYLDET_ERR_INVALID_ARGUMENT, "bad sharding arguments");
+    shard_evals(n_evals, parts, part, first, count);
+    return SYLDET_OK;
+}
+
+int syldet_shard_samples(const syldet_config_t *cfg, int64_t first_eval, int64_t count, int64_t *s0, int64_t *s1)
+{
+    if (!cfg || !s0 || !s1 || first_eval < 0 || count < 0) return fail(SYLDET_ERR_INVALID_ARGUMENT, "bad argument");
+    syldet_geometry_t g;
+    if (int st = compute_geometry(*cfg, &g)) return st;
+    *s0 = first_eval * g.hop;
+    *s1 = count > 0 ? (first_eval + count + cfg->time_range - 2) * g.hop + g.gap + cfg->window_length : *s0;
+    return SYLDET_OK;
+}
+
+int syldet_create_sharded(const syldet_config_t *cfg, int32_t n_channels, const int32_t *devices, int32_t n_devices, int32_t engine,
+                          int32_t exchange, syldet_sharded_t **out)
+{
+    if (!cfg || !devices || !out) return fail(SYLDET_ERR_INVALID_ARGUMENT, "NULL argument");
+    *out = nullptr;
+    if (n_devices < 1 || n_devices > 1024) return fail(SYLDET_ERR_INVALID_ARGUMENT, "n_devices must be in [1, 1024]");
+    if (n_channels < 1) return fail(SYLDET_ERR_INVALID_ARGUMENT, "n_channels must be positive");
+    if (exchange != SYLDET_EXCHANGE_RCCL && exchange != SYLDET_EXCHANGE_PEER_COPY) return fail(SYLDET_ERR_INVALID_ARGUMENT, "unknown exchange");
+    std::unique_ptr<syldet_sharded> b(new (std::nothrow) syldet_sharded());
+    if (!b) return fail(SYLDET_ERR_OUT_OF_MEMORY, "out of memory");
+    DeviceGuard restore;
+    // RCCL refuses a device listed twice; such a bank (the rehearsal of the shard logic on a one-GPU box) exchanges by copies
+    std::vector<int32_t> seen(devices, devices + n_devices);
+    std::sort(seen.begin(), seen.end());
+    if (std::adjacent_find(seen.begin(), seen.end()) != seen.end()) exchange = SYLDET_EXCHANGE_PEER_COPY;
+    b->exchange = exchange;
+    b->channels = n_channels;
+    b->time_range = cfg->time_range;
+    b->window = cfg->window_length;
+    b->time_mode = n_channels < n_devices;
+    std::vector<syldet_shard_t> table((size_t)n_devices);
+    if (int st = shard_table(n_channels, n_devices, table.data())) return st;
+    try {
+        b->shards.resize((size_t)n_devices);
+    } catch (const std::bad_alloc &) {
+        return fail(SYLDET_ERR_OUT_OF_MEMORY, "out of memory");
+    }
+    int st = SYLDET_OK;
+    for (int32_t i = 0; i < n_devices && st == SYLDET_OK; i++) {
+        syldet_sharded::Shard &s = b->shards[(size_t)i];
+        s.info = table[(size_t)i];
+        s.info.device = devices[i];
+        s.flags.device = s.send.device = s.recv.device = devices[i];
+        st = syldet_create(cfg, s.info.channels, devices[i], engine, &s.bank);      // (validates the device, makes it current)
+        if (st) break;
+        hipError_t e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&s.packed, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&s.pulled, hipEventDisableTiming);
+        if (e != hipSuccess) st = fail(SYLDET_ERR_DEVICE, std::string("stream / event: ") + hipGetErrorString(e));
+    }
+    if (st == SYLDET_OK) st = syldet_get_geometry(b->shards[0].bank, &b->geom);
+    if (st) {
+        const std::string msg = syldet_last_error();               // (the teardown below must not lose the message)
+        syldet_sharded_destroy(b.release());
+        return fail(st, msg);
+    }
+    *out = b.release();
+    return SYLDET_OK;
+}
+
+int syldet_sharded_destroy(syldet_sharded_t *b)
+{
+    if (!b) return SYLDET_OK;
+    DeviceGuard restore;
+    for (auto &s : b->shards) {
+        if (s.stream) {
+            (void)hipSetDevice(s.info.device);
+            (void)hipStreamSynchronize(s.stream);
+        }
+    }
+    for (auto &s : b->shards)
+        if (s.comm) (void)rccl()->CommDestroy(s.comm);
+    for (auto &s : b->shards) {
+        (void)hipSetDevice(s.info.device);
+        if (s.packed) (void)hipEventDestroy(s.packed);
+        if (s.pulled) (void)hipEventDestroy(s.pulled);
+        if (s.stream) (void)hipStreamDestroy(s.stream);
+        s.flags.release();
+        s.send.release();
+        s.recv.release();
+        if (s.bank) syldet_destroy(s.bank);
+    }
+    delete b;
+    return SYLDET_OK;
+}
+
+int32_t syldet_sharded_channels(const syldet_sharded_t *b) { return b ? b->channels : 0; }
+int32_t syldet_sharded_shards(const syldet_sharded_t *b) { return b ? (int32_t)b->shards.size() : 0; }
+int32_t syldet_sharded_rccl_ranks(const syldet_sharded_t *b) { return (b && b->exchange == SYLDET_EXCHANGE_RCCL) ? (int32_t)b->shards.size() : 0; }
+
+int syldet_sharded_shard(const syldet_sharded_t *b, int32_t shard, syldet_shard_t *out)
+{
+    if (!b || !out || shard < 0 || shard >= (int32_t)b->shards.size()) return fail(SYLDET_ERR_INVALID_ARGUMENT, "bad argument");
+    *out = b->shards[(size_t)shard].info;
+    return SYLDET_OK;
+}
+
+syldet_t *syldet_sharded_bank(syldet_sharded_t *b, int32_t shard)
+{
+    return (b && shard >= 0 && shard < (int32_t)b->shards.size()) ? b->shards[(size_t)shard].bank : nullptr;
+}
+
+void *syldet_sharded_stream(syldet_sharded_t *b, int32_t shard)
+{
+    return (b && shard >= 0 && shard < (int32_t)b->shards.size()) ? (void *)b->shards[(size_t)shard].stream : nullptr;
+}
+
+int syldet_sharded_ranges(const syldet_sharded_t *b, int32_t shard, int64_t n_samples, int64_t *s0, int64_t *s1, int64_t *e0, int64_t *count)
+{
+    if (!b || shard < 0 || shard >= (int32_t)b->shards.size() || n_samples < 0) return fail(SYLDET_ERR_INVALID_ARGUMENT, "bad argument");
+    ranges_of(b, b->shards[(size_t)shard], n_samples, s0, s1, e0, count);
+    return SYLDET_OK;
+}
+
+// Host buffers: one thread per shard drives that device's pipelined syldet_run on the shard's rows of the caller's arrays
+// (for a time-sharded shard: its stretch of its channel's row).  The results of a shard are contiguous in the caller's
+// [C][E] layout only when it owns whole rows; a time-sharded shard has one row, and its stretch is contiguous too.
+int syldet_sharded_run(syldet_sharded_t *b, const float *samples, int64_t n_samples, int64_t channel_stride, float *outputs, uint8_t *flags)
+{
+    if (!b) return fail(SYLDET_ERR_INVALID_ARGUMENT, "NULL handle");
+    if (n_samples < 0) return fail(SYLDET_ERR_INVALID_ARGUMENT, "n_samples must be >= 0");
+    if (!samples && n_samples > 0) return fail(SYLDET_ERR_INVALID_ARGUMENT, "NULL samples");
+    if (b->channels > 1 && channel_stride < n_samples) return fail(SYLDET_ERR_INVALID_ARGUMENT, "channel_stride must be >= n_samples");
+    std::lock_guard<std::mutex> lock(b->mu);
+    const int64_t E = syldet_count_evals(b->shards[0].bank, n_samples);
+    if (E <= 0) return SYLDET_OK;
+    const int n = (int)b->shards.size(), n_out = b->geom.outputs;
+    std::vector<int> status((size_t)n, SYLDET_OK);
+    std::vector<std::string> message((size_t)n);
+    auto work = [&](int i) {
+        const syldet_sharded::Shard &s = b->shards[(size_t)i];
+        int64_t s0, s1, e0, cnt;
+        ranges_of(b, s, n_samples, &s0, &s1, &e0, &cnt);
+        if (cnt <= 0) return;
+        const size_t row = (size_t)s.info.first_channel;
+        // a shard of whole rows runs [channels][E]; a time-sharded one runs its single row's stretch as a recording of its own
+        status[(size_t)i] = syldet_run(s.bank, samples + row * (size_t)channel_stride + s0, s1 - s0, channel_stride,
+                                       outputs ? outputs + (row * (size_t)E + (size_t)e0) * (size_t)n_out : nullptr,
+                                       flags ? flags + row * (size_t)E + (size_t)e0 : nullptr);
+        if (status[(size_t)i]) message[(size_t)i] = syldet_last_error();       // (the error text is per thread)
+    };
+    std::vector<std::thread> th;
+    try {
+        for (int i = 1; i < n; i++) th.emplace_back(work, i);
+    } catch (...) {
+        for (int i = (int)th.size() + 1; i < n; i++) work(i);
+    }
+    work(0);
+    for (auto &t : th) t.join();
+    for (int i = 0; i < n; i++)
+        if (status[(size_t)i]) return fail(status[(size_t)i], "shard " + std::to_string(i) + ": " + message[(size_t)i]);
+    return SYLDET_OK;
+}
+
+int syldet_sharded_run_device(syldet_sharded_t *b, const float *const *d_samples, int64_t n_samples, const int64_t *strides,
+                              float *const *d_outputs, uint8_t *const *d_flags, uint8_t *const *d_flags_all)
+{
+    if (!b || !d_samples || !strides) return fail(SYLDET_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (n_samples < 0) return fail(SYLDET_ERR_INVALID_ARGUMENT, "n_samples must be >= 0");
+    std::lock_guard<std::mutex> lock(b->mu);
+    DeviceGuard restore;
+    const int n = (int)b->shards.size();
+    const int64_t E = syldet_count_evals(b->shards[0].bank, n_samples);
+    if (E <= 0) return SYLDET_OK;
+    const bool gather = d_flags_all != nullptr;
+    if (gather) {
+        for (int i = 0; i < n; i++)
+            if (!d_flags_all[i] || ((uintptr_t)d_flags_all[i] & 7)) return fail(SYLDET_ERR_INVALID_ARGUMENT, "d_flags_all entries must be 8-byte aligned device pointers");
+        if (int st = bring_up_comms(b)) return st;
+    }
+    // what travels: bit rows of whole channels (padded to the longest shard), or -- time-sharded -- the raw flags of a stretch
+    const int64_t row_bytes = (E + 7) / 8;
+    int64_t chunk = 0;                                            // bytes every shard contributes
+    int32_t padded_rows = 0;
+    if (b->time_mode) {
+        for (auto &s : b->shards) {
+            int64_t cnt;
+            ranges_of(b, s, n_samples, nullptr, nullptr, nullptr, &cnt);
+            chunk = std::max(chunk, cnt);
+        }
+    } else {
+        for (auto &s : b->shards) padded_rows = std::max(padded_rows, s.info.channels);
+        chunk = (int64_t)padded_rows * row_bytes;                 // (exactly: the unpacking addresses block s at s * padded_rows rows)
+    }
+    if (b->time_mode) chunk = (chunk + 15) / 16 * 16;
+
+    // 1. every shard's kernels, each on its own device and stream: all queued before anything else
+    for (int i = 0; i < n; i++) {
+        syldet_sharded::Shard &s = b->shards[(size_t)i];
+        int64_t s0, s1, e0, cnt;
+        ranges_of(b, s, n_samples, &s0, &s1, &e0, &cnt);
+        SYLDET_HIP(hipSetDevice(s.info.device));
+        uint8_t *fl = d_flags ? d_flags[i] : nullptr;
+        if (gather && !fl) {
+            if (int st = s.flags.reserve((size_t)s.info.channels * (size_t)std::max<int64_t>(cnt, 1))) return st;
+            fl = (uint8_t *)s.flags.ptr;
+        }
+        if (gather) {
+            if (int st = s.send.reserve((size_t)chunk)) return st;
+            if (int st = s.recv.reserve((size_t)chunk * (size_t)n)) return st;
+        }
+        if (cnt <= 0) continue;
+        if (!d_samples[i]) return fail(SYLDET_ERR_INVALID_ARGUMENT, "NULL samples for shard " + std::to_string(i));
+        if (int st = syldet_run_device(s.bank, d_samples[i], s1 - s0, strides[i], d_outputs ? d_outputs[i] : nullptr, fl, s.stream)) return st;
+        if (gather) {
+            // (copy exchange: the last batch's rows may still be on their way out of the send buffer to another device)
+            if (b->exchange == SYLDET_EXCHANGE_PEER_COPY)
+                for (int j = 0; j < n; j++)
+                    if (j != i) SYLDET_HIP(hipStreamWaitEvent(s.stream, b->shards[(size_t)j].pulled, 0));
+            if (b->time_mode)
+                SYLDET_HIP(hipMemcpyAsync(s.send.ptr, fl, (size_t)cnt, hipMemcpyDeviceToDevice, s.stream));
+            else
+                SYLDET_HIP(launch_pack_flags(fl, s.info.channels, E, (uint8_t *)s.send.ptr, s.stream));
+        }
+    }
+    if (!gather) return SYLDET_OK;
+
+    // 2. the one exchange
+    if (b->exchange == SYLDET_EXCHANGE_RCCL) {
+        Rccl *r = rccl();
+        SYLDET_NCCL(r->GroupStart());
+        for (int i = 0; i < n; i++) {
+            syldet_sharded::Shard &s = b->shards[(size_t)i];
+            ncclResult_t st = r->AllGather(s.send.ptr, s.recv.ptr, (size_t)chunk, ncclUint8, s.comm, s.stream);
+            if (st != ncclSuccess) {
+                (void)r->GroupEnd();
+                return fail(SYLDET_ERR_DEVICE, std::string("ncclAllGather: ") + r->GetErrorString(st));
+            }
+        }
+        SYLDET_NCCL(r->GroupEnd());
+    } else {
+        for (int i = 0; i < n; i++) {
+            syldet_sharded::Shard &s = b->shards[(size_t)i];
+            SYLDET_HIP(hipSetDevice(s.info.device));
+            SYLDET_HIP(hipEventRecord(s.packed, s.stream));
+        }
+        for (int j = 0; j < n; j++) {                             // device j pulls every shard's rows
+            syldet_sharded::Shard &d = b->shards[(size_t)j];
+            SYLDET_HIP(hipSetDevice(d.info.device));
+            for (int i = 0; i < n; i++) {
+                syldet_sharded::Shard &s = b->shards[(size_t)i];
+                if (i != j) SYLDET_HIP(hipStreamWaitEvent(d.stream, s.packed, 0));
+                char *dst = (char *)d.recv.ptr + (size_t)i * (size_t)chunk;
+                if (s.info.device == d.info.device)
+                    SYLDET_HIP(hipMemcpyAsync(dst, s.send.ptr, (size_t)chunk, hipMemcpyDeviceToDevice, d.stream));
+                else
+                    SYLDET_HIP(hipMemcpyPeerAsync(dst, d.info.device, s.send.ptr, s.info.device, (size_t)chunk, d.stream));
+            }
+            SYLDET_HIP(hipEventRecord(d.pulled, d.stream));
+        }
+    }
+
+    // 3. on every device: the gathered rows into [C][E] flags
+    for (int j = 0; j < n; j++) {
+        syldet_sharded::Shard &d = b->shards[(size_t)j];
+        SYLDET_HIP(hipSetDevice(d.info.device));
+        if (!b->time_mode) {
+            SYLDET_HIP(launch_unpack_flags_gathered((const uint8_t *)d.recv.ptr, b->channels, E, n, padded_rows, d_flags_all[j], d.stream));
+            continue;
+        }
+        for (int i = 0; i < n; i++) {
+            int64_t e0, cnt;
+            ranges_of(b, b->shards[(size_t)i], n_samples, nullptr, nullptr, &e0, &cnt);
+            if (cnt > 0)
+                SYLDET_HIP(hipMemcpyAsync(d_flags_all[j] + (size_t)b->shards[(size_t)i].info.first_channel * (size_t)E + (size_t)e0,
+                                          (const char *)d.recv.ptr + (size_t)i * (size_t)chunk, (size_t)cnt, hipMemcpyDeviceToDevice, d.stream));
+        }
+    }
+    return SYLDET_OK;
+}
+
+int syldet_sharded_synchronize(syldet_sharded_t *b)
+{
+    if (!b) return fail(SYLDET_ERR_INVALID_ARGUMENT, "NULL handle");
+    DeviceGuard restore;
+    for (auto &s : b->shards) {
+        SYLDET_HIP(hipSetDevice(s.info.device));
+        SYLDET_HIP(hipStreamSynchronize(s.stream));
+    }
+    return SYLDET_OK;
+}
+
+}  // extern "C"

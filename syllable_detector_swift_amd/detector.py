@@ -36,9 +36,25 @@ class SyllableDetector:
         check(_abi.lib.syldet_get_geometry(self._h, C.byref(g)))
         self.geometry = g
 
+    @classmethod
+    def borrowed(cls, bank, shard: int) -> "SyllableDetector":
+        """Shard `shard`'s own bank of a ShardedSyllableDetectorBank as a SyllableDetector (timings, fix-up statistics, spot
+        checks); it belongs to the sharded bank and is not destroyed with this object."""
+        self = cls.__new__(cls)
+        self.config = bank.config
+        self.channels = int(bank.shards[shard].channels)
+        self.device = int(bank.shards[shard].device)
+        self._h = _abi.Handle(_abi.lib.syldet_sharded_bank(bank._h, int(shard)))
+        self._borrowed = True
+        g = _abi.Geometry()
+        check(_abi.lib.syldet_get_geometry(self._h, C.byref(g)))
+        self.geometry = g
+        return self
+
     def close(self):
         if getattr(self, "_h", None):
-            _abi.lib.syldet_destroy(self._h)
+            if not getattr(self, "_borrowed", False):
+                _abi.lib.syldet_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -234,12 +250,18 @@ class SyllableDetector:
         return int(_abi.lib.syldet_segment_evals(self._h, int(n_samples)))
 
     # ---- batch, host arrays -------------------------------------------------------
-    def runHost(self, samples: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    def runHost(self, samples: np.ndarray, outputs: Optional[np.ndarray] = None, flags: Optional[np.ndarray] = None) -> Tuple[np.ndarray, np.ndarray]:
+        """syldet_run: the batch call on host arrays, pipelined along time inside the library.  `outputs` / `flags`: arrays to
+        write into (e.g. bank.PinnedArray views, which the DMA engines write in place)."""
         a = np.ascontiguousarray(samples, dtype=np.float32).reshape(self.channels, -1)
         S = a.shape[1]
-        E = self.countEvaluations(S)
-        out = np.zeros((self.channels, E, self.geometry.outputs), np.float32)
-        fl = np.zeros((self.channels, E), np.uint8)
+        E = max(self.countEvaluations(S), 0)
+        out = outputs if outputs is not None else np.zeros((self.channels, E, self.geometry.outputs), np.float32)
+        fl = flags if flags is not None else np.zeros((self.channels, E), np.uint8)
+        if out.shape != (self.channels, E, self.geometry.outputs) or out.dtype != np.float32 or not out.flags.c_contiguous:
+            raise ValueError("outputs must be a C-contiguous float32 array [channels, E, outputs]")
+        if fl.shape != (self.channels, E) or fl.dtype != np.uint8 or not fl.flags.c_contiguous:
+            raise ValueError("flags must be a C-contiguous uint8 array [channels, E]")
         check(_abi.lib.syldet_run(self._h, a.ctypes.data_as(_abi.c_float_p), S, S,
                                   out.ctypes.data_as(_abi.c_float_p), fl.ctypes.data_as(_abi.c_uint8_p)))
         return out, fl

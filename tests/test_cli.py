@@ -69,3 +69,19 @@ def test_probe_reports_bad_files(tmp_path):
     assert lines[0] == "Unable to read %s: no fmt chunk" % bad
     assert lines[1] == "Unable to read %s: not a RIFF/WAVE file" % notwav
     assert lines[2] == "Unable to read %s: cannot open file" % (tmp_path / "missing.wav")
+
+
+def test_the_one_output_line_the_reference_holds():
+    """SyllableDetectorCLI/main.swift:33 shows an event line, `0,1593298,36.1292063492063,0.918557`: channel 0, sample
+    1 593 298 at 44.1 kHz, output 0.918557 -- 15 and 6 significant digits, which is what `\\(Double)` / `\\(Float)` print under
+    the Swift 4.0 toolchain the project declares (project.pbxproj:593).  `--format swift4` must reproduce it byte for byte
+    from (sample, rate, fp32 output); the default prints the shortest digits that round-trip (Swift >= 4.2)."""
+    r = run("--format", "swift4", "--format-line", "0", "1593298", "44100", "0.918557")
+    assert r.returncode == 0 and r.stdout == "0,1593298,36.1292063492063,0.918557\n"
+    r = run("--format-line", "0", "1593298", "44100", "0.918557")
+    assert r.returncode == 0 and r.stdout == "0,1593298,%r,%s\n" % (1593298 / 44100, "0.918557")
+    # whole numbers get ".0" in both forms; small and large values keep C's exponent form under swift4
+    assert run("--format", "swift4", "--format-line", "3", "88200", "44100", "1", "0.5").stdout == "3,88200,2.0,1.0,0.5\n"
+    assert run("--format", "swift4", "--format-line", "1", "1", "3", "0.33333334", "1e-7").stdout == "1,1,0.333333333333333,0.333333,1e-07\n"
+    assert run("--format", "shortest", "--format-line", "1", "1", "3", "0.33333334").stdout == "1,1,0.3333333333333333,0.33333334\n"
+    assert run("--format", "swift5").returncode == 64

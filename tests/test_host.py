@@ -239,3 +239,44 @@ def test_header_is_plain_c_and_the_library_refuses_to_run_without_a_device(tmp_p
     np.zeros(4000, np.float32).tofile(str(tmp_path / "x.f32"))
     r = subprocess.run([exe, str(tmp_path / "net.txt"), str(tmp_path / "x.f32")], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and r.stdout.strip() == "no-device", (r.stdout, r.stderr)
+
+
+def test_shard_table_of_the_sharded_bank_matches_the_process_per_gpu_table():
+    """syldet_shard_table / syldet_shard_evaluations / syldet_shard_samples (the one-process bank's host arithmetic, no device)
+    against dist.shard_channels / shard_plane / shard_evaluations / time_shard_samples: 4096 / 8 (BASELINE configs[3]), the
+    ragged 4099 / 8, and fewer channels than shards."""
+    import ctypes as C
+    from syllable_detector_swift_amd import dist
+    from syllable_detector_swift_amd.bank import shard_table
+    for total, world in ((4096, 8), (4099, 8), (8, 8), (9, 4), (3, 8), (1, 4), (2, 3), (7, 1), (5, 7)):
+        got = shard_table(total, world)
+        want = [dist.shard_plane(total, world, r) for r in range(world)]
+        assert got == want, (total, world)
+        if total >= world:
+            assert [(f, n) for f, n, _, _ in got] == [dist.shard_channels(total, world, r) for r in range(world)]
+            assert sum(n for _, n, _, _ in got) == total
+    assert shard_table(4096, 8) == [(512 * r, 512, 0, 1) for r in range(8)]
+    assert [n for _, n, _, _ in shard_table(4099, 8)] == [513, 513, 513, 512, 512, 512, 512, 512]
+    with pytest.raises(sd.SyllableDetectorError):
+        shard_table(0, 4)
+    cfg = util.sample_net()
+    c, keep = cfg.to_abi()
+    for E, parts in ((15877, 8), (5, 8), (100, 3), (0, 2)):
+        for part in range(parts):
+            f, n = C.c_int64(), C.c_int64()
+            assert _abi.lib.syldet_shard_evaluations(E, parts, part, C.byref(f), C.byref(n)) == 0
+            assert (f.value, n.value) == dist.shard_evaluations(E, parts, part)
+            s0, s1 = C.c_int64(), C.c_int64()
+            assert _abi.lib.syldet_shard_samples(C.byref(c), f.value, n.value, C.byref(s0), C.byref(s1)) == 0
+            assert (s0.value, s1.value) == dist.time_shard_samples(132, 0, 256, 10, f.value, n.value)
+    assert _abi.lib.syldet_shard_evaluations(10, 2, 2, C.byref(f), C.byref(n)) == _abi.ERR_INVALID_ARGUMENT
+
+
+def test_sharded_bank_refuses_to_exist_without_a_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("device runs: tests/test_sharded_gpu.py")
+    from syllable_detector_swift_amd.bank import ShardedSyllableDetectorBank
+    with pytest.raises(sd.SyllableDetectorError) as e:
+        ShardedSyllableDetectorBank(util.sample_net(), 8, [0, 1])
+    assert e.value.status == _abi.ERR_NO_DEVICE

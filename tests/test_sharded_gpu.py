@@ -1,0 +1,170 @@
+"""The detector bank that spans several GPUs of ONE process (syldet_create_sharded; the reference is one process that owns
+every channel: Processor.swift:57-59,128-141, main.swift:86-89,126-130) and the pipelined host-pointer batch call, on the one
+GPU of the test box: `devices = [0]` is one RCCL rank (the library's own ncclCommInitAll + ncclAllGather), `devices = [0, 0,
+...]` rehearses the shard table, the time-axis split and the copy exchange.  Every result must be the plain bank's, bit for
+bit: the kernels scale per frame or per hop-aligned block, so a shard's evaluations do not depend on how the bank is cut."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import pyoracle as po
+import util
+from syllable_detector_swift_amd import SyllableDetector, _abi, nets, synth
+from syllable_detector_swift_amd.bank import PinnedArray, ShardedSyllableDetectorBank
+
+pytestmark = pytest.mark.gpu
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _plain(cfg, x, engine=0):
+    torch = _torch()
+    with SyllableDetector(cfg, channels=x.shape[0], device=0, engine=engine) as det:
+        out, fl = det.run(torch.from_numpy(x).cuda())
+        torch.cuda.synchronize()
+        return out.cpu().numpy(), fl.cpu().numpy()
+
+
+def _check_bank(cfg, x, devices, exchange=_abi.EXCHANGE_RCCL, want=None):
+    torch = _torch()
+    C, S = x.shape
+    want_out, want_fl = want if want is not None else _plain(cfg, x)
+    with ShardedSyllableDetectorBank(cfg, C, devices, exchange=exchange) as bank:
+        blocks = bank.scatter(x)
+        for rep in range(2):                                   # (twice: the exchange buffers are reused)
+            outs, fls, alls = bank.run(blocks, S)
+            bank.synchronize()
+        for i, s in enumerate(bank.shards):
+            _, _, e0, cnt = bank.ranges(i, S)
+            rows = slice(s.first_channel, s.first_channel + s.channels)
+            assert np.array_equal(outs[i].cpu().numpy(), want_out[rows, e0:e0 + cnt]), "outputs of shard %d" % i
+            assert np.array_equal(fls[i].cpu().numpy(), want_fl[rows, e0:e0 + cnt]), "flags of shard %d" % i
+            assert np.array_equal(alls[i].cpu().numpy(), want_fl), "gathered flags on shard %d's device" % i
+        out_h, fl_h = bank.runHost(x)
+        assert np.array_equal(out_h, want_out) and np.array_equal(fl_h, want_fl), "host-pointer call"
+        return bank.rcclRanks
+
+
+def test_one_rank_rccl_bank_equals_the_plain_bank_on_the_syllable_case(oracle_lib):
+    """devices = {0}: the library's own RCCL communicator (one rank) carries the exchange; results are the plain bank's and
+    the oracle's."""
+    cfg, x, gold = util.load_case("case_sample_syllables")
+    x = np.stack([x, x[::-1].copy(), 0.5 * x]).astype(np.float32)
+    want = _plain(cfg, x)
+    assert _check_bank(cfg, x, [0], want=want) == 1
+    o = util.oracle_for(cfg)
+    _, wfl, w64 = o.run(x[0], po.F64)
+    util.assert_outputs_close(want[0][0], w64)
+    util.assert_flags_exact(want[1][0], w64, cfg.thresholds, cfg.rule)
+    assert want[1][0].sum() > 0
+
+
+@pytest.mark.parametrize("channels,shards", [(5, 2), (8, 4), (7, 3), (2, 3), (1, 4), (3, 8)])
+def test_shard_tables_on_one_device(channels, shards):
+    """Ragged channel blocks (5 / 2, 7 / 3), equal ones (8 / 4) and the time-axis split with its halo (2 / 3: one channel cut
+    in two, one whole; 1 / 4; 3 / 8), all shards on device 0 with the copy exchange."""
+    cfg = util.sample_net()
+    x = synth.channels(channels, 30000 + 137 * channels, first=40)
+    assert _check_bank(cfg, x, [0] * shards) == 0
+
+
+def test_time_sharded_bank_on_other_engines():
+    """The halo is geometry, not a property of one kernel: 1024-point frames on the block-transform kernel and a chain the
+    generic engine takes, cut along time."""
+    for cfg in (nets.config3(), nets.variant(util.sample_net(), spectrogramScaling="db")):
+        hop = cfg.windowLength - cfg.windowOverlap
+        x = synth.channels(2, cfg.windowLength + 700 * hop + 5, first=7, fs=cfg.samplingRate)
+        _check_bank(cfg, x, [0] * 5)
+
+
+def test_configs3_shard_shape_through_the_one_rank_bank():
+    """BASELINE configs[3]'s per-GPU shape (512 channels x 2^21 samples) through the sharded handle with devices = {0}:
+    bit-identical to the plain bank, gathered flags through the library's RCCL group."""
+    torch = _torch()
+    cfg = util.sample_net()
+    C, S = 512, 1 << 21
+    dev = torch.device("cuda", 0)
+    x = synth.channels_on_device(C, S, dev)
+    with SyllableDetector(cfg, channels=C, device=0) as det:
+        want_out, want_fl = det.run(x)
+        torch.cuda.synchronize()
+    with ShardedSyllableDetectorBank(cfg, C, [0]) as bank:
+        outs, fls, alls = bank.run([x], S)
+        bank.synchronize()
+        assert bank.rcclRanks == 1
+        assert torch.equal(outs[0], want_out) and torch.equal(fls[0], want_fl) and torch.equal(alls[0], want_fl)
+
+
+def test_c_program_over_the_sharded_abi(tmp_path):
+    """tests/c/sharded_bank.c (strict C99): plain bank vs the sharded handle, host and device calls, identical bits -- as one
+    RCCL rank and as three shards of two channels (time-axis split) with the copy exchange."""
+    exe = os.path.join(os.path.dirname(_abi.LIB_PATH), "sharded_bank")
+    if not os.path.exists(exe):
+        pytest.skip("sharded_bank not built (run __graft_entry__.build())")
+    cfg, x, gold = util.load_case("case_sample_syllables")
+    x = np.stack([x[:60000], x[20000:80000]]).astype(np.float32)
+    (tmp_path / "net.txt").write_text(cfg.toText())
+    x.tofile(str(tmp_path / "x.f32"))
+    for devices, ranks in (("0", 1), ("0,0,0", 0)):
+        r = subprocess.run([exe, str(tmp_path / "net.txt"), str(tmp_path / "x.f32"), "2", devices], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr
+        E, det, rk, word = r.stdout.split()
+        assert word == "identical" and int(rk) == ranks and int(det) > 0
+        assert int(E) == (60000 - 256) // 132 + 1 - 9
+
+
+# ---- the host-pointer batch call as a pipeline along time -------------------------------------------------------------
+
+@pytest.mark.parametrize("kind", ["fold", "generic", "config3"])
+def test_pipelined_host_call_equals_the_device_call_across_stage_seams(kind, monkeypatch):
+    """syldet_run cut into many stages (SYLDET_HOST_CHUNK_BYTES forces seams every few hundred evaluations) == the one-shot
+    device call, bit for bit, where the kernels scale per frame or per hop-aligned block; pageable and pinned buffers."""
+    torch = _torch()
+    cfg, engine = {"fold": (util.sample_net(), 0), "generic": (util.sample_net(), 1), "config3": (nets.config3(), 0)}[kind]
+    hop = cfg.windowLength - cfg.windowOverlap
+    C = 3
+    S = cfg.windowLength + 2500 * hop + 77
+    x = synth.channels(C, S, first=3, fs=cfg.samplingRate)
+    x[1] *= np.float32(1e-3)
+    want_out, want_fl = _plain(cfg, x, engine)
+    E = want_out.shape[1]
+    for chunk in (C * 4 * hop * 300, C * 4 * hop * 997, 1 << 30):
+        monkeypatch.setenv("SYLDET_HOST_CHUNK_BYTES", str(chunk))
+        with SyllableDetector(cfg, channels=C, device=0, engine=engine) as det:
+            out, fl = det.runHost(x)
+            assert np.array_equal(out, want_out) and np.array_equal(fl, want_fl), "pageable buffers, stages of %d bytes" % chunk
+            px, po_, pf = PinnedArray(x.shape, np.float32), PinnedArray(want_out.shape, np.float32), PinnedArray(want_fl.shape, np.uint8)
+            px.array[:] = x
+            po_.array[:] = -1
+            pf.array[:] = 7
+            det.runHost(px.array, outputs=po_.array, flags=pf.array)
+            assert np.array_equal(po_.array, want_out) and np.array_equal(pf.array, want_fl), "pinned buffers, stages of %d bytes" % chunk
+            # a strided source (rows of a longer recording) and results only partly asked for
+            wide = np.zeros((C, S + 50), np.float32)
+            wide[:, :S] = x
+            out2 = np.zeros_like(want_out)
+            _abi.lib.syldet_run(det._h, wide.ctypes.data_as(_abi.c_float_p), S, S + 50, out2.ctypes.data_as(_abi.c_float_p), None)
+            assert np.array_equal(out2, want_out)
+            for p in (px, po_, pf):
+                p.free()
+    assert E > 2000
+
+
+def test_pipelined_host_call_on_a_pass_scaled_kernel_stays_inside_the_bar(oracle_lib, monkeypatch):
+    """The pass-scaled kernels (here the register-resident-basis kernel under SYLDET_FUSED_NOFOLD) agree between tilings to a
+    few 1e-7, not to the bit: a staged run is held to the oracle like any other."""
+    monkeypatch.setenv("SYLDET_FUSED_NOFOLD", "1")
+    cfg, x, gold = util.load_case("case_sample_syllables")
+    x = x[:90000]
+    monkeypatch.setenv("SYLDET_HOST_CHUNK_BYTES", str(4 * 132 * 150))
+    with SyllableDetector(cfg, channels=1, device=0) as det:
+        out, fl = det.runHost(x[None, :])
+    o = util.oracle_for(cfg)
+    _, wfl, w64 = o.run(x, po.F64)
+    util.assert_outputs_close(out[0], w64)
+    util.assert_flags_exact(fl[0], w64, cfg.thresholds, cfg.rule)
