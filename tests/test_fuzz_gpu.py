@@ -116,8 +116,13 @@ def test_random_configuration(oracle_lib, seed):
         # exceeds 1 (an fp32 value of 1000 has an ulp of 6e-5: no fp32 evaluation order is closer to the anchor than that).
         strict = cfg.spectrogramScaling == "linear" and cfg.spectrum == _abi.SPECTRUM_POWER and not few
         bar = np.full(w64.shape[0], max(util.TOL, 4.0 * own))
+        own_e = np.zeros(w64.shape[0])
+        own_e[ok] = (np.abs(o32[ok] - w64[ok]) / np.maximum(1.0, np.abs(w64[ok]))).max(axis=1)
+        floor_e = None                                           # what no fp32 evaluation can hold (util.widened_evaluations)
         if strict and names[:1] == ["l2normalize"]:            # a band that holds little of its frames' energy: see util.band_condition
-            bar = np.maximum(bar, 2.0 ** -21 * util.band_condition(o, cfg, x[c]))
+            kappa = util.band_condition(o, cfg, x[c])
+            bar = np.maximum(bar, 2.0 ** -21 * kappa)
+            floor_e = 2.0 ** -23 * kappa
         if strict and not normalised:
             cols = o.spectrogram(x[c], po.F64)
             T = cfg.timeRange
@@ -136,15 +141,21 @@ def test_random_configuration(oracle_lib, seed):
                 over = np.nonzero(err > tol)[0]
                 if len(over):
                     tol = np.full(int(ok.sum()), tol)
-                    tol[over] = np.maximum(tol[over], 2.0 * util.log_condition(o, cfg, x[c], o.spectrogram(x[c], po.F64), np.nonzero(ok)[0][over]))
+                    moves = util.log_condition(o, cfg, x[c], o.spectrogram(x[c], po.F64), np.nonzero(ok)[0][over])
+                    tol[over] = np.maximum(tol[over], 2.0 * moves)
+                    floor_e = np.zeros(w64.shape[0])
+                    floor_e[np.nonzero(ok)[0][over]] = moves
             if ok.any():
                 errv = (np.abs(out[c][ok] - w64[ok]) / np.maximum(1.0, np.abs(w64[ok]))).max(axis=1)
                 flat = max(util.TOL, 4.0 * own) if (strict and widen == 1.0) else max(1e-4, 30.0 * own)
                 why = ""
                 if (errv > flat).any():
                     why = "log condition" if cfg.spectrogramScaling != "linear" else ("kappa" if names[:1] == ["l2normalize"] else "column level")
+                wide = util.widened_evaluations(errv, own_e[ok], flat, tol, floor_e[ok] if floor_e is not None else None)
                 util.sweep_record("any configuration", seed, {1: "generic engine", 2: "fused engine", 3: "wide"}.get(engine, str(engine)) + (" (on request)" if widen != 1.0 else ""),
-                                  errv.max(), own, flat, (errv / np.broadcast_to(np.asarray(tol, np.float64), errv.shape)).max(), why)
+                                  errv.max(), own, flat, (errv / np.broadcast_to(np.asarray(tol, np.float64), errv.shape)).max(), why, wide)
+                # (the engine AUTO selects: an error beyond the flat bar must be one fp32 itself cannot avoid there)
+                assert widen != 1.0 or not wide or wide["unexplained"] == 0, "beyond the flat bar where fp32 holds it: %s" % wide
                 util.assert_outputs_close(out[c][ok], w64[ok], tol)
                 util.assert_flags_exact(fl[c][ok], w64[ok], cfg.thresholds, cfg.rule, tol)
             assert not fl[c][~ok].any()
@@ -254,7 +265,8 @@ def test_random_example_class_detector_on_the_register_resident_kernel(oracle_li
         assert [nm for nm, _ in det.lastTimings()] == [kernel]
         out, fl = out.cpu().numpy(), fl.cpu().numpy()
     for c in range(C):
-        w32, _, w64 = o.run(x[c], po.F64, cfg.rule)
+        _, _, w64 = o.run(x[c], po.F64, cfg.rule)
+        w32 = o.run(x[c], po.F32, cfg.rule)[0]                   # the fp32 port: the reference's operation order in fp32
         ok = np.isfinite(w64).all(axis=1)
         own = float((np.abs(w32[ok] - w64[ok]) / np.maximum(1.0, np.abs(w64[ok]))).max()) if ok.any() else 0.0
         assert out[c].shape == w64.shape
@@ -262,10 +274,14 @@ def test_random_example_class_detector_on_the_register_resident_kernel(oracle_li
         # 1e-5 (or 4x the fp32 port's own distance from the anchor); where the band holds only a small part of its frames'
         # energy no fp32 transform knows it to 1e-5 of its own norm (util.band_condition), and the bar follows
         flat = max(util.TOL, 4.0 * own)
-        tol = np.maximum(flat, 2.0 ** -21 * util.band_condition(o, cfg, x[c]))[ok]
+        kappa = util.band_condition(o, cfg, x[c])
+        tol = np.maximum(flat, 2.0 ** -21 * kappa)[ok]
         if ok.any():
             err = (np.abs(out[c][ok] - w64[ok]) / np.maximum(1.0, np.abs(w64[ok]))).max(axis=1)
-            util.sweep_record("example class", seed, kernel, err.max(), own, flat, (err / tol).max(), "kappa" if (err > flat).any() else "")
+            own_e = (np.abs(w32[ok] - w64[ok]) / np.maximum(1.0, np.abs(w64[ok]))).max(axis=1)
+            wide = util.widened_evaluations(err, own_e, flat, tol, 2.0 ** -23 * kappa[ok])
+            util.sweep_record("example class", seed, kernel, err.max(), own, flat, (err / tol).max(), "kappa" if (err > flat).any() else "", wide)
+            assert not wide or wide["unexplained"] == 0, "beyond the flat bar where fp32 holds it: %s" % wide
             util.assert_outputs_close(out[c][ok], w64[ok], tol)
             util.assert_flags_exact(fl[c][ok], w64[ok], cfg.thresholds, cfg.rule, tol)
         assert not fl[c][~ok].any()
@@ -311,14 +327,19 @@ def test_random_frames_of_four_hops(oracle_lib, seed):
         assert [nm for nm, _ in det.lastTimings()] == ["bdft_net_kernel"]
         out, fl = out.cpu().numpy(), fl.cpu().numpy()
     for c in range(C):
-        w32, _, w64 = o.run(x[c], po.F64, cfg.rule)
+        _, _, w64 = o.run(x[c], po.F64, cfg.rule)
+        w32 = o.run(x[c], po.F32, cfg.rule)[0]                   # the fp32 port: the reference's operation order in fp32
         ok = np.isfinite(w64).all(axis=1)
         own = float((np.abs(w32[ok] - w64[ok]) / np.maximum(1.0, np.abs(w64[ok]))).max()) if ok.any() else 0.0
         assert (np.isfinite(out[c]).all(axis=1) == ok).all(), "NaN/inf evaluations must coincide"
         flat = max(util.TOL, 4.0 * own)
-        tol = np.maximum(flat, 2.0 ** -21 * util.band_condition(o, cfg, x[c]))[ok]
+        kappa = util.band_condition(o, cfg, x[c])
+        tol = np.maximum(flat, 2.0 ** -21 * kappa)[ok]
         if ok.any():
             err = (np.abs(out[c][ok] - w64[ok]) / np.maximum(1.0, np.abs(w64[ok]))).max(axis=1)
-            util.sweep_record("frames of four hops", seed, "bdft_net_kernel", err.max(), own, flat, (err / tol).max(), "kappa" if (err > flat).any() else "")
+            own_e = (np.abs(w32[ok] - w64[ok]) / np.maximum(1.0, np.abs(w64[ok]))).max(axis=1)
+            wide = util.widened_evaluations(err, own_e, flat, tol, 2.0 ** -23 * kappa[ok])
+            util.sweep_record("frames of four hops", seed, "bdft_net_kernel", err.max(), own, flat, (err / tol).max(), "kappa" if (err > flat).any() else "", wide)
+            assert not wide or wide["unexplained"] == 0, "beyond the flat bar where fp32 holds it: %s" % wide
             util.assert_outputs_close(out[c][ok], w64[ok], tol)
             util.assert_flags_exact(fl[c][ok], w64[ok], cfg.thresholds, cfg.rule, tol)

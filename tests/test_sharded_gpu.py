@@ -113,7 +113,7 @@ def test_c_program_over_the_sharded_abi(tmp_path):
     for devices, ranks in (("0", 1), ("0,0,0", 0)):
         r = subprocess.run([exe, str(tmp_path / "net.txt"), str(tmp_path / "x.f32"), "2", devices], capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr
-        E, det, rk, word = r.stdout.split()
+        E, det, rk, word = r.stdout.strip().splitlines()[-1].split()      # (RCCL prints a version banner to stdout with its first communicator)
         assert word == "identical" and int(rk) == ranks and int(det) > 0
         assert int(E) == (60000 - 256) // 132 + 1 - 9
 

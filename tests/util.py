@@ -183,19 +183,48 @@ def select_fused(monkeypatch, kernel):
 SWEEP_LOG = []
 
 
-def sweep_record(sweep, seed, kernel, err, own, flat_bar, bar_used, reason):
+def sweep_record(sweep, seed, kernel, err, own, flat_bar, bar_used, reason, widened=None):
     """One (draw, channel) of a random sweep: the worst output error relative to max(1, |anchor|), the fp32 port's own
     distance from the anchor, the flat bar (1e-5 or 4x own; 1e-4 or 30x own for log / dB), the worst ratio of error to the
-    bar that was applied, and why a wider bar was applied, if one was ("" | "kappa" | "column level" | "log condition")."""
+    bar that was applied, and why a wider bar was applied, if one was ("" | "kappa" | "column level" | "log condition").
+    `widened`: what widened_evaluations() found for the evaluations beyond the flat bar."""
     SWEEP_LOG.append({"sweep": sweep, "seed": int(seed), "kernel": kernel, "err": float(err), "own": float(own),
-                      "flat_bar": float(flat_bar), "err_over_bar": float(bar_used), "wider_bar": reason})
+                      "flat_bar": float(flat_bar), "err_over_bar": float(bar_used), "wider_bar": reason, "widened": widened})
+
+
+def widened_evaluations(errv, own_e, flat, tol, floor_e):
+    """The evidence a wider bar needs.  errv: this path's error per evaluation; own_e: the fp32 port's own distance from the
+    anchor per evaluation (the reference's operation order in fp32); flat: the flat bar; tol: the bar applied; floor_e: what
+    the conditioning argument says NO fp32 evaluation can hold there (kappa 2^-23 for a band that holds 1 / kappa of its
+    frames' norm; the anchor's own movement under 2^-23 bin errors for log / dB; None where only the port speaks).
+    A bar wider than the flat one is legitimate only where fp32 itself cannot hold the flat bar: the port is already half way
+    there (own_e > flat / 2) or the conditioning floor is beyond it (floor_e > flat).  Anywhere else an error above the flat
+    bar is a miss of THIS path's arithmetic, whatever the wider bar says: returned as `unexplained` (callers fail on it)."""
+    errv = np.asarray(errv, np.float64)
+    over = np.nonzero(errv > flat)[0]
+    if over.size == 0:
+        return None
+    own_e = np.broadcast_to(np.asarray(own_e, np.float64), errv.shape)
+    tol = np.broadcast_to(np.asarray(tol, np.float64), errv.shape)
+    floor = np.broadcast_to(np.asarray(floor_e if floor_e is not None else 0.0, np.float64), errv.shape)
+    explained = (own_e[over] > 0.5 * flat) | (floor[over] > flat)
+    w = over[np.argmax(errv[over] / flat)]
+    rec = {"evaluations_over_flat_bar": int(over.size), "unexplained": int((~explained).sum()),
+           "worst": {"evaluation": int(w), "err": float(errv[w]), "own": float(own_e[w]), "fp32_floor": float(floor[w]),
+                     "flat_bar": float(flat), "bar_used": float(tol[w])}}
+    if (~explained).any():
+        u = over[~explained][np.argmax(errv[over][~explained])]
+        rec["worst_unexplained"] = {"evaluation": int(u), "err": float(errv[u]), "own": float(own_e[u]), "fp32_floor": float(floor[u]),
+                                    "flat_bar": float(flat), "bar_used": float(tol[u])}
+    return rec
 
 
 def sweep_summary():
     out = {}
     for r in SWEEP_LOG:
         d = out.setdefault(r["sweep"], {"records": 0, "needed_wider_bar": {}, "worst_err": 0.0, "worst_err_over_own": 0.0,
-                                         "worst_err_over_bar": 0.0, "worst_err_over_flat_bar": 0.0, "kernels": {}})
+                                         "worst_err_over_bar": 0.0, "worst_err_over_flat_bar": 0.0, "kernels": {},
+                                         "widened_records": []})
         d["records"] += 1
         d["kernels"][r["kernel"]] = d["kernels"].get(r["kernel"], 0) + 1
         d["worst_err"] = max(d["worst_err"], r["err"])
@@ -206,4 +235,8 @@ def sweep_summary():
         if r["err"] > r["flat_bar"]:
             k = r["wider_bar"] or "none (failed)"
             d["needed_wider_bar"][k] = d["needed_wider_bar"].get(k, 0) + 1
+        if r["wider_bar"] != "" or r.get("widened"):
+            # every record that was held to a bar wider than the flat one, in full: seed, kernel, the errors, the bars, and
+            # whether fp32 itself fails the flat bar there (widened_evaluations)
+            d["widened_records"].append({k: r[k] for k in ("seed", "kernel", "err", "own", "flat_bar", "err_over_bar", "wider_bar", "widened")})
     return out
