@@ -88,6 +88,12 @@ def lib(native: bool = False):
             _lib_native = _load(build_native())
         return _lib_native
     if _lib is None:
+        # SYLDET_ORACLE_LIB: another build of the SAME source (the AddressSanitizer build of tests/sanitize, run under
+        # LD_PRELOAD=libasan by tests/test_sanitizers.py)
+        alt = os.environ.get("SYLDET_ORACLE_LIB")
+        if alt:
+            _lib = _load(alt)
+            return _lib
         if not os.path.exists(LIB_PATH):
             build()
         _lib = _load(LIB_PATH)

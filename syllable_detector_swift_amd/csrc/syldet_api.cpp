@@ -22,6 +22,7 @@
 
 #include "fused_plan.hpp"
 #include "kernels.hpp"
+#include "sample_ring.hpp"
 #include "syldet_internal.hpp"
 
 using namespace sd;
@@ -86,30 +87,6 @@ struct PinnedBuffer {
     }
 };
 
-// Per-channel streaming state: the reference's two rings restated as one single-producer /
-// single-consumer sample ring ("samples from the first frame of the next evaluation onward") + a queue of
-// evaluations already computed on the device.  The producer side (append) touches only the ring's tail and
-// reads head / frames_done -- no lock, no allocation: it can sit on an audio I/O thread like
-// TPCircularBufferProduceBytes does (TPCircularBuffer.h:14,177-185).
-struct ChannelStream {
-    std::vector<float> ring;                 // power-of-two capacity `mask + 1`; allocated by the first append (batch-only banks never pay for it)
-    uint64_t mask = 0;
-    std::atomic<uint64_t> tail{0};           // producer: total samples ever appended
-    std::atomic<uint64_t> head{0};           // consumer: first sample of the next evaluation
-    std::atomic<int64_t> frames_done{0};     // STFT frames the reference would have extracted so far
-    // consumer side only
-    std::deque<std::vector<float>> ready;    // evaluated outputs not yet handed out
-    std::vector<float> last;                 // lastOutputs
-    std::mutex mu;                           // ready / last (consumer vs. readers of last*; never taken by append)
-
-    void copy_out(uint64_t from, float *dst, size_t n) const
-    {
-        const size_t at = (size_t)(from & mask), first = std::min(n, ring.size() - at);   // n > 0 only after an append: the ring exists
-        std::memcpy(dst, ring.data() + at, first * sizeof(float));
-        if (n > first) std::memcpy(dst + first, ring.data(), (n - first) * sizeof(float));
-    }
-};
-
 }  // namespace
 
 struct syldet {
@@ -118,6 +95,7 @@ struct syldet {
     int channels = 0;
     int device = 0;
     int engine = SYLDET_ENGINE_GENERIC;
+    int engine_asked = SYLDET_ENGINE_AUTO;      // what syldet_create was asked for (AUTO commits to the fused engine only for what it can hold to 1e-5)
 
     // Diagnostic switches (A/B runs, and the tests that hold two forms of a kernel against each other): read from the
     // environment ONCE, when the handle is created -- never on the launch path, and a handle keeps the form it was created for.
@@ -224,7 +202,6 @@ struct syldet {
 
 namespace {
 
-const int64_t kSampleRingBytes = 409600;   // CircularShortTimeFourierTransform.init(buffer:) default :61
 
 int build_tables(syldet *h)
 {
@@ -362,6 +339,16 @@ int upload_wide(syldet *h, std::string &why)
             fo[(size_t)i] = (fo[(size_t)i] - (double)f.x_offsets[i]) * (double)f.gains[i] + (double)f.y;
             fa[(size_t)i] *= (double)f.gains[i];
         }
+    }
+    // The fold quantises v r (not u = a v r + o) to bf16: an error of 2^-9 |a_i v_i r| in u_i.  For maps trained on a range
+    // around zero (the example net: offsets of 1e-5, gains of 4) that is the better deal; for a range away from zero
+    // (x in [0.05, 0.06]: |a x| = 11 against |u| <= 1) the same relative error is |o_i| times larger in u than bf16(u) would
+    // leave, and the 1e-2 bar goes.  |o_i| = |u_i - a_i v_i r| bounds |a_i v_i r| wherever u is O(1): such chains keep the
+    // preparation kernel, which rounds u itself.
+    if (front) {
+        double worst = 0.0;
+        for (int i = 0; i < I; i++) worst = std::max(worst, std::fabs(fo[(size_t)i]));
+        if (!(worst <= 4.0)) front = false;
     }
     for (int ch = 0; ch < n_chunks; ch++) {
         uint16_t *frag = pack.data() + (size_t)ch * chunk_u16;
@@ -641,8 +628,10 @@ int run_on_stream(syldet *h, const float *d_samples, int64_t S, int64_t stride, 
     SYLDET_HIP(hipSetDevice(h->device));
     h->prof_begin();
     // the fused kernel addresses a channel's results with 32-bit byte offsets; longer rows take the generic engine
-    if (h->engine == SYLDET_ENGINE_FUSED && (uint64_t)E * (uint64_t)h->geom.outputs * 4u < 0xFFFFFFF0ull) {
-        FusedDesc d = h->fused.desc;
+    bool fused_route = h->engine == SYLDET_ENGINE_FUSED && (uint64_t)E * (uint64_t)h->geom.outputs * 4u < 0xFFFFFFF0ull;
+    FusedDesc d{};
+    if (fused_route) {
+        d = h->fused.desc;
         fused_segmentation(d, E, C);
         d.stamps = nullptr;
         d.fix = FixList{nullptr, nullptr, 0};
@@ -650,6 +639,17 @@ int run_on_stream(syldet *h, const float *d_samples, int64_t S, int64_t stride, 
         d.ko = h->sw.fused_ko;
         d.force_classic = h->sw.fused_classic ? 1 : 0;
         d.no_fold = h->sw.fused_nofold ? 1 : 0;
+        // Which fused kernel THIS batch gets is known only now (the fold kernel addresses a row with 32-bit byte offsets; a
+        // diagnostic switch may rule it out).  The batch takes the fused route only if that kernel can run it (plans whose hop
+        // only the fold kernel holds have no 8-wave form: classic_ok == 0) and, for log / dB columns under AUTO, only on the fold
+        // kernel -- the one AUTO committed to for them at create time: the pass-scaled kernels do not hold 1e-5 there.  Anything
+        // else goes to the generic engine below, like the long rows.
+        const int choice = fused_choice(d, J);
+        const bool runnable = choice != 0 || d.classic_ok;
+        const bool in_contract = h->cfg.view.scaling == SYLDET_SCALING_LINEAR || choice == 2 || h->engine_asked == SYLDET_ENGINE_FUSED;
+        if (!runnable || !in_contract) fused_route = false;
+    }
+    if (fused_route) {
         // diagnostic only: SYLDET_FUSED_STAMPS=1 runs the stamped instantiation and prints where a
         // workgroup pass spends its cycles (never set in tests or the benchmark)
         if (h->sw.fused_stamps) {
@@ -782,6 +782,7 @@ int syldet_create(const syldet_config_t *cfg, int32_t n_channels, int32_t device
     SYLDET_HIP(hipSetDevice(device));
     h->device = device;
     h->channels = n_channels;
+    h->engine_asked = engine;
     h->engine = SYLDET_ENGINE_GENERIC;
     if (engine != SYLDET_ENGINE_GENERIC && engine != SYLDET_ENGINE_WIDE_BF16) {
         // The fused engine hands columns to the first layer as f16 hi + lo pairs.  For linear |X| columns that is below
@@ -1220,46 +1221,14 @@ int syldet_detections(syldet_t *h, const uint8_t *flags, int64_t n_evals, double
 // the consumer asks for a value and none is queued, every evaluation those samples allow
 // is computed in one device pass and queued.  Results are the batch engine's.
 
-// TPCircularBufferProduceBytes fails when fewer than n*4 bytes are free (TPCircularBuffer.h:177-185);
-// the bytes in the reference's ring are the samples no extracted frame has consumed yet.
-static bool stream_has_room(const syldet *h, const ChannelStream &cs, int64_t n)
-{
-    const uint64_t tail = cs.tail.load(std::memory_order_relaxed);
-    const int64_t unconsumed = (int64_t)tail - cs.frames_done.load(std::memory_order_acquire) * h->geom.hop;
-    if ((unconsumed + n) * 4 > kSampleRingBytes) return false;
-    // (cannot overrun the un-evaluated samples: the ring is sized for the bound above plus the evaluation carry)
-    return (int64_t)(tail - cs.head.load(std::memory_order_acquire)) + n <= (int64_t)(cs.mask + 1);
-}
-
-// The ring comes into being with a channel's first samples (the only allocation the producer side ever makes);
-// the consumer never looks at it before `tail` says there is something in it.
-static int stream_ensure_ring(ChannelStream &cs)
-{
-    if (!cs.ring.empty()) return SYLDET_OK;
-    try {
-        cs.ring.assign((size_t)(cs.mask + 1), 0.0f);
-    } catch (const std::bad_alloc &) {
-        return fail(SYLDET_ERR_OUT_OF_MEMORY, "out of memory");
-    }
-    return SYLDET_OK;
-}
-
-static void stream_write(ChannelStream &cs, const float *data, int64_t n, int64_t step)
-{
-    const uint64_t tail = cs.tail.load(std::memory_order_relaxed);
-    float *ring = cs.ring.data();
-    for (int64_t i = 0; i < n; i++) ring[(size_t)((tail + (uint64_t)i) & cs.mask)] = data[i * step];
-    cs.tail.store(tail + (uint64_t)n, std::memory_order_release);
-}
-
 int syldet_append(syldet_t *h, int32_t channel, const float *data, int64_t n_samples)
 {
     if (!h || channel < 0 || channel >= h->channels || n_samples < 0 || (n_samples > 0 && !data))
         return fail(SYLDET_ERR_INVALID_ARGUMENT, "bad argument");
     ChannelStream &cs = *h->streams[(size_t)channel];
-    if (!stream_has_room(h, cs, n_samples)) return fail(SYLDET_ERR_BUFFER_FULL, "Insufficient space on buffer.");
-    if (int st = stream_ensure_ring(cs)) return st;
-    stream_write(cs, data, n_samples, 1);
+    if (!cs.has_room(n_samples, h->geom.hop)) return fail(SYLDET_ERR_BUFFER_FULL, "Insufficient space on buffer.");
+    if (!cs.ensure_ring()) return fail(SYLDET_ERR_OUT_OF_MEMORY, "out of memory");
+    cs.write(data, n_samples, 1);
     return SYLDET_OK;
 }
 
@@ -1270,10 +1239,10 @@ int syldet_append_interleaved(syldet_t *h, const float *data, int64_t n_frames, 
     // all channels or none: a caller that retries after "buffer full" must not double a block on some of them
     // (room only grows between the check and the writes: the consumer is the only other party)
     for (int c = 0; c < h->channels; c++)
-        if (!stream_has_room(h, *h->streams[(size_t)c], n_frames)) return fail(SYLDET_ERR_BUFFER_FULL, "Insufficient space on buffer.");
+        if (!h->streams[(size_t)c]->has_room(n_frames, h->geom.hop)) return fail(SYLDET_ERR_BUFFER_FULL, "Insufficient space on buffer.");
     for (int c = 0; c < h->channels; c++)
-        if (int st = stream_ensure_ring(*h->streams[(size_t)c])) return st;
-    for (int c = 0; c < h->channels; c++) stream_write(*h->streams[(size_t)c], data + c, n_frames, total_channels);
+        if (!h->streams[(size_t)c]->ensure_ring()) return fail(SYLDET_ERR_OUT_OF_MEMORY, "out of memory");
+    for (int c = 0; c < h->channels; c++) h->streams[(size_t)c]->write(data + c, n_frames, total_channels);
     return SYLDET_OK;
 }
 

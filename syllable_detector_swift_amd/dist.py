@@ -233,16 +233,31 @@ class ShardedSyllableDetector:
         """local_samples: this rank's [count, S] block -- when time-sharded, its [1, s1 - s0] slice of a recording of
         `n_samples` (sample_range()).  Returns (outputs_local, flags) where flags is the gathered [total_channels, E]
         tensor when `gather`, else the local one."""
-        outputs, flags = self.detector.run(local_samples)
         if self.time_sharded:
             if n_samples is None:
                 raise ValueError("a time-sharded run needs the recording's length (n_samples)")
+            # A rank whose slice is not its sample_range() would otherwise raise alone while its peers wait in the gather for
+            # ever: the check comes BEFORE anything is launched, and its verdict is agreed on by every rank (one tiny
+            # all-reduce), so that either all ranks raise or none does.
+            s0, s1 = self.sample_range(n_samples)
+            ok = int(local_samples.shape[1]) == s1 - s0
+            if gather and self.world > 1:
+                import torch
+                import torch.distributed as dist
+                t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=local_samples.device)
+                dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+                all_ok = bool(int(t.item()))
+            else:
+                all_ok = ok
+            if not all_ok:
+                raise ValueError("local samples are not this rank's sample_range() of the recording" if not ok else
+                                 "another rank's samples are not its sample_range() of the recording")
+            outputs, flags = self.detector.run(local_samples)
             E = self.detector.countEvaluations(n_samples)
-            if int(flags.shape[1]) != shard_evaluations(E, self.parts, self.part)[1]:
-                raise ValueError("local samples are not this rank's sample_range() of the recording")
             if gather and self.world > 1:
                 flags = gather_time_shards(flags, self.total_channels, E, self.group)
             return outputs, flags
+        outputs, flags = self.detector.run(local_samples)
         if gather and self.world > 1:
             flags = gather_flags(flags, self.total_channels, self.group)
         return outputs, flags

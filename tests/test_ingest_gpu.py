@@ -125,7 +125,7 @@ WIDE_TOL = 1e-2      # bf16 inputs and first-layer weights (8-bit significands),
 
 
 @pytest.mark.parametrize("shape", ["config5", "H96_3out_logsig", "H40_normalize", "H72_2out_satlin", "config5_shape32", "config5_prepared",
-                                   "H64_affine_only", "H48_two_maps"])
+                                   "H64_affine_only", "H48_two_maps", "H64_narrow_range_maps"])
 def test_wide_network_bf16_mfma_engine(oracle_lib, shape, monkeypatch):
     """The opt-in wide engine (first layer as a bf16 MFMA GEMM over thousands of evaluations) against the fp64 anchor,
     to bf16's bar; flags wherever the anchor is farther than that from the threshold.  The four instantiations of the
@@ -149,6 +149,14 @@ def test_wide_network_bf16_mfma_engine(oracle_lib, shape, monkeypatch):
         cfg = nets.variant(base, net=nets.random_net(rng, 290, (64,), 1, in_fns=("mapstd",)))
     elif shape == "H48_two_maps":
         cfg = nets.variant(base, net=nets.random_net(rng, 290, (48,), 1, in_fns=("l2normalize", "mapminmax", "mapstd")))
+    elif shape == "H64_narrow_range_maps":
+        # a mapminmax trained on inputs that sit in a narrow range away from zero: |gain x| >> |u|.  Folding such a map into the
+        # first layer would quantise gain x (not u) to bf16; the engine must take the preparation route here
+        net = nets.random_net(rng, 290, (64,), 1, in_fns=("l2normalize", "mapminmax"))
+        f = net.inputProcessing[1]
+        f.xOffsets = np.full(290, 0.05, np.float32)
+        f.gains = np.full(290, 100.0, np.float32)
+        cfg = nets.variant(base, net=net)
     elif shape == "H72_2out_satlin":
         cfg = nets.variant(base, net=nets.random_net(rng, 290, (72,), 2, transfer=("SatLin", "TanSig")), thresholds=[0.1, 0.2])
     else:
@@ -168,7 +176,7 @@ def test_wide_network_bf16_mfma_engine(oracle_lib, shape, monkeypatch):
         # [l2normalize,] affine maps on linear columns: the GEMM reads the columns itself; other chains (and the old shape,
         # and the switch) go through a preparation kernel
         prepared = [k for k in names if k.startswith("wide_prep")]
-        direct = shape != "H40_normalize" and "SYLDET_WIDE_SHAPE32" not in os.environ and "SYLDET_WIDE_NO_FRONT" not in os.environ
+        direct = shape not in ("H40_normalize", "H64_narrow_range_maps") and "SYLDET_WIDE_SHAPE32" not in os.environ and "SYLDET_WIDE_NO_FRONT" not in os.environ
         assert (prepared == []) == direct
     worst = 0.0
     for c in range(C):
