@@ -297,6 +297,65 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
         }
     }
 
+    // ---- the fold kernel's second fold (kernels_fused_s.hip, F2): for W == N the once-folded positions pair up again,
+    // m with N/2 - m:  cos(theta_k (N/2 - m)) = (-1)^k cos(theta_k m),  sin(theta_k (N/2 - m)) = -(-1)^k sin(theta_k m)  (theta_k = 2 pi k / N).
+    // With a[m] = w[c+m] (x[c+m] + x[c-m]), b[m] = w[c+m] (x[c+m] - x[c-m]) (the window now applied by the lanes, in fp32):
+    //     Re' X[k] = sum_{m=1}^{N/4-1} cos(theta_k m) (a[m] + (-1)^k a[N/2-m])  +  [w[c] x[c] + (-1)^k w[0] x[0]]  +  a[N/4] cos(pi k / 2)
+    //     Im' X[k] = -sum_{m=1}^{N/4-1} sin(theta_k m) (b[m] - (-1)^k b[N/2-m])  -  b[N/4] sin(pi k / 2)
+    // Even and odd bins become GEMMs of their own with K = N/4 = 64 and ONE row tile each (a band of at most 32 bins has at most
+    // 16 of either parity): 4 GEMMs x 2 k-steps x 3 products = 24 matrix instructions per 16 frames instead of 48, a basis of
+    // 64 registers.  Slot 0 of the real rows (cos 0 = 1) takes the centre sample and the frame's first sample; slot 0 of the odd
+    // imaginary rows (sin 0 = 0: free) takes b[N/4] against -sin(pi k / 2); a[N/4] meets the even real rows on the vector side.
+    d.s2_ok = 0;
+    if (d.s_ok && W == 256 && N == 256 && H <= 4 && !d.s_padp) {
+        d.s2_ok = 1;
+        const int ke0 = g.f0 + (g.f0 & 1), ko0 = g.f0 + 1 - (g.f0 & 1);          // first even / odd bin of the band
+        d.s2_pe = ke0 - g.f0;
+        d.s2_po = ko0 - g.f0;
+        p.sfrag2.assign((size_t)2 * 4 * 2 * 64 * 8, 0);
+        for (int ks = 0; ks < 2; ks++)
+            for (int gm = 0; gm < 4; gm++)
+                for (int l = 0; l < 64; l++)
+                    for (int j = 0; j < 8; j++) {
+                        const int r = l & 15, m = 32 * ks + 8 * (l >> 4) + j;
+                        const int k = ((gm & 1) ? ko0 : ke0) + 2 * r;
+                        double v = 0.0;
+                        if (k < g.f1) {
+                            const double ang = two_pi * (double)(((int64_t)k * m) % N) / (double)N;
+                            if (gm < 2) v = std::cos(ang);                                     // (m = 0: 1, against the two lone samples)
+                            else if (m > 0) v = -std::sin(ang);
+                            else v = gm == 3 ? -std::sin(two_pi * (double)(((int64_t)k * (N / 4)) % N) / (double)N) : 0.0;   // b[N/4]'s slot
+                            if (gm >= 2 && k == 0) v = 0.0;                                    // DC is real (:323)
+                            v *= 8192.0;
+                        }
+                        uint16_t hi, lo;
+                        split_half(v, hi, lo);
+                        const size_t base = ((((size_t)ks * 4 + gm) * 2) * 64 + l) * 8 + j;
+                        p.sfrag2[base] = hi;
+                        p.sfrag2[base + 64 * 8] = lo;
+                    }
+        // window coefficients of the positions lane group gq folds: w[c + m] and w[N/2 - (c - ...)] = w[m], the two sides of the
+        // symmetric table averaged as above
+        p.swin2.assign((size_t)4 * 16 * 2, 0.0f);
+        for (int gq = 0; gq < 4; gq++)
+            for (int ks = 0; ks < 2; ks++)
+                for (int i = 0; i < 8; i++) {
+                    const int m = 32 * ks + 8 * gq + i;
+                    const double w1 = m == 0 ? (double)win[128] : 0.5 * ((double)win[(size_t)(128 + m)] + (double)win[(size_t)(128 - m)]);
+                    const double w2 = m == 0 ? (double)win[0] : 0.5 * ((double)win[(size_t)m] + (double)win[(size_t)(256 - m)]);
+                    p.swin2[((size_t)gq * 16 + ks * 8 + i) * 2 + 0] = (float)w1;
+                    p.swin2[((size_t)gq * 16 + ks * 8 + i) * 2 + 1] = (float)w2;
+                }
+        p.s2c.assign((size_t)64 * 8, 0.0f);
+        for (int l = 0; l < 64; l++) {
+            for (int i = 0; i < 4; i++) {
+                const int k = ke0 + 2 * (4 * (l >> 4) + i);
+                if (k < g.f1) p.s2c[(size_t)l * 8 + i] = (float)(std::cos(two_pi * (double)(((int64_t)k * (N / 4)) % N) / (double)N) * 8192.0);
+            }
+            p.s2c[(size_t)l * 8 + 4] = (float)(0.5 * ((double)win[192] + (double)win[64]));
+        }
+    }
+
     // |X[k]| <= (sum_n |D[k][n]|) * max|x|: with samples scaled below 2^14 the column shift keeps |X| * 2^(cse-shift) < 2^13
     {
         double rowsum_max = 1.0;
@@ -348,6 +407,21 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
                     split_half(v, hi, lo);
                     p.afrag_t[(((size_t)m * 2 + 0) * 64 + l) * 8 + j] = hi;
                     p.afrag_t[(((size_t)m * 2 + 1) * 64 + l) * 8 + j] = lo;
+                }
+    // ... in the bin order of the twice-folded result: k = 8 g + j -> band bin 8 g + pe + 2 j (j < 4), 8 g + po + 2 (j - 4) (j >= 4)
+    p.afrag_t2.assign((size_t)3 * 2 * 64 * 8, 0);
+    if (H <= 4 && d.s2_ok)
+        for (int m = 0; m < 3; m++)
+            for (int l = 0; l < 64; l++)
+                for (int j = 0; j < 8; j++) {
+                    const int r = 16 * m + (l & 15), t = r / 4, h = r % 4, gq = l >> 4;
+                    const int bin = j < 4 ? 8 * gq + d.s2_pe + 2 * j : 8 * gq + d.s2_po + 2 * (j - 4);
+                    double v = 0.0;
+                    if (t < T && h < H && bin < F) v = (double)L0.weights[(size_t)h * I + t * F + bin] * a[(size_t)(t * F + bin)] * wscale;
+                    uint16_t hi, lo;
+                    split_half(v, hi, lo);
+                    p.afrag_t2[(((size_t)m * 2 + 0) * 64 + l) * 8 + j] = hi;
+                    p.afrag_t2[(((size_t)m * 2 + 1) * 64 + l) * 8 + j] = lo;
                 }
     // ... and for 5 .. 16 hidden units (kernels_fused_s.hip, HQ = ceil(H / 4) quads): row tile (m, q), row 4 g + i of it = tap
     // 4 m + g, unit 4 q + i -- lane group g of a result then holds tap 4 m + g for every quad, as with one quad
@@ -419,6 +493,33 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
         }
         if (!(lip > 1e-30)) lip = 1e-30;
         if (!(lip < 1e30)) lip = 1e30;
+        // The same chain as a root-sum-square (errors of different inputs and units carry random signs): what the arithmetic's
+        // OWN relative error does to an output.  hi/lo-split operands and three products leave about 2^-21.4 (3.6e-7) of a frame's
+        // column level in every bin (measured against the fp64 anchor: DESIGN 7).  Behind a normaliser that is 3.6e-7 of a
+        // unit-norm vector whatever the recording's level; WITHOUT one the network sees the columns at the recording's level and
+        // the same relative error grows with it -- a window of norm U moves output o by about 3.6e-7 U / sqrt(I) g_o,
+        // g_o^2 = sum_h (w1[o][h] ||W'_h||_2)^2.  An fp32 FFT is eight times closer there, so once that expectation passes a
+        // quarter of the 1e-5 bar the evaluation is recomputed exactly (fixup_kernel) rather than reported at a level-dependent bar.
+        double grss = 0.0;
+        for (int o = 0; o < n_out; o++) {
+            double g2 = 0.0;
+            if (c.n_layers == 2) {
+                for (int h = 0; h < H; h++) {
+                    const double t = (double)c.layers[1].weights[(size_t)o * H + h] * rown[(size_t)h];
+                    g2 += t * t;
+                }
+                g2 *= slope(c.layers[1].transfer) * slope(c.layers[1].transfer);
+            } else {
+                g2 = rown[(size_t)o] * rown[(size_t)o];
+            }
+            double go = std::sqrt(g2);
+            for (int k = 0; k < c.n_output_fns; k++) go /= std::max(1e-30, std::fabs((double)c.output_fns[k].gains[o]));
+            grss = std::max(grss, go);
+        }
+        {
+            const double k = 3.6e-7 * grss / (std::sqrt((double)I) * 2.5e-6);
+            d.guard_loud = (float)std::min(std::max(k * k, 1e-30), 1e30);
+        }
         // Grid floors, in units of a stored column value.  The 8-wave kernel splits every column into f16 hi + lo at the
         // pass's scale: half an f16 subnormal step (2^-25) per bin plus the sample grid's share.  The register-resident-basis
         // kernel gives every frame its own column exponent, which leaves the sample grid: 2^-25 per sample of a pass scaled to

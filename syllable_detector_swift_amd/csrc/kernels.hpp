@@ -154,6 +154,15 @@ struct FusedDesc {
     // shape does not fit it
     int s_ok, s_waves, s_perm, s_ring_chunks, s_pstride, s_tp, s_lds_wave, s_seg_evals;
     int s_padp;                 // 0, or the padding period (floats) of the fold kernel's sample ring: hops that are multiples of 64 (fused_plan.cpp)
+    // ... and its second-fold instantiation (W == N == 256, one quad of units, plain ring): s2_ok; s2_pe / s2_po = band index of
+    // the first even / odd bin (0 and 1 in some order): lane group g of a result holds band bins 8 g + s2_pe + 2 i (even tile
+    // rows 4 g + i) and 8 g + s2_po + 2 i (odd tile)
+    int s2_ok, s2_pe, s2_po;
+    int no_fold2;               // the handle was created under SYLDET_FUSED_NOFOLD2=1: the once-folded form where both take the shape (A/B runs)
+    const uint4 *sfrag2;        // [2 k-steps][Re even, Re odd, Im even, Im odd][hi,lo][64 lanes] A-operand fragments of the twice-folded basis
+    const float *swin2;         // [4 lane groups][2 k-steps][8][2] window coefficients w[128 + m], w[m] for m = 32 ks + 8 g + i
+    const float *s2c;           // [64 lanes][8]: cos(pi k / 2) 2^13 for the lane's four even bins, w[192], padding
+    const uint4 *afrag_t2;      // afrag_t in the bin order of the twice-folded result
     const uint4 *sfrag;         // [W/64 k-steps][s, d][bins 0-15, 16-31][hi,lo][64 lanes] A-operand fragments of the folded basis
     const uint4 *afrag_w;       // [3][HQ quads of hidden units][hi,lo][64 lanes] the first layer with all taps as rows for 5 .. 16 units
     const float *slone;         // [64 lanes][8] the frame's first sample's real coefficients for the lane's bins
@@ -180,6 +189,8 @@ struct FusedDesc {
     int guard_se_abs_r, guard_se_abs_c;   // no normaliser: passes scaled below this exponent are loud enough for the floor to matter
     float guard_spect;          // spectrogram instantiation: a frame's column sum of squares (grid units) ...
     int guard_se_abs_s;         //   ... in passes scaled below this exponent
+    float guard_loud;           // no normaliser: (window sum of squares in true units) * guard_loud > 1 means the three-product arithmetic's
+                                //   2^-21.4 of the column level, through the network, is expected beyond a quarter of the 1e-5 bar (symmetric-fold kernel)
     FixList fix;                // work list of evaluations to recompute (null counters: guard off)
     int force_classic;          // the handle was created under SYLDET_FUSED_CLASSIC=1: the 8-wave kernel where both take the shape
     int no_fold;                // the handle was created under SYLDET_FUSED_NOFOLD=1: not the symmetric-fold kernel

@@ -85,7 +85,12 @@ __device__ __forceinline__ void split2(float a, float b, unsigned &hi, unsigned 
 // PADP: 0, or the power of two that divides the hop when the hop is a multiple of 64 floats: the frames of a tile would then
 // all start on the same LDS banks, so the ring is laid out with one quad of padding after every PADP floats -- a frame's
 // start moves on by one bank group per frame, and inside a frame the padding is a compile-time offset per access.
-template <int K2, bool GEN, int HQ, int NW, int PADP = 0>
+// F2: the second fold (W == N == 256: K2 == 4, one quad of units, plain ring).  The once-folded positions pair up again (m with
+// 128 - m), even and odd bins become GEMMs of their own with K = 64 and one row tile each -- 24 matrix instructions per 16 frames
+// instead of 48, a basis of 64 registers -- and the window is applied by the lanes in fp32 (fused_plan.cpp, s2_ok).  A lane then
+// folds exactly 64 + 6 samples of its frame, so it reads them from the ring ONCE: the frame's loudest sample is taken from the
+// registers the fold reads (16 ds_read_b128 a tile instead of 32).
+template <int K2, bool GEN, int HQ, int NW, int PADP = 0, bool F2 = false>
 __global__ void __launch_bounds__(64 * NW, 1)
 fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t stride, int64_t s_eff, int64_t E,
                float *__restrict__ outputs, uint8_t *__restrict__ flags)
@@ -133,16 +138,40 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
 
     // ---- constants in registers: the folded basis (A operands; s: real rows against the sums, d: imaginary rows against
     // the differences), the first layer with all taps as rows, the lone sample's real coefficients
-    half8 as_[K2][2][2], ad_[K2][2][2];               // [k-step][row tile: bins 0-15, 16-31][hi, lo]
+    constexpr int KB = F2 ? 1 : K2;                   // (the twice-folded basis lives in b2 below)
+    half8 as_[KB][2][2], ad_[KB][2][2];               // [k-step][row tile: bins 0-15, 16-31][hi, lo]
+    if (!F2) {
 #pragma unroll
-    for (int ks = 0; ks < K2; ks++)
+        for (int ks = 0; ks < KB; ks++)
 #pragma unroll
-        for (int m = 0; m < 2; m++)
+            for (int m = 0; m < 2; m++)
 #pragma unroll
-            for (int p = 0; p < 2; p++) {
-                as_[ks][m][p] = as_half8(reinterpret_cast<const uint32x4 *>(d.sfrag)[(((ks * 2 + 0) * 2 + m) * 2 + p) * 64 + lane]);
-                ad_[ks][m][p] = as_half8(reinterpret_cast<const uint32x4 *>(d.sfrag)[(((ks * 2 + 1) * 2 + m) * 2 + p) * 64 + lane]);
-            }
+                for (int p = 0; p < 2; p++) {
+                    as_[ks][m][p] = as_half8(reinterpret_cast<const uint32x4 *>(d.sfrag)[(((ks * 2 + 0) * 2 + m) * 2 + p) * 64 + lane]);
+                    ad_[ks][m][p] = as_half8(reinterpret_cast<const uint32x4 *>(d.sfrag)[(((ks * 2 + 1) * 2 + m) * 2 + p) * 64 + lane]);
+                }
+    }
+    // twice folded: [k-step][Re even bins, Re odd, Im even, Im odd][hi, lo]; the window coefficients w[128 + m], w[m] of the
+    // positions m = 32 ks + 8 g + i this lane folds; cos(pi k / 2) 2^13 for its four even bins; w[192]
+    half8 b2[F2 ? 2 : 1][F2 ? 4 : 1][2];
+    float w1c[F2 ? 16 : 1], w2c[F2 ? 16 : 1], ce[4] = {0.f, 0.f, 0.f, 0.f}, w192 = 0.0f;
+    if (F2) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+            for (int gm = 0; gm < 4; gm++)
+#pragma unroll
+                for (int p = 0; p < 2; p++)
+                    b2[ks][gm][p] = as_half8(reinterpret_cast<const uint32x4 *>(d.sfrag2)[((ks * 4 + gm) * 2 + p) * 64 + lane]);
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            w1c[i] = d.swin2[(g * 16 + i) * 2];
+            w2c[i] = d.swin2[(g * 16 + i) * 2 + 1];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) ce[i] = d.s2c[lane * 8 + i];
+        w192 = d.s2c[lane * 8 + 4];
+    }
     // (row tile 3 q + m... in table order [m][q]: tap 4 m + g, units 4 q .. 4 q + 3 for lane group g of its result)
     half8 aft[3][HQ][2];
 #pragma unroll
@@ -151,10 +180,10 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
         for (int q = 0; q < HQ; q++)
 #pragma unroll
             for (int p = 0; p < 2; p++)
-                aft[m][q][p] = as_half8(reinterpret_cast<const uint32x4 *>(HQ == 1 ? d.afrag_t : d.afrag_w)[((m * HQ + q) * 2 + p) * 64 + lane]);
+                aft[m][q][p] = as_half8(reinterpret_cast<const uint32x4 *>(F2 ? d.afrag_t2 : (HQ == 1 ? d.afrag_t : d.afrag_w))[((m * HQ + q) * 2 + p) * 64 + lane]);
     float cre[8];                                     // w[0] cos(pi k W / N) 2^13 for this lane's bins 4 g + i, 16 + 4 g + i
 #pragma unroll
-    for (int i = 0; i < 8; i++) cre[i] = d.slone[lane * 8 + i];
+    for (int i = 0; i < 8; i++) cre[i] = F2 ? 0.0f : d.slone[lane * 8 + i];
     if (kTbl && n == 0) {
 #pragma unroll
         for (int i = 0; i < 8; i++) gtab[i] = cre[i];
@@ -250,7 +279,8 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
     const float klog = scaling == 1 ? 0.6931471805599453f : 6.020599913279624f;      // ln 2, 20 log10 2
     bool binv[8];                                     // which of this lane's 8 bins are band bins (rows past F are zeros: log 0)
 #pragma unroll
-    for (int i = 0; i < 8; i++) binv[i] = (i < 4 ? 4 * g + i : 16 + 4 * g + (i - 4)) < d.F;
+    for (int i = 0; i < 8; i++)
+        binv[i] = (F2 ? (i < 4 ? 8 * g + d.s2_pe + 2 * i : 8 * g + d.s2_po + 2 * (i - 4)) : (i < 4 ? 4 * g + i : 16 + 4 * g + (i - 4))) < d.F;
     const float kmag = pow2f(-13 - d.col_shift);
     const bool guard_on = d.fix.counters != nullptr;
     const float guard_k = norm == 1 ? d.guard_r : (norm == 0 ? d.guard_rel_r : d.guard_range_r);
@@ -265,6 +295,29 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
         else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         const float *fp = ring + fo + sk((int)fo);    // this lane's frame: W samples from here (the mirror makes them contiguous)
 
+        // ---- twice folded: this lane's 64 + 6 samples of its frame, read once.  For m0 = 32 ks + 8 g:
+        //   P1 = x[m0 .. m0+7], P3 = x[128+m0 .. +7] (two quads each), x[128-m0-i] and x[256-m0-i], i = 0..7: two quads
+        //   [120-m0, 128-m0), [248-m0, 256-m0) and the words x[128-m0], x[256-m0]; x[64] and x[192] for the self-paired position
+        floatx4 P1[2][2], P3[2][2], P2[2][2], P4[2][2];
+        float P2w[2], P4w[2], x64 = 0.0f, x192 = 0.0f;
+        if (F2) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+                const float *a = fp + 32 * ks + 8 * g, *b = fp + 120 - 32 * ks - 8 * g;
+                P1[ks][0] = *reinterpret_cast<const floatx4 *>(a);
+                P1[ks][1] = *reinterpret_cast<const floatx4 *>(a + 4);
+                P3[ks][0] = *reinterpret_cast<const floatx4 *>(a + 128);
+                P3[ks][1] = *reinterpret_cast<const floatx4 *>(a + 132);
+                P2[ks][0] = *reinterpret_cast<const floatx4 *>(b);
+                P2[ks][1] = *reinterpret_cast<const floatx4 *>(b + 4);
+                P2w[ks] = b[8];
+                P4[ks][0] = *reinterpret_cast<const floatx4 *>(b + 128);
+                P4[ks][1] = *reinterpret_cast<const floatx4 *>(b + 132);
+                P4w[ks] = b[136];                        // (g == 0, ks == 0: x[256], the next frame's -- read, never used)
+            }
+            x64 = fp[64];
+            x192 = fp[192];
+        }
         // ---- the frame's own scale from its loudest sample (this lane looks at a quarter of the frame)
         float amax;
 #ifdef SYLDET_S_NOMAX                // (diagnostic knock-outs, tools/s_knockouts.sh: wrong results by construction, never the shipped library)
@@ -272,12 +325,32 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
 #else
         {
             float m0 = 0.0f, m1 = 0.0f;
-            const floatx4 *q0 = reinterpret_cast<const floatx4 *>(fp + (W / 4) * g + sk((W / 4) * g));   // (a quarter never crosses a padding)
+            if (F2) {
+                // (every word read above lies inside the frame except x[256]: the four lanes' sets cover the frame)
 #pragma unroll
-            for (int q = 0; q < W / 16; q++) {
-                const floatx4 v = q0[q];
-                m0 = absmax3(m0, v[0], v[1]);
-                m1 = absmax3(m1, v[2], v[3]);
+                for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        m0 = absmax3(m0, P1[ks][h][0], P1[ks][h][1]);
+                        m1 = absmax3(m1, P1[ks][h][2], P1[ks][h][3]);
+                        m0 = absmax3(m0, P3[ks][h][0], P3[ks][h][1]);
+                        m1 = absmax3(m1, P3[ks][h][2], P3[ks][h][3]);
+                        m0 = absmax3(m0, P2[ks][h][0], P2[ks][h][1]);
+                        m1 = absmax3(m1, P2[ks][h][2], P2[ks][h][3]);
+                        m0 = absmax3(m0, P4[ks][h][0], P4[ks][h][1]);
+                        m1 = absmax3(m1, P4[ks][h][2], P4[ks][h][3]);
+                    }
+                m0 = absmax3(m0, P2w[0], P2w[1]);
+                m1 = absmax3(m1, g == 0 ? 0.0f : P4w[0], P4w[1]);
+                m0 = absmax3(m0, x64, x192);
+            } else {
+                const floatx4 *q0 = reinterpret_cast<const floatx4 *>(fp + (W / 4) * g + sk((W / 4) * g));   // (a quarter never crosses a padding)
+#pragma unroll
+                for (int q = 0; q < W / 16; q++) {
+                    const floatx4 v = q0[q];
+                    m0 = absmax3(m0, v[0], v[1]);
+                    m1 = absmax3(m1, v[2], v[3]);
+                }
             }
             amax = fmaxf(m0, m1);                      // (v_max3 drops NaNs: plain non-negative numbers from here on)
             auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(amax), __float_as_uint(amax), false, false);
@@ -289,14 +362,16 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
         // status of the frame for the precision guard: 0 fine, 1 silent (its column is exact zeros), 2 the grid cannot hold it
         // (an infinite sample, or a level above 2^113)
         const int ex = (int)((__float_as_uint(amax) >> 23) & 0xffu);
-        int se = 140 - ex;                            // 2^se puts the loudest sample into [2^13, 2^14)
+        // 2^se puts the loudest sample into [2^13, 2^14); twice folded into [2^12, 2^13): a folded position is the sum of four
+        // samples there, under window coefficients that add up to 2 at most (rectangular)
+        int se = (F2 ? 139 : 140) - ex;
         const int fst = amax > 0.0f ? ((ex == 255 || se < -100) ? 2 : 0) : 1;
         se = amax > 0.0f ? (se < -100 ? -100 : (se > 113 ? 113 : se)) : 0;
         const float sx = pow2f(se);
         if (t == 0) {                                 // the segment's reference exponent: the loudest frame of its first tile
             const float tm = wave_max_nonneg(amax);
             const int exr = (int)((__float_as_uint(tm) >> 23) & 0xffu);
-            int r0 = 140 - exr;
+            int r0 = (F2 ? 139 : 140) - exr;
             r0 = tm > 0.0f ? (r0 < -100 ? -100 : (r0 > 113 ? 113 : r0)) : 0;
             se_ref = __builtin_amdgcn_readfirstlane(r0);
         }
@@ -307,11 +382,65 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
         // ---- the folded DFT: per k-step this lane folds, scales and splits 8 positions of its frame, then 12 MFMAs
         const float xl = fp[0] * sx;                  // the frame's first sample (no partner)
         floatx4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // re 0-15, re 16-31, im 0-15, im 16-31
+        float a64 = 0.0f;                             // twice folded: re even, re odd, im even, im odd; the self-paired position's sum
         const float *xpb = fp + W / 2 + 8 * g, *xmb = fp + W / 2 - 8 * g;
         const float *xmz = xmb + ((PADP && g == 0) ? 4 : 0);     // (the word c - m0 of lane group 0 sits on a piece's first position)
 #ifndef SYLDET_S_NODFT
+        if (F2) {
+            a64 = w192 * fmaf(x192, sx, x64 * sx);
+            const float b64 = w192 * fmaf(x192, sx, -(x64 * sx));
 #pragma unroll
-        for (int ks = 0; ks < K2; ks++) {
+            for (int ks = 0; ks < 2; ks++) {
+                // position m = 32 ks + 8 g + i:  xa = x[128 + m], xb = x[128 - m], xc = x[256 - m], xd = x[m]
+                const float xa[8] = {P3[ks][0][0], P3[ks][0][1], P3[ks][0][2], P3[ks][0][3], P3[ks][1][0], P3[ks][1][1], P3[ks][1][2], P3[ks][1][3]};
+                const float xd[8] = {P1[ks][0][0], P1[ks][0][1], P1[ks][0][2], P1[ks][0][3], P1[ks][1][0], P1[ks][1][1], P1[ks][1][2], P1[ks][1][3]};
+                const float xb[8] = {P2w[ks], P2[ks][1][3], P2[ks][1][2], P2[ks][1][1], P2[ks][1][0], P2[ks][0][3], P2[ks][0][2], P2[ks][0][1]};
+                const float xc[8] = {P4w[ks], P4[ks][1][3], P4[ks][1][2], P4[ks][1][1], P4[ks][1][0], P4[ks][0][3], P4[ks][0][2], P4[ks][0][1]};
+                float ap[8], am[8], bm[8], bp[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const float t1 = xb[i] * sx, t2 = xd[i] * sx;
+                    float s1 = fmaf(xa[i], sx, t1), d1 = fmaf(xa[i], sx, -t1);       // once folded about the centre: position m
+                    float s2 = fmaf(xc[i], sx, t2), d2 = fmaf(xc[i], sx, -t2);       //                               position 128 - m
+                    if (ks == 0 && i == 0) {
+                        // m = 0 has no partners: the centre sample x[128] under w[128] and the frame's first sample x[0] under w[0]
+                        s1 = g == 0 ? xa[0] * sx : s1;
+                        s2 = g == 0 ? t2 : s2;
+                    }
+                    const float w1 = w1c[ks * 8 + i], w2 = w2c[ks * 8 + i];
+                    const float p = w2 * s2, q = w2 * d2;
+                    ap[i] = fmaf(w1, s1, p);                                         // even bins, real
+                    am[i] = fmaf(w1, s1, -p);                                        // odd bins, real
+                    bm[i] = fmaf(w1, d1, -q);                                        // even bins, imaginary
+                    bp[i] = fmaf(w1, d1, q);                                         // odd bins, imaginary
+                }
+                if (ks == 0) {                        // slot 0 of the imaginary rows: sin 0 -- free; the odd bins' takes the self-paired position
+                    bm[0] = g == 0 ? 0.0f : bm[0];
+                    bp[0] = g == 0 ? b64 : bp[0];
+                }
+                uint32x4 vh[4], vl[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    unsigned h, l;
+                    split2(ap[2 * j], ap[2 * j + 1], h, l);
+                    vh[0][j] = h; vl[0][j] = l;
+                    split2(am[2 * j], am[2 * j + 1], h, l);
+                    vh[1][j] = h; vl[1][j] = l;
+                    split2(bm[2 * j], bm[2 * j + 1], h, l);
+                    vh[2][j] = h; vl[2][j] = l;
+                    split2(bp[2 * j], bp[2 * j + 1], h, l);
+                    vh[3][j] = h; vl[3][j] = l;
+                }
+#pragma unroll
+                for (int gm = 0; gm < 4; gm++) acc[gm] = mfma(b2[ks][gm][0], as_half8(vh[gm]), acc[gm]);
+#pragma unroll
+                for (int gm = 0; gm < 4; gm++) acc[gm] = mfma(b2[ks][gm][0], as_half8(vl[gm]), acc[gm]);
+#pragma unroll
+                for (int gm = 0; gm < 4; gm++) acc[gm] = mfma(b2[ks][gm][1], as_half8(vh[gm]), acc[gm]);
+            }
+        } else {
+#pragma unroll
+        for (int ks = 0; ks < KB; ks++) {
             // x[c + m0 + i], i = 0..7, and x[c - m0 - i]: words c-m0-8 .. c-m0-1 as two quads, and the word c - m0
             const int skp = sk(W / 2 + 32 * ks), skm = sk(W / 2 - 32 * ks - 32), skw = sk(W / 2 - 32 * ks);   // (constants once unrolled)
             const floatx4 p0 = *reinterpret_cast<const floatx4 *>(xpb + 32 * ks + skp), p1 = *reinterpret_cast<const floatx4 *>(xpb + 32 * ks + 4 + skp);
@@ -350,6 +479,7 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
 #pragma unroll
             for (int m = 0; m < 2; m++) acc[2 + m] = mfma(ad_[ks][m][1], bdh, acc[2 + m]);
         }
+        }
 #else
         acc[0][0] = xpb[0]; acc[1][1] = xmb[0];
 #endif
@@ -374,7 +504,10 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
         }
 #pragma unroll
         for (int i = 0; i < 8; i++) {
-            const float re = fmaf(cre_l[i], xl, acc[i >> 2][i & 3]), im = acc[2 + (i >> 2)][i & 3];
+            // once folded: acc = re 0-15, re 16-31, im 0-15, im 16-31, the first sample's real part on top;
+            // twice folded: acc = re even, re odd, im even, im odd, the self-paired position's sum on top of the even real rows
+            const float re = F2 ? (i < 4 ? fmaf(ce[i], a64, acc[0][i]) : acc[1][i & 3]) : fmaf(cre_l[i], xl, acc[i >> 2][i & 3]);
+            const float im = F2 ? (i < 4 ? acc[2][i] : acc[3][i & 3]) : acc[2 + (i >> 2)][i & 3];
             cval[i] = __builtin_amdgcn_sqrtf(fmaf(re, re, im * im)) * kmag;
         }
         if (GEN && scaling != 0) {
@@ -456,6 +589,7 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
                 st0 = mean * pow2f(dsc);
                 st1 = m2 * pow2f(2 * dsc);
             }
+            if (GEN && norm == 0) st1 = st0;           // no normaliser: the frame's sum of squares once more, for the window's level (the loudness guard)
             const float fw = far ? INFINITY : ((fst == 1 || (GEN && scaling != 0)) ? 0.0f : pow2f(2 * dsc));
             if (g == 0) *reinterpret_cast<floatx4 *>(prow + 4 * HQ * TP) = floatx4{st0, fw, st1, 0.0f};
         }
@@ -478,7 +612,8 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
             for (int q = 0; q < HQ; q++) zp[q] = pv[0][q] + pv[1][q] + pv[2][q];
             if (GEN && (norm == 0 || norm == 2)) {    // no normaliser: the guard wants the quietest column of the window; Normalize: the window's minimum
                 ssp = fminf(fminf(g < T ? s0[0] : INFINITY, g + 4 < T ? s1[0] : INFINITY), g + 8 < T ? s2[0] : INFINITY);
-                st1p = fmaxf(fmaxf(g < T ? s0[2] : -INFINITY, g + 4 < T ? s1[2] : -INFINITY), g + 8 < T ? s2[2] : -INFINITY);
+                st1p = norm == 0 ? s0[2] + s1[2] + s2[2]     // (... and the window's whole sum of squares: rows of taps past timeRange read zeros)
+                                 : fmaxf(fmaxf(g < T ? s0[2] : -INFINITY, g + 4 < T ? s1[2] : -INFINITY), g + 8 < T ? s2[2] : -INFINITY);
             } else {                                  // sums (rows of taps past timeRange read zeros)
                 ssp = s0[0] + s1[0] + s2[0];
                 st1p = s0[2] + s1[2] + s2[2];
@@ -509,6 +644,8 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
                 const float m = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
                 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
                 st1w = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+            } else if (GEN && norm == 0) {            // the window's sum of squares (relative to the reference exponent)
+                st1w = xor32_sum(xor16_sum(st1p));
             } else if (GEN && norm == 3) {
                 // mean and M2 of the window from its frames' (equal counts F): M2 = sum M2_t + F sum (mean_t - mean)^2
                 const float mean = ssw / (float)T;
@@ -632,6 +769,13 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
                 const int lg = (int)((__float_as_uint(fww) >> 23) & 0xffu) - 127;
                 if (se_ref - lg / 2 >= d.guard_se_abs_r) bad = false;
             }
+            if (GEN && norm == 0 && scaling == 0 && vld) {
+                // ... and loud enough for the arithmetic's own relative error to matter?  (fused_plan.cpp, guard_loud: the window's
+                // norm in true units through the network's root-sum-square gain)
+                const int ush2 = 2 * (d.col_shift - se_ref);
+                const float u2 = st1w * pow2f(ush2 < -120 ? -120 : (ush2 > 120 ? 120 : ush2));
+                if (u2 * d.guard_loud > 1.0f) bad = true;
+            }
             if (__builtin_amdgcn_ballot_w64(bad) != 0ull) {
                 const int er0 = kTile * t - (T - 1);
                 const int lo = er0 < 0 ? 0 : er0, hi = er0 + kTile < seg_len ? er0 + kTile : seg_len;
@@ -664,11 +808,11 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
     }
 }
 
-template <int K2, bool GEN, int HQ, int NW, int PADP = 0>
+template <int K2, bool GEN, int HQ, int NW, int PADP = 0, bool F2 = false>
 hipError_t launch_one(const FusedDesc &d, const float *samples, int64_t stride, int C, int64_t s_eff, int64_t E,
                       float *outputs, uint8_t *flags, hipStream_t stream)
 {
-    auto kern = fused_s_kernel<K2, GEN, HQ, NW, PADP>;
+    auto kern = fused_s_kernel<K2, GEN, HQ, NW, PADP, F2>;
     constexpr int kWaves = NW;
     const int lds = d.s_lds_wave * kWaves;
     hipError_t st = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -722,6 +866,11 @@ hipError_t launch_fused_s(const FusedDesc &d, const float *samples, int64_t stri
         return hipErrorInvalidValue;
     }
 #undef SD_S_PAD
+    // W == N == 256, up to four hidden units: the twice-folded instantiation (SYLDET_FUSED_NOFOLD2=1 keeps the once-folded one: A/B runs)
+    if (d.s2_ok && !d.no_fold2 && d.W == 256 && d.H <= 4) {
+        if (exact) return launch_one<4, false, 1, 8, 0, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
+        return launch_one<4, true, 1, 8, 0, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
+    }
     SD_S_GO(4) SD_S_GO(2) SD_S_GO(1) SD_S_GO(3)
 #undef SD_S_GO
     return hipErrorInvalidValue;

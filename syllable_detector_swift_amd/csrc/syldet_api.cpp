@@ -109,6 +109,7 @@ struct syldet {
         bool no_guard = false;        // SYLDET_NO_GUARD: the precision guard off
         bool no_mlpx = false;         // SYLDET_NO_MLPX: the interpretive network kernels under AUTO
         bool fused_nofold = false;    // SYLDET_FUSED_NOFOLD: not the symmetric-fold kernel (the register-resident-basis / 8-wave kernels)
+        bool fused_nofold2 = false;   // SYLDET_FUSED_NOFOLD2: the fold kernel's once-folded form where the twice-folded one takes the shape
         bool fused_stamps = false;    // SYLDET_FUSED_STAMPS: the stamped diagnostic instantiation
         int fused_ko = 0;             // SYLDET_FUSED_KO=<mask>: knock-out instantiation
         long long host_chunk = 0;     // SYLDET_HOST_CHUNK_BYTES=<n>: bytes of input per stage of the host-pointer pipeline (tests force seams with it)
@@ -124,6 +125,7 @@ struct syldet {
             no_guard = std::getenv("SYLDET_NO_GUARD") != nullptr;
             no_mlpx = std::getenv("SYLDET_NO_MLPX") != nullptr;
             fused_nofold = std::getenv("SYLDET_FUSED_NOFOLD") != nullptr;
+            fused_nofold2 = std::getenv("SYLDET_FUSED_NOFOLD2") != nullptr;
             fused_stamps = std::getenv("SYLDET_FUSED_STAMPS") != nullptr;
             fused_ko = std::getenv("SYLDET_FUSED_KO") ? std::atoi(std::getenv("SYLDET_FUSED_KO")) : 0;
         }
@@ -418,6 +420,8 @@ int upload_plan(syldet *h, FusedPlan &p, DeviceBuffer &buf)
     const size_t o_wt = put(p.afrag_t.data(), p.afrag_t.size() * 2);
     const size_t o_sf = put(p.sfrag.data(), p.sfrag.size() * 2), o_sl = put(p.slone.data(), p.slone.size() * 4);
     const size_t o_ww = put(p.afrag_w.data(), p.afrag_w.size() * 2);
+    const size_t o_s2 = put(p.sfrag2.data(), p.sfrag2.size() * 2), o_w2 = put(p.swin2.data(), p.swin2.size() * 4);
+    const size_t o_c2 = put(p.s2c.data(), p.s2c.size() * 4), o_t2 = put(p.afrag_t2.data(), p.afrag_t2.size() * 2);
     if (int st = buf.reserve(blob.size())) return st;
     SYLDET_HIP(hipMemcpy(buf.ptr, blob.data(), blob.size(), hipMemcpyHostToDevice));
     unsigned char *base = (unsigned char *)buf.ptr;
@@ -428,6 +432,10 @@ int upload_plan(syldet *h, FusedPlan &p, DeviceBuffer &buf)
     d.sfrag = (const uint4 *)(base + o_sf);
     d.slone = (const float *)(base + o_sl);
     d.afrag_w = (const uint4 *)(base + o_ww);
+    d.sfrag2 = (const uint4 *)(base + o_s2);
+    d.swin2 = (const float *)(base + o_w2);
+    d.s2c = (const float *)(base + o_c2);
+    d.afrag_t2 = (const uint4 *)(base + o_t2);
     d.koff = (const int *)(base + o_k);
     d.bias0 = (const float *)(base + o_b);
     d.rvec = (const float *)(base + o_r);
@@ -639,6 +647,7 @@ int run_on_stream(syldet *h, const float *d_samples, int64_t S, int64_t stride, 
         d.ko = h->sw.fused_ko;
         d.force_classic = h->sw.fused_classic ? 1 : 0;
         d.no_fold = h->sw.fused_nofold ? 1 : 0;
+        d.no_fold2 = h->sw.fused_nofold2 ? 1 : 0;
         // Which fused kernel THIS batch gets is known only now (the fold kernel addresses a row with 32-bit byte offsets; a
         // diagnostic switch may rule it out).  The batch takes the fused route only if that kernel can run it (plans whose hop
         // only the fold kernel holds have no 8-wave form: classic_ok == 0) and, for log / dB columns under AUTO, only on the fold

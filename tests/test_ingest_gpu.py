@@ -179,10 +179,13 @@ def test_wide_network_bf16_mfma_engine(oracle_lib, shape, monkeypatch):
         direct = shape not in ("H40_normalize", "H64_narrow_range_maps") and "SYLDET_WIDE_SHAPE32" not in os.environ and "SYLDET_WIDE_NO_FRONT" not in os.environ
         assert (prepared == []) == direct
     worst = 0.0
+    # (the narrow-range maps put the network's inputs at |u| up to ~25: bf16 leaves 2^-9 of THAT in every input whichever
+    # route rounds it, so that shape is held to 4x the bar -- what the case pins is the route)
+    tol = 4 * WIDE_TOL if shape == "H64_narrow_range_maps" else WIDE_TOL
     for c in range(C):
         _, _, w64 = o.run(x[c], po.F64, cfg.rule)
-        util.assert_outputs_close(out[c], w64, WIDE_TOL)
-        util.assert_flags_exact(fl[c], w64, cfg.thresholds, cfg.rule, WIDE_TOL)
+        util.assert_outputs_close(out[c], w64, tol)
+        util.assert_flags_exact(fl[c], w64, cfg.thresholds, cfg.rule, tol)
         worst = max(worst, float(np.abs(out[c] - w64).max()))
     assert worst > 1e-7, "bf16 rounding should be visible: is the engine really running?"
 
