@@ -265,6 +265,7 @@ hipError_t launch_fused_spectrogram(const FusedDesc &d, const float *samples, in
 // the same contract on the register-resident-basis kernel; only called when d.r_ok and fused_r_applicable(d)
 bool fused_r_applicable(const FusedDesc &d);
 bool fused_r_has_stamps();      // built with -DSYLDET_R_STAMPS (phase timing, SYLDET_FUSED_STAMPS=1)
+bool fused_s_has_stamps();      // built with -DSYLDET_S_STAMPS: where a wave of the fold kernel waits (SYLDET_FUSED_STAMPS=1)
 hipError_t launch_fused_r(const FusedDesc &d, const float *samples, int64_t stride, int C, int64_t S, int64_t J,
                           int64_t E, float *outputs, uint8_t *flags, hipStream_t stream);
 // the same contract on the symmetric-fold kernel; only called when fused_s_applicable(d)

@@ -788,7 +788,7 @@ int fused_choice(const FusedDesc &d, int64_t J)
     // them with padding and is the faster one there for 192- and 256-sample windows: 2.13 against 3.08 ms at hop 64, 1.23 against
     // 1.63 at hop 128 -- MEASUREMENTS R3.4)
     const bool banked = d.hop % 64 == 0 && d.W > 128 && !d.s_padp && fused_r_applicable(d) && (!classic || !d.classic_ok);
-    if (!classic && !d.no_fold && !d.ko && !d.stamps && !banked && fused_s_applicable(d) && s_eff * 4 < 0x7fffffffll) return 2;
+    if (!classic && !d.no_fold && !d.ko && (!d.stamps || fused_s_has_stamps()) && !banked && fused_s_applicable(d) && s_eff * 4 < 0x7fffffffll) return 2;
     if ((!classic || !d.classic_ok) && !d.ko && fused_r_applicable(d) && (!d.stamps || fused_r_has_stamps() || !d.classic_ok)) return 1;
     return 0;
 }

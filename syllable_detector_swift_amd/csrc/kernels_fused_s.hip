@@ -289,10 +289,17 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
     issue_upto(need(0) < allowed(0) ? need(0) : allowed(0));
     int se_ref = 0;                                   // products are stored relative to the segment's first frame that has a level
 
+#ifdef SYLDET_S_STAMPS                // (diagnostic build: shader clocks a wave spends waiting for its samples' DMA / for the LDS, and in all)
+    unsigned long long st_vm = 0, st_lg = 0;
+    const unsigned long long st_begin = __builtin_amdgcn_s_memtime();
+#define SD_STAMP(var, stmt) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long t0_ = __builtin_amdgcn_s_memtime(); stmt; \
+                              const unsigned long long t1_ = __builtin_amdgcn_s_memtime(); var += t1_ - t0_; }
+#else
+#define SD_STAMP(var, stmt) { stmt; }
+#endif
     for (int t = 0; t < tiles; t++) {
         // tile t's chunks have landed (behind them in the queue: nothing but the two result stores of tile t - 1)
-        if (t == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        SD_STAMP(st_vm, if (t == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"));
         const float *fp = ring + fo + sk((int)fo);    // this lane's frame: W samples from here (the mirror makes them contiguous)
 
         // ---- twice folded: this lane's 64 + 6 samples of its frame, read once.  For m0 = 32 ks + 8 g:
@@ -317,6 +324,10 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
             }
             x64 = fp[64];
             x192 = fp[192];
+            // the raw samples of this tile are dead as soon as they are in registers: all of the next tile's chunks, a whole tile
+            // of arithmetic ahead of their use
+            SD_STAMP(st_lg, asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"));
+            if (t + 1 < tiles) issue_upto(need(t + 1));
         }
         // ---- the frame's own scale from its loudest sample (this lane looks at a quarter of the frame)
         float amax;
@@ -377,7 +388,7 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
         }
 
         // the next tile's samples, as far as the ring has room while this tile is read
-        if (t + 1 < tiles) issue_upto(need(t + 1) < allowed(t) ? need(t + 1) : allowed(t));
+        if (!F2 && t + 1 < tiles) issue_upto(need(t + 1) < allowed(t) ? need(t + 1) : allowed(t));
 
         // ---- the folded DFT: per k-step this lane folds, scales and splits 8 positions of its frame, then 12 MFMAs
         const float xl = fp[0] * sx;                  // the frame's first sample (no partner)
@@ -484,8 +495,10 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
         acc[0][0] = xpb[0]; acc[1][1] = xmb[0];
 #endif
         // the raw samples of this tile are dead (every read of them has returned): the rest of the next tile's chunks
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (t + 1 < tiles) issue_upto(need(t + 1));
+        if (!F2) {
+            SD_STAMP(st_lg, asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"));
+            if (t + 1 < tiles) issue_upto(need(t + 1));
+        }
 
         // ---- |X| (zvabs / 2, CircularShortTimeFourierTransform.swift:329-333) of this lane's 8 bins, the frame's sum of squares,
         // the f16 hi + lo split of the column under the frame's own column exponent, the tap products of the first layer.
@@ -806,6 +819,16 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
         fo += (unsigned)(kTile * hop);
         fo = fo >= (unsigned)R ? fo - (unsigned)R : fo;
     }
+#ifdef SYLDET_S_STAMPS
+    if (d.stamps && lane == 0) {
+        atomicAdd(d.stamps + 0, __builtin_amdgcn_s_memtime() - st_begin);
+        atomicAdd(d.stamps + 1, st_vm);
+        atomicAdd(d.stamps + 2, st_lg);
+        atomicAdd(d.stamps + 3, (unsigned long long)tiles);
+        atomicAdd(d.stamps + 4, 1ull);
+    }
+#endif
+#undef SD_STAMP
 }
 
 template <int K2, bool GEN, int HQ, int NW, int PADP = 0, bool F2 = false>
@@ -828,6 +851,15 @@ hipError_t launch_one(const FusedDesc &d, const float *samples, int64_t stride, 
 // The class fused_r_kernel takes (two layers, at most 4 hidden units, at most 4 outputs, linear |X| columns, no normaliser
 // or l2normalize in front of the affine maps, at most one output map), for windows of 64, 128, 192 or 256 samples that are
 // symmetric (all of the reference's are), any timeRange up to 12, hops that are multiples of 4 and leave room for the ring.
+bool fused_s_has_stamps()
+{
+#ifdef SYLDET_S_STAMPS
+    return true;
+#else
+    return false;
+#endif
+}
+
 bool fused_s_applicable(const FusedDesc &d)
 {
     // (log / dB columns too: every frame is transformed at its own scale, so a bin's error is relative to its frame, as an fp32

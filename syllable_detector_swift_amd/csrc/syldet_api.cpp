@@ -557,6 +557,18 @@ int build_dft_plan(syldet *h)
     return SYLDET_OK;
 }
 
+// Does the network's input chain start with a scale-invariant normaliser (l2normalize, normalize, normalizestd:
+// NeuralNet.swift:41-109)?  Behind one, the network sees a unit-scale vector whatever the recording's level, and the
+// matrix-core transforms' error -- 2^-21.4 of a frame's column level -- is 2^-21.4 of that unit.  Without one the network sees
+// the columns at the recording's level, and the same relative error grows with it where an fp32 FFT's is eight times smaller:
+// AUTO then keeps true fp32 transforms, except on the fold kernel, which knows when the level makes the difference and
+// recomputes those evaluations exactly (guard_loud, fused_plan.cpp).
+bool normalised_chain(const syldet_config_t &c)
+{
+    return c.n_input_fns > 0 && (c.input_fns[0].kind == SYLDET_FN_L2NORMALIZE || c.input_fns[0].kind == SYLDET_FN_NORMALIZE ||
+                                 c.input_fns[0].kind == SYLDET_FN_NORMALIZESTD);
+}
+
 int64_t count_frames(const syldet *h, int64_t S)
 {
     const int64_t need = (int64_t)h->geom.gap + h->cfg.view.window_length;   // :286-288
@@ -603,7 +615,10 @@ int stft_on_stream(syldet *h, const float *d_samples, int64_t stride, int C, int
     // columns that go through log / dB keep the generic FFT: its error is relative to the frame, the block-floating-point
     // DFT's to the loudest sample of the 128-frame pass, and the logarithm turns relative error of weak bins into absolute
     const bool log_input = for_network && h->cfg.view.scaling != SYLDET_SCALING_LINEAR;
-    if (h->has_dft && !log_input && (uint64_t)J * (uint64_t)h->geom.bins * 4u < 0xFFFFFFF0ull) {
+    // ... and columns that meet a network without a normaliser in front keep it too (normalised_chain above); the wide engine
+    // is bf16 behind either
+    const bool level_input = for_network && !normalised_chain(h->cfg.view) && h->engine != SYLDET_ENGINE_WIDE_BF16 && h->engine_asked == SYLDET_ENGINE_AUTO;
+    if (h->has_dft && !log_input && !level_input && (uint64_t)J * (uint64_t)h->geom.bins * 4u < 0xFFFFFFF0ull) {
         FusedDesc d = h->dft.desc;
         fused_segmentation(d, J, C);
         d.spect_out = d_columns;
@@ -655,12 +670,31 @@ int run_on_stream(syldet *h, const float *d_samples, int64_t S, int64_t stride, 
         // else goes to the generic engine below, like the long rows.
         const int choice = fused_choice(d, J);
         const bool runnable = choice != 0 || d.classic_ok;
-        const bool in_contract = h->cfg.view.scaling == SYLDET_SCALING_LINEAR || choice == 2 || h->engine_asked == SYLDET_ENGINE_FUSED;
+        const bool in_contract = ((h->cfg.view.scaling == SYLDET_SCALING_LINEAR && normalised_chain(h->cfg.view)) || choice == 2 || h->engine_asked == SYLDET_ENGINE_FUSED);
         if (!runnable || !in_contract) fused_route = false;
     }
     if (fused_route) {
         // diagnostic only: SYLDET_FUSED_STAMPS=1 runs the stamped instantiation and prints where a
         // workgroup pass spends its cycles (never set in tests or the benchmark)
+        if (h->sw.fused_stamps && fused_s_has_stamps() && fused_choice(d, J) == 2) {
+            // the fold kernel's stamped build (-DSYLDET_S_STAMPS): shader clocks its waves spend waiting, summed over all waves
+            if (int st = h->d_stamps.reserve(16 * sizeof(unsigned long long))) return st;
+            SYLDET_HIP(hipMemsetAsync(h->d_stamps.ptr, 0, 16 * sizeof(unsigned long long), stream));
+            d.stamps = (unsigned long long *)h->d_stamps.ptr;
+            {
+                KernelTimer t(h, stream, "fused_s_kernel");
+                SYLDET_HIP(launch_fused(d, d_samples, stride, C, S, J, E, d_outputs, d_flags, stream));
+            }
+            unsigned long long host[16];
+            SYLDET_HIP(hipMemcpyAsync(host, h->d_stamps.ptr, sizeof(host), hipMemcpyDeviceToHost, stream));
+            SYLDET_HIP(hipStreamSynchronize(stream));
+            const double w = (double)host[4], tl = (double)host[3];
+            std::fprintf(stderr, "[syldet stamps] fold kernel: %.0f waves, %.1f tiles each; per tile: %.0f clocks in all, %.0f waiting for the samples' DMA (%.1f %%), "
+                                 "%.0f waiting for the LDS reads of the samples (%.1f %%)\n",
+                         w, tl / w, (double)host[0] / tl, (double)host[1] / tl, 100.0 * (double)host[1] / (double)host[0], (double)host[2] / tl,
+                         100.0 * (double)host[2] / (double)host[0]);
+            return SYLDET_OK;
+        }
         if (h->sw.fused_stamps) {
             const bool rk = fused_r_applicable(d) && fused_r_has_stamps() && !h->sw.fused_classic;   // which kernel the launcher picks
             const int64_t seg = rk ? d.r_seg_evals : d.seg_evals;
@@ -810,7 +844,15 @@ int syldet_create(const syldet_config_t *cfg, int32_t n_channels, int32_t device
                 h->fused.reason = "log/dB scaling: AUTO keeps the generic engine for 1e-5 parity";
             }
         } else if (make_fused_plan(h->cfg.view, h->geom, h->fused)) {
-            h->engine = SYLDET_ENGINE_FUSED;
+            const bool fold = fused_s_applicable(h->fused.desc) && !h->sw.fused_nofold && !h->sw.fused_classic;
+            if (engine == SYLDET_ENGINE_AUTO && !normalised_chain(h->cfg.view) && !fold) {
+                // no normaliser in front of the network: the pass-scaled kernels' error follows the recording's level
+                // (normalised_chain above); only the fold kernel guards against that
+                h->fused = FusedPlan();
+                h->fused.reason = "no normaliser in front of the network: AUTO keeps fp32 transforms outside the fold kernel's class";
+            } else {
+                h->engine = SYLDET_ENGINE_FUSED;
+            }
         } else if (engine == SYLDET_ENGINE_FUSED) {
             return fail(SYLDET_ERR_UNSUPPORTED, "fused engine not available for this configuration: " + h->fused.reason);
         }

@@ -110,14 +110,20 @@ def test_guard_stays_quiet_on_ordinary_audio(oracle_lib, chain, level):
             out, fl = det.run(torch.from_numpy(x).cuda())
             torch.cuda.synchronize()
             assert det.geometry.engine == 2
-            assert det.fixupStats() == (0, 0), (chain, H, det.fixupStats())
+            items, over = det.fixupStats()
+            # Without a normaliser the network sees the columns at the recording's level: at level 1 the bursts' columns
+            # (|X| ~ 20, under gains of 1 .. 2: network inputs of 50) put the matrix-core arithmetic's 2^-21.4 of that level past the
+            # 1e-5 bar where an fp32 FFT still holds it -- those windows ARE what the grid cannot hold to the contract, and the fold
+            # kernel hands exactly them to the exact path (guard_loud).  Everything else must never reach it.
+            loud = level == 1.0 and (not chain or chain[0] not in ("l2normalize", "normalize", "normalizestd"))
+            assert over == 0 and ((items == 0) or loud), (chain, H, (items, over))
+            if loud:
+                assert items < (132 * 700 // 132) * 2 // 16 // 2, items            # at most the bursts, never the noise between them
             out = out.cpu().numpy()
         o = util.oracle_for(cfg)
         for c in range(2):
-            w32, _, w64 = o.run(x[c], po.F64)
+            _, _, w64 = o.run(x[c], po.F64)
+            w32 = o.run(x[c], po.F32)[0]
             own = float(np.abs(w32 - w64).max())
-            bar = np.full(w64.shape[0], max(util.TOL, 4 * own))
-            if not chain or chain[0] not in ("l2normalize", "normalize", "normalizestd"):
-                cols = o.spectrogram(x[c], po.F64)
-                bar = np.maximum(bar, util.TOL * np.array([cols[e:e + 10].max() for e in range(w64.shape[0])]))
-            util.assert_outputs_close(out[c], w64, bar)
+            # (one bar for every chain: 1e-5, or 4x the fp32 port's own distance -- no allowance for the recording's level)
+            util.assert_outputs_close(out[c], w64, max(util.TOL, 4 * own))
