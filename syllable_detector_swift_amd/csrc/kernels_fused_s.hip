@@ -612,6 +612,17 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
         floatx4 zp[HQ];
         float ssp, fwp, st1p = 0.0f;                  // this lane group's share of the window's statistics (its taps g, g + 4, g + 8)
         float sq0[3];                                 // (normalizestd: the frames' means once more)
+        // The last T - 1 frames' rows go to the front for the next tile.  Their reads are issued HERE, with the evaluation's own
+        // (one wait for both; clamped indices instead of masked lanes), their writes behind the evaluation's reads -- a wave's LDS
+        // operations execute in order, and source rows 16 .. never overlap destination rows 0 .. T - 2 (T - 1 < 16).
+        const int nq = (T - 1) * PS / 4;
+        floatx4 cy0 = {0.f, 0.f, 0.f, 0.f}, cy1 = cy0, cy2 = cy0;
+        if (HQ == 1) {                                // at most 143 quads (two or three a lane)
+            const floatx4 *src = reinterpret_cast<const floatx4 *>(rows + kTile * PS);
+            cy0 = src[lane < nq ? lane : 0];
+            cy1 = src[lane + 64 < nq ? lane + 64 : 0];
+            if (nq > 128) cy2 = src[lane + 128 < nq ? lane + 128 : 0];
+        }
         {
             floatx4 pv[3][HQ];
 #pragma unroll
@@ -799,20 +810,15 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
                 }
             }
         }
-        // ---- the last T - 1 frames' rows go to the front for the next tile (a wave's LDS operations execute in order)
+        // ---- the carried rows' writes (their reads went out with the evaluation's)
         {
-            const floatx4 *src = reinterpret_cast<const floatx4 *>(rows + kTile * PS);
             floatx4 *dst = reinterpret_cast<floatx4 *>(rows);
-            const int nq = (T - 1) * PS / 4;               // (source rows 16 .. and destination rows 0 .. T - 2 never overlap: T - 1 < 16)
-            if (HQ == 1) {                                 // at most 143 quads
-                floatx4 h0 = {0.f, 0.f, 0.f, 0.f}, h1 = h0, h2 = h0;
-                if (lane < nq) h0 = src[lane];
-                if (lane + 64 < nq) h1 = src[lane + 64];
-                if (lane + 128 < nq) h2 = src[lane + 128];
-                if (lane < nq) dst[lane] = h0;
-                if (lane + 64 < nq) dst[lane + 64] = h1;
-                if (lane + 128 < nq) dst[lane + 128] = h2;
+            if (HQ == 1) {
+                if (lane < nq) dst[lane] = cy0;
+                if (lane + 64 < nq) dst[lane + 64] = cy1;
+                if (nq > 128 && lane + 128 < nq) dst[lane + 128] = cy2;
             } else {
+                const floatx4 *src = reinterpret_cast<const floatx4 *>(rows + kTile * PS);
                 for (int i = lane; i < nq; i += 64) dst[i] = src[i];
             }
         }
