@@ -307,7 +307,7 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
     // 64 registers.  Slot 0 of the real rows (cos 0 = 1) takes the centre sample and the frame's first sample; slot 0 of the odd
     // imaginary rows (sin 0 = 0: free) takes b[N/4] against -sin(pi k / 2); a[N/4] meets the even real rows on the vector side.
     d.s2_ok = 0;
-    if (d.s_ok && W == 256 && N == 256 && H <= 4 && !d.s_padp) {
+    if (d.s_ok && W == 256 && N == 256 && H <= 4) {
         d.s2_ok = 1;
         const int ke0 = g.f0 + (g.f0 & 1), ko0 = g.f0 + 1 - (g.f0 & 1);          // first even / odd bin of the band
         d.s2_pe = ke0 - g.f0;

@@ -309,21 +309,23 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
         float P2w[2], P4w[2], x64 = 0.0f, x192 = 0.0f;
         if (F2) {
 #pragma unroll
+            // (padded ring: position i of the frame sits at fp[i + sk(i)]; the quads lie inside one piece each, so the padding
+            // is a constant per access -- only the word x[128 - m0] of lane group 0, k-step 0 is on the far side of one)
             for (int ks = 0; ks < 2; ks++) {
                 const float *a = fp + 32 * ks + 8 * g, *b = fp + 120 - 32 * ks - 8 * g;
                 P1[ks][0] = *reinterpret_cast<const floatx4 *>(a);
                 P1[ks][1] = *reinterpret_cast<const floatx4 *>(a + 4);
-                P3[ks][0] = *reinterpret_cast<const floatx4 *>(a + 128);
-                P3[ks][1] = *reinterpret_cast<const floatx4 *>(a + 132);
-                P2[ks][0] = *reinterpret_cast<const floatx4 *>(b);
-                P2[ks][1] = *reinterpret_cast<const floatx4 *>(b + 4);
-                P2w[ks] = b[8];
-                P4[ks][0] = *reinterpret_cast<const floatx4 *>(b + 128);
-                P4[ks][1] = *reinterpret_cast<const floatx4 *>(b + 132);
-                P4w[ks] = b[136];                        // (g == 0, ks == 0: x[256], the next frame's -- read, never used)
+                P3[ks][0] = *reinterpret_cast<const floatx4 *>(a + 128 + sk(128));
+                P3[ks][1] = *reinterpret_cast<const floatx4 *>(a + 132 + sk(128));
+                P2[ks][0] = *reinterpret_cast<const floatx4 *>(b + sk(64));
+                P2[ks][1] = *reinterpret_cast<const floatx4 *>(b + 4 + sk(64));
+                P2w[ks] = (PADP && ks == 0) ? b[8 + (g == 0 ? sk(128) : sk(64))] : b[8 + sk(64)];
+                P4[ks][0] = *reinterpret_cast<const floatx4 *>(b + 128 + sk(192));
+                P4[ks][1] = *reinterpret_cast<const floatx4 *>(b + 132 + sk(192));
+                P4w[ks] = b[136 + sk(192)];             // (g == 0, ks == 0: x[256], the next frame's -- read, never used)
             }
-            x64 = fp[64];
-            x192 = fp[192];
+            x64 = fp[64 + sk(64)];
+            x192 = fp[192 + sk(192)];
             // the raw samples of this tile are dead as soon as they are in registers: all of the next tile's chunks, a whole tile
             // of arithmetic ahead of their use
             SD_STAMP(st_lg, asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"));
@@ -896,6 +898,10 @@ hipError_t launch_fused_s(const FusedDesc &d, const float *samples, int64_t stri
 #define SD_S_PAD(K2_, P_)                                                                                              \
     if (d.W == 64 * K2_ && d.s_padp == P_) {                                                                           \
         if (d.H > 4) return hipErrorInvalidValue;                                                                      \
+        if (K2_ == 4 && d.s2_ok && !d.no_fold2) {                                                                      \
+            if (exact) return launch_one<4, false, 1, 8, P_, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream); \
+            return launch_one<4, true, 1, 8, P_, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);       \
+        }                                                                                                              \
         if (exact) return launch_one<K2_, false, 1, 8, P_>(d, samples, stride, C, s_eff, E, outputs, flags, stream);   \
         return launch_one<K2_, true, 1, 8, P_>(d, samples, stride, C, s_eff, E, outputs, flags, stream);               \
     }
