@@ -84,9 +84,7 @@ for wl, dom in (("sample", "fused_s_kernel"), ("config3", "fft1k_net_kernel"), (
     summary[wl] = {"kernel_stats": ks, "bench_kernel_ms": line["roofline"]["kernel_ms"] if line else None,
                    "bench_steps": line.get("steps") if line else None, "bench_preroll_steps": line.get("preroll_steps") if line else None,
                    "timed_region_from_the_trace": timed_region_ms(wl, dom, line.get("steps") if line else 0)}
-    if wl == "config5":
-        continue
-    fetch, write = counters(wl + "_fetch"), counters(wl + "_write")
+    fetch, write = (counters(wl + "_fetch"), counters(wl + "_write")) if wl != "config5" else ({}, {})    # (config5's roof is the matrix pipe)
     if dom in fetch and dom in write and line:
         fk, wk = fetch[dom]["FETCH_SIZE"], write[dom]["WRITE_SIZE"]
         hbm = 2.0 * fk * 1024.0 + wk * 1024.0
@@ -116,6 +114,10 @@ for wl, dom in (("sample", "fused_s_kernel"), ("config3", "fft1k_net_kernel"), (
             der["lds_bank_conflict_fraction"] = c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"]
         if "SQ_WAIT_ANY" in c and "SQ_WAVE_CYCLES" in c:
             der["wait_any_fraction_of_wave_cycles"] = c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]
+        if "SQ_WAIT_INST_ANY" in c and "SQ_WAVE_CYCLES" in c:
+            der["wait_inst_any_fraction_of_wave_cycles"] = c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"]
+        if "SQ_INSTS_VALU" in c and "SQ_INSTS_MFMA" in c and c["SQ_INSTS_MFMA"]:
+            der["valu_to_mfma_instruction_ratio"] = c["SQ_INSTS_VALU"] / c["SQ_INSTS_MFMA"]
         summary[wl]["utilisation"] = {"kernel": dom, "counters": c, "derived": der}
 json.dump(summary, open(os.path.join(DST, "%s_profile_summary.json" % R), "w"), indent=1)
 print(json.dumps({k: (v if k == "source" else {kk: vv for kk, vv in v.items() if kk != "utilisation"}) for k, v in summary.items()}, indent=1)[:3000])

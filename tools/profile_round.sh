@@ -4,7 +4,7 @@
 #   usage: tools/profile_round.sh r02
 # Counters are collected in passes of their own (--kernel-trace + --pmc only), the program right behind "--".
 set -u
-R=${1:-r03}
+R=${1:-r04}
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/prof_$R
 mkdir -p $OUT
@@ -32,6 +32,7 @@ for grp in "SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_LDS_I
   tag=$(echo $grp | tr ' ' '_' | cut -c1-30)
   run_pmc sample_$tag "$grp"
   run_pmc config3_$tag "$grp" --workload config3
+  run_pmc config5_$tag "$grp" --workload config5
 done
 cd $ROOT
 python3 tools/profile_collect.py $R
