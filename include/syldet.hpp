@@ -127,6 +127,57 @@ private:
     syldet_geometry_t geometry_{};
 };
 
+// One bank over several GPUs of this host, ONE process -- the reference's shape: ProcessorBase.init builds one detector per
+// channel and one serial queue drains them all (Processor.swift:57-59,82,128-141; main.swift:86-89,126-130).  The library places
+// a sub-bank and a stream on every listed device, splits the channels into contiguous blocks (time-axis ranges with a halo
+// when there are fewer channels than devices) and gathers the flags with one RCCL all-gather of their bits per batch.
+class SyllableDetectorShardedBank {
+public:
+    SyllableDetectorShardedBank(const SyllableDetectorConfig &config, int channels, const std::vector<int32_t> &devices,
+                                int engine = SYLDET_ENGINE_AUTO, int exchange = SYLDET_EXCHANGE_RCCL)
+    {
+        check(syldet_create_sharded(config.raw(), channels, devices.data(), (int32_t)devices.size(), engine, exchange, &b_));
+        check(syldet_get_geometry(syldet_sharded_bank(b_, 0), &geometry_));
+    }
+    ~SyllableDetectorShardedBank() { syldet_sharded_destroy(b_); }
+    SyllableDetectorShardedBank(const SyllableDetectorShardedBank &) = delete;
+    SyllableDetectorShardedBank &operator=(const SyllableDetectorShardedBank &) = delete;
+
+    const syldet_geometry_t &geometry() const { return geometry_; }
+    int channels() const { return syldet_sharded_channels(b_); }
+    int shards() const { return syldet_sharded_shards(b_); }
+    int rcclRanks() const { return syldet_sharded_rccl_ranks(b_); }
+    syldet_shard_t shard(int i) const
+    {
+        syldet_shard_t s;
+        check(syldet_sharded_shard(b_, i, &s));
+        return s;
+    }
+    int64_t countEvaluations(int64_t samples) const { return syldet_count_evals(syldet_sharded_bank(b_, 0), samples); }
+    // whole recordings, host buffers: samples [channels][n] -> outputs [channels][E][outputs], flags [channels][E];
+    // every device's copies and kernels are in flight together
+    void run(const float *samples, int64_t n, std::vector<float> &outputs, std::vector<uint8_t> &flags)
+    {
+        const int64_t E = countEvaluations(n) > 0 ? countEvaluations(n) : 0;
+        outputs.assign((size_t)channels() * (size_t)E * (size_t)geometry_.outputs, 0.0f);
+        flags.assign((size_t)channels() * (size_t)E, 0);
+        check(syldet_sharded_run(b_, samples, n, n, outputs.data(), flags.data()));
+    }
+    // per-shard device blocks (syldet_sharded_ranges says which samples shard i reads); flagsAll[i]: every channel's flags on
+    // device i through the one exchange.  Asynchronous: synchronize() before reading.
+    void runDevice(const float *const *d_samples, int64_t n, const int64_t *strides, float *const *d_outputs, uint8_t *const *d_flags,
+                   uint8_t *const *d_flagsAll)
+    {
+        check(syldet_sharded_run_device(b_, d_samples, n, strides, d_outputs, d_flags, d_flagsAll));
+    }
+    void synchronize() { check(syldet_sharded_synchronize(b_)); }
+    syldet_sharded_t *raw() { return b_; }
+
+private:
+    syldet_sharded_t *b_ = nullptr;
+    syldet_geometry_t geometry_{};
+};
+
 // One channel of a bank with the reference's per-detector surface.
 class SyllableDetector {
 public:

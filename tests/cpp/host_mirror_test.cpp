@@ -50,6 +50,19 @@ int main(int argc, char **argv)
         std::vector<uint8_t> flags;
         bank.run(x.data(), (int64_t)x.size(), outputs, flags);
         const std::vector<int64_t> idx = bank.detections(flags.data(), (int64_t)flags.size(), 0.0, 0);
+        // ... and the same recording through the one-process sharded bank (a bank over a list of devices: here device 0 listed
+        // twice, so the one channel is cut along time into two stretches with a halo): identical bits
+        {
+            syldetxx::SyllableDetectorShardedBank sharded(config, 1, {0, 0});
+            if (sharded.shards() != 2 || sharded.channels() != 1 || sharded.shard(1).parts != 2) return 7;
+            std::vector<float> so;
+            std::vector<uint8_t> sf;
+            sharded.run(x.data(), (int64_t)x.size(), so, sf);
+            if (so != outputs || sf != flags) {
+                std::fprintf(stderr, "host_mirror_test: the sharded bank's results differ from the plain bank's\n");
+                return 8;
+            }
+        }
         std::FILE *o = std::fopen(argv[3], "wb");
         if (!o) return 6;
         std::fwrite(streamed.data(), sizeof(float), streamed.size(), o);
