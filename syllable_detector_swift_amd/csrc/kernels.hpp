@@ -74,6 +74,7 @@ struct WideDesc {
     // the input chain is [l2normalize,] affine maps on linear columns, the affine part folded into the first layer by the host,
     // so the B operands are bf16(v / |v|) (l2 = 1) or bf16(v): no [evaluations][320] image in HBM, no preparation kernel
     int front, l2, I, F;
+    int wg8;                    // two workgroups of 8 waves a CU instead of one of 16 (kernels_wide.hip, NWV)
     const uint4 *wpack;         // [n_chunks][kWideChunkBytes / 16]
     const float *b1;            // [n_out]
     const float *out_params;    // per output fn: y, gain[n_out], xoff[n_out]

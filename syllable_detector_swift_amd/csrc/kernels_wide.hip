@@ -355,19 +355,23 @@ wide_gemm_kernel(WideDesc d, const uint4 *__restrict__ xn, int64_t NE, float *__
 // ------------------------------------------------------------------------------------
 typedef float floatx4w __attribute__((ext_vector_type(4)));
 // FRONT: the B operands are made here from the |X| columns (WideDesc::front) instead of being read from the prepared image.
-template <int NOUT, bool SIG, bool FRONT>
-__global__ void __launch_bounds__(kBlock, 1)
+// NWV: waves per workgroup.  16 (one workgroup of 512 evaluations a CU) or 8 (two workgroups of 256 a CU, each with its own
+// chunk buffers and its own barrier: the two run out of phase, so that one's MFMA phase meets the other's epilogue --
+// behind ONE barrier the 16 waves run every chunk in lockstep, 160 MFMAs with the vector unit waiting, then four epilogues
+// with the matrix pipe idle; MEASUREMENTS R4.6).  The price: every workgroup streams the weights, so twice the L2 -> LDS bytes.
+template <int NOUT, bool SIG, bool FRONT, int NWV = 16>
+__global__ void __launch_bounds__(64 * NWV, NWV == 16 ? 1 : 4)
 wide_gemm16_kernel(WideDesc d, const uint4 *__restrict__ xn, const float *__restrict__ columns, int64_t J, int64_t E, int64_t NE,
                    float *__restrict__ outputs, uint8_t *__restrict__ flags)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int kWaves = kBlock / 64, kK2 = kWideK / 32;
+    constexpr int kWaves = NWV, kK2 = kWideK / 32, kBl = 64 * NWV, kTl = 32 * NWV;
     uint4 *buf0 = reinterpret_cast<uint4 *>(smem), *buf1 = buf0 + kChunkU4Pad;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, g = lane >> 4;
     // FRONT: a workgroup's 512 evaluations are consecutive ones of ONE channel (grid y), so the columns under them are one
     // stretch of 511 F + I floats, staged through LDS once; otherwise evaluations are numbered through all channels
-    const int64_t e_blk = (int64_t)blockIdx.x * kWideTile;        // (FRONT: within channel blockIdx.y)
+    const int64_t e_blk = (int64_t)blockIdx.x * kTl;        // (FRONT: within channel blockIdx.y)
     int64_t ev[2];
     bool ev_ok[2];
 #pragma unroll
@@ -392,15 +396,15 @@ wide_gemm16_kernel(WideDesc d, const uint4 *__restrict__ xn, const float *__rest
         // evaluations goes through LDS (behind the two chunk buffers): coalesced loads once, then every lane picks its own
         float *stage = reinterpret_cast<float *>(smem + 2 * kChunkU4Pad * 16);
         const int F = d.F, I = d.I;
-        const int span = (kWideTile - 1) * F + I;                 // (wide_front_stage_floats - 1)
+        const int span = (kTl - 1) * F + I;                 // (wide_front_stage_floats - 1)
         const float *chan = columns + (int64_t)blockIdx.y * J * F;
         const int64_t first = e_blk * F, limit = J * (int64_t)F;
-        for (int i = tid; i < span; i += kBlock) stage[i] = first + i < limit ? chan[first + i] : 0.0f;
+        for (int i = tid; i < span; i += kBl) stage[i] = first + i < limit ? chan[first + i] : 0.0f;
         float *css = stage + span + 32;                           // [frames under the workgroup] a column's sum of squares (32 floats of slack: reads past I stay inside)
         __syncthreads();
         const int T = I / F;                                      // (I = F timeRange: SyllableDetector.swift:52-55)
         if (d.l2) {
-            for (int f = tid; f < kWideTile + T - 1; f += kBlock) {
+            for (int f = tid; f < kTl + T - 1; f += kBl) {
                 float a = 0.0f;
                 for (int b = 0; b < F; b++) a = fmaf(stage[f * F + b], stage[f * F + b], a);
                 css[f] = a;
@@ -444,7 +448,7 @@ wide_gemm16_kernel(WideDesc d, const uint4 *__restrict__ xn, const float *__rest
         for (int o = 0; o < NOUT; o++) ysum[t][o] = 0.0f;
     auto fetch_chunk = [&](int ch, uint4 *dst) {
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
+        for (int j = 0; j < (21 + kWaves - 1) / kWaves; j++) {
             const int i0 = (wave + kWaves * j) * 64;
             if (i0 < kChunkU4) {
                 const int i = i0 + lane < kChunkU4 ? i0 + lane : kChunkU4 - 1;
@@ -503,7 +507,7 @@ wide_gemm16_kernel(WideDesc d, const uint4 *__restrict__ xn, const float *__rest
     asm volatile("" : "+v"(tid2));                                // (recomputed: held across the loop they cost two spilled pairs)
 #pragma unroll
     for (int t = 0; t < 2; t++) {
-        const int64_t el = (int64_t)blockIdx.x * kWideTile + (tid2 >> 6) * 32 + 16 * t + (tid2 & 15);
+        const int64_t el = (int64_t)blockIdx.x * kTl + (tid2 >> 6) * 32 + 16 * t + (tid2 & 15);
         ev[t] = FRONT ? (int64_t)blockIdx.y * E + el : el;
         ev_ok[t] = FRONT ? el < E : el < NE;
     }
@@ -538,7 +542,8 @@ wide_gemm16_kernel(WideDesc d, const uint4 *__restrict__ xn, const float *__rest
 
 // the input chains the training script writes -- [l2normalize,] one affine map -- take the chain-specialised kernel
 // floats of |X| columns under one workgroup's 512 consecutive evaluations (WideDesc::front), and whether they fit behind the chunk buffers
-int wide_front_stage_floats(int F, int I) { return (kWideTile - 1) * F + I + 32 + kWideTile + I / (F > 0 ? F : 1); }   // (+ slack, + the columns' sums of squares)
+int wide_front_stage_floats(int F, int I, int tile) { return (tile - 1) * F + I + 32 + tile + I / (F > 0 ? F : 1); }   // (+ slack, + the columns' sums of squares)
+int wide_front_stage_floats(int F, int I) { return wide_front_stage_floats(F, I, kWideTile); }
 bool wide_front_fits(int F, int I) { return (size_t)wide_front_stage_floats(F, I) * 4 + 2 * kChunkU4Pad * 16 <= 150 * 1024; }
 
 bool wide_prep_is_chain(const NetDesc &n)
@@ -569,6 +574,17 @@ hipError_t launch_wide_gemm(const WideDesc &d, const void *xn, const float *colu
     dim3 grid((unsigned)((NE + kWideTile - 1) / kWideTile));
     if (d.shape16) {                      // the 16x16x32 shape (what ships; the other one under SYLDET_WIDE_SHAPE32=1, with its own packing)
         const bool one16 = d.n_out == 1;
+        // two workgroups of 8 waves a CU (WideDesc::wg8) where the columns under 256 evaluations and the chunk buffers fit twice
+        const bool wg8 = d.wg8 && d.front && one16 && (size_t)wide_front_stage_floats(d.F, d.I, 256) * 4 + 2 * kChunkU4Pad * 16 <= 78 * 1024;
+        if (wg8) {
+            auto k8 = d.sig ? wide_gemm16_kernel<1, true, true, 8> : wide_gemm16_kernel<1, false, true, 8>;
+            if (E <= 0 || NE % E != 0) return hipErrorInvalidValue;
+            const size_t lds8 = 2 * kChunkU4Pad * 16 + (size_t)wide_front_stage_floats(d.F, d.I, 256) * 4;
+            hipError_t st8 = hipFuncSetAttribute((const void *)k8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8);
+            if (st8 != hipSuccess) return st8;
+            hipLaunchKernelGGL(k8, dim3((unsigned)((E + 255) / 256), (unsigned)(NE / E)), dim3(512), lds8, stream, d, (const uint4 *)xn, columns, J, E, NE, outputs, flags);
+            return hipGetLastError();
+        }
         auto k16 = d.front ? (d.sig ? (one16 ? wide_gemm16_kernel<1, true, true> : wide_gemm16_kernel<4, true, true>)
                                     : (one16 ? wide_gemm16_kernel<1, false, true> : wide_gemm16_kernel<4, false, true>))
                            : (d.sig ? (one16 ? wide_gemm16_kernel<1, true, false> : wide_gemm16_kernel<4, true, false>)

@@ -280,3 +280,30 @@ def test_sharded_bank_refuses_to_exist_without_a_device():
     with pytest.raises(sd.SyllableDetectorError) as e:
         ShardedSyllableDetectorBank(util.sample_net(), 8, [0, 1])
     assert e.value.status == _abi.ERR_NO_DEVICE
+
+
+def test_sharded_abi_rejects_bad_arguments_without_touching_a_device():
+    import ctypes as C
+    cfg = util.sample_net()
+    c, keep = cfg.to_abi()
+    h = _abi.Handle()
+    devs = (C.c_int32 * 2)(0, 1)
+    lib = _abi.lib
+    assert lib.syldet_create_sharded(None, 4, devs, 2, 0, 0, C.byref(h)) == _abi.ERR_INVALID_ARGUMENT
+    assert lib.syldet_create_sharded(C.byref(c), 4, None, 2, 0, 0, C.byref(h)) == _abi.ERR_INVALID_ARGUMENT
+    assert lib.syldet_create_sharded(C.byref(c), 0, devs, 2, 0, 0, C.byref(h)) == _abi.ERR_INVALID_ARGUMENT
+    assert lib.syldet_create_sharded(C.byref(c), 4, devs, 0, 0, 0, C.byref(h)) == _abi.ERR_INVALID_ARGUMENT
+    assert lib.syldet_create_sharded(C.byref(c), 4, devs, 2, 0, 7, C.byref(h)) == _abi.ERR_INVALID_ARGUMENT      # unknown exchange
+    assert not h.value
+    # NULL handles: statuses and zeros, never a crash
+    assert lib.syldet_sharded_destroy(None) == 0
+    assert lib.syldet_sharded_channels(None) == 0 and lib.syldet_sharded_shards(None) == 0 and lib.syldet_sharded_rccl_ranks(None) == 0
+    assert lib.syldet_sharded_run(None, None, 0, 0, None, None) == _abi.ERR_INVALID_ARGUMENT
+    assert lib.syldet_sharded_run_device(None, None, 0, None, None, None, None) == _abi.ERR_INVALID_ARGUMENT
+    assert lib.syldet_sharded_synchronize(None) == _abi.ERR_INVALID_ARGUMENT
+    assert not lib.syldet_sharded_bank(None, 0) and not lib.syldet_sharded_stream(None, 0)
+    s = _abi.Shard()
+    assert lib.syldet_sharded_shard(None, 0, C.byref(s)) == _abi.ERR_INVALID_ARGUMENT
+    assert lib.syldet_shard_table(4, 2, None) == _abi.ERR_INVALID_ARGUMENT
+    p = C.c_void_p()
+    assert lib.syldet_host_alloc(16, None) == _abi.ERR_INVALID_ARGUMENT and lib.syldet_host_free(None) == 0
