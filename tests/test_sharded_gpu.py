@@ -168,3 +168,83 @@ def test_pipelined_host_call_on_a_pass_scaled_kernel_stays_inside_the_bar(oracle
     _, wfl, w64 = o.run(x, po.F64)
     util.assert_outputs_close(out[0], w64)
     util.assert_flags_exact(fl[0], w64, cfg.thresholds, cfg.rule)
+
+
+def test_sharded_bank_edge_cases():
+    """Fewer evaluations than time shards (a shard with nothing to do), recordings too short for one evaluation, results only
+    partly asked for, the library's own flag buffers when the caller keeps none."""
+    import ctypes as C
+    torch = _torch()
+    cfg = util.sample_net()
+    hop, W, T = 132, 256, cfg.timeRange
+    # 3 evaluations over 4 time shards of one channel: one shard computes nothing
+    S = W + (T - 1 + 2) * hop + 5
+    x = synth.channels(1, S, first=9)
+    want_out, want_fl = _plain(cfg, x)
+    assert want_out.shape[1] == 3
+    with ShardedSyllableDetectorBank(cfg, 1, [0, 0, 0, 0]) as bank:
+        counts = [bank.ranges(i, S)[3] for i in range(4)]
+        assert sorted(counts) == [0, 1, 1, 1]
+        blocks = bank.scatter(x)
+        outs, fls, alls = bank.run(blocks, S)
+        bank.synchronize()
+        for i in range(4):
+            _, _, e0, cnt = bank.ranges(i, S)
+            assert np.array_equal(outs[i].cpu().numpy(), want_out[:, e0:e0 + cnt])
+            assert np.array_equal(alls[i].cpu().numpy(), want_fl)
+        out_h, fl_h = bank.runHost(x)
+        assert np.array_equal(out_h, want_out) and np.array_equal(fl_h, want_fl)
+        # too short for one evaluation: nothing to do, nothing touched
+        short = synth.channels(1, W + (T - 2) * hop, first=1)
+        o2, f2 = bank.runHost(short)
+        assert o2.shape == (1, 0, 1) and f2.shape == (1, 0)
+    # flags only / outputs only through the host call; the device call without per-shard flag buffers (the exchange uses the library's own)
+    x = synth.channels(5, 40000, first=2)
+    want_out, want_fl = _plain(cfg, x)
+    with ShardedSyllableDetectorBank(cfg, 5, [0, 0]) as bank:
+        E = want_out.shape[1]
+        fl = np.zeros((5, E), np.uint8)
+        assert _abi.lib.syldet_sharded_run(bank._h, x.ctypes.data_as(_abi.c_float_p), x.shape[1], x.shape[1], None, fl.ctypes.data_as(_abi.c_uint8_p)) == 0
+        assert np.array_equal(fl, want_fl)
+        out = np.zeros_like(want_out)
+        assert _abi.lib.syldet_sharded_run(bank._h, x.ctypes.data_as(_abi.c_float_p), x.shape[1], x.shape[1], out.ctypes.data_as(_abi.c_float_p), None) == 0
+        assert np.array_equal(out, want_out)
+        blocks = bank.scatter(x)
+        alls = [torch.empty((5, E), dtype=torch.uint8, device="cuda") for _ in range(2)]
+        arr = lambda ts: (C.c_void_p * 2)(*[t.data_ptr() for t in ts])
+        strides = (C.c_int64 * 2)(*[int(b.stride(0)) for b in blocks])
+        assert _abi.lib.syldet_sharded_run_device(bank._h, arr(blocks), x.shape[1], strides, None, None, arr(alls)) == 0
+        bank.synchronize()
+        assert all(np.array_equal(a.cpu().numpy(), want_fl) for a in alls)
+        # a misaligned gathered-flags pointer is refused, not written through
+        bad = (C.c_void_p * 2)(alls[0].data_ptr() + 1, alls[1].data_ptr())
+        assert _abi.lib.syldet_sharded_run_device(bank._h, arr(blocks), x.shape[1], strides, None, None, bad) == _abi.ERR_INVALID_ARGUMENT
+
+
+@pytest.mark.parametrize("switch", ["SYLDET_FUSED_NOFOLD2", "SYLDET_WIDE_WG16"])
+def test_ab_switches_give_the_same_results(oracle_lib, monkeypatch, switch):
+    """The forms kept behind switches for A/B runs (the once-folded fold kernel; the wide GEMM as one 16-wave workgroup a CU)
+    stay correct: same oracle, same bars."""
+    torch = _torch()
+    if switch == "SYLDET_FUSED_NOFOLD2":
+        cfg, x, gold = util.load_case("case_sample_syllables")
+        x = x[:90000]
+        engine, tol = 0, 1e-5
+    else:
+        cfg = nets.wide_mlp(util.sample_net())
+        x = synth.channel(70000, 4)
+        engine, tol = _abi.ENGINE_WIDE_BF16, 1e-2
+    o = util.oracle_for(cfg)
+    _, wfl, w64 = o.run(x, po.F64)
+    outs = []
+    for on in (False, True):
+        if on:
+            monkeypatch.setenv(switch, "1")
+        with SyllableDetector(cfg, channels=1, device=0, engine=engine) as det:
+            out, fl = det.run(torch.from_numpy(x[None, :]).cuda())
+            torch.cuda.synchronize()
+            out, fl = out.cpu().numpy()[0], fl.cpu().numpy()[0]
+        util.assert_outputs_close(out, w64, tol)
+        util.assert_flags_exact(fl, w64, cfg.thresholds, cfg.rule, tol)
+        outs.append(out)
+    assert np.abs(outs[0] - outs[1]).max() <= 2 * tol
