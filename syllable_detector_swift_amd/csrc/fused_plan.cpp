@@ -105,7 +105,10 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
         else if (k0 == SYLDET_FN_NORMALIZE) { norm = 2; first_affine = 1; }
         else if (k0 == SYLDET_FN_NORMALIZESTD) { norm = 3; first_affine = 1; }
     }
-    if (F > 32) return no("too many bins");
+    // more than 32 bins: only the fold kernel's twice-folded form with two row tiles per parity holds them (W == N == 256, one quad
+    // of hidden units, plain ring: kernels_fused_s.hip, NT = 2); the other fused kernels and tables below are built for 32
+    const bool wide_band = F > 32;
+    if (F > 64 || (wide_band && !(W == 256 && N == 256 && H <= 4 && c.n_layers == 2 && g.hop % 64 != 0))) return no("too many bins");
     if (H > 16) return no("first layer too wide");
     std::vector<double> a((size_t)I, 1.0), b((size_t)I, 0.0);
     for (int k = first_affine; k < c.n_input_fns; k++) {
@@ -150,7 +153,7 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
     d.lds_red = take(64);
     d.lds_cst = take((32 + kMaxFns * 33) * 4);       // thresholds + output maps (kCst* in kernels_fused.hip)
     d.lds_total = off;
-    d.classic_ok = (off <= 160 * 1024 && classic_hop_ok) ? 1 : 0;        // (the register-resident-basis kernel has its own, smaller layout: decided below)
+    d.classic_ok = (off <= 160 * 1024 && classic_hop_ok && !wide_band) ? 1 : 0;        // (the register-resident-basis kernel has its own, smaller layout: decided below)
     {   // the register-resident-basis kernel's own pass geometry and LDS layout
         const int rn = (kFusedRTileFrames - 1) * hop + KS * 32;
         const int rl = (rn / 4 + kFusedRBlock - 1) / kFusedRBlock;
@@ -170,7 +173,7 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
         d.r_lds_red = rtake(64);
         d.r_lds_cst = rtake((32 + kMaxFns * 33) * 4);
         d.r_lds_total = roff;
-        d.r_ok = (rl <= kFusedRMaxLoads && roff <= 160 * 1024) ? 1 : 0;
+        d.r_ok = (rl <= kFusedRMaxLoads && roff <= 160 * 1024 && !wide_band) ? 1 : 0;
     }
 
     // ---- DFT basis fragments: A operand of v_mfma_f32_16x16x32_f16, lane l holds row l&15 of its tile,
@@ -235,7 +238,7 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
             padp = 0;
             chunk_bytes = 1024;
         }
-        const int s_waves = (HQ == 1 || (HQ == 2 && fits(ring_chunks(kFusedSBlock / 64)))) ? kFusedSBlock / 64 : kFusedSBlock / 128;
+        const int s_waves = (!wide_band && (HQ == 1 || (HQ == 2 && fits(ring_chunks(kFusedSBlock / 64))))) ? kFusedSBlock / 64 : kFusedSBlock / 128;
         const int per_wave = 160 * 1024 / s_waves;
         const int RC = ring_chunks(s_waves);
         if (sym && H <= 16 && c.n_layers == 2 && fits(RC)) {
@@ -307,17 +310,21 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
     // 64 registers.  Slot 0 of the real rows (cos 0 = 1) takes the centre sample and the frame's first sample; slot 0 of the odd
     // imaginary rows (sin 0 = 0: free) takes b[N/4] against -sin(pi k / 2); a[N/4] meets the even real rows on the vector side.
     d.s2_ok = 0;
+    d.s2_nt = 1;
     if (d.s_ok && W == 256 && N == 256 && H <= 4) {
         d.s2_ok = 1;
+        const int NT = wide_band ? 2 : 1;                 // row tiles per parity
+        d.s2_nt = NT;
         const int ke0 = g.f0 + (g.f0 & 1), ko0 = g.f0 + 1 - (g.f0 & 1);          // first even / odd bin of the band
         d.s2_pe = ke0 - g.f0;
         d.s2_po = ko0 - g.f0;
-        p.sfrag2.assign((size_t)2 * 4 * 2 * 64 * 8, 0);
+        p.sfrag2.assign((size_t)2 * 4 * NT * 2 * 64 * 8, 0);
         for (int ks = 0; ks < 2; ks++)
             for (int gm = 0; gm < 4; gm++)
+              for (int tau = 0; tau < NT; tau++)
                 for (int l = 0; l < 64; l++)
                     for (int j = 0; j < 8; j++) {
-                        const int r = l & 15, m = 32 * ks + 8 * (l >> 4) + j;
+                        const int r = 16 * tau + (l & 15), m = 32 * ks + 8 * (l >> 4) + j;
                         const int k = ((gm & 1) ? ko0 : ke0) + 2 * r;
                         double v = 0.0;
                         if (k < g.f1) {
@@ -330,7 +337,7 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
                         }
                         uint16_t hi, lo;
                         split_half(v, hi, lo);
-                        const size_t base = ((((size_t)ks * 4 + gm) * 2) * 64 + l) * 8 + j;
+                        const size_t base = (((((size_t)ks * 4 + gm) * NT + tau) * 2) * 64 + l) * 8 + j;
                         p.sfrag2[base] = hi;
                         p.sfrag2[base + 64 * 8] = lo;
                     }
@@ -346,13 +353,14 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
                     p.swin2[((size_t)gq * 16 + ks * 8 + i) * 2 + 0] = (float)w1;
                     p.swin2[((size_t)gq * 16 + ks * 8 + i) * 2 + 1] = (float)w2;
                 }
-        p.s2c.assign((size_t)64 * 8, 0.0f);
+        p.s2c.assign((size_t)64 * 16, 0.0f);                // per lane: cos(pi k / 2) 2^13 of its even rows 4 tau + i, then w[192] at [8]
         for (int l = 0; l < 64; l++) {
-            for (int i = 0; i < 4; i++) {
-                const int k = ke0 + 2 * (4 * (l >> 4) + i);
-                if (k < g.f1) p.s2c[(size_t)l * 8 + i] = (float)(std::cos(two_pi * (double)(((int64_t)k * (N / 4)) % N) / (double)N) * 8192.0);
-            }
-            p.s2c[(size_t)l * 8 + 4] = (float)(0.5 * ((double)win[192] + (double)win[64]));
+            for (int tau = 0; tau < NT; tau++)
+                for (int i = 0; i < 4; i++) {
+                    const int k = ke0 + 2 * (16 * tau + 4 * (l >> 4) + i);
+                    if (k < g.f1) p.s2c[(size_t)l * 16 + 4 * tau + i] = (float)(std::cos(two_pi * (double)(((int64_t)k * (N / 4)) % N) / (double)N) * 8192.0);
+                }
+            p.s2c[(size_t)l * 16 + 8] = (float)(0.5 * ((double)win[192] + (double)win[64]));
         }
     }
 
@@ -409,19 +417,20 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
                     p.afrag_t[(((size_t)m * 2 + 1) * 64 + l) * 8 + j] = lo;
                 }
     // ... in the bin order of the twice-folded result: k = 8 g + j -> band bin 8 g + pe + 2 j (j < 4), 8 g + po + 2 (j - 4) (j >= 4)
-    p.afrag_t2.assign((size_t)3 * 2 * 64 * 8, 0);
+    p.afrag_t2.assign((size_t)3 * d.s2_nt * 2 * 64 * 8, 0);
     if (H <= 4 && d.s2_ok)
         for (int m = 0; m < 3; m++)
+          for (int tau = 0; tau < d.s2_nt; tau++)                 // (one k-step of the tap GEMM per 32 bins)
             for (int l = 0; l < 64; l++)
                 for (int j = 0; j < 8; j++) {
                     const int r = 16 * m + (l & 15), t = r / 4, h = r % 4, gq = l >> 4;
-                    const int bin = j < 4 ? 8 * gq + d.s2_pe + 2 * j : 8 * gq + d.s2_po + 2 * (j - 4);
+                    const int bin = 32 * tau + (j < 4 ? 8 * gq + d.s2_pe + 2 * j : 8 * gq + d.s2_po + 2 * (j - 4));
                     double v = 0.0;
                     if (t < T && h < H && bin < F) v = (double)L0.weights[(size_t)h * I + t * F + bin] * a[(size_t)(t * F + bin)] * wscale;
                     uint16_t hi, lo;
                     split_half(v, hi, lo);
-                    p.afrag_t2[(((size_t)m * 2 + 0) * 64 + l) * 8 + j] = hi;
-                    p.afrag_t2[(((size_t)m * 2 + 1) * 64 + l) * 8 + j] = lo;
+                    p.afrag_t2[((((size_t)m * d.s2_nt + tau) * 2 + 0) * 64 + l) * 8 + j] = hi;
+                    p.afrag_t2[((((size_t)m * d.s2_nt + tau) * 2 + 1) * 64 + l) * 8 + j] = lo;
                 }
     // ... and for 5 .. 16 hidden units (kernels_fused_s.hip, HQ = ceil(H / 4) quads): row tile (m, q), row 4 g + i of it = tap
     // 4 m + g, unit 4 q + i -- lane group g of a result then holds tap 4 m + g for every quad, as with one quad

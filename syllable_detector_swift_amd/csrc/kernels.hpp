@@ -159,6 +159,7 @@ struct FusedDesc {
     // the first even / odd bin (0 and 1 in some order): lane group g of a result holds band bins 8 g + s2_pe + 2 i (even tile
     // rows 4 g + i) and 8 g + s2_po + 2 i (odd tile)
     int s2_ok, s2_pe, s2_po;
+    int s2_nt;                  // row tiles per parity of the twice-folded form: 1 (up to 32 bins) or 2 (33 .. 64 bins: 4 waves a workgroup)
     int no_fold2;               // the handle was created under SYLDET_FUSED_NOFOLD2=1: the once-folded form where both take the shape (A/B runs)
     const uint4 *sfrag2;        // [2 k-steps][Re even, Re odd, Im even, Im odd][hi,lo][64 lanes] A-operand fragments of the twice-folded basis
     const float *swin2;         // [4 lane groups][2 k-steps][8][2] window coefficients w[128 + m], w[m] for m = 32 ks + 8 g + i

@@ -90,7 +90,10 @@ __device__ __forceinline__ void split2(float a, float b, unsigned &hi, unsigned 
 // instead of 48, a basis of 64 registers -- and the window is applied by the lanes in fp32 (fused_plan.cpp, s2_ok).  A lane then
 // folds exactly 64 + 6 samples of its frame, so it reads them from the ring ONCE: the frame's loudest sample is taken from the
 // registers the fold reads (16 ds_read_b128 a tile instead of 32).
-template <int K2, bool GEN, int HQ, int NW, int PADP = 0, bool F2 = false>
+// NT: row tiles per parity of the twice-folded form: 1 (bands of up to 32 bins), or 2 -- bands of up to 64 bins (11 kHz at 44.1 kHz under
+// 256-point frames) stay one launch: 48 + 18 matrix instructions a tile, a basis of 128 registers beside the 70 samples a lane
+// holds, so 4 waves a workgroup, one per SIMD, with 512 registers and twice the LDS each.
+template <int K2, bool GEN, int HQ, int NW, int PADP = 0, bool F2 = false, int NT = 1>
 __global__ void __launch_bounds__(64 * NW, 1)
 fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t stride, int64_t s_eff, int64_t E,
                float *__restrict__ outputs, uint8_t *__restrict__ flags)
@@ -153,34 +156,40 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
     }
     // twice folded: [k-step][Re even bins, Re odd, Im even, Im odd][hi, lo]; the window coefficients w[128 + m], w[m] of the
     // positions m = 32 ks + 8 g + i this lane folds; cos(pi k / 2) 2^13 for its four even bins; w[192]
-    half8 b2[F2 ? 2 : 1][F2 ? 4 : 1][2];
-    float w1c[F2 ? 16 : 1], w2c[F2 ? 16 : 1], ce[4] = {0.f, 0.f, 0.f, 0.f}, w192 = 0.0f;
+    half8 b2[F2 ? 2 : 1][F2 ? 4 * NT : 1][2];        // (row tile tau of GEMM gm: index gm + 4 tau)
+    float w1c[F2 ? 16 : 1], w2c[F2 ? 16 : 1], ce[4 * NT], w192 = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4 * NT; i++) ce[i] = 0.0f;
     if (F2) {
 #pragma unroll
         for (int ks = 0; ks < 2; ks++)
 #pragma unroll
             for (int gm = 0; gm < 4; gm++)
 #pragma unroll
-                for (int p = 0; p < 2; p++)
-                    b2[ks][gm][p] = as_half8(reinterpret_cast<const uint32x4 *>(d.sfrag2)[((ks * 4 + gm) * 2 + p) * 64 + lane]);
+                for (int tau = 0; tau < NT; tau++)
+#pragma unroll
+                    for (int p = 0; p < 2; p++)
+                        b2[ks][gm + 4 * tau][p] = as_half8(reinterpret_cast<const uint32x4 *>(d.sfrag2)[(((ks * 4 + gm) * NT + tau) * 2 + p) * 64 + lane]);
 #pragma unroll
         for (int i = 0; i < 16; i++) {
             w1c[i] = d.swin2[(g * 16 + i) * 2];
             w2c[i] = d.swin2[(g * 16 + i) * 2 + 1];
         }
 #pragma unroll
-        for (int i = 0; i < 4; i++) ce[i] = d.s2c[lane * 8 + i];
-        w192 = d.s2c[lane * 8 + 4];
+        for (int i = 0; i < 4 * NT; i++) ce[i] = d.s2c[lane * 16 + i];       // (tile tau's four even rows: 4 tau + i)
+        w192 = d.s2c[lane * 16 + 8];
     }
     // (row tile 3 q + m... in table order [m][q]: tap 4 m + g, units 4 q .. 4 q + 3 for lane group g of its result)
-    half8 aft[3][HQ][2];
+    half8 aft[3][HQ][NT][2];                          // (twice folded, 64 bins: one k-step of the tap GEMM per 32 bins)
 #pragma unroll
     for (int m = 0; m < 3; m++)
 #pragma unroll
         for (int q = 0; q < HQ; q++)
 #pragma unroll
-            for (int p = 0; p < 2; p++)
-                aft[m][q][p] = as_half8(reinterpret_cast<const uint32x4 *>(F2 ? d.afrag_t2 : (HQ == 1 ? d.afrag_t : d.afrag_w))[((m * HQ + q) * 2 + p) * 64 + lane]);
+            for (int tau = 0; tau < NT; tau++)
+#pragma unroll
+                for (int p = 0; p < 2; p++)
+                    aft[m][q][tau][p] = as_half8(reinterpret_cast<const uint32x4 *>(F2 ? d.afrag_t2 : (HQ == 1 ? d.afrag_t : d.afrag_w))[(((m * HQ + q) * NT + tau) * 2 + p) * 64 + lane]);
     float cre[8];                                     // w[0] cos(pi k W / N) 2^13 for this lane's bins 4 g + i, 16 + 4 g + i
 #pragma unroll
     for (int i = 0; i < 8; i++) cre[i] = F2 ? 0.0f : d.slone[lane * 8 + i];
@@ -277,10 +286,12 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
     const int tf0 = GEN ? d.tf0 : 0, tf1 = GEN ? d.tf1 : 2, norm = GEN ? d.norm : 1;
     const int scaling = GEN ? d.scaling : 0;          // linear |X|, or ln / 20 log10 of it in front of the chain (SyllableDetector.swift:184-212)
     const float klog = scaling == 1 ? 0.6931471805599453f : 6.020599913279624f;      // ln 2, 20 log10 2
-    bool binv[8];                                     // which of this lane's 8 bins are band bins (rows past F are zeros: log 0)
+    bool binv[8 * NT];                                // which of this lane's 8 (16) bins are band bins (rows past F are zeros: log 0)
 #pragma unroll
-    for (int i = 0; i < 8; i++)
-        binv[i] = (F2 ? (i < 4 ? 8 * g + d.s2_pe + 2 * i : 8 * g + d.s2_po + 2 * (i - 4)) : (i < 4 ? 4 * g + i : 16 + 4 * g + (i - 4))) < d.F;
+    for (int i = 0; i < 8 * NT; i++) {
+        const int tau = i >> 3, ii = i & 7;
+        binv[i] = (F2 ? 32 * tau + (ii < 4 ? 8 * g + d.s2_pe + 2 * ii : 8 * g + d.s2_po + 2 * (ii - 4)) : (ii < 4 ? 4 * g + ii : 16 + 4 * g + (ii - 4))) < d.F;
+    }
     const float kmag = pow2f(-13 - d.col_shift);
     const bool guard_on = d.fix.counters != nullptr;
     const float guard_k = norm == 1 ? d.guard_r : (norm == 0 ? d.guard_rel_r : d.guard_range_r);
@@ -394,7 +405,9 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
 
         // ---- the folded DFT: per k-step this lane folds, scales and splits 8 positions of its frame, then 12 MFMAs
         const float xl = fp[0] * sx;                  // the frame's first sample (no partner)
-        floatx4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // re 0-15, re 16-31, im 0-15, im 16-31
+        floatx4 acc[4 * NT];                          // re 0-15, re 16-31, im 0-15, im 16-31 (twice folded: re even, re odd, im even, im odd of row tile tau at 4 tau + ..)
+#pragma unroll
+        for (int i = 0; i < 4 * NT; i++) acc[i] = floatx4{0.f, 0.f, 0.f, 0.f};
         float a64 = 0.0f;                             // twice folded: re even, re odd, im even, im odd; the self-paired position's sum
         const float *xpb = fp + W / 2 + 8 * g, *xmb = fp + W / 2 - 8 * g;
         const float *xmz = xmb + ((PADP && g == 0) ? 4 : 0);     // (the word c - m0 of lane group 0 sits on a piece's first position)
@@ -445,11 +458,11 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
                     vh[3][j] = h; vl[3][j] = l;
                 }
 #pragma unroll
-                for (int gm = 0; gm < 4; gm++) acc[gm] = mfma(b2[ks][gm][0], as_half8(vh[gm]), acc[gm]);
+                for (int gm = 0; gm < 4 * NT; gm++) acc[gm] = mfma(b2[ks][gm][0], as_half8(vh[gm & 3]), acc[gm]);
 #pragma unroll
-                for (int gm = 0; gm < 4; gm++) acc[gm] = mfma(b2[ks][gm][0], as_half8(vl[gm]), acc[gm]);
+                for (int gm = 0; gm < 4 * NT; gm++) acc[gm] = mfma(b2[ks][gm][0], as_half8(vl[gm & 3]), acc[gm]);
 #pragma unroll
-                for (int gm = 0; gm < 4; gm++) acc[gm] = mfma(b2[ks][gm][1], as_half8(vh[gm]), acc[gm]);
+                for (int gm = 0; gm < 4 * NT; gm++) acc[gm] = mfma(b2[ks][gm][1], as_half8(vh[gm & 3]), acc[gm]);
             }
         } else {
 #pragma unroll
@@ -505,7 +518,7 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
         // ---- |X| (zvabs / 2, CircularShortTimeFourierTransform.swift:329-333) of this lane's 8 bins, the frame's sum of squares,
         // the f16 hi + lo split of the column under the frame's own column exponent, the tap products of the first layer.
         // acc holds X 2^(se + 13); cval = |X| 2^(se - col_shift).
-        float cval[8], mss = 0.0f;
+        float cval[8 * NT], mss = 0.0f;
         float cre_l[8];
         if (kTbl) {                                   // (the address passes through an opaque statement: the fetch stays in the loop)
             const float *tp = gtab;
@@ -518,21 +531,22 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
             for (int i = 0; i < 8; i++) cre_l[i] = cre[i];
         }
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
+        for (int i = 0; i < 8 * NT; i++) {
             // once folded: acc = re 0-15, re 16-31, im 0-15, im 16-31, the first sample's real part on top;
-            // twice folded: acc = re even, re odd, im even, im odd, the self-paired position's sum on top of the even real rows
-            const float re = F2 ? (i < 4 ? fmaf(ce[i], a64, acc[0][i]) : acc[1][i & 3]) : fmaf(cre_l[i], xl, acc[i >> 2][i & 3]);
-            const float im = F2 ? (i < 4 ? acc[2][i] : acc[3][i & 3]) : acc[2 + (i >> 2)][i & 3];
+            // twice folded: acc = re even, re odd, im even, im odd (of row tile tau), the self-paired position's sum on top of the even real rows
+            const int tau = i >> 3, ii = i & 7;
+            const float re = F2 ? (ii < 4 ? fmaf(ce[4 * tau + ii], a64, acc[4 * tau][ii]) : acc[4 * tau + 1][ii & 3]) : fmaf(cre_l[ii], xl, acc[ii >> 2][ii & 3]);
+            const float im = F2 ? (ii < 4 ? acc[4 * tau + 2][ii] : acc[4 * tau + 3][ii & 3]) : acc[2 + (ii >> 2)][ii & 3];
             cval[i] = __builtin_amdgcn_sqrtf(fmaf(re, re, im * im)) * kmag;
         }
         if (GEN && scaling != 0) {
             // log / dB columns: |X| = cval 2^(col_shift - se) in true units; v_log_f32 is log2; ln 0 = -inf as in the reference
             const float off = (float)(d.col_shift - se) * klog;
 #pragma unroll
-            for (int i = 0; i < 8; i++) cval[i] = binv[i] ? fmaf(__builtin_amdgcn_logf(cval[i]), klog, off) : 0.0f;
+            for (int i = 0; i < 8 * NT; i++) cval[i] = binv[i] ? fmaf(__builtin_amdgcn_logf(cval[i]), klog, off) : 0.0f;
         }
 #pragma unroll
-        for (int i = 0; i < 8; i++) mss = fmaf(cval[i], cval[i], mss);
+        for (int i = 0; i < 8 * NT; i++) mss = fmaf(cval[i], cval[i], mss);
         mss = xor32_sum(xor16_sum(mss));
         // products and sums of squares are stored relative to the segment's reference exponent (* 2^dsc, * 4^dsc): a window
         // straddles frames of different scales.  Frames 2^45 away from it, and frames the grid cannot hold, condemn their windows.
@@ -546,22 +560,25 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
         tb = (unsigned)min(max((int)tb, 16 << 23), 80 << 23);
         const float fs_up = __uint_as_float((203u << 23) - tb);
         const float fs_ring = __uint_as_float(tb + ((unsigned)(dsc + 51) << 23));
-        uint32x4 bh, bl;
+        uint32x4 bh[NT], bl[NT];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < 4 * NT; j++) {
             unsigned h, l;
             split2(cval[2 * j] * fs_up, cval[2 * j + 1] * fs_up, h, l);
-            bh[j] = h; bl[j] = l;
+            bh[j >> 2][j & 3] = h; bl[j >> 2][j & 3] = l;
         }
-        const half8 vbh = as_half8(bh), vbl = as_half8(bl);
         floatx4 pt[3][HQ];
 #pragma unroll
         for (int m = 0; m < 3; m++)
 #pragma unroll
             for (int q = 0; q < HQ; q++) {
-                pt[m][q] = mfma(aft[m][q][0], vbh, floatx4{0.f, 0.f, 0.f, 0.f});
-                pt[m][q] = mfma(aft[m][q][0], vbl, pt[m][q]);
-                pt[m][q] = mfma(aft[m][q][1], vbh, pt[m][q]);
+                pt[m][q] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int tau = 0; tau < NT; tau++) {
+                    pt[m][q] = mfma(aft[m][q][tau][0], as_half8(bh[tau]), pt[m][q]);
+                    pt[m][q] = mfma(aft[m][q][tau][0], as_half8(bl[tau]), pt[m][q]);
+                    pt[m][q] = mfma(aft[m][q][tau][1], as_half8(bh[tau]), pt[m][q]);
+                }
             }
 #pragma unroll
         for (int m = 0; m < 3; m++)
@@ -574,7 +591,7 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
             if (GEN && norm == 2) {                   // Normalize (NeuralNet.swift:69-96): the frame's smallest and largest band bin
                 float mn = INFINITY, mx = -INFINITY;
 #pragma unroll
-                for (int i = 0; i < 8; i++) {
+                for (int i = 0; i < 8 * NT; i++) {
                     mn = binv[i] ? fminf(mn, cval[i]) : mn;
                     mx = binv[i] ? fmaxf(mx, cval[i]) : mx;
                 }
@@ -591,12 +608,12 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
             } else if (GEN && norm == 3) {            // NormalizeStd (:105-108): the frame's mean and sum of squared deviations
                 float sm = 0.0f;
 #pragma unroll
-                for (int i = 0; i < 8; i++) sm += binv[i] ? cval[i] : 0.0f;
+                for (int i = 0; i < 8 * NT; i++) sm += binv[i] ? cval[i] : 0.0f;
                 sm = xor32_sum(xor16_sum(sm));
                 const float mean = sm / (float)d.F;
                 float m2 = 0.0f;
 #pragma unroll
-                for (int i = 0; i < 8; i++) {
+                for (int i = 0; i < 8 * NT; i++) {
                     const float dl = cval[i] - mean;
                     m2 = binv[i] ? fmaf(dl, dl, m2) : m2;
                 }
@@ -839,11 +856,11 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
 #undef SD_STAMP
 }
 
-template <int K2, bool GEN, int HQ, int NW, int PADP = 0, bool F2 = false>
+template <int K2, bool GEN, int HQ, int NW, int PADP = 0, bool F2 = false, int NT = 1>
 hipError_t launch_one(const FusedDesc &d, const float *samples, int64_t stride, int C, int64_t s_eff, int64_t E,
                       float *outputs, uint8_t *flags, hipStream_t stream)
 {
-    auto kern = fused_s_kernel<K2, GEN, HQ, NW, PADP, F2>;
+    auto kern = fused_s_kernel<K2, GEN, HQ, NW, PADP, F2, NT>;
     constexpr int kWaves = NW;
     const int lds = d.s_lds_wave * kWaves;
     hipError_t st = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -873,6 +890,7 @@ bool fused_s_applicable(const FusedDesc &d)
     // (log / dB columns too: every frame is transformed at its own scale, so a bin's error is relative to its frame, as an fp32
     // FFT's is -- what the logarithm makes of that is the same for both)
     const bool cls = d.norm >= 0 && d.norm <= 3 && d.n_layers == 2 && d.n_out >= 1 && d.n_out <= 4 && d.H <= 16 && d.n_out_fns <= 1;
+    if (d.F > 32 && !(d.s2_ok && d.s2_nt == 2 && !d.no_fold2)) return false;      // (only the twice-folded form holds more than 32 bins)
     return d.s_ok && d.T <= 12 && cls;
 }
 
@@ -911,6 +929,11 @@ hipError_t launch_fused_s(const FusedDesc &d, const float *samples, int64_t stri
     }
 #undef SD_S_PAD
     // W == N == 256, up to four hidden units: the twice-folded instantiation (SYLDET_FUSED_NOFOLD2=1 keeps the once-folded one: A/B runs)
+    if (d.s2_ok && d.s2_nt == 2) {                   // bands of 33 .. 64 bins: the twice-folded form with two row tiles per parity, 4 waves
+        if (d.no_fold2 || d.s_padp) return hipErrorInvalidValue;
+        if (exact) return launch_one<4, false, 1, 4, 0, true, 2>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
+        return launch_one<4, true, 1, 4, 0, true, 2>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
+    }
     if (d.s2_ok && !d.no_fold2 && d.W == 256 && d.H <= 4) {
         if (exact) return launch_one<4, false, 1, 8, 0, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
         return launch_one<4, true, 1, 8, 0, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);

@@ -361,3 +361,71 @@ def test_random_frames_of_four_hops(oracle_lib, seed):
             assert not wide or wide["unexplained"] == 0, "beyond the flat bar where fp32 holds it: %s" % wide
             util.assert_outputs_close(out[c][ok], w64[ok], tol)
             util.assert_flags_exact(fl[c][ok], w64[ok], cfg.thresholds, cfg.rule, tol)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SYLDET_FUZZ_DRAWS_WIDE", "16"))))
+def test_random_wide_band_detector(oracle_lib, seed):
+    """Bands of 33 .. 64 bins under 256-point frames (kernels_fused_s.hip, two row tiles per parity, 4 waves a workgroup): random
+    bands, hops, timeRanges, window types, networks of the example class (and a few with other transfer functions / several
+    outputs), lengths around the wave segments, level steps of up to 50 dB -- against the fp64 anchor at the flat bar, with the
+    same evidence rule as the other sweeps."""
+    import torch
+    rng = np.random.default_rng(52000 + seed)
+    hop = int(rng.choice([32, 48, 68, 84, 100, 116, 124, 132, 132, 136, 140, 160, 180]))
+    N = W = 256
+    F = int(rng.integers(33, 65))
+    f0 = int(rng.integers(0, N // 2 - F + 1))
+    lo, hi = max((f0 - 0.4) * FS / N, 0.0), (f0 + F - 1 + 0.4) * FS / N
+    r = frequencyIndexRange(N, FS, lo, hi)
+    F = r[1] - r[0]
+    T = int(rng.integers(1, 13))
+    n_out = 1 if rng.random() < 0.7 else int(rng.integers(2, 5))
+    exact = rng.random() < 0.6
+    net = nets.random_net(rng, F * T, (int(rng.integers(1, 5)),), n_out,
+                          transfer=("TanSig", "PureLin") if exact else (["TanSig", "LogSig", "SatLin"][int(rng.integers(0, 3))], ["PureLin", "TanSig"][int(rng.integers(0, 2))]),
+                          in_fns=[("l2normalize",), ("l2normalize", "mapminmax"), ("l2normalize", "mapstd"), ("normalize",), ("normalizestd", "mapminmax")][int(rng.integers(0, 3 if exact else 5))],
+                          out_fns=[(), ("mapminmax",), ("mapstd",)][int(rng.integers(0, 3))])
+    cfg = SyllableDetectorConfig(FS, N, W, W - hop, (lo, hi), T, "linear", [float(t) for t in rng.uniform(-0.5, 0.8, n_out)], net,
+                                 window=int(rng.integers(0, 4)), spectrum=_abi.SPECTRUM_POWER, rule=int(rng.integers(0, 2)))
+    if not (32 < F <= 64):
+        pytest.skip("the band's bins fell outside 33 .. 64")
+    edges = [T, 15, 16, 17, 31, 32, 33, 63, 64, 65, 250, 1000, 3000]
+    frames = max(T, int(edges[seed % len(edges)]))
+    S = W + (frames - 1) * hop + int(rng.integers(0, hop))
+    C = int(rng.integers(1, 4))
+    x = synth.channels(C, S, first=seed * 11, fs=FS) * float(10.0 ** rng.uniform(-3, 1))
+    if rng.random() < 0.6:
+        env = np.ones(S)
+        for _ in range(int(rng.integers(1, 4))):
+            env[int(rng.integers(0, S)):] *= float(10.0 ** rng.uniform(-2.5, 2.5))
+        x = x * np.clip(env, 1e-3, 1e3)[None, :]
+    x = x.astype(np.float32)
+    o = util.oracle_for(cfg)
+    with sd.SyllableDetector(cfg, channels=C) as det:
+        det.profile(True)
+        out, fl = det.run(torch.from_numpy(x).cuda())
+        torch.cuda.synchronize()
+        names = [nm for nm, _ in det.lastTimings()]
+        # (hops that are multiples of 64 have no padded form with two row tiles: the generic engine keeps them)
+        assert names == ["fused_s_kernel"] or hop % 64 == 0, names
+        out, fl = out.cpu().numpy(), fl.cpu().numpy()
+    for c in range(C):
+        _, _, w64 = o.run(x[c], po.F64, cfg.rule)
+        w32 = o.run(x[c], po.F32, cfg.rule)[0]
+        ok = np.isfinite(w64).all(axis=1)
+        own = float((np.abs(w32[ok] - w64[ok]) / np.maximum(1.0, np.abs(w64[ok]))).max()) if ok.any() else 0.0
+        assert (np.isfinite(out[c]).all(axis=1) == ok).all(), "NaN/inf evaluations must coincide"
+        flat = max(util.TOL, 4.0 * own)
+        names_in = [f.function for f in cfg.net.inputProcessing]
+        kappa = util.band_condition(o, cfg, x[c]) if names_in[:1] == ["l2normalize"] else np.ones(w64.shape[0])
+        tol = np.maximum(flat, 2.0 ** -21 * kappa)[ok]
+        if ok.any():
+            err = (np.abs(out[c][ok] - w64[ok]) / np.maximum(1.0, np.abs(w64[ok]))).max(axis=1)
+            own_e = (np.abs(w32[ok] - w64[ok]) / np.maximum(1.0, np.abs(w64[ok]))).max(axis=1)
+            own_e = np.array([own_e[max(0, e - cfg.timeRange + 1): e + cfg.timeRange].max() for e in range(len(own_e))])
+            wide = util.widened_evaluations(err, own_e, util.TOL, tol, 2.0 ** -23 * kappa[ok] if names_in[:1] == ["l2normalize"] else None)
+            util.sweep_record("bands of 33 to 64 bins", seed, names[0], err.max(), own, flat, (err / tol).max(), "kappa" if (err > flat).any() else "", wide)
+            assert not wide or wide["unexplained"] == 0, "beyond the flat bar where fp32 holds it: %s" % wide
+            util.assert_outputs_close(out[c][ok], w64[ok], tol)
+            util.assert_flags_exact(fl[c][ok], w64[ok], cfg.thresholds, cfg.rule, tol)
+        assert not fl[c][~ok].any()

@@ -35,3 +35,57 @@ def test_rows_past_2_gib_leave_the_fused_route_where_only_the_fold_kernel_holds_
             assert not any(nm.startswith("fused") for nm in names), names
         v = spotcheck.check(det, cfg, x, out, fl, [0], width=96)
         assert v["max_error"] <= 1e-5
+
+
+@pytest.mark.parametrize("lo,hi,hop,T,kind", [(1000.0, 11000.0, 132, 10, "exact"), (2000.0, 7600.0, 132, 10, "exact"), (0.0, 10900.0, 100, 5, "gen"),
+                                               (3000.0, 10000.0, 68, 12, "db"), (500.0, 11000.0, 132, 3, "multi")])
+def test_bands_of_up_to_64_bins_stay_one_launch(oracle_lib, lo, hi, hop, T, kind, monkeypatch):
+    """A band wider than 5.5 kHz at 44.1 kHz under 256-point frames is more than 32 bins: the fold kernel's twice-folded form
+    takes up to 64 (two row tiles per parity, 4 waves a workgroup) instead of the two launches of the generic engine
+    (frequencyIndexRange, CircularShortTimeFourierTransform.swift:166-191: (1000, 11000) Hz is bins [6, 64))."""
+    import torch
+    from syllable_detector_swift_amd.config import frequencyIndexRange
+    import pyoracle as po
+    base = util.sample_net()
+    f0, f1 = frequencyIndexRange(256, 44100.0, lo, hi)
+    F = f1 - f0
+    assert 32 < F <= 64
+    rng = np.random.default_rng(int(lo + hi + hop))
+    if kind == "exact":
+        net = nets.random_net(rng, F * T, (4,), 1)
+    elif kind == "gen":
+        net = nets.random_net(rng, F * T, (3,), 1, transfer=("LogSig", "SatLin"), in_fns=("normalizestd", "mapstd"))
+    elif kind == "db":
+        net = nets.random_net(rng, F * T, (4,), 1, in_fns=("l2normalize",))
+    else:
+        net = nets.random_net(rng, F * T, (2,), 3, in_fns=("l2normalize", "mapminmax"), out_fns=("mapminmax",))
+    cfg = nets.variant(base, freqRange=(lo, hi), windowOverlap=256 - hop, timeRange=T, net=net,
+                       thresholds=[0.4] * net.layers[-1].outputs, spectrogramScaling="db" if kind == "db" else "linear",
+                       rule=_abi.RULE_ANY if kind == "multi" else _abi.RULE_FIRST)
+    C = 2
+    x = (synth.channels(C, 256 + 2500 * hop + 17, first=21) * np.array([[1.0], [3e-3]])).astype(np.float32)
+    x[1, 100000:] *= np.float32(300.0)                            # a level step: every frame has its own scale
+    o = util.oracle_for(cfg)
+    with SyllableDetector(cfg, channels=C, device=0) as det:
+        assert det.geometry.engine == _abi.ENGINE_FUSED and det.geometry.bins == F
+        det.profile(True)
+        out, fl = det.run(torch.from_numpy(x).cuda())
+        torch.cuda.synchronize()
+        assert [nm for nm, _ in det.lastTimings()] == ["fused_s_kernel"]
+        assert det.fixupStats() == (0, 0)
+        out, fl = out.cpu().numpy(), fl.cpu().numpy()
+    for c in range(C):
+        _, _, w64 = o.run(x[c], po.F64, cfg.rule)
+        w32 = o.run(x[c], po.F32, cfg.rule)[0]
+        own = float(np.abs(w32 - w64).max())
+        tol = max(1e-5, 4 * own) if kind != "db" else max(1e-4, 30 * own)
+        util.assert_outputs_close(out[c], w64, tol)
+        util.assert_flags_exact(fl[c], w64, cfg.thresholds, cfg.rule, tol)
+    # ... and with the second fold switched off such a band is the generic engine's (nothing else holds 64 bins)
+    monkeypatch.setenv("SYLDET_FUSED_NOFOLD2", "1")
+    with SyllableDetector(cfg, channels=C, device=0) as det:
+        det.profile(True)
+        out2, _ = det.run(torch.from_numpy(x).cuda())
+        torch.cuda.synchronize()
+        assert not any(nm.startswith("fused_s") for nm, _ in det.lastTimings())
+        assert np.abs(out2.cpu().numpy() - out).max() <= (2e-5 if kind != "db" else 2e-4)
