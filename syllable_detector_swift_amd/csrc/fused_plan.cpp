@@ -311,7 +311,7 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
     // imaginary rows (sin 0 = 0: free) takes b[N/4] against -sin(pi k / 2); a[N/4] meets the even real rows on the vector side.
     d.s2_ok = 0;
     d.s2_nt = 1;
-    if (d.s_ok && W == 256 && N == 256 && H <= 4) {
+    if (d.s_ok && W == 256 && N == 256 && H <= 16 && c.n_layers == 2) {
         d.s2_ok = 1;
         const int NT = wide_band ? 2 : 1;                 // row tiles per parity
         d.s2_nt = NT;
@@ -432,6 +432,25 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
                     p.afrag_t2[((((size_t)m * d.s2_nt + tau) * 2 + 0) * 64 + l) * 8 + j] = hi;
                     p.afrag_t2[((((size_t)m * d.s2_nt + tau) * 2 + 1) * 64 + l) * 8 + j] = lo;
                 }
+    // ... the wider layers' fragments (afrag_w below) in that bin order
+    {
+        const int HQ = (H + 3) / 4;
+        p.afrag_w2.assign((size_t)3 * HQ * 2 * 64 * 8, 0);
+        if (HQ > 1 && d.s2_ok && d.s2_nt == 1)
+            for (int m = 0; m < 3; m++)
+                for (int q = 0; q < HQ; q++)
+                    for (int l = 0; l < 64; l++)
+                        for (int j = 0; j < 8; j++) {
+                            const int r = l & 15, t = 4 * m + r / 4, h = 4 * q + r % 4, gq = l >> 4;
+                            const int bin = j < 4 ? 8 * gq + d.s2_pe + 2 * j : 8 * gq + d.s2_po + 2 * (j - 4);
+                            double v = 0.0;
+                            if (t < T && h < H && bin < F) v = (double)L0.weights[(size_t)h * I + t * F + bin] * a[(size_t)(t * F + bin)] * wscale;
+                            uint16_t hi, lo;
+                            split_half(v, hi, lo);
+                            p.afrag_w2[((((size_t)m * HQ + q) * 2 + 0) * 64 + l) * 8 + j] = hi;
+                            p.afrag_w2[((((size_t)m * HQ + q) * 2 + 1) * 64 + l) * 8 + j] = lo;
+                        }
+    }
     // ... and for 5 .. 16 hidden units (kernels_fused_s.hip, HQ = ceil(H / 4) quads): row tile (m, q), row 4 g + i of it = tap
     // 4 m + g, unit 4 q + i -- lane group g of a result then holds tap 4 m + g for every quad, as with one quad
     {

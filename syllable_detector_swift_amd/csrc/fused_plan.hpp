@@ -18,7 +18,7 @@ struct FusedPlan {
     std::vector<uint16_t> afrag, afrag_t, afrag_w;
     std::vector<uint16_t> sfrag;     // the folded basis of the symmetric-fold kernel
     std::vector<float> slone;
-    std::vector<uint16_t> sfrag2, afrag_t2;   // the second-fold instantiation's basis and first layer
+    std::vector<uint16_t> sfrag2, afrag_t2, afrag_w2;   // the second-fold instantiation's basis and first layer
     std::vector<float> swin2, s2c;
     std::vector<int> koff;
     std::vector<float> bias0, rvec, w1, b1, out_params;

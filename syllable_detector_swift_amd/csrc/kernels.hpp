@@ -165,6 +165,7 @@ struct FusedDesc {
     const float *swin2;         // [4 lane groups][2 k-steps][8][2] window coefficients w[128 + m], w[m] for m = 32 ks + 8 g + i
     const float *s2c;           // [64 lanes][8]: cos(pi k / 2) 2^13 for the lane's four even bins, w[192], padding
     const uint4 *afrag_t2;      // afrag_t in the bin order of the twice-folded result
+    const uint4 *afrag_w2;      // afrag_w in that order (5 .. 16 hidden units)
     const uint4 *sfrag;         // [W/64 k-steps][s, d][bins 0-15, 16-31][hi,lo][64 lanes] A-operand fragments of the folded basis
     const uint4 *afrag_w;       // [3][HQ quads of hidden units][hi,lo][64 lanes] the first layer with all taps as rows for 5 .. 16 units
     const float *slone;         // [64 lanes][8] the frame's first sample's real coefficients for the lane's bins

@@ -189,7 +189,7 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
             for (int tau = 0; tau < NT; tau++)
 #pragma unroll
                 for (int p = 0; p < 2; p++)
-                    aft[m][q][tau][p] = as_half8(reinterpret_cast<const uint32x4 *>(F2 ? d.afrag_t2 : (HQ == 1 ? d.afrag_t : d.afrag_w))[(((m * HQ + q) * NT + tau) * 2 + p) * 64 + lane]);
+                    aft[m][q][tau][p] = as_half8(reinterpret_cast<const uint32x4 *>(F2 ? (HQ == 1 ? d.afrag_t2 : d.afrag_w2) : (HQ == 1 ? d.afrag_t : d.afrag_w))[(((m * HQ + q) * NT + tau) * 2 + p) * 64 + lane]);
     float cre[8];                                     // w[0] cos(pi k W / N) 2^13 for this lane's bins 4 g + i, 16 + 4 g + i
 #pragma unroll
     for (int i = 0; i < 8; i++) cre[i] = F2 ? 0.0f : d.slone[lane * 8 + i];
@@ -934,7 +934,16 @@ hipError_t launch_fused_s(const FusedDesc &d, const float *samples, int64_t stri
         if (exact) return launch_one<4, false, 1, 4, 0, true, 2>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
         return launch_one<4, true, 1, 4, 0, true, 2>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
     }
-    if (d.s2_ok && !d.no_fold2 && d.W == 256 && d.H <= 4) {
+    if (d.s2_ok && !d.no_fold2 && d.W == 256) {       // (5 .. 16 hidden units too: the halved basis and the single pass do not depend on the layer's width)
+        if (d.H > 12) return launch_one<4, true, 4, 4, 0, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
+        if (d.H > 8) return launch_one<4, true, 3, 4, 0, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
+        // (5 .. 8 hidden units on eight waves stay once-folded: with two accumulator sets AND the kept samples the twice-folded
+        // form spills at 256 registers and measures 10 % slower there -- except under hops that are multiples of 64, where
+        // reading the ring once (its rows then collide on the banks: there is no padded ring for wider layers) is worth 15 %;
+        // MEASUREMENTS.md R4.8)
+        if (d.H > 4 && d.s_waves == 8 && d.hop % 64 == 0) return launch_one<4, true, 2, 8, 0, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
+        if (d.H > 4 && d.s_waves == 8) return launch_one<4, true, 2, 8>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
+        if (d.H > 4) return launch_one<4, true, 2, 4, 0, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
         if (exact) return launch_one<4, false, 1, 8, 0, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
         return launch_one<4, true, 1, 8, 0, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
     }

@@ -425,6 +425,7 @@ int upload_plan(syldet *h, FusedPlan &p, DeviceBuffer &buf)
     const size_t o_ww = put(p.afrag_w.data(), p.afrag_w.size() * 2);
     const size_t o_s2 = put(p.sfrag2.data(), p.sfrag2.size() * 2), o_w2 = put(p.swin2.data(), p.swin2.size() * 4);
     const size_t o_c2 = put(p.s2c.data(), p.s2c.size() * 4), o_t2 = put(p.afrag_t2.data(), p.afrag_t2.size() * 2);
+    const size_t o_x2 = put(p.afrag_w2.data(), p.afrag_w2.size() * 2);
     if (int st = buf.reserve(blob.size())) return st;
     SYLDET_HIP(hipMemcpy(buf.ptr, blob.data(), blob.size(), hipMemcpyHostToDevice));
     unsigned char *base = (unsigned char *)buf.ptr;
@@ -439,6 +440,7 @@ int upload_plan(syldet *h, FusedPlan &p, DeviceBuffer &buf)
     d.swin2 = (const float *)(base + o_w2);
     d.s2c = (const float *)(base + o_c2);
     d.afrag_t2 = (const uint4 *)(base + o_t2);
+    d.afrag_w2 = (const uint4 *)(base + o_x2);
     d.koff = (const int *)(base + o_k);
     d.bias0 = (const float *)(base + o_b);
     d.rvec = (const float *)(base + o_r);

@@ -89,3 +89,49 @@ def test_bands_of_up_to_64_bins_stay_one_launch(oracle_lib, lo, hi, hop, T, kind
         torch.cuda.synchronize()
         assert not any(nm.startswith("fused_s") for nm, _ in det.lastTimings())
         assert np.abs(out2.cpu().numpy() - out).max() <= (2e-5 if kind != "db" else 2e-4)
+
+
+@pytest.mark.parametrize("H,n_out,hop,T,chain", [(5, 1, 132, 12, ("l2normalize",)), (8, 1, 128, 10, ("l2normalize",)), (8, 2, 64, 12, ("l2normalize", "mapstd")),
+                                                  (9, 1, 132, 10, ("l2normalize",)), (12, 4, 100, 8, ("normalizestd",)),
+                                                  (13, 1, 132, 10, ("l2normalize", "mapminmax")), (16, 4, 132, 10, ("l2normalize",)),
+                                                  (16, 1, 68, 5, ("normalize", "mapstd"))])
+def test_five_to_sixteen_hidden_units_on_the_twice_folded_form(oracle_lib, H, n_out, hop, T, chain, monkeypatch):
+    """The reference's network class has no limit on the hidden layer (NeuralNet.swift:155-170: any layer sizes); the fold
+    kernel takes up to 16 units as one to four accumulator sets, and 256-point frames under a 256-sample window run twice-folded
+    for every set count that keeps its registers (four waves: 9 .. 16 units, and 5 .. 8 where the ring leaves room for four
+    waves only).  Both forms against the fp64 anchor, and against each other."""
+    import torch
+    import pyoracle as po
+    base = util.sample_net()
+    from syllable_detector_swift_amd.config import frequencyIndexRange
+    f0, f1 = frequencyIndexRange(256, base.samplingRate, *base.freqRange)
+    F = f1 - f0
+    rng = np.random.default_rng(9000 + 16 * H + hop)
+    net = nets.random_net(rng, F * T, (H,), n_out, in_fns=chain)
+    cfg = nets.variant(base, windowOverlap=256 - hop, timeRange=T, net=net, thresholds=[0.3] * n_out,
+                       rule=_abi.RULE_ANY if n_out > 1 else _abi.RULE_FIRST)
+    C = 3
+    x = (synth.channels(C, 256 + 3100 * hop + 29, first=5) * np.array([[1.0], [2e-3], [40.0]])).astype(np.float32)
+    x[1, 150000:] *= np.float32(500.0)
+    o = util.oracle_for(cfg)
+    xd = torch.from_numpy(x).cuda()
+    res = {}
+    for form in ("twice", "once"):
+        if form == "once":
+            monkeypatch.setenv("SYLDET_FUSED_NOFOLD2", "1")
+        with SyllableDetector(cfg, channels=C, device=0) as det:
+            assert det.geometry.engine == _abi.ENGINE_FUSED
+            det.profile(True)
+            out, fl = det.run(xd)
+            torch.cuda.synchronize()
+            names = [nm for nm, _ in det.lastTimings()]
+            assert names and all(nm.startswith("fused") for nm in names), names
+            res[form] = (out.cpu().numpy(), fl.cpu().numpy(), names)
+    for c in range(C):
+        _, _, w64 = o.run(x[c], po.F64, cfg.rule)
+        w32 = o.run(x[c], po.F32, cfg.rule)[0]
+        own = float((np.abs(w32 - w64) / np.maximum(1.0, np.abs(w64))).max())
+        tol = max(1e-5, 4 * own)
+        for form in res:
+            util.assert_outputs_close(res[form][0][c], w64, tol)
+            util.assert_flags_exact(res[form][1][c], w64, cfg.thresholds, cfg.rule, tol)
