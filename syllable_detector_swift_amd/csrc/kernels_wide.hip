@@ -32,6 +32,7 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 constexpr int kBlock = kWideBlock;            // 1024 threads = 16 waves
 constexpr int kWave = 64;
+typedef __attribute__((address_space(3))) void lds_void;
 constexpr int kKSteps = kWideK / 16;          // 20 k-steps of 16
 constexpr int kChunkU4 = kWideChunkBytes / 16;     // 1320
 constexpr int kChunkU4Pad = 21 * 64;               // an LDS buffer holds whole 64-element spans (the DMA writes base + 16 lane)
@@ -367,7 +368,8 @@ wide_gemm16_kernel(WideDesc d, const uint4 *__restrict__ xn, const float *__rest
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int kWaves = NWV, kK2 = kWideK / 32, kBl = 64 * NWV, kTl = 32 * NWV;
     uint4 *buf0 = reinterpret_cast<uint4 *>(smem), *buf1 = buf0 + kChunkU4Pad;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (a scalar: the DMA's LDS base and span tests stay out of the vector registers)
     const int n = lane & 15, g = lane >> 4;
     // FRONT: a workgroup's 512 evaluations are consecutive ones of ONE channel (grid y), so the columns under them are one
     // stretch of 511 F + I floats, staged through LDS once; otherwise evaluations are numbered through all channels
@@ -446,24 +448,32 @@ wide_gemm16_kernel(WideDesc d, const uint4 *__restrict__ xn, const float *__rest
     for (int t = 0; t < 2; t++)
 #pragma unroll
         for (int o = 0; o < NOUT; o++) ysum[t][o] = 0.0f;
+    // (a buffer resource over the packed weights: a lane's address is one 32-bit offset, the chunk's a scalar)
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const uint64_t wp = (uint64_t)(uintptr_t)d.wpack;
+    const u32x4 w_rs4 = {(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)wp), (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(wp >> 32)) & 0xffffu,
+                         (unsigned)(d.n_chunks * kChunkU4 * 16), 0x00020000u};
     auto fetch_chunk = [&](int ch, uint4 *dst) {
 #pragma unroll
         for (int j = 0; j < (21 + kWaves - 1) / kWaves; j++) {
             const int i0 = (wave + kWaves * j) * 64;
             if (i0 < kChunkU4) {
                 const int i = i0 + lane < kChunkU4 ? i0 + lane : kChunkU4 - 1;
-                __builtin_amdgcn_global_load_lds(d.wpack + (size_t)ch * kChunkU4 + i, dst + i0, 16, 0, 0);
+                // (written out: behind the builtin the compiler takes the DMA for a store that may alias every later LDS read and
+                // waits for it -- vmcnt(0) -- before the chunk's first ds_read, i.e. for the NEXT chunk's bytes at the top of
+                // every chunk.  The wait that matters is the explicit one before the barrier.)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"                       // ("clobber list contains reserved registers: m0" -- it does, on purpose)
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                             :: "s"((unsigned)(uintptr_t)(dst + i0)), "v"((unsigned)i * 16u), "s"(w_rs4), "s"((unsigned)ch * (unsigned)(kChunkU4 * 16))
+                             : "memory", "m0");
+#pragma clang diagnostic pop
             }
         }
     };
-    fetch_chunk(0, buf0);
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    __syncthreads();
-    for (int ch = 0; ch < d.n_chunks; ch++) {
-        const uint4 *cur = (ch & 1) ? buf1 : buf0;
-        if (ch + 1 < d.n_chunks) fetch_chunk(ch + 1, (ch & 1) ? buf0 : buf1);
+    // a chunk: 20 MFMAs a tile pair from the chunk's fragments in LDS; then the hidden values and their share of the outputs
+    auto multiply = [&](const uint4 *cur, floatx4w (&acc)[2][2]) {
         const float *cst = reinterpret_cast<const float *>(cur + kKSteps * 64);
-        floatx4w acc[2][2];                                       // [unit tile][evaluation tile]: register i = unit 16 ut + 4 g + i
 #pragma unroll
         for (int ut = 0; ut < 2; ut++) {
             const float4 b0 = *reinterpret_cast<const float4 *>(cst + 16 * ut + 4 * g);
@@ -475,11 +485,15 @@ wide_gemm16_kernel(WideDesc d, const uint4 *__restrict__ xn, const float *__rest
             union { uint4 u; bf16x8 v; } a0, a1;
             a0.u = cur[(2 * ks + 0) * 64 + lane];
             a1.u = cur[(2 * ks + 1) * 64 + lane];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0.v, B[0][ks], acc[0][0], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1.v, B[0][ks], acc[1][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0.v, B[1][ks], acc[0][1], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1.v, B[1][ks], acc[1][1], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0.v, B[t][ks], acc[0][t], 0, 0, 0);
+                acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1.v, B[t][ks], acc[1][t], 0, 0, 0);
+            }
         }
+    };
+    auto finish = [&](const uint4 *cur, floatx4w (&acc)[2][2]) {
+        const float *cst = reinterpret_cast<const float *>(cur + kKSteps * 64);
 #pragma unroll
         for (int ut = 0; ut < 2; ut++) {
 #pragma unroll
@@ -499,6 +513,16 @@ wide_gemm16_kernel(WideDesc d, const uint4 *__restrict__ xn, const float *__rest
                 }
             }
         }
+    };
+    fetch_chunk(0, buf0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+    for (int ch = 0; ch < d.n_chunks; ch++) {
+        const uint4 *cur = (ch & 1) ? buf1 : buf0;
+        if (ch + 1 < d.n_chunks) fetch_chunk(ch + 1, (ch & 1) ? buf0 : buf1);
+        floatx4w acc[2][2];                                       // [unit tile][evaluation tile]: register i = unit 16 ut + 4 g + i
+        multiply(cur, acc);
+        finish(cur, acc);
         __builtin_amdgcn_s_waitcnt(0x0F70);
         __syncthreads();
     }

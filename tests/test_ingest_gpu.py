@@ -125,7 +125,8 @@ WIDE_TOL = 1e-2      # bf16 inputs and first-layer weights (8-bit significands),
 
 
 @pytest.mark.parametrize("shape", ["config5", "H96_3out_logsig", "H40_normalize", "H72_2out_satlin", "config5_shape32", "config5_prepared",
-                                   "H64_affine_only", "H48_two_maps", "H64_narrow_range_maps"])
+                                   "H64_affine_only", "H48_two_maps", "H64_narrow_range_maps", "H32_one_chunk", "H96_three_chunks",
+                                   "H128_four_chunks"])
 def test_wide_network_bf16_mfma_engine(oracle_lib, shape, monkeypatch):
     """The opt-in wide engine (first layer as a bf16 MFMA GEMM over thousands of evaluations) against the fp64 anchor,
     to bf16's bar; flags wherever the anchor is farther than that from the threshold.  The four instantiations of the
@@ -145,6 +146,9 @@ def test_wide_network_bf16_mfma_engine(oracle_lib, shape, monkeypatch):
     elif shape == "H96_3out_logsig":
         cfg = nets.variant(base, net=nets.random_net(rng, 290, (96,), 3, transfer=("LogSig", "TanSig")), thresholds=[0.1, 0.2, 0.3],
                            rule=_abi.RULE_ANY)
+    elif shape in ("H32_one_chunk", "H96_three_chunks", "H128_four_chunks"):
+        # one, three and four chunks of 32 hidden units through the two chunk buffers (config5 has 128, the others two or three)
+        cfg = nets.variant(base, net=nets.random_net(rng, 290, (int(shape[1:shape.index("_")]),), 1))
     elif shape == "H64_affine_only":                     # (no normaliser: the columns themselves, x 30 so that they are not all tiny)
         cfg = nets.variant(base, net=nets.random_net(rng, 290, (64,), 1, in_fns=("mapstd",)))
     elif shape == "H48_two_maps":

@@ -440,6 +440,23 @@ def test_other_baseline_workloads_at_full_size(oracle_lib, workload):
             assert worst > 1e-7, "bf16 rounding should be visible: is the wide engine really running?"
 
 
+def test_wide_engine_is_reproducible_at_full_size():
+    """BASELINE configs[4] at the benchmark's size, three times: bit-identical outputs and flags.  A grid of sixty rounds of
+    workgroups is where a race between a workgroup's waves shows -- round 4's staggered GEMM was bit-identical at test sizes
+    and differed in 1-10 % of the evaluations here (MEASUREMENTS.md R4.6)."""
+    torch = _torch()
+    cfg, C, S = nets.wide_mlp(nets.from_npz()), 64, 1 << 24
+    x = synth.channels_on_device(C, S, "cuda", fs=cfg.samplingRate)
+    with sd.SyllableDetector(cfg, channels=C, engine=_abi.ENGINE_WIDE_BF16) as det:
+        out0, fl0 = det.run(x)
+        torch.cuda.synchronize()
+        out0, fl0 = out0.clone(), fl0.clone()
+        for _ in range(2):
+            out, fl = det.run(x)
+            torch.cuda.synchronize()
+            assert torch.equal(out, out0) and torch.equal(fl, fl0)
+
+
 def test_wide_hidden_layer_on_auto_keeps_its_spectrogram_front(oracle_lib):
     """A 290 -> 5000 -> 1 network under AUTO runs on the generic engine behind the fused DFT front half; the exact
     recomputation behind that front half handles frames only and must not count the network's LDS buffers (4 waves x 2 x
