@@ -440,14 +440,29 @@ def test_other_baseline_workloads_at_full_size(oracle_lib, workload):
             assert worst > 1e-7, "bf16 rounding should be visible: is the wide engine really running?"
 
 
-def test_wide_engine_is_reproducible_at_full_size():
-    """BASELINE configs[4] at the benchmark's size, three times: bit-identical outputs and flags.  A grid of sixty rounds of
-    workgroups is where a race between a workgroup's waves shows -- round 4's staggered GEMM was bit-identical at test sizes
-    and differed in 1-10 % of the evaluations here (MEASUREMENTS.md R4.6)."""
+@pytest.mark.parametrize("workload", ["sample", "hop128", "wide_band", "config3", "config5"])
+def test_full_size_runs_are_reproducible(workload):
+    """The benchmark's batches three times each: bit-identical outputs and flags.  A grid of many rounds of workgroups is
+    where a race between a workgroup's waves shows -- round 4's staggered wide GEMM was bit-identical at test sizes and
+    differed in 1-10 % of the evaluations at this one (MEASUREMENTS.md R4.6)."""
     torch = _torch()
-    cfg, C, S = nets.wide_mlp(nets.from_npz()), 64, 1 << 24
+    base = nets.from_npz()
+    engine = _abi.ENGINE_AUTO
+    if workload == "config3":
+        cfg, C, S = nets.config3(), 512, 1 << 21
+    elif workload == "config5":
+        cfg, C, S, engine = nets.wide_mlp(base), 64, 1 << 24, _abi.ENGINE_WIDE_BF16
+    elif workload == "hop128":
+        cfg, C, S = nets.variant(base, windowOverlap=128), 64, 1 << 24
+    elif workload == "wide_band":
+        from syllable_detector_swift_amd.config import frequencyIndexRange
+        f0, f1 = frequencyIndexRange(256, base.samplingRate, 1000.0, 11000.0)
+        net = nets.random_net(np.random.default_rng(11), (f1 - f0) * 10, (4,), 1)
+        cfg, C, S = nets.variant(base, freqRange=(1000.0, 11000.0), net=net), 64, 1 << 24
+    else:
+        cfg, C, S = base, 64, 1 << 24
     x = synth.channels_on_device(C, S, "cuda", fs=cfg.samplingRate)
-    with sd.SyllableDetector(cfg, channels=C, engine=_abi.ENGINE_WIDE_BF16) as det:
+    with sd.SyllableDetector(cfg, channels=C, engine=engine) as det:
         out0, fl0 = det.run(x)
         torch.cuda.synchronize()
         out0, fl0 = out0.clone(), fl0.clone()
