@@ -265,6 +265,9 @@ hipError_t launch_fused(const FusedDesc &d, const float *samples, int64_t stride
 int fused_choice(const FusedDesc &d, int64_t J);    // 0 the 8-wave kernel, 1 the register-resident-basis kernel, 2 the symmetric-fold kernel
 // the DFT front half alone: samples -> [C][J][F] columns; d: a plan for timeRange 1 with spect_out / spect_power set
 hipError_t launch_fused_spectrogram(const FusedDesc &d, const float *samples, int64_t stride, int C, int64_t J, hipStream_t stream);
+// ... on the symmetric-fold kernel's twice-folded form, where the plan allows it (256-point frames under a 256-sample window)
+bool fused_s_spectrogram_applicable(const FusedDesc &d);
+hipError_t launch_fused_s_spectrogram(const FusedDesc &d, const float *samples, int64_t stride, int C, int64_t J, hipStream_t stream);
 // the same contract on the register-resident-basis kernel; only called when d.r_ok and fused_r_applicable(d)
 bool fused_r_applicable(const FusedDesc &d);
 bool fused_r_has_stamps();      // built with -DSYLDET_R_STAMPS (phase timing, SYLDET_FUSED_STAMPS=1)

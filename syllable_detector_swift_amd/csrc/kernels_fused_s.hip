@@ -93,7 +93,9 @@ __device__ __forceinline__ void split2(float a, float b, unsigned &hi, unsigned 
 // NT: row tiles per parity of the twice-folded form: 1 (bands of up to 32 bins), or 2 -- bands of up to 64 bins (11 kHz at 44.1 kHz under
 // 256-point frames) stay one launch: 48 + 18 matrix instructions a tile, a basis of 128 registers beside the 70 samples a lane
 // holds, so 4 waves a workgroup, one per SIMD, with 512 registers and twice the LDS each.
-template <int K2, bool GEN, int HQ, int NW, int PADP = 0, bool F2 = false, int NT = 1>
+// SPECT: the |X| (or |X|^2) columns themselves leave, [C][J][F] fp32 (E counts frames then: the plan's stand-in network has
+// timeRange 1), nothing of the network runs -- the front half of the wide engine and of syldet_spectrogram*.
+template <int K2, bool GEN, int HQ, int NW, int PADP = 0, bool F2 = false, int NT = 1, bool SPECT = false>
 __global__ void __launch_bounds__(64 * NW, 1)
 fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t stride, int64_t s_eff, int64_t E,
                float *__restrict__ outputs, uint8_t *__restrict__ flags)
@@ -203,6 +205,8 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
     const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(
         outputs ? outputs + (int64_t)c * E * n_out : nullptr, 0, outputs ? (int)(E * n_out * 4) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t flg_rs = __builtin_amdgcn_make_buffer_rsrc(flags ? flags + (int64_t)c * E : nullptr, 0, flags ? (int)E : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t spc_rs = __builtin_amdgcn_make_buffer_rsrc(
+        SPECT ? d.spect_out + (int64_t)c * E * d.F : nullptr, 0, SPECT ? (int)(E * d.F * 4) : 0, 0x00020000);
 
     // ---- the sample stream: chunk q holds samples [256 q, 256 q + 256) behind the segment's first one, in ring slot q mod RC;
     // slot 0's chunks are written a second time behind the ring (the mirror), so that a frame's reads never wrap.
@@ -310,7 +314,9 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
 #endif
     for (int t = 0; t < tiles; t++) {
         // tile t's chunks have landed (behind them in the queue: nothing but the two result stores of tile t - 1)
-        SD_STAMP(st_vm, if (t == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"));
+        // (SPECT: the five column stores of tile t - 1)
+        SD_STAMP(st_vm, if (t == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else if (SPECT) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"));
         const float *fp = ring + fo + sk((int)fo);    // this lane's frame: W samples from here (the mirror makes them contiguous)
 
         // ---- twice folded: this lane's 64 + 6 samples of its frame, read once.  For m0 = 32 ks + 8 g:
@@ -538,6 +544,56 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
             const float re = F2 ? (ii < 4 ? fmaf(ce[4 * tau + ii], a64, acc[4 * tau][ii]) : acc[4 * tau + 1][ii & 3]) : fmaf(cre_l[ii], xl, acc[ii >> 2][ii & 3]);
             const float im = F2 ? (ii < 4 ? acc[4 * tau + 2][ii] : acc[4 * tau + 3][ii & 3]) : acc[2 + (ii >> 2)][ii & 3];
             cval[i] = __builtin_amdgcn_sqrtf(fmaf(re, re, im * im)) * kmag;
+        }
+        if constexpr (SPECT) {
+            // columns only: |X| = cval 2^(col_shift - se) in true units (zvabs / 2, :329-333), or |X|^2 (zvmags / 4, :270-274), of
+            // this lane's band bins -> HBM; this lane's frame is frame fr of the tile (the slot permutation), evaluation = frame (timeRange 1)
+            static_assert(NT == 1 && F2, "the spectrogram instantiation is the twice-folded one");
+            const int er = kTile * t + fr;
+            const bool vld = er < seg_len;
+            const int ush = d.col_shift - se;
+            const float up = pow2f(ush < -126 ? -126 : (ush > 126 ? 126 : ush));
+            const unsigned rowo = (e_b32 + (unsigned)er) * (unsigned)d.F;
+            // this lane's eight bins 8 g .. 8 g + 7 in band order (the even / odd GEMMs' rows interleave; which comes first
+            // depends on the parity of the band's first bin): two quads a lane, 32 contiguous bytes of its frame's row
+            const bool odd_first = d.s2_pe != 0;
+            float v8[8];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float me = cval[i] * up, mo = cval[4 + i] * up;
+                const float a = odd_first ? mo : me, b = odd_first ? me : mo;
+                v8[2 * i] = d.spect_power ? a * a : a;
+                v8[2 * i + 1] = d.spect_power ? b * b : b;
+            }
+            // whole quads as one store each; the band's last, partial quad (F mod 4 bins) as single words
+            const int fq = d.F >> 2, rem = d.F & 3;
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const int Q = 2 * g + q;
+                const uint32x4 w = {__float_as_uint(v8[4 * q]), __float_as_uint(v8[4 * q + 1]), __float_as_uint(v8[4 * q + 2]), __float_as_uint(v8[4 * q + 3])};
+                __builtin_amdgcn_raw_buffer_store_b128(w, spc_rs, (vld && Q < fq) ? (rowo + 4u * (unsigned)Q) * 4u : 0xFFFFFFFFu, 0, 0);
+            }
+            {
+                const bool mine = vld && (fq >> 1) == g;                 // the partial quad is this lane group's quad fq & 1
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    const float pv = (fq & 1) ? v8[4 + j] : v8[j];
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(pv), spc_rs, (mine && j < rem) ? (rowo + 4u * (unsigned)fq + (unsigned)j) * 4u : 0xFFFFFFFFu, 0, 0);
+                }
+            }
+            // the precision guard: a frame the grid cannot hold (an infinite sample, a level above 2^113) is recomputed from its
+            // samples -- every other frame carries its own scale.  16 frames of a wave are one work item.
+            if (guard_on && __builtin_amdgcn_ballot_w64(vld && fst == 2) != 0ull) {
+                const int lo = kTile * t, hi = lo + kTile < seg_len ? lo + kTile : seg_len;
+                if (lane == 0 && hi > lo) {
+                    const unsigned sl = atomicAdd(d.fix.counters, 1u);
+                    if (sl < d.fix.capacity) d.fix.items[sl] = FixItem{c, e_b32 + (unsigned)lo, hi - lo, 1};
+                    else d.fix.counters[3] = 1u;
+                }
+            }
+            fo += (unsigned)(kTile * hop);
+            fo = fo >= (unsigned)R ? fo - (unsigned)R : fo;
+            continue;
         }
         if (GEN && scaling != 0) {
             // log / dB columns: |X| = cval 2^(col_shift - se) in true units; v_log_f32 is log2; ln 0 = -inf as in the reference
@@ -856,11 +912,11 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
 #undef SD_STAMP
 }
 
-template <int K2, bool GEN, int HQ, int NW, int PADP = 0, bool F2 = false, int NT = 1>
+template <int K2, bool GEN, int HQ, int NW, int PADP = 0, bool F2 = false, int NT = 1, bool SPECT = false>
 hipError_t launch_one(const FusedDesc &d, const float *samples, int64_t stride, int C, int64_t s_eff, int64_t E,
                       float *outputs, uint8_t *flags, hipStream_t stream)
 {
-    auto kern = fused_s_kernel<K2, GEN, HQ, NW, PADP, F2, NT>;
+    auto kern = fused_s_kernel<K2, GEN, HQ, NW, PADP, F2, NT, SPECT>;
     constexpr int kWaves = NW;
     const int lds = d.s_lds_wave * kWaves;
     hipError_t st = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -950,6 +1006,24 @@ hipError_t launch_fused_s(const FusedDesc &d, const float *samples, int64_t stri
     SD_S_GO(4) SD_S_GO(2) SD_S_GO(1) SD_S_GO(3)
 #undef SD_S_GO
     return hipErrorInvalidValue;
+}
+
+// The DFT front half alone on the twice-folded form: |X| or |X|^2 columns [C][J][F] (d.spect_out), for 256-point frames under a
+// 256-sample window; the plan is the stand-in network's (timeRange 1, one unit: syldet_api.cpp, build_dft_plan).
+bool fused_s_spectrogram_applicable(const FusedDesc &d)
+{
+    return d.s_ok && d.s2_ok && d.s2_nt == 1 && !d.no_fold2 && d.W == 256 && d.T == 1 && d.F <= 32 && (d.s_padp == 0 || d.s_padp == 64 || d.s_padp == 128);
+}
+
+hipError_t launch_fused_s_spectrogram(const FusedDesc &d, const float *samples, int64_t stride, int C, int64_t J, hipStream_t stream)
+{
+    if (J <= 0 || C <= 0) return hipSuccess;
+    if (!fused_s_spectrogram_applicable(d) || d.spect_out == nullptr) return hipErrorInvalidValue;
+    const int64_t s_eff = (J - 1) * (int64_t)d.hop + d.gap + d.W;
+    if (s_eff * 4 >= 0x7fffffffll || (uint64_t)J * (uint64_t)d.F * 4u >= 0xFFFFFFF0ull) return hipErrorInvalidValue;
+    if (d.s_padp == 64) return launch_one<4, false, 1, 8, 64, true, 1, true>(d, samples, stride, C, s_eff, J, nullptr, nullptr, stream);
+    if (d.s_padp == 128) return launch_one<4, false, 1, 8, 128, true, 1, true>(d, samples, stride, C, s_eff, J, nullptr, nullptr, stream);
+    return launch_one<4, false, 1, 8, 0, true, 1, true>(d, samples, stride, C, s_eff, J, nullptr, nullptr, stream);
 }
 
 }  // namespace sd

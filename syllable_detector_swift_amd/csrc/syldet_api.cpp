@@ -545,17 +545,21 @@ int build_dft_plan(syldet *h)
     const syldet_config_t &c = h->cfg.view;
     syldet_config_t sc = c;
     const int F = h->geom.bins;
-    std::vector<float> w((size_t)F, 0.0f), b(1, 0.0f);
-    syldet_layer_t layer{};
-    layer.inputs = F; layer.outputs = 1; layer.transfer = SYLDET_TF_PURELIN; layer.weights = w.data(); layer.biases = b.data();
+    // (two layers, F -> 1 -> 1: the class the symmetric-fold kernel's plan is made for)
+    std::vector<float> w((size_t)F, 0.0f), b(1, 0.0f), w2(1, 1.0f);
+    syldet_layer_t layers[2] = {};
+    layers[0].inputs = F; layers[0].outputs = 1; layers[0].transfer = SYLDET_TF_PURELIN; layers[0].weights = w.data(); layers[0].biases = b.data();
+    layers[1].inputs = 1; layers[1].outputs = 1; layers[1].transfer = SYLDET_TF_PURELIN; layers[1].weights = w2.data(); layers[1].biases = b.data();
     double thr = 0.0;
     sc.time_range = 1; sc.scaling = SYLDET_SCALING_LINEAR; sc.spectrum = SYLDET_SPECTRUM_POWER;
     sc.n_input_fns = 0; sc.input_fns = nullptr; sc.n_output_fns = 0; sc.output_fns = nullptr;
-    sc.n_layers = 1; sc.layers = &layer; sc.n_thresholds = 1; sc.thresholds = &thr;
+    sc.n_layers = 2; sc.layers = layers; sc.n_thresholds = 1; sc.thresholds = &thr;
     syldet_geometry_t sg = h->geom;
     sg.inputs = F; sg.outputs = 1;
     if (!make_fused_plan(sc, sg, h->dft)) return SYLDET_OK;          // not applicable: the generic FFT stays
-    if (!h->dft.desc.classic_ok) return SYLDET_OK;                   // (the spectrogram instantiation is the 8-wave kernel's: its shapes only)
+    // (two spectrogram instantiations: the fold kernel's twice-folded form for 256-point frames under a 256-sample window,
+    // the 8-wave kernel's for its shapes)
+    if (!h->dft.desc.classic_ok && !fused_s_spectrogram_applicable(h->dft.desc)) return SYLDET_OK;
     if (int st = upload_plan(h, h->dft, h->d_dft)) return st;
     h->dft.desc.spect_power = c.spectrum == SYLDET_SPECTRUM_MAGNITUDE ? 1 : 0;
     h->has_dft = true;
@@ -629,15 +633,24 @@ int stft_on_stream(syldet *h, const float *d_samples, int64_t stride, int C, int
         d.spect_out = d_columns;
         d.stamps = nullptr;
         d.ko = 0;
+        d.no_fold2 = h->sw.fused_nofold2 ? 1 : 0;
+        // the fold kernel's spectrogram instantiation where the plan allows it (rows under 2 GiB: its 32-bit byte offsets)
+        const bool fold = !h->sw.fused_nofold && fused_s_spectrogram_applicable(d) &&
+                          ((J - 1) * (int64_t)d.hop + d.gap + d.W) * 4 < 0x7fffffffll;
+        if (!fold && !d.classic_ok) goto generic_transform;
         // the precision guard's work list, and behind the kernel the exact recomputation of the frames it reports
-        if (int st = prepare_fix(h, C, J, (J + d.seg_evals - 1) / d.seg_evals, stream, d.fix)) return st;
-        {
+        if (int st = prepare_fix(h, C, J, (J + d.seg_evals - 1) / d.seg_evals + (d.s_seg_evals > 0 ? (J + d.s_seg_evals - 1) / d.s_seg_evals : 0), stream, d.fix)) return st;
+        if (fold) {
+            KernelTimer t(h, stream, "fused_s_kernel (spectrogram)");
+            SYLDET_HIP(launch_fused_s_spectrogram(d, d_samples, stride, C, J, stream));
+        } else {
             KernelTimer t(h, stream, "fused_kernel (spectrogram)");
             SYLDET_HIP(launch_fused_spectrogram(d, d_samples, stride, C, J, stream));
         }
         SYLDET_HIP(launch_fixup(h->fixd, h->net, d_samples, stride, J, 0, nullptr, nullptr, d_columns, d.fix, stream));
         return SYLDET_OK;
     }
+generic_transform:
     if (!h->sw.no_stft_lanes && stft_lanes_applicable(h->stft, d_samples, stride)) {
         KernelTimer t(h, stream, "stft_lanes_kernel");
         SYLDET_HIP(launch_stft_lanes(h->stft, d_samples, stride, C, J, d_columns, stream));

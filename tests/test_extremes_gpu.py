@@ -91,6 +91,8 @@ def test_extreme_inputs_spectrogram(oracle_lib, name, spectrum):
     util.assert_columns_close(cols[ok], want[ok])
     if names == ["fused_kernel (spectrogram)"]:
         assert over == 0 and (items > 0) == (name in ("one inf", "step 1e12"))
+    if names == ["fused_s_kernel (spectrogram)"]:      # (every frame has its own scale: only what no grid holds is recomputed)
+        assert over == 0 and (items > 0) == (name == "one inf")
 
 
 @pytest.mark.parametrize("chain", [(), ("l2normalize",), ("l2normalize", "mapminmax"), ("normalize",), ("normalizestd", "mapstd"), ("mapstd", "mapminmax")])

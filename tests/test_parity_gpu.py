@@ -411,7 +411,7 @@ def test_other_baseline_workloads_at_full_size(oracle_lib, workload):
         cfg, C, S, engine, tol, kernels = nets.config3(), 512, 1 << 21, _abi.ENGINE_AUTO, util.TOL, ["bdft_net_kernel"]
     else:
         cfg, C, S, engine, tol = nets.wide_mlp(nets.from_npz()), 64, 1 << 24, _abi.ENGINE_WIDE_BF16, 1e-2
-        kernels = ["fused_kernel (spectrogram)", "wide_gemm16_kernel"]   # (no preparation pass: the GEMM reads the columns)
+        kernels = ["fused_s_kernel (spectrogram)", "wide_gemm16_kernel"]   # (no preparation pass: the GEMM reads the columns)
     x = synth.channels_on_device(C, S, "cuda", fs=cfg.samplingRate)
     chans = [0, C // 2 - 1, C - 1]
     with sd.SyllableDetector(cfg, channels=C, engine=engine) as det:
@@ -472,6 +472,46 @@ def test_full_size_runs_are_reproducible(workload):
             assert torch.equal(out, out0) and torch.equal(fl, fl0)
 
 
+@pytest.mark.parametrize("hop,band,window,spectrum", [(132, (2000.0, 7000.0), 0, 0), (128, (500.0, 5800.0), 1, 0), (64, (3000.0, 8000.0), 2, 1),
+                                                       (100, (2150.0, 7300.0), 0, 1), (204, (0.0, 5000.0), 3, 0), (16, (2000.0, 7000.0), 0, 0)])
+def test_spectrogram_on_the_fold_kernel_and_on_the_older_one(oracle_lib, hop, band, window, spectrum, monkeypatch):
+    """syldet_spectrogram* (extractPower / extractMagnitude, CircularShortTimeFourierTransform.swift:221-337, sliced to the band:
+    SyllableDetector.swift:134-151) for 256-point frames under a 256-sample window: the fold kernel's twice-folded spectrogram
+    instantiation (plain and padded rings, bands that start on even and on odd bins, every window type, |X| and |X|^2), and
+    with SYLDET_FUSED_NOFOLD=1 the 8-wave kernel's -- both against the fp64 anchor, ragged lengths, a level step, three channels."""
+    torch = _torch()
+    base = util.sample_net()
+    from syllable_detector_swift_amd.config import frequencyIndexRange
+    f0, f1 = frequencyIndexRange(256, base.samplingRate, *band)
+    rng = np.random.default_rng(hop)
+    net = nets.random_net(rng, (f1 - f0) * 3, (2,), 1)
+    cfg = nets.variant(base, freqRange=band, windowOverlap=256 - hop, timeRange=3, net=net, window=window,
+                       spectrum=_abi.SPECTRUM_MAGNITUDE if spectrum else _abi.SPECTRUM_POWER)
+    C = 3
+    x = (synth.channels(C, 256 + 2347 * hop + 5, first=31) * np.array([[1.0], [4e-3], [25.0]])).astype(np.float32)
+    x[1, 90000:] *= np.float32(700.0)
+    o = util.oracle_for(cfg)
+    want = [o.spectrogram(x[c], po.F64) for c in range(C)]
+    got = {}
+    for form in ("fold", "older"):
+        if form == "older":
+            monkeypatch.setenv("SYLDET_FUSED_NOFOLD", "1")
+        with sd.SyllableDetector(cfg, channels=C) as det:      # (AUTO: a handle created for the generic engine keeps fp32 FFTs throughout)
+            det.profile(True)
+            cols = det.spectrogram(torch.from_numpy(x).cuda())
+            torch.cuda.synchronize()
+            names = [nm for nm, _ in det.lastTimings()]
+            if form == "fold":
+                assert names == ["fused_s_kernel (spectrogram)"], names
+                assert det.fixupStats() == (0, 0)
+            else:
+                assert names and "fused_s" not in names[0], names
+            got[form] = cols.cpu().numpy()
+        for c in range(C):
+            assert got[form][c].shape == want[c].shape
+            util.assert_columns_close(got[form][c], want[c])
+
+
 def test_wide_hidden_layer_on_auto_keeps_its_spectrogram_front(oracle_lib):
     """A 290 -> 5000 -> 1 network under AUTO runs on the generic engine behind the fused DFT front half; the exact
     recomputation behind that front half handles frames only and must not count the network's LDS buffers (4 waves x 2 x
@@ -487,7 +527,7 @@ def test_wide_hidden_layer_on_auto_keeps_its_spectrogram_front(oracle_lib):
         out, fl = det.run(torch.from_numpy(x).cuda())
         cols = det.spectrogram(torch.from_numpy(x).cuda())
         torch.cuda.synchronize()
-        assert det.lastTimings()[0][0] == "fused_kernel (spectrogram)"
+        assert det.lastTimings()[0][0] == "fused_s_kernel (spectrogram)"
     o = util.oracle_for(cfg)
     for c in range(2):
         _, _, w64 = o.run(x[c], po.F64, cfg.rule)
