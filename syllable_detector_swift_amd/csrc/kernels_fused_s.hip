@@ -312,6 +312,13 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
 #else
 #define SD_STAMP(var, stmt) { stmt; }
 #endif
+    // Everything the prologue fetched -- basis, tables, tile 0's chunks -- is here before the loop, and the COMPILER is told so
+    // (the builtin, not an asm string): otherwise its wait-count model carries the prologue's loads into the loop as still
+    // pending and guards their first uses in every iteration with vmcnt(6) / (1) / (0) -- waits that in steady state only make a
+    // wave wait for the NEXT tile's DMA chunks a quarter, a half and four fifths of the way through the current tile.
+#ifndef SYLDET_S_NO_PREWAIT            // (diagnostic build: tools/variant_libs.sh kernels_fused_s.hip noprewait -DSYLDET_S_NO_PREWAIT)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+#endif
     for (int t = 0; t < tiles; t++) {
         // tile t's chunks have landed (behind them in the queue: nothing but the two result stores of tile t - 1)
         // (SPECT: the five column stores of tile t - 1)
@@ -918,7 +925,11 @@ hipError_t launch_one(const FusedDesc &d, const float *samples, int64_t stride, 
 {
     auto kern = fused_s_kernel<K2, GEN, HQ, NW, PADP, F2, NT, SPECT>;
     constexpr int kWaves = NW;
+#ifdef SYLDET_S_ONEWAVE
+    const int lds = kWaves == 4 ? 100 * 1024 : d.s_lds_wave * kWaves;       // (one workgroup a CU)
+#else
     const int lds = d.s_lds_wave * kWaves;
+#endif
     hipError_t st = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (st != hipSuccess) return st;
     const int64_t segs = (E + d.s_seg_evals - 1) / d.s_seg_evals;         // wave segments per channel
@@ -1000,6 +1011,9 @@ hipError_t launch_fused_s(const FusedDesc &d, const float *samples, int64_t stri
         if (d.H > 4 && d.s_waves == 8 && d.hop % 64 == 0) return launch_one<4, true, 2, 8, 0, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
         if (d.H > 4 && d.s_waves == 8) return launch_one<4, true, 2, 8>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
         if (d.H > 4) return launch_one<4, true, 2, 4, 0, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
+#ifdef SYLDET_S_ONEWAVE                // (diagnostic build: ONE wave a SIMD -- how long does a tile take a wave with nobody to share with?)
+        if (exact) return launch_one<4, false, 1, 4, 0, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
+#endif
         if (exact) return launch_one<4, false, 1, 8, 0, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
         return launch_one<4, true, 1, 8, 0, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
     }
