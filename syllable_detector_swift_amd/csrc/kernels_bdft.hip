@@ -437,6 +437,9 @@ bdft_net_kernel(const MlpxDesc d, const BdftDesc bd, const float *__restrict__ s
     };
     using yes = std::integral_constant<bool, true>;
     using no = std::integral_constant<bool, false>;
+#ifndef SYLDET_B_NO_PREWAIT
+    __builtin_amdgcn_s_waitcnt(0x0F70);              // (the compiler is told that the prologue's loads are complete: kernels_fused_s.hip has the story)
+#endif
     for (int tr = 0; tr < tiles; tr++) {
         iteration(yes{}, no{}, 0);
         for (int s = 1; s < kSubs; s++) iteration(yes{}, yes{}, s - 1);
