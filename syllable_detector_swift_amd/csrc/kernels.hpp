@@ -75,6 +75,8 @@ struct WideDesc {
     // so the B operands are bf16(v / |v|) (l2 = 1) or bf16(v): no [evaluations][320] image in HBM, no preparation kernel
     int front, l2, I, F;
     int wg8;                    // two workgroups of 8 waves a CU instead of one of 16 (kernels_wide.hip, NWV)
+    int stagger;                // (wg8) waves 4-7 run one epilogue behind waves 0-3 (kernels_wide.hip, STG)
+    int dma_builtin;            // (wg8, unstaggered) the weight DMA through __builtin_amdgcn_global_load_lds instead of the assembly statement
     const uint4 *wpack;         // [n_chunks][kWideChunkBytes / 16]
     const float *b1;            // [n_out]
     const float *out_params;    // per output fn: y, gain[n_out], xoff[n_out]

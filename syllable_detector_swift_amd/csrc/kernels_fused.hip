@@ -346,8 +346,15 @@ fused_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t strid
                 float nn = 0.0f, mean = 0.0f, m2 = 0.0f;
                 for (int t = 0; t < T; t++) {                 // pairwise-stable combination of per-frame (mean, M2)
                     const float nb = (float)d.F, tot = nn + nb, dlt = stat[wslot + t] - mean;
-                    mean += dlt * nb / tot;
-                    m2 += stat[PS + wslot + t] + dlt * dlt * nn * nb / tot;
+                    // (the two updates stay scalar: packed into v_pk_mul_f32 the compiler took the common factors from the high
+                    // registers of src1 by operand selection -- the form tools/check_pk_opsel.py refuses, MEASUREMENTS R5.1)
+                    float m2_step = dlt * dlt * nn * nb / tot;
+                    asm volatile("" : "+v"(m2_step));
+                    float mean_step = dlt * nb / tot;
+                    asm volatile("" : "+v"(mean_step));
+                    mean += mean_step;
+                    m2 += stat[PS + wslot + t] + m2_step;
+                    asm volatile("" : "+v"(mean), "+v"(m2));
                     nn = tot;
                 }
                 const float sd = sqrtf(m2 / (float)d.I);

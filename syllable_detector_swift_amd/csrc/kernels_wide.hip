@@ -32,7 +32,6 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 constexpr int kBlock = kWideBlock;            // 1024 threads = 16 waves
 constexpr int kWave = 64;
-typedef __attribute__((address_space(3))) void lds_void;
 constexpr int kKSteps = kWideK / 16;          // 20 k-steps of 16
 constexpr int kChunkU4 = kWideChunkBytes / 16;     // 1320
 constexpr int kChunkU4Pad = 21 * 64;               // an LDS buffer holds whole 64-element spans (the DMA writes base + 16 lane)
@@ -355,12 +354,22 @@ wide_gemm_kernel(WideDesc d, const uint4 *__restrict__ xn, int64_t NE, float *__
 //   D [16 units x 16 evals]: lane l holds evaluation l % 16; register i holds unit 4 (l / 16) + i
 // ------------------------------------------------------------------------------------
 typedef float floatx4w __attribute__((ext_vector_type(4)));
+#ifdef SYLDET_WIDE_X_TRACE      // (diagnostic build: evaluation tile 0's running output sum after every chunk, [workgroup][wave][chunk][lane])
+__device__ float *g_wide_trace = nullptr;
+#endif
 // FRONT: the B operands are made here from the |X| columns (WideDesc::front) instead of being read from the prepared image.
 // NWV: waves per workgroup.  16 (one workgroup of 512 evaluations a CU) or 8 (two workgroups of 256 a CU, each with its own
 // chunk buffers and its own barrier: the two run out of phase, so that one's MFMA phase meets the other's epilogue --
 // behind ONE barrier the 16 waves run every chunk in lockstep, 160 MFMAs with the vector unit waiting, then four epilogues
 // with the matrix pipe idle; MEASUREMENTS R4.6).  The price: every workgroup streams the weights, so twice the L2 -> LDS bytes.
-template <int NOUT, bool SIG, bool FRONT, int NWV = 16>
+// STG (NWV = 8 only): the second half of the workgroup's waves -- the SIMD partners of the first half -- runs one epilogue behind: on
+// every SIMD one wave is in a chunk's matrix instructions while its partner finishes the chunk before (MI355X_MICROARCH.md, "Two
+// waves per SIMD", item 9).  A chunk then has readers during TWO barrier intervals, so the weights rotate through three buffers (the
+// third laid over the front's stage, which is dead once the operands are in registers).  Every sum is made in the unstaggered order:
+// the results are the unstaggered kernel's bit for bit.
+// DMAB: the weight DMA through the compiler's builtin instead of the assembly statement (A/B and parity of the two forms:
+// SYLDET_WIDE_DMA_BUILTIN=1; behind the builtin every later LDS read waits for the DMA, see fetch_chunk).
+template <int NOUT, bool SIG, bool FRONT, int NWV = 16, bool STG = false, bool DMAB = false>
 __global__ void __launch_bounds__(64 * NWV, NWV == 16 ? 1 : 4)
 wide_gemm16_kernel(WideDesc d, const uint4 *__restrict__ xn, const float *__restrict__ columns, int64_t J, int64_t E, int64_t NE,
                    float *__restrict__ outputs, uint8_t *__restrict__ flags)
@@ -453,19 +462,33 @@ wide_gemm16_kernel(WideDesc d, const uint4 *__restrict__ xn, const float *__rest
     const uint64_t wp = (uint64_t)(uintptr_t)d.wpack;
     const u32x4 w_rs4 = {(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)wp), (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(wp >> 32)) & 0xffffu,
                          (unsigned)(d.n_chunks * kChunkU4 * 16), 0x00020000u};
+    const unsigned lane16 = (unsigned)lane * 16u;
     auto fetch_chunk = [&](int ch, uint4 *dst) {
+#if defined(SYLDET_WIDE_X_DMATRAIL)                                   // (diagnostic: only the waves that pass a barrier last issue the DMA)
+        constexpr int kIssuers = STG ? kWaves / 2 : kWaves;
+        const int iw = STG ? wave - kWaves / 2 : wave;
+        if (iw < 0) return;
+#else
+        constexpr int kIssuers = kWaves;
+        const int iw = wave;
+#endif
 #pragma unroll
-        for (int j = 0; j < (21 + kWaves - 1) / kWaves; j++) {
-            const int i0 = (wave + kWaves * j) * 64;
-            if (i0 < kChunkU4) {
-                const int i = i0 + lane < kChunkU4 ? i0 + lane : kChunkU4 - 1;
+        for (int j = 0; j < (21 + kIssuers - 1) / kIssuers; j++) {
+            const int i0 = (iw + kIssuers * j) * 64;
+            if (i0 < kChunkU4 && DMAB) {
+                const int i = i0 + lane < kChunkU4 ? i0 + lane : kChunkU4 - 1;   // (no range check on this path: the last span's lanes stay inside the chunk)
+                __builtin_amdgcn_global_load_lds(d.wpack + (size_t)ch * kChunkU4 + i, dst + i0, 16, 0, 0);
+            } else if (i0 < kChunkU4) {
+                // (the chunk ends inside the last span: its lanes past the end read the next chunk's first bytes -- past the last chunk
+                // the buffer's range check answers -- into the padding of the LDS buffer, which nobody reads; so every piece's lane
+                // offset is the same register and everything else of its address is scalar)
                 // (written out: behind the builtin the compiler takes the DMA for a store that may alias every later LDS read and
                 // waits for it -- vmcnt(0) -- before the chunk's first ds_read, i.e. for the NEXT chunk's bytes at the top of
                 // every chunk.  The wait that matters is the explicit one before the barrier.)
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"                       // ("clobber list contains reserved registers: m0" -- it does, on purpose)
                 asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                             :: "s"((unsigned)(uintptr_t)(dst + i0)), "v"((unsigned)i * 16u), "s"(w_rs4), "s"((unsigned)ch * (unsigned)(kChunkU4 * 16))
+                             :: "s"((unsigned)(uintptr_t)(dst + i0)), "v"(lane16), "s"(w_rs4), "s"((unsigned)ch * (unsigned)(kChunkU4 * 16) + (unsigned)i0 * 16u)
                              : "memory", "m0");
 #pragma clang diagnostic pop
             }
@@ -492,8 +515,20 @@ wide_gemm16_kernel(WideDesc d, const uint4 *__restrict__ xn, const float *__rest
             }
         }
     };
-    auto finish = [&](const uint4 *cur, floatx4w (&acc)[2][2]) {
+#ifdef SYLDET_WIDE_X_TRACE
+    // (diagnostic build: per chunk five records [lane][4] -- tile 0's hidden values of unit tiles 0 and 1, the second-layer weights the lane read for them, the running sums after the chunk -- [workgroup][wave][chunk][5][lane][4], stored through
+    // inline assembly so that the compiler's wait counts stay what they are without it)
+    const uint64_t tp = (uint64_t)(uintptr_t)g_wide_trace + ((((uint64_t)blockIdx.y * gridDim.x + blockIdx.x) * kWaves + wave) * (uint64_t)d.n_chunks * 5) * 1024;
+    const u32x4 t_rs4 = {(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)tp), (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(tp >> 32)) & 0xffffu,
+                         (unsigned)__builtin_amdgcn_readfirstlane(g_wide_trace ? d.n_chunks * 5 * 1024 : 0), 0x00020000u};
+#endif
+    auto finish = [&](const uint4 *cur, floatx4w (&acc)[2][2], int ch) {
         const float *cst = reinterpret_cast<const float *>(cur + kKSteps * 64);
+#ifdef SYLDET_WIDE_X_PAD                                              // (diagnostic: idle states between the last matrix instruction and the first read of its result)
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15");
+        __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
         for (int ut = 0; ut < 2; ut++) {
 #pragma unroll
@@ -501,30 +536,115 @@ wide_gemm16_kernel(WideDesc d, const uint4 *__restrict__ xn, const float *__rest
 #pragma unroll
                 for (int j = 0; j < 4; j++)
                     acc[ut][t][j] = SIG ? __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(acc[ut][t][j]) + 1.0f) : transfer_fast(d.tf0, acc[ut][t][j]);
+#ifdef SYLDET_WIDE_X_TRACE
+            asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen" :: "v"(acc[ut][0]), "v"(lane16), "s"(t_rs4), "s"((unsigned)(ch * 5 + ut) * 1024u) : "memory");
+#endif
 #pragma unroll
             for (int o = 0; o < NOUT; o++) {                      // (rows of unused outputs are zero in the table)
                 const float4 w1 = *reinterpret_cast<const float4 *>(cst + 32 + 32 * o + 16 * ut + 4 * g);
+#ifdef SYLDET_WIDE_X_TRACE
+                if (o == 0) {
+                    const floatx4w w1v = {w1.x, w1.y, w1.z, w1.w};
+                    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen" :: "v"(w1v), "v"(lane16), "s"(t_rs4), "s"((unsigned)(ch * 5 + 2 + ut) * 1024u) : "memory");
+                }
+#endif
 #pragma unroll
                 for (int t = 0; t < 2; t++) {
-                    ysum[t][o] = fmaf(acc[ut][t][0], w1.x, ysum[t][o]);
-                    ysum[t][o] = fmaf(acc[ut][t][1], w1.y, ysum[t][o]);
-                    ysum[t][o] = fmaf(acc[ut][t][2], w1.z, ysum[t][o]);
-                    ysum[t][o] = fmaf(acc[ut][t][3], w1.w, ysum[t][o]);
+                    // (the weight FIRST: the compiler packs the two tiles' multiply-adds into v_pk_fma_f32 and takes w1.y / w1.w -- the high
+                    // registers of their pairs -- by operand selection; on src1 that selection loses the low half's product in lanes 48-63
+                    // whenever another wave of the SIMD is in its matrix instructions (tools/ubench/pkfma_opsel.hip, MEASUREMENTS R5.1), on
+                    // src0 it does not.  The build checks the ISA of every kernel for the src1 form: tools/check_pk_opsel.py.)
+                    ysum[t][o] = fmaf(w1.x, acc[ut][t][0], ysum[t][o]);
+                    ysum[t][o] = fmaf(w1.y, acc[ut][t][1], ysum[t][o]);
+                    ysum[t][o] = fmaf(w1.z, acc[ut][t][2], ysum[t][o]);
+                    ysum[t][o] = fmaf(w1.w, acc[ut][t][3], ysum[t][o]);
                 }
             }
         }
+#ifdef SYLDET_WIDE_X_TRACE
+        {
+            const floatx4w yv = {ysum[0][0], ysum[1][0], 0.0f, 0.0f};
+            asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen" :: "v"(yv), "v"(lane16), "s"(t_rs4), "s"((unsigned)(ch * 5 + 4) * 1024u) : "memory");
+        }
+#endif
     };
-    fetch_chunk(0, buf0);
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    __syncthreads();
-    for (int ch = 0; ch < d.n_chunks; ch++) {
-        const uint4 *cur = (ch & 1) ? buf1 : buf0;
-        if (ch + 1 < d.n_chunks) fetch_chunk(ch + 1, (ch & 1) ? buf0 : buf1);
-        floatx4w acc[2][2];                                       // [unit tile][evaluation tile]: register i = unit 16 ut + 4 g + i
-        multiply(cur, acc);
-        finish(cur, acc);
+    if constexpr (!STG) {
+        fetch_chunk(0, buf0);
         __builtin_amdgcn_s_waitcnt(0x0F70);
         __syncthreads();
+        for (int ch = 0; ch < d.n_chunks; ch++) {
+            const uint4 *cur = (ch & 1) ? buf1 : buf0;
+            if (ch + 1 < d.n_chunks) fetch_chunk(ch + 1, (ch & 1) ? buf0 : buf1);
+            floatx4w acc[2][2];                                   // [unit tile][evaluation tile]: register i = unit 16 ut + 4 g + i
+            multiply(cur, acc);
+            finish(cur, acc, ch);
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            __syncthreads();
+        }
+    } else {
+        static_assert(!STG || (NWV == 8 && FRONT), "the staggered form is the two-workgroups-a-CU kernel's");
+        // Chunk c lives in buffer c mod 3.  In barrier interval c (between barrier c and barrier c + 1) the leading waves read
+        // chunk c, the trailing waves chunks c - 1 (its second-layer weights) and c, and everybody's share of chunk c + 1 is on its
+        // way into buffer (c + 1) mod 3 = (c - 2) mod 3, whose last readers -- the trailing waves, in interval c - 1 -- retired
+        // their reads (lgkmcnt(0)) before barrier c.  A wave waits for its own pieces of chunk c + 1 (vmcnt(0)) before barrier
+        // c + 1; its readers are behind that barrier.
+        auto bufp = [&](int b) { return buf0 + b * kChunkU4Pad; };    // (the third one is the front's stage)
+        auto next = [](int b) { return b == 2 ? 0 : b + 1; };
+        auto seal = [&]() {
+            // (The compiler is free to move a chunk's register arithmetic across its barrier and to interleave the trailing waves'
+            // epilogue with their next matrix instructions -- 15.78 ms against 15.96 with everything pinned to its interval
+            // (-DSYLDET_WIDE_X_STRICT), 15.98 unstaggered, one box, profiles/r05_wide_stagger_ab.txt.  What it must not do is read LDS
+            // across the barrier, and it cannot: the barrier is a fence for it.)
+#ifdef SYLDET_WIDE_X_STRICT
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+#ifdef SYLDET_WIDE_X_NOLGKM
+            __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0) only
+#else
+            __builtin_amdgcn_s_waitcnt(0x0070);                   // vmcnt(0): my pieces of the next chunk have landed; lgkmcnt(0): my reads of this interval are done
+#endif
+            __syncthreads();
+#ifdef SYLDET_WIDE_X_BAR2
+            __builtin_amdgcn_s_waitcnt(0x0070);
+            __syncthreads();
+#endif
+#ifdef SYLDET_WIDE_X_STRICT
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+        };
+        const int nch = d.n_chunks;
+        fetch_chunk(0, bufp(0));
+        seal();
+        if (wave < kWaves / 2) {
+            int bi = 0;
+            for (int ch = 0; ch < nch; ch++) {
+                const int bn = next(bi);
+                if (ch + 1 < nch) fetch_chunk(ch + 1, bufp(bn));
+                floatx4w acc[2][2];
+                multiply(bufp(bi), acc);
+                finish(bufp(bi), acc, ch);
+                    seal();
+                bi = bn;
+            }
+        } else {
+            floatx4w acc[2][2];                                   // (chunk c - 1's sums cross barrier c in registers)
+            if (1 < nch) fetch_chunk(1, bufp(1));
+            multiply(bufp(0), acc);
+            seal();
+            int bp = 0, bi = 1;
+            for (int ch = 1; ch < nch; ch++) {
+                const int bn = next(bi);
+                if (ch + 1 < nch) fetch_chunk(ch + 1, bufp(bn));
+                finish(bufp(bp), acc, ch - 1);
+#ifdef SYLDET_WIDE_X_STRICT                                           // (diagnostic: the chunk before finished before this one's matrix instructions start)
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+                multiply(bufp(bi), acc);
+                seal();
+                bp = bi; bi = bn;
+            }
+            finish(bufp(bp), acc, nch - 1);
+        }
     }
     // the four lane groups hold disjoint units of the same evaluations
     int tid2 = threadIdx.x;
@@ -591,6 +711,12 @@ hipError_t launch_wide_prep(const NetDesc &n, int F, const float *columns, int C
     return hipGetLastError();
 }
 
+#ifdef SYLDET_WIDE_X_TRACE
+static float *g_trace_host_ptr = nullptr;
+static size_t g_trace_bytes = 0;
+extern "C" int syldet_debug_wide_trace(void **ptr, size_t *bytes) { *ptr = g_trace_host_ptr; *bytes = g_trace_bytes; return 0; }
+#endif
+
 hipError_t launch_wide_gemm(const WideDesc &d, const void *xn, const float *columns, int64_t J, int64_t E, int64_t NE, float *outputs,
                             uint8_t *flags, hipStream_t stream)
 {
@@ -601,11 +727,25 @@ hipError_t launch_wide_gemm(const WideDesc &d, const void *xn, const float *colu
         // two workgroups of 8 waves a CU (WideDesc::wg8) where the columns under 256 evaluations and the chunk buffers fit twice
         const bool wg8 = d.wg8 && d.front && one16 && (size_t)wide_front_stage_floats(d.F, d.I, 256) * 4 + 2 * kChunkU4Pad * 16 <= 78 * 1024;
         if (wg8) {
-            auto k8 = d.sig ? wide_gemm16_kernel<1, true, true, 8> : wide_gemm16_kernel<1, false, true, 8>;
+            auto k8 = d.dma_builtin ? (d.sig ? wide_gemm16_kernel<1, true, true, 8, false, true> : wide_gemm16_kernel<1, false, true, 8, false, true>)
+                      : d.stagger   ? (d.sig ? wide_gemm16_kernel<1, true, true, 8, true> : wide_gemm16_kernel<1, false, true, 8, true>)
+                                    : (d.sig ? wide_gemm16_kernel<1, true, true, 8> : wide_gemm16_kernel<1, false, true, 8>);
             if (E <= 0 || NE % E != 0) return hipErrorInvalidValue;
-            const size_t lds8 = 2 * kChunkU4Pad * 16 + (size_t)wide_front_stage_floats(d.F, d.I, 256) * 4;
+            // (the staggered form's third chunk buffer lies over the stage: whichever is longer)
+            const size_t lds8 = 2 * kChunkU4Pad * 16 + std::max((size_t)wide_front_stage_floats(d.F, d.I, 256) * 4, (size_t)kChunkU4Pad * 16);
             hipError_t st8 = hipFuncSetAttribute((const void *)k8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8);
             if (st8 != hipSuccess) return st8;
+#ifdef SYLDET_WIDE_X_TRACE
+            {
+                const size_t need = (size_t)((E + 255) / 256) * (size_t)(NE / E) * 8 * (size_t)d.n_chunks * 5 * 1024;
+                if (need > g_trace_bytes) {
+                    if (g_trace_host_ptr) (void)hipFree(g_trace_host_ptr);
+                    if (hipMalloc((void **)&g_trace_host_ptr, need) != hipSuccess) return hipErrorOutOfMemory;
+                    g_trace_bytes = need;
+                    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wide_trace), &g_trace_host_ptr, sizeof(float *));
+                }
+            }
+#endif
             hipLaunchKernelGGL(k8, dim3((unsigned)((E + 255) / 256), (unsigned)(NE / E)), dim3(512), lds8, stream, d, (const uint4 *)xn, columns, J, E, NE, outputs, flags);
             return hipGetLastError();
         }

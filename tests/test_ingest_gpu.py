@@ -194,6 +194,41 @@ def test_wide_network_bf16_mfma_engine(oracle_lib, shape, monkeypatch):
     assert worst > 1e-7, "bf16 rounding should be visible: is the engine really running?"
 
 
+@pytest.mark.parametrize("H", [4096, 96])
+def test_wide_gemm_forms_agree_bit_for_bit(H, monkeypatch):
+    """Every form of the 16x16x32 GEMM makes its sums in the same order, so their results are the same bits: the staggered
+    two-workgroup form that ships (waves 4-7 one epilogue behind waves 0-3, three chunk buffers), the unstaggered one
+    (SYLDET_WIDE_NOSTAGGER: round 4's), the same with the weight DMA through the compiler's builtin instead of the assembly
+    statement (SYLDET_WIDE_DMA_BUILTIN), and one workgroup of 16 waves (SYLDET_WIDE_WG16).  Several rounds of workgroups per
+    CU (the staggered form's run-to-run differences of round 4 -- a packed multiply-add that loses a product beside another
+    wave's matrix instructions, MEASUREMENTS R5.1 -- showed only there), each form twice."""
+    torch = _torch()
+    base = nets.from_npz()
+    cfg = nets.wide_mlp(base) if H == 4096 else nets.variant(base, net=nets.random_net(np.random.default_rng(5), 290, (H,), 1))
+    C, S = 16, 1 << 22                                   # 16 x 31 760 evaluations: ~2000 workgroups of 256, four rounds of the chip
+    x = synth.channels_on_device(C, S, torch.device("cuda", 0), fs=cfg.samplingRate)
+    results = {}
+    for form, env in (("staggered", {}), ("unstaggered", {"SYLDET_WIDE_NOSTAGGER": "1"}),
+                      ("builtin DMA", {"SYLDET_WIDE_NOSTAGGER": "1", "SYLDET_WIDE_DMA_BUILTIN": "1"}), ("16 waves", {"SYLDET_WIDE_WG16": "1"})):
+        for k in ("SYLDET_WIDE_NOSTAGGER", "SYLDET_WIDE_DMA_BUILTIN", "SYLDET_WIDE_WG16"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with sd.SyllableDetector(cfg, channels=C, engine=_abi.ENGINE_WIDE_BF16) as det:
+            det.profile(True)
+            runs = []
+            for _ in range(2):
+                out, fl = det.run(x)
+                torch.cuda.synchronize()
+                runs.append((out.cpu().numpy(), fl.cpu().numpy()))
+            assert [k for k, _ in det.lastTimings() if k.startswith("wide_gemm")] == ["wide_gemm16_kernel"]
+        assert np.array_equal(runs[0][0], runs[1][0], equal_nan=True) and np.array_equal(runs[0][1], runs[1][1]), "%s: two runs differ" % form
+        results[form] = runs[0]
+    for form in ("unstaggered", "builtin DMA", "16 waves"):
+        differ = int((results[form][0] != results["staggered"][0]).sum())
+        assert differ == 0 and np.array_equal(results[form][1], results["staggered"][1]), "%s against staggered: %d outputs differ" % (form, differ)
+
+
 def test_wide_engine_is_opt_in_and_checks_the_shape():
     base = nets.from_npz()
     with sd.SyllableDetector(nets.wide_mlp(base), channels=1) as det:          # AUTO never picks bf16
