@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Regenerates tests/golden/* (run in the build container only; needs /root/reference).
+"""Regenerates tests/golden/* (run in the build container only; needs /root/reference -- except `make_golden.py deep`,
+which adds the deeper networks' cases from the committed sample_net.npz).
 
 What it writes
   sample_net.npz          the reference's example network (sample.txt) re-encoded as arrays
@@ -136,5 +137,31 @@ def main():
                    rule=po.RULE_ANY if v["outs"] > 1 else po.RULE_FIRST)
 
 
+def deep_cases():
+    """Networks of three and four layers (NeuralNet.apply runs any layerCount: NeuralNet.swift:310-313,
+    SyllableDetectorConfig.swift:232-259).  Made from the committed sample_net.npz: needs no reference tree
+    (python tests/golden/make_golden.py deep)."""
+    base = nets.from_npz(os.path.join(GOLD, "sample_net.npz"))
+    template = np.load(os.path.join(GOLD, "syllable_template.npy"))
+    rng = np.random.default_rng(515)
+    # three layers behind the example front-end, on audio that holds syllables; first-output rule
+    n3 = nets.random_net(rng, 290, (6, 3), 1, transfer=("TanSig", "LogSig", "PureLin"), in_fns=("l2normalize", "mapminmax"), out_fns=("mapminmax",))
+    xa = synth.syllable_channel(1 << 17, template, seed=7)
+    write_case("case_deep3_sample_front", nets.variant(base, net=n3, thresholds=[0.416194]), xa, False, {"kind": "syllable_channel", "seed": 7})
+    # four layers, two outputs under the any-output rule, log columns behind normalizestd, the small front-end
+    small = dict(samplingRate=16000.0, fourierLength=128, windowLength=96, freqRange=(500.0, 4000.0), timeRange=6)
+    I = (33 - 4) * 6
+    n4 = nets.random_net(rng, I, (8, 4, 3), 2, transfer=("SatLin", "TanSig", "LogSig", "PureLin"), in_fns=("normalizestd", "mapstd"),
+                         out_fns=("mapstd", "mapminmax"))
+    c4 = SyllableDetectorConfig(small["samplingRate"], small["fourierLength"], small["windowLength"], 32, small["freqRange"], small["timeRange"],
+                                "log", [0.958960, 0.359288], n4)
+    xe = synth.channel(1 << 15, 9, fs=16000.0)
+    write_case("case_deep4_small_front_any", c4, xe, False, {"kind": "channel_fs16000", "seed": 9}, rule=po.RULE_ANY)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "deep":
+        deep_cases()
+    else:
+        main()
+        deep_cases()
