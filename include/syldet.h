@@ -257,6 +257,12 @@ int syldet_append(syldet_t *h, int32_t channel, const float *data, int64_t n_sam
  * CircularShortTimeFourierTransform.swift:203-217: de-interleaves frame-major audio into
  * every channel of the bank (total_channels == syldet_channels(h))                       */
 int syldet_append_interleaved(syldet_t *h, const float *data, int64_t n_frames, int32_t total_channels);
+/* The same call's fromChannel: the bank sits on a SUBSET of a wider device stream -- channel c of the bank takes channel
+ * source_channel[c] of the total_channels interleaved in `data` (appendInterleavedData(_:withSamples:fromChannel:ofTotalChannels:),
+ * CircularShortTimeFourierTransform.swift:203-217, takes one channel of the stream per call: :213's stride is the stream's width).
+ * source_channel: syldet_channels(h) entries, each in [0, total_channels); a stream channel may feed several bank channels.    */
+int syldet_append_interleaved_channels(syldet_t *h, const float *data, int64_t n_frames, int32_t total_channels,
+                                       const int32_t *source_channel);
 /* processNewValue() -> Bool, SyllableDetector.swift:153-217: 1 = a new evaluation is in
  * last_outputs, 0 = not enough data yet                                                  */
 int syldet_process_new_value(syldet_t *h, int32_t channel);
@@ -308,7 +314,9 @@ int syldet_unpack_flags_device(const uint8_t *d_bits, int64_t rows, int64_t row_
  * instead: a shard then computes a contiguous range of one channel's evaluations from its samples plus a halo of
  * (timeRange - 1) hop + window - hop (+ gap) samples (evaluation e is frames e .. e + timeRange - 1, frame j is samples
  * [j hop + gap, j hop + gap + window): SyllableDetector.swift:153-217, CircularShortTimeFourierTransform.swift:286-302).
- * Every kernel scales per frame or per hop-aligned block, so a shard's results are the unsharded bank's bit for bit.
+ * The kernels AUTO selects for the benchmark configurations scale per frame (fold kernel) or per hop-aligned block
+ * (block-transform, FFT kernels), so a shard's results there are the unsharded bank's bit for bit; the pass-scaled fused
+ * kernels (SYLDET_FUSED_NOFOLD / _CLASSIC, shapes outside the fold kernel's class) agree between tilings to a few 1e-7 only.
  * The data path has no collective.  The one exchange -- every device receives every channel's detection flags -- is ONE
  * all-gather of the bit-packed rows per batch, on RCCL communicators the library makes itself (ncclCommInitAll, one
  * process; librccl is loaded on first use, so hosts with one GPU never pay for it).                                   */
@@ -342,9 +350,12 @@ int syldet_sharded_destroy(syldet_sharded_t *b);
 int32_t syldet_sharded_channels(const syldet_sharded_t *b);
 int32_t syldet_sharded_shards(const syldet_sharded_t *b);
 int syldet_sharded_shard(const syldet_sharded_t *b, int32_t shard, syldet_shard_t *out);
-/* the shard's own bank (borrowed: destroyed with the sharded bank) and the stream its work is queued on */
+/* the shard's own bank (borrowed: destroyed with the sharded bank), the stream its kernels (and own results) are queued on,
+ * and the stream its share of the exchange runs on (d_flags_all[shard] is complete when THAT stream has drained: the exchange
+ * of batch i runs beside the kernels of batch i + 1, as Processor.swift:128-141's queue hands out results while audio arrives) */
 syldet_t *syldet_sharded_bank(syldet_sharded_t *b, int32_t shard);
 void *syldet_sharded_stream(syldet_sharded_t *b, int32_t shard);
+void *syldet_sharded_exchange_stream(syldet_sharded_t *b, int32_t shard);
 /* For a recording of n_samples per channel: the samples [*s0, *s1) shard `shard` reads of each of its channels (all of them
  * unless time-sharded) and the evaluations [*e0, *e0 + *count) it computes.  Any output pointer may be NULL.            */
 int syldet_sharded_ranges(const syldet_sharded_t *b, int32_t shard, int64_t n_samples, int64_t *s0, int64_t *s1,
@@ -358,8 +369,10 @@ int syldet_sharded_run(syldet_sharded_t *b, const float *samples, int64_t n_samp
  * sample range (syldet_sharded_ranges) of a recording of n_samples per channel; d_outputs[i] [channels_i][count_i][outputs]
  * and d_flags[i] [channels_i][count_i] receive its own results (either array, or any entry, may be NULL);
  * d_flags_all[i], when the array is given, receives EVERY channel's flags [C][E] on device i (8-byte aligned) through the
- * one exchange.  Asynchronous: every shard's kernel is launched before the exchange is queued; results are complete after
- * syldet_sharded_synchronize (or after synchronising syldet_sharded_stream(b, i) for shard i's own results).             */
+ * one exchange.  Asynchronous: every shard's kernel is launched before the exchange is queued, and the exchange runs on
+ * streams of its own (two sets of buffers in turn), so the next call's kernels start without waiting for this call's
+ * collective; results are complete after syldet_sharded_synchronize (or after synchronising syldet_sharded_stream(b, i) for
+ * shard i's own results, syldet_sharded_exchange_stream(b, i) for d_flags_all[i]).                                       */
 int syldet_sharded_run_device(syldet_sharded_t *b, const float *const *d_samples, int64_t n_samples, const int64_t *strides,
                               float *const *d_outputs, uint8_t *const *d_flags, uint8_t *const *d_flags_all);
 int syldet_sharded_synchronize(syldet_sharded_t *b);

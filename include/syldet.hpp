@@ -112,6 +112,11 @@ public:
         return queued;
     }
     void appendInterleavedData(const float *data, int64_t frames) { check(syldet_append_interleaved(h_, data, frames, channels())); }
+    // fromChannel / ofTotalChannels (CircularShortTimeFourierTransform.swift:203-217): the bank on a subset of a wider stream
+    void appendInterleavedData(const float *data, int64_t frames, int32_t totalChannels, const int32_t *fromChannels)
+    {
+        check(syldet_append_interleaved_channels(h_, data, frames, totalChannels, fromChannels));
+    }
     // TrackDetector's sample numbering and debounce (TrackDetector.swift:39-43, :65-100)
     std::vector<int64_t> detections(const uint8_t *flags, int64_t nEvals, double debounceSeconds, int channel)
     {
@@ -137,7 +142,13 @@ public:
                                 int engine = SYLDET_ENGINE_AUTO, int exchange = SYLDET_EXCHANGE_RCCL)
     {
         check(syldet_create_sharded(config.raw(), channels, devices.data(), (int32_t)devices.size(), engine, exchange, &b_));
-        check(syldet_get_geometry(syldet_sharded_bank(b_, 0), &geometry_));
+        try {
+            check(syldet_get_geometry(syldet_sharded_bank(b_, 0), &geometry_));
+        } catch (...) {                                            // (no destructor runs for a constructor that throws)
+            syldet_sharded_destroy(b_);
+            b_ = nullptr;
+            throw;
+        }
     }
     ~SyllableDetectorShardedBank() { syldet_sharded_destroy(b_); }
     SyllableDetectorShardedBank(const SyllableDetectorShardedBank &) = delete;

@@ -118,6 +118,7 @@ SIGNATURES = {
     "syldet_segment_evals": (C.c_int64, [Handle, C.c_int64]),
     "syldet_append": (C.c_int, [Handle, C.c_int32, c_float_p, C.c_int64]),
     "syldet_append_interleaved": (C.c_int, [Handle, c_float_p, C.c_int64, C.c_int32]),
+    "syldet_append_interleaved_channels": (C.c_int, [Handle, c_float_p, C.c_int64, C.c_int32, C.POINTER(C.c_int32)]),
     "syldet_process_new_value": (C.c_int, [Handle, C.c_int32]),
     "syldet_process_all": (C.c_int, [Handle, c_int64_p]),
     "syldet_pending_evaluations": (C.c_int64, [Handle, C.c_int32]),
@@ -148,6 +149,7 @@ SIGNATURES = {
     "syldet_sharded_shard": (C.c_int, [Handle, C.c_int32, C.POINTER(Shard)]),
     "syldet_sharded_bank": (Handle, [Handle, C.c_int32]),
     "syldet_sharded_stream": (C.c_void_p, [Handle, C.c_int32]),
+    "syldet_sharded_exchange_stream": (C.c_void_p, [Handle, C.c_int32]),
     "syldet_sharded_ranges": (C.c_int, [Handle, C.c_int32, C.c_int64, c_int64_p, c_int64_p, c_int64_p, c_int64_p]),
     "syldet_sharded_run": (C.c_int, [Handle, c_float_p, C.c_int64, C.c_int64, c_float_p, c_uint8_p]),
     "syldet_sharded_run_device": (C.c_int, [Handle, c_void_pp, C.c_int64, c_int64_p, c_void_pp, c_void_pp, c_void_pp]),

@@ -85,6 +85,11 @@ class ShardedSyllableDetectorBank:
         E = max(self.countEvaluations(S), 0)
         out = outputs if outputs is not None else np.zeros((self.channels, E, self.geometry.outputs), np.float32)
         fl = flags if flags is not None else np.zeros((self.channels, E), np.uint8)
+        # (the library writes these rows from one thread per shard: a wrong array would be written out of bounds)
+        if not (isinstance(out, np.ndarray) and out.dtype == np.float32 and out.flags["C_CONTIGUOUS"] and out.shape == (self.channels, E, self.geometry.outputs)):
+            raise ValueError("outputs must be a C-contiguous float32 array [%d, %d, %d]" % (self.channels, E, self.geometry.outputs))
+        if not (isinstance(fl, np.ndarray) and fl.dtype == np.uint8 and fl.flags["C_CONTIGUOUS"] and fl.shape == (self.channels, E)):
+            raise ValueError("flags must be a C-contiguous uint8 array [%d, %d]" % (self.channels, E))
         check(_abi.lib.syldet_sharded_run(self._h, a.ctypes.data_as(_abi.c_float_p), S, a.strides[0] // 4,
                                           out.ctypes.data_as(_abi.c_float_p), fl.ctypes.data_as(_abi.c_uint8_p)))
         return out, fl
@@ -120,10 +125,14 @@ class ShardedSyllableDetectorBank:
             fls.append(flags[i] if flags is not None else torch.empty((s.channels, cnt), dtype=torch.uint8, device=dev))
             if gather:
                 alls.append(flags_all[i] if flags_all is not None else torch.empty((self.channels, E), dtype=torch.uint8, device=dev))
-            if tuple(outs[-1].shape) != (s.channels, cnt, n_out) or tuple(fls[-1].shape) != (s.channels, cnt) or not outs[-1].is_contiguous() or not fls[-1].is_contiguous():
-                raise ValueError("result tensors of shard %d have the wrong shape" % i)
-            if gather and (tuple(alls[-1].shape) != (self.channels, E) or not alls[-1].is_contiguous() or alls[-1].device != dev):
-                raise ValueError("gathered flags of shard %d have the wrong shape or device" % i)
+            if (tuple(outs[-1].shape) != (s.channels, cnt, n_out) or tuple(fls[-1].shape) != (s.channels, cnt) or not outs[-1].is_contiguous()
+                    or not fls[-1].is_contiguous() or outs[-1].dtype != torch.float32 or fls[-1].dtype != torch.uint8
+                    or outs[-1].device != dev or fls[-1].device != dev):
+                raise ValueError("result tensors of shard %d: float32 [%d, %d, %d] and uint8 [%d, %d], contiguous, on device %d" % (
+                    i, s.channels, cnt, n_out, s.channels, cnt, s.device))
+            if gather and (tuple(alls[-1].shape) != (self.channels, E) or not alls[-1].is_contiguous() or alls[-1].device != dev
+                           or alls[-1].dtype != torch.uint8):
+                raise ValueError("gathered flags of shard %d: uint8 [%d, %d], contiguous, on device %d" % (i, self.channels, E, s.device))
         arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
         strides = (C.c_int64 * n)(*[int(b.stride(0)) for b in blocks])
         check(_abi.lib.syldet_sharded_run_device(self._h, arr(blocks), int(n_samples), strides, arr(outs), arr(fls),
@@ -132,6 +141,11 @@ class ShardedSyllableDetectorBank:
 
     def synchronize(self):
         check(_abi.lib.syldet_sharded_synchronize(self._h))
+
+    def streams(self, shard: int) -> Tuple[int, int]:
+        """(compute stream, exchange stream) of a shard as hipStream_t values: the shard's own results are ordered on the
+        first, its gathered flags on the second."""
+        return int(_abi.lib.syldet_sharded_stream(self._h, int(shard)) or 0), int(_abi.lib.syldet_sharded_exchange_stream(self._h, int(shard)) or 0)
 
 
 def _is_rows(a, channels) -> bool:

@@ -26,6 +26,11 @@ __device__ __forceinline__ float wave_reduce(float v, Op op)
     return op(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 __device__ __forceinline__ float wave_sum(float v) { return wave_reduce(v, [](float a, float b) { return a + b; }); }
+__device__ __forceinline__ double wave_sum_f64(double v)
+{
+    for (int m = 1; m < kWave; m <<= 1) v += __shfl_xor(v, m, kWave);
+    return v;
+}
 __device__ __forceinline__ float wave_min(float v) { return wave_reduce(v, [](float a, float b) { return fminf(a, b); }); }
 __device__ __forceinline__ float wave_max(float v) { return wave_reduce(v, [](float a, float b) { return fmaxf(a, b); }); }
 
@@ -93,11 +98,24 @@ __device__ __forceinline__ void mlp_eval_wave(const NetDesc &n, const float *src
         __syncthreads();
     }
 
+    // No normaliser in front of the network: the first layer meets the columns at the recording's level, and a unit's sum can be
+    // a small difference of large terms (columns of 3000 under weights of both signs: terms of +-180 that cancel to O(1)) -- in fp32
+    // no order of summation holds 1e-5 there (round 5's sweep without level-dependent bars, draw 4125: 1.2e-5 here, 5e-6 for the
+    // reference's own order).  Those sums are made in fp64: the products are exact, the sum is correctly rounded once.
+    const bool first_f64 = n.n_in_fns == 0 || n.in_fns[0].kind >= 3;
     float *cur = bufA, *nxt = bufB;
     for (int l = 0; l < n.n_layers; l++) {
         const DevLayer L = n.layers[l];
         const float *W = P + L.w;
-        if (L.out < kWave) {
+        if (l == 0 && first_f64) {
+            for (int o = 0; o < L.out; o++) {
+                double acc = 0.0;
+                const float *wrow = W + (size_t)o * L.in;
+                for (int i = lane; i < L.in; i += kWave) acc = fma((double)wrow[i], (double)cur[i], acc);
+                acc = wave_sum_f64(acc);
+                if (lane == 0) nxt[o] = transfer(L.tf, (float)(acc + (double)P[L.b + o]));
+            }
+        } else if (L.out < kWave) {
             // few outputs: the whole wave reduces one dot product at a time
             for (int o = 0; o < L.out; o++) {
                 float acc = 0.0f;

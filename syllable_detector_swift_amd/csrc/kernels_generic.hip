@@ -754,8 +754,10 @@ hipError_t launch_mlp_generic(const NetDesc &n, int F, const float *columns, int
                               float *outputs, uint8_t *flags, hipStream_t stream)
 {
     if (E <= 0 || C <= 0) return hipSuccess;
-    // small first layer: the register-resident kernel
-    if (n.n_layers >= 1 && n.n_layers <= 2 && n.n_out <= 8 && (n.n_layers == 1 || n.layers[1].in == n.layers[0].out)) {
+    // small first layer: the register-resident kernel (not for chains without a normaliser: their first layer is summed in fp64,
+    // which only the any-shape kernel does -- generic_eval.hpp)
+    const bool normalised = n.n_in_fns > 0 && n.in_fns[0].kind < 3;
+    if (normalised && n.n_layers >= 1 && n.n_layers <= 2 && n.n_out <= 8 && (n.n_layers == 1 || n.layers[1].in == n.layers[0].out)) {
         const int H = n.layers[0].out;
         const int64_t per_block = (int64_t)(kBlock / kWave) * kSmallRun;
         dim3 grid((unsigned)((E + per_block - 1) / per_block), (unsigned)C);

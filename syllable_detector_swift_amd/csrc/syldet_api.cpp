@@ -1321,6 +1321,21 @@ int syldet_append_interleaved(syldet_t *h, const float *data, int64_t n_frames, 
     return SYLDET_OK;
 }
 
+int syldet_append_interleaved_channels(syldet_t *h, const float *data, int64_t n_frames, int32_t total_channels, const int32_t *source_channel)
+{
+    if (!h || n_frames < 0 || (n_frames > 0 && !data) || total_channels < 1 || !source_channel)
+        return fail(SYLDET_ERR_INVALID_ARGUMENT, "bad argument");
+    for (int c = 0; c < h->channels; c++)
+        if (source_channel[c] < 0 || source_channel[c] >= total_channels) return fail(SYLDET_ERR_INVALID_ARGUMENT, "source channel outside the stream");
+    // all channels or none, as syldet_append_interleaved
+    for (int c = 0; c < h->channels; c++)
+        if (!h->streams[(size_t)c]->has_room(n_frames, h->geom.hop)) return fail(SYLDET_ERR_BUFFER_FULL, "Insufficient space on buffer.");
+    for (int c = 0; c < h->channels; c++)
+        if (!h->streams[(size_t)c]->ensure_ring()) return fail(SYLDET_ERR_OUT_OF_MEMORY, "out of memory");
+    for (int c = 0; c < h->channels; c++) h->streams[(size_t)c]->write(data + source_channel[c], n_frames, total_channels);
+    return SYLDET_OK;
+}
+
 // Evaluates what the listed channels have pending: channels with the same number of new evaluations share one
 // pinned staging block, one H2D copy, one launch and one D2H copy; the results join each channel's queue of
 // computed evaluations.  Adds the number queued to *queued.

@@ -152,10 +152,13 @@ struct syldet_sharded {
     struct Shard {
         syldet_shard_t info{};
         syldet_t *bank = nullptr;
-        hipStream_t stream = nullptr;
-        hipEvent_t packed = nullptr;          // this shard's rows are in its send buffer
-        hipEvent_t pulled = nullptr;          // (copy exchange) this device has read every shard's send buffer
-        DevMem flags, send, recv;             // own flags when the caller keeps none | packed rows | every shard's packed rows
+        hipStream_t stream = nullptr;         // the shard's kernels, and the packing of its flags
+        hipStream_t xstream = nullptr;        // the exchange and the unpacking: batch i + 1's kernels do not wait for batch i's collective
+        // two sets of exchange buffers, taken in turn (set k of batch i is free again when batch i - 2's exchange has left it)
+        hipEvent_t packed[2] = {nullptr, nullptr};     // (compute stream) this shard's rows are in send[k]
+        hipEvent_t pulled[2] = {nullptr, nullptr};     // (exchange stream, copy exchange) this device has read every shard's send[k]
+        hipEvent_t unpacked[2] = {nullptr, nullptr};   // (exchange stream) send[k] / recv[k] of this shard are done with
+        DevMem flags, send[2], recv[2];       // own flags when the caller keeps none | packed rows | every shard's packed rows
         ncclComm_t comm = nullptr;
     };
     std::vector<Shard> shards;
@@ -164,6 +167,7 @@ struct syldet_sharded {
     int exchange = SYLDET_EXCHANGE_RCCL;
     bool time_mode = false;                   // fewer channels than shards: ranges of evaluations, raw bytes in the exchange
     bool comms_up = false;
+    int turn = 0;                             // which set of exchange buffers the next gathering batch takes
     std::mutex mu;                            // one batch call at a time
 };
 
@@ -255,12 +259,16 @@ int syldet_create_sharded(const syldet_config_t *cfg, int32_t n_channels, const 
         syldet_sharded::Shard &s = b->shards[(size_t)i];
         s.info = table[(size_t)i];
         s.info.device = devices[i];
-        s.flags.device = s.send.device = s.recv.device = devices[i];
+        s.flags.device = s.send[0].device = s.send[1].device = s.recv[0].device = s.recv[1].device = devices[i];
         st = syldet_create(cfg, s.info.channels, devices[i], engine, &s.bank);      // (validates the device, makes it current)
         if (st) break;
         hipError_t e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&s.packed, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&s.pulled, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&s.xstream, hipStreamNonBlocking);
+        for (int k = 0; k < 2 && e == hipSuccess; k++) {
+            e = hipEventCreateWithFlags(&s.packed[k], hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&s.pulled[k], hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&s.unpacked[k], hipEventDisableTiming);
+        }
         if (e != hipSuccess) st = fail(SYLDET_ERR_DEVICE, std::string("stream / event: ") + hipGetErrorString(e));
     }
     if (st == SYLDET_OK) st = syldet_get_geometry(b->shards[0].bank, &b->geom);
@@ -278,21 +286,24 @@ int syldet_sharded_destroy(syldet_sharded_t *b)
     if (!b) return SYLDET_OK;
     DeviceGuard restore;
     for (auto &s : b->shards) {
-        if (s.stream) {
-            (void)hipSetDevice(s.info.device);
-            (void)hipStreamSynchronize(s.stream);
-        }
+        if (s.stream || s.xstream) (void)hipSetDevice(s.info.device);
+        if (s.stream) (void)hipStreamSynchronize(s.stream);
+        if (s.xstream) (void)hipStreamSynchronize(s.xstream);
     }
     for (auto &s : b->shards)
         if (s.comm) (void)rccl()->CommDestroy(s.comm);
     for (auto &s : b->shards) {
         (void)hipSetDevice(s.info.device);
-        if (s.packed) (void)hipEventDestroy(s.packed);
-        if (s.pulled) (void)hipEventDestroy(s.pulled);
+        for (int k = 0; k < 2; k++) {
+            if (s.packed[k]) (void)hipEventDestroy(s.packed[k]);
+            if (s.pulled[k]) (void)hipEventDestroy(s.pulled[k]);
+            if (s.unpacked[k]) (void)hipEventDestroy(s.unpacked[k]);
+            s.send[k].release();
+            s.recv[k].release();
+        }
         if (s.stream) (void)hipStreamDestroy(s.stream);
+        if (s.xstream) (void)hipStreamDestroy(s.xstream);
         s.flags.release();
-        s.send.release();
-        s.recv.release();
         if (s.bank) syldet_destroy(s.bank);
     }
     delete b;
@@ -320,6 +331,11 @@ void *syldet_sharded_stream(syldet_sharded_t *b, int32_t shard)
     return (b && shard >= 0 && shard < (int32_t)b->shards.size()) ? (void *)b->shards[(size_t)shard].stream : nullptr;
 }
 
+void *syldet_sharded_exchange_stream(syldet_sharded_t *b, int32_t shard)
+{
+    return (b && shard >= 0 && shard < (int32_t)b->shards.size()) ? (void *)b->shards[(size_t)shard].xstream : nullptr;
+}
+
 int syldet_sharded_ranges(const syldet_sharded_t *b, int32_t shard, int64_t n_samples, int64_t *s0, int64_t *s1, int64_t *e0, int64_t *count)
 {
     if (!b || shard < 0 || shard >= (int32_t)b->shards.size() || n_samples < 0) return fail(SYLDET_ERR_INVALID_ARGUMENT, "bad argument");
@@ -337,6 +353,7 @@ int syldet_sharded_run(syldet_sharded_t *b, const float *samples, int64_t n_samp
     if (!samples && n_samples > 0) return fail(SYLDET_ERR_INVALID_ARGUMENT, "NULL samples");
     if (b->channels > 1 && channel_stride < n_samples) return fail(SYLDET_ERR_INVALID_ARGUMENT, "channel_stride must be >= n_samples");
     std::lock_guard<std::mutex> lock(b->mu);
+    DeviceGuard restore;                                          // (work(0) runs on the caller's thread and makes shard 0's device current)
     const int64_t E = syldet_count_evals(b->shards[0].bank, n_samples);
     if (E <= 0) return SYLDET_OK;
     const int n = (int)b->shards.size(), n_out = b->geom.outputs;
@@ -399,7 +416,23 @@ int syldet_sharded_run_device(syldet_sharded_t *b, const float *const *d_samples
     }
     if (b->time_mode) chunk = (chunk + 15) / 16 * 16;
 
-    // 1. every shard's kernels, each on its own device and stream: all queued before anything else
+    // The exchange buffers of set k: before any of them is replaced by a longer one, nothing may still be reading it (under the
+    // copy exchange OTHER devices' streams pull from a shard's send buffer; hipFree waits for the owning device only)
+    const int k = b->turn;
+    if (gather) {
+        bool grow = false;
+        for (auto &s : b->shards) grow = grow || (size_t)chunk > s.send[k].cap || (size_t)chunk * (size_t)n > s.recv[k].cap;
+        if (grow) {
+            for (auto &s : b->shards) {
+                SYLDET_HIP(hipSetDevice(s.info.device));
+                SYLDET_HIP(hipStreamSynchronize(s.stream));
+                SYLDET_HIP(hipStreamSynchronize(s.xstream));
+            }
+        }
+        b->turn ^= 1;
+    }
+
+    // 1. every shard's kernels, each on its own device and compute stream: all queued before anything else
     for (int i = 0; i < n; i++) {
         syldet_sharded::Shard &s = b->shards[(size_t)i];
         int64_t s0, s1, e0, cnt;
@@ -411,32 +444,42 @@ int syldet_sharded_run_device(syldet_sharded_t *b, const float *const *d_samples
             fl = (uint8_t *)s.flags.ptr;
         }
         if (gather) {
-            if (int st = s.send.reserve((size_t)chunk)) return st;
-            if (int st = s.recv.reserve((size_t)chunk * (size_t)n)) return st;
+            if (int st = s.send[k].reserve((size_t)chunk)) return st;
+            if (int st = s.recv[k].reserve((size_t)chunk * (size_t)n)) return st;
         }
         if (cnt <= 0) continue;
         if (!d_samples[i]) return fail(SYLDET_ERR_INVALID_ARGUMENT, "NULL samples for shard " + std::to_string(i));
         if (int st = syldet_run_device(s.bank, d_samples[i], s1 - s0, strides[i], d_outputs ? d_outputs[i] : nullptr, fl, s.stream)) return st;
         if (gather) {
-            // (copy exchange: the last batch's rows may still be on their way out of the send buffer to another device)
+            // set k's last use was two gathering batches ago: its exchange (this shard's collective, or -- copy exchange -- the
+            // other devices' pulls out of this send buffer) must have left it before the packing below writes it again.  The
+            // kernel above does not wait for any of this: only the packing does.
+            SYLDET_HIP(hipStreamWaitEvent(s.stream, s.unpacked[k], 0));
             if (b->exchange == SYLDET_EXCHANGE_PEER_COPY)
                 for (int j = 0; j < n; j++)
-                    if (j != i) SYLDET_HIP(hipStreamWaitEvent(s.stream, b->shards[(size_t)j].pulled, 0));
+                    if (j != i) SYLDET_HIP(hipStreamWaitEvent(s.stream, b->shards[(size_t)j].pulled[k], 0));
             if (b->time_mode)
-                SYLDET_HIP(hipMemcpyAsync(s.send.ptr, fl, (size_t)cnt, hipMemcpyDeviceToDevice, s.stream));
+                SYLDET_HIP(hipMemcpyAsync(s.send[k].ptr, fl, (size_t)cnt, hipMemcpyDeviceToDevice, s.stream));
             else
-                SYLDET_HIP(launch_pack_flags(fl, s.info.channels, E, (uint8_t *)s.send.ptr, s.stream));
+                SYLDET_HIP(launch_pack_flags(fl, s.info.channels, E, (uint8_t *)s.send[k].ptr, s.stream));
+            SYLDET_HIP(hipEventRecord(s.packed[k], s.stream));
         }
     }
     if (!gather) return SYLDET_OK;
 
-    // 2. the one exchange
+    // 2. the one exchange, on the exchange streams: the compute streams are free for the next batch's kernels at once
+    //    (dist.PipelinedFlagGather does the same for the process-per-GPU launcher)
+    for (int i = 0; i < n; i++) {
+        syldet_sharded::Shard &s = b->shards[(size_t)i];
+        SYLDET_HIP(hipSetDevice(s.info.device));
+        SYLDET_HIP(hipStreamWaitEvent(s.xstream, s.packed[k], 0));
+    }
     if (b->exchange == SYLDET_EXCHANGE_RCCL) {
         Rccl *r = rccl();
         SYLDET_NCCL(r->GroupStart());
         for (int i = 0; i < n; i++) {
             syldet_sharded::Shard &s = b->shards[(size_t)i];
-            ncclResult_t st = r->AllGather(s.send.ptr, s.recv.ptr, (size_t)chunk, ncclUint8, s.comm, s.stream);
+            ncclResult_t st = r->AllGather(s.send[k].ptr, s.recv[k].ptr, (size_t)chunk, ncclUint8, s.comm, s.xstream);
             if (st != ncclSuccess) {
                 (void)r->GroupEnd();
                 return fail(SYLDET_ERR_DEVICE, std::string("ncclAllGather: ") + r->GetErrorString(st));
@@ -444,42 +487,38 @@ int syldet_sharded_run_device(syldet_sharded_t *b, const float *const *d_samples
         }
         SYLDET_NCCL(r->GroupEnd());
     } else {
-        for (int i = 0; i < n; i++) {
-            syldet_sharded::Shard &s = b->shards[(size_t)i];
-            SYLDET_HIP(hipSetDevice(s.info.device));
-            SYLDET_HIP(hipEventRecord(s.packed, s.stream));
-        }
         for (int j = 0; j < n; j++) {                             // device j pulls every shard's rows
             syldet_sharded::Shard &d = b->shards[(size_t)j];
             SYLDET_HIP(hipSetDevice(d.info.device));
             for (int i = 0; i < n; i++) {
                 syldet_sharded::Shard &s = b->shards[(size_t)i];
-                if (i != j) SYLDET_HIP(hipStreamWaitEvent(d.stream, s.packed, 0));
-                char *dst = (char *)d.recv.ptr + (size_t)i * (size_t)chunk;
+                if (i != j) SYLDET_HIP(hipStreamWaitEvent(d.xstream, s.packed[k], 0));
+                char *dst = (char *)d.recv[k].ptr + (size_t)i * (size_t)chunk;
                 if (s.info.device == d.info.device)
-                    SYLDET_HIP(hipMemcpyAsync(dst, s.send.ptr, (size_t)chunk, hipMemcpyDeviceToDevice, d.stream));
+                    SYLDET_HIP(hipMemcpyAsync(dst, s.send[k].ptr, (size_t)chunk, hipMemcpyDeviceToDevice, d.xstream));
                 else
-                    SYLDET_HIP(hipMemcpyPeerAsync(dst, d.info.device, s.send.ptr, s.info.device, (size_t)chunk, d.stream));
+                    SYLDET_HIP(hipMemcpyPeerAsync(dst, d.info.device, s.send[k].ptr, s.info.device, (size_t)chunk, d.xstream));
             }
-            SYLDET_HIP(hipEventRecord(d.pulled, d.stream));
+            SYLDET_HIP(hipEventRecord(d.pulled[k], d.xstream));
         }
     }
 
-    // 3. on every device: the gathered rows into [C][E] flags
+    // 3. on every device, still on its exchange stream: the gathered rows into [C][E] flags
     for (int j = 0; j < n; j++) {
         syldet_sharded::Shard &d = b->shards[(size_t)j];
         SYLDET_HIP(hipSetDevice(d.info.device));
         if (!b->time_mode) {
-            SYLDET_HIP(launch_unpack_flags_gathered((const uint8_t *)d.recv.ptr, b->channels, E, n, padded_rows, d_flags_all[j], d.stream));
-            continue;
+            SYLDET_HIP(launch_unpack_flags_gathered((const uint8_t *)d.recv[k].ptr, b->channels, E, n, padded_rows, d_flags_all[j], d.xstream));
+        } else {
+            for (int i = 0; i < n; i++) {
+                int64_t e0, cnt;
+                ranges_of(b, b->shards[(size_t)i], n_samples, nullptr, nullptr, &e0, &cnt);
+                if (cnt > 0)
+                    SYLDET_HIP(hipMemcpyAsync(d_flags_all[j] + (size_t)b->shards[(size_t)i].info.first_channel * (size_t)E + (size_t)e0,
+                                              (const char *)d.recv[k].ptr + (size_t)i * (size_t)chunk, (size_t)cnt, hipMemcpyDeviceToDevice, d.xstream));
+            }
         }
-        for (int i = 0; i < n; i++) {
-            int64_t e0, cnt;
-            ranges_of(b, b->shards[(size_t)i], n_samples, nullptr, nullptr, &e0, &cnt);
-            if (cnt > 0)
-                SYLDET_HIP(hipMemcpyAsync(d_flags_all[j] + (size_t)b->shards[(size_t)i].info.first_channel * (size_t)E + (size_t)e0,
-                                          (const char *)d.recv.ptr + (size_t)i * (size_t)chunk, (size_t)cnt, hipMemcpyDeviceToDevice, d.stream));
-        }
+        SYLDET_HIP(hipEventRecord(d.unpacked[k], d.xstream));
     }
     return SYLDET_OK;
 }
@@ -491,6 +530,7 @@ int syldet_sharded_synchronize(syldet_sharded_t *b)
     for (auto &s : b->shards) {
         SYLDET_HIP(hipSetDevice(s.info.device));
         SYLDET_HIP(hipStreamSynchronize(s.stream));
+        SYLDET_HIP(hipStreamSynchronize(s.xstream));
     }
     return SYLDET_OK;
 }

@@ -81,9 +81,19 @@ class SyllableDetector:
         a = np.ascontiguousarray(data, dtype=np.float32)
         check(_abi.lib.syldet_append(self._h, channel, a.ctypes.data_as(_abi.c_float_p), a.size))
 
-    def appendInterleavedData(self, data) -> None:
-        a = np.ascontiguousarray(data, dtype=np.float32).reshape(-1, self.channels)
-        check(_abi.lib.syldet_append_interleaved(self._h, a.ctypes.data_as(_abi.c_float_p), a.shape[0], self.channels))
+    def appendInterleavedData(self, data, fromChannels=None) -> None:
+        """appendInterleavedData(_:withSamples:fromChannel:ofTotalChannels:) (CircularShortTimeFourierTransform.swift:203-217):
+        `data` [frames, total channels]; fromChannels (one stream channel per bank channel) picks a subset of a wider stream."""
+        if fromChannels is None:
+            a = np.ascontiguousarray(data, dtype=np.float32).reshape(-1, self.channels)
+            check(_abi.lib.syldet_append_interleaved(self._h, a.ctypes.data_as(_abi.c_float_p), a.shape[0], self.channels))
+            return
+        a = np.ascontiguousarray(data, np.float32)
+        src = np.ascontiguousarray(fromChannels, np.int32)
+        if a.ndim != 2 or src.shape != (self.channels,):
+            raise ValueError("data [frames, total channels] and one source channel per bank channel")
+        check(_abi.lib.syldet_append_interleaved_channels(self._h, a.ctypes.data_as(_abi.c_float_p), a.shape[0], a.shape[1],
+                                                          src.ctypes.data_as(_abi.C.POINTER(_abi.C.c_int32))))
 
     def processNewValue(self, channel: int = 0) -> bool:
         return check(_abi.lib.syldet_process_new_value(self._h, channel)) == 1

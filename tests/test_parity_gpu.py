@@ -326,6 +326,33 @@ def test_interleaved_append(oracle_lib):
             util.assert_outputs_close(np.array(outs).reshape(-1, 1), o.run(x[c], po.F64)[2])
 
 
+def test_interleaved_append_from_a_subset_of_a_wider_stream(oracle_lib):
+    """appendInterleavedData(_:withSamples:fromChannel:ofTotalChannels:) (CircularShortTimeFourierTransform.swift:203-217) takes ONE
+    channel out of a wider stream: a bank of three detectors on channels 5, 0 and 5 again of an eight-channel device stream, fed in
+    ragged callbacks, against the oracle on those channels; bad source channels are refused before anything is written."""
+    cfg = util.sample_net()
+    o = util.oracle_for(cfg)
+    total, S = 8, 6000
+    x = np.stack([synth.channel(S, 40 + c) for c in range(total)])
+    frames = np.ascontiguousarray(x.T)                             # [frames][8]
+    pick = [5, 0, 5]
+    with sd.SyllableDetector(cfg, channels=3) as det:
+        with pytest.raises(sd.SyllableDetectorError):
+            det.appendInterleavedData(frames[:10], fromChannels=[0, 1, 8])
+        with pytest.raises(sd.SyllableDetectorError):
+            det.appendInterleavedData(frames[:10], fromChannels=[0, -1, 2])
+        at = 0
+        for n in (32, 500, 1, 2999, 2468):                        # (sums to 6000)
+            det.appendInterleavedData(frames[at:at + n], fromChannels=pick)
+            at += n
+        assert at == S
+        for c, src in enumerate(pick):
+            outs = []
+            while det.processNewValue(c):
+                outs.append(det.lastOutputsFor(c))
+            util.assert_outputs_close(np.array(outs).reshape(-1, 1), o.run(x[src], po.F64)[2])
+
+
 def test_host_pointer_entry_points(oracle_lib):
     cfg, x, gold = util.load_case("case_sample_syllables")
     o = util.oracle_for(cfg)

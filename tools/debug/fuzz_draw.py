@@ -56,3 +56,12 @@ for c in range(C):
         print("   max |x| in pass", float(np.abs(x[c][lo * hop:(lo + 128) * hop + cfg.windowLength]).max()))
     for b in bad[:5]:
         print("   e", b, "out", out[c][b], "w64", w64[b], "w32", w32[b], "env at", env[(b + cfg.timeRange) * hop])
+        # where the error is made: the GPU's columns through the anchor's network (fp64), the fp32 port's columns through it,
+        # and the anchor's columns through the fp32 port's network
+        T = cfg.timeRange
+        sc = (lambda v: np.log(v) if cfg.spectrogramScaling == "log" else 20 * np.log10(v) if cfg.spectrogramScaling == "db" else v)
+        for label, cols, prec in (("gpu columns, fp64 network", colg, po.F64), ("port columns, fp64 network", cols32, po.F64), ("anchor columns, fp32 network", cols64, po.F32),
+                                  ("gpu columns, fp32 network", colg, po.F32)):
+            y = o.net_apply(sc(cols[b:b + T].reshape(-1).astype(np.float64)).astype(np.float32 if prec == po.F32 else np.float64), prec)
+            print("      %-30s err %.3g" % (label, float((np.abs(y - w64[b]) / np.maximum(1.0, np.abs(w64[b]))).max())))
+    print("   network:", [(L.inputs, L.outputs, L.transferFunction) for L in cfg.net.layers], [f.function for f in cfg.net.inputProcessing], "window", cfg.window, "N", cfg.fourierLength)
