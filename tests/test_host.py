@@ -220,6 +220,38 @@ def test_mfma_hazard_checker_sees_a_vector_write_in_front_of_a_hand_placed_mfma(
     assert chk.check(str(waited)) == (1, [])
 
 
+def test_operand_selection_checker_refuses_src1_high_into_the_low_half(tmp_path):
+    """tools/check_pk_opsel.py (csrc/Makefile runs it on the ISA of every kernel file): a packed fp32 instruction that takes
+    src1's high register into its low half loses that half's product beside another wave's matrix instructions on MI355X
+    (tools/ubench/pkfma_opsel.hip, MEASUREMENTS R5.1); the same selection on src0 / src2 and op_sel_hi are fine.  Also the two
+    checks on functions that issue LDS-DMA through assembly: M0 theirs alone, vmcnt(0) in front of every later barrier."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("chk2", os.path.join(ROOT, "tools", "check_pk_opsel.py"))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    head = "_Z1kv:\n"
+    fine = tmp_path / "fine.s"
+    fine.write_text(head + "\tv_pk_fma_f32 v[0:1], v[2:3], v[4:5], v[0:1] op_sel:[1,0,0]\n\tv_pk_fma_f32 v[0:1], v[2:3], v[4:5], v[0:1] op_sel_hi:[1,0,1]\n"
+                    "\tv_pk_mul_f32 v[0:1], v[2:3], v[4:5]\n\tv_fma_mix_f32 v0, v1, v2, v3 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n")
+    bad, n_pk, n_dma = chk.check(str(fine))
+    assert bad == [] and n_pk == 3 and n_dma == 0
+    for line in ("v_pk_fma_f32 v[0:1], v[2:3], v[4:5], v[0:1] op_sel:[0,1,0]", "v_pk_mul_f32 v[0:1], v[2:3], v[4:5] op_sel:[0,1]",
+                 "v_pk_add_f32 v[0:1], v[2:3], v[4:5] op_sel:[1,1] op_sel_hi:[0,1]", "v_fma_mix_f32 v0, v1, v2, v3 op_sel:[0,1,0] op_sel_hi:[0,1,0]"):
+        f = tmp_path / "bad.s"
+        f.write_text(head + "\t" + line + "\n")
+        assert len(chk.check(str(f))[0]) == 1, line
+    dma = "\t;;#ASMSTART\n\ts_mov_b32 m0, s7\n\ts_nop 0\n\tbuffer_load_dwordx4 v1, s[0:3], s6 offen lds\n\t;;#ASMEND\n"
+    ok = tmp_path / "dma_ok.s"
+    ok.write_text(head + "\ts_barrier\n" + dma + "\tv_add_f32_e32 v2, v3, v4\n\ts_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier\n")
+    assert chk.check(str(ok)) == ([], 0, 1)                        # (the barrier in front of the first DMA is the prologue's)
+    nowait = tmp_path / "dma_nowait.s"
+    nowait.write_text(head + dma + "\tv_add_f32_e32 v2, v3, v4\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier\n")
+    assert len(chk.check(str(nowait))[0]) == 1
+    m0 = tmp_path / "dma_m0.s"
+    m0.write_text(head + dma + "\ts_mov_b32 m0, s9\n\ts_waitcnt vmcnt(0)\n\ts_barrier\n")
+    assert len(chk.check(str(m0))[0]) == 1
+
+
 def test_header_is_plain_c_and_the_library_refuses_to_run_without_a_device(tmp_path):
     """include/syldet.h compiles as strict C99 (-pedantic -Werror) and a C program links against libsyldet -- the way the
     reference's bridging header binds its one C API (Common/Common-Bridging-Header.h:5).  Without a gfx950 device the

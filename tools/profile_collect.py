@@ -99,7 +99,7 @@ for wl, dom in (("sample", "fused_s_kernel"), ("config3", "fft1k_net_kernel"), (
         json.dump(t, open(os.path.join(DST, "%s_%straffic.json" % (R, "" if wl == "sample" else wl + "_")), "w"), indent=1)
         summary[wl]["traffic_ratio"] = hbm / alg
     util = {}
-    for f in glob.glob(os.path.join(SRC, "pmc_%s_SQ*" % wl)):
+    for f in glob.glob(os.path.join(SRC, "pmc_%s_SQ*" % wl)):          # (every utilisation group's directory is pmc_<workload>_SQ_<counters>)
         if os.path.isdir(f):
             for k, d in counters(os.path.basename(f)[4:]).items():
                 util.setdefault(k, {}).update(d)
@@ -118,6 +118,24 @@ for wl, dom in (("sample", "fused_s_kernel"), ("config3", "fft1k_net_kernel"), (
             der["wait_inst_any_fraction_of_wave_cycles"] = c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"]
         if "SQ_INSTS_VALU" in c and "SQ_INSTS_MFMA" in c and c["SQ_INSTS_MFMA"]:
             der["valu_to_mfma_instruction_ratio"] = c["SQ_INSTS_VALU"] / c["SQ_INSTS_MFMA"]
+        # The decomposition that closes: GRBM_GUI_ACTIVE is summed over the 8 XCDs, so /8 is the launch in
+        # shader clocks; the matrix pipe's busy fraction BY TIME is instructions x 16 clocks (a 16x16x32 MFMA is four passes of
+        # four) over 1024 SIMDs x those clocks -- SQ_BUSY_CU_CYCLES, the old denominator, shrinks when CUs idle at the launch's
+        # tail and flatters the pipe.  roofline = busy x useful K / padded K x sclk / 2.4 GHz for the wide GEMM.
+        tr = summary[wl].get("timed_region_from_the_trace") or {}
+        if "GRBM_GUI_ACTIVE" in c and c["GRBM_GUI_ACTIVE"]:
+            clocks = c["GRBM_GUI_ACTIVE"] / 8.0
+            der["launch_shader_clocks (GRBM_GUI_ACTIVE / 8 XCDs)"] = clocks
+            ms = (ks or {}).get(dom, {}).get("average_ms") or tr.get("average_ms")
+            if ms:
+                der["sclk_GHz (clocks / rocprofv3 average duration)"] = clocks / (ms * 1e6)
+            if "SQ_INSTS_MFMA" in c:
+                busy = c["SQ_INSTS_MFMA"] * 16.0 / (1024.0 * clocks)
+                der["mfma_pipe_busy_fraction_by_time (INSTS_MFMA x 16 / (1024 SIMDs x clocks))"] = busy
+                if wl == "config5" and ms:
+                    der["roofline_from_counters (busy x 290/320 x sclk / 2.4 GHz)"] = busy * 290.0 / 320.0 * (clocks / (ms * 1e6)) / 2.4
+            if "SQ_INSTS_VALU" in c:
+                der["valu_issue_slots_used_fraction (INSTS_VALU x 4 / (1024 SIMDs x clocks); packed and transcendental instructions take 8)"] = c["SQ_INSTS_VALU"] * 4.0 / (1024.0 * clocks)
         summary[wl]["utilisation"] = {"kernel": dom, "counters": c, "derived": der}
 json.dump(summary, open(os.path.join(DST, "%s_profile_summary.json" % R), "w"), indent=1)
 print(json.dumps({k: (v if k == "source" else {kk: vv for kk, vv in v.items() if kk != "utilisation"}) for k, v in summary.items()}, indent=1)[:3000])

@@ -4,7 +4,7 @@
 #   usage: tools/profile_round.sh r02
 # Counters are collected in passes of their own (--kernel-trace + --pmc only), the program right behind "--".
 set -u
-R=${1:-r04}
+R=${1:-r05}
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/prof_$R
 mkdir -p $OUT
@@ -28,11 +28,11 @@ run_pmc sample_fetch FETCH_SIZE
 run_pmc sample_write WRITE_SIZE
 run_pmc config3_fetch FETCH_SIZE --workload config3
 run_pmc config3_write WRITE_SIZE --workload config3
-for grp in "SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS" "SQ_WAIT_ANY SQ_WAIT_INST_ANY"; do
+for grp in "GRBM_GUI_ACTIVE SQ_WAVES" "SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS" "SQ_WAIT_ANY SQ_WAIT_INST_ANY"; do
   tag=$(echo $grp | tr ' ' '_' | cut -c1-30)
-  run_pmc sample_$tag "$grp"
-  run_pmc config3_$tag "$grp" --workload config3
-  run_pmc config5_$tag "$grp" --workload config5
+  run_pmc sample_SQ_$tag "$grp"
+  run_pmc config3_SQ_$tag "$grp" --workload config3
+  run_pmc config5_SQ_$tag "$grp" --workload config5
 done
 cd $ROOT
 python3 tools/profile_collect.py $R
