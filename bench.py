@@ -121,33 +121,34 @@ BINDING = {
 }
 
 
-def binding_of(kernel, launch, seconds=1.0):
-    """`launch()` queues one step.  Loops it for `seconds` while rocm-smi is polled: socket power and shader clock under THIS kernel
-    (the timed region is tens of milliseconds, too short for the tool's sampling).  Issue-slot use comes from the committed PMC
+def binding_of(kernel, launch, seconds=1.0, device_index=0):
+    """`launch()` queues one step.  Loops it for `seconds` while the package's power and shader-clock sensors are read (hwmon, every
+    10 ms): socket power and clock under THIS kernel (the timed region is tens of milliseconds: the package figure lags behind it).  Issue-slot use comes from the committed PMC
     passes when they cover the kernel (profiles/r*_profile_summary.json), like `traffic`."""
-    import subprocess
     import threading
     import torch
     resource, evidence = BINDING.get(kernel, ("unknown", "no evidence recorded for this kernel"))
     watts, mhz, stop = [], [], [False]
 
+    # the package's own sensors through sysfs (what rocm-smi prints): no child process, nothing executed beside a process that holds the GPU
+    hw = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_input"))
+    hwdir = os.path.dirname(hw[min(device_index, len(hw) - 1)]) if hw else None
+
+    def read_num(name):
+        try:
+            return float(open(os.path.join(hwdir, name)).read().strip())
+        except Exception:
+            return None
+    cap = read_num("power1_cap") if hwdir else None
+
     def poll():
-        while not stop[0]:
-            try:
-                o = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--csv"], capture_output=True, text=True, timeout=5).stdout
-                rows = [l.split(",") for l in o.splitlines() if l.strip()]
-                head = rows[0]
-                for r in rows[1:2]:                                  # (device 0's row)
-                    for h, v in zip(head, r):
-                        if "power" in h.lower() and "(w)" in h.lower():
-                            watts.append(float(v))
-                        if h.lower().startswith("sclk") and "mhz" in v.lower():
-                            mhz.append(float(v.strip("()MHzmhz ")))
-                        elif "sclk clock speed" in h.lower():
-                            mhz.append(float(v.strip("()MHzmhz ")))
-            except Exception:
-                pass
-            time.sleep(0.02)
+        while not stop[0] and hwdir:
+            w, f = read_num("power1_input"), read_num("freq1_input")
+            if w is not None:
+                watts.append(w / 1e6)
+            if f is not None:
+                mhz.append(f / 1e6)
+            time.sleep(0.01)
     th = threading.Thread(target=poll, daemon=True)
     th.start()
     t0 = time.perf_counter()
@@ -157,11 +158,15 @@ def binding_of(kernel, launch, seconds=1.0):
             launch()
         torch.cuda.synchronize()
         n += 4
+    looped_ms = 1e3 * (time.perf_counter() - t0) / max(n, 1)
     stop[0] = True
     th.join(timeout=6)
     med = lambda v: sorted(v)[len(v) // 2] if v else None
-    rec = {"resource": resource, "evidence": evidence, "socket_w": med(watts), "sclk_mhz": med(mhz), "power_limit_w": 1400,
-           "samples": len(watts), "launches_while_sampled": n, "issue_slot_utilisation": None, "issue_slot_source": None}
+    rec = {"resource": resource, "evidence": evidence, "socket_w": med(watts[len(watts) // 2:]), "sclk_mhz": med(mhz[len(mhz) // 2:]),   # (the loop's second half: the ramp is over)
+           "power_limit_w": (cap / 1e6) if cap else 1400,
+           "samples": len(watts), "launches_while_sampled": n,
+           "ms_per_step_looped": looped_ms,        # (wall clock over the loop, a synchronisation every four steps: the regime of a job that runs for seconds)
+           "issue_slot_utilisation": None, "issue_slot_source": None}
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_profile_summary.json")), reverse=True):
         try:
             for wl, v in json.load(open(path)).items():
@@ -388,21 +393,28 @@ def single_process(args):
     bank = ShardedSyllableDetectorBank(cfg, total, devices, engine=args.engine)
     g = bank.geometry
     J, E = bank.countFrames(S), bank.countEvaluations(S)
-    blocks, outs, fls, alls = [], [], [], []
+    blocks, outs, fls, fls_b, alls = [], [], [], [], []
     for i, sh in enumerate(bank.shards):
         dev = torch.device("cuda", sh.device)
         blocks.append(synth.channels_on_device(sh.channels, S, dev, first=sh.first_channel, fs=cfg.samplingRate))
         outs.append(torch.empty((sh.channels, E, g.outputs), dtype=torch.float32, device=dev))
         fls.append(torch.empty((sh.channels, E), dtype=torch.uint8, device=dev))
+        fls_b.append(torch.empty((sh.channels, E), dtype=torch.uint8, device=dev))
         alls.append(torch.empty((total, E), dtype=torch.uint8, device=dev))
     dets = [sd.SyllableDetector.borrowed(bank, i) for i in range(N)]
     for d in dets:
         d.profile(True, history=max(args.steps, 1))
 
-    def step():
-        bank.run(blocks, S, gather=True, outputs=outs, flags=fls, flags_all=alls)
-
+    # every shard's own flags land in one of two tensors in turn: a batch's flags are packed on the exchange stream while the next
+    # batch's kernel runs, and a kernel that writes the tensor still being packed from would have to wait for that (the library
+    # checks).  The last step's (the one verified below) are in `fls`.
     preroll = args.preroll if args.preroll is not None else 150
+    left = [preroll + args.warmup + args.steps]                   # steps still to come: the last one (0 left after it) writes `fls`
+
+    def step():
+        left[0] -= 1
+        bank.run(blocks, S, gather=True, outputs=outs, flags=fls if left[0] % 2 == 0 else fls_b, flags_all=alls)
+
     for _ in range(preroll + args.warmup):
         step()
     bank.synchronize()

@@ -134,10 +134,11 @@ pack_flags_kernel(const uint8_t *__restrict__ flags, int64_t row_len, int64_t ro
 // extra == 0 and padded == base the map is the identity.
 __device__ __forceinline__ int64_t gathered_row(int64_t r, int64_t padded, int64_t base, int64_t extra)
 {
-    const int64_t big = extra * (base + 1);
-    if (r < big) return (r / (base + 1)) * padded + r % (base + 1);
-    const int64_t q = r - big;
-    return (extra + q / base) * padded + q % base;
+    // (rows <= 65535: 32-bit divisions)
+    const unsigned r32 = (unsigned)r, b32 = (unsigned)base, big = (unsigned)extra * (b32 + 1);
+    if (r32 < big) return (int64_t)(r32 / (b32 + 1)) * padded + r32 % (b32 + 1);
+    const unsigned q = r32 - big;
+    return (extra + (int64_t)(q / b32)) * padded + q % b32;
 }
 
 template <bool MAPPED>
@@ -148,7 +149,30 @@ unpack_flags_kernel(const uint8_t *__restrict__ bits, int64_t rows, int64_t row_
     // one aligned 8-byte store per thread over the flat [rows * row_len] output; a thread's eight flags may straddle two rows
     const int64_t q = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8, total = rows * row_len;
     if (q >= total) return;
-    int64_t row = q / row_len, i = q - row * row_len;
+    // (the plane's row of flat index q: a 32-bit division wherever the plane is under 2^32 flags -- 4096 x 15 877 is 6.5e7)
+    int64_t row, i;
+    if (total < (int64_t)0xffffffffLL) {
+        const unsigned r32 = (unsigned)q / (unsigned)row_len;
+        row = r32;
+        i = (int64_t)((unsigned)q - r32 * (unsigned)row_len);
+    } else {
+        row = q / row_len;
+        i = q - row * row_len;
+    }
+    if (i + 8 <= row_len) {
+        // eight flags of ONE row (all but a row's last group): bits i .. i + 7 of it sit in two bytes at most; bit k -> byte k by one
+        // multiplication (round 5: the byte-a-bit loop below took 35 us for 512 x 15 877 flags, and on eight GPUs every device
+        // unpacks eight times that per batch)
+        const int64_t src = MAPPED ? gathered_row(row, padded, base, extra) : row;
+        const uint8_t *p = bits + src * row_bytes + (i >> 3);
+        unsigned w = p[0];
+        if ((i & 7) != 0) w |= (unsigned)p[1] << 8;               // (i + 8 <= row_len and i % 8 != 0: the next byte is inside the row)
+        const uint64_t b = (w >> (i & 7)) & 0xffu;
+        const uint64_t spread = (b * 0x0101010101010101ULL) & 0x8040201008040201ULL;      // byte k keeps bit k
+        const uint64_t out8 = ((spread + 0x7f7f7f7f7f7f7f7fULL) >> 7) & 0x0101010101010101ULL;   // non-zero byte -> 1
+        *reinterpret_cast<uint64_t *>(flags + q) = out8;
+        return;
+    }
     uint64_t out = 0;
 #pragma unroll
     for (int k = 0; k < 8; k++) {

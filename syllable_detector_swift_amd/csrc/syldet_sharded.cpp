@@ -152,13 +152,15 @@ struct syldet_sharded {
     struct Shard {
         syldet_shard_t info{};
         syldet_t *bank = nullptr;
-        hipStream_t stream = nullptr;         // the shard's kernels, and the packing of its flags
-        hipStream_t xstream = nullptr;        // the exchange and the unpacking: batch i + 1's kernels do not wait for batch i's collective
+        hipStream_t stream = nullptr;         // the shard's kernels, and nothing else
+        hipStream_t xstream = nullptr;        // packing, exchange, unpacking: batch i + 1's kernels do not wait for batch i's collective
         // two sets of exchange buffers, taken in turn (set k of batch i is free again when batch i - 2's exchange has left it)
-        hipEvent_t packed[2] = {nullptr, nullptr};     // (compute stream) this shard's rows are in send[k]
+        hipEvent_t computed[2] = {nullptr, nullptr};   // (compute stream) this shard's kernel of the batch that took set k has finished
+        hipEvent_t packed[2] = {nullptr, nullptr};     // (exchange stream) this shard's rows are in send[k]
         hipEvent_t pulled[2] = {nullptr, nullptr};     // (exchange stream, copy exchange) this device has read every shard's send[k]
         hipEvent_t unpacked[2] = {nullptr, nullptr};   // (exchange stream) send[k] / recv[k] of this shard are done with
-        DevMem flags, send[2], recv[2];       // own flags when the caller keeps none | packed rows | every shard's packed rows
+        DevMem flags[2], send[2], recv[2];    // own flags when the caller keeps none (one per set) | packed rows | every shard's packed rows
+        const uint8_t *set_fl[2] = {nullptr, nullptr};   // the flags set k's last batch was packed from (a caller may hand one tensor to every batch)
         ncclComm_t comm = nullptr;
     };
     std::vector<Shard> shards;
@@ -259,13 +261,14 @@ int syldet_create_sharded(const syldet_config_t *cfg, int32_t n_channels, const 
         syldet_sharded::Shard &s = b->shards[(size_t)i];
         s.info = table[(size_t)i];
         s.info.device = devices[i];
-        s.flags.device = s.send[0].device = s.send[1].device = s.recv[0].device = s.recv[1].device = devices[i];
+        s.flags[0].device = s.flags[1].device = s.send[0].device = s.send[1].device = s.recv[0].device = s.recv[1].device = devices[i];
         st = syldet_create(cfg, s.info.channels, devices[i], engine, &s.bank);      // (validates the device, makes it current)
         if (st) break;
         hipError_t e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&s.xstream, hipStreamNonBlocking);
         for (int k = 0; k < 2 && e == hipSuccess; k++) {
             e = hipEventCreateWithFlags(&s.packed[k], hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&s.computed[k], hipEventDisableTiming);
             if (e == hipSuccess) e = hipEventCreateWithFlags(&s.pulled[k], hipEventDisableTiming);
             if (e == hipSuccess) e = hipEventCreateWithFlags(&s.unpacked[k], hipEventDisableTiming);
         }
@@ -296,6 +299,8 @@ int syldet_sharded_destroy(syldet_sharded_t *b)
         (void)hipSetDevice(s.info.device);
         for (int k = 0; k < 2; k++) {
             if (s.packed[k]) (void)hipEventDestroy(s.packed[k]);
+            if (s.computed[k]) (void)hipEventDestroy(s.computed[k]);
+            s.flags[k].release();
             if (s.pulled[k]) (void)hipEventDestroy(s.pulled[k]);
             if (s.unpacked[k]) (void)hipEventDestroy(s.unpacked[k]);
             s.send[k].release();
@@ -303,7 +308,6 @@ int syldet_sharded_destroy(syldet_sharded_t *b)
         }
         if (s.stream) (void)hipStreamDestroy(s.stream);
         if (s.xstream) (void)hipStreamDestroy(s.xstream);
-        s.flags.release();
         if (s.bank) syldet_destroy(s.bank);
     }
     delete b;
@@ -421,7 +425,13 @@ int syldet_sharded_run_device(syldet_sharded_t *b, const float *const *d_samples
     const int k = b->turn;
     if (gather) {
         bool grow = false;
-        for (auto &s : b->shards) grow = grow || (size_t)chunk > s.send[k].cap || (size_t)chunk * (size_t)n > s.recv[k].cap;
+        for (int i = 0; i < n; i++) {
+            syldet_sharded::Shard &s = b->shards[(size_t)i];
+            int64_t cnt;
+            ranges_of(b, s, n_samples, nullptr, nullptr, nullptr, &cnt);
+            grow = grow || (size_t)chunk > s.send[k].cap || (size_t)chunk * (size_t)n > s.recv[k].cap ||
+                   (!(d_flags && d_flags[i]) && (size_t)s.info.channels * (size_t)std::max<int64_t>(cnt, 1) > s.flags[k].cap);
+        }
         if (grow) {
             for (auto &s : b->shards) {
                 SYLDET_HIP(hipSetDevice(s.info.device));
@@ -432,37 +442,37 @@ int syldet_sharded_run_device(syldet_sharded_t *b, const float *const *d_samples
         b->turn ^= 1;
     }
 
-    // 1. every shard's kernels, each on its own device and compute stream: all queued before anything else
+    // 1. every shard's kernels, each on its own device and compute stream: all queued before anything else -- and nothing else
+    //    is queued there: the packing of the flags belongs to the exchange (a kernel of its own between two batches' kernels cost
+    //    the compute stream ~19 us a batch against ~3 us between back-to-back kernels)
+    std::vector<uint8_t *> fls((size_t)n, nullptr);
+    std::vector<int64_t> cnts((size_t)n, 0);
     for (int i = 0; i < n; i++) {
         syldet_sharded::Shard &s = b->shards[(size_t)i];
         int64_t s0, s1, e0, cnt;
         ranges_of(b, s, n_samples, &s0, &s1, &e0, &cnt);
+        cnts[(size_t)i] = cnt;
         SYLDET_HIP(hipSetDevice(s.info.device));
         uint8_t *fl = d_flags ? d_flags[i] : nullptr;
         if (gather && !fl) {
-            if (int st = s.flags.reserve((size_t)s.info.channels * (size_t)std::max<int64_t>(cnt, 1))) return st;
-            fl = (uint8_t *)s.flags.ptr;
+            if (int st = s.flags[k].reserve((size_t)s.info.channels * (size_t)std::max<int64_t>(cnt, 1))) return st;
+            fl = (uint8_t *)s.flags[k].ptr;
         }
+        fls[(size_t)i] = fl;
         if (gather) {
             if (int st = s.send[k].reserve((size_t)chunk)) return st;
             if (int st = s.recv[k].reserve((size_t)chunk * (size_t)n)) return st;
         }
         if (cnt <= 0) continue;
         if (!d_samples[i]) return fail(SYLDET_ERR_INVALID_ARGUMENT, "NULL samples for shard " + std::to_string(i));
+        // the flags this kernel writes may be the tensor the batch before is still being packed from (a caller that hands the same
+        // one to every batch; the library's own are one per set): only then does the kernel wait for that packing
+        for (int kk = 0; kk < 2; kk++)
+            if (fl && fl == s.set_fl[kk]) SYLDET_HIP(hipStreamWaitEvent(s.stream, s.packed[kk], 0));
         if (int st = syldet_run_device(s.bank, d_samples[i], s1 - s0, strides[i], d_outputs ? d_outputs[i] : nullptr, fl, s.stream)) return st;
         if (gather) {
-            // set k's last use was two gathering batches ago: its exchange (this shard's collective, or -- copy exchange -- the
-            // other devices' pulls out of this send buffer) must have left it before the packing below writes it again.  The
-            // kernel above does not wait for any of this: only the packing does.
-            SYLDET_HIP(hipStreamWaitEvent(s.stream, s.unpacked[k], 0));
-            if (b->exchange == SYLDET_EXCHANGE_PEER_COPY)
-                for (int j = 0; j < n; j++)
-                    if (j != i) SYLDET_HIP(hipStreamWaitEvent(s.stream, b->shards[(size_t)j].pulled[k], 0));
-            if (b->time_mode)
-                SYLDET_HIP(hipMemcpyAsync(s.send[k].ptr, fl, (size_t)cnt, hipMemcpyDeviceToDevice, s.stream));
-            else
-                SYLDET_HIP(launch_pack_flags(fl, s.info.channels, E, (uint8_t *)s.send[k].ptr, s.stream));
-            SYLDET_HIP(hipEventRecord(s.packed[k], s.stream));
+            SYLDET_HIP(hipEventRecord(s.computed[k], s.stream));
+            s.set_fl[k] = fl;
         }
     }
     if (!gather) return SYLDET_OK;
@@ -472,7 +482,19 @@ int syldet_sharded_run_device(syldet_sharded_t *b, const float *const *d_samples
     for (int i = 0; i < n; i++) {
         syldet_sharded::Shard &s = b->shards[(size_t)i];
         SYLDET_HIP(hipSetDevice(s.info.device));
-        SYLDET_HIP(hipStreamWaitEvent(s.xstream, s.packed[k], 0));
+        SYLDET_HIP(hipStreamWaitEvent(s.xstream, s.computed[k], 0));
+        // set k's last use was two gathering batches ago.  This shard's own collective and unpacking of that batch are earlier
+        // work of this very stream; under the copy exchange the OTHER devices pulled from this send buffer: their pulls first
+        if (b->exchange == SYLDET_EXCHANGE_PEER_COPY)
+            for (int j = 0; j < n; j++)
+                if (j != i) SYLDET_HIP(hipStreamWaitEvent(s.xstream, b->shards[(size_t)j].pulled[k], 0));
+        if (cnts[(size_t)i] > 0) {
+            if (b->time_mode)
+                SYLDET_HIP(hipMemcpyAsync(s.send[k].ptr, fls[(size_t)i], (size_t)cnts[(size_t)i], hipMemcpyDeviceToDevice, s.xstream));
+            else
+                SYLDET_HIP(launch_pack_flags(fls[(size_t)i], s.info.channels, E, (uint8_t *)s.send[k].ptr, s.xstream));
+        }
+        SYLDET_HIP(hipEventRecord(s.packed[k], s.xstream));
     }
     if (b->exchange == SYLDET_EXCHANGE_RCCL) {
         Rccl *r = rccl();

@@ -361,7 +361,7 @@ def test_producer_thread_against_consumer_thread(oracle_lib):
 
 # ---- the multi-GPU exchange travels as bits -------------------------------------------------------
 
-@pytest.mark.parametrize("shape", [(1, 1), (3, 7), (5, 8), (4, 127090), (64, 1000), (2, 65)])
+@pytest.mark.parametrize("shape", [(1, 1), (3, 7), (5, 8), (4, 127090), (64, 1000), (2, 65), (7, 13), (512, 15877), (3, 16), (9, 23)])
 def test_flag_bits_round_trip(shape):
     torch = _torch()
     from syllable_detector_swift_amd.dist import pack_flags, unpack_flags
