@@ -571,12 +571,22 @@ def main():
     gather = PipelinedFlagGather(C, E, total, dev) if (exchange and equal) else None
     gathered = None
 
+    # (with the pipelined exchange the flags land in two tensors in turn: a batch's flags are packed on the side stream while the
+    # next batch's kernel runs; `flags` holds the last step's -- the one verified below -- and those of every second one before it)
+    flags_b = torch.empty_like(flags) if gather is not None else None
+    left = [0]                                           # steps still to come in the current stretch (set by the loops below)
+
     def step():
         nonlocal gathered
-        det.run(x, outputs, flags)
         if gather is not None:
-            gather.submit(flags)
-        elif exchange:
+            left[0] -= 1
+            fl = flags if left[0] % 2 == 0 else flags_b
+            gather.before_run(fl)
+            det.run(x, outputs, fl)
+            gather.submit(fl)
+            return
+        det.run(x, outputs, flags)
+        if exchange:
             gathered = gather_flags(flags, total)        # ragged shards: the padded form, on the compute stream
 
     # From an idle device the clock governor takes 30-50 ms of back-to-back launches to reach the state it then holds for
@@ -588,6 +598,7 @@ def main():
     # ... and BEFORE it, the from-idle regime for the record: W warmup launches on the idle device, then K timed steps
     # (what `--preroll 0` measures), with the same barriers; the pre-rolled measurement below is the headline.
     from_idle = None
+    left[0] = ((args.warmup + args.steps) if preroll > 0 else 0) + preroll + args.warmup + args.steps    # every step() to come
     if preroll > 0:
         for _ in range(args.warmup):
             step()

@@ -468,7 +468,8 @@ int syldet_sharded_run_device(syldet_sharded_t *b, const float *const *d_samples
         // the flags this kernel writes may be the tensor the batch before is still being packed from (a caller that hands the same
         // one to every batch; the library's own are one per set): only then does the kernel wait for that packing
         for (int kk = 0; kk < 2; kk++)
-            if (fl && fl == s.set_fl[kk]) SYLDET_HIP(hipStreamWaitEvent(s.stream, s.packed[kk], 0));
+            if (fl && fl == s.set_fl[kk] && hipEventQuery(s.packed[kk]) == hipErrorNotReady)     // (a wait is a packet on the stream: only if needed)
+                SYLDET_HIP(hipStreamWaitEvent(s.stream, s.packed[kk], 0));
         if (int st = syldet_run_device(s.bank, d_samples[i], s1 - s0, strides[i], d_outputs ? d_outputs[i] : nullptr, fl, s.stream)) return st;
         if (gather) {
             SYLDET_HIP(hipEventRecord(s.computed[k], s.stream));

@@ -145,11 +145,14 @@ def gather_flags(local_flags, total_channels: int, group=None, packed=None):
 
 
 class PipelinedFlagGather:
-    """gather_flags for a stream of batches on GPUs with equal shards.  The exchange of batch i -- bit-packing on the
-    compute stream (it has to read the flags before the next batch's kernel overwrites them: 10 us), then the one
-    all-gather and the unpacking on a side stream -- runs under the kernels of batch i+1 instead of between them: xGMI is
-    point-to-point, the ring all-gather of 8 ranks is per-link bound, and it is the only thing a rank ever waits for.
-    Buffers alternate between two sets; `result(k)` makes the current stream wait for exchange k."""
+    """gather_flags for a stream of batches on GPUs with equal shards.  The whole exchange of batch i -- bit-packing, the one
+    all-gather, the unpacking -- runs on a side stream under the kernels of batch i+1 instead of between them: xGMI is
+    point-to-point, the ring all-gather of 8 ranks is per-link bound, and it is the only thing a rank ever waits for.  (Round 5:
+    the packing too.  As a kernel of its own between two batches' kernels it cost the compute stream ~19 us a batch against ~3 us
+    between back-to-back kernels.)  The packing READS the batch's flags after the compute stream has moved on, so a kernel that
+    writes the same tensor again must wait for it: call `before_run(flags)` in front of that kernel -- with two flags tensors
+    taken in turn the wait is for the packing of two batches ago, i.e. none.  Buffers alternate between two sets; `result(k)`
+    makes the current stream wait for exchange k."""
 
     def __init__(self, local_rows: int, E: int, total_channels: int, device, group=None):
         import torch
@@ -164,7 +167,16 @@ class PipelinedFlagGather:
         self.out = [torch.empty((total_channels, self.E), dtype=torch.uint8, device=self.device) for _ in range(2)]
         self.side = torch.cuda.Stream(self.device)
         self.done = [None, None]
+        self.packed = [None, None]           # (event, data_ptr of the flags tensor the packing read)
         self.n = 0
+
+    def before_run(self, local_flags) -> None:
+        """In front of the kernel that WRITES `local_flags`: the current stream waits for any packing still reading that tensor."""
+        import torch
+        cur = torch.cuda.current_stream(self.device)
+        for p in self.packed:
+            if p is not None and p[1] == local_flags.data_ptr() and not p[0].query():    # (a wait costs the stream a packet: only if it is needed)
+                cur.wait_event(p[0])
 
     def submit(self, local_flags) -> int:
         """Queue the exchange of this batch's flags (written by work already queued on the current stream)."""
@@ -173,17 +185,18 @@ class PipelinedFlagGather:
         k = self.n & 1
         self.n += 1
         cur = torch.cuda.current_stream(self.device)
-        if self.done[k] is not None:
-            cur.wait_event(self.done[k])                 # set k's previous exchange has been through (two batches ago)
-        pack_flags(local_flags, out=self.bits[k])
-        packed = torch.cuda.Event()
-        packed.record(cur)
+        computed = torch.cuda.Event()
+        computed.record(cur)
         with torch.cuda.stream(self.side):
-            self.side.wait_event(packed)
+            self.side.wait_event(computed)           # (set k's previous exchange is earlier work of this same stream)
+            pack_flags(local_flags, out=self.bits[k])
+            packed = torch.cuda.Event()
+            packed.record(self.side)
             dist.all_gather_into_tensor(self.gbits[k], self.bits[k], group=self.group)
             unpack_flags(self.gbits[k], self.E, out=self.out[k])
             done = torch.cuda.Event()
             done.record(self.side)
+        self.packed[k] = (packed, local_flags.data_ptr())
         self.done[k] = done
         return k
 
