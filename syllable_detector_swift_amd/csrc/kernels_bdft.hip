@@ -53,7 +53,12 @@ using namespace fused_dev;
 
 constexpr int kBlock = kBdftBlock;             // 512 threads = 8 waves, two per SIMD
 constexpr int kWaves = kBlock / 64;
-constexpr int kTile = 128;                     // column rows of a tile: timeRange - 1 carried + 96 new
+constexpr int kTile = 112;                     // rows of the column ring: timeRange - 1 carried + 96 new fit (seven row tiles of 16; not a power of two: wrap())
+#ifndef SYLDET_B_PS
+#define SYLDET_B_PS 48                        // (diagnostic builds try other strides)
+#endif
+constexpr int kPS = SYLDET_B_PS;                       // floats per row of tap products: 12 taps x 4 units (rows 48 floats apart spread four consecutive rows over all banks)
+__device__ __forceinline__ int wrap(int r) { return r >= kTile ? r - kTile : r; }      // (r < 2 kTile)
 constexpr int kSubs = 6;                       // sub-tiles of 16 blocks per tile
 constexpr int kNew = 16 * kSubs;               // new frames (= evaluations) per tile
 
@@ -91,8 +96,10 @@ __device__ __forceinline__ float shl_prev(float v)
 {
     return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x100 + (16 - Q), 0xF, 0xF, true));   // row_shl:16-Q
 }
+// lead + column n - Q of the stream.  One of the two shifted values is zero in every lane, so the order of the additions does not
+// change a bit of the result -- but in this order each shift folds into its addition (v_add_f32_dpp): two instructions, not four
 template <int Q>
-__device__ __forceinline__ float back(float cur, float prev) { return shr_cur<Q>(cur) + shl_prev<Q>(prev); }   // column n - Q of the stream
+__device__ __forceinline__ float back_add(float lead, float cur, float prev) { return (lead + shr_cur<Q>(cur)) + shl_prev<Q>(prev); }
 
 // KS: k-steps of 32 folded positions per block (hop = 64 KS).  RR: blocks per frame (4, 2, 1).  SC: log / dB columns.
 template <int KS, bool SC, int RR>
@@ -103,8 +110,11 @@ bdft_net_kernel(const MlpxDesc d, const BdftDesc bd, const float *__restrict__ s
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int KB = 4, R = RR, HOP = 64 * KS;
     // LDS: first-layer fragments | columns hi | columns lo | per-frame sums, exponents | B fragments (two buffers) | edge bins |
-    // per-wave partial sums | block maxima;  the tap products of a tile sit where the second fragment buffer and the edge bins are
-    const int CS = d.col_stride, PS = d.p_stride;
+    // per-wave partial sums | block maxima | records | the tap products of a tile.  (Round 5: the products have a place of their own --
+    // they used to sit where the second fragment buffer and the edge bins are -- so that a tile's end can run under the next tile's
+    // first iterations; the room came from a ring of 112 column rows instead of 128: 158 of the CU's 160 KB.)
+    const int CS = d.col_stride;
+    constexpr int PS = kPS;
     uint32x4 *afr = reinterpret_cast<uint32x4 *>(smem);
     _Float16 *colh = reinterpret_cast<_Float16 *>(smem + 3 * KB * 2 * 1024);
     _Float16 *coll = colh + kTile * CS;
@@ -114,12 +124,12 @@ bdft_net_kernel(const MlpxDesc d, const BdftDesc bd, const float *__restrict__ s
     constexpr int kFragBytes = 4 * KS * 1024 < 16384 ? 16384 : 4 * KS * 1024;   // s hi, s lo, d hi, d lo: KS fragments each (and room for the products)
     uint32x2 *bfr0 = reinterpret_cast<uint32x2 *>(scr), *bfr1 = reinterpret_cast<uint32x2 *>(scr + kFragBytes);
     floatx4 *edges = reinterpret_cast<floatx4 *>(scr + 2 * kFragBytes);                  // [2 parities][16 frames][32 lane groups] (re0, im0, re3, im3)
-    float *pbuf = reinterpret_cast<float *>(scr + kFragBytes);                           // [tile][PS] over buffer 1 and the edges
     float *ssf8 = reinterpret_cast<float *>(scr + 2 * kFragBytes + 2 * 16 * 32 * 16);   // [tile][8 waves]
     unsigned *bmax = reinterpret_cast<unsigned *>(ssf8 + kTile * kWaves);                 // [4][16] block maxima (bit patterns of |x|), by sub-tile & 3
     // [4][16] what the multiplying waves need of a block and of the frame ending on it, made once by the fold:
     // (x[0] 2^e, 2^(-e-13): the block's first sample in the fragments' units and the way back; the frame's column scale up, down)
     floatx4 *recs = reinterpret_cast<floatx4 *>(bmax + 64);
+    float *pbuf = reinterpret_cast<float *>(recs + 64);                                  // [ring rows][PS]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -142,6 +152,7 @@ bdft_net_kernel(const MlpxDesc d, const BdftDesc bd, const float *__restrict__ s
     }
     if (tid < kTile) { ssf[tid] = 0.0f; fsc[tid] = 0.0f; }
     for (int i = tid; i < kTile * kWaves; i += kBlock) ssf8[i] = 0.0f;
+    for (int i = tid; i < kTile * kPS; i += kBlock) pbuf[i] = 0.0f;                         // (the first tile's carried rows: no frames, no products)
     if (tid < 64) bmax[tid] = 0u;
     const float b0[4] = {d.bias0[0], d.bias0[1], d.bias0[2], d.bias0[3]}, w1[4] = {d.w1[0], d.w1[1], d.w1[2], d.w1[3]};
     const double thr = d.thresholds[0];
@@ -252,7 +263,8 @@ bdft_net_kernel(const MlpxDesc d, const BdftDesc bd, const float *__restrict__ s
     floatx4 vre_prev = yre, vim_prev = yre;                          // ... and the first level of the sliding sum
     float upc = 0.0f, dnc = 0.0f;                                    // ... and the frames' column scales
     int64_t u = 0;                                                   // sub-tile counter of the run
-    int rbase = 0;                                                   // the tile's first (carried) row in the ring of 128 column rows: no copying between tiles
+    int rbase = 0;                                                   // the tile's first (carried) row in the ring of column rows: no copying between tiles
+    int wrow = T - 1;                                                // the ring row of the next sub-tile to finish columns of (sub-tile q: 16 q + T - 1, wrapped)
     auto blk_of = [&](int64_t uu) { return fbase + 16 * uu + (R - 1); };   // first block of sub-tile uu (frames end on their last block)
 
     // prologue: sub-tiles 0, 1 and 2 loaded, the maxima of the first two taken, sub-tile 0 folded.  In the loop a sub-tile's
@@ -317,26 +329,31 @@ bdft_net_kernel(const MlpxDesc d, const BdftDesc bd, const float *__restrict__ s
         for (int i = 0; i < 4; i++) {
             bre[i] = fmaf(cre[i], x0s, are[i]) * un;
             bim[i] = aim[i] * un;
+#ifndef SYLDET_B_CONTRACT
+            // (kept out of the compiler's sight as products: contracted into the sliding sum's additions they would take the
+            // shifts' place in them -- a move and a multiply-add where one shifted addition does)
+            asm volatile("" : "+v"(bre[i]), "+v"(bim[i]));
+#endif
         }
         // ---- frames end on their last block.  Four blocks a frame: Y'_n = sum_{q' < 4} rho^(3 - q') B'_{n - q'} with rho = (-i)^k, k = i (mod 4):
         // 1, -i, -1, i for i = 0 .. 3.  In two levels: V_n = rho B'_n + B'_{n-1}, Y'_n = rho^2 V_n + V_{n-2} -- two shifts a value
         // instead of three (the previous sub-tile's last columns carry: B' for the first level, V for the second).
         floatx4 vre = bre, vim = bim;
         if (R == 4) {
-            vre[0] = bre[0] + back<1>(bre[0], bre_prev[0]);   vim[0] = bim[0] + back<1>(bim[0], bim_prev[0]);      // rho = 1
-            vre[1] = bim[1] + back<1>(bre[1], bre_prev[1]);   vim[1] = -bre[1] + back<1>(bim[1], bim_prev[1]);     // -i z = (b, -a)
-            vre[2] = -bre[2] + back<1>(bre[2], bre_prev[2]);  vim[2] = -bim[2] + back<1>(bim[2], bim_prev[2]);     // -z
-            vre[3] = -bim[3] + back<1>(bre[3], bre_prev[3]);  vim[3] = bre[3] + back<1>(bim[3], bim_prev[3]);      // i z = (-b, a)
-            yre[0] = vre[0] + back<2>(vre[0], vre_prev[0]);   yim[0] = vim[0] + back<2>(vim[0], vim_prev[0]);      // rho^2 = 1
-            yre[1] = -vre[1] + back<2>(vre[1], vre_prev[1]);  yim[1] = -vim[1] + back<2>(vim[1], vim_prev[1]);     // -1
-            yre[2] = vre[2] + back<2>(vre[2], vre_prev[2]);   yim[2] = vim[2] + back<2>(vim[2], vim_prev[2]);      // 1
-            yre[3] = -vre[3] + back<2>(vre[3], vre_prev[3]);  yim[3] = -vim[3] + back<2>(vim[3], vim_prev[3]);     // -1
+            vre[0] = back_add<1>(bre[0], bre[0], bre_prev[0]);    vim[0] = back_add<1>(bim[0], bim[0], bim_prev[0]);     // rho = 1
+            vre[1] = back_add<1>(bim[1], bre[1], bre_prev[1]);    vim[1] = back_add<1>(-bre[1], bim[1], bim_prev[1]);    // -i z = (b, -a)
+            vre[2] = back_add<1>(-bre[2], bre[2], bre_prev[2]);   vim[2] = back_add<1>(-bim[2], bim[2], bim_prev[2]);    // -z
+            vre[3] = back_add<1>(-bim[3], bre[3], bre_prev[3]);   vim[3] = back_add<1>(bre[3], bim[3], bim_prev[3]);     // i z = (-b, a)
+            yre[0] = back_add<2>(vre[0], vre[0], vre_prev[0]);    yim[0] = back_add<2>(vim[0], vim[0], vim_prev[0]);     // rho^2 = 1
+            yre[1] = back_add<2>(-vre[1], vre[1], vre_prev[1]);   yim[1] = back_add<2>(-vim[1], vim[1], vim_prev[1]);    // -1
+            yre[2] = back_add<2>(vre[2], vre[2], vre_prev[2]);    yim[2] = back_add<2>(vim[2], vim[2], vim_prev[2]);     // 1
+            yre[3] = back_add<2>(-vre[3], vre[3], vre_prev[3]);   yim[3] = back_add<2>(-vim[3], vim[3], vim_prev[3]);    // -1
         } else if (R == 2) {
             // two blocks a frame: Y'_n = rho B'_n + B'_{n-1} with rho = (-1)^k
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                yre[i] = ((i & 1) ? -bre[i] : bre[i]) + back<1>(bre[i], bre_prev[i]);
-                yim[i] = ((i & 1) ? -bim[i] : bim[i]) + back<1>(bim[i], bim_prev[i]);
+                yre[i] = back_add<1>((i & 1) ? -bre[i] : bre[i], bre[i], bre_prev[i]);
+                yim[i] = back_add<1>((i & 1) ? -bim[i] : bim[i], bim[i], bim_prev[i]);
             }
         } else {
             yre = bre; yim = bim;                                    // (a frame is its block: not instantiated -- the FFT kernels are faster there)
@@ -347,7 +364,7 @@ bdft_net_kernel(const MlpxDesc d, const BdftDesc bd, const float *__restrict__ s
         edges[(par * 32 + 4 * wave + g) * 16 + n] = floatx4{yre[0], yim[0], yre[3], yim[3]};
         bre_prev = bre; bim_prev = bim; vre_prev = vre; vim_prev = vim;
     };
-    auto stage_window = [&](int sp, bool fh) {                                // sub-tile u - 1 (row block sp of the tile): window taps, |X|, columns
+    auto stage_window = [&](bool fh) {                                       // sub-tile u - 1 (ring rows wrow ..): window taps, |X|, columns
         const int pe = (int)((u - 1) & 1);                           // (u: this iteration's sub-tile, or one past the tile's last in the drain iteration)
         const int G = 4 * wave + g;
         const floatx4 eL = G > 0 ? edges[(pe * 32 + G - 1) * 16 + n] : floatx4{0.f, 0.f, 0.f, 0.f};
@@ -372,7 +389,7 @@ bdft_net_kernel(const MlpxDesc d, const BdftDesc bd, const float *__restrict__ s
             ssq = inb ? fmaf(cv[i], cv[i], ssq) : ssq;
         }
         ssq = xor32_sum(xor16_sum(ssq));
-        const int rw = (rbase + (T - 1) + 16 * sp + n) & (kTile - 1);
+        const int rw = wrap(wrow + n);
         unsigned h0, l0, h1, l1;
         const float upw = scaling != 0 ? 16.0f : upc;               // (logarithms are within +-800: a fixed scale keeps them under f16's 65504)
         split2(cv[0] * upw, cv[1] * upw, h0, l0);
@@ -403,60 +420,28 @@ bdft_net_kernel(const MlpxDesc d, const BdftDesc bd, const float *__restrict__ s
 #else
     constexpr bool kDoW = true;
 #endif
-    // One iteration: a barrier, then this wave's stages.  MM: there is a sub-tile to multiply (and to load and fold for);
-    // WW: there is one to finish columns of -- the tile's first iteration has none (the last tile's drain took it), its
-    // drain iteration nothing else.  Three straight-line bodies, no per-stage conditions in the loop.
-    // bfr[u & 1] holds sub-tile u's fragments, bmax[(u + 1) & 3] sub-tile u + 1's maxima, edges[(u - 1) & 1] sub-tile u - 1's edge bins
-    auto iteration = [&](auto mm_, auto ww_, int sp) {
-        constexpr bool MM = decltype(mm_)::value, WW = decltype(ww_)::value;
-        SD_BT(0)
-        __syncthreads();
-        SD_BT(1)
-        if (first_half) {
-            if (WW && kDoW) stage_window(sp, true);
-            SD_BT(4)
-            if (MM && kDoM) stage_mfma();
-            SD_BT(2)
-            if (MM) stage_load_fold(true);
-            SD_BT(3)
-        } else {
-            if (MM) stage_load_fold(false);
-            SD_BT(3)
-            if (WW && kDoW) stage_window(sp, false);
-            SD_BT(4)
-            if (MM && kDoM) stage_mfma();
-            SD_BT(2)
-        }
-        if (MM) {
-            // ---- sub-tile u + 2's block maxima (its samples were loaded an iteration ago); the stream moves on
-            raw_max(r2, bmax + ((u + 2) & 3) * 16);
-            r1 = r2;
-            r2 = r3;
-            u++;
-        }
-    };
-    using yes = std::integral_constant<bool, true>;
-    using no = std::integral_constant<bool, false>;
-#ifndef SYLDET_B_NO_PREWAIT
-    __builtin_amdgcn_s_waitcnt(0x0F70);              // (the compiler is told that the prologue's loads are complete: kernels_fused_s.hip has the story)
-#endif
-    for (int tr = 0; tr < tiles; tr++) {
-        iteration(yes{}, no{}, 0);
-        for (int s = 1; s < kSubs; s++) iteration(yes{}, yes{}, s - 1);
-        iteration(no{}, yes{}, kSubs - 1);
-        SD_BT(0)
-        __syncthreads();
-        SD_BT(1)
-        // ---- the frames' sums of squares from the waves' partial sums, in a fixed order
-        if (tid < kTile) {
+    // ---- a tile's end, in two stages that run inside the NEXT tile's second and third iterations (round 5; the last tile's after the
+    // loop), so that the stream of sub-tiles never stops: every iteration multiplies one sub-tile and finishes the columns of the one
+    // before, across tile boundaries, and a tile costs six barriers instead of nine.
+    // (1) the frames' sums of squares from the waves' partial sums, in a fixed order, and the tap products of the tile's NEW rows,
+    // P[(t, h), j] for all taps at once (three row tiles), back to true units; the carried rows' sums and products are the tile
+    // before's, still in place (zeros in front of the first tile) -- and must be: the iteration that runs this stage is already
+    // writing the next tile's first columns over the carried rows (the ring has 112 rows, a tile uses 107).
+    // (2) the evaluations, an iteration later: they read sums and products only.
+    int rbase_end = 0, tr_end = -1;                                  // the ending tile's first ring row and index (none yet)
+    auto stage_taps = [&]() {
+        auto is_new = [&](int row) {                                 // a ring row the ending tile has made itself
+            const int rel = row - rbase_end + (row < rbase_end ? kTile : 0);
+            return (unsigned)(rel - (T - 1)) < (unsigned)kNew;
+        };
+        if (tid < kTile && is_new(tid)) {
             float a = 0.0f;
 #pragma unroll
             for (int w = 0; w < kWaves; w++) a += ssf8[tid * kWaves + w];
-            ssf[tid] = a;                                            // (a carried row's partial sums are still in place: the same sum again)
+            ssf[tid] = a;
         }
-        // ---- tap products of this wave's 16 rows, P[(t, h), j] for all taps at once (three row tiles), back to true units
 #ifndef SYLDET_B_NOTAPS
-        {
+        if (wave < kTile / 16) {
             const int fr = 16 * wave + n;
             const _Float16 *bph = colh + fr * CS + 8 * g, *bpl = coll + fr * CS + 8 * g;
             floatx4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -473,14 +458,17 @@ bdft_net_kernel(const MlpxDesc d, const BdftDesc bd, const float *__restrict__ s
                 }
             }
             const float dn = fsc[fr];
+            if (is_new(fr)) {                                        // (the other rows of the tile: half-written columns, nobody's products)
 #pragma unroll
-            for (int m = 0; m < 3; m++) *reinterpret_cast<floatx4 *>(pbuf + fr * PS + 4 * (4 * m + g)) = acc[m] * dn;
+                for (int m = 0; m < 3; m++) *reinterpret_cast<floatx4 *>(pbuf + fr * PS + 4 * (4 * m + g)) = acc[m] * dn;
+            }
         }
 #endif
-        __syncthreads();
+    };
+    auto stage_evaluate = [&]() {
 #ifndef SYLDET_B_NOEVAL
-        // ---- evaluations, four threads each: row r starts the window of evaluation fbase + kNew tr + r - (T - 1); thread j of the
-        // four takes taps j, j + 4, j + 8 and then hidden unit j (quad permutes carry the sums)
+        // four threads an evaluation: row r starts the window of evaluation fbase + kNew tr + r - (T - 1); thread j of the four
+        // takes taps j, j + 4, j + 8 and then hidden unit j (quad permutes carry the sums)
         if (tid < 4 * kNew) {
             const int r = tid >> 2, j = tid & 3;
             floatx4 z = {0.f, 0.f, 0.f, 0.f};
@@ -489,7 +477,7 @@ bdft_net_kernel(const MlpxDesc d, const BdftDesc bd, const float *__restrict__ s
             for (int tt = 0; tt < 3; tt++) {
                 const int t = j + 4 * tt;
                 if (t < T) {
-                    const int rr = (rbase + r + t) & (kTile - 1);
+                    const int rr = wrap(rbase_end + r + t);
                     z += *reinterpret_cast<const floatx4 *>(pbuf + rr * PS + 4 * t);
                     ssw += ssf[rr];
                 }
@@ -516,16 +504,94 @@ bdft_net_kernel(const MlpxDesc d, const BdftDesc bd, const float *__restrict__ s
 #pragma unroll
             for (int h = 0; h < 4; h++) y = fmaf(w1[h], thq[h], y);
             y = (y - d.oa) / d.og + d.ob;
-            const int64_t ev = fbase + (int64_t)kNew * tr + r - (T - 1);
+            const int64_t ev = fbase + (int64_t)kNew * tr_end + r - (T - 1);
             const bool st = j == 0 && ev >= E0 && ev < E1;
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y), out_rs, st ? (unsigned)ev * 4u : 0xFFFFFFFFu, 0, 0);
             __builtin_amdgcn_raw_buffer_store_b8((unsigned char)((double)y >= thr ? 1 : 0), flg_rs, st ? (unsigned)ev : 0xFFFFFFFFu, 0, 0);
         }
 #endif
-        rbase = (rbase + kNew) & (kTile - 1);          // the last T - 1 rows are the next tile's first: the ring moves on, nothing is copied
-        // (the next iteration's barrier also says that the products are read: the second fragment buffer and the edges are free again)
+    };
+
+    // One iteration: a barrier, then this wave's stages.  MM: there is a sub-tile to multiply (and to load and fold for);
+    // WW: there is one to finish columns of -- all but the run's first iteration; the run's last has nothing else.  END: which stage
+    // of the tile before's end this iteration carries (1: sums and tap products; 2: evaluations).  Straight-line bodies, no
+    // per-stage conditions in the loop.
+    // bfr[u & 1] holds sub-tile u's fragments, bmax[(u + 1) & 3] sub-tile u + 1's maxima, edges[(u - 1) & 1] sub-tile u - 1's edge bins
+    auto iteration = [&](auto mm_, auto ww_, auto end_) {
+        constexpr bool MM = decltype(mm_)::value, WW = decltype(ww_)::value;
+        constexpr int END = decltype(end_)::value;
+        SD_BT(0)
+        __syncthreads();
+        SD_BT(1)
+        if (END == 2 && tr_end >= 0) stage_evaluate();
+        SD_BT(5)
+        if (first_half) {
+            if (WW && kDoW) stage_window(true);
+            if (END == 1 && tr_end >= 0) stage_taps();
+            SD_BT(4)
+            if (MM && kDoM) stage_mfma();
+            SD_BT(2)
+            if (MM) stage_load_fold(true);
+            SD_BT(3)
+        } else {
+            if (MM) stage_load_fold(false);
+            SD_BT(3)
+            if (WW && kDoW) stage_window(false);
+            if (END == 1 && tr_end >= 0) stage_taps();
+            SD_BT(4)
+            if (MM && kDoM) stage_mfma();
+            SD_BT(2)
+        }
+        if (WW) wrow = wrap(wrow + 16);
+        if (MM) {
+            // ---- sub-tile u + 2's block maxima (its samples were loaded an iteration ago); the stream moves on
+            raw_max(r2, bmax + ((u + 2) & 3) * 16);
+            r1 = r2;
+            r2 = r3;
+            u++;
+        }
+    };
+    using yes = std::integral_constant<bool, true>;
+    using no = std::integral_constant<bool, false>;
+    using end0 = std::integral_constant<int, 0>;
+    using end1 = std::integral_constant<int, 1>;
+    using end2 = std::integral_constant<int, 2>;
+#ifndef SYLDET_B_NO_PREWAIT
+    __builtin_amdgcn_s_waitcnt(0x0F70);              // (the compiler is told that the prologue's loads are complete: kernels_fused_s.hip has the story)
+#endif
+#ifdef SYLDET_B_END_INLINE                           // (diagnostic: the tile's end between the tiles, as through round 4)
+    for (int tr = 0; tr < tiles; tr++) {
+        iteration(yes{}, no{}, end0{});
+        for (int s = 1; s < kSubs; s++) iteration(yes{}, yes{}, end0{});
+        iteration(no{}, yes{}, end0{});
+        rbase_end = rbase; tr_end = tr;
+        __syncthreads();
+        stage_taps();
+        __syncthreads();
+        stage_evaluate();
+        rbase = wrap(rbase + kNew);
+    }
+#else
+    if (tiles > 0) iteration(yes{}, no{}, end0{});   // the run's first sub-tile: nothing to finish columns of yet
+    for (int tr = 0; tr < tiles; tr++) {
+        if (tr > 0) iteration(yes{}, yes{}, end0{});
+        iteration(yes{}, yes{}, end1{});
+        iteration(yes{}, yes{}, end2{});
+        for (int s = 3; s < kSubs; s++) iteration(yes{}, yes{}, end0{});
+        rbase_end = rbase; tr_end = tr;
+        rbase = wrap(rbase + kNew);                    // the last T - 1 rows are the next tile's first: the ring moves on, nothing is copied
+    }
+    if (tr_end >= 0) {                               // the last sub-tile's columns, the last tile's end
+        iteration(no{}, yes{}, end0{});
+        SD_BT(0)
+        __syncthreads();
+        SD_BT(1)
+        stage_taps();
+        __syncthreads();
+        stage_evaluate();
         SD_BT(5)
     }
+#endif
 #ifdef SYLDET_B_STAMPS
     if (lane == 0 && (wave == 0 || wave == 4))
         for (int i = 0; i < 8; i++) atomicAdd(&g_bdft_stamps[(wave ? 8 : 0) + i], tsum[i]);
@@ -549,8 +615,9 @@ hipError_t launch_bdft_net(const MlpxDesc &d, const BdftDesc &bd, const float *s
     dim3 grid((unsigned)runs, (unsigned)C);
     const int KS = bd.hop / 64;
     const int frag = 4 * KS * 1024 < 16384 ? 16384 : 4 * KS * 1024;
-    const int lds = 3 * 4 * 2 * 1024 + 2 * kTile * d.col_stride * 2 + 2 * kTile * 4 + 2 * frag + 2 * 16 * 32 * 16 + kTile * kWaves * 4 + 4 * 16 * 4 + 4 * 16 * 16;
-    if (lds > 160 * 1024 || kTile * d.p_stride * 4 > frag + 2 * 16 * 32 * 16) return hipErrorInvalidValue;
+    const int lds = 3 * 4 * 2 * 1024 + 2 * kTile * d.col_stride * 2 + 2 * kTile * 4 + 2 * frag + 2 * 16 * 32 * 16 + kTile * kWaves * 4 + 4 * 16 * 4 + 4 * 16 * 16 +
+                    kTile * kPS * 4;
+    if (lds > 160 * 1024 || d.T > 12 || d.T - 1 + kNew > kTile) return hipErrorInvalidValue;
 #ifdef SYLDET_B_STAMPS
 #define SD_BDFT_STAMP_REPORT                                                                                                   \
     {                                                                                                                          \
