@@ -112,8 +112,9 @@ BINDING = {
                        "(tools/power_probe.py; round 4's 1175 W was two samples of a 0.2 s run: the package figure lags); in a run as short "
                        "as the timed region the clock is still high and what is left is two waves a SIMD both waiting inside one tile's "
                        "dependent chain, ~68 % of the vector issue slots in use; HBM traffic 1.01x algorithmic (MEASUREMENTS R4.1, R5.3)"),
-    "bdft_net_kernel": ("valu_issue+power", "~250 vector and 24 matrix instructions a wave and 16-frame iteration: two waves a SIMD fill most "
-                        "vector issue slots, at the part's power limit; HBM traffic 1.00x algorithmic (MEASUREMENTS R3.5, R4.5, R5.4)"),
+    "bdft_net_kernel": ("valu_issue+power", "~240 vector and 24 matrix instructions a wave and 16-frame iteration (a tile's end runs inside the next tile since "
+                        "round 5): two waves a SIMD fill most vector issue slots, near the part's power limit; HBM traffic 1.00x "
+                        "algorithmic (MEASUREMENTS R3.5, R4.5, R5.4)"),
     "fft1k_net_kernel": ("valu_issue+lds", "radix-8 register FFT with two LDS transposes a frame (MEASUREMENTS, old 4.2c)"),
     "wide_gemm16_kernel": ("mfma+valu_issue", "matrix pipe busy ~60 % of the launch's clocks: the epilogue's two transcendentals a hidden value "
                            "share the issue port with the matrix instructions' issue, at 1290-1350 W with the clock below 2.4 GHz; "
