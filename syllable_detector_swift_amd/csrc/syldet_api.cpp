@@ -194,6 +194,8 @@ struct syldet {
     // a ring of the last prof_depth batch calls: kMaxTimed kernel slots each, two events a slot
     static constexpr int kMaxTimed = 8;
     struct ProfCall { int count = 0; const char *names[kMaxTimed] = {}; };
+    unsigned *prof_items = nullptr;          // [prof_items_n] page-locked: the exact path's work items of each profiled call (timed_fixup)
+    int prof_items_n = 0;
     std::vector<hipEvent_t> events;          // [prof_depth][kMaxTimed][2], created on first use
     std::vector<ProfCall> prof_calls;        // [prof_depth]
     int prof_depth = 1;
@@ -205,6 +207,7 @@ struct syldet {
         if ((int)prof_calls.size() != prof_depth) prof_calls.assign((size_t)prof_depth, ProfCall());
         prof_seq++;
         prof_calls[(size_t)prof_cur()].count = 0;
+        if (prof_items && prof_cur() < prof_items_n) prof_items[prof_cur()] = 0u;
     }
 };
 
@@ -622,6 +625,30 @@ struct KernelTimer {
     size_t base = 0;
 };
 
+// The exact recomputation behind a fused kernel is timed like every other launch; syldet_timings lists it for the calls whose work
+// list was not empty (an empty list is a launch of a few microseconds -- not what a profile is read for; a loud recording through a
+// network without a normaliser can spend fifty times the fused kernel's time here: MEASUREMENTS R5.7).  The list's length follows
+// the launch to a page-locked word of the call's slot.
+const char kFixupName[] = "fixup_kernel";
+template <class F>
+int timed_fixup(syldet *h, hipStream_t stream, F launch)
+{
+    KernelTimer t(h, stream, kFixupName);
+    SYLDET_HIP(launch());
+    if (t.slot < 0 || !h->d_fix.ptr) return SYLDET_OK;
+    if (h->prof_items_n < h->prof_depth) {
+        // (the first profiled call since the history's depth grew: once, and nothing may still be writing the old array)
+        SYLDET_HIP(hipDeviceSynchronize());
+        if (h->prof_items) (void)hipHostFree(h->prof_items);
+        h->prof_items = nullptr; h->prof_items_n = 0;
+        SYLDET_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->prof_items), sizeof(unsigned) * (size_t)h->prof_depth, hipHostMallocDefault));
+        h->prof_items_n = h->prof_depth;
+        for (int i = 0; i < h->prof_items_n; i++) h->prof_items[i] = 0u;
+    }
+    SYLDET_HIP(hipMemcpyAsync(&h->prof_items[h->prof_cur()], static_cast<const unsigned *>(h->d_fix.ptr) + 2, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+    return SYLDET_OK;
+}
+
 // samples -> [C][J][F] columns: the fused engine's DFT half where its shape allows (and the handle was not created
 // for the generic engine outright), the generic FFT otherwise
 int stft_on_stream(syldet *h, const float *d_samples, int64_t stride, int C, int64_t J, float *d_columns, hipStream_t stream,
@@ -653,8 +680,7 @@ int stft_on_stream(syldet *h, const float *d_samples, int64_t stride, int C, int
             KernelTimer t(h, stream, "fused_kernel (spectrogram)");
             SYLDET_HIP(launch_fused_spectrogram(d, d_samples, stride, C, J, stream));
         }
-        SYLDET_HIP(launch_fixup(h->fixd, h->net, d_samples, stride, J, 0, nullptr, nullptr, d_columns, d.fix, stream));
-        return SYLDET_OK;
+        return timed_fixup(h, stream, [&] { return launch_fixup(h->fixd, h->net, d_samples, stride, J, 0, nullptr, nullptr, d_columns, d.fix, stream); });
     }
 generic_transform:
     if (!h->sw.no_stft_lanes && stft_lanes_applicable(h->stft, d_samples, stride)) {
@@ -764,8 +790,7 @@ int run_on_stream(syldet *h, const float *d_samples, int64_t S, int64_t stride, 
             KernelTimer t(h, stream, names[fused_choice(d, J)]);
             SYLDET_HIP(launch_fused(d, d_samples, stride, C, S, J, E, d_outputs, d_flags, stream));
         }
-        SYLDET_HIP(launch_fixup(h->fixd, h->net, d_samples, stride, J, E, d_outputs, d_flags, nullptr, d.fix, stream));
-        return SYLDET_OK;
+        return timed_fixup(h, stream, [&] { return launch_fixup(h->fixd, h->net, d_samples, stride, J, E, d_outputs, d_flags, nullptr, d.fix, stream); });
     }
     // (+ 16 bytes: the matrix-core network stage reads a frame's last bins as a whole quad)
     if (int st = h->d_columns.reserve((size_t)C * (size_t)J * (size_t)h->geom.bins * sizeof(float) + 16)) return st;
@@ -955,6 +980,7 @@ int syldet_destroy(syldet_t *h)
     }
     for (hipEvent_t e : h->events)
         if (e) (void)hipEventDestroy(e);
+    if (h->prof_items) (void)hipHostFree(h->prof_items);
     for (DeviceBuffer *b : {&h->d_window, &h->d_tw, &h->d_sw, &h->d_params, &h->d_thr, &h->d_columns, &h->d_fused, &h->d_mlpx, &h->d_stamps, &h->d_fix, &h->d_ctab, &h->d_planar, &h->d_wide, &h->d_xn, &h->d_dft, &h->d_stage_in,
                             &h->d_stage_out, &h->d_stage_flags, &h->d_stage_idx, &h->d_stage_cnt})
         b->release();
@@ -1011,15 +1037,21 @@ int syldet_timings(syldet_t *h, int32_t calls_back, double *milliseconds, const 
     if (h->prof_calls.empty() || calls_back >= h->prof_depth || (int64_t)calls_back >= h->prof_seq) return SYLDET_OK;
     const int idx = (int)((h->prof_seq - 1 - calls_back) % h->prof_depth);
     const syldet::ProfCall &pc = h->prof_calls[(size_t)idx];
-    *count = pc.count;
-    for (int i = 0; i < pc.count && i < capacity; i++) {
+    int n = 0;
+    for (int i = 0; i < pc.count; i++) {
         const size_t base = (size_t)(idx * syldet::kMaxTimed + i) * 2;
         SYLDET_HIP(hipEventSynchronize(h->events[base + 1]));
-        float ms = 0.0f;
-        SYLDET_HIP(hipEventElapsedTime(&ms, h->events[base], h->events[base + 1]));
-        milliseconds[i] = (double)ms;
-        if (names) names[i] = pc.names[i];
+        // the exact path is listed for calls that gave it work (timed_fixup; its count has arrived with the event)
+        if (pc.names[i] == kFixupName && !(h->prof_items && idx < h->prof_items_n && h->prof_items[idx] != 0u)) continue;
+        if (n < capacity) {
+            float ms = 0.0f;
+            SYLDET_HIP(hipEventElapsedTime(&ms, h->events[base], h->events[base + 1]));
+            milliseconds[n] = (double)ms;
+            if (names) names[n] = pc.names[i];
+        }
+        n++;
     }
+    *count = n;
     return SYLDET_OK;
 }
 

@@ -81,7 +81,7 @@ def test_extreme_inputs_spectrogram(oracle_lib, name, spectrum):
         det.profile(True)
         cols = det.spectrogram(torch.from_numpy(x[None]).cuda())
         torch.cuda.synchronize()
-        names = [nm for nm, _ in det.lastTimings()]
+        names = util.launched(det)
         cols = cols.cpu().numpy()[0]
         items, over = det.fixupStats()
     o = util.oracle_for(cfg)
@@ -129,3 +129,23 @@ def test_guard_stays_quiet_on_ordinary_audio(oracle_lib, chain, level):
             own = float(np.abs(w32 - w64).max())
             # (one bar for every chain: 1e-5, or 4x the fp32 port's own distance -- no allowance for the recording's level)
             util.assert_outputs_close(out[c], w64, max(util.TOL, 4 * own))
+
+
+def test_profile_lists_the_exact_path_only_for_calls_that_gave_it_work():
+    """syldet_timings (Time.swift:36-100's place): the fix-up launch behind a fused kernel is timed like every other kernel and listed
+    for the calls whose work list was not empty -- a recording ten times full scale through a network without a normaliser spends most
+    of its time there (MEASUREMENTS R5.7), ordinary audio none."""
+    import torch
+    from syllable_detector_swift_amd import nets
+    base = util.sample_net()
+    cfg = nets.variant(base, net=nets.random_net(np.random.default_rng(3), 290, (4,), 1, in_fns=()))
+    x = torch.from_numpy(synth.channels(4, 132 * 2000 + 256, first=1).astype(np.float32)).cuda()
+    with sd.SyllableDetector(cfg, channels=4) as det:
+        det.profile(True, history=3)
+        for level in (0.01, 10.0, 0.01):
+            det.run(x * level)
+        torch.cuda.synchronize()
+        quiet2, loud, quiet1 = (det.timingsOf(k) for k in range(3))
+        items, over = det.fixupStats()
+    assert [n for n, _ in quiet1] == ["fused_s_kernel"] and [n for n, _ in quiet2] == ["fused_s_kernel"] and (items, over) == (0, 0)
+    assert [n for n, _ in loud] == ["fused_s_kernel", "fixup_kernel"] and loud[1][1] > loud[0][1]

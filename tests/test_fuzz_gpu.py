@@ -283,7 +283,7 @@ def test_random_example_class_detector_on_the_register_resident_kernel(oracle_li
         det.profile(True)
         out, fl = det.run(torch.from_numpy(x).cuda())
         torch.cuda.synchronize()
-        assert [nm for nm, _ in det.lastTimings()] == [kernel]
+        assert util.launched(det) == [kernel]
         out, fl = out.cpu().numpy(), fl.cpu().numpy()
     for c in range(C):
         _, _, w64 = o.run(x[c], po.F64, cfg.rule)
@@ -346,7 +346,7 @@ def test_random_frames_of_four_hops(oracle_lib, seed):
         det.profile(True)
         out, fl = det.run(torch.from_numpy(x).cuda())
         torch.cuda.synchronize()
-        assert [nm for nm, _ in det.lastTimings()] == ["bdft_net_kernel"]
+        assert util.launched(det) == ["bdft_net_kernel"]
         out, fl = out.cpu().numpy(), fl.cpu().numpy()
     for c in range(C):
         _, _, w64 = o.run(x[c], po.F64, cfg.rule)
@@ -410,7 +410,7 @@ def test_random_wide_band_detector(oracle_lib, seed):
         det.profile(True)
         out, fl = det.run(torch.from_numpy(x).cuda())
         torch.cuda.synchronize()
-        names = [nm for nm, _ in det.lastTimings()]
+        names = util.launched(det)
         # (hops that are multiples of 64 have no padded form with two row tiles: the generic engine keeps them)
         assert names == ["fused_s_kernel"] or hop % 64 == 0, names
         out, fl = out.cpu().numpy(), fl.cpu().numpy()

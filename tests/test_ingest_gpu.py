@@ -174,7 +174,7 @@ def test_wide_network_bf16_mfma_engine(oracle_lib, shape, monkeypatch):
         out, fl = det.run(torch.from_numpy(x).cuda())
         torch.cuda.synchronize()
         out, fl = out.cpu().numpy(), fl.cpu().numpy()
-        names = [k for k, _ in det.lastTimings()]
+        names = util.launched(det)
         gemm = [k for k in names if k.startswith("wide_gemm")]
         assert gemm == (["wide_gemm_kernel"] if "SYLDET_WIDE_SHAPE32" in os.environ else ["wide_gemm16_kernel"])
         # [l2normalize,] affine maps on linear columns: the GEMM reads the columns itself; other chains (and the old shape,

@@ -221,7 +221,7 @@ def test_several_outputs_on_the_register_resident_kernel(oracle_lib, monkeypatch
         torch.cuda.synchronize()
         # (hops that are multiples of 64: the fold kernel's padded ring is instantiated for up to four hidden units; wider
         # layers stay on the register-resident-basis kernel and its padded staging)
-        assert [nm for nm, _ in det.lastTimings()] == ["fused_r_kernel" if (hop % 64 == 0 and H > 4) else kernel]
+        assert util.launched(det) == ["fused_r_kernel" if (hop % 64 == 0 and H > 4) else kernel]
         out, fl = out.cpu().numpy(), fl.cpu().numpy()
     fired = 0
     for c in range(2):
@@ -283,7 +283,7 @@ def test_streaming_api_equals_batch(oracle_lib, name):
         util.assert_outputs_close(got, w64)
         det.profile(True)
         batch, _ = det.runHost(np.stack([x, x]))
-        kernels = [nm for nm, _ in det.lastTimings()]
+        kernels = util.launched(det)
         # Streaming results are the batch engine's.  Identical bits on the generic engine and on the symmetric-fold kernel,
         # which scales every FRAME by itself: a result depends on the samples under its window, not on how the audio is cut
         # into calls, tiles or segments (the reference is chunking-invariant too: SyllableDetector.swift:153-217).  The two
@@ -418,7 +418,7 @@ def test_benchmark_size_against_the_oracle(oracle_lib, monkeypatch, C, log2S, ke
         det.profile(True)
         out, fl = det.run(x)
         torch.cuda.synchronize()
-        assert [nm for nm, _ in det.lastTimings()] == [kernel]
+        assert util.launched(det) == [kernel]
         assert det.fixupStats() == (0, 0)                       # ordinary audio never reaches the slow path
         res = spotcheck.check(det, cfg, x, out, fl, chans)
         assert res["evaluations_checked"] >= 3 * 3 * 150 and res["segment_evaluations"] == seg
@@ -447,7 +447,7 @@ def test_other_baseline_workloads_at_full_size(oracle_lib, workload):
         det.profile(True)
         out, fl = det.run(x)
         torch.cuda.synchronize()
-        assert [nm for nm, _ in det.lastTimings()] == kernels
+        assert util.launched(det) == kernels
         assert torch.isfinite(out).all()
         res = spotcheck.check(det, cfg, x, out, fl, chans, width=96 if workload == "config3" else 160, tol=tol)
         # + the middle of each checked channel: seams of the kernels' own tiles (128 frames; 512 evaluations)
@@ -527,7 +527,7 @@ def test_spectrogram_on_the_fold_kernel_and_on_the_older_one(oracle_lib, hop, ba
             det.profile(True)
             cols = det.spectrogram(torch.from_numpy(x).cuda())
             torch.cuda.synchronize()
-            names = [nm for nm, _ in det.lastTimings()]
+            names = util.launched(det)
             if form == "fold":
                 assert names == ["fused_s_kernel (spectrogram)"], names
                 assert det.fixupStats() == (0, 0)
@@ -581,7 +581,7 @@ def test_log_and_db_columns_on_the_fold_kernel(oracle_lib, scaling, chain):
         det.profile(True)
         out, fl = det.run(torch.from_numpy(x).cuda())
         torch.cuda.synchronize()
-        assert [nm for nm, _ in det.lastTimings()] == ["fused_s_kernel"]
+        assert util.launched(det) == ["fused_s_kernel"]
         assert det.fixupStats() == (0, 0)
         out, fl = out.cpu().numpy(), fl.cpu().numpy()
     o = util.oracle_for(cfg)
@@ -687,7 +687,7 @@ def test_both_fused_kernels_against_the_oracle_and_each_other(oracle_lib, monkey
             det.profile(True)
             out, fl = det.run(xd)
             torch.cuda.synchronize()
-            assert [nm for nm, _ in det.lastTimings()] == [kernel]
+            assert util.launched(det) == [kernel]
             out, fl = out.cpu().numpy(), fl.cpu().numpy()
         got[kernel] = out
         for c in range(channels):
@@ -717,7 +717,7 @@ def test_older_fused_kernels_keep_what_the_fold_kernel_does_not_take(oracle_lib,
             det.profile(True)
             out, fl = det.run(xd)
             torch.cuda.synchronize()
-            assert [nm for nm, _ in det.lastTimings()] == ["fused_kernel"]
+            assert util.launched(det) == ["fused_kernel"]
         _, _, w64 = util.oracle_for(cfg).run(x[0], po.F64)
         util.assert_outputs_close(out.cpu().numpy()[0], w64)
 
@@ -741,7 +741,7 @@ def test_normalize_and_normalizestd_chains_on_the_fold_kernel(oracle_lib, chain,
         det.profile(True)
         out, fl = det.run(torch.from_numpy(x).cuda())
         torch.cuda.synchronize()
-        assert [nm for nm, _ in det.lastTimings()] == ["fused_s_kernel"]
+        assert util.launched(det) == ["fused_s_kernel"]
         out, fl = out.cpu().numpy(), fl.cpu().numpy()
     o = util.oracle_for(cfg)
     for c in range(2):
@@ -774,7 +774,7 @@ def test_wider_hidden_layers_on_the_fold_kernel(oracle_lib, H, n_out, T, hop, ch
         det.profile(True)
         out, fl = det.run(torch.from_numpy(x).cuda())
         torch.cuda.synchronize()
-        assert [nm for nm, _ in det.lastTimings()] == ["fused_s_kernel"]
+        assert util.launched(det) == ["fused_s_kernel"]
         out, fl = out.cpu().numpy(), fl.cpu().numpy()
     o = util.oracle_for(cfg)
     for c in range(2):
@@ -825,7 +825,7 @@ def test_network_stage_on_the_matrix_cores(oracle_lib, N, lo, hi, T, H, scaling)
             det.profile(True)
             out, fl = det.run(xd)
             torch.cuda.synchronize()
-            assert [nm for nm, _ in det.lastTimings()][-1] == kernel
+            assert util.launched(det)[-1] == kernel
             out, fl = out.cpu().numpy(), fl.cpu().numpy()
         for c in range(2):
             _, _, w64 = o.run(x[c], po.F64)
@@ -864,7 +864,7 @@ def test_frames_of_four_hops_on_the_block_transform_kernel(oracle_lib, N, window
         det.profile(True)
         out, fl = det.run(torch.from_numpy(x).cuda())
         torch.cuda.synchronize()
-        names = [nm for nm, _ in det.lastTimings()]
+        names = util.launched(det)
         assert names[-1] == ("bdft_net_kernel" if window != _abi.WINDOW_BLACKMAN else ("fft1k_net_kernel" if N == 1024 and F % 4 == 0 else "mlp_mfma_kernel")), names
         out, fl = out.cpu().numpy(), fl.cpu().numpy()
     o = util.oracle_for(cfg)
@@ -903,7 +903,7 @@ def test_frames_of_two_hops_on_the_block_transform_kernel(oracle_lib, N, hop, wi
         det.profile(True)
         out, fl = det.run(torch.from_numpy(x).cuda())
         torch.cuda.synchronize()
-        assert [nm for nm, _ in det.lastTimings()] == (["bdft_net_kernel"] if N >= 512 else ["stft_lanes_kernel", "mlp_mfma_kernel"])
+        assert util.launched(det) == (["bdft_net_kernel"] if N >= 512 else ["stft_lanes_kernel", "mlp_mfma_kernel"])
         out, fl = out.cpu().numpy(), fl.cpu().numpy()
     o = util.oracle_for(cfg)
     for c in range(3):
@@ -988,7 +988,7 @@ def test_1024_point_frames_in_one_launch_and_in_two(oracle_lib, monkeypatch):
                 det.profile(True)
                 out, fl = det.run(torch.from_numpy(x).cuda())
                 torch.cuda.synchronize()
-                names = [nm for nm, _ in det.lastTimings()]
+                names = util.launched(det)
                 assert names == expect, names
                 out, fl = out.cpu().numpy(), fl.cpu().numpy()
             for c in range(3):
@@ -1004,7 +1004,7 @@ def test_1024_point_frames_in_one_launch_and_in_two(oracle_lib, monkeypatch):
         det.profile(True)
         out, _ = det.run(xs)
         torch.cuda.synchronize()
-        assert [nm for nm, _ in det.lastTimings()] == ["fft1k_net_kernel"]
+        assert util.launched(det) == ["fft1k_net_kernel"]
         for c in range(2):
             util.assert_outputs_close(out[c].cpu().numpy(), o.run(xs[c].cpu().numpy(), po.F64)[2])
     monkeypatch.delenv("SYLDET_NO_BDFT", raising=False)
@@ -1012,7 +1012,7 @@ def test_1024_point_frames_in_one_launch_and_in_two(oracle_lib, monkeypatch):
         det.profile(True)
         out, _ = det.run(xs)
         torch.cuda.synchronize()
-        assert [nm for nm, _ in det.lastTimings()] == ["bdft_net_kernel"]
+        assert util.launched(det) == ["bdft_net_kernel"]
         for c in range(2):
             util.assert_outputs_close(out[c].cpu().numpy(), o.run(xs[c].cpu().numpy(), po.F64)[2])
 
@@ -1037,7 +1037,7 @@ def test_hops_that_are_multiples_of_64_on_the_fold_kernel(oracle_lib, W, hop, H)
             det.profile(True)
             out, fl = det.run(torch.from_numpy(x).cuda())
             torch.cuda.synchronize()
-            assert [nm for nm, _ in det.lastTimings()] == ["fused_s_kernel"]
+            assert util.launched(det) == ["fused_s_kernel"]
             assert det.fixupStats() == (0, 0)
             out, fl = out.cpu().numpy(), fl.cpu().numpy()
         for c in range(C):

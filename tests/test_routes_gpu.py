@@ -24,12 +24,12 @@ def test_rows_past_2_gib_leave_the_fused_route_where_only_the_fold_kernel_holds_
         x = synth.channels_on_device(1, S_short, dev, fs=cfg.samplingRate)
         det.run(x)
         torch.cuda.synchronize()
-        assert [nm for nm, _ in det.lastTimings()][0] == "fused_s_kernel"
+        assert util.launched(det)[0] == "fused_s_kernel"
         del x
         x = synth.channels_on_device(1, S_long, dev, fs=cfg.samplingRate)
         out, fl = det.run(x)
         torch.cuda.synchronize()
-        names = [nm for nm, _ in det.lastTimings()]
+        names = util.launched(det)
         assert not any(nm.startswith("fused") and "spectrogram" not in nm for nm in names), names   # (the DFT half as an STFT is fine for linear columns)
         if variant == "db":
             assert not any(nm.startswith("fused") for nm in names), names
@@ -71,7 +71,7 @@ def test_bands_of_up_to_64_bins_stay_one_launch(oracle_lib, lo, hi, hop, T, kind
         det.profile(True)
         out, fl = det.run(torch.from_numpy(x).cuda())
         torch.cuda.synchronize()
-        assert [nm for nm, _ in det.lastTimings()] == ["fused_s_kernel"]
+        assert util.launched(det) == ["fused_s_kernel"]
         assert det.fixupStats() == (0, 0)
         out, fl = out.cpu().numpy(), fl.cpu().numpy()
     for c in range(C):
@@ -124,7 +124,7 @@ def test_five_to_sixteen_hidden_units_on_the_twice_folded_form(oracle_lib, H, n_
             det.profile(True)
             out, fl = det.run(xd)
             torch.cuda.synchronize()
-            names = [nm for nm, _ in det.lastTimings()]
+            names = util.launched(det)
             assert names and all(nm.startswith("fused") for nm in names), names
             res[form] = (out.cpu().numpy(), fl.cpu().numpy(), names)
     for c in range(C):

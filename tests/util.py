@@ -240,3 +240,10 @@ def sweep_summary():
             # whether fp32 itself fails the flat bar there (widened_evaluations)
             d["widened_records"].append({k: r[k] for k in ("seed", "kernel", "err", "own", "flat_bar", "err_over_bar", "wider_bar", "widened")})
     return out
+
+
+def launched(det):
+    """Names of the kernels of the detector's last batch call, in launch order -- without the exact recomputation behind a fused
+    kernel ("fixup_kernel"), which syldet_timings lists exactly for the calls that gave it work (level steps inside a pass-scaled
+    kernel's pass do; tests/test_extremes_gpu.py holds that rule itself)."""
+    return [name for name, _ in det.lastTimings() if name != "fixup_kernel"]
