@@ -175,6 +175,17 @@ bdft_net_kernel(const MlpxDesc d, const BdftDesc bd, const float *__restrict__ s
     for (int i = 0; i < 4; i++) cre[i] = bd.cre[(wave * 64 + lane) * 4 + i];
     const float wa0 = bd.a0, wc = bd.a1c, wsn = bd.a1s;               // a_0, (a_1 / 2) cos theta, (a_1 / 2) sin theta
     const int fb0 = bd.kb0 + 16 * wave + 4 * g - bd.f0;              // band index of this lane's first bin (the band is [0, F))
+    // the taps per bin: zero outside the band where the columns are linear -- such a column is then 0 by itself, its square needs no
+    // mask in the frame's sum (log columns keep the mask: a logarithm is not zero there)
+    float wA[4], wC[4], wS[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const bool on = SC || (unsigned)(fb0 + i) < (unsigned)F;
+        wA[i] = on ? wa0 : 0.0f; wC[i] = on ? wc : 0.0f; wS[i] = on ? wsn : 0.0f;
+#ifdef SYLDET_B_TAPS_UNIFORM
+        wA[i] = wa0; wC[i] = wc; wS[i] = wsn;
+#endif
+    }
 
     // ---- the fold's thread layout: block n of the sub-tile, positions m = 32 ks + 8 gf + 4 half + j (j < 4)
     const int f_ks = wave % KS, f_half = (wave / KS) & 1;
@@ -340,6 +351,32 @@ bdft_net_kernel(const MlpxDesc d, const BdftDesc bd, const float *__restrict__ s
         // instead of three (the previous sub-tile's last columns carry: B' for the first level, V for the second).
         floatx4 vre = bre, vim = bim;
         if (R == 4) {
+#ifndef SYLDET_B_SUM_PAIRS
+            // (in phases: the eight first halves, then the eight second halves -- a shifted addition that reads the register the
+            // instruction before wrote waits two states; eight independent ones apart it waits none)
+            const float l1[8] = {bre[0], bim[0], bim[1], -bre[1], -bre[2], -bim[2], -bim[3], bre[3]};
+            const float c1[8] = {bre[0], bim[0], bre[1], bim[1], bre[2], bim[2], bre[3], bim[3]};
+            const float p1[8] = {bre_prev[0], bim_prev[0], bre_prev[1], bim_prev[1], bre_prev[2], bim_prev[2], bre_prev[3], bim_prev[3]};
+            float t1[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) t1[k] = l1[k] + shr_cur<1>(c1[k]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < 8; k++) t1[k] = t1[k] + shl_prev<1>(p1[k]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; i++) { vre[i] = t1[2 * i]; vim[i] = t1[2 * i + 1]; }
+            const float p2[8] = {vre_prev[0], vim_prev[0], vre_prev[1], vim_prev[1], vre_prev[2], vim_prev[2], vre_prev[3], vim_prev[3]};
+            float t2[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) t2[k] = ((k >> 1) & 1 ? -t1[k] : t1[k]) + shr_cur<2>(t1[k]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < 8; k++) t2[k] = t2[k] + shl_prev<2>(p2[k]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; i++) { yre[i] = t2[2 * i]; yim[i] = t2[2 * i + 1]; }
+#else
             vre[0] = back_add<1>(bre[0], bre[0], bre_prev[0]);    vim[0] = back_add<1>(bim[0], bim[0], bim_prev[0]);     // rho = 1
             vre[1] = back_add<1>(bim[1], bre[1], bre_prev[1]);    vim[1] = back_add<1>(-bre[1], bim[1], bim_prev[1]);    // -i z = (b, -a)
             vre[2] = back_add<1>(-bre[2], bre[2], bre_prev[2]);   vim[2] = back_add<1>(-bim[2], bim[2], bim_prev[2]);    // -z
@@ -348,6 +385,7 @@ bdft_net_kernel(const MlpxDesc d, const BdftDesc bd, const float *__restrict__ s
             yre[1] = back_add<2>(-vre[1], vre[1], vre_prev[1]);   yim[1] = back_add<2>(-vim[1], vim[1], vim_prev[1]);    // -1
             yre[2] = back_add<2>(vre[2], vre[2], vre_prev[2]);    yim[2] = back_add<2>(vim[2], vim[2], vim_prev[2]);     // 1
             yre[3] = back_add<2>(-vre[3], vre[3], vre_prev[3]);   yim[3] = back_add<2>(-vim[3], vim[3], vim_prev[3]);    // -1
+#endif
         } else if (R == 2) {
             // two blocks a frame: Y'_n = rho B'_n + B'_{n-1} with rho = (-1)^k
 #pragma unroll
@@ -374,8 +412,8 @@ bdft_net_kernel(const MlpxDesc d, const BdftDesc bd, const float *__restrict__ s
         float cv[4], ssq = 0.0f;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const float xr = fmaf(wa0, yre[i], fmaf(wc, reL[i] + reR[i], -wsn * (imL[i] - imR[i])));
-            const float xi = fmaf(wa0, yim[i], fmaf(wsn, reL[i] - reR[i], wc * (imL[i] + imR[i])));
+            const float xr = fmaf(wA[i], yre[i], fmaf(wC[i], reL[i] + reR[i], -wS[i] * (imL[i] - imR[i])));
+            const float xi = fmaf(wA[i], yim[i], fmaf(wS[i], reL[i] - reR[i], wC[i] * (imL[i] + imR[i])));
             cv[i] = __builtin_amdgcn_sqrtf(fmaf(xr, xr, xi * xi));        // zvabs / 2, :329-333 (Y is the DFT itself, not twice it)
             const bool inb = (unsigned)(fb0 + i) < (unsigned)F;
             if (scaling != 0) {
@@ -386,7 +424,11 @@ bdft_net_kernel(const MlpxDesc d, const BdftDesc bd, const float *__restrict__ s
                 const float l = __builtin_amdgcn_logf(tiny ? cv[i] * 0x1p64f : cv[i]) - (tiny ? 64.0f : 0.0f);
                 cv[i] = inb ? l * lscale : 0.0f;
             }
+#ifdef SYLDET_B_TAPS_UNIFORM
             ssq = inb ? fmaf(cv[i], cv[i], ssq) : ssq;
+#else
+            ssq = (!SC || inb) ? fmaf(cv[i], cv[i], ssq) : ssq;
+#endif
         }
         ssq = xor32_sum(xor16_sum(ssq));
         const int rw = wrap(wrow + n);
@@ -577,6 +619,9 @@ bdft_net_kernel(const MlpxDesc d, const BdftDesc bd, const float *__restrict__ s
         if (tr > 0) iteration(yes{}, yes{}, end0{});
         iteration(yes{}, yes{}, end1{});
         iteration(yes{}, yes{}, end2{});
+#ifndef SYLDET_B_NOUNROLL                            // (unrolled: the three sets of raw samples in flight rotate by renaming, not by copies: -1.3 %)
+#pragma unroll
+#endif
         for (int s = 3; s < kSubs; s++) iteration(yes{}, yes{}, end0{});
         rbase_end = rbase; tr_end = tr;
         rbase = wrap(rbase + kNew);                    // the last T - 1 rows are the next tile's first: the ring moves on, nothing is copied
