@@ -129,26 +129,41 @@ def binding_of(kernel, launch, seconds=1.0, device_index=0):
     import threading
     import torch
     resource, evidence = BINDING.get(kernel, ("unknown", "no evidence recorded for this kernel"))
-    watts, mhz, stop = [], [], [False]
+    stop = [False]
 
     # the package's own sensors through sysfs (what rocm-smi prints): no child process, nothing executed beside a process that holds the GPU
+    # WHICH package: the card whose PCI address is this HIP device's (a box shows one GPU of a host of eight: card0 is not it in
+    # general); without a match every package is read and the one that draws most during the loop is taken, and the record says so
     hw = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_input"))
-    hwdir = os.path.dirname(hw[min(device_index, len(hw) - 1)]) if hw else None
+    hwdirs = [os.path.dirname(h) for h in hw]
+    sensor = None
+    try:
+        import ctypes
+        buf = ctypes.create_string_buffer(64)
+        if ctypes.CDLL("libamdhip64.so").hipDeviceGetPCIBusId(buf, 64, int(device_index)) == 0:
+            bdf = buf.value.decode().lower()                       # "0000:c5:00.0"
+            for hd in hwdirs:
+                if bdf and bdf in os.path.realpath(os.path.join(hd, "..", "..")).lower():
+                    hwdirs, sensor = [hd], "pci " + bdf
+                    break
+    except Exception:
+        pass
 
-    def read_num(name):
+    def read_num(hd, name):
         try:
-            return float(open(os.path.join(hwdir, name)).read().strip())
+            return float(open(os.path.join(hd, name)).read().strip())
         except Exception:
             return None
-    cap = read_num("power1_cap") if hwdir else None
+    per = {hd: ([], []) for hd in hwdirs}
 
     def poll():
-        while not stop[0] and hwdir:
-            w, f = read_num("power1_input"), read_num("freq1_input")
-            if w is not None:
-                watts.append(w / 1e6)
-            if f is not None:
-                mhz.append(f / 1e6)
+        while not stop[0] and hwdirs:
+            for hd in hwdirs:
+                w, f = read_num(hd, "power1_input"), read_num(hd, "freq1_input")
+                if w is not None:
+                    per[hd][0].append(w / 1e6)
+                if f is not None:
+                    per[hd][1].append(f / 1e6)
             time.sleep(0.01)
     th = threading.Thread(target=poll, daemon=True)
     th.start()
@@ -163,9 +178,14 @@ def binding_of(kernel, launch, seconds=1.0, device_index=0):
     stop[0] = True
     th.join(timeout=6)
     med = lambda v: sorted(v)[len(v) // 2] if v else None
+    hwdir = max(hwdirs, key=lambda hd: med(per[hd][0]) or 0.0) if hwdirs else None
+    if hwdir and sensor is None:
+        sensor = "busiest of %d packages" % len(hwdirs)
+    watts, mhz = per[hwdir] if hwdir else ([], [])
+    cap = read_num(hwdir, "power1_cap") if hwdir else None
     rec = {"resource": resource, "evidence": evidence, "socket_w": med(watts[len(watts) // 2:]), "sclk_mhz": med(mhz[len(mhz) // 2:]),   # (the loop's second half: the ramp is over)
            "power_limit_w": (cap / 1e6) if cap else 1400,
-           "samples": len(watts), "launches_while_sampled": n,
+           "samples": len(watts), "sensor": sensor, "launches_while_sampled": n,
            "ms_per_step_looped": looped_ms,        # (wall clock over the loop, a synchronisation every four steps: the regime of a job that runs for seconds)
            "issue_slot_utilisation": None, "issue_slot_source": None}
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_profile_summary.json")), reverse=True):

@@ -175,6 +175,7 @@ bdft_net_kernel(const MlpxDesc d, const BdftDesc bd, const float *__restrict__ s
     for (int i = 0; i < 4; i++) cre[i] = bd.cre[(wave * 64 + lane) * 4 + i];
     const float wa0 = bd.a0, wc = bd.a1c, wsn = bd.a1s;               // a_0, (a_1 / 2) cos theta, (a_1 / 2) sin theta
     const int fb0 = bd.kb0 + 16 * wave + 4 * g - bd.f0;              // band index of this lane's first bin (the band is [0, F))
+    const int lane_col = n * CS + 16 * wave + 4 * g, lane_ssf = n * kWaves + wave;
     // the taps per bin: zero outside the band where the columns are linear -- such a column is then 0 by itself, its square needs no
     // mask in the frame's sum (log columns keep the mask: a logarithm is not zero there)
     float wA[4], wC[4], wS[4];
@@ -274,8 +275,11 @@ bdft_net_kernel(const MlpxDesc d, const BdftDesc bd, const float *__restrict__ s
     floatx4 vre_prev = yre, vim_prev = yre;                          // ... and the first level of the sliding sum
     float upc = 0.0f, dnc = 0.0f;                                    // ... and the frames' column scales
     int64_t u = 0;                                                   // sub-tile counter of the run
-    int rbase = 0;                                                   // the tile's first (carried) row in the ring of column rows: no copying between tiles
-    int wrow = T - 1;                                                // the ring row of the next sub-tile to finish columns of (sub-tile q: 16 q + T - 1, wrapped)
+    // the ring of column rows: sub-tile q's sixteen new rows are rows 16 (q mod 7) .. + 15 -- a block that never wraps inside, so a
+    // lane's row address is one addition -- and a tile's first (carried) row lies timeRange - 1 rows in front of its first new one;
+    // no copying between tiles
+    int rbase = kTile - (T - 1);
+    int wrow = 0;                                                    // the first ring row of the next sub-tile to finish columns of
     auto blk_of = [&](int64_t uu) { return fbase + 16 * uu + (R - 1); };   // first block of sub-tile uu (frames end on their last block)
 
     // prologue: sub-tiles 0, 1 and 2 loaded, the maxima of the first two taken, sub-tile 0 folded.  In the loop a sub-tile's
@@ -431,15 +435,15 @@ bdft_net_kernel(const MlpxDesc d, const BdftDesc bd, const float *__restrict__ s
 #endif
         }
         ssq = xor32_sum(xor16_sum(ssq));
-        const int rw = wrap(wrow + n);
+        const int rw = wrow + n;
         unsigned h0, l0, h1, l1;
         const float upw = scaling != 0 ? 16.0f : upc;               // (logarithms are within +-800: a fixed scale keeps them under f16's 65504)
         split2(cv[0] * upw, cv[1] * upw, h0, l0);
         split2(cv[2] * upw, cv[3] * upw, h1, l1);
-        const int cb = 16 * wave + 4 * g;                            // column index = bin - kb0 (the first layer's fragments are in that order)
-        *reinterpret_cast<uint32x2 *>(colh + rw * CS + cb) = uint32x2{h0, h1};
-        *reinterpret_cast<uint32x2 *>(coll + rw * CS + cb) = uint32x2{l0, l1};
-        if (g == 0) ssf8[rw * kWaves + wave] = ssq;
+        // column index = bin - kb0 (the first layer's fragments are in that order); the lane's share of the address is loop-invariant
+        *reinterpret_cast<uint32x2 *>(colh + wrow * CS + lane_col) = uint32x2{h0, h1};
+        *reinterpret_cast<uint32x2 *>(coll + wrow * CS + lane_col) = uint32x2{l0, l1};
+        if (g == 0) ssf8[wrow * kWaves + lane_ssf] = ssq;
         if (fh && wave == 0 && g == 0) fsc[rw] = scaling != 0 ? 0.0625f : dnc;
     };
 
