@@ -278,7 +278,7 @@ bdft_net_kernel(const MlpxDesc d, const BdftDesc bd, const float *__restrict__ s
     // the ring of column rows: sub-tile q's sixteen new rows are rows 16 (q mod 7) .. + 15 -- a block that never wraps inside, so a
     // lane's row address is one addition -- and a tile's first (carried) row lies timeRange - 1 rows in front of its first new one;
     // no copying between tiles
-    int rbase = kTile - (T - 1);
+    int rbase = wrap(kTile - (T - 1));
     int wrow = 0;                                                    // the first ring row of the next sub-tile to finish columns of
     auto blk_of = [&](int64_t uu) { return fbase + 16 * uu + (R - 1); };   // first block of sub-tile uu (frames end on their last block)
 

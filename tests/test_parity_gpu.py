@@ -1044,3 +1044,33 @@ def test_hops_that_are_multiples_of_64_on_the_fold_kernel(oracle_lib, W, hop, H)
             _, _, w64 = o.run(x[c], po.F64, cfg.rule)
             util.assert_outputs_close(out[c], w64)
             util.assert_flags_exact(fl[c], w64, cfg.thresholds, cfg.rule)
+
+
+@pytest.mark.parametrize("T", [1, 2, 12])
+def test_block_transform_kernel_at_its_tile_boundaries(oracle_lib, T):
+    """kernels_bdft.hip ends a tile of 96 evaluations inside the next one (the last sub-tile's columns, then the tap products of the
+    tile's new rows, then the evaluations, in the next tile's first three iterations) and the run's last tile after a drain
+    iteration: recordings of one channel whose evaluation counts sit on and around every boundary of that schedule -- one
+    evaluation, one sub-tile, one tile exactly, one more, the ring's 107 used rows, two and three tiles -- for the shortest and the
+    longest window of columns the kernel takes (timeRange 1, 2, 12: 0, 1 and 11 carried rows)."""
+    torch = _torch()
+    from syllable_detector_swift_amd.config import SyllableDetectorConfig, frequencyIndexRange
+    N, hop = 1024, 256
+    rng = np.random.default_rng(40 + T)
+    f0, f1 = frequencyIndexRange(N, 44100.0, 1500.0, 6500.0)
+    net = nets.random_net(rng, (f1 - f0) * T, (4,), 1, in_fns=("l2normalize", "mapminmax"), out_fns=("mapminmax",))
+    cfg = SyllableDetectorConfig(44100.0, N, N, N - hop, (1500.0, 6500.0), T, "linear", [0.4], net, window=_abi.WINDOW_HANNING)
+    o = util.oracle_for(cfg)
+    whole = synth.channels(1, N + hop * 420, first=5).astype(np.float32)
+    for E in (1, 2, 15, 16, 17, 95, 96, 97, 106, 107, 108, 112, 191, 192, 193, 288, 289, 383, 384, 385):
+        S = N + hop * (E + T - 2) + (E % 3) * 57                    # E evaluations and a ragged tail
+        x = whole[:, :S]
+        with sd.SyllableDetector(cfg, channels=1) as det:
+            det.profile(True)
+            out, fl = det.run(torch.from_numpy(x).cuda())
+            torch.cuda.synchronize()
+            assert util.launched(det) == ["bdft_net_kernel"] and out.shape[1] == E, (E, out.shape, util.launched(det))
+            out, fl = out.cpu().numpy(), fl.cpu().numpy()
+        _, _, w64 = o.run(x[0], po.F64)
+        util.assert_outputs_close(out[0], w64)
+        util.assert_flags_exact(fl[0], w64, cfg.thresholds, cfg.rule)
