@@ -447,7 +447,6 @@ bdft_net_kernel(const MlpxDesc d, const BdftDesc bd, const float *__restrict__ s
         if (fh && wave == 0 && g == 0) fsc[rw] = scaling != 0 ? 0.0625f : dnc;
     };
 
-    const bool first_half = wave < kWaves / 2;
 #ifdef SYLDET_B_STAMPS
     unsigned long long tsum[8] = {0}, tk = 0;
 #define SD_BT(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long now = __builtin_amdgcn_s_memtime(); tsum[i] += now - tk; tk = now; __builtin_amdgcn_sched_barrier(0); }
@@ -466,6 +465,7 @@ bdft_net_kernel(const MlpxDesc d, const BdftDesc bd, const float *__restrict__ s
 #else
     constexpr bool kDoW = true;
 #endif
+    const bool first_half = wave < kWaves / 2;
     // ---- a tile's end, in two stages that run inside the NEXT tile's second and third iterations (round 5; the last tile's after the
     // loop), so that the stream of sub-tiles never stops: every iteration multiplies one sub-tile and finishes the columns of the one
     // before, across tile boundaries, and a tile costs six barriers instead of nine.
@@ -515,6 +515,8 @@ bdft_net_kernel(const MlpxDesc d, const BdftDesc bd, const float *__restrict__ s
 #ifndef SYLDET_B_NOEVAL
         // four threads an evaluation: row r starts the window of evaluation fbase + kNew tr + r - (T - 1); thread j of the four
         // takes taps j, j + 4, j + 8 and then hidden unit j (quad permutes carry the sums)
+        // (tried: on the first-half waves alone, which reach the barrier with time to spare -- the waits even out, 685 / 198 -> 620 / 665
+        // clocks an iteration, and the kernel is 0.5 % slower: MEASUREMENTS R5.4)
         if (tid < 4 * kNew) {
             const int r = tid >> 2, j = tid & 3;
             floatx4 z = {0.f, 0.f, 0.f, 0.f};
@@ -573,8 +575,9 @@ bdft_net_kernel(const MlpxDesc d, const BdftDesc bd, const float *__restrict__ s
         SD_BT(5)
         if (first_half) {
             if (WW && kDoW) stage_window(true);
-            if (END == 1 && tr_end >= 0) stage_taps();
             SD_BT(4)
+            if (END == 1 && tr_end >= 0) stage_taps();
+            SD_BT(5)
             if (MM && kDoM) stage_mfma();
             SD_BT(2)
             if (MM) stage_load_fold(true);
@@ -583,8 +586,9 @@ bdft_net_kernel(const MlpxDesc d, const BdftDesc bd, const float *__restrict__ s
             if (MM) stage_load_fold(false);
             SD_BT(3)
             if (WW && kDoW) stage_window(false);
-            if (END == 1 && tr_end >= 0) stage_taps();
             SD_BT(4)
+            if (END == 1 && tr_end >= 0) stage_taps();
+            SD_BT(5)
             if (MM && kDoM) stage_mfma();
             SD_BT(2)
         }
