@@ -224,7 +224,9 @@ int syldet_detections(syldet_t *h, const uint8_t *flags, int64_t n_evals, double
  * is launched on.  syldet_last_timings blocks until the last call's events have completed and
  * returns up to `capacity` kernel durations in milliseconds, in launch order, with their names.
  * The exact recomputation behind the fused kernels' precision guard ("fixup_kernel") is listed for
- * the calls that gave it work (syldet_fixup_stats' items > 0): on ordinary audio it is an empty launch.  */
+ * the calls that gave it work (syldet_fixup_stats' items > 0): on ordinary audio it is an empty launch.
+ * Its duration is the kernel's own (device clock, first workgroup in to last out), and reading it
+ * waits for the stream the call was made on.                                                       */
 int syldet_profile(syldet_t *h, int enable);
 int syldet_last_timings(syldet_t *h, double *milliseconds, const char **names, int32_t capacity, int32_t *count);
 /* Keep the events of the last `calls` batch calls instead of one (waits for the handle's stream, drops what was recorded), so

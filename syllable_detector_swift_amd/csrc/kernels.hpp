@@ -125,9 +125,10 @@ struct FixItem {
     int kind;
 };
 struct FixList {
-    unsigned *counters;         // [0] items appended, [1] workgroups done, [2] items of the last launch, [3] overflow (sticky)
+    unsigned *counters;         // [0] items appended, [1] workgroups done, [2] items of the last launch, [3] overflow (sticky), [4] the launch's first 10 ns tick (of 8 words)
     FixItem *items;
     unsigned capacity;
+    unsigned *host_count = nullptr;   // two page-locked words for the launch's item count and its duration in 10 ns ticks (profiling: syldet_timings), or null
 };
 
 struct FusedDesc {

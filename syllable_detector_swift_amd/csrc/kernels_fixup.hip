@@ -25,7 +25,7 @@ namespace {
 using namespace generic_dev;
 
 constexpr int kBlock = 256;
-constexpr int kFixGrid = 128;                   // (an empty list -- the ordinary case -- should cost a few microseconds, not a full grid)
+constexpr int kFixGrid = 512;                   // two workgroups a CU when the list is long; an empty list -- the ordinary case -- still costs one launch of a few microseconds (MEASUREMENTS R5.7)
 constexpr int kMaxFrames = kFixMaxCount + 11;      // frames behind one item: its evaluations' windows (timeRange <= 12)
 
 __global__ void __launch_bounds__(kBlock)
@@ -45,7 +45,17 @@ fixup_kernel(const FixDesc fd, const NetDesc n, const float *__restrict__ sample
 
     unsigned count = list.counters[0];
     count = count < list.capacity ? count : list.capacity;
-    if (count != 0) {
+    if (count == 0) {
+        // the ordinary case, behind every batch call: nothing to reset (the counters are as a finished launch leaves them), so no
+        // workgroup takes part in the last-one-out protocol below -- 512 atomics on one word are 10 us, this is a bare launch
+        if (blockIdx.x == 0 && tid == 0) {
+            list.counters[2] = 0u;
+            if (list.host_count) *list.host_count = 0u;
+        }
+        return;
+    }
+    if (blockIdx.x == 0 && tid == 0) list.counters[4] = (unsigned)__builtin_amdgcn_s_memrealtime();    // (the constant 100 MHz counter)
+    {
         for (int i = tid; i < N; i += kBlock) ctab[i] = fd.ctab[i];
         for (int i = tid; i < W; i += kBlock) win[i] = fd.window[i];
     }
@@ -102,6 +112,10 @@ fixup_kernel(const FixDesc fd, const NetDesc n, const float *__restrict__ sample
         __threadfence();
         const unsigned done = atomicAdd(list.counters + 1, 1u);
         if (done == gridDim.x - 1) {
+            if (list.host_count) {                    // the launch times itself: no events of its own around a launch that is empty on ordinary audio
+                list.host_count[1] = (unsigned)__builtin_amdgcn_s_memrealtime() - list.counters[4];
+                list.host_count[0] = list.counters[0];
+            }
             list.counters[2] = list.counters[0];
             list.counters[0] = 0u;
             list.counters[1] = 0u;

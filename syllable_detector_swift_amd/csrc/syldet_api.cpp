@@ -149,7 +149,7 @@ struct syldet {
     FusedPlan fused;
     DeviceBuffer d_stamps;            // diagnostic stamps (SYLDET_FUSED_STAMPS)
     // precision guard of the fused kernels (kernels.hpp, FixItem): work list + what the exact recomputation needs
-    DeviceBuffer d_fix;               // 4 counters | items
+    DeviceBuffer d_fix;               // 8 counters | items
     DeviceBuffer d_ctab;              // [N] (cos, sin)(2 pi m / N) fp64
     FixDesc fixd{};
     bool has_fix = false;
@@ -193,7 +193,8 @@ struct syldet {
     bool profiling = false;
     // a ring of the last prof_depth batch calls: kMaxTimed kernel slots each, two events a slot
     static constexpr int kMaxTimed = 8;
-    struct ProfCall { int count = 0; const char *names[kMaxTimed] = {}; };
+    struct ProfCall { int count = 0; const char *names[kMaxTimed] = {}; bool fix = false; hipStream_t fix_stream = nullptr; };   // fix: the exact path was launched behind the call's kernels (on fix_stream)
+    unsigned *prof_items_dev = nullptr;      // ... as the device addresses it
     unsigned *prof_items = nullptr;          // [prof_items_n] page-locked: the exact path's work items of each profiled call (timed_fixup)
     int prof_items_n = 0;
     std::vector<hipEvent_t> events;          // [prof_depth][kMaxTimed][2], created on first use
@@ -207,7 +208,8 @@ struct syldet {
         if ((int)prof_calls.size() != prof_depth) prof_calls.assign((size_t)prof_depth, ProfCall());
         prof_seq++;
         prof_calls[(size_t)prof_cur()].count = 0;
-        if (prof_items && prof_cur() < prof_items_n) prof_items[prof_cur()] = 0u;
+        prof_calls[(size_t)prof_cur()].fix = false;
+        if (prof_items && prof_cur() < prof_items_n) prof_items[2 * prof_cur()] = prof_items[2 * prof_cur() + 1] = 0u;
     }
 };
 
@@ -497,13 +499,13 @@ int prepare_fix(syldet *h, int C, int64_t units, int64_t segments, hipStream_t s
     // syldet_fixup_stats reports: the guard is never silently off)
     uint64_t cap = (uint64_t)C * (uint64_t)((units + 15) / 16 + 8 * segments + 16);
     if (cap > (1ull << 26)) cap = 1ull << 26;
-    const size_t bytes = 16 + (size_t)cap * sizeof(FixItem);
+    const size_t bytes = 32 + (size_t)cap * sizeof(FixItem);
     if (bytes > h->d_fix.cap) {
         if (int st = h->d_fix.reserve(bytes + bytes / 4)) return st;
-        SYLDET_HIP(hipMemsetAsync(h->d_fix.ptr, 0, 16, stream));
+        SYLDET_HIP(hipMemsetAsync(h->d_fix.ptr, 0, 32, stream));
     }
     out.counters = (unsigned *)h->d_fix.ptr;
-    out.items = (FixItem *)((char *)h->d_fix.ptr + 16);
+    out.items = (FixItem *)((char *)h->d_fix.ptr + 32);
     out.capacity = (unsigned)cap;
     return SYLDET_OK;
 }
@@ -625,27 +627,32 @@ struct KernelTimer {
     size_t base = 0;
 };
 
-// The exact recomputation behind a fused kernel is timed like every other launch; syldet_timings lists it for the calls whose work
-// list was not empty (an empty list is a launch of a few microseconds -- not what a profile is read for; a loud recording through a
-// network without a normaliser can spend fifty times the fused kernel's time here: MEASUREMENTS R5.7).  The list's length follows
-// the launch to a page-locked word of the call's slot.
+// The exact recomputation behind a fused kernel: on ordinary audio an empty launch behind EVERY batch call, so it gets no events of
+// its own (two event records are ~9 us on the stream: 1 % of the headline's step) -- it times itself (the device's 100 MHz counter,
+// first workgroup in to last workgroup out) and leaves its work list's length and its duration in two page-locked words of the
+// call's slot; syldet_timings lists it for the calls that gave it work (a loud recording through a network without a normaliser can
+// spend ten times the fused kernel's time here: MEASUREMENTS R5.7).
 const char kFixupName[] = "fixup_kernel";
 template <class F>
-int timed_fixup(syldet *h, hipStream_t stream, F launch)
+int timed_fixup(syldet *h, hipStream_t stream, FixList list, F launch)
 {
-    KernelTimer t(h, stream, kFixupName);
-    SYLDET_HIP(launch());
-    if (t.slot < 0 || !h->d_fix.ptr) return SYLDET_OK;
-    if (h->prof_items_n < h->prof_depth) {
-        // (the first profiled call since the history's depth grew: once, and nothing may still be writing the old array)
-        SYLDET_HIP(hipDeviceSynchronize());
-        if (h->prof_items) (void)hipHostFree(h->prof_items);
-        h->prof_items = nullptr; h->prof_items_n = 0;
-        SYLDET_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->prof_items), sizeof(unsigned) * (size_t)h->prof_depth, hipHostMallocDefault));
-        h->prof_items_n = h->prof_depth;
-        for (int i = 0; i < h->prof_items_n; i++) h->prof_items[i] = 0u;
+    if (h->profiling && !h->prof_calls.empty() && list.counters) {
+        if (h->prof_items_n < h->prof_depth) {
+            // (the first profiled call since the history's depth grew: once, and nothing may still be writing the old array)
+            SYLDET_HIP(hipDeviceSynchronize());
+            if (h->prof_items) (void)hipHostFree(h->prof_items);
+            h->prof_items = nullptr; h->prof_items_dev = nullptr; h->prof_items_n = 0;
+            SYLDET_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->prof_items), 2 * sizeof(unsigned) * (size_t)h->prof_depth, hipHostMallocMapped));
+            SYLDET_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&h->prof_items_dev), h->prof_items, 0));
+            h->prof_items_n = h->prof_depth;
+            for (int i = 0; i < 2 * h->prof_items_n; i++) h->prof_items[i] = 0u;
+        }
+        syldet::ProfCall &pc = h->prof_calls[(size_t)h->prof_cur()];
+        pc.fix = true;
+        pc.fix_stream = stream;
+        list.host_count = h->prof_items_dev + 2 * h->prof_cur();
     }
-    SYLDET_HIP(hipMemcpyAsync(&h->prof_items[h->prof_cur()], static_cast<const unsigned *>(h->d_fix.ptr) + 2, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+    SYLDET_HIP(launch(list));
     return SYLDET_OK;
 }
 
@@ -680,7 +687,7 @@ int stft_on_stream(syldet *h, const float *d_samples, int64_t stride, int C, int
             KernelTimer t(h, stream, "fused_kernel (spectrogram)");
             SYLDET_HIP(launch_fused_spectrogram(d, d_samples, stride, C, J, stream));
         }
-        return timed_fixup(h, stream, [&] { return launch_fixup(h->fixd, h->net, d_samples, stride, J, 0, nullptr, nullptr, d_columns, d.fix, stream); });
+        return timed_fixup(h, stream, d.fix, [&](const FixList &l) { return launch_fixup(h->fixd, h->net, d_samples, stride, J, 0, nullptr, nullptr, d_columns, l, stream); });
     }
 generic_transform:
     if (!h->sw.no_stft_lanes && stft_lanes_applicable(h->stft, d_samples, stride)) {
@@ -790,7 +797,7 @@ int run_on_stream(syldet *h, const float *d_samples, int64_t S, int64_t stride, 
             KernelTimer t(h, stream, names[fused_choice(d, J)]);
             SYLDET_HIP(launch_fused(d, d_samples, stride, C, S, J, E, d_outputs, d_flags, stream));
         }
-        return timed_fixup(h, stream, [&] { return launch_fixup(h->fixd, h->net, d_samples, stride, J, E, d_outputs, d_flags, nullptr, d.fix, stream); });
+        return timed_fixup(h, stream, d.fix, [&](const FixList &l) { return launch_fixup(h->fixd, h->net, d_samples, stride, J, E, d_outputs, d_flags, nullptr, l, stream); });
     }
     // (+ 16 bytes: the matrix-core network stage reads a frame's last bins as a whole quad)
     if (int st = h->d_columns.reserve((size_t)C * (size_t)J * (size_t)h->geom.bins * sizeof(float) + 16)) return st;
@@ -1041,8 +1048,6 @@ int syldet_timings(syldet_t *h, int32_t calls_back, double *milliseconds, const 
     for (int i = 0; i < pc.count; i++) {
         const size_t base = (size_t)(idx * syldet::kMaxTimed + i) * 2;
         SYLDET_HIP(hipEventSynchronize(h->events[base + 1]));
-        // the exact path is listed for calls that gave it work (timed_fixup; its count has arrived with the event)
-        if (pc.names[i] == kFixupName && !(h->prof_items && idx < h->prof_items_n && h->prof_items[idx] != 0u)) continue;
         if (n < capacity) {
             float ms = 0.0f;
             SYLDET_HIP(hipEventElapsedTime(&ms, h->events[base], h->events[base + 1]));
@@ -1050,6 +1055,20 @@ int syldet_timings(syldet_t *h, int32_t calls_back, double *milliseconds, const 
             if (names) names[n] = pc.names[i];
         }
         n++;
+    }
+    // the exact path, behind the call's kernels: listed for calls that gave it work, with the duration it measured itself (timed_fixup)
+    if (pc.fix && h->prof_items && idx < h->prof_items_n) {
+        if (hipStreamSynchronize(pc.fix_stream) != hipSuccess) {       // (a caller's stream that is gone by now: everything, then)
+            (void)hipGetLastError();
+            SYLDET_HIP(hipDeviceSynchronize());
+        }
+        if (h->prof_items[2 * idx] != 0u) {
+            if (n < capacity) {
+                milliseconds[n] = (double)h->prof_items[2 * idx + 1] * 1e-5;
+                if (names) names[n] = kFixupName;
+            }
+            n++;
+        }
     }
     *count = n;
     return SYLDET_OK;
