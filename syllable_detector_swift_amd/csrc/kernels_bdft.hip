@@ -309,6 +309,19 @@ bdft_net_kernel(const MlpxDesc d, const BdftDesc bd, const float *__restrict__ s
         fold_store(r1, (int)((u + 1) & 3), (u & 1) ? bfr0 : bfr1, fh);
 #endif
     };
+    // the first k-step's fragments are asked for before the window stage, whose arithmetic then covers their way out of LDS
+    // (SYLDET_B_PREFETCH k-steps: 1 ships)
+#ifndef SYLDET_B_PREFETCH
+#define SYLDET_B_PREFETCH 1                       // (k-steps of fragments asked for ahead: 1 is -0.9 %, 2 is -0.7 %: MEASUREMENTS R5.4)
+#endif
+    uint32x4 pf[SYLDET_B_PREFETCH > 0 ? SYLDET_B_PREFETCH : 1][4] = {};
+    auto mfma_prefetch = [&]() {
+        const uint32x4 *bf = reinterpret_cast<const uint32x4 *>((u & 1) ? bfr1 : bfr0) + lane;
+#pragma unroll
+        for (int q = 0; q < SYLDET_B_PREFETCH; q++)
+#pragma unroll
+            for (int w = 0; w < 4; w++) pf[q][w] = bf[(w * KS + q) * 64];
+    };
     auto stage_mfma = [&]() {                                        // sub-tile u: B', the sliding sum, the edge bins
         const int par = (int)(u & 1);
         // ---- B'_n[k] for this wave's bins: cosine rows against the sums, sine rows against the differences
@@ -317,10 +330,10 @@ bdft_net_kernel(const MlpxDesc d, const BdftDesc bd, const float *__restrict__ s
         floatx4 are = {0.f, 0.f, 0.f, 0.f}, aim = are;
         uint32x4 fr[2][4];                                           // fragments two k-steps ahead of their MFMAs
 #pragma unroll
-        for (int w = 0; w < 4; w++) fr[0][w] = bf[(w * KS + 0) * 64];
+        for (int w = 0; w < 4; w++) fr[0][w] = SYLDET_B_PREFETCH >= 1 ? pf[0][w] : bf[(w * KS + 0) * 64];
         if (KS > 1) {
 #pragma unroll
-            for (int w = 0; w < 4; w++) fr[1][w] = bf[(w * KS + 1) * 64];
+            for (int w = 0; w < 4; w++) fr[1][w] = SYLDET_B_PREFETCH >= 2 ? pf[SYLDET_B_PREFETCH >= 2 ? 1 : 0][w] : bf[(w * KS + 1) * 64];
         }
 #pragma unroll
         for (int ks = 0; ks < KS; ks++) {
@@ -406,11 +419,19 @@ bdft_net_kernel(const MlpxDesc d, const BdftDesc bd, const float *__restrict__ s
         edges[(par * 32 + 4 * wave + g) * 16 + n] = floatx4{yre[0], yim[0], yre[3], yim[3]};
         bre_prev = bre; bim_prev = bim; vre_prev = vre; vim_prev = vim;
     };
+    floatx4 eLp = {0.f, 0.f, 0.f, 0.f}, eRp = eLp;
+    auto window_prefetch = [&]() {                                   // the neighbours' edge bins asked for a stage ahead (-0.4 %)
+        const int pe = (int)((u - 1) & 1);
+        const int G = 4 * wave + g;
+        eLp = G > 0 ? edges[(pe * 32 + G - 1) * 16 + n] : floatx4{0.f, 0.f, 0.f, 0.f};
+        eRp = G < 31 ? edges[(pe * 32 + G + 1) * 16 + n] : floatx4{0.f, 0.f, 0.f, 0.f};
+    };
     auto stage_window = [&](bool fh) {                                       // sub-tile u - 1 (ring rows wrow ..): window taps, |X|, columns
         const int pe = (int)((u - 1) & 1);                           // (u: this iteration's sub-tile, or one past the tile's last in the drain iteration)
         const int G = 4 * wave + g;
-        const floatx4 eL = G > 0 ? edges[(pe * 32 + G - 1) * 16 + n] : floatx4{0.f, 0.f, 0.f, 0.f};
-        const floatx4 eR = G < 31 ? edges[(pe * 32 + G + 1) * 16 + n] : floatx4{0.f, 0.f, 0.f, 0.f};
+        // (a wave of the second half asked for them before its fold: window_prefetch)
+        const floatx4 eL = fh ? (G > 0 ? edges[(pe * 32 + G - 1) * 16 + n] : floatx4{0.f, 0.f, 0.f, 0.f}) : eLp;
+        const floatx4 eR = fh ? (G < 31 ? edges[(pe * 32 + G + 1) * 16 + n] : floatx4{0.f, 0.f, 0.f, 0.f}) : eRp;
         const float reL[4] = {eL[2], yre[0], yre[1], yre[2]}, imL[4] = {eL[3], yim[0], yim[1], yim[2]};
         const float reR[4] = {yre[1], yre[2], yre[3], eR[0]}, imR[4] = {yim[1], yim[2], yim[3], eR[1]};
         float cv[4], ssq = 0.0f;
@@ -574,6 +595,7 @@ bdft_net_kernel(const MlpxDesc d, const BdftDesc bd, const float *__restrict__ s
         if (END == 2 && tr_end >= 0) stage_evaluate();
         SD_BT(5)
         if (first_half) {
+            if (MM) mfma_prefetch();
             if (WW && kDoW) stage_window(true);
             SD_BT(4)
             if (END == 1 && tr_end >= 0) stage_taps();
@@ -583,8 +605,10 @@ bdft_net_kernel(const MlpxDesc d, const BdftDesc bd, const float *__restrict__ s
             if (MM) stage_load_fold(true);
             SD_BT(3)
         } else {
+            if (WW && kDoW) window_prefetch();
             if (MM) stage_load_fold(false);
             SD_BT(3)
+            if (MM) mfma_prefetch();
             if (WW && kDoW) stage_window(false);
             SD_BT(4)
             if (END == 1 && tr_end >= 0) stage_taps();
