@@ -605,6 +605,18 @@ bdft_net_kernel(const MlpxDesc d, const BdftDesc bd, const float *__restrict__ s
             if (MM) stage_load_fold(true);
             SD_BT(3)
         } else {
+#ifdef SYLDET_B_ORDER_WLM                            // (diagnostic: window, fold, multiply in the second half too)
+            if (WW && kDoW) window_prefetch();
+            if (WW && kDoW) stage_window(false);
+            SD_BT(4)
+            if (END == 1 && tr_end >= 0) stage_taps();
+            SD_BT(5)
+            if (MM) mfma_prefetch();
+            if (MM) stage_load_fold(false);
+            SD_BT(3)
+            if (MM && kDoM) stage_mfma();
+            SD_BT(2)
+#else
             if (WW && kDoW) window_prefetch();
             if (MM) stage_load_fold(false);
             SD_BT(3)
@@ -615,6 +627,7 @@ bdft_net_kernel(const MlpxDesc d, const BdftDesc bd, const float *__restrict__ s
             SD_BT(5)
             if (MM && kDoM) stage_mfma();
             SD_BT(2)
+#endif
         }
         if (WW) wrow = wrap(wrow + 16);
         if (MM) {
