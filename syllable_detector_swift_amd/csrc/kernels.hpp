@@ -77,6 +77,7 @@ struct WideDesc {
     int wg8;                    // two workgroups of 8 waves a CU instead of one of 16 (kernels_wide.hip, NWV)
     int stagger;                // (wg8) waves 4-7 run one epilogue behind waves 0-3 (kernels_wide.hip, STG)
     int dma_builtin;            // (wg8, unstaggered) the weight DMA through __builtin_amdgcn_global_load_lds instead of the assembly statement
+    int tiles4;                 // (wg8, staggered) one workgroup of 8 waves a CU with four evaluation tiles a wave (kernels_wide.hip, TPW)
     const uint4 *wpack;         // [n_chunks][kWideChunkBytes / 16]
     const float *b1;            // [n_out]
     const float *out_params;    // per output fn: y, gain[n_out], xoff[n_out]

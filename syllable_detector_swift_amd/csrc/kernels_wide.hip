@@ -369,13 +369,16 @@ __device__ float *g_wide_trace = nullptr;
 // the results are the unstaggered kernel's bit for bit.
 // DMAB: the weight DMA through the compiler's builtin instead of the assembly statement (A/B and parity of the two forms:
 // SYLDET_WIDE_DMA_BUILTIN=1; behind the builtin every later LDS read waits for the DMA, see fetch_chunk).
-template <int NOUT, bool SIG, bool FRONT, int NWV = 16, bool STG = false, bool DMAB = false>
-__global__ void __launch_bounds__(64 * NWV, NWV == 16 ? 1 : 4)
+// TPW: evaluation tiles of 16 a wave.  2: 128 registers, four waves a SIMD (two workgroups of 8 a CU, or one of 16).  4 (with NWV = 8: ONE
+// workgroup of 8 waves a CU, two waves a SIMD, 256 registers): a chunk's fragments, read from LDS once a wave, then feed twice the
+// matrix instructions -- eight waves reading every chunk's 20 KB took as long as the chunk's matrix instructions.
+template <int NOUT, bool SIG, bool FRONT, int NWV = 16, bool STG = false, bool DMAB = false, int TPW = 2>
+__global__ void __launch_bounds__(64 * NWV, TPW == 4 ? 2 : (NWV == 16 ? 1 : 4))
 wide_gemm16_kernel(WideDesc d, const uint4 *__restrict__ xn, const float *__restrict__ columns, int64_t J, int64_t E, int64_t NE,
                    float *__restrict__ outputs, uint8_t *__restrict__ flags)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int kWaves = NWV, kK2 = kWideK / 32, kBl = 64 * NWV, kTl = 32 * NWV;
+    constexpr int kWaves = NWV, kK2 = kWideK / 32, kBl = 64 * NWV, kTl = 16 * TPW * NWV;
     uint4 *buf0 = reinterpret_cast<uint4 *>(smem), *buf1 = buf0 + kChunkU4Pad;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (a scalar: the DMA's LDS base and span tests stay out of the vector registers)
@@ -383,18 +386,18 @@ wide_gemm16_kernel(WideDesc d, const uint4 *__restrict__ xn, const float *__rest
     // FRONT: a workgroup's 512 evaluations are consecutive ones of ONE channel (grid y), so the columns under them are one
     // stretch of 511 F + I floats, staged through LDS once; otherwise evaluations are numbered through all channels
     const int64_t e_blk = (int64_t)blockIdx.x * kTl;        // (FRONT: within channel blockIdx.y)
-    int64_t ev[2];
-    bool ev_ok[2];
+    int64_t ev[TPW];
+    bool ev_ok[TPW];
 #pragma unroll
-    for (int t = 0; t < 2; t++) {
-        const int64_t el = e_blk + wave * 32 + 16 * t + n;
+    for (int t = 0; t < TPW; t++) {
+        const int64_t el = e_blk + wave * (16 * TPW) + 16 * t + n;
         ev[t] = FRONT ? (int64_t)blockIdx.y * E + el : el;
         ev_ok[t] = FRONT ? el < E : el < NE;
     }
-    bf16x8 B[2][kK2];
+    bf16x8 B[TPW][kK2];
     if (!FRONT) {
 #pragma unroll
-        for (int t = 0; t < 2; t++)
+        for (int t = 0; t < TPW; t++)
 #pragma unroll
             for (int ks = 0; ks < kK2; ks++) {
                 union { uint4 u; bf16x8 v; } b;
@@ -423,8 +426,8 @@ wide_gemm16_kernel(WideDesc d, const uint4 *__restrict__ xn, const float *__rest
             __syncthreads();
         }
 #pragma unroll
-        for (int t = 0; t < 2; t++) {
-            const int el = wave * 32 + 16 * t + n;
+        for (int t = 0; t < TPW; t++) {
+            const int el = wave * (16 * TPW) + 16 * t + n;
             int off = el * F + 8 * g;
             const int lim = I - 8 * g;
             float rinv = 1.0f;
@@ -452,9 +455,9 @@ wide_gemm16_kernel(WideDesc d, const uint4 *__restrict__ xn, const float *__rest
         }
         __syncthreads();                                          // (nothing else uses the stage; the chunk buffers are next)
     }
-    float ysum[2][NOUT];
+    float ysum[TPW][NOUT];
 #pragma unroll
-    for (int t = 0; t < 2; t++)
+    for (int t = 0; t < TPW; t++)
 #pragma unroll
         for (int o = 0; o < NOUT; o++) ysum[t][o] = 0.0f;
     // (a buffer resource over the packed weights: a lane's address is one 32-bit offset, the chunk's a scalar)
@@ -495,13 +498,13 @@ wide_gemm16_kernel(WideDesc d, const uint4 *__restrict__ xn, const float *__rest
         }
     };
     // a chunk: 20 MFMAs a tile pair from the chunk's fragments in LDS; then the hidden values and their share of the outputs
-    auto multiply = [&](const uint4 *cur, floatx4w (&acc)[2][2]) {
+    auto multiply = [&](const uint4 *cur, floatx4w (&acc)[2][TPW]) {
         const float *cst = reinterpret_cast<const float *>(cur + kKSteps * 64);
 #pragma unroll
         for (int ut = 0; ut < 2; ut++) {
             const float4 b0 = *reinterpret_cast<const float4 *>(cst + 16 * ut + 4 * g);
 #pragma unroll
-            for (int t = 0; t < 2; t++) acc[ut][t] = floatx4w{b0.x, b0.y, b0.z, b0.w};
+            for (int t = 0; t < TPW; t++) acc[ut][t] = floatx4w{b0.x, b0.y, b0.z, b0.w};
         }
 #pragma unroll
         for (int ks = 0; ks < kK2; ks++) {
@@ -509,7 +512,7 @@ wide_gemm16_kernel(WideDesc d, const uint4 *__restrict__ xn, const float *__rest
             a0.u = cur[(2 * ks + 0) * 64 + lane];
             a1.u = cur[(2 * ks + 1) * 64 + lane];
 #pragma unroll
-            for (int t = 0; t < 2; t++) {
+            for (int t = 0; t < TPW; t++) {
                 acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0.v, B[t][ks], acc[0][t], 0, 0, 0);
                 acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1.v, B[t][ks], acc[1][t], 0, 0, 0);
             }
@@ -522,7 +525,7 @@ wide_gemm16_kernel(WideDesc d, const uint4 *__restrict__ xn, const float *__rest
     const u32x4 t_rs4 = {(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)tp), (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(tp >> 32)) & 0xffffu,
                          (unsigned)__builtin_amdgcn_readfirstlane(g_wide_trace ? d.n_chunks * 5 * 1024 : 0), 0x00020000u};
 #endif
-    auto finish = [&](const uint4 *cur, floatx4w (&acc)[2][2], int ch) {
+    auto finish = [&](const uint4 *cur, floatx4w (&acc)[2][TPW], int ch) {
         const float *cst = reinterpret_cast<const float *>(cur + kKSteps * 64);
 #ifdef SYLDET_WIDE_X_PAD                                              // (diagnostic: idle states between the last matrix instruction and the first read of its result)
         __builtin_amdgcn_sched_barrier(0);
@@ -532,7 +535,7 @@ wide_gemm16_kernel(WideDesc d, const uint4 *__restrict__ xn, const float *__rest
 #pragma unroll
         for (int ut = 0; ut < 2; ut++) {
 #pragma unroll
-            for (int t = 0; t < 2; t++)
+            for (int t = 0; t < TPW; t++)
 #pragma unroll
                 for (int j = 0; j < 4; j++)
                     acc[ut][t][j] = SIG ? __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(acc[ut][t][j]) + 1.0f) : transfer_fast(d.tf0, acc[ut][t][j]);
@@ -549,7 +552,7 @@ wide_gemm16_kernel(WideDesc d, const uint4 *__restrict__ xn, const float *__rest
                 }
 #endif
 #pragma unroll
-                for (int t = 0; t < 2; t++) {
+                for (int t = 0; t < TPW; t++) {
                     // (the weight FIRST: the compiler packs the two tiles' multiply-adds into v_pk_fma_f32 and takes w1.y / w1.w -- the high
                     // registers of their pairs -- by operand selection; on src1 that selection loses the low half's product in lanes 48-63
                     // whenever another wave of the SIMD is in its matrix instructions (tools/ubench/pkfma_opsel.hip, MEASUREMENTS R5.1), on
@@ -575,7 +578,7 @@ wide_gemm16_kernel(WideDesc d, const uint4 *__restrict__ xn, const float *__rest
         for (int ch = 0; ch < d.n_chunks; ch++) {
             const uint4 *cur = (ch & 1) ? buf1 : buf0;
             if (ch + 1 < d.n_chunks) fetch_chunk(ch + 1, (ch & 1) ? buf0 : buf1);
-            floatx4w acc[2][2];                                   // [unit tile][evaluation tile]: register i = unit 16 ut + 4 g + i
+            floatx4w acc[2][TPW];                                   // [unit tile][evaluation tile]: register i = unit 16 ut + 4 g + i
             multiply(cur, acc);
             finish(cur, acc, ch);
             __builtin_amdgcn_s_waitcnt(0x0F70);
@@ -620,14 +623,14 @@ wide_gemm16_kernel(WideDesc d, const uint4 *__restrict__ xn, const float *__rest
             for (int ch = 0; ch < nch; ch++) {
                 const int bn = next(bi);
                 if (ch + 1 < nch) fetch_chunk(ch + 1, bufp(bn));
-                floatx4w acc[2][2];
+                floatx4w acc[2][TPW];
                 multiply(bufp(bi), acc);
                 finish(bufp(bi), acc, ch);
                     seal();
                 bi = bn;
             }
         } else {
-            floatx4w acc[2][2];                                   // (chunk c - 1's sums cross barrier c in registers)
+            floatx4w acc[2][TPW];                                   // (chunk c - 1's sums cross barrier c in registers)
             if (1 < nch) fetch_chunk(1, bufp(1));
             multiply(bufp(0), acc);
             seal();
@@ -650,13 +653,13 @@ wide_gemm16_kernel(WideDesc d, const uint4 *__restrict__ xn, const float *__rest
     int tid2 = threadIdx.x;
     asm volatile("" : "+v"(tid2));                                // (recomputed: held across the loop they cost two spilled pairs)
 #pragma unroll
-    for (int t = 0; t < 2; t++) {
-        const int64_t el = (int64_t)blockIdx.x * kTl + (tid2 >> 6) * 32 + 16 * t + (tid2 & 15);
+    for (int t = 0; t < TPW; t++) {
+        const int64_t el = (int64_t)blockIdx.x * kTl + (tid2 >> 6) * (16 * TPW) + 16 * t + (tid2 & 15);
         ev[t] = FRONT ? (int64_t)blockIdx.y * E + el : el;
         ev_ok[t] = FRONT ? el < E : el < NE;
     }
 #pragma unroll
-    for (int t = 0; t < 2; t++) {
+    for (int t = 0; t < TPW; t++) {
 #pragma unroll
         for (int o = 0; o < NOUT; o++) {
             auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(ysum[t][o]), __float_as_uint(ysum[t][o]), false, false);
@@ -727,6 +730,16 @@ hipError_t launch_wide_gemm(const WideDesc &d, const void *xn, const float *colu
         // two workgroups of 8 waves a CU (WideDesc::wg8) where the columns under 256 evaluations and the chunk buffers fit twice
         const bool wg8 = d.wg8 && d.front && one16 && (size_t)wide_front_stage_floats(d.F, d.I, 256) * 4 + 2 * kChunkU4Pad * 16 <= 78 * 1024;
         if (wg8) {
+            if (d.tiles4 && d.stagger && !d.dma_builtin && (size_t)wide_front_stage_floats(d.F, d.I, 512) * 4 + 2 * kChunkU4Pad * 16 <= 158 * 1024) {
+                // one workgroup of 8 waves a CU, four evaluation tiles a wave (TPW = 4)
+                auto k4 = d.sig ? wide_gemm16_kernel<1, true, true, 8, true, false, 4> : wide_gemm16_kernel<1, false, true, 8, true, false, 4>;
+                if (E <= 0 || NE % E != 0) return hipErrorInvalidValue;
+                const size_t lds4 = 2 * kChunkU4Pad * 16 + std::max((size_t)wide_front_stage_floats(d.F, d.I, 512) * 4, (size_t)kChunkU4Pad * 16);
+                hipError_t st4 = hipFuncSetAttribute((const void *)k4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
+                if (st4 != hipSuccess) return st4;
+                hipLaunchKernelGGL(k4, dim3((unsigned)((E + 511) / 512), (unsigned)(NE / E)), dim3(512), lds4, stream, d, (const uint4 *)xn, columns, J, E, NE, outputs, flags);
+                return hipGetLastError();
+            }
             auto k8 = d.dma_builtin ? (d.sig ? wide_gemm16_kernel<1, true, true, 8, false, true> : wide_gemm16_kernel<1, false, true, 8, false, true>)
                       : d.stagger   ? (d.sig ? wide_gemm16_kernel<1, true, true, 8, true> : wide_gemm16_kernel<1, false, true, 8, true>)
                                     : (d.sig ? wide_gemm16_kernel<1, true, true, 8> : wide_gemm16_kernel<1, false, true, 8>);

@@ -106,6 +106,7 @@ struct syldet {
         bool wide_wg16 = false;       // SYLDET_WIDE_WG16: the wide engine's GEMM as one workgroup of 16 waves a CU (rounds 1-3), not two of 8
         bool wide_stagger = true;     // SYLDET_WIDE_NOSTAGGER: the two-workgroup GEMM WITHOUT waves 4-7 running one epilogue behind waves 0-3 (round 4's order)
         bool wide_dma_builtin = false;   // SYLDET_WIDE_DMA_BUILTIN: (unstaggered) the weight DMA through the compiler's builtin, not the assembly statement
+        bool wide_tiles4 = false;     // SYLDET_WIDE_T4: the staggered GEMM as one workgroup a CU with four evaluation tiles a wave
         bool wide_shape32 = false;    // SYLDET_WIDE_SHAPE32: the wide engine's GEMM on the 32x32x16 MFMA shape (rounds 1-2), not 16x16x32
         bool no_bdft = false;         // SYLDET_NO_BDFT: frames of four hops on the FFT kernels, not the block-transform kernel
         bool no_stft_lanes = false;   // SYLDET_NO_STFT_LANES: the LDS Stockham FFT instead of the lane-butterfly one
@@ -126,6 +127,7 @@ struct syldet {
             wide_wg16 = std::getenv("SYLDET_WIDE_WG16") != nullptr;
             wide_stagger = std::getenv("SYLDET_WIDE_NOSTAGGER") == nullptr;
             wide_dma_builtin = std::getenv("SYLDET_WIDE_DMA_BUILTIN") != nullptr;
+            wide_tiles4 = std::getenv("SYLDET_WIDE_T4") != nullptr;
             wide_no_front = std::getenv("SYLDET_WIDE_NO_FRONT") != nullptr;
             no_stft_lanes = std::getenv("SYLDET_NO_STFT_LANES") != nullptr;
             no_guard = std::getenv("SYLDET_NO_GUARD") != nullptr;
@@ -411,6 +413,7 @@ int upload_wide(syldet *h, std::string &why)
     d.wg8 = h->sw.wide_wg16 ? 0 : 1;
     d.stagger = h->sw.wide_stagger ? 1 : 0;
     d.dma_builtin = h->sw.wide_dma_builtin ? 1 : 0;
+    d.tiles4 = h->sw.wide_tiles4 ? 1 : 0;
     d.wpack = (const uint4 *)h->d_wide.ptr;
     d.b1 = (const float *)((const char *)h->d_wide.ptr + pack_bytes);
     d.out_params = d.b1 + n_out;

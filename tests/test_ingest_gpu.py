@@ -199,7 +199,8 @@ def test_wide_gemm_forms_agree_bit_for_bit(H, monkeypatch):
     """Every form of the 16x16x32 GEMM makes its sums in the same order, so their results are the same bits: the staggered
     two-workgroup form that ships (waves 4-7 one epilogue behind waves 0-3, three chunk buffers), the unstaggered one
     (SYLDET_WIDE_NOSTAGGER: round 4's), the same with the weight DMA through the compiler's builtin instead of the assembly
-    statement (SYLDET_WIDE_DMA_BUILTIN), and one workgroup of 16 waves (SYLDET_WIDE_WG16).  Several rounds of workgroups per
+    statement (SYLDET_WIDE_DMA_BUILTIN), one workgroup of 16 waves (SYLDET_WIDE_WG16), and one of 8 with four evaluation tiles a wave
+    (SYLDET_WIDE_T4: round 5's experiment, MEASUREMENTS R5.1c).  Several rounds of workgroups per
     CU (the staggered form's run-to-run differences of round 4 -- a packed multiply-add that loses a product beside another
     wave's matrix instructions, MEASUREMENTS R5.1 -- showed only there), each form twice."""
     torch = _torch()
@@ -209,8 +210,9 @@ def test_wide_gemm_forms_agree_bit_for_bit(H, monkeypatch):
     x = synth.channels_on_device(C, S, torch.device("cuda", 0), fs=cfg.samplingRate)
     results = {}
     for form, env in (("staggered", {}), ("unstaggered", {"SYLDET_WIDE_NOSTAGGER": "1"}),
-                      ("builtin DMA", {"SYLDET_WIDE_NOSTAGGER": "1", "SYLDET_WIDE_DMA_BUILTIN": "1"}), ("16 waves", {"SYLDET_WIDE_WG16": "1"})):
-        for k in ("SYLDET_WIDE_NOSTAGGER", "SYLDET_WIDE_DMA_BUILTIN", "SYLDET_WIDE_WG16"):
+                      ("builtin DMA", {"SYLDET_WIDE_NOSTAGGER": "1", "SYLDET_WIDE_DMA_BUILTIN": "1"}), ("16 waves", {"SYLDET_WIDE_WG16": "1"}),
+                      ("four tiles a wave", {"SYLDET_WIDE_T4": "1"})):
+        for k in ("SYLDET_WIDE_NOSTAGGER", "SYLDET_WIDE_DMA_BUILTIN", "SYLDET_WIDE_WG16", "SYLDET_WIDE_T4"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -224,7 +226,7 @@ def test_wide_gemm_forms_agree_bit_for_bit(H, monkeypatch):
             assert [k for k, _ in det.lastTimings() if k.startswith("wide_gemm")] == ["wide_gemm16_kernel"]
         assert np.array_equal(runs[0][0], runs[1][0], equal_nan=True) and np.array_equal(runs[0][1], runs[1][1]), "%s: two runs differ" % form
         results[form] = runs[0]
-    for form in ("unstaggered", "builtin DMA", "16 waves"):
+    for form in ("unstaggered", "builtin DMA", "16 waves", "four tiles a wave"):
         differ = int((results[form][0] != results["staggered"][0]).sum())
         assert differ == 0 and np.array_equal(results[form][1], results["staggered"][1]), "%s against staggered: %d outputs differ" % (form, differ)
 
