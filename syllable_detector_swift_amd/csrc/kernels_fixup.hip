@@ -54,7 +54,8 @@ fixup_kernel(const FixDesc fd, const NetDesc n, const float *__restrict__ sample
         }
         return;
     }
-    if (blockIdx.x == 0 && tid == 0) list.counters[4] = (unsigned)__builtin_amdgcn_s_memrealtime();    // (the constant 100 MHz counter)
+    // (the constant 100 MHz counter; stored and read back at device scope: the reader's CU may hold the line from its read of the count)
+    if (blockIdx.x == 0 && tid == 0) __hip_atomic_store(list.counters + 4, (unsigned)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     {
         for (int i = tid; i < N; i += kBlock) ctab[i] = fd.ctab[i];
         for (int i = tid; i < W; i += kBlock) win[i] = fd.window[i];
@@ -113,7 +114,7 @@ fixup_kernel(const FixDesc fd, const NetDesc n, const float *__restrict__ sample
         const unsigned done = atomicAdd(list.counters + 1, 1u);
         if (done == gridDim.x - 1) {
             if (list.host_count) {                    // the launch times itself: no events of its own around a launch that is empty on ordinary audio
-                list.host_count[1] = (unsigned)__builtin_amdgcn_s_memrealtime() - list.counters[4];
+                list.host_count[1] = (unsigned)__builtin_amdgcn_s_memrealtime() - __hip_atomic_load(list.counters + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 list.host_count[0] = list.counters[0];
             }
             list.counters[2] = list.counters[0];
