@@ -339,3 +339,20 @@ def test_sharded_abi_rejects_bad_arguments_without_touching_a_device():
     assert lib.syldet_shard_table(4, 2, None) == _abi.ERR_INVALID_ARGUMENT
     p = C.c_void_p()
     assert lib.syldet_host_alloc(16, None) == _abi.ERR_INVALID_ARGUMENT and lib.syldet_host_free(None) == 0
+
+
+def test_shift_fusion_checker_tells_shifted_additions_from_moves(tmp_path):
+    """tools/check_dpp_fusion.py (run by csrc/Makefile on kernels_bdft.hip's ISA): the block-transform kernel's sliding sums keep their
+    speed only while every lane shift is an operand of its addition."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_dpp_fusion", os.path.join(ROOT, "tools", "check_dpp_fusion.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    head = "_ZN2sd15bdft_net_kernelILi4EEEv: ; @_ZN2sd15bdft_net_kernelILi4EEEv\n"
+    fused = tmp_path / "fused.s"
+    fused.write_text(head + "\tv_add_f32_dpp v1, v2, v3 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n" * 200 +
+                     "\tv_mov_b32_dpp v4, v5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n" * 300 + "\ts_endpgm\n")
+    assert mod.check(str(fused))[1] == []
+    moves = tmp_path / "moves.s"
+    moves.write_text(head + "\tv_mov_b32_dpp v4, v5 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\tv_pk_add_f32 v[0:1], v[2:3], v[4:5]\n" * 200 + "\ts_endpgm\n")
+    assert len(mod.check(str(moves))[1]) == 1
