@@ -55,9 +55,15 @@ constexpr int kBlock = kBdftBlock;             // 512 threads = 8 waves, two per
 constexpr int kWaves = kBlock / 64;
 constexpr int kTile = 112;                     // rows of the column ring: timeRange - 1 carried + 96 new fit (seven row tiles of 16; not a power of two: wrap())
 #ifndef SYLDET_B_PS
-#define SYLDET_B_PS 48                        // (diagnostic builds try other strides)
+#define SYLDET_B_PS 52                        // (diagnostic builds try other strides)
 #endif
-constexpr int kPS = SYLDET_B_PS;                       // floats per row of tap products: 12 taps x 4 units (rows 48 floats apart spread four consecutive rows over all banks)
+// floats per row of tap products: 12 taps x 4 units and a slot of padding.  13 slots of 16 bytes a row: the tap stage's 16-byte
+// stores (eight consecutive lanes = eight consecutive rows at a time, 32 banks) fall on eight different slots; the evaluations'
+// 16-byte reads (sixteen lanes at a time in the hardware's own grouping, 64 banks: MI355X_MICROARCH.md, LDS) do too once the sixteen
+// evaluations of a wave are dealt to its quads in the order kEvalOrder -- with rows 12 slots apart the stores were four-way
+// conflicts (a third of the kernel's bank-conflict cycles, tools/bdft_conflicts.sh), with 13 and the plain order the reads two-way
+constexpr int kPS = SYLDET_B_PS;
+constexpr unsigned long long kEvalOrder = 0xfd57ce64b9138a20ull;       // quad q of a wave takes its evaluation (kEvalOrder >> 4 q) & 15
 __device__ __forceinline__ int wrap(int r) { return r >= kTile ? r - kTile : r; }      // (r < 2 kTile)
 constexpr int kSubs = 6;                       // sub-tiles of 16 blocks per tile
 constexpr int kNew = 16 * kSubs;               // new frames (= evaluations) per tile
@@ -189,7 +195,10 @@ bdft_net_kernel(const MlpxDesc d, const BdftDesc bd, const float *__restrict__ s
     }
 
     // ---- the fold's thread layout: block n of the sub-tile, positions m = 32 ks + 8 gf + 4 half + j (j < 4)
-    const int f_ks = wave % KS, f_half = (wave / KS) & 1;
+    // (which half of its eight positions a thread folds alternates with bit 3 of its block: an 8-byte store is served sixteen
+    // consecutive lanes at a time over 32 banks (MI355X_MICROARCH.md, LDS), and with one half per WAVE blocks n and n + 8 -- 16-byte
+    // slots 128 bytes apart -- met in the same banks: 39 % of the kernel's bank-conflict cycles, tools/bdft_conflicts.sh)
+    const int f_ks = wave % KS, f_half = ((wave / KS) ^ (n >> 3)) & 1;
     const bool folder = wave < 2 * KS;
     const int f_m = 32 * f_ks + 8 * g + 4 * f_half;
     // raw samples of one block's share: x[c + m .. c + m + 3], x[c - m - 4 .. c - m - 1], x[c - m], and the block's first sample
@@ -202,7 +211,7 @@ bdft_net_kernel(const MlpxDesc d, const BdftDesc bd, const float *__restrict__ s
         r.p = as_floatx4(__builtin_amdgcn_raw_buffer_load_b128(in_rs, ok ? o + (unsigned)f_m * 4u : 0xFFFFFFF0u, 0, 0));
         r.q = as_floatx4(__builtin_amdgcn_raw_buffer_load_b128(in_rs, ok ? o - (unsigned)(f_m + 4) * 4u : 0xFFFFFFF0u, 0, 0));
         r.z = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(in_rs, ok ? o - (unsigned)f_m * 4u : 0xFFFFFFF0u, 0, 0));
-        r.x0 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(in_rs, (ok && wave == 0) ? (unsigned)base * 4u : 0xFFFFFFF0u, 0, 0));
+        r.x0 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(in_rs, (ok && (wave == 0 || f_m == 0)) ? (unsigned)base * 4u : 0xFFFFFFF0u, 0, 0));   // (wave 0: the block's record; f_m == 0: slot 0 of the differences)
         return r;
     };
     auto raw_max = [&](const Raw &r, unsigned *slot) {               // this thread's share of its block's loudest sample
@@ -539,7 +548,7 @@ bdft_net_kernel(const MlpxDesc d, const BdftDesc bd, const float *__restrict__ s
         // (tried: on the first-half waves alone, which reach the barrier with time to spare -- the waits even out, 685 / 198 -> 620 / 665
         // clocks an iteration, and the kernel is 0.5 % slower: MEASUREMENTS R5.4)
         if (tid < 4 * kNew) {
-            const int r = tid >> 2, j = tid & 3;
+            const int r = (tid >> 6) * 16 + (int)((kEvalOrder >> (((tid >> 2) & 15) * 4)) & 15ull), j = tid & 3;
             floatx4 z = {0.f, 0.f, 0.f, 0.f};
             float ssw = 0.0f;
 #pragma unroll
