@@ -1046,8 +1046,9 @@ def test_hops_that_are_multiples_of_64_on_the_fold_kernel(oracle_lib, W, hop, H)
             util.assert_flags_exact(fl[c], w64, cfg.thresholds, cfg.rule)
 
 
+@pytest.mark.parametrize("N,hop", [(1024, 256), (512, 256), (512, 128)])
 @pytest.mark.parametrize("T", [1, 2, 12])
-def test_block_transform_kernel_at_its_tile_boundaries(oracle_lib, T):
+def test_block_transform_kernel_at_its_tile_boundaries(oracle_lib, T, N, hop):
     """kernels_bdft.hip ends a tile of 96 evaluations inside the next one (the last sub-tile's columns, then the tap products of the
     tile's new rows, then the evaluations, in the next tile's first three iterations) and the run's last tile after a drain
     iteration: recordings of one channel whose evaluation counts sit on and around every boundary of that schedule -- one
@@ -1055,8 +1056,7 @@ def test_block_transform_kernel_at_its_tile_boundaries(oracle_lib, T):
     longest window of columns the kernel takes (timeRange 1, 2, 12: 0, 1 and 11 carried rows)."""
     torch = _torch()
     from syllable_detector_swift_amd.config import SyllableDetectorConfig, frequencyIndexRange
-    N, hop = 1024, 256
-    rng = np.random.default_rng(40 + T)
+    rng = np.random.default_rng(40 + T)               # (frames of four blocks at two block lengths, and of two blocks)
     f0, f1 = frequencyIndexRange(N, 44100.0, 1500.0, 6500.0)
     net = nets.random_net(rng, (f1 - f0) * T, (4,), 1, in_fns=("l2normalize", "mapminmax"), out_fns=("mapminmax",))
     cfg = SyllableDetectorConfig(44100.0, N, N, N - hop, (1500.0, 6500.0), T, "linear", [0.4], net, window=_abi.WINDOW_HANNING)
