@@ -30,8 +30,12 @@
 //                            |  the lane groups' edge bins of sub-tile u -> LDS
 //                            |  window taps, |X|, f16 hi + lo columns of sub-tile u-1 (its neighbours' edge bins arrived with the barrier)
 //                            |  block maxima of sub-tile u+2 (LDS atomic max)
-// Six sub-tiles (96 new frames) make a tile; then kernels_fft1k.hip's back half: all taps of the first layer as the rows of one
-// GEMM over the tile's columns, one thread per evaluation for the rest of the network, the last timeRange - 1 columns carried.
+// Six sub-tiles (96 new frames) make a tile; its end is kernels_fft1k.hip's back half: all taps of the first layer as the rows of one
+// GEMM over the tile's new columns, four threads per evaluation for the rest of the network, the last timeRange - 1 columns carried
+// in a ring of 112 column rows.  Since round 5 the stream of sub-tiles does not stop for it: tile N's last columns are finished in
+// tile N + 1's first iteration, its tap products made in the second, its evaluations in the third (stage_taps, stage_evaluate).
+// What the ISA must look like for the speed measured (MEASUREMENTS R5.4): built without the SLP vectoriser, the sliding
+// sums' lane shifts inside their additions (tools/check_dpp_fusion.py checks it at build time).
 //
 // gfx950 only.  wave = 64.
 
