@@ -263,14 +263,19 @@ def side_record(workload, local_rank, steps=10, warmup=2, verify=True, preroll_s
             f_frame = 2 * L[0].inputs * L[0].outputs + 2 * L[0].outputs * L[1].outputs
             wk = next(k for k in means if k.startswith("wide_gemm"))          # wide_gemm16_kernel, or wide_gemm_kernel under SYLDET_WIDE_SHAPE32
             tf = C * E * f_frame / (means[wk] * 1e-3) / 1e12
+            tf_step = C * E * f_frame / (elapsed / steps) / 1e12        # end to end: the spectrogram front's launch is inside the step
             rec["roofline"] = {"bound": "mfma", "kernel": wk, "kernel_ms": means[wk], "achieved": tf,
-                               "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_BF16_PEAK_TFLOPS, "all_kernels_ms": means}
+                               "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_BF16_PEAK_TFLOPS,
+                               "frac_end_to_end": tf_step / MFMA_BF16_PEAK_TFLOPS, "achieved_end_to_end": tf_step,
+                               "note": "frac: the GEMM kernel's launch from its HIP events; frac_end_to_end: the same flops over the whole step (spectrogram front + GEMM)",
+                               "all_kernels_ms": means}
         else:
             dom = max((k for k in means if k != "fixup_kernel"), key=means.get)
             b_frame = 4 * g.hop + 4 * g.outputs + 1
             gbs = C * J * b_frame / (means[dom] * 1e-3) / 1e9
+            gbs_step = C * J * b_frame / (elapsed / steps) / 1e9
             rec["roofline"] = {"bound": "hbm", "kernel": dom, "kernel_ms": means[dom], "achieved": gbs, "peak": HBM_PEAK_GBS,
-                               "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "all_kernels_ms": means}
+                               "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "frac_by_step": gbs_step / HBM_PEAK_GBS, "all_kernels_ms": means}
         wk_or_dom = rec["roofline"]["kernel"]
         rec["roofline"]["kernel_ms_per_step"] = [round(v, 4) for v in reversed(kernel_ms[wk_or_dom])]   # (in launch order)
         try:
@@ -283,7 +288,15 @@ def side_record(workload, local_rank, steps=10, warmup=2, verify=True, preroll_s
                 v = spotcheck.check(det, cfg, x, outputs, flags, sorted({0, max(C // 2 - 1, 0), C - 1}),
                                     width=160 if workload != "config3" else 64, tol=1e-2 if engine == 3 else 1e-5)
                 rec["verified"] = True
-                rec["verify"] = {k: v[k] for k in ("evaluations_checked", "max_error", "tolerance")}
+                rec["verify"] = {k: v[k] for k in ("evaluations_checked", "detections", "max_error", "tolerance")}
+                # once more on planted syllables (an extra launch after the timed region): flags that fire, compared exactly
+                chs = sorted({0, max(C // 2 - 1, 0), C - 1})
+                if workload == "hop128" and spotcheck.plant(det, cfg, x, chs):
+                    det.run(x, outputs, flags)
+                    torch.cuda.synchronize()
+                    v = spotcheck.check(det, cfg, x, outputs, flags, chs, tol=1e-5)
+                    rec["verify_planted"] = {k: v[k] for k in ("evaluations_checked", "detections", "max_error", "tolerance")}
+                    rec["verified"] = bool(v["detections"] > 0)
             except AssertionError as e:
                 rec["verified"] = False
                 rec["verify"] = {"error": str(e)[:300]}
@@ -392,17 +405,41 @@ def host_record(cfg, det_engine, local_rank, x):
     return rec
 
 
-def single_process(args):
-    """All N GPUs from ONE process through the sharded bank (BASELINE configs[3]'s shape per GPU; weak scaling)."""
+def open_sharded_bank(cfg, total, devices, engine):
+    """The one-process bank under the RCCL exchange, its communicators brought up NOW (syldet_sharded_connect) so that a host whose
+    RCCL does not come up is known before anything is timed; on an error the bank is made again IN THIS PROCESS with the copy
+    exchange (hipMemcpyPeerAsync, no RCCL) and the line says so.  A process that has touched the GPU is never re-executed."""
+    from syllable_detector_swift_amd import _abi
+    from syllable_detector_swift_amd.bank import ShardedSyllableDetectorBank
+    info = {"exchange": None, "rccl_error": None}
+    bank = ShardedSyllableDetectorBank(cfg, total, devices, engine=engine)
+    try:
+        bank.connect()
+    except Exception as e:
+        info["rccl_error"] = "%s: %s" % (type(e).__name__, str(e)[:300])
+        bank.close()
+        bank = ShardedSyllableDetectorBank(cfg, total, devices, engine=engine, exchange=_abi.EXCHANGE_PEER_COPY)
+        bank.connect()
+    info["exchange"] = "rccl" if bank.rcclRanks > 0 else "peer_copy"
+    return bank, info
+
+
+def single_process(args, devices=None, emit=True, tag="BASELINE configs[3]"):
+    """All N GPUs from ONE process through the sharded bank (BASELINE configs[3]'s shape per GPU; weak scaling).  `devices`: the
+    HIP device of every shard (default 0 .. N-1; a device listed several times rehearses the whole branch on one GPU, with the copy
+    exchange -- RCCL refuses duplicates)."""
     import numpy as np
     import torch
     import syllable_detector_swift_amd as sd
-    from syllable_detector_swift_amd import nets, synth
+    from syllable_detector_swift_amd import _abi, nets, synth
     from syllable_detector_swift_amd.bank import ShardedSyllableDetectorBank
-    N = args.gpus
-    sys.stdout.flush()
-    json_fd = os.dup(1)
-    os.dup2(2, 1)
+    devices = list(devices) if devices is not None else list(range(args.gpus))
+    N = len(devices)
+    json_fd = None
+    if emit:
+        sys.stdout.flush()
+        json_fd = os.dup(1)
+        os.dup2(2, 1)
     cfg = nets.from_npz()
     if args.overlap is not None:
         cfg = nets.variant(cfg, windowOverlap=args.overlap)
@@ -410,40 +447,72 @@ def single_process(args):
     S = 1 << (args.log2_samples or 21)
     total = args.total_channels if args.total_channels is not None else N * Cg
     scaling = "strong" if args.total_channels is not None else "weak"
-    devices = list(range(N))
-    bank = ShardedSyllableDetectorBank(cfg, total, devices, engine=args.engine)
+    preroll = args.preroll if args.preroll is not None else 150
+
+    def build(bank):
+        g = bank.geometry
+        E = bank.countEvaluations(S)
+        blocks, outs, fls, fls_b, alls = [], [], [], [], []
+        for i, sh in enumerate(bank.shards):
+            dev = torch.device("cuda", sh.device)
+            blocks.append(synth.channels_on_device(sh.channels, S, dev, first=sh.first_channel, fs=cfg.samplingRate))
+            outs.append(torch.empty((sh.channels, E, g.outputs), dtype=torch.float32, device=dev))
+            fls.append(torch.empty((sh.channels, E), dtype=torch.uint8, device=dev))
+            fls_b.append(torch.empty((sh.channels, E), dtype=torch.uint8, device=dev))
+            alls.append(torch.empty((total, E), dtype=torch.uint8, device=dev))
+        # The bank's streams are its own (non-blocking): they do not wait for torch's stream, on which the audio above is still
+        # being generated -- and the result tensors just handed out may be the generator's freed temporaries (torch's allocator
+        # reuses them in ITS stream's order).  Everything torch queued finishes before the bank's first kernel is queued.
+        for d in sorted(set(devices)):
+            torch.cuda.synchronize(d)
+        # every shard's own flags land in one of two tensors in turn: a batch's flags are packed on the exchange stream while the
+        # next batch's kernel runs, and a kernel that writes the tensor still being packed from would have to wait for that (the
+        # library checks).  Two prepared calls (arguments checked once; a call is then the ABI call alone).
+        calls = (bank.prepare(blocks, S, outs, fls, alls), bank.prepare(blocks, S, outs, fls_b, alls))
+        calls[1]()
+        calls[0]()                                                   # the first gathering batches: buffers, and under RCCL the first collective
+        bank.synchronize()
+        return blocks, outs, fls, fls_b, alls, calls
+
+    bank, xinfo = open_sharded_bank(cfg, total, devices, args.engine)
+    try:
+        blocks, outs, fls, fls_b, alls, calls = build(bank)
+    except Exception as e:
+        if bank.rcclRanks == 0:
+            raise
+        # the communicators came up but the first collective did not go through: the copy exchange, in this same process
+        xinfo["rccl_error"] = "first batch: %s: %s" % (type(e).__name__, str(e)[:300])
+        bank.close()
+        torch.cuda.empty_cache()
+        bank = ShardedSyllableDetectorBank(cfg, total, devices, engine=args.engine, exchange=_abi.EXCHANGE_PEER_COPY)
+        bank.connect()
+        xinfo["exchange"] = "peer_copy"
+        blocks, outs, fls, fls_b, alls, calls = build(bank)
     g = bank.geometry
     J, E = bank.countFrames(S), bank.countEvaluations(S)
-    blocks, outs, fls, fls_b, alls = [], [], [], [], []
-    for i, sh in enumerate(bank.shards):
-        dev = torch.device("cuda", sh.device)
-        blocks.append(synth.channels_on_device(sh.channels, S, dev, first=sh.first_channel, fs=cfg.samplingRate))
-        outs.append(torch.empty((sh.channels, E, g.outputs), dtype=torch.float32, device=dev))
-        fls.append(torch.empty((sh.channels, E), dtype=torch.uint8, device=dev))
-        fls_b.append(torch.empty((sh.channels, E), dtype=torch.uint8, device=dev))
-        alls.append(torch.empty((total, E), dtype=torch.uint8, device=dev))
     dets = [sd.SyllableDetector.borrowed(bank, i) for i in range(N)]
     for d in dets:
         d.profile(True, history=max(args.steps, 1))
 
-    # every shard's own flags land in one of two tensors in turn: a batch's flags are packed on the exchange stream while the next
-    # batch's kernel runs, and a kernel that writes the tensor still being packed from would have to wait for that (the library
-    # checks).  The last step's (the one verified below) are in `fls`.
-    preroll = args.preroll if args.preroll is not None else 150
     left = [preroll + args.warmup + args.steps]                   # steps still to come: the last one (0 left after it) writes `fls`
+    host_s = []
 
     def step():
         left[0] -= 1
-        bank.run(blocks, S, gather=True, outputs=outs, flags=fls if left[0] % 2 == 0 else fls_b, flags_all=alls)
+        t = time.perf_counter()
+        calls[0 if left[0] % 2 == 0 else 1]()
+        host_s.append(time.perf_counter() - t)
 
     for _ in range(preroll + args.warmup):
         step()
     bank.synchronize()
+    del host_s[:]
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     bank.synchronize()
     elapsed = time.perf_counter() - t0
+    host_ms = sorted(1e3 * v for v in host_s)
     b_frame = 4 * g.hop + 4 * g.outputs + 1
     per_dev = []
     for d in dets:
@@ -452,36 +521,53 @@ def single_process(args):
             for nm, ms in d.timingsOf(back):
                 km.setdefault(nm, []).append(ms)
         per_dev.append({k: sum(v) / len(v) for k, v in km.items()})
-    dom = max(per_dev[0], key=per_dev[0].get)
+    dom = max((k for k in per_dev[0] if k != "fixup_kernel"), key=per_dev[0].get)
     worst_ms = max(m[dom] for m in per_dev)
+    fix = [d.fixupStats() for d in dets]
     C0 = bank.shards[0].channels
-    achieved = C0 * J * b_frame / (per_dev[0][dom] * 1e-3) / 1e9
+    Cmax = max(sh.channels for sh in bank.shards)
+    step_ms = 1e3 * elapsed / args.steps
+    by_events = C0 * J * b_frame / (per_dev[0][dom] * 1e-3) / 1e9
+    by_step = Cmax * J * b_frame / (step_ms * 1e-3) / 1e9          # per device: the longest shard's bytes over the whole job's step
     value = total * J * args.steps / elapsed
-    line = {"metric": "audio frames/sec (256-pt STFT + 2-layer MLP), whole job", "value": value, "unit": "frames/s", "n_gpus": N,
-            "steps": args.steps, "warmup": args.warmup, "preroll_steps": preroll, "ms_per_step": 1e3 * elapsed / args.steps,
+    distinct = len(set(devices))
+    line = {"metric": "audio frames/sec (256-pt STFT + 2-layer MLP), whole job", "value": value, "unit": "frames/s", "n_gpus": distinct,
+            "steps": args.steps, "warmup": args.warmup, "preroll_steps": preroll, "ms_per_step": step_ms,
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f32 (I/O and accumulate; products as f16 hi/lo split x3 on MFMA)" if g.engine == 2 else "f32", "data": "synthetic",
-            "per_gpu": value / N, "launcher": "single-process",
-            "config": {"workload": "BASELINE configs[3]: sample.txt network, %d channels sharded across %d MI355X (%d x 2^%d samples per GPU), RCCL gather of detection flags"
-                                   % (total, N, Cg, S.bit_length() - 1),
+            "per_gpu": value / distinct, "launcher": "single-process", "shards": N, "devices": devices,
+            "config": {"workload": "%s: sample.txt network, %d channels sharded across %d MI355X (%d x 2^%d samples per shard), %s of detection flags"
+                                   % (tag, total, distinct, Cg, S.bit_length() - 1, "RCCL gather" if xinfo["exchange"] == "rccl" else "peer-copy gather"),
                        "channels_per_gpu": [sh.channels for sh in bank.shards], "total_channels": total, "samples_per_channel": S, "frames_per_channel": J,
                        "evaluations_per_channel": E, "fourier_length": cfg.fourierLength, "hop": g.hop, "bins": [g.f0, g.f1], "time_range": cfg.timeRange,
                        "engine": {1: "generic", 2: "fused", 3: "wide_bf16"}.get(g.engine, str(g.engine)),
-                       "sharding": "one process, one handle (syldet_create_sharded): a sub-bank and a stream per device, contiguous channel blocks, no data-path "
-                                   "collective; one ncclAllGather of the bit-packed flags per step inside the library's own RCCL group (ncclCommInitAll)"},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                       "sharding": "one process, one handle (syldet_create_sharded): a sub-bank, two streams and a launcher thread per device, contiguous channel "
+                                   "blocks, no data-path collective; one all-gather of the bit-packed flags per step (ncclAllGather inside the library's own "
+                                   "RCCL group, ncclCommInitAll; hipMemcpyPeerAsync under the copy exchange)"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": by_step, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by_step / HBM_PEAK_GBS,
+                         "achieved_kernel_events": by_events, "frac_kernel_events": by_events / HBM_PEAK_GBS,
                          "traffic": None, "traffic_source": None, "algorithmic_bytes_per_launch": C0 * J * b_frame, "algorithmic_bytes_per_frame": b_frame,
                          "kernel_ms": per_dev[0], "kernel_ms_per_device": [m[dom] for m in per_dev], "slowest_device_kernel_ms": worst_ms,
-                         "note": "per device: device 0's launch"},
-            "rccl_ranks": bank.rcclRanks, "gathered_flags_shape": [total, E],
-            "gathered_bytes_per_rank_per_step": max(sh.channels for sh in bank.shards) * ((E + 7) // 8)}
+                         "note": "per device; frac: the longest shard's algorithmic bytes over the job's step time; frac_kernel_events: device 0's launch from its HIP events"},
+            "exchange": xinfo["exchange"], "rccl_error": xinfo["rccl_error"], "rccl_ranks": bank.rcclRanks, "launcher_threads": bank.launcherThreads,
+            "host_enqueue_ms": {"median": host_ms[len(host_ms) // 2], "p90": host_ms[int(0.9 * (len(host_ms) - 1))], "max": host_ms[-1],
+                                "note": "wall time of the one call that queues a batch on every shard (the kernel takes ~0.9 ms)"},
+            "gathered_flags_shape": [total, E],
+            "gathered_bytes_per_rank_per_step": Cmax * ((E + 7) // 8),
+            "fixups": {"work_items_last_step_per_shard": [int(f[0]) for f in fix], "overflow": int(max(f[1] for f in fix)),
+                       "note": "16-evaluation items the precision guard sent to the exact fp64 recomputation (0 for ordinary audio)"}}
     if not args.no_verify:
         # every device holds every channel's flags: all copies equal device 0's, whose own rows equal its local flags; and the
-        # last step's outputs of the first and last shard against the oracle
+        # last step's outputs of the first and last shard against the oracle -- then once more on planted syllables (an extra,
+        # untimed step), so that the flags compared are not all zero
         import spotcheck
-        same = all(bool(torch.equal(alls[i].cpu(), alls[0].cpu())) for i in range(1, N))
-        own = all(bool(torch.equal(alls[i][sh.first_channel: sh.first_channel + sh.channels], fls[i])) for i, sh in enumerate(bank.shards))
-        line["gathered_flags_identical_on_every_device"] = bool(same and own)
+
+        def gathered_ok():
+            same = all(bool(torch.equal(alls[i].cpu(), alls[0].cpu())) for i in range(1, N))
+            own = all(bool(torch.equal(alls[i][sh.first_channel: sh.first_channel + sh.channels], fls[i])) for i, sh in enumerate(bank.shards))
+            return bool(same and own)
+        ok = gathered_ok()
+        line["gathered_flags_identical_on_every_device"] = ok
         try:
             checks = {}
             for i in sorted({0, N - 1}):
@@ -489,13 +575,36 @@ def single_process(args):
                 torch.cuda.set_device(sh.device)
                 checks["shard%d" % i] = spotcheck.check(dets[i], cfg, blocks[i], outs[i], fls[i], sorted({0, sh.channels - 1}), tol=1e-5)
             line["verify"] = checks
-            line["verified"] = bool(same and own)
+            planted = 0
+            for i in sorted({0, N - 1}):
+                planted += spotcheck.plant(dets[i], cfg, blocks[i], sorted({0, bank.shards[i].channels - 1}))
+            if planted:
+                calls[0]()
+                bank.synchronize()
+                ok2 = gathered_ok()
+                pchecks = {"gathered_flags_identical_on_every_device": ok2}
+                for i in sorted({0, N - 1}):
+                    sh = bank.shards[i]
+                    torch.cuda.set_device(sh.device)
+                    pchecks["shard%d" % i] = spotcheck.check(dets[i], cfg, blocks[i], outs[i], fls[i], sorted({0, sh.channels - 1}), tol=1e-5)
+                pchecks["detections"] = sum(v["detections"] for k, v in pchecks.items() if k.startswith("shard"))
+                line["verify_planted"] = pchecks
+                ok = ok and ok2 and pchecks["detections"] > 0
+            line["verified"] = bool(ok)
         except AssertionError as e:
             line["verified"] = False
             line["verify"] = {"error": str(e)[:400]}
-    sys.stdout.flush()
-    os.write(json_fd, (json.dumps(line) + "\n").encode())
+    line["summary"] = {"frac_by_step": line["roofline"]["frac"], "frac_by_kernel_events": line["roofline"]["frac_kernel_events"],
+                       "n_gpus": distinct, "shards": N, "exchange": xinfo["exchange"], "rccl_ranks": bank.rcclRanks,
+                       "host_enqueue_ms_median": line["host_enqueue_ms"]["median"], "verified": line.get("verified"),
+                       "detections_checked": line.get("verify_planted", {}).get("detections")}
     bank.close()
+    del blocks, outs, fls, fls_b, alls, calls
+    torch.cuda.empty_cache()
+    if emit:
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
+    return line
 
 
 def main():
@@ -517,16 +626,25 @@ def main():
     ap.add_argument("--force-gather", action="store_true", help="run the flag exchange even with one rank (rehearsal of the multi-GPU step)")
     ap.add_argument("--single-process", action="store_true",
                     help="drive all --gpus devices from this one process through the library's sharded bank (the default when --gpus > 1 and no torch.distributed launcher set WORLD_SIZE)")
+    ap.add_argument("--devices", default=None,
+                    help="single-process form: the HIP device of every shard, e.g. 0,1,2,3; a device listed several times (0,0,0,0,0,0,0,0) rehearses the "
+                         "whole N > 1 branch on one GPU with the copy exchange")
     args = ap.parse_args()
+    if args.devices is not None:
+        devs = [int(v) for v in args.devices.split(",") if v.strip() != ""]
+        args.gpus = len(devs)
+        single_process(args, devices=devs)
+        return
     if args.single_process or (args.gpus > 1 and "WORLD_SIZE" not in os.environ):
-        return single_process(args)
+        single_process(args)
+        return
 
     import numpy as np
     import torch
     import torch.distributed as dist
     import syllable_detector_swift_amd as sd
     from syllable_detector_swift_amd import nets, synth
-    from syllable_detector_swift_amd.dist import PipelinedFlagGather, gather_flags, shard_channels
+    from syllable_detector_swift_amd.dist import HostFlagGather, PipelinedFlagGather, gather_flags, shard_channels
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -537,17 +655,47 @@ def main():
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
+    # one rank per GPU: LOCAL_RANK's device (modulo the devices this process sees: two ranks on a one-GPU box rehearse the whole
+    # branch -- RCCL refuses two ranks on one device, which is exactly the failure the fallback below is for)
+    local_dev = local_rank % max(torch.cuda.device_count(), 1)
+    nccl_group, xinfo = None, {"exchange": None, "rccl_error": None}
     if exchange:
-        torch.cuda.set_device(local_rank)
-        if world == 1:                                   # rehearsal: a one-rank RCCL group
+        torch.cuda.set_device(local_dev)
+        # The job's control plane is a gloo group (rendezvous, barriers, the reductions of the timing): it comes up wherever TCP to
+        # 127.0.0.1 does.  RCCL carries the one data exchange, on a group of its own -- brought up and PROBED here, before anything is
+        # timed, and every rank learns over gloo whether every rank's probe went through: either all ranks exchange over RCCL or all
+        # fall back to the host-staged gloo gather (dist.HostFlagGather), in this same process, and the line says which.
+        if world == 1:                                   # rehearsal: one rank
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29593")
-            dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+            dist.init_process_group(backend="gloo", rank=0, world_size=1)
         else:
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group(backend="gloo")
+        ok = 1
+        try:
+            if os.environ.get("SYLDET_BENCH_NO_RCCL"):                 # (test hook: the fallback on a box where RCCL works)
+                raise RuntimeError("SYLDET_BENCH_NO_RCCL is set")
+            nccl_group = dist.new_group(backend="nccl")
+            probe = torch.zeros((world, 8), dtype=torch.uint8, device=torch.device("cuda", local_dev))
+            mine = torch.full((8,), rank + 1, dtype=torch.uint8, device=torch.device("cuda", local_dev))
+            dist.all_gather_into_tensor(probe, mine, group=nccl_group)
+            torch.cuda.synchronize()
+            if probe.cpu().tolist() != [[r + 1] * 8 for r in range(world)]:
+                raise RuntimeError("the probe all-gather returned wrong rows")
+        except Exception as e:
+            ok = 0
+            xinfo["rccl_error"] = "%s: %s" % (type(e).__name__, str(e)[:300])
+        agreed = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
+        if int(agreed.item()) == 0:
+            nccl_group = None
+            if xinfo["rccl_error"] is None:
+                xinfo["rccl_error"] = "another rank's RCCL probe failed"
+        xinfo["exchange"] = "rccl" if nccl_group is not None else "gloo_host"
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", local_dev)
     torch.cuda.set_device(dev)
+    local_rank = local_dev                               # (every later use is "this rank's device")
 
     multi = exchange                                     # the multi-GPU step (or its one-rank rehearsal): configs[3]'s shape
     if args.workload == "config3":
@@ -589,7 +737,9 @@ def main():
     # ONE collective per batch: [total, E] u8 flags on every rank, as bits; with equal shards the exchange of batch i runs on
     # a side stream under the kernel of batch i+1 (the timed region ends with every exchange finished: synchronize below)
     equal = total == world * C
-    gather = PipelinedFlagGather(C, E, total, dev) if (exchange and equal) else None
+    gather = None
+    if exchange and equal:
+        gather = PipelinedFlagGather(C, E, total, dev, group=nccl_group) if nccl_group is not None else HostFlagGather(C, E, total, dev)
     gathered = None
 
     # (with the pipelined exchange the flags land in two tensors in turn: a batch's flags are packed on the side stream while the
@@ -608,7 +758,8 @@ def main():
             return
         det.run(x, outputs, flags)
         if exchange:
-            gathered = gather_flags(flags, total)        # ragged shards: the padded form, on the compute stream
+            # ragged shards: the padded form, on the compute stream (through the host when RCCL did not come up)
+            gathered = gather_flags(flags, total, group=nccl_group) if nccl_group is not None else gather_flags(flags.cpu(), total, packed=False).to(dev)
 
     # From an idle device the clock governor takes 30-50 ms of back-to-back launches to reach the state it then holds for
     # seconds (tools/ramp_probe.py, profiles/r03_clock_ramp.txt: 1.42, 1.17, 1.04, 0.977 ms a launch over the first 50 launches of
@@ -660,9 +811,9 @@ def main():
     for back in range(args.steps):                       # the timed steps' kernels, from their events
         for nm, ms in det.timingsOf(back):
             kernel_ms.setdefault(nm, []).append(ms)
-    frames_local = torch.tensor([float(C * J)], dtype=torch.float64, device=dev)
+    frames_local = torch.tensor([float(C * J)], dtype=torch.float64)       # (host tensors: the control plane is the gloo group)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         dist.all_reduce(frames_local, op=dist.ReduceOp.SUM)
@@ -677,7 +828,10 @@ def main():
         dom = max(means, key=means.get)
         # the dominant kernel's launch covers C*J frames of this rank; when the path is split over
         # several kernels each is charged the whole frame's algorithmic bytes (none moves fewer)
-        achieved = C * J * b_frame / (means[dom] * 1e-3) / 1e9
+        achieved_events = C * J * b_frame / (means[dom] * 1e-3) / 1e9
+        # (the line's `frac` is the conservative one: the same bytes over the STEP time the line reports -- launch gaps and the small
+        # kernels behind the dominant one included; the dominant kernel's own launch, from its HIP events, beside it)
+        achieved = C * J * b_frame / (elapsed / args.steps) / 1e9
         traffic, traffic_source = measured_traffic(C, S, g.hop, {1: "generic", 2: "fused"}.get(g.engine, ""), dom)
         engine_name = {1: "generic", 2: "fused", 3: "wide_bf16"}.get(g.engine, str(g.engine))
         line = {
@@ -698,7 +852,9 @@ def main():
                        "sharding": ("contiguous channel blocks, %d on this rank of %d; no data-path collective; one all-gather of flags (as bits) per step%s"
                                     % (C, total, ", on a side stream under the next step's kernel" if gather is not None else "")) if exchange else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         "frac": achieved / HBM_PEAK_GBS, "achieved_kernel_events": achieved_events, "frac_kernel_events": achieved_events / HBM_PEAK_GBS,
+                         "frac_is": "algorithmic bytes per launch / ms_per_step (the step the driver times); frac_kernel_events: / the dominant kernel's mean HIP-event duration over the same K launches",
+                         "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": C * J * b_frame,
                          "algorithmic_bytes_per_frame": b_frame, "kernel_ms": means},
             "fixups": {"work_items_last_step": fixups, "overflow": fix_overflow,
@@ -708,12 +864,18 @@ def main():
             idle_elapsed, idle_means = from_idle
             idom = max(idle_means, key=idle_means.get)
             line["from_idle"] = {"ms_per_step": 1e3 * idle_elapsed / args.steps, "kernel": idom, "kernel_ms": idle_means[idom],
-                                 "frac": C * J * b_frame / (idle_means[idom] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                 "frac": C * J * b_frame / (idle_elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
+                                 "frac_kernel_events": C * J * b_frame / (idle_means[idom] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                  "value_local": C * J * args.steps / idle_elapsed,
-                                 "note": "the same K steps timed first, after W warmup launches on an idle device and before the pre-roll (rank 0's clock)"}
+                                 "note": "the same K steps timed first, after W warmup launches on an idle device and before the pre-roll (rank 0's clock): what a job of a few dozen launches sees"}
+            if g.engine != 3:
+                line["roofline"]["from_idle_frac"] = line["from_idle"]["frac"]            # (inside the object the driver keeps)
+                line["roofline"]["from_idle_frac_kernel_events"] = line["from_idle"]["frac_kernel_events"]
         if exchange:
             line["launcher"] = "torch.distributed.run, one process per GPU"
-            line["rccl_ranks"] = dist.get_world_size()
+            line["rccl_ranks"] = dist.get_world_size() if nccl_group is not None else 0
+            line["exchange"], line["rccl_error"] = xinfo["exchange"], xinfo["rccl_error"]
+            line["control_plane"] = "gloo (rendezvous, barriers, timing reductions); the flags' all-gather alone is on RCCL"
             line["gathered_flags_shape"] = [total, E]
             line["gathered_bytes_per_rank_per_step"] = C * ((E + 7) // 8) if gather is not None else C * E
         if g.engine == 3:
@@ -723,8 +885,11 @@ def main():
             wk = next(k for k in means if k.startswith("wide_gemm"))
             tf = C * E * f_frame / (means[wk] * 1e-3) / 1e12
             line["dtype"] = "bf16"
-            line["roofline"] = {"bound": "mfma", "kernel": wk, "achieved": tf, "peak": MFMA_BF16_PEAK_TFLOPS,
-                                "unit": "TFLOP/s", "frac": tf / MFMA_BF16_PEAK_TFLOPS, "traffic": None, "traffic_source": None,
+            tf_step = C * E * f_frame / (elapsed / args.steps) / 1e12
+            line["roofline"] = {"bound": "mfma", "kernel": wk, "achieved": tf_step, "peak": MFMA_BF16_PEAK_TFLOPS,
+                                "unit": "TFLOP/s", "frac": tf_step / MFMA_BF16_PEAK_TFLOPS, "achieved_kernel_events": tf, "frac_kernel_events": tf / MFMA_BF16_PEAK_TFLOPS,
+                                "frac_is": "flops per step / ms_per_step (spectrogram front + GEMM: end to end); frac_kernel_events: / the GEMM kernel's own HIP-event duration",
+                                "traffic": None, "traffic_source": None,
                                 "algorithmic_flops_per_launch": C * E * f_frame, "algorithmic_flops_per_frame": f_frame, "kernel_ms": means}
         if world == 1:
             # what binds the dominant kernel, beside the contract's yardstick (after the timed region: the probe loops the step for a second)
@@ -737,8 +902,8 @@ def main():
             # the bf16 engine at its own, separately stated bar
             import spotcheck
             try:
-                line["verify"] = spotcheck.check(det, cfg, x, outputs, flags, sorted({0, max(C // 2 - 1, 0), C - 1}),
-                                                 tol=1e-2 if g.engine == 3 else 1e-5)
+                chs = sorted({0, max(C // 2 - 1, 0), C - 1})
+                line["verify"] = spotcheck.check(det, cfg, x, outputs, flags, chs, tol=1e-2 if g.engine == 3 else 1e-5)
                 line["verified"] = True
             except AssertionError as e:
                 line["verified"] = False
@@ -759,6 +924,21 @@ def main():
             ncpu = os.cpu_count() or 1
             if ncpu > 1:                                      # also channels spread over all host cores
                 line["cpu_baseline_all_cores"] = cpu_baseline(cfg, host, threads=ncpu)
+        if not args.no_verify and line.get("verified") and g.engine != 3:
+            # The benchmark's audio never fires the sample network (its flags are all zero): template syllables are written over the
+            # checked stretches AFTER the timed region (and after the CPU legs, which read the same tensor), one more (untimed)
+            # launch of this rank's kernel alone -- no exchange -- and the same check again: flags that fire, bit for bit
+            import spotcheck
+            try:
+                chs = sorted({0, max(C // 2 - 1, 0), C - 1})
+                if spotcheck.plant(det, cfg, x, chs):
+                    det.run(x, outputs, flags)
+                    torch.cuda.synchronize()
+                    line["verify_planted"] = spotcheck.check(det, cfg, x, outputs, flags, chs, tol=1e-5)
+                    line["verified"] = bool(line["verify_planted"]["detections"] > 0)
+            except AssertionError as e:
+                line["verified"] = False
+                line["verify_planted"] = {"error": str(e)[:400]}
         if world == 1 and not args.no_also and args.workload == "sample" and args.engine == 0 and args.overlap is None \
                 and args.channels is None and args.log2_samples is None and not exchange:
             # the other single-GPU BASELINE workloads and the guard's worst ordinary case, in the same process and on the same
@@ -778,6 +958,37 @@ def main():
                 line["also"]["live"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
             if "roofline" in line["also"].get("clicks", {}):
                 line["also"]["clicks"]["slowdown_vs_headline"] = line["also"]["clicks"]["ms_per_step"] / line["ms_per_step"]
+            # BASELINE configs[3]'s shape PER GPU (512 channels x 2^21 samples) through the one-process bank on this one device, a
+            # one-rank RCCL group carrying the exchange: the like-for-like N = 1 point of the 1 -> 8 curve (`--gpus N` runs this
+            # shape on every GPU; the headline above is configs[1]'s 64 x 2^24, whose launch differs by a few per cent)
+            try:
+                a4 = argparse.Namespace(gpus=1, steps=args.steps, warmup=args.warmup, preroll=100, channels=512, log2_samples=21,
+                                        total_channels=None, overlap=None, engine=0, no_verify=args.no_verify)
+                r4 = single_process(a4, devices=[local_rank], emit=False, tag="BASELINE configs[3]'s shard shape on one GPU")
+                line["also"]["config4_shard"] = {k: r4[k] for k in ("value", "unit", "ms_per_step", "steps", "preroll_steps", "config", "roofline", "exchange", "rccl_error",
+                                                                   "rccl_ranks", "launcher_threads", "host_enqueue_ms", "verified", "verify_planted") if k in r4}
+            except Exception as e:
+                line["also"]["config4_shard"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        # LAST key of the line (the driver's record keeps the line's tail): every fraction of the run in one small object
+        also = line.get("also", {})
+        rf = lambda wl, key="frac": also.get(wl, {}).get("roofline", {}).get(key)
+        bind = line["roofline"].get("binding", {}) if isinstance(line["roofline"].get("binding"), dict) else {}
+        looped = None
+        if bind.get("ms_per_step_looped") and g.engine != 3:
+            looped = C * J * b_frame / (bind["ms_per_step_looped"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+        line["summary"] = {"workload": args.workload, "n_gpus": world, "value": value,
+                           "frac_by_step": line["roofline"]["frac"], "frac_by_kernel_events": line["roofline"]["frac_kernel_events"],
+                           "from_idle_frac": line.get("from_idle", {}).get("frac"), "looped_frac": looped,
+                           "config3_frac": rf("config3"), "config3_frac_by_step": rf("config3", "frac_by_step"),
+                           "config5_frac": rf("config5"), "config5_frac_end_to_end": rf("config5", "frac_end_to_end"),
+                           "hop128_frac": rf("hop128"), "hop128_frac_by_step": rf("hop128", "frac_by_step"), "clicks_frac": rf("clicks"),
+                           "config4_shard_frac_by_step": rf("config4_shard"), "config4_shard_frac_by_kernel_events": rf("config4_shard", "frac_kernel_events"),
+                           "config4_shard_value": also.get("config4_shard", {}).get("value"),
+                           "verified": {k: v for k, v in [("headline", line.get("verified"))] + [(wl, r.get("verified")) for wl, r in also.items() if isinstance(r, dict) and "verified" in r]},
+                           "detections_checked": line.get("verify_planted", {}).get("detections"),
+                           "traffic_over_algorithmic": (line["roofline"]["traffic"] / line["roofline"]["algorithmic_bytes_per_launch"])
+                           if line["roofline"].get("traffic") and line["roofline"].get("algorithmic_bytes_per_launch") else None,
+                           "cpu_baseline_frames_per_s": line.get("cpu_baseline", {}).get("value")}
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     det.close()

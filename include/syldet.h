@@ -373,15 +373,29 @@ int syldet_sharded_run(syldet_sharded_t *b, const float *samples, int64_t n_samp
  * sample range (syldet_sharded_ranges) of a recording of n_samples per channel; d_outputs[i] [channels_i][count_i][outputs]
  * and d_flags[i] [channels_i][count_i] receive its own results (either array, or any entry, may be NULL);
  * d_flags_all[i], when the array is given, receives EVERY channel's flags [C][E] on device i (8-byte aligned) through the
- * one exchange.  Asynchronous: every shard's kernel is launched before the exchange is queued, and the exchange runs on
+ * one exchange.  The bank's streams are its own (hipStreamNonBlocking): work the caller has queued elsewhere that produces the
+ * samples -- or still reads memory now handed over as a result array -- must have finished (or be ordered by the caller's own
+ * events on syldet_sharded_stream) before the call.  Asynchronous: every shard's kernel is launched before the exchange is queued, and the exchange runs on
  * streams of its own (two sets of buffers in turn), so the next call's kernels start without waiting for this call's
- * collective; results are complete after syldet_sharded_synchronize (or after synchronising syldet_sharded_stream(b, i) for
+ * collective.  The queueing itself runs on the bank's launcher threads, every shard at once (syldet_sharded_launcher_threads);
+ * the call returns when every shard's work is queued.  Results are complete after syldet_sharded_synchronize (or after synchronising syldet_sharded_stream(b, i) for
  * shard i's own results, syldet_sharded_exchange_stream(b, i) for d_flags_all[i]).                                       */
 int syldet_sharded_run_device(syldet_sharded_t *b, const float *const *d_samples, int64_t n_samples, const int64_t *strides,
                               float *const *d_outputs, uint8_t *const *d_flags, uint8_t *const *d_flags_all);
 int syldet_sharded_synchronize(syldet_sharded_t *b);
 /* RCCL ranks behind the exchange (0 under SYLDET_EXCHANGE_PEER_COPY) */
 int32_t syldet_sharded_rccl_ranks(const syldet_sharded_t *b);
+/* Brings the exchange up NOW instead of inside the first gathering batch: under SYLDET_EXCHANGE_RCCL loads librccl and makes
+ * the communicators (ncclCommInitAll over the bank's devices); under the copy exchange enables peer access between the bank's
+ * devices where the hardware offers it.  A caller that wants to fall back (a host whose RCCL does not come up) calls this
+ * right after syldet_create_sharded and, on an error, destroys the bank and makes it again with SYLDET_EXCHANGE_PEER_COPY
+ * -- in the same process: nothing here needs a fresh one.                                                                   */
+int syldet_sharded_connect(syldet_sharded_t *b);
+/* Launcher threads of the bank: one per shard, alive as long as the bank, each with its shard's device current; a batch call's
+ * per-shard queueing (kernel, packing, the exchange's waits and records, unpacking) runs on all of them at once.  0 for a bank
+ * of one shard and for banks made under SYLDET_SHARDED_INLINE=1, whose calls queue shard after shard on the caller's thread
+ * (the reference's own shape: one serial queue, Processor.swift:82).                                                         */
+int32_t syldet_sharded_launcher_threads(const syldet_sharded_t *b);
 
 /* ResamplerLinear, Common/Resampler.swift:20-76 (used when the device rate differs from the
  * network's: Processor.swift:116-121, ViewControllerProcessor.swift:247-250), for n_channels

@@ -155,6 +155,8 @@ SIGNATURES = {
     "syldet_sharded_run_device": (C.c_int, [Handle, c_void_pp, C.c_int64, c_int64_p, c_void_pp, c_void_pp, c_void_pp]),
     "syldet_sharded_synchronize": (C.c_int, [Handle]),
     "syldet_sharded_rccl_ranks": (C.c_int32, [Handle]),
+    "syldet_sharded_connect": (C.c_int, [Handle]),
+    "syldet_sharded_launcher_threads": (C.c_int32, [Handle]),
 }
 
 

@@ -66,6 +66,16 @@ class ShardedSyllableDetectorBank:
     def rcclRanks(self) -> int:
         return int(_abi.lib.syldet_sharded_rccl_ranks(self._h))
 
+    @property
+    def launcherThreads(self) -> int:
+        """Persistent per-shard launcher threads of the bank (0: one shard, or SYLDET_SHARDED_INLINE=1)."""
+        return int(_abi.lib.syldet_sharded_launcher_threads(self._h))
+
+    def connect(self) -> None:
+        """Bring the exchange up now (RCCL: librccl + ncclCommInitAll; copy exchange: peer access) instead of inside the first
+        gathering batch; raises on failure, so a caller can make the bank again with EXCHANGE_PEER_COPY in the same process."""
+        check(_abi.lib.syldet_sharded_connect(self._h))
+
     def countEvaluations(self, n_samples: int) -> int:
         return int(_abi.lib.syldet_count_evals(_abi.lib.syldet_sharded_bank(self._h, 0), int(n_samples)))
 
@@ -138,6 +148,35 @@ class ShardedSyllableDetectorBank:
         check(_abi.lib.syldet_sharded_run_device(self._h, arr(blocks), int(n_samples), strides, arr(outs), arr(fls),
                                                  arr(alls) if gather else None))
         return outs, fls, (alls if gather else None)
+
+    def prepare(self, blocks, n_samples: int, outputs, flags, flags_all=None):
+        """run()'s argument checks once, then a callable that queues one batch on exactly these tensors with nothing but the
+        ABI call (a stream of batches over the same buffers: eight shards' worth of Python checks cost more than the library's
+        queueing).  The callable keeps the tensors alive."""
+        gather = flags_all is not None
+        n = len(self.shards)
+        import torch
+        E = max(self.countEvaluations(n_samples), 0)
+        n_out = self.geometry.outputs
+        for i, s in enumerate(self.shards):
+            s0, s1, _, cnt = self.ranges(i, n_samples)
+            dev = torch.device("cuda", s.device)
+            want = [(blocks[i], torch.float32, (s.channels, s1 - s0)), (outputs[i], torch.float32, (s.channels, cnt, n_out)),
+                    (flags[i], torch.uint8, (s.channels, cnt))] + ([(flags_all[i], torch.uint8, (self.channels, E))] if gather else [])
+            for t, dt, shape in want:
+                if not (t.is_cuda and t.device == dev and t.dtype == dt and tuple(t.shape) == shape and (t.is_contiguous() or (t is blocks[i] and t.stride(1) == 1))):
+                    raise ValueError("shard %d: a %s tensor %s on device %d is expected" % (i, dt, list(shape), s.device))
+        arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+        a_blocks, a_outs, a_fls, a_alls = arr(blocks), arr(outputs), arr(flags), (arr(flags_all) if gather else None)
+        strides = (C.c_int64 * n)(*[int(b.stride(0)) for b in blocks])
+        keep = (list(blocks), list(outputs), list(flags), list(flags_all) if gather else None)
+        h, f, S = self._h, _abi.lib.syldet_sharded_run_device, int(n_samples)
+
+        def call(_keep=keep):
+            st = f(h, a_blocks, S, strides, a_outs, a_fls, a_alls)
+            if st:
+                check(st)
+        return call
 
     def synchronize(self):
         check(_abi.lib.syldet_sharded_synchronize(self._h))

@@ -263,6 +263,13 @@ hipError_t launch_pack_flags(const uint8_t *flags, int64_t rows, int64_t row_len
 hipError_t launch_unpack_flags(const uint8_t *bits, int64_t rows, int64_t row_len, uint8_t *flags, hipStream_t stream);
 hipError_t launch_unpack_flags_gathered(const uint8_t *bits, int64_t rows, int64_t row_len, int64_t shards, int64_t padded,
                                         uint8_t *flags, hipStream_t stream);
+// (the copy exchange: every shard's packed rows behind a pointer of its own, read where they lie)
+constexpr int kMaxFlagSources = 16;
+struct FlagSources {
+    const uint8_t *p[kMaxFlagSources] = {};
+};
+hipError_t launch_unpack_flags_from(const FlagSources &from, int64_t rows, int64_t row_len, int64_t shards, int64_t padded,
+                                    uint8_t *flags, hipStream_t stream);
 
 hipError_t launch_fused(const FusedDesc &d, const float *samples, int64_t stride, int C, int64_t S, int64_t J,
                         int64_t E, float *outputs, uint8_t *flags, hipStream_t stream);

@@ -141,11 +141,21 @@ __device__ __forceinline__ int64_t gathered_row(int64_t r, int64_t padded, int64
     return (extra + (int64_t)(q / b32)) * padded + q % b32;
 }
 
-template <bool MAPPED>
+// MODE 0: bit row r is row r of `bits`; 1: the gathered layout above behind ONE base pointer (the all-gather's receive buffer); 2: the
+// same layout with every block behind a pointer of its own (`from`: a shard's rows are read where they lie -- its send buffer on
+// this device, or the slot a peer copy filled -- the copy exchange of the one-process bank makes no copy it does not need)
+template <int MODE>
 __global__ void __launch_bounds__(256)
 unpack_flags_kernel(const uint8_t *__restrict__ bits, int64_t rows, int64_t row_len, int64_t row_bytes, uint8_t *__restrict__ flags,
-                    int64_t padded, int64_t base, int64_t extra)
+                    int64_t padded, int64_t base, int64_t extra, const FlagSources from)
 {
+    constexpr bool MAPPED = MODE != 0;
+    // the first byte of source bit row `src` (a row of the gathered layout: block src / padded, row src % padded of it)
+    auto row_ptr = [&](int64_t src) -> const uint8_t * {
+        if (MODE != 2) return bits + src * row_bytes;
+        const unsigned blk = (unsigned)src / (unsigned)padded;
+        return from.p[blk] + (int64_t)((unsigned)src - blk * (unsigned)padded) * row_bytes;
+    };
     // one aligned 8-byte store per thread over the flat [rows * row_len] output; a thread's eight flags may straddle two rows
     const int64_t q = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8, total = rows * row_len;
     if (q >= total) return;
@@ -164,7 +174,7 @@ unpack_flags_kernel(const uint8_t *__restrict__ bits, int64_t rows, int64_t row_
         // multiplication (round 5: the byte-a-bit loop below took 35 us for 512 x 15 877 flags, and on eight GPUs every device
         // unpacks eight times that per batch)
         const int64_t src = MAPPED ? gathered_row(row, padded, base, extra) : row;
-        const uint8_t *p = bits + src * row_bytes + (i >> 3);
+        const uint8_t *p = row_ptr(src) + (i >> 3);
         unsigned w = p[0];
         if ((i & 7) != 0) w |= (unsigned)p[1] << 8;               // (i + 8 <= row_len and i % 8 != 0: the next byte is inside the row)
         const uint64_t b = (w >> (i & 7)) & 0xffu;
@@ -178,7 +188,7 @@ unpack_flags_kernel(const uint8_t *__restrict__ bits, int64_t rows, int64_t row_
     for (int k = 0; k < 8; k++) {
         if (q + k < total) {
             const int64_t src = MAPPED ? gathered_row(row, padded, base, extra) : row;
-            const unsigned b = bits[src * row_bytes + (i >> 3)];
+            const unsigned b = row_ptr(src)[i >> 3];
             out |= (uint64_t)((b >> (i & 7)) & 1u) << (8 * k);
             if (++i == row_len) { i = 0; row++; }
         }
@@ -207,7 +217,7 @@ hipError_t launch_unpack_flags(const uint8_t *bits, int64_t rows, int64_t row_le
     const bool aligned = (reinterpret_cast<uintptr_t>(flags) & 7) == 0;
     if (!aligned || threads > 0x7fffffffLL * 256) return hipErrorInvalidValue;
     dim3 grid((unsigned)((threads + 255) / 256));
-    hipLaunchKernelGGL(unpack_flags_kernel<false>, grid, dim3(256), 0, stream, bits, rows, row_len, row_bytes, flags, (int64_t)0, (int64_t)1, (int64_t)0);
+    hipLaunchKernelGGL(unpack_flags_kernel<0>, grid, dim3(256), 0, stream, bits, rows, row_len, row_bytes, flags, (int64_t)0, (int64_t)1, (int64_t)0, FlagSources{});
     return hipGetLastError();
 }
 
@@ -223,7 +233,25 @@ hipError_t launch_unpack_flags_gathered(const uint8_t *bits, int64_t rows, int64
     const bool aligned = (reinterpret_cast<uintptr_t>(flags) & 7) == 0;
     if (!aligned || threads > 0x7fffffffLL * 256) return hipErrorInvalidValue;
     dim3 grid((unsigned)((threads + 255) / 256));
-    hipLaunchKernelGGL(unpack_flags_kernel<true>, grid, dim3(256), 0, stream, bits, rows, row_len, row_bytes, flags, padded, rows / shards, rows % shards);
+    hipLaunchKernelGGL(unpack_flags_kernel<1>, grid, dim3(256), 0, stream, bits, rows, row_len, row_bytes, flags, padded, rows / shards, rows % shards, FlagSources{});
+    return hipGetLastError();
+}
+
+// ... with block s at from.p[s] (shards <= kMaxFlagSources)
+hipError_t launch_unpack_flags_from(const FlagSources &from, int64_t rows, int64_t row_len, int64_t shards, int64_t padded,
+                                    uint8_t *flags, hipStream_t stream)
+{
+    if (rows <= 0 || row_len <= 0) return hipSuccess;
+    if (shards <= 0 || shards > kMaxFlagSources || rows < shards || padded < (rows + shards - 1) / shards) return hipErrorInvalidValue;
+    for (int64_t i = 0; i < shards; i++)
+        if (!from.p[i]) return hipErrorInvalidValue;
+    const int64_t row_bytes = (row_len + 7) / 8;
+    const int64_t threads = (rows * row_len + 7) / 8;
+    const bool aligned = (reinterpret_cast<uintptr_t>(flags) & 7) == 0;
+    if (!aligned || threads > 0x7fffffffLL * 256 || shards * padded > 0x7fffffffLL) return hipErrorInvalidValue;
+    dim3 grid((unsigned)((threads + 255) / 256));
+    hipLaunchKernelGGL(unpack_flags_kernel<2>, grid, dim3(256), 0, stream, (const uint8_t *)nullptr, rows, row_len, row_bytes, flags, padded, rows / shards,
+                       rows % shards, from);
     return hipGetLastError();
 }
 

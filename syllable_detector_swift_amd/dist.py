@@ -211,6 +211,50 @@ class PipelinedFlagGather:
         self.side.synchronize()
 
 
+class HostFlagGather:
+    """PipelinedFlagGather's interface over a CPU group (`gloo`): the bit-packed rows go to the host, through the group's
+    all-gather, and back -- what a job falls back to when RCCL does not come up between its ranks (bench.py agrees on that over
+    the gloo group before anything is timed).  Synchronous: the exchange of a batch is complete when submit() returns."""
+
+    def __init__(self, local_rows: int, E: int, total_channels: int, device, group=None):
+        import torch
+        import torch.distributed as dist
+        world = dist.get_world_size(group)
+        if local_rows * world != total_channels:
+            raise ValueError("HostFlagGather needs equal shards (use gather_flags on CPU tensors for ragged ones)")
+        self.E, self.group, self.device = int(E), group, torch.device(device)
+        nb = (self.E + 7) // 8
+        self.bits = torch.empty((local_rows, nb), dtype=torch.uint8, device=self.device)
+        self.hbits = torch.empty((local_rows, nb), dtype=torch.uint8).pin_memory()
+        self.hall = torch.empty((total_channels, nb), dtype=torch.uint8).pin_memory()
+        self.gbits = torch.empty((total_channels, nb), dtype=torch.uint8, device=self.device)
+        self.out = [torch.empty((total_channels, self.E), dtype=torch.uint8, device=self.device) for _ in range(2)]
+        self.n = 0
+
+    def before_run(self, local_flags) -> None:
+        pass                                             # (submit() has waited for the packing before it returned)
+
+    def submit(self, local_flags) -> int:
+        import torch
+        import torch.distributed as dist
+        k = self.n & 1
+        self.n += 1
+        pack_flags(local_flags, out=self.bits)
+        self.hbits.copy_(self.bits)                      # (synchronous for the host: the kernel and the packing have finished)
+        torch.cuda.current_stream(self.device).synchronize()
+        dist.all_gather_into_tensor(self.hall, self.hbits, group=self.group)
+        self.gbits.copy_(self.hall, non_blocking=True)
+        unpack_flags(self.gbits, self.E, out=self.out[k])
+        return k
+
+    def result(self, k: int):
+        return self.out[k]
+
+    def synchronize(self):
+        import torch
+        torch.cuda.current_stream(self.device).synchronize()
+
+
 class ShardedSyllableDetector:
     """This rank's share of a `total_channels`-wide bank on its own GPU: a block of channels, or -- with fewer channels than
     ranks -- a stretch of one channel's time axis (`time_sharded`; see the module docstring)."""

@@ -137,6 +137,120 @@ def test_exchange_of_one_batch_runs_beside_the_kernels_of_the_next(devices, exch
             assert compute and exch and compute != exch
 
 
+def test_launcher_threads_and_the_inline_form_give_the_same_bits(monkeypatch):
+    """A bank of several shards queues a batch on one persistent launcher thread per shard (round 6); SYLDET_SHARDED_INLINE=1
+    keeps round 5's form, shard after shard on the caller's thread.  Both against the plain bank, bit for bit, ragged blocks and
+    the time-axis split; a stream of batches through prepared calls (the benchmark's loop)."""
+    torch = _torch()
+    cfg = util.sample_net()
+    for channels, shards in ((7, 3), (2, 5)):
+        x = synth.channels(channels, 36000 + 91 * channels, first=21)
+        want = _plain(cfg, x)
+        for inline in (False, True):
+            if inline:
+                monkeypatch.setenv("SYLDET_SHARDED_INLINE", "1")
+            else:
+                monkeypatch.delenv("SYLDET_SHARDED_INLINE", raising=False)
+            with ShardedSyllableDetectorBank(cfg, channels, [0] * shards) as bank:
+                assert bank.launcherThreads == (0 if inline else shards)
+            assert _check_bank(cfg, x, [0] * shards, want=want) == 0
+    monkeypatch.delenv("SYLDET_SHARDED_INLINE", raising=False)
+    with ShardedSyllableDetectorBank(cfg, 1, [0]) as bank:
+        assert bank.launcherThreads == 0                        # one shard: the caller's thread
+    # prepared calls: 40 batches back to back, two flags sets in turn, nothing waits in between
+    C, S = 6, 50000
+    x = synth.channels(C, S, first=33)
+    want_out, want_fl = _plain(cfg, x)
+    with ShardedSyllableDetectorBank(cfg, C, [0, 0, 0, 0]) as bank:
+        bank.connect()
+        blocks = bank.scatter(x)
+        outs, fls, alls = bank.run(blocks, S)
+        fls_b = [torch.empty_like(f) for f in fls]
+        calls = (bank.prepare(blocks, S, outs, fls, alls), bank.prepare(blocks, S, outs, fls_b, alls))
+        for k in range(40):
+            calls[k & 1]()
+        bank.synchronize()
+        for i, s in enumerate(bank.shards):
+            rows = slice(s.first_channel, s.first_channel + s.channels)
+            assert np.array_equal(outs[i].cpu().numpy(), want_out[rows]) and np.array_equal(fls_b[i].cpu().numpy(), want_fl[rows])
+            assert np.array_equal(fls[i].cpu().numpy(), want_fl[rows]) and np.array_equal(alls[i].cpu().numpy(), want_fl)
+        with pytest.raises(ValueError):
+            bank.prepare(blocks, S, outs, [f[:, 1:] for f in fls], alls)
+
+
+def test_a_host_without_rccl_falls_back_in_the_same_process(monkeypatch):
+    """SYLDET_RCCL_FAIL=1 makes ncclCommInitAll's step fail: connect() raises (and so would the first gathering batch), the
+    same process makes the bank again with the copy exchange, results are the plain bank's."""
+    from syllable_detector_swift_amd.config import SyllableDetectorError as SyldetError
+    cfg = util.sample_net()
+    x = synth.channels(3, 30000, first=8)
+    want = _plain(cfg, x)
+    monkeypatch.setenv("SYLDET_RCCL_FAIL", "1")
+    with ShardedSyllableDetectorBank(cfg, 3, [0]) as bank:
+        with pytest.raises(SyldetError):
+            bank.connect()
+        with pytest.raises(SyldetError):
+            bank.run(bank.scatter(x), 30000)
+    assert _check_bank(cfg, x, [0], exchange=_abi.EXCHANGE_PEER_COPY, want=want) == 0
+    monkeypatch.delenv("SYLDET_RCCL_FAIL")
+    assert _check_bank(cfg, x, [0], want=want) == 1
+
+
+def _bench(args, env=None, launcher=None, timeout=600):
+    """bench.py as the driver runs it (a child process; its one stdout line parsed)."""
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    e.update(env or {})
+    cmd = (launcher or [sys.executable]) + [os.path.join(root, "bench.py")] + args
+    r = subprocess.run(cmd, env=e, capture_output=True, text=True, timeout=timeout, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_multi_gpu_branch_rehearsed_on_one_device():
+    """`bench.py --devices 0,0,0,0,0,0,0,0`: the whole single-process N > 1 branch -- eight shards, launcher threads, the exchange
+    (by copies: RCCL refuses a device listed twice), per-device timings, gathered flags on every device, the oracle check of the
+    first and last shard on the timed step and on planted syllables, JSON emission with `summary` as its last key."""
+    line = _bench(["--devices", "0,0,0,0,0,0,0,0", "--channels", "4", "--log2-samples", "16", "--steps", "4", "--warmup", "1", "--preroll", "3"])
+    assert line["shards"] == 8 and line["n_gpus"] == 1 and line["launcher"] == "single-process" and line["launcher_threads"] == 8
+    assert line["exchange"] == "peer_copy" and line["rccl_ranks"] == 0 and line["rccl_error"] is None
+    assert line["config"]["channels_per_gpu"] == [4] * 8 and line["gathered_flags_shape"][0] == 32
+    assert line["gathered_flags_identical_on_every_device"] is True and line["verified"] is True
+    assert len(line["roofline"]["kernel_ms_per_device"]) == 8 and line["roofline"]["frac"] > 0
+    assert line["verify_planted"]["detections"] > 0 and set(line["verify"]) == {"shard0", "shard7"}
+    assert list(line)[-1] == "summary" and line["summary"]["exchange"] == "peer_copy"
+    assert line["value"] == pytest.approx(32 * line["config"]["frames_per_channel"] / (line["ms_per_step"] * 1e-3), rel=1e-6)
+
+
+def test_bench_single_process_falls_back_when_rccl_does_not_come_up():
+    """One shard on device 0 is one RCCL rank; with SYLDET_RCCL_FAIL=1 the communicator step fails, and bench.py makes the bank
+    again in the same process with the copy exchange and says so in the line."""
+    args = ["--devices", "0", "--channels", "6", "--log2-samples", "16", "--steps", "3", "--warmup", "1", "--preroll", "2"]
+    ok = _bench(args)
+    assert ok["exchange"] == "rccl" and ok["rccl_ranks"] == 1 and ok["rccl_error"] is None and ok["verified"] is True
+    fb = _bench(args, env={"SYLDET_RCCL_FAIL": "1"})
+    assert fb["exchange"] == "peer_copy" and fb["rccl_ranks"] == 0 and "SYLDET_RCCL_FAIL" in fb["rccl_error"] and fb["verified"] is True
+    assert fb["verify_planted"]["detections"] == ok["verify_planted"]["detections"] > 0
+
+
+def test_bench_process_per_gpu_branch_rehearsed_with_two_ranks_on_one_device():
+    """The launcher the driver uses (torch.distributed.run, one process per rank), two ranks on the box's one GPU: the gloo
+    control plane, the agreement on the exchange, the host-staged fallback (SYLDET_BENCH_NO_RCCL: RCCL refuses two ranks on one
+    device anyway), barriers, max-over-ranks timing, rank 0's line."""
+    import sys
+    launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29641"]
+    line = _bench(["--gpus", "2", "--channels", "6", "--log2-samples", "16", "--steps", "3", "--warmup", "1", "--preroll", "2"],
+                  env={"SYLDET_BENCH_NO_RCCL": "1"}, launcher=launcher)
+    assert line["n_gpus"] == 2 and line["exchange"] == "gloo_host" and line["rccl_ranks"] == 0 and "SYLDET_BENCH_NO_RCCL" in line["rccl_error"]
+    assert line["config"]["total_channels"] == 12 and line["gathered_flags_shape"][0] == 12 and line["verified"] is True
+    assert line["verify_planted"]["detections"] > 0 and list(line)[-1] == "summary"
+    assert line["value"] == pytest.approx(12 * line["config"]["frames_per_channel"] / (line["ms_per_step"] * 1e-3), rel=1e-6)
+
+
 # More than one GPU on the box: the multi-rank RCCL exchange itself (ncclCommInitAll over distinct devices, the grouped
 # all-gather issued from one thread, the ragged padded_rows layout).  Defined only where it can run: the builder's and the
 # driver's test boxes have ONE GPU, where this has never executed (README says so).

@@ -23,15 +23,24 @@ for shards, exchange, label in ((a.shards, _abi.EXCHANGE_PEER_COPY, "copy exchan
         blocks = bank.scatter(x)
         outs, fls, alls = bank.run(blocks, S)
         bank.synchronize()
-        for gather in (True, False):
-            t = []
-            for k in range(a.batches):
-                t0 = time.perf_counter()
-                bank.run(blocks, S, gather=gather, outputs=outs, flags=fls, flags_all=alls if gather else None)
-                t.append(time.perf_counter() - t0)
-                if k % 16 == 15:
-                    bank.synchronize()
-            bank.synchronize()
-            t = np.sort(np.array(t)) * 1e3
-            print("%d shards on one device, %s, %s: host time per batch call (Python + ctypes + library) median %.3f ms, p90 %.3f ms" % (
-                shards, label, "with the exchange" if gather else "kernels only", t[len(t) // 2], t[int(0.9 * len(t))]), flush=True)
+        print("launcher threads: %d%s" % (bank.launcherThreads, " (SYLDET_SHARDED_INLINE)" if os.environ.get("SYLDET_SHARDED_INLINE") else ""), flush=True)
+        fls_b = [torch.empty_like(f) for f in fls]
+        prepared = (bank.prepare(blocks, S, outs, fls, alls), bank.prepare(blocks, S, outs, fls_b, alls))
+        for form in ("prepared call (the ABI call alone)", "bank.run (argument checks in Python every call)"):
+            for gather in (True, False):
+                if form.startswith("prepared") and not gather:
+                    continue
+                t = []
+                for k in range(a.batches):
+                    t0 = time.perf_counter()
+                    if form.startswith("prepared"):
+                        prepared[k & 1]()
+                    else:
+                        bank.run(blocks, S, gather=gather, outputs=outs, flags=fls, flags_all=alls if gather else None)
+                    t.append(time.perf_counter() - t0)
+                    if k % 16 == 15:
+                        bank.synchronize()
+                bank.synchronize()
+                t = np.sort(np.array(t)) * 1e3
+                print("%d shards on one device, %s, %s, %s: host time per batch call median %.3f ms, p90 %.3f ms" % (
+                    shards, label, "with the exchange" if gather else "kernels only", form, t[len(t) // 2], t[int(0.9 * len(t))]), flush=True)
