@@ -92,7 +92,8 @@ def test_random_configuration(oracle_lib, seed):
         runs.append((out.cpu().numpy(), fl.cpu().numpy(), det.geometry.engine, 1.0))
     if runs[0][2] != _abi.ENGINE_FUSED and cfg.spectrogramScaling != "linear":
         # AUTO keeps log / dB scalings on the generic engine (the fused one hands columns to the first layer as f16 hi + lo
-        # pairs: 2^-22 relative on values up to ~100); there the fused engine is checked on request, to a wider bar
+        # pairs: 2^-22 relative on values up to ~100); there the fused engine is checked on request -- to the same bar and the
+        # same evidence rule as AUTO's choice since round 6
         try:
             with sd.SyllableDetector(cfg, channels=C, engine=_abi.ENGINE_FUSED) as det:
                 out, fl = det.run(torch.from_numpy(x).cuda())
@@ -103,70 +104,58 @@ def test_random_configuration(oracle_lib, seed):
     for c in range(C):
         w32, _, w64 = o.run(x[c], po.F64, cfg.rule)
         ok = np.isfinite(w64).all(axis=1)
-        # The strict bar (1e-5, or 4x the oracle's own fp32-vs-fp64 distance where that is larger) applies to what AUTO
-        # selects for the detector's own mode.  log / dB of near-empty bins and normalisers over a handful of nearly equal
-        # values are ill-conditioned: two legitimate fp32 evaluation orders differ by 10-30x the oracle port's own error
-        # there, so those draws only have to stay within 30x of it (this sweep is for bugs, which show up as 1e-2).
         o32 = o.run(x[c], po.F32, cfg.rule)[0]
         own = float((np.abs(o32[ok] - w64[ok]) / np.maximum(1.0, np.abs(w64[ok]))).max()) if ok.any() else 0.0
         names = [f.function for f in cfg.net.inputProcessing]
         few = cfg.net.layers[0].inputs <= 8 and any(f in ("normalize", "normalizestd") for f in names)
         if few and cfg.net.layers[0].inputs <= 3:
             continue            # (a - b) / |a - b| of two or three nearly equal values: a sign, not a number to compare
-        # strict = the detector's own mode: 1e-5 (or 4x the fp32 port's own distance from the anchor), with or without a
-        # normaliser in front of the network -- no bar follows the recording's level any more (round 5): beyond the flat bar an
-        # evaluation needs the evidence of util.widened_evaluations (fp32 itself beyond half the bar there, or the conditioning
-        # floor beyond it), whatever its chain.
-        strict = cfg.spectrogramScaling == "linear" and cfg.spectrum == _abi.SPECTRUM_POWER and not few
-        bar = np.full(w64.shape[0], max(util.TOL, 4.0 * own))
+        # ONE rule for every draw (round 6: log / dB columns, |X|^2 columns, small normalisers and the fused engine on request
+        # no longer start from 1e-4 or 30x the port's distance): the flat bar is 1e-5 (or 4x the fp32 port's own distance from the
+        # anchor); beyond 1e-5 an evaluation needs the evidence of util.widened_evaluations -- fp32 itself beyond half the bar on
+        # the evaluations that share a frame with it, or a conditioning floor beyond the bar: kappa 2^-23 behind l2normalize on
+        # linear columns (util.band_condition), else how far the ANCHOR's output moves when every bin moves by 2^-23 of its frame's
+        # norm, the error any fp32 transform leaves there (util.log_condition: the logarithm of a near-empty bin, a normaliser over a
+        # handful of nearly equal values, squared columns) -- and `unexplained == 0` is asserted for every engine that ran.
+        detector_mode = cfg.spectrogramScaling == "linear" and cfg.spectrum == _abi.SPECTRUM_POWER
         own_e = np.zeros(w64.shape[0])
         own_e[ok] = (np.abs(o32[ok] - w64[ok]) / np.maximum(1.0, np.abs(w64[ok]))).max(axis=1)
-        floor_e = None                                           # what no fp32 evaluation can hold (util.widened_evaluations)
-        if strict and names[:1] == ["l2normalize"]:            # a band that holds little of its frames' energy: see util.band_condition
-            kappa = util.band_condition(o, cfg, x[c])
-            bar = np.maximum(bar, 2.0 ** -21 * kappa)
-            floor_e = 2.0 ** -23 * kappa
+        T_ = cfg.timeRange
+        # the fp32 port's own distance over the evaluations that share a frame with this one (their windows overlap: the
+        # conditioning of a stretch of audio is not a property of one evaluation's rounding luck)
+        own_nb = np.array([own_e[max(0, e - T_ + 1): e + T_].max() for e in range(len(own_e))])
+        idx_ok = np.nonzero(ok)[0]
+        flat = max(util.TOL, 4.0 * own)
+        kappa_floor, cols64 = None, None
+        if detector_mode and names[:1] == ["l2normalize"]:     # a band that holds little of its frames' energy: see util.band_condition
+            kappa_floor = 2.0 ** -23 * util.band_condition(o, cfg, x[c])
         for out, fl, engine, widen in runs:
             assert out[c].shape == w64.shape
             assert (np.isfinite(out[c]).all(axis=1) == ok).all(), "NaN/inf evaluations must coincide"
-            tol = bar[ok] if (strict and widen == 1.0) else max(1e-4, 30.0 * own)
-            if ok.any() and cfg.spectrogramScaling != "linear" and np.isscalar(tol):
-                # log / dB: where the flat bar is exceeded, the bar follows the conditioning of that evaluation -- twice what
-                # the anchor's own output moves under the bin errors any fp32 transform leaves (util.log_condition)
-                err = (np.abs(out[c][ok] - w64[ok]) / np.maximum(1.0, np.abs(w64[ok]))).max(axis=1)
-                over = np.nonzero(err > tol)[0]
-                if len(over):
-                    tol = np.full(int(ok.sum()), tol)
-                    moves = util.log_condition(o, cfg, x[c], o.spectrogram(x[c], po.F64), np.nonzero(ok)[0][over])
-                    tol[over] = np.maximum(tol[over], 2.0 * moves)
-                    floor_e = np.zeros(w64.shape[0])
-                    floor_e[np.nonzero(ok)[0][over]] = moves
             if ok.any():
                 errv = (np.abs(out[c][ok] - w64[ok]) / np.maximum(1.0, np.abs(w64[ok]))).max(axis=1)
-                flat = max(util.TOL, 4.0 * own) if (strict and widen == 1.0) else max(1e-4, 30.0 * own)
+                tol = np.full(errv.shape, flat)
+                floor_e = np.zeros(errv.shape)
                 why = ""
-                if (errv > flat).any():
-                    why = "log condition" if cfg.spectrogramScaling != "linear" else ("kappa" if names[:1] == ["l2normalize"] else "column level")
-                # (the evidence is taken against the bar without its "4x own" clause: 1e-5 in the detector's own mode, 1e-4 for
-                # log / dB and the other modes -- beyond THAT an evaluation needs fp32 itself to fail there)
-                flat_ev = util.TOL if (strict and widen == 1.0) else 1e-4
-                over_ev = np.nonzero(errv > flat_ev)[0]
-                if len(over_ev) and cfg.spectrogramScaling != "linear":
-                    # (log / dB: the conditioning floor of exactly the evaluations beyond the flat bar)
-                    if floor_e is None:
-                        floor_e = np.zeros(w64.shape[0])
-                    todo = [i for i in np.nonzero(ok)[0][over_ev] if floor_e[i] == 0.0]
-                    if todo:
-                        floor_e[todo] = util.log_condition(o, cfg, x[c], o.spectrogram(x[c], po.F64), todo)
-                # the fp32 port's own distance over the evaluations that share a frame with this one (their windows overlap: the
-                # conditioning of a stretch of audio is not a property of one evaluation's rounding luck)
-                T_ = cfg.timeRange
-                own_nb = np.array([own_e[max(0, e - T_ + 1): e + T_].max() for e in range(len(own_e))])
-                wide = util.widened_evaluations(errv, own_nb[ok], flat_ev, tol, floor_e[ok] if floor_e is not None else None)
+                over = np.nonzero(errv > util.TOL)[0]
+                if kappa_floor is not None:
+                    floor_e = kappa_floor[ok].copy()
+                    tol = np.maximum(tol, 4.0 * floor_e)
+                    why = "kappa" if (errv > flat).any() else ""
+                elif len(over):
+                    # the conditioning floor of exactly the evaluations beyond 1e-5; the bar there: twice what the anchor itself moves
+                    if cols64 is None:
+                        cols64 = o.spectrogram(x[c], po.F64)
+                    moves = util.log_condition(o, cfg, x[c], cols64, idx_ok[over])
+                    floor_e[over] = moves
+                    tol[over] = np.maximum(tol[over], 2.0 * moves)
+                    if (errv > flat).any():
+                        why = "log condition" if cfg.spectrogramScaling != "linear" else "perturbation floor"
+                wide = util.widened_evaluations(errv, own_nb[ok], util.TOL, tol, floor_e)
                 util.sweep_record("any configuration", seed, {1: "generic engine", 2: "fused engine", 3: "wide"}.get(engine, str(engine)) + (" (on request)" if widen != 1.0 else ""),
-                                  errv.max(), own, flat, (errv / np.broadcast_to(np.asarray(tol, np.float64), errv.shape)).max(), why, wide)
-                # (the engine AUTO selects: an error beyond the flat bar must be one fp32 itself cannot avoid there)
-                assert widen != 1.0 or not wide or wide["unexplained"] == 0, "beyond the flat bar where fp32 holds it: %s" % wide
+                                  errv.max(), own, flat, (errv / tol).max(), why, wide)
+                # (every engine, AUTO's and the fused one on request: an error beyond 1e-5 must be one fp32 itself cannot avoid there)
+                assert not wide or wide["unexplained"] == 0, "beyond the flat bar where fp32 holds it: %s" % wide
                 util.assert_outputs_close(out[c][ok], w64[ok], tol)
                 util.assert_flags_exact(fl[c][ok], w64[ok], cfg.thresholds, cfg.rule, tol)
             assert not fl[c][~ok].any()
@@ -220,7 +209,7 @@ def test_random_configuration_streaming(oracle_lib, seed):
     o32 = o.run(x, po.F32, cfg.rule)[0]
     own = float((np.abs(o32[ok] - w64[ok]) / np.maximum(1.0, np.abs(w64[ok]))).max()) if ok.any() else 0.0
     if ok.any():
-        util.assert_outputs_close(got[ok], w64[ok], max(util.TOL, 4.0 * own) if cfg.spectrum == _abi.SPECTRUM_POWER else max(1e-4, 30 * own))
+        util.check_with_evidence(o, cfg, x, got, None, w64=w64, w32=o32, check_flags=False)
 
 
 def draw_example_class(rng):

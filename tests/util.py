@@ -134,7 +134,7 @@ def band_condition(o: "po.Oracle", cfg, x: np.ndarray, cols64: np.ndarray = None
 
 
 def log_condition(o: "po.Oracle", cfg, x: np.ndarray, cols64: np.ndarray, evals, trials: int = 6) -> np.ndarray:
-    """For log / dB columns: how far the anchor's own output moves when every bin's amplitude moves by +-2^-23 of the norm of
+    """For log / dB columns (and, with the identity for the logarithm, any other chain): how far the anchor's own output moves when every bin's amplitude moves by +-2^-23 of the norm of
     its frame's whole spectrum -- the error any fp32 transform leaves in a bin (band_condition's premise; a bin 60 dB under
     the rest of its frame is known to 1e-4 of itself, and the logarithm turns that into an absolute error of the network's
     input).  Per evaluation of `evals`: the largest move over a few random sign patterns, fp64 network on perturbed columns."""
@@ -146,7 +146,9 @@ def log_condition(o: "po.Oracle", cfg, x: np.ndarray, cols64: np.ndarray, evals,
     fr = np.lib.stride_tricks.sliding_window_view(x.astype(np.float64)[gap:], W)[::hop][:J]
     delta = 2.0 ** -23 * np.sqrt(0.5 * N * ((fr * w[None, :]) ** 2).sum(axis=1))      # amplitude units of the columns
     power = cols64.min() >= 0.0 and getattr(cfg, "spectrum", 0) == 1                    # |X|^2 columns
-    scale = (lambda c: np.log(c)) if cfg.spectrogramScaling == "log" else (lambda c: 20.0 * np.log10(c))
+    # (linear columns too, since round 6: the same premise prices every chain -- a normaliser over a handful of nearly equal
+    # values, |X|^2 columns -- not only the logarithm)
+    scale = {"log": (lambda c: np.log(c)), "db": (lambda c: 20.0 * np.log10(c))}.get(cfg.spectrogramScaling, lambda c: c)
     rng = np.random.default_rng(1)
     moves = np.zeros(len(evals))
     for n, e in enumerate(evals):
@@ -217,6 +219,47 @@ def widened_evaluations(errv, own_e, flat, tol, floor_e):
         rec["worst_unexplained"] = {"evaluation": int(u), "err": float(errv[u]), "own": float(own_e[u]), "fp32_floor": float(floor[u]),
                                     "flat_bar": float(flat), "bar_used": float(tol[u])}
     return rec
+
+
+def check_with_evidence(o: "po.Oracle", cfg, x: np.ndarray, out, fl, w64=None, w32=None, check_flags: bool = True):
+    """One channel of one run against the anchor under the ONE rule of the suite (round 6: log / dB columns included): the flat bar
+    is 1e-5 (or 4x the fp32 port's own distance from the anchor); an evaluation beyond 1e-5 needs evidence that fp32 itself cannot
+    hold it there -- the port beyond half the bar on the evaluations that share a frame with it, or a conditioning floor beyond the
+    bar (band_condition behind l2normalize on linear |X| columns, else log_condition's perturbation of the anchor) -- and its bar
+    is then 4x / 2x that floor.  Asserts `unexplained == 0`, the values, and the flags outside the guard band; returns
+    (worst error, widened record or None)."""
+    if w64 is None:
+        w64 = o.run(x, po.F64, cfg.rule)[2]
+    if w32 is None:
+        w32 = o.run(x, po.F32, cfg.rule)[0]
+    out = np.asarray(out, np.float64).reshape(w64.shape)
+    ok = np.isfinite(w64).all(axis=1)
+    assert (np.isfinite(out).all(axis=1) == ok).all(), "NaN/inf evaluations must coincide"
+    if not ok.any():
+        return 0.0, None
+    rel = lambda a: (np.abs(a[ok] - w64[ok]) / np.maximum(1.0, np.abs(w64[ok]))).max(axis=1)
+    errv, own_v = rel(out), np.zeros(w64.shape[0])
+    own_v[ok] = rel(np.asarray(w32, np.float64))
+    T = cfg.timeRange
+    own_nb = np.array([own_v[max(0, e - T + 1): e + T].max() for e in range(len(own_v))])[ok]
+    flat = max(TOL, 4.0 * float(own_v.max()))
+    tol, floor_e = np.full(errv.shape, flat), np.zeros(errv.shape)
+    names = [f.function for f in cfg.net.inputProcessing]
+    over = np.nonzero(errv > TOL)[0]
+    if cfg.spectrogramScaling == "linear" and getattr(cfg, "spectrum", 0) == 0 and names[:1] == ["l2normalize"]:
+        floor_e = 2.0 ** -23 * band_condition(o, cfg, x)[ok]
+        tol = np.maximum(tol, 4.0 * floor_e)
+    elif len(over):
+        moves = log_condition(o, cfg, x, o.spectrogram(x, po.F64), np.nonzero(ok)[0][over])
+        floor_e[over] = moves
+        tol[over] = np.maximum(tol[over], 2.0 * moves)
+    wide = widened_evaluations(errv, own_nb, TOL, tol, floor_e)
+    assert not wide or wide["unexplained"] == 0, "beyond the flat bar where fp32 holds it: %s" % wide
+    assert_outputs_close(out[ok], w64[ok], tol)
+    if check_flags and fl is not None:
+        assert_flags_exact(np.asarray(fl)[ok], w64[ok], cfg.thresholds, cfg.rule, tol)
+        assert not np.asarray(fl)[~ok].any()
+    return float(errv.max()), wide
 
 
 def sweep_summary():
