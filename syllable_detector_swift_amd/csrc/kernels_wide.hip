@@ -372,7 +372,12 @@ __device__ float *g_wide_trace = nullptr;
 // TPW: evaluation tiles of 16 a wave.  2: 128 registers, four waves a SIMD (two workgroups of 8 a CU, or one of 16).  4 (with NWV = 8: ONE
 // workgroup of 8 waves a CU, two waves a SIMD, 256 registers): a chunk's fragments, read from LDS once a wave, then feed twice the
 // matrix instructions -- eight waves reading every chunk's 20 KB took as long as the chunk's matrix instructions.
-template <int NOUT, bool SIG, bool FRONT, int NWV = 16, bool STG = false, bool DMAB = false, int TPW = 2>
+// POLY (with SIG; SYLDET_WIDE_TANH_POLY=1, an A/B form): the hidden value is tanh_poly(acc) -- |acc| clamped to 3.3, then seven odd
+// terms in packed fp32 (minimax with the clamp's tail: 1.36e-3 from tanh; tools/fit_tanh_poly.py) -- instead of 1 / (2^acc + 1)
+// through exp2 and rcp: nine packed instructions and two clamps for two hidden values, no transcendental.  (In packed f16 the
+// same polynomial is 1.5e-2 ... 3e-2 from tanh -- its high coefficients are f16 denormals and Horner's sums cancel -- so the
+// 1e-2 bar rules that form out before any timing: MEASUREMENTS R6.3.)
+template <int NOUT, bool SIG, bool FRONT, int NWV = 16, bool STG = false, bool DMAB = false, int TPW = 2, bool POLY = false>
 __global__ void __launch_bounds__(64 * NWV, TPW == 4 ? 2 : (NWV == 16 ? 1 : 4))
 wide_gemm16_kernel(WideDesc d, const uint4 *__restrict__ xn, const float *__restrict__ columns, int64_t J, int64_t E, int64_t NE,
                    float *__restrict__ outputs, uint8_t *__restrict__ flags)
@@ -456,10 +461,15 @@ wide_gemm16_kernel(WideDesc d, const uint4 *__restrict__ xn, const float *__rest
         __syncthreads();                                          // (nothing else uses the stage; the chunk buffers are next)
     }
     float ysum[TPW][NOUT];
+    typedef float float2w __attribute__((ext_vector_type(2)));
+    float2w ysum2[TPW][NOUT];                                     // (POLY: the sums of a lane's even and odd units apart, one packed multiply-add a pair)
 #pragma unroll
     for (int t = 0; t < TPW; t++)
 #pragma unroll
-        for (int o = 0; o < NOUT; o++) ysum[t][o] = 0.0f;
+        for (int o = 0; o < NOUT; o++) {
+            ysum[t][o] = 0.0f;
+            ysum2[t][o] = float2w{0.0f, 0.0f};
+        }
     // (a buffer resource over the packed weights: a lane's address is one 32-bit offset, the chunk's a scalar)
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     const uint64_t wp = (uint64_t)(uintptr_t)d.wpack;
@@ -532,6 +542,50 @@ wide_gemm16_kernel(WideDesc d, const uint4 *__restrict__ xn, const float *__rest
         asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15");
         __builtin_amdgcn_sched_barrier(0);
 #endif
+        if constexpr (POLY) {
+            static_assert(!POLY || SIG, "the polynomial stands for TanSig / LogSig");
+            // tanh_poly on pairs (registers 0,1 and 2,3 of a result tile are neighbours): clamp, u = x x, Horner in u, times x
+            constexpr float kC = 3.3f;
+            const float2w c0 = {0.9934016466140747f, 0.9934016466140747f}, c1 = {-0.30040496587753296f, -0.30040496587753296f},
+                          c2 = {0.08361941576004028f, 0.08361941576004028f}, c3 = {-0.015534450300037861f, -0.015534450300037861f},
+                          c4 = {0.0017269821837544441f, 0.0017269821837544441f}, c5 = {-0.00010273736552335322f, -0.00010273736552335322f},
+                          c6 = {2.5018941869348055e-06f, 2.5018941869348055e-06f};
+#pragma unroll
+            for (int ut = 0; ut < 2; ut++) {
+                float2w hv[TPW][2];
+#pragma unroll
+                for (int t = 0; t < TPW; t++)
+#pragma unroll
+                    for (int pr = 0; pr < 2; pr++) {
+                        const float2w x = {__builtin_amdgcn_fmed3f(acc[ut][t][2 * pr], -kC, kC), __builtin_amdgcn_fmed3f(acc[ut][t][2 * pr + 1], -kC, kC)};
+                        const float2w u = x * x;
+                        float2w q = __builtin_elementwise_fma(c6, u, c5);
+                        q = __builtin_elementwise_fma(q, u, c4);
+                        q = __builtin_elementwise_fma(q, u, c3);
+                        q = __builtin_elementwise_fma(q, u, c2);
+                        q = __builtin_elementwise_fma(q, u, c1);
+                        q = __builtin_elementwise_fma(q, u, c0);
+                        hv[t][pr] = q * x;
+                    }
+#pragma unroll
+                for (int o = 0; o < NOUT; o++) {
+                    const float4 w1 = *reinterpret_cast<const float4 *>(cst + 32 + 32 * o + 16 * ut + 4 * g);
+                    const float2w wa = {w1.x, w1.y}, wb = {w1.z, w1.w};
+#pragma unroll
+                    for (int t = 0; t < TPW; t++) {
+                        ysum2[t][o] = __builtin_elementwise_fma(wa, hv[t][0], ysum2[t][o]);      // (the weights first: see below)
+                        ysum2[t][o] = __builtin_elementwise_fma(wb, hv[t][1], ysum2[t][o]);
+                    }
+                }
+            }
+            if (ch == d.n_chunks - 1) {
+#pragma unroll
+                for (int t = 0; t < TPW; t++)
+#pragma unroll
+                    for (int o = 0; o < NOUT; o++) ysum[t][o] = ysum2[t][o].x + ysum2[t][o].y;
+            }
+            return;
+        }
 #pragma unroll
         for (int ut = 0; ut < 2; ut++) {
 #pragma unroll
@@ -725,6 +779,9 @@ hipError_t launch_wide_gemm(const WideDesc &d, const void *xn, const float *colu
 {
     if (NE <= 0) return hipSuccess;
     dim3 grid((unsigned)((NE + kWideTile - 1) / kWideTile));
+    // (the polynomial form exists for one output on the front-end forms only; upload_wide folded the tables for it, so anything
+    // else must refuse rather than run the exp2 form on the polynomial's tables)
+    if (d.poly && !(d.shape16 && d.front && d.n_out == 1)) return hipErrorInvalidValue;
     if (d.shape16) {                      // the 16x16x32 shape (what ships; the other one under SYLDET_WIDE_SHAPE32=1, with its own packing)
         const bool one16 = d.n_out == 1;
         // two workgroups of 8 waves a CU (WideDesc::wg8) where the columns under 256 evaluations and the chunk buffers fit twice
@@ -732,7 +789,8 @@ hipError_t launch_wide_gemm(const WideDesc &d, const void *xn, const float *colu
         if (wg8) {
             if (d.tiles4 && d.stagger && !d.dma_builtin && (size_t)wide_front_stage_floats(d.F, d.I, 512) * 4 + 2 * kChunkU4Pad * 16 <= 158 * 1024) {
                 // one workgroup of 8 waves a CU, four evaluation tiles a wave (TPW = 4)
-                auto k4 = d.sig ? wide_gemm16_kernel<1, true, true, 8, true, false, 4> : wide_gemm16_kernel<1, false, true, 8, true, false, 4>;
+                auto k4 = d.poly ? wide_gemm16_kernel<1, true, true, 8, true, false, 4, true>
+                          : d.sig ? wide_gemm16_kernel<1, true, true, 8, true, false, 4> : wide_gemm16_kernel<1, false, true, 8, true, false, 4>;
                 if (E <= 0 || NE % E != 0) return hipErrorInvalidValue;
                 const size_t lds4 = 2 * kChunkU4Pad * 16 + std::max((size_t)wide_front_stage_floats(d.F, d.I, 512) * 4, (size_t)kChunkU4Pad * 16);
                 hipError_t st4 = hipFuncSetAttribute((const void *)k4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
@@ -740,9 +798,12 @@ hipError_t launch_wide_gemm(const WideDesc &d, const void *xn, const float *colu
                 hipLaunchKernelGGL(k4, dim3((unsigned)((E + 511) / 512), (unsigned)(NE / E)), dim3(512), lds4, stream, d, (const uint4 *)xn, columns, J, E, NE, outputs, flags);
                 return hipGetLastError();
             }
-            auto k8 = d.dma_builtin ? (d.sig ? wide_gemm16_kernel<1, true, true, 8, false, true> : wide_gemm16_kernel<1, false, true, 8, false, true>)
-                      : d.stagger   ? (d.sig ? wide_gemm16_kernel<1, true, true, 8, true> : wide_gemm16_kernel<1, false, true, 8, true>)
-                                    : (d.sig ? wide_gemm16_kernel<1, true, true, 8> : wide_gemm16_kernel<1, false, true, 8>);
+            auto k8 = d.dma_builtin ? (d.poly ? wide_gemm16_kernel<1, true, true, 8, false, true, 2, true>
+                                       : d.sig ? wide_gemm16_kernel<1, true, true, 8, false, true> : wide_gemm16_kernel<1, false, true, 8, false, true>)
+                      : d.stagger   ? (d.poly ? wide_gemm16_kernel<1, true, true, 8, true, false, 2, true>
+                                       : d.sig ? wide_gemm16_kernel<1, true, true, 8, true> : wide_gemm16_kernel<1, false, true, 8, true>)
+                                    : (d.poly ? wide_gemm16_kernel<1, true, true, 8, false, false, 2, true>
+                                       : d.sig ? wide_gemm16_kernel<1, true, true, 8> : wide_gemm16_kernel<1, false, true, 8>);
             if (E <= 0 || NE % E != 0) return hipErrorInvalidValue;
             // (the staggered form's third chunk buffer lies over the stage: whichever is longer)
             const size_t lds8 = 2 * kChunkU4Pad * 16 + std::max((size_t)wide_front_stage_floats(d.F, d.I, 256) * 4, (size_t)kChunkU4Pad * 16);
@@ -762,7 +823,7 @@ hipError_t launch_wide_gemm(const WideDesc &d, const void *xn, const float *colu
             hipLaunchKernelGGL(k8, dim3((unsigned)((E + 255) / 256), (unsigned)(NE / E)), dim3(512), lds8, stream, d, (const uint4 *)xn, columns, J, E, NE, outputs, flags);
             return hipGetLastError();
         }
-        auto k16 = d.front ? (d.sig ? (one16 ? wide_gemm16_kernel<1, true, true> : wide_gemm16_kernel<4, true, true>)
+        auto k16 = (d.poly && d.front && one16) ? wide_gemm16_kernel<1, true, true, 16, false, false, 2, true> : d.front ? (d.sig ? (one16 ? wide_gemm16_kernel<1, true, true> : wide_gemm16_kernel<4, true, true>)
                                     : (one16 ? wide_gemm16_kernel<1, false, true> : wide_gemm16_kernel<4, false, true>))
                            : (d.sig ? (one16 ? wide_gemm16_kernel<1, true, false> : wide_gemm16_kernel<4, true, false>)
                                     : (one16 ? wide_gemm16_kernel<1, false, false> : wide_gemm16_kernel<4, false, false>));

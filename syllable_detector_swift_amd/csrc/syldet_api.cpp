@@ -107,6 +107,7 @@ struct syldet {
         bool wide_stagger = true;     // SYLDET_WIDE_NOSTAGGER: the two-workgroup GEMM WITHOUT waves 4-7 running one epilogue behind waves 0-3 (round 4's order)
         bool wide_dma_builtin = false;   // SYLDET_WIDE_DMA_BUILTIN: (unstaggered) the weight DMA through the compiler's builtin, not the assembly statement
         bool wide_tiles4 = false;     // SYLDET_WIDE_T4: the staggered GEMM as one workgroup a CU with four evaluation tiles a wave
+        bool wide_tanh_poly = false;  // SYLDET_WIDE_TANH_POLY: the wide GEMM's hidden TanSig / LogSig layer through a clamped odd polynomial (seven terms, packed fp32), no transcendentals
         bool wide_shape32 = false;    // SYLDET_WIDE_SHAPE32: the wide engine's GEMM on the 32x32x16 MFMA shape (rounds 1-2), not 16x16x32
         bool no_bdft = false;         // SYLDET_NO_BDFT: frames of four hops on the FFT kernels, not the block-transform kernel
         bool no_stft_lanes = false;   // SYLDET_NO_STFT_LANES: the LDS Stockham FFT instead of the lane-butterfly one
@@ -128,6 +129,7 @@ struct syldet {
             wide_stagger = std::getenv("SYLDET_WIDE_NOSTAGGER") == nullptr;
             wide_dma_builtin = std::getenv("SYLDET_WIDE_DMA_BUILTIN") != nullptr;
             wide_tiles4 = std::getenv("SYLDET_WIDE_T4") != nullptr;
+            wide_tanh_poly = std::getenv("SYLDET_WIDE_TANH_POLY") != nullptr;
             wide_no_front = std::getenv("SYLDET_WIDE_NO_FRONT") != nullptr;
             no_stft_lanes = std::getenv("SYLDET_NO_STFT_LANES") != nullptr;
             no_guard = std::getenv("SYLDET_NO_GUARD") != nullptr;
@@ -336,8 +338,6 @@ int upload_wide(syldet *h, std::string &why)
     // logsig(x) = 1 / (2^(s x) + 1) with s = -log2(e).  The kernel then computes r = 1 / (2^acc + 1) with acc = s (W0 x + b0)
     // and y += w1' r, where w1' = -2 w1 and b1' = b1 + sum w1 for tanh, unchanged for logsig.
     const bool sig = L0.transfer == SYLDET_TF_TANSIG || L0.transfer == SYLDET_TF_LOGSIG;
-    const double sc = !sig ? 1.0 : (L0.transfer == SYLDET_TF_TANSIG ? 2.8853900817779268 : -1.4426950408889634);
-    const double w1s = (sig && L0.transfer == SYLDET_TF_TANSIG) ? -2.0 : 1.0;
     const bool shape16 = !h->sw.wide_shape32;
     // The input chain the training script writes -- [l2normalize,] affine maps, on linear columns -- needs no preparation pass:
     // u_i = a_i (v_i r) + o_i with r = 1 / |v| (or 1), so W0 u + b0 = (W0 diag a) (v r) + (W0 o + b0): the affine part goes
@@ -365,6 +365,13 @@ int upload_wide(syldet *h, std::string &why)
         for (int i = 0; i < I; i++) worst = std::max(worst, std::fabs(fo[(size_t)i]));
         if (!(worst <= 4.0)) front = false;
     }
+    // SYLDET_WIDE_TANH_POLY (round 6, an A/B form): the kernel evaluates t = tanh_poly(acc) -- a clamped odd polynomial, no
+    // transcendental -- and y += w1' t.  tanh: acc = W0 x + b0, w1' = w1; logsig(x) = 1/2 + tanh(x / 2) / 2: acc = (W0 x + b0) / 2,
+    // w1' = w1 / 2, b1' = b1 + sum w1 / 2.
+    const bool poly = sig && shape16 && front && n_out == 1 && h->sw.wide_tanh_poly;   // (the forms that have an instantiation: kernels_wide.hip)
+    const double sc = !sig ? 1.0 : poly ? (L0.transfer == SYLDET_TF_TANSIG ? 1.0 : 0.5)
+                                        : (L0.transfer == SYLDET_TF_TANSIG ? 2.8853900817779268 : -1.4426950408889634);
+    const double w1s = !sig ? 1.0 : poly ? (L0.transfer == SYLDET_TF_TANSIG ? 1.0 : 0.5) : (L0.transfer == SYLDET_TF_TANSIG ? -2.0 : 1.0);
     for (int ch = 0; ch < n_chunks; ch++) {
         uint16_t *frag = pack.data() + (size_t)ch * chunk_u16;
         for (int ks = 0; ks < kWideK / 16; ks++)
@@ -390,8 +397,10 @@ int upload_wide(syldet *h, std::string &why)
     std::vector<float> misc((size_t)n_out);
     for (int o = 0; o < n_out; o++) {
         double b = (double)L1.biases[o];
-        if (sig && L0.transfer == SYLDET_TF_TANSIG)
+        if (sig && !poly && L0.transfer == SYLDET_TF_TANSIG)
             for (int u = 0; u < H; u++) b += (double)L1.weights[(size_t)o * H + u];
+        if (poly && L0.transfer == SYLDET_TF_LOGSIG)
+            for (int u = 0; u < H; u++) b += 0.5 * (double)L1.weights[(size_t)o * H + u];
         misc[(size_t)o] = (float)b;
     }
     for (int k = 0; k < c.n_output_fns; k++) {
@@ -408,6 +417,7 @@ int upload_wide(syldet *h, std::string &why)
     d.H = H; d.n_chunks = n_chunks; d.n_out = n_out; d.tf0 = L0.transfer; d.tf1 = L1.transfer; d.rule = c.rule;
     d.n_out_fns = c.n_output_fns;
     d.sig = sig ? 1 : 0;
+    d.poly = poly ? 1 : 0;
     d.shape16 = shape16 ? 1 : 0;
     d.front = front ? 1 : 0; d.l2 = l2; d.I = I; d.F = h->geom.bins;
     d.wg8 = h->sw.wide_wg16 ? 0 : 1;

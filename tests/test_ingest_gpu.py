@@ -126,7 +126,7 @@ WIDE_TOL = 1e-2      # bf16 inputs and first-layer weights (8-bit significands),
 
 @pytest.mark.parametrize("shape", ["config5", "H96_3out_logsig", "H40_normalize", "H72_2out_satlin", "config5_shape32", "config5_prepared",
                                    "H64_affine_only", "H48_two_maps", "H64_narrow_range_maps", "H32_one_chunk", "H96_three_chunks",
-                                   "H128_four_chunks"])
+                                   "H128_four_chunks", "config5_tanh_poly", "H96_logsig_tanh_poly", "H96_3out_logsig_tanh_poly"])
 def test_wide_network_bf16_mfma_engine(oracle_lib, shape, monkeypatch):
     """The opt-in wide engine (first layer as a bf16 MFMA GEMM over thousands of evaluations) against the fp64 anchor,
     to bf16's bar; flags wherever the anchor is farther than that from the threshold.  The four instantiations of the
@@ -139,10 +139,19 @@ def test_wide_network_bf16_mfma_engine(oracle_lib, shape, monkeypatch):
     if shape == "config5_prepared":                      # (the inputs as a bf16 image made by the preparation kernel, as in rounds 1-2)
         monkeypatch.setenv("SYLDET_WIDE_NO_FRONT", "1")
         shape = "config5"
+    poly = shape.endswith("_tanh_poly")
+    if poly:
+        # SYLDET_WIDE_TANH_POLY=1 (round 6, an A/B form): the hidden TanSig / LogSig layer through a clamped seven-term odd polynomial
+        # in packed fp32 (1.36e-3 from tanh) instead of exp2 + rcp; one-output front-end forms only -- a three-output network
+        # keeps the exact form under the switch.  Same bar; the worst error must stay under 6e-3.
+        monkeypatch.setenv("SYLDET_WIDE_TANH_POLY", "1")
+        shape = shape[:-len("_tanh_poly")]
     base = nets.from_npz()
     rng = np.random.default_rng(3)
     if shape == "config5":
         cfg = nets.wide_mlp(base)
+    elif shape == "H96_logsig":
+        cfg = nets.variant(base, net=nets.random_net(rng, 290, (96,), 1, transfer=("LogSig", "PureLin")), thresholds=[0.1])
     elif shape == "H96_3out_logsig":
         cfg = nets.variant(base, net=nets.random_net(rng, 290, (96,), 3, transfer=("LogSig", "TanSig")), thresholds=[0.1, 0.2, 0.3],
                            rule=_abi.RULE_ANY)
@@ -192,18 +201,25 @@ def test_wide_network_bf16_mfma_engine(oracle_lib, shape, monkeypatch):
         util.assert_flags_exact(fl[c], w64, cfg.thresholds, cfg.rule, tol)
         worst = max(worst, float(np.abs(out[c] - w64).max()))
     assert worst > 1e-7, "bf16 rounding should be visible: is the engine really running?"
+    if poly:
+        assert worst <= 6e-3, "the polynomial form's worst distance from the anchor: %.3g" % worst
+        print("SYLDET_WIDE_TANH_POLY %s: worst |output - anchor| = %.3g" % (shape, worst))
 
 
+@pytest.mark.parametrize("poly", [False, True])
 @pytest.mark.parametrize("H", [4096, 96])
-def test_wide_gemm_forms_agree_bit_for_bit(H, monkeypatch):
+def test_wide_gemm_forms_agree_bit_for_bit(H, poly, monkeypatch):
     """Every form of the 16x16x32 GEMM makes its sums in the same order, so their results are the same bits: the staggered
     two-workgroup form that ships (waves 4-7 one epilogue behind waves 0-3, three chunk buffers), the unstaggered one
     (SYLDET_WIDE_NOSTAGGER: round 4's), the same with the weight DMA through the compiler's builtin instead of the assembly
     statement (SYLDET_WIDE_DMA_BUILTIN), one workgroup of 16 waves (SYLDET_WIDE_WG16), and one of 8 with four evaluation tiles a wave
     (SYLDET_WIDE_T4: round 5's experiment, MEASUREMENTS R5.1c).  Several rounds of workgroups per
     CU (the staggered form's run-to-run differences of round 4 -- a packed multiply-add that loses a product beside another
-    wave's matrix instructions, MEASUREMENTS R5.1 -- showed only there), each form twice."""
+    wave's matrix instructions, MEASUREMENTS R5.1 -- showed only there), each form twice.  `poly`: the same five forms under
+    SYLDET_WIDE_TANH_POLY=1 (the hidden layer through the polynomial), bit-identical among themselves."""
     torch = _torch()
+    if poly:
+        monkeypatch.setenv("SYLDET_WIDE_TANH_POLY", "1")
     base = nets.from_npz()
     cfg = nets.wide_mlp(base) if H == 4096 else nets.variant(base, net=nets.random_net(np.random.default_rng(5), 290, (H,), 1))
     C, S = 16, 1 << 22                                   # 16 x 31 760 evaluations: ~2000 workgroups of 256, four rounds of the chip
