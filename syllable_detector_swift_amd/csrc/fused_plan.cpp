@@ -210,6 +210,8 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
     {
         d.s_ok = 0;
         d.s_padp = 0;
+        d.s_cs8 = 0;
+        d.s_cs8_rc = 0;
         bool sym = (W % 64 == 0) && (g.gap % 4 == 0);
         // (to an ulp of the fp32 table: the two sides are averaged below, which moves a coefficient by 2^-25 of itself at most)
         for (int nn = 1; nn < W && sym; nn++) sym = std::fabs((double)win[(size_t)nn] - (double)win[(size_t)(W - nn)]) <= 2.4e-7 * std::fabs((double)win[(size_t)nn]) + 1e-30;
@@ -253,6 +255,17 @@ bool make_fused_plan(const syldet_config_t &c, const syldet_geometry_t &g, Fused
 #endif
             d.s_ring_chunks = RC; d.s_pstride = PSs; d.s_tp = TP;
             d.s_lds_wave = per_wave;
+            // hop 128 (where the padded ring is in use): the same share of the LDS as slots of 1280 bytes, no mirror chunk -- the
+            // twice-folded form's other ring layout (kernels_fused_s.hip, CS8); a tile's span and the next tile's eight chunks
+            d.s_cs8 = 0;
+            d.s_cs8_rc = 0;
+            if (d.s_padp == 128 && hop == 128) {
+                const int rc8 = std::min(16, (per_wave - (row_bytes + 15) / 16 * 16) / 1280);
+                if (rc8 >= (span + 255) / 256 + 1) {
+                    d.s_cs8 = 1;
+                    d.s_cs8_rc = rc8;
+                }
+            }
             const int K2 = W / 64, c0 = W / 2;
             // A operands, lane l: row l & 15 of its tile, k = 8 (l >> 4) + j -> folded position m = 32 ks + k.
             // s rows (real part): w[c0 + m] cos(2 pi k m / N), half of it at m = 0 (s[0] = 2 x[c0]);

@@ -165,6 +165,8 @@ struct FusedDesc {
     // rows 4 g + i) and 8 g + s2_po + 2 i (odd tile)
     int s2_ok, s2_pe, s2_po;
     int s2_nt;                  // row tiles per parity of the twice-folded form: 1 (up to 32 bins) or 2 (33 .. 64 bins: 4 waves a workgroup)
+    int s_cs8, s_cs8_rc;        // hop 128 under a 256-sample window, one quad of units: the ring as whole chunks staggered over the banks (kernels_fused_s.hip, CS8) and its slots
+    int no_cs8;                 // the handle was created under SYLDET_FUSED_PAD128=1: the padded pieces where both take the shape (A/B runs)
     int no_fold2;               // the handle was created under SYLDET_FUSED_NOFOLD2=1: the once-folded form where both take the shape (A/B runs)
     const uint4 *sfrag2;        // [2 k-steps][Re even, Re odd, Im even, Im odd][hi,lo][64 lanes] A-operand fragments of the twice-folded basis
     const float *swin2;         // [4 lane groups][2 k-steps][8][2] window coefficients w[128 + m], w[m] for m = 32 ks + 8 g + i

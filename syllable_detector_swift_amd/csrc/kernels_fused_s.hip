@@ -85,6 +85,14 @@ __device__ __forceinline__ void split2(float a, float b, unsigned &hi, unsigned 
 // PADP: 0, or the power of two that divides the hop when the hop is a multiple of 64 floats: the frames of a tile would then
 // all start on the same LDS banks, so the ring is laid out with one quad of padding after every PADP floats -- a frame's
 // start moves on by one bank group per frame, and inside a frame the padding is a compile-time offset per access.
+// PADP == 1 (CS8; hop 128, twice folded; round 6): no padding INSIDE a chunk -- whole chunks are staggered over the banks instead.
+// Chunk q sits in slot q mod RC of 1280 bytes at offset 16 S[q & 7], S = {0, 1, 4, 5, 8, 9, 12, 13}: one full-wave DMA
+// instruction a chunk (the padded pieces take one each: two a chunk at hop 128, and an LDS-DMA instruction is the dearest
+// instruction of the tile), no mirror chunk.  At hop 128 an even frame IS a chunk, an odd frame the second half of one and the first
+// half of the next: a lane reads its frame's positions 0 .. 127 through one base and 128 .. 255 through another, both advanced by
+// eight slots a tile (q & 7 -- the pad -- is a constant of the lane).  The eight even frames a ds_read_b128 lane group reads with
+// lane group g start on quads S[j] (+ 2 g), the eight odd ones with g + 1 on S[j] + 2 (+ 2 g): sixteen different quads of the
+// 256-byte bank row -- conflict-free, as the padded ring is.
 // F2: the second fold (W == N == 256: K2 == 4, one quad of units, plain ring).  The once-folded positions pair up again (m with
 // 128 - m), even and odd bins become GEMMs of their own with K = 64 and one row tile each -- 24 matrix instructions per 16 frames
 // instead of 48, a basis of 64 registers -- and the window is applied by the lanes in fp32 (fused_plan.cpp, s2_ok).  A lane then
@@ -123,13 +131,15 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
 
     // ---- wave-private LDS: sample ring (RC chunks of 256 floats + one mirror chunk), tap products, a zero quad
     unsigned char *wbase = smem + (size_t)wave * d.s_lds_wave;
-    const int RC = d.s_ring_chunks, R = RC * 256;
-    constexpr int kSub = PADP ? 256 / PADP : 1;       // padded pieces of a chunk of 256 floats
-    constexpr int kChunkB = 1024 + (PADP ? 16 * kSub : 0);
-    auto sk = [](int i) { return PADP ? 4 * (i / (PADP ? PADP : 1)) : 0; };   // padding (floats) in front of position i of a frame / of the ring
+    const int RC = PADP == 1 ? d.s_cs8_rc : d.s_ring_chunks, R = RC * 256;
+    constexpr bool CS8 = PADP == 1;                   // whole chunks staggered over the banks (hop 128: see the header)
+    static_assert(!CS8 || (F2 && HQ == 1 && NT == 1), "staggered chunks: the twice-folded form at hop 128");
+    constexpr int kSub = PADP > 1 ? 256 / PADP : 1;   // padded pieces of a chunk of 256 floats
+    constexpr int kChunkB = CS8 ? 1280 : 1024 + (PADP > 1 ? 16 * kSub : 0);
+    auto sk = [](int i) { return PADP > 1 ? 4 * (i / (PADP > 1 ? PADP : 1)) : 0; };   // padding (floats) in front of position i of a frame / of the ring
     float *ring = reinterpret_cast<float *>(wbase);
     const int PS = d.s_pstride, TP = d.s_tp;          // floats per frame row: 4 TP tap products, sum of squares, floor weight, padding
-    float *rows = reinterpret_cast<float *>(wbase + (size_t)(RC + 1) * kChunkB);    // [T - 1 + 16][PS]
+    float *rows = reinterpret_cast<float *>(wbase + (size_t)(RC + (CS8 ? 0 : 1)) * kChunkB);    // [T - 1 + 16][PS]
     float *zquad = rows + (T - 1 + kTile) * PS;       // 8 HQ floats: HQ zero quads (what taps past timeRange read), HQ quads for stores that have no place
     // Two quads of units at two waves a SIMD: 256 registers hold the basis, 48 registers of first-layer fragments and the
     // loop's working set only if the constants that depend on the lane group alone wait in LDS (4 groups x 20 floats behind the
@@ -216,7 +226,10 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
     auto issue_upto = [&](int last) {
         while (cn <= last) {
             const unsigned voff = org + (unsigned)cn * 1024u + (unsigned)lane * 16u;
-            if (PADP == 0) {
+            if (CS8) {
+                const int pad = ((cn & 6) << 1) | (cn & 1);              // S[cn & 7]
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rs, (lds_void *)(wbase + slot * kChunkB + 16 * pad), 16, voff, 0, 0, 2 /* nt */);
+            } else if (PADP == 0) {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rs, (lds_void *)(wbase + slot * 1024), 16, voff, 0, 0, 2 /* nt */);
                 if (slot == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rs, (lds_void *)(wbase + RC * 1024), 16, voff, 0, 0, 2);
             } else {
@@ -238,6 +251,12 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
 
     // ---- per-lane LDS places.  fo: this lane's frame inside the ring (floats), advanced by 16 hop a tile.
     unsigned fo = (unsigned)(hop * fr);                                  // < R (launcher: 16 hop <= R)
+    // CS8: byte offsets of the slots that hold this lane's positions 0 .. 127 (sb1) and 128 .. 255 (sb2), and what does not change:
+    // the chunks' pads, and which half of its chunk each part is
+    unsigned sb1 = (unsigned)((fr >> 1) * kChunkB), sb2 = (unsigned)(((fr >> 1) + (fr & 1)) * kChunkB);
+    const int jq1 = (fr >> 1) & 7, jq2 = ((fr >> 1) + (fr & 1)) & 7;
+    const unsigned cb1 = (unsigned)(16 * (((jq1 & 6) << 1) | (jq1 & 1)) + ((fr & 1) ? 512 : 0));
+    const unsigned cb2 = (unsigned)(16 * (((jq2 & 6) << 1) | (jq2 & 1)) + ((fr & 1) ? 0 : 512));
     float *prow = rows + (T - 1 + fr) * PS;                              // this frame's row of tap products
     const float *erow = rows + n * PS;                                   // evaluation n: rows n .. n + T - 1
     const float *pv_p[3], *sv_p[3];
@@ -324,7 +343,9 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
         // (SPECT: the five column stores of tile t - 1)
         SD_STAMP(st_vm, if (t == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else if (SPECT) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
                         else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"));
-        const float *fp = ring + fo + sk((int)fo);    // this lane's frame: W samples from here (the mirror makes them contiguous)
+        const float *f1 = reinterpret_cast<const float *>(wbase + sb1 + cb1);       // (CS8) positions 0 .. 127 of this lane's frame
+        const float *f2 = reinterpret_cast<const float *>(wbase + sb2 + cb2);       //       positions 128 .. 255, at f2[position - 128]
+        const float *fp = CS8 ? f1 : ring + fo + sk((int)fo);    // this lane's frame: W samples from here (the mirror makes them contiguous)
 
         // ---- twice folded: this lane's 64 + 6 samples of its frame, read once.  For m0 = 32 ks + 8 g:
         //   P1 = x[m0 .. m0+7], P3 = x[128+m0 .. +7] (two quads each), x[128-m0-i] and x[256-m0-i], i = 0..7: two quads
@@ -336,6 +357,21 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
             // (padded ring: position i of the frame sits at fp[i + sk(i)]; the quads lie inside one piece each, so the padding
             // is a constant per access -- only the word x[128 - m0] of lane group 0, k-step 0 is on the far side of one)
             for (int ks = 0; ks < 2; ks++) {
+                if (CS8) {
+                    const float *a1 = f1 + 32 * ks + 8 * g, *a2 = f2 + 32 * ks + 8 * g;
+                    const float *b1 = f1 + 120 - 32 * ks - 8 * g, *b3 = f2 + 120 - 32 * ks - 8 * g;
+                    P1[ks][0] = *reinterpret_cast<const floatx4 *>(a1);
+                    P1[ks][1] = *reinterpret_cast<const floatx4 *>(a1 + 4);
+                    P3[ks][0] = *reinterpret_cast<const floatx4 *>(a2);
+                    P3[ks][1] = *reinterpret_cast<const floatx4 *>(a2 + 4);
+                    P2[ks][0] = *reinterpret_cast<const floatx4 *>(b1);
+                    P2[ks][1] = *reinterpret_cast<const floatx4 *>(b1 + 4);
+                    P2w[ks] = (ks == 0) ? (g == 0 ? f2 : b1 + 8)[0] : b1[8];       // (position 128 - m0: the second part's first word for lane group 0)
+                    P4[ks][0] = *reinterpret_cast<const floatx4 *>(b3);
+                    P4[ks][1] = *reinterpret_cast<const floatx4 *>(b3 + 4);
+                    P4w[ks] = b3[8];                      // (g == 0, ks == 0: position 256, the next frame's -- read, never used)
+                    continue;
+                }
                 const float *a = fp + 32 * ks + 8 * g, *b = fp + 120 - 32 * ks - 8 * g;
                 P1[ks][0] = *reinterpret_cast<const floatx4 *>(a);
                 P1[ks][1] = *reinterpret_cast<const floatx4 *>(a + 4);
@@ -348,8 +384,8 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
                 P4[ks][1] = *reinterpret_cast<const floatx4 *>(b + 132 + sk(192));
                 P4w[ks] = b[136 + sk(192)];             // (g == 0, ks == 0: x[256], the next frame's -- read, never used)
             }
-            x64 = fp[64 + sk(64)];
-            x192 = fp[192 + sk(192)];
+            x64 = CS8 ? f1[64] : fp[64 + sk(64)];
+            x192 = CS8 ? f2[64] : fp[192 + sk(192)];
             // the raw samples of this tile are dead as soon as they are in registers: all of the next tile's chunks, a whole tile
             // of arithmetic ahead of their use
             SD_STAMP(st_lg, asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"));
@@ -600,6 +636,10 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
             }
             fo += (unsigned)(kTile * hop);
             fo = fo >= (unsigned)R ? fo - (unsigned)R : fo;
+            if (CS8) {
+                sb1 += 8u * kChunkB; sb1 = sb1 >= (unsigned)(RC * kChunkB) ? sb1 - (unsigned)(RC * kChunkB) : sb1;
+                sb2 += 8u * kChunkB; sb2 = sb2 >= (unsigned)(RC * kChunkB) ? sb2 - (unsigned)(RC * kChunkB) : sb2;
+            }
             continue;
         }
         if (GEN && scaling != 0) {
@@ -906,6 +946,10 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
         }
         fo += (unsigned)(kTile * hop);
         fo = fo >= (unsigned)R ? fo - (unsigned)R : fo;
+        if (CS8) {                                    // eight chunks a tile: the slots move on, the pads (q & 7) stay
+            sb1 += 8u * kChunkB; sb1 = sb1 >= (unsigned)(RC * kChunkB) ? sb1 - (unsigned)(RC * kChunkB) : sb1;
+            sb2 += 8u * kChunkB; sb2 = sb2 >= (unsigned)(RC * kChunkB) ? sb2 - (unsigned)(RC * kChunkB) : sb2;
+        }
     }
 #ifdef SYLDET_S_STAMPS
     if (d.stamps && lane == 0) {
@@ -990,6 +1034,11 @@ hipError_t launch_fused_s(const FusedDesc &d, const float *samples, int64_t stri
         if (exact) return launch_one<K2_, false, 1, 8, P_>(d, samples, stride, C, s_eff, E, outputs, flags, stream);   \
         return launch_one<K2_, true, 1, 8, P_>(d, samples, stride, C, s_eff, E, outputs, flags, stream);               \
     }
+    // hop 128 under the twice-folded form: whole chunks staggered over the banks (CS8; SYLDET_FUSED_PAD128=1 keeps the padded pieces)
+    if (d.s_cs8 && !d.no_cs8 && d.s2_ok && !d.no_fold2 && d.W == 256 && d.H <= 4 && d.s2_nt == 1) {
+        if (exact) return launch_one<4, false, 1, 8, 1, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
+        return launch_one<4, true, 1, 8, 1, true>(d, samples, stride, C, s_eff, E, outputs, flags, stream);
+    }
     if (d.s_padp) {
         SD_S_PAD(4, 64) SD_S_PAD(4, 128)
         return hipErrorInvalidValue;
@@ -1035,6 +1084,7 @@ hipError_t launch_fused_s_spectrogram(const FusedDesc &d, const float *samples, 
     if (!fused_s_spectrogram_applicable(d) || d.spect_out == nullptr) return hipErrorInvalidValue;
     const int64_t s_eff = (J - 1) * (int64_t)d.hop + d.gap + d.W;
     if (s_eff * 4 >= 0x7fffffffll || (uint64_t)J * (uint64_t)d.F * 4u >= 0xFFFFFFF0ull) return hipErrorInvalidValue;
+    if (d.s_cs8 && !d.no_cs8) return launch_one<4, false, 1, 8, 1, true, 1, true>(d, samples, stride, C, s_eff, J, nullptr, nullptr, stream);
     if (d.s_padp == 64) return launch_one<4, false, 1, 8, 64, true, 1, true>(d, samples, stride, C, s_eff, J, nullptr, nullptr, stream);
     if (d.s_padp == 128) return launch_one<4, false, 1, 8, 128, true, 1, true>(d, samples, stride, C, s_eff, J, nullptr, nullptr, stream);
     return launch_one<4, false, 1, 8, 0, true, 1, true>(d, samples, stride, C, s_eff, J, nullptr, nullptr, stream);

@@ -114,6 +114,7 @@ struct syldet {
         bool no_guard = false;        // SYLDET_NO_GUARD: the precision guard off
         bool no_mlpx = false;         // SYLDET_NO_MLPX: the interpretive network kernels under AUTO
         bool fused_nofold = false;    // SYLDET_FUSED_NOFOLD: not the symmetric-fold kernel (the register-resident-basis / 8-wave kernels)
+        bool fused_pad128 = false;    // SYLDET_FUSED_PAD128: hop 128 on the fold kernel's padded pieces, not the staggered chunks (round 6)
         bool fused_nofold2 = false;   // SYLDET_FUSED_NOFOLD2: the fold kernel's once-folded form where the twice-folded one takes the shape
         bool fused_stamps = false;    // SYLDET_FUSED_STAMPS: the stamped diagnostic instantiation
         int fused_ko = 0;             // SYLDET_FUSED_KO=<mask>: knock-out instantiation
@@ -136,6 +137,7 @@ struct syldet {
             no_mlpx = std::getenv("SYLDET_NO_MLPX") != nullptr;
             fused_nofold = std::getenv("SYLDET_FUSED_NOFOLD") != nullptr;
             fused_nofold2 = std::getenv("SYLDET_FUSED_NOFOLD2") != nullptr;
+            fused_pad128 = std::getenv("SYLDET_FUSED_PAD128") != nullptr;
             fused_stamps = std::getenv("SYLDET_FUSED_STAMPS") != nullptr;
             fused_ko = std::getenv("SYLDET_FUSED_KO") ? std::atoi(std::getenv("SYLDET_FUSED_KO")) : 0;
         }
@@ -687,6 +689,7 @@ int stft_on_stream(syldet *h, const float *d_samples, int64_t stride, int C, int
         d.stamps = nullptr;
         d.ko = 0;
         d.no_fold2 = h->sw.fused_nofold2 ? 1 : 0;
+        d.no_cs8 = h->sw.fused_pad128 ? 1 : 0;
         // the fold kernel's spectrogram instantiation where the plan allows it (rows under 2 GiB: its 32-bit byte offsets)
         const bool fold = !h->sw.fused_nofold && fused_s_spectrogram_applicable(d) &&
                           ((J - 1) * (int64_t)d.hop + d.gap + d.W) * 4 < 0x7fffffffll;
@@ -733,6 +736,7 @@ int run_on_stream(syldet *h, const float *d_samples, int64_t S, int64_t stride, 
         d.force_classic = h->sw.fused_classic ? 1 : 0;
         d.no_fold = h->sw.fused_nofold ? 1 : 0;
         d.no_fold2 = h->sw.fused_nofold2 ? 1 : 0;
+        d.no_cs8 = h->sw.fused_pad128 ? 1 : 0;
         // Which fused kernel THIS batch gets is known only now (the fold kernel addresses a row with 32-bit byte offsets; a
         // diagnostic switch may rule it out).  The batch takes the fused route only if that kernel can run it (plans whose hop
         // only the fold kernel holds have no 8-wave form: classic_ok == 0) and, for log / dB columns under AUTO, only on the fold

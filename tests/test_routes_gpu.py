@@ -130,3 +130,51 @@ def test_five_to_sixteen_hidden_units_on_the_twice_folded_form(oracle_lib, H, n_
         for form in res:
             util.assert_outputs_close(res[form][0][c], w64, tol)
             util.assert_flags_exact(res[form][1][c], w64, cfg.thresholds, cfg.rule, tol)
+
+
+@pytest.mark.parametrize("kind,T,S", [("exact", 10, 256 + 9 * 128), ("exact", 10, 256 + 24 * 128 + 77), ("exact", 10, 700001), ("exact", 1, 40000), ("exact", 12, 90011),
+                                      ("gen_db", 10, 120000), ("gen_logsig_3out", 7, 65536)])
+def test_hop_128_ring_as_staggered_chunks_and_as_padded_pieces(oracle_lib, kind, T, S, monkeypatch):
+    """Hop 128 under a 256-sample window (BASELINE configs[0]'s framing) puts every frame of a tile on the same LDS banks.  Round 3's
+    cure pads the ring inside a chunk (two half-wave DMA instructions a chunk, a mirror chunk); round 6's staggers WHOLE chunks over
+    the banks (one DMA instruction a chunk, a frame read through two bases; kernels_fused_s.hip, CS8) and is what ships;
+    SYLDET_FUSED_PAD128=1 keeps the padded pieces.  Same samples, same arithmetic per frame: the two forms must agree bit for bit,
+    and both with the oracle -- one tile, ragged tails, rings that wrap many times, several wave segments, the spectrogram call."""
+    import torch
+    import pyoracle as po
+    base = util.sample_net()
+    rng = np.random.default_rng(41)
+    if kind == "exact":
+        cfg = nets.variant(base, windowOverlap=128, timeRange=T,
+                           net=base.net if T == 10 else nets.random_net(rng, 29 * T, (4,), 1, in_fns=("l2normalize", "mapminmax"), out_fns=("mapminmax",)))
+    elif kind == "gen_db":
+        cfg = nets.variant(base, windowOverlap=128, spectrogramScaling="db",
+                           net=nets.random_net(rng, 290, (3,), 1, in_fns=("l2normalize",), out_fns=()), thresholds=[0.1])
+    else:
+        cfg = nets.variant(base, windowOverlap=128, timeRange=T, net=nets.random_net(rng, 29 * T, (4,), 3, transfer=("LogSig", "TanSig"), in_fns=("l2normalize", "mapstd")),
+                           thresholds=[0.1, 0.2, 0.3], rule=_abi.RULE_ANY)
+    C = 3
+    x = synth.channels(C, S, first=12, fs=cfg.samplingRate)
+    x[1] *= np.float32(2e-3)
+    x[2, S // 3:] *= np.float32(40.0)
+    got = {}
+    for form in ("staggered chunks", "padded pieces"):
+        if form == "padded pieces":
+            monkeypatch.setenv("SYLDET_FUSED_PAD128", "1")
+        with SyllableDetector(cfg, channels=C, device=0) as det:
+            assert det.geometry.engine == _abi.ENGINE_FUSED
+            det.profile(True)
+            out, fl = det.run(torch.from_numpy(x).cuda())
+            torch.cuda.synchronize()
+            assert util.launched(det) == ["fused_s_kernel"]
+            cols = det.spectrogram(torch.from_numpy(x).cuda())
+            torch.cuda.synchronize()
+            got[form] = (out.cpu().numpy(), fl.cpu().numpy(), cols.cpu().numpy())
+    monkeypatch.delenv("SYLDET_FUSED_PAD128")
+    a, b = got["staggered chunks"], got["padded pieces"]
+    assert np.array_equal(a[0], b[0], equal_nan=True) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2], equal_nan=True)
+    o = util.oracle_for(cfg)
+    for c in range(C):
+        util.check_with_evidence(o, cfg, x[c], a[0][c], a[1][c])
+        if cfg.spectrogramScaling == "linear":
+            util.assert_columns_close(a[2][c], o.spectrogram(x[c], po.F64))
