@@ -69,6 +69,7 @@ struct WideDesc {
     int H, n_chunks;            // first-layer outputs, chunks of 32 of them (zero padded)
     int n_out, tf0, tf1, rule, n_out_fns;
     int sig;                    // TanSig / LogSig hidden layer folded into the tables (see wide_gemm_kernel)
+    int m32;                    // the staggered two-workgroup GEMM on v_mfma_f32_32x32x16_bf16, chunks packed for it: SYLDET_WIDE_M32 (kernels_wide.hip, wide_gemm32s_kernel)
     int poly;                   // (sig, shape16) the folded tables are for tanh_poly(acc) instead of 1 / (2^acc + 1): SYLDET_WIDE_TANH_POLY
     int shape16;                // the chunks are packed for v_mfma_f32_16x16x32_bf16 ([k-step of 32][unit tile of 16]): wide_gemm16_kernel
     // front = 1: the GEMM kernel reads the |X| columns itself (an evaluation's inputs are I consecutive floats of [C][J][F]) --

@@ -582,7 +582,13 @@ wide_gemm16_kernel(WideDesc d, const uint4 *__restrict__ xn, const float *__rest
 #pragma unroll
                 for (int t = 0; t < TPW; t++)
 #pragma unroll
-                    for (int o = 0; o < NOUT; o++) ysum[t][o] = ysum2[t][o].x + ysum2[t][o].y;
+                    for (int o = 0; o < NOUT; o++) {
+                        // (the two halves of a pair as ONE plain addition, written out: left to the compiler, two tiles' horizontal sums become
+                        // a v_pk_add_f32 that selects src1's high half into the low half -- the form tools/check_pk_opsel.py forbids)
+                        float r;
+                        asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(ysum2[t][o].x), "v"(ysum2[t][o].y));
+                        ysum[t][o] = r;
+                    }
             }
             return;
         }
@@ -739,6 +745,195 @@ wide_gemm16_kernel(WideDesc d, const uint4 *__restrict__ xn, const float *__rest
     }
 }
 
+
+// ------------------------------------------------------------------------------------
+// Round 6 (SYLDET_WIDE_M32=1, an A/B form): the staggered two-workgroups-a-CU GEMM on v_mfma_f32_32x32x16_bf16.  bench.py's counters
+// say the 16x16x32 kernel is bound by the SIMD's ISSUE port (a chunk costs a wave ~1000 issue clocks -- 40 matrix instructions at 8,
+// sixteen hidden values at ~20, reads, DMA pieces -- four waves a SIMD: 4000 against the matrix pipe's 2560), and a 32x32x16
+// instruction holds the port for the same 8 clocks while it does twice the work: 19 instructions a chunk and wave instead of 40
+// (19, not 20: 290 inputs fill 19 k-steps of 16 -- the 16x16x32 shape pads to 320), at the price of 12 % more energy per flop
+// (profiles/r03_energy_probe.txt) under a kernel that already runs at 1.9-2.0 GHz.  A wave owns 32 evaluations as ONE column
+// tile (19 or 20 x 4 registers of B operands), a chunk's 32 hidden units are one row tile:
+//   A [32 units x 16 k]:   lane l holds unit l % 32, k = 8 (l / 32) + 0..7      (from LDS; the host's 32x32x16 packing)
+//   B [16 k x 32 evals]:   lane l holds evaluation l % 32, k = 8 (l / 32) + 0..7
+//   D [32 units x 32 evals]: lane l holds evaluation l % 32; register i holds unit 8 (i / 4) + 4 (l / 32) + i % 4
+// One output, the front end (columns read here), 8 waves, staggered halves, three chunk buffers, the DMA as the assembly statement:
+// the shipped kernel's structure (see wide_gemm16_kernel), nothing else instantiated.  KSN: k-steps that hold inputs.
+template <bool SIG, int KSN>
+__global__ void __launch_bounds__(512, 4)
+wide_gemm32s_kernel(WideDesc d, const float *__restrict__ columns, int64_t J, int64_t E, int64_t NE, float *__restrict__ outputs,
+                    uint8_t *__restrict__ flags)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int kWaves = 8, kBl = 512, kTl = 256;
+    uint4 *buf0 = reinterpret_cast<uint4 *>(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 31, g = lane >> 5;
+    const int64_t e_blk = (int64_t)blockIdx.x * kTl;              // (within channel blockIdx.y)
+    bf16x8 B[KSN];
+    {
+        // evaluation e of channel c: frames e .. e + T - 1 = I consecutive floats of the channel's [J][F] columns; this lane holds
+        // inputs 16 ks + 8 g + 0..7 of evaluation wave 32 + n.  The stretch under the workgroup's 256 evaluations goes through LDS
+        float *stage = reinterpret_cast<float *>(smem + 2 * kChunkU4Pad * 16);
+        const int F = d.F, I = d.I;
+        const int span = (kTl - 1) * F + I;
+        const float *chan = columns + (int64_t)blockIdx.y * J * F;
+        const int64_t first = e_blk * F, limit = J * (int64_t)F;
+        for (int i = tid; i < span; i += kBl) stage[i] = first + i < limit ? chan[first + i] : 0.0f;
+        float *css = stage + span + 32;
+        __syncthreads();
+        const int T = I / F;
+        if (d.l2) {
+            for (int f = tid; f < kTl + T - 1; f += kBl) {
+                float a = 0.0f;
+                for (int b = 0; b < F; b++) a = fmaf(stage[f * F + b], stage[f * F + b], a);
+                css[f] = a;
+            }
+            __syncthreads();
+        }
+        const int el = wave * 32 + n;
+        int off = el * F + 8 * g;
+        const int lim = I - 8 * g;
+        float rinv = 1.0f;
+        if (d.l2) {
+            float ss = 0.0f;
+            for (int tt = 0; tt < T; tt++) ss += css[el + tt];
+            rinv = 1.0f / sqrtf(ss);                              // (silence: 0 * inf = NaN, as the reference's 0 / 0)
+        }
+        asm volatile("" : "+v"(off), "+v"(rinv));
+        const float *src = stage + off;
+#pragma unroll
+        for (int ks = 0; ks < KSN; ks++) {
+            bf16x8 b;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const float x = src[16 * ks + j];                 // (always read; inputs past I are the next frames' values: zeroed)
+                b[j] = (__bf16)((16 * ks + j < lim ? x : 0.0f) * rinv);
+            }
+            union { bf16x8 v; uint4 u; } pk;
+            pk.v = b;
+            asm volatile("" : "+v"(pk.u.x), "+v"(pk.u.y), "+v"(pk.u.z), "+v"(pk.u.w));
+            B[ks] = pk.v;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    }
+    float ysum0 = 0.0f, ysum1 = 0.0f;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const uint64_t wp = (uint64_t)(uintptr_t)d.wpack;
+    const u32x4 w_rs4 = {(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)wp), (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(wp >> 32)) & 0xffffu,
+                         (unsigned)(d.n_chunks * kChunkU4 * 16), 0x00020000u};
+    const unsigned lane16 = (unsigned)lane * 16u;
+    auto fetch_chunk = [&](int ch, uint4 *dst) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const int piece = wave + kWaves * j;                   // piece p = fragment of k-step p (p < 20), then the constants
+            const int i0 = piece * 64;
+            // (a k-step that holds no inputs is all zeros and is not multiplied: its piece stays where it is)
+            if (i0 < kChunkU4 && !(piece >= KSN && piece < kKSteps)) {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                             :: "s"((unsigned)(uintptr_t)(dst + i0)), "v"(lane16), "s"(w_rs4), "s"((unsigned)ch * (unsigned)(kChunkU4 * 16) + (unsigned)i0 * 16u)
+                             : "memory", "m0");
+#pragma clang diagnostic pop
+            }
+        }
+    };
+    auto multiply = [&](const uint4 *cur, floatx16 &acc) {
+        const float *cst = reinterpret_cast<const float *>(cur + kKSteps * 64);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {                              // the accumulators start at the bias: register 4 q + i holds unit 8 q + 4 g + i
+            const float4 b0 = *reinterpret_cast<const float4 *>(cst + 8 * q + 4 * g);
+            acc[4 * q] = b0.x; acc[4 * q + 1] = b0.y; acc[4 * q + 2] = b0.z; acc[4 * q + 3] = b0.w;
+        }
+#pragma unroll
+        for (int ks = 0; ks < KSN; ks++) {
+            union { uint4 u; bf16x8 v; } a;
+            a.u = cur[ks * 64 + lane];
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, B[ks], acc, 0, 0, 0);
+        }
+    };
+    auto finish = [&](const uint4 *cur, floatx16 &acc) {
+        const float *cst = reinterpret_cast<const float *>(cur + kKSteps * 64);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const float4 w1 = *reinterpret_cast<const float4 *>(cst + 32 + 8 * q + 4 * g);
+            float h[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) h[i] = SIG ? __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(acc[4 * q + i]) + 1.0f) : transfer_fast(d.tf0, acc[4 * q + i]);
+            // (the weight first: see wide_gemm16_kernel)
+            float &y = (q & 1) ? ysum1 : ysum0;
+            y = fmaf(w1.x, h[0], y);
+            y = fmaf(w1.y, h[1], y);
+            y = fmaf(w1.z, h[2], y);
+            y = fmaf(w1.w, h[3], y);
+        }
+    };
+    {
+        // chunk c lives in buffer c mod 3 (the third over the front's stage); waves 4-7 run one epilogue behind waves 0-3: wide_gemm16_kernel, STG
+        auto bufp = [&](int b) { return buf0 + b * kChunkU4Pad; };
+        auto next = [](int b) { return b == 2 ? 0 : b + 1; };
+        auto seal = [&]() {
+            __builtin_amdgcn_s_waitcnt(0x0070);                   // vmcnt(0): my pieces of the next chunk have landed; lgkmcnt(0): my reads of this interval are done
+            __syncthreads();
+        };
+        const int nch = d.n_chunks;
+        if (KSN < kKSteps) {                                       // (the k-steps that are never fetched: never read either -- nothing to clear)
+        }
+        fetch_chunk(0, bufp(0));
+        seal();
+        if (wave < kWaves / 2) {
+            int bi = 0;
+            for (int ch = 0; ch < nch; ch++) {
+                const int bn = next(bi);
+                if (ch + 1 < nch) fetch_chunk(ch + 1, bufp(bn));
+                floatx16 acc;
+                multiply(bufp(bi), acc);
+                finish(bufp(bi), acc);
+                seal();
+                bi = bn;
+            }
+        } else {
+            floatx16 acc;                                           // (chunk c - 1's sums cross barrier c in registers)
+            if (1 < nch) fetch_chunk(1, bufp(1));
+            multiply(bufp(0), acc);
+            seal();
+            int bp = 0, bi = 1;
+            for (int ch = 1; ch < nch; ch++) {
+                const int bn = next(bi);
+                if (ch + 1 < nch) fetch_chunk(ch + 1, bufp(bn));
+                finish(bufp(bp), acc);
+                multiply(bufp(bi), acc);
+                seal();
+                bp = bi; bi = bn;
+            }
+            finish(bufp(bp), acc);
+        }
+    }
+    // the two lane halves hold disjoint units of the same evaluation
+    float ysum = ysum0 + ysum1;
+    {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(ysum), __float_as_uint(ysum), false, false);
+        ysum = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    int tid2 = threadIdx.x;
+    asm volatile("" : "+v"(tid2));
+    const int64_t el = (int64_t)blockIdx.x * kTl + (tid2 >> 6) * 32 + (tid2 & 31);
+    if ((tid2 & 32) == 0 && el < E) {
+        const int64_t ev = (int64_t)blockIdx.y * E + el;
+        float y = transfer_fast(d.tf1, ysum + d.b1[0]);
+        for (int q = 0; q < d.n_out_fns; q++) {
+            const float *op = d.out_params + q * (1 + 2 * d.n_out);
+            y = (y - op[0]) / op[1] + op[1 + d.n_out];
+        }
+        if (outputs) outputs[ev] = y;
+        if (flags) flags[ev] = ((double)y >= d.thresholds[0]) ? 1 : 0;
+    }
+    (void)NE;
+}
+
 }  // namespace
 
 // the input chains the training script writes -- [l2normalize,] one affine map -- take the chain-specialised kernel
@@ -782,6 +977,17 @@ hipError_t launch_wide_gemm(const WideDesc &d, const void *xn, const float *colu
     // (the polynomial form exists for one output on the front-end forms only; upload_wide folded the tables for it, so anything
     // else must refuse rather than run the exp2 form on the polynomial's tables)
     if (d.poly && !(d.shape16 && d.front && d.n_out == 1)) return hipErrorInvalidValue;
+    if (d.m32) {                          // the staggered two-workgroup GEMM on the 32x32x16 shape (SYLDET_WIDE_M32=1: upload_wide packed the chunks for it)
+        if (!(d.front && d.n_out == 1 && !d.poly) || E <= 0 || NE % E != 0) return hipErrorInvalidValue;
+        if ((size_t)wide_front_stage_floats(d.F, d.I, 256) * 4 + 2 * kChunkU4Pad * 16 > 78 * 1024) return hipErrorInvalidValue;
+        const bool k19 = d.I <= 304;
+        auto k32 = d.sig ? (k19 ? wide_gemm32s_kernel<true, 19> : wide_gemm32s_kernel<true, 20>) : (k19 ? wide_gemm32s_kernel<false, 19> : wide_gemm32s_kernel<false, 20>);
+        const size_t lds32 = 2 * kChunkU4Pad * 16 + std::max((size_t)wide_front_stage_floats(d.F, d.I, 256) * 4, (size_t)kChunkU4Pad * 16);
+        hipError_t st32 = hipFuncSetAttribute((const void *)k32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32);
+        if (st32 != hipSuccess) return st32;
+        hipLaunchKernelGGL(k32, dim3((unsigned)((E + 255) / 256), (unsigned)(NE / E)), dim3(512), lds32, stream, d, columns, J, E, NE, outputs, flags);
+        return hipGetLastError();
+    }
     if (d.shape16) {                      // the 16x16x32 shape (what ships; the other one under SYLDET_WIDE_SHAPE32=1, with its own packing)
         const bool one16 = d.n_out == 1;
         // two workgroups of 8 waves a CU (WideDesc::wg8) where the columns under 256 evaluations and the chunk buffers fit twice

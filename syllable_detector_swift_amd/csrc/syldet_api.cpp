@@ -107,6 +107,7 @@ struct syldet {
         bool wide_stagger = true;     // SYLDET_WIDE_NOSTAGGER: the two-workgroup GEMM WITHOUT waves 4-7 running one epilogue behind waves 0-3 (round 4's order)
         bool wide_dma_builtin = false;   // SYLDET_WIDE_DMA_BUILTIN: (unstaggered) the weight DMA through the compiler's builtin, not the assembly statement
         bool wide_tiles4 = false;     // SYLDET_WIDE_T4: the staggered GEMM as one workgroup a CU with four evaluation tiles a wave
+        bool wide_m32 = false;        // SYLDET_WIDE_M32: the staggered wide GEMM on the 32x32x16 MFMA shape (round 6, an A/B form)
         bool wide_tanh_poly = false;  // SYLDET_WIDE_TANH_POLY: the wide GEMM's hidden TanSig / LogSig layer through a clamped odd polynomial (seven terms, packed fp32), no transcendentals
         bool wide_shape32 = false;    // SYLDET_WIDE_SHAPE32: the wide engine's GEMM on the 32x32x16 MFMA shape (rounds 1-2), not 16x16x32
         bool no_bdft = false;         // SYLDET_NO_BDFT: frames of four hops on the FFT kernels, not the block-transform kernel
@@ -131,6 +132,7 @@ struct syldet {
             wide_dma_builtin = std::getenv("SYLDET_WIDE_DMA_BUILTIN") != nullptr;
             wide_tiles4 = std::getenv("SYLDET_WIDE_T4") != nullptr;
             wide_tanh_poly = std::getenv("SYLDET_WIDE_TANH_POLY") != nullptr;
+            wide_m32 = std::getenv("SYLDET_WIDE_M32") != nullptr;
             wide_no_front = std::getenv("SYLDET_WIDE_NO_FRONT") != nullptr;
             no_stft_lanes = std::getenv("SYLDET_NO_STFT_LANES") != nullptr;
             no_guard = std::getenv("SYLDET_NO_GUARD") != nullptr;
@@ -370,6 +372,10 @@ int upload_wide(syldet *h, std::string &why)
     // SYLDET_WIDE_TANH_POLY (round 6, an A/B form): the kernel evaluates t = tanh_poly(acc) -- a clamped odd polynomial, no
     // transcendental -- and y += w1' t.  tanh: acc = W0 x + b0, w1' = w1; logsig(x) = 1/2 + tanh(x / 2) / 2: acc = (W0 x + b0) / 2,
     // w1' = w1 / 2, b1' = b1 + sum w1 / 2.
+    // SYLDET_WIDE_M32: the chunks in the 32x32x16 order for wide_gemm32s_kernel (one output, the front end, 256 evaluations' columns
+    // and two chunk buffers in half a CU's LDS: launch_wide_gemm checks the same)
+    const bool m32 = shape16 && front && n_out == 1 && h->sw.wide_m32 && !h->sw.wide_tanh_poly;
+    const bool pack16 = shape16 && !m32;
     const bool poly = sig && shape16 && front && n_out == 1 && h->sw.wide_tanh_poly;   // (the forms that have an instantiation: kernels_wide.hip)
     const double sc = !sig ? 1.0 : poly ? (L0.transfer == SYLDET_TF_TANSIG ? 1.0 : 0.5)
                                         : (L0.transfer == SYLDET_TF_TANSIG ? 2.8853900817779268 : -1.4426950408889634);
@@ -381,8 +387,8 @@ int upload_wide(syldet *h, std::string &why)
                 for (int j = 0; j < 8; j++) {
                     // 32x32x16: fragment ks = k-step of 16, lane l = unit l % 32, k = 8 (l / 32) + j
                     // 16x16x32: fragment ks = (k-step of 32, unit tile of 16), lane l = unit l % 16 of its tile, k = 8 (l / 16) + j
-                    const int unit = shape16 ? 32 * ch + 16 * (ks & 1) + (l & 15) : 32 * ch + (l & 31);
-                    const int k = shape16 ? 32 * (ks >> 1) + 8 * (l >> 4) + j : 16 * ks + 8 * (l >> 5) + j;
+                    const int unit = pack16 ? 32 * ch + 16 * (ks & 1) + (l & 15) : 32 * ch + (l & 31);
+                    const int k = pack16 ? 32 * (ks >> 1) + 8 * (l >> 4) + j : 16 * ks + 8 * (l >> 5) + j;
                     const float v = (unit < H && k < I) ? (float)(sc * (double)L0.weights[(size_t)unit * I + k] * (front ? fa[(size_t)k] : 1.0)) : 0.0f;
                     frag[((size_t)ks * 64 + l) * 8 + j] = to_bf16(v);
                 }
@@ -420,6 +426,7 @@ int upload_wide(syldet *h, std::string &why)
     d.n_out_fns = c.n_output_fns;
     d.sig = sig ? 1 : 0;
     d.poly = poly ? 1 : 0;
+    d.m32 = m32 ? 1 : 0;
     d.shape16 = shape16 ? 1 : 0;
     d.front = front ? 1 : 0; d.l2 = l2; d.I = I; d.F = h->geom.bins;
     d.wg8 = h->sw.wide_wg16 ? 0 : 1;
@@ -826,7 +833,7 @@ int run_on_stream(syldet *h, const float *d_samples, int64_t S, int64_t stride, 
             KernelTimer t(h, stream, wide_prep_is_chain(h->net) ? "wide_prep_chain_kernel" : "wide_prep_kernel");
             SYLDET_HIP(launch_wide_prep(h->net, h->geom.bins, (const float *)h->d_columns.ptr, C, J, E, h->d_xn.ptr, stream));
         }
-        KernelTimer t(h, stream, h->wide.shape16 ? "wide_gemm16_kernel" : "wide_gemm_kernel");
+        KernelTimer t(h, stream, h->wide.m32 ? "wide_gemm32s_kernel" : (h->wide.shape16 ? "wide_gemm16_kernel" : "wide_gemm_kernel"));
         SYLDET_HIP(launch_wide_gemm(h->wide, h->d_xn.ptr, (const float *)h->d_columns.ptr, J, E, (int64_t)C * E, d_outputs, d_flags, stream));
         return SYLDET_OK;
     }

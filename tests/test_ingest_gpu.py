@@ -126,7 +126,8 @@ WIDE_TOL = 1e-2      # bf16 inputs and first-layer weights (8-bit significands),
 
 @pytest.mark.parametrize("shape", ["config5", "H96_3out_logsig", "H40_normalize", "H72_2out_satlin", "config5_shape32", "config5_prepared",
                                    "H64_affine_only", "H48_two_maps", "H64_narrow_range_maps", "H32_one_chunk", "H96_three_chunks",
-                                   "H128_four_chunks", "config5_tanh_poly", "H96_logsig_tanh_poly", "H96_3out_logsig_tanh_poly"])
+                                   "H128_four_chunks", "config5_tanh_poly", "H96_logsig_tanh_poly", "H96_3out_logsig_tanh_poly",
+                                   "config5_m32", "H96_three_chunks_m32", "H32_one_chunk_m32", "H48_two_maps_m32", "H96_3out_logsig_m32"])
 def test_wide_network_bf16_mfma_engine(oracle_lib, shape, monkeypatch):
     """The opt-in wide engine (first layer as a bf16 MFMA GEMM over thousands of evaluations) against the fp64 anchor,
     to bf16's bar; flags wherever the anchor is farther than that from the threshold.  The four instantiations of the
@@ -139,6 +140,12 @@ def test_wide_network_bf16_mfma_engine(oracle_lib, shape, monkeypatch):
     if shape == "config5_prepared":                      # (the inputs as a bf16 image made by the preparation kernel, as in rounds 1-2)
         monkeypatch.setenv("SYLDET_WIDE_NO_FRONT", "1")
         shape = "config5"
+    m32 = shape.endswith("_m32")
+    if m32:
+        # SYLDET_WIDE_M32=1 (round 6, an A/B form): the staggered two-workgroup GEMM on v_mfma_f32_32x32x16_bf16, 19 k-steps of 16 for
+        # 290 inputs; one-output front-end networks only -- a three-output network keeps the 16x16x32 kernel under the switch
+        monkeypatch.setenv("SYLDET_WIDE_M32", "1")
+        shape = shape[:-len("_m32")]
     poly = shape.endswith("_tanh_poly")
     if poly:
         # SYLDET_WIDE_TANH_POLY=1 (round 6, an A/B form): the hidden TanSig / LogSig layer through a clamped seven-term odd polynomial
@@ -185,7 +192,9 @@ def test_wide_network_bf16_mfma_engine(oracle_lib, shape, monkeypatch):
         out, fl = out.cpu().numpy(), fl.cpu().numpy()
         names = util.launched(det)
         gemm = [k for k in names if k.startswith("wide_gemm")]
-        assert gemm == (["wide_gemm_kernel"] if "SYLDET_WIDE_SHAPE32" in os.environ else ["wide_gemm16_kernel"])
+        one_out_front = shape in ("config5", "H32_one_chunk", "H96_three_chunks", "H128_four_chunks", "H64_affine_only", "H48_two_maps")
+        assert gemm == (["wide_gemm_kernel"] if "SYLDET_WIDE_SHAPE32" in os.environ else
+                        ["wide_gemm32s_kernel"] if (m32 and one_out_front) else ["wide_gemm16_kernel"])
         # [l2normalize,] affine maps on linear columns: the GEMM reads the columns itself; other chains (and the old shape,
         # and the switch) go through a preparation kernel
         prepared = [k for k in names if k.startswith("wide_prep")]
