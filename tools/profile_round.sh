@@ -4,7 +4,7 @@
 #   usage: tools/profile_round.sh r02
 # Counters are collected in passes of their own (--kernel-trace + --pmc only), the program right behind "--".
 set -u
-R=${1:-r05}
+R=${1:-r06}
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/prof_$R
 mkdir -p $OUT
