@@ -338,6 +338,13 @@ fused_s_kernel(const FusedDesc d, const float *__restrict__ samples, int64_t str
 #ifndef SYLDET_S_NO_PREWAIT            // (diagnostic build: tools/variant_libs.sh kernels_fused_s.hip noprewait -DSYLDET_S_NO_PREWAIT)
     __builtin_amdgcn_s_waitcnt(0x0F70);
 #endif
+    // (round 6 experiment, MEASUREMENTS R6.5: a static priority for one wave of every SIMD's pair -- MI355X_MICROARCH.md, "Two waves per
+    // SIMD", item 4 -- built only under these defines)
+#if defined(SYLDET_S_SETPRIO_SECOND)
+    if (wave >= kWaves / 2) __builtin_amdgcn_s_setprio(1);
+#elif defined(SYLDET_S_SETPRIO_FIRST)
+    if (wave < kWaves / 2) __builtin_amdgcn_s_setprio(1);
+#endif
     for (int t = 0; t < tiles; t++) {
         // tile t's chunks have landed (behind them in the queue: nothing but the two result stores of tile t - 1)
         // (SPECT: the five column stores of tile t - 1)

@@ -675,6 +675,11 @@ wide_gemm16_kernel(WideDesc d, const uint4 *__restrict__ xn, const float *__rest
             __builtin_amdgcn_sched_barrier(0);
 #endif
         };
+#if defined(SYLDET_WIDE_X_SETPRIO_TRAIL)                 // (round 6 experiments: a static priority for the trailing / the leading half)
+        if (wave >= kWaves / 2) __builtin_amdgcn_s_setprio(1);
+#elif defined(SYLDET_WIDE_X_SETPRIO_LEAD)
+        if (wave < kWaves / 2) __builtin_amdgcn_s_setprio(1);
+#endif
         const int nch = d.n_chunks;
         fetch_chunk(0, bufp(0));
         seal();
