@@ -885,8 +885,7 @@ wide_gemm32s_kernel(WideDesc d, const float *__restrict__ columns, int64_t J, in
             __syncthreads();
         };
         const int nch = d.n_chunks;
-        if (KSN < kKSteps) {                                       // (the k-steps that are never fetched: never read either -- nothing to clear)
-        }
+        // (k-steps that hold no inputs are neither fetched nor read: nothing to clear)
         fetch_chunk(0, bufp(0));
         seal();
         if (wave < kWaves / 2) {
