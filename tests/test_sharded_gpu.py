@@ -251,6 +251,19 @@ def test_bench_process_per_gpu_branch_rehearsed_with_two_ranks_on_one_device():
     assert line["value"] == pytest.approx(12 * line["config"]["frames_per_channel"] / (line["ms_per_step"] * 1e-3), rel=1e-6)
 
 
+def test_bench_one_rank_through_the_rccl_group_of_the_process_per_gpu_launcher():
+    """`bench.py --force-gather` under torch.distributed.run with ONE rank: the branch the driver's N > 1 runs take when RCCL comes
+    up -- gloo control plane, the RCCL group of its own with its probe, dist.PipelinedFlagGather on a side stream -- on the shard shape's
+    smaller cousin; the line says which exchange carried the flags."""
+    import sys
+    launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29643"]
+    line = _bench(["--gpus", "1", "--force-gather", "--channels", "8", "--log2-samples", "17", "--steps", "3", "--warmup", "1", "--preroll", "2", "--no-cpu-baseline"],
+                  launcher=launcher)
+    assert line["n_gpus"] == 1 and line["exchange"] == "rccl" and line["rccl_ranks"] == 1 and line["rccl_error"] is None
+    assert line["gathered_flags_shape"][0] == 8 and line["verified"] is True and line["verify_planted"]["detections"] > 0
+    assert "side stream" in line["config"]["sharding"] and list(line)[-1] == "summary"
+
+
 # More than one GPU on the box: the multi-rank RCCL exchange itself (ncclCommInitAll over distinct devices, the grouped
 # all-gather issued from one thread, the ragged padded_rows layout).  Defined only where it can run: the builder's and the
 # driver's test boxes have ONE GPU, where this has never executed (README says so).
