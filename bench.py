@@ -206,7 +206,7 @@ def binding_of(kernel, launch, seconds=1.0, device_index=0):
     return rec
 
 
-def side_record(workload, local_rank, steps=10, warmup=2, verify=True, preroll_s=0.15):
+def side_record(workload, local_rank, steps=20, warmup=3, verify=True, preroll_s=0.15):
     """One sub-record of the `also` object: another single-GPU BASELINE workload (configs[2] "config3": 1024-point frames;
     configs[4] "config5": the 4096-hidden network as a bf16 MFMA GEMM) or the headline workload on adversarial audio
     ("clicks": a full-scale click every 64 frames over a cage at -80 dBFS, which the precision guard legitimately sends to
