@@ -158,6 +158,10 @@ public:
     int channels() const { return syldet_sharded_channels(b_); }
     int shards() const { return syldet_sharded_shards(b_); }
     int rcclRanks() const { return syldet_sharded_rccl_ranks(b_); }
+    int launcherThreads() const { return syldet_sharded_launcher_threads(b_); }
+    // brings the exchange up now (RCCL communicators, or peer access for the copy exchange); throws where the first gathering
+    // batch would otherwise have -- a caller that wants to fall back makes the bank again with SYLDET_EXCHANGE_PEER_COPY
+    void connect() { check(syldet_sharded_connect(b_)); }
     syldet_shard_t shard(int i) const
     {
         syldet_shard_t s;

@@ -80,6 +80,10 @@ final class SyllableDetectorShardedBank {
 
     deinit { syldet_sharded_destroy(handle) }
 
+    /// Brings the flag exchange up now (RCCL communicators over the bank's devices) instead of inside the first batch that
+    /// gathers; false where that fails -- the application may then make the bank again for the copy exchange.
+    func connect() -> Bool { return syldet_sharded_connect(handle) == 0 }
+
     func countEvaluations(samplesPerChannel n: Int) -> Int {
         return max(0, Int(syldet_count_evals(syldet_sharded_bank(handle, 0), Int64(n))))
     }
