@@ -55,6 +55,8 @@ int main(int argc, char **argv)
         {
             syldetxx::SyllableDetectorShardedBank sharded(config, 1, {0, 0});
             if (sharded.shards() != 2 || sharded.channels() != 1 || sharded.shard(1).parts != 2) return 7;
+            sharded.connect();                                     // (a device listed twice: the copy exchange -- nothing to bring up, no RCCL)
+            if (sharded.rcclRanks() != 0 || sharded.launcherThreads() != 2) return 9;
             std::vector<float> so;
             std::vector<uint8_t> sf;
             sharded.run(x.data(), (int64_t)x.size(), so, sf);
