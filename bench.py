@@ -949,6 +949,9 @@ def main():
             line["also"] = {}
             for wl in ("config3", "config5", "clicks", "hop128"):
                 try:
+                    # (every side record in the headline's own regime -- an idle device, the pre-roll, warmup, K steps -- not in
+                    # whatever state the record before it left the package in: configs[4]'s one-second loop at 1350 W does not cool in 0.1 s)
+                    time.sleep(1.0)
                     line["also"][wl] = side_record(wl, local_rank, verify=not args.no_verify)
                 except Exception as e:                       # a side record must never cost the headline its line
                     line["also"][wl] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
