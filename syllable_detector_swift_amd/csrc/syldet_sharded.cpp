@@ -193,7 +193,7 @@ struct syldet_sharded {
     struct Crew {
         std::vector<std::thread> threads;
         std::mutex m;
-        std::condition_variable cv;
+        std::condition_variable cv, done_cv;      // a phase is posted | the last launcher has finished it
         std::atomic<uint64_t> ticket{0};
         std::atomic<int> pending{0};
         int phase = 0;
@@ -401,7 +401,10 @@ void launcher_main(syldet_sharded *b, int i)
             c.status[(size_t)i] = st;
             c.message[(size_t)i] = syldet_last_error();            // (the error text is per thread)
         }
-        c.pending.fetch_sub(1, std::memory_order_release);
+        if (c.pending.fetch_sub(1, std::memory_order_acq_rel) == 1) {   // the last one out: the caller may be asleep (a long phase)
+            std::lock_guard<std::mutex> lk(c.m);
+            c.done_cv.notify_one();
+        }
     }
 }
 
@@ -425,10 +428,16 @@ int run_phase(syldet_sharded *b, int phase)
         c.ticket.fetch_add(1, std::memory_order_release);
     }
     c.cv.notify_all();
+    // a device batch's phases take tens of microseconds: the caller looks for their end for a while; the host-pointer call's
+    // phase takes as long as the recording: then it sleeps until the last launcher wakes it
     int spins = 0;
     while (c.pending.load(std::memory_order_acquire) != 0) {
-        if (++spins > 4096) std::this_thread::yield();
-        else __builtin_ia32_pause();
+        if (++spins > 20000) {
+            std::unique_lock<std::mutex> lk(c.m);
+            c.done_cv.wait(lk, [&] { return c.pending.load(std::memory_order_acquire) == 0; });
+            break;
+        }
+        __builtin_ia32_pause();
     }
     for (int i = 0; i < n; i++)
         if (c.status[(size_t)i]) return fail(c.status[(size_t)i], "shard " + std::to_string(i) + ": " + c.message[(size_t)i]);
