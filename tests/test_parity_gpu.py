@@ -260,7 +260,7 @@ def test_detection_indices_and_debounce(oracle_lib):
             assert np.array_equal(idx.cpu().numpy()[0, :int(cnt[0])], gold[key])
 
 
-@pytest.mark.parametrize("name", ["case_sample_syllables", "case_chain_normstd_log"])
+@pytest.mark.parametrize("name", ["case_sample_syllables", "case_chain_normstd_log", "case_sample_hop128"])
 def test_streaming_api_equals_batch(oracle_lib, name):
     """appendAudioData / processNewValue / lastOutputs / lastDetected / seenSyllable, ragged appends."""
     cfg, x, _ = util.load_case(name)
