@@ -218,3 +218,30 @@ def test_resampler_restatement(oracle_lib):
     np.testing.assert_allclose(y, np.arange(y.size, dtype=np.float32) * step, rtol=1e-6)   # linear ramp is reproduced
     y2 = r.resample(x + 480)
     assert y2.size in (440, 441)
+
+
+@pytest.mark.parametrize("N,W,overlap,band", [(256, 256, 124, (2000.0, 7000.0)), (256, 256, 128, (2000.0, 7000.0)), (1024, 1024, 768, (2000.0, 7000.0)),
+                                              (512, 384, 100, (500.0, 9000.0))])
+def test_spectrogram_against_scipy_signal(oracle_lib, N, W, overlap, band):
+    """A third, independent statement of the framing (hop = W - overlap, frames while W samples are left, zero padding to N), the
+    periodic window and |X| (round 6): scipy.signal.stft -- its own segmentation and FFT code -- unscaled by the window's sum,
+    against the oracle's fp64 columns over the band.  (The reference's |X| is zvabs of vDSP's packed 2 x DFT, halved:
+    CircularShortTimeFourierTransform.swift:320-333 -- the DFT's magnitude.)"""
+    scipy_signal = pytest.importorskip("scipy.signal")
+    from syllable_detector_swift_amd.config import frequencyIndexRange
+    base = util.sample_net()
+    f0, f1 = frequencyIndexRange(N, base.samplingRate, band[0], band[1])
+    # (only the geometry and the transform are used: a one-column network of the band's width keeps the configuration valid)
+    cfg = nets.variant(base, fourierLength=N, windowLength=W, windowOverlap=overlap, freqRange=band, timeRange=1,
+                       net=nets.random_net(np.random.default_rng(1), f1 - f0, (2,), 1))
+    o = util.oracle_for(cfg)
+    frames = 58
+    x = synth.channel(W + (frames - 1) * (W - overlap) + 33, 6, fs=cfg.samplingRate)
+    cols = o.spectrogram(x, po.F64)
+    w = o.window().astype(np.float64)
+    _, _, Z = scipy_signal.stft(x.astype(np.float64), fs=cfg.samplingRate, window=w, nperseg=W, noverlap=overlap, nfft=N, boundary=None, padded=False,
+                                return_onesided=True)
+    mag = np.abs(Z) * w.sum()                              # (stft divides by the window's sum)
+    assert mag.shape[1] == cols.shape[0] == frames and (o.g.f0, o.g.f1) == (f0, f1)
+    want = mag[f0:f1, :].T
+    assert np.abs(cols - want).max() <= 1e-10 * max(1.0, want.max())
