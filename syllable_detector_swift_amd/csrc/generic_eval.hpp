@@ -102,12 +102,19 @@ __device__ __forceinline__ void mlp_eval_wave(const NetDesc &n, const float *src
     // a small difference of large terms (columns of 3000 under weights of both signs: terms of +-180 that cancel to O(1)) -- in fp32
     // no order of summation holds 1e-5 there (round 5's sweep without level-dependent bars, draw 4125: 1.2e-5 here, 5e-6 for the
     // reference's own order).  Those sums are made in fp64: the products are exact, the sum is correctly rounded once.
+    // Round 6: and so are the sums of every layer behind it for as long as nothing has bounded the values -- a PureLin layer hands the
+    // level on (dB columns of -60 .. +20 through 7 -> 15 -> 2 linear layers: hidden values of hundreds that the second layer cancels to
+    // 0.6; the 6000-draw sweep's draw 3104 under the one bar: 1.1e-5 in fp32 with EXACT columns).  TanSig, LogSig and SatLin bound
+    // their outputs: the layers behind them are summed in fp32 as before.
     const bool first_f64 = n.n_in_fns == 0 || n.in_fns[0].kind >= 3;
+    bool level_f64 = first_f64;
     float *cur = bufA, *nxt = bufB;
     for (int l = 0; l < n.n_layers; l++) {
         const DevLayer L = n.layers[l];
         const float *W = P + L.w;
-        if (l == 0 && first_f64) {
+        const bool this_f64 = level_f64;
+        level_f64 = level_f64 && L.tf == 2;                  // (2: PureLin)
+        if (this_f64) {
             for (int o = 0; o < L.out; o++) {
                 double acc = 0.0;
                 const float *wrow = W + (size_t)o * L.in;
