@@ -48,6 +48,11 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+# The host driver of these boxes supports dmabuf IPC only: without this RCCL (and any sharing of device memory between processes)
+# fails with `hipIpcGetMemHandle: invalid argument`.  It is exported on the pool's boxes already; set here, before anything loads the
+# HIP runtime, for a launcher that starts ranks from a cleaner environment.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_BF16_PEAK_TFLOPS = 2500.0 # MI355X_MICROARCH.md: dense bf16 matrix peak (no sparsity)
 
