@@ -245,3 +245,19 @@ def test_spectrogram_against_scipy_signal(oracle_lib, N, W, overlap, band):
     assert mag.shape[1] == cols.shape[0] == frames and (o.g.f0, o.g.f1) == (f0, f1)
     want = mag[f0:f1, :].T
     assert np.abs(cols - want).max() <= 1e-10 * max(1.0, want.max())
+
+
+def test_the_evidence_rule_itself():
+    """tests/util.py::widened_evaluations, the one rule of the suite since round 6, on made-up numbers: an error beyond the flat bar
+    is explained only where the fp32 port is beyond half the bar on the evaluations that share a frame, or the conditioning floor is;
+    anything else is `unexplained` whatever bar was applied."""
+    errv = np.array([2e-6, 1.2e-5, 3e-5, 1.1e-5, 4e-5])
+    own = np.array([1e-7, 6e-6, 1e-6, 1e-6, 1e-7])          # (already the neighbourhood's maximum)
+    floor = np.array([0.0, 0.0, 2e-5, 4e-6, 4.9e-6])
+    tol = np.full(5, 1e-4)
+    w = util.widened_evaluations(errv, own, util.TOL, tol, floor)
+    assert w["evaluations_over_flat_bar"] == 4 and w["unexplained"] == 2      # evaluations 3 and 4: neither the port nor the floor speaks
+    assert w["worst_unexplained"]["evaluation"] == 4 and w["worst"]["evaluation"] == 4
+    assert util.widened_evaluations(np.array([9e-6, 1e-6]), own[:2], util.TOL, tol[:2], None) is None
+    ok = util.widened_evaluations(np.array([2e-5]), np.array([5.1e-6]), util.TOL, np.array([1e-4]), None)
+    assert ok["unexplained"] == 0
