@@ -279,8 +279,11 @@ def side_record(workload, local_rank, steps=20, warmup=3, verify=True, preroll_s
             b_frame = 4 * g.hop + 4 * g.outputs + 1
             gbs = C * J * b_frame / (means[dom] * 1e-3) / 1e9
             gbs_step = C * J * b_frame / (elapsed / steps) / 1e9
+            traffic, traffic_source = (None, None) if workload == "clicks" else \
+                measured_traffic(C, S, g.hop, {1: "generic", 2: "fused"}.get(g.engine, ""), None)
             rec["roofline"] = {"bound": "hbm", "kernel": dom, "kernel_ms": means[dom], "achieved": gbs, "peak": HBM_PEAK_GBS,
-                               "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "frac_by_step": gbs_step / HBM_PEAK_GBS, "all_kernels_ms": means}
+                               "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "frac_by_step": gbs_step / HBM_PEAK_GBS,
+                               "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": C * J * b_frame, "all_kernels_ms": means}
         wk_or_dom = rec["roofline"]["kernel"]
         rec["roofline"]["kernel_ms_per_step"] = [round(v, 4) for v in reversed(kernel_ms[wk_or_dom])]   # (in launch order)
         try:
